@@ -1,0 +1,341 @@
+"""ctypes binding of the C-ABI in include/flipv.h (libflipv.so, HIP / gfx950).
+
+This is plumbing only: every call goes straight to the hand-written HIP library.  There is no
+Python or CPU implementation of any operator here; if the shared library is missing or no HIP
+device is visible the calls fail loudly (FlipvError / OSError).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libflipv.so")
+
+GRID_IDS = dict(U=0, V=1, W=2, SAVED_U=3, SAVED_V=4, SAVED_W=5, VALID_U=6, VALID_V=7, VALID_W=8,
+                LIQUID_PHI=9, SOLID_PHI=10, WEIGHT_U=11, WEIGHT_V=12, WEIGHT_W=13, VISCOSITY=14,
+                PRESSURE=15)
+PHASES = ["sdf", "p2g", "bodyforce", "viscosity", "project", "constrain", "advect"]
+VOLUME_IDS = dict(center=0, U=1, V=2, W=3, edgeU=4, edgeV=5, edgeW=6)
+
+# every symbol include/flipv.h declares (tests/test_abi.py checks the header against this and the .so)
+SYMBOLS = [
+    "flipv_create", "flipv_create_on_device", "flipv_destroy", "flipv_last_error", "flipv_device_name",
+    "flipv_default_params", "flipv_set_params", "flipv_get_params", "flipv_set_gravity",
+    "flipv_set_solid_sdf", "flipv_set_viscosity_uniform", "flipv_set_viscosity",
+    "flipv_upload_particles", "flipv_download_particles", "flipv_num_particles",
+    "flipv_grid_elements", "flipv_read_grid", "flipv_write_grid",
+    "flipv_cfl", "flipv_particle_sdf", "flipv_p2g", "flipv_extrapolate", "flipv_save_velocity",
+    "flipv_advect_velocity_field", "flipv_body_force", "flipv_viscosity_solve", "flipv_compute_weights",
+    "flipv_pressure_solve", "flipv_apply_pressure", "flipv_constrain", "flipv_update_particle_velocities",
+    "flipv_advect_particles", "flipv_read_viscosity_volume", "flipv_substep", "flipv_advance",
+    "flipv_kernel_stats_reset", "flipv_kernel_stats_get", "flipv_synchronize", "flipv_bench_spmv",
+    "flipv_bench_copy",
+]
+
+
+class FlipvError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("cfl_number", C.c_float), ("min_frac", C.c_float), ("pic_ratio", C.c_float),
+                ("extrapolation_layers", C.c_int), ("pressure_tolerance", C.c_double),
+                ("pressure_rel_tolerance", C.c_double), ("pressure_max_iterations", C.c_int),
+                ("viscosity_tolerance", C.c_double), ("viscosity_max_iterations", C.c_int),
+                ("viscosity_accept_tolerance", C.c_double), ("precision", C.c_int),
+                ("kernel_timing", C.c_int), ("check_every", C.c_int), ("reserved", C.c_int * 8)]
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("rhs_norm", C.c_double),
+                ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Stats(C.Structure):
+    _fields_ = [("phase_ms", C.c_double * 7), ("total_ms", C.c_double), ("dt", C.c_float),
+                ("substeps", C.c_int), ("viscosity", SolveInfo), ("pressure", SolveInfo)]
+
+    def as_dict(self):
+        return dict(phase_ms=dict(zip(PHASES, list(self.phase_ms))), total_ms=self.total_ms, dt=self.dt,
+                    substeps=self.substeps, viscosity=self.viscosity.as_dict(), pressure=self.pressure.as_dict())
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("pressure_spmv_ms", C.c_double), ("pressure_spmv_launches", C.c_long),
+                ("pressure_spmv_cells", C.c_double), ("viscosity_spmv_ms", C.c_double),
+                ("viscosity_spmv_launches", C.c_long), ("viscosity_spmv_cells", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+fp = C.POINTER(C.c_float)
+
+
+def load():
+    """Load libflipv.so (built in-tree by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError("libflipv.so not built: run `make -C flipviscosity3d_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no fallback implementation")
+    L = C.CDLL(LIB_PATH)
+    ctx = C.c_void_p
+    L.flipv_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(ctx)]
+    L.flipv_create_on_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(ctx)]
+    L.flipv_destroy.argtypes = [ctx]
+    L.flipv_last_error.restype = C.c_char_p
+    L.flipv_last_error.argtypes = [ctx]
+    L.flipv_device_name.argtypes = [ctx, C.c_char_p, C.c_size_t]
+    L.flipv_default_params.argtypes = [C.POINTER(Params)]
+    L.flipv_set_params.argtypes = [ctx, C.POINTER(Params)]
+    L.flipv_get_params.argtypes = [ctx, C.POINTER(Params)]
+    L.flipv_set_gravity.argtypes = [ctx, C.c_float, C.c_float, C.c_float]
+    L.flipv_set_solid_sdf.argtypes = [ctx, fp]
+    L.flipv_set_viscosity_uniform.argtypes = [ctx, C.c_float]
+    L.flipv_set_viscosity.argtypes = [ctx, fp]
+    L.flipv_upload_particles.argtypes = [ctx, fp, C.c_size_t]
+    L.flipv_download_particles.argtypes = [ctx, fp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.flipv_num_particles.restype = C.c_size_t
+    L.flipv_num_particles.argtypes = [ctx]
+    L.flipv_grid_elements.restype = C.c_size_t
+    L.flipv_grid_elements.argtypes = [ctx, C.c_int]
+    L.flipv_read_grid.argtypes = [ctx, C.c_int, fp]
+    L.flipv_write_grid.argtypes = [ctx, C.c_int, fp]
+    L.flipv_cfl.argtypes = [ctx, fp]
+    for n in ("flipv_particle_sdf", "flipv_p2g", "flipv_extrapolate", "flipv_save_velocity",
+              "flipv_advect_velocity_field", "flipv_compute_weights", "flipv_constrain",
+              "flipv_update_particle_velocities", "flipv_kernel_stats_reset", "flipv_synchronize"):
+        getattr(L, n).argtypes = [ctx]
+    for n in ("flipv_body_force", "flipv_apply_pressure", "flipv_advect_particles"):
+        getattr(L, n).argtypes = [ctx, C.c_float]
+    L.flipv_viscosity_solve.argtypes = [ctx, C.c_float, C.POINTER(SolveInfo)]
+    L.flipv_pressure_solve.argtypes = [ctx, C.c_float, C.POINTER(SolveInfo)]
+    L.flipv_read_viscosity_volume.argtypes = [ctx, C.c_int, fp]
+    L.flipv_substep.argtypes = [ctx, C.c_float, C.POINTER(Stats)]
+    L.flipv_advance.argtypes = [ctx, C.c_float, C.POINTER(Stats)]
+    L.flipv_kernel_stats_get.argtypes = [ctx, C.POINTER(KernelStats)]
+    L.flipv_bench_spmv.argtypes = [ctx, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.flipv_bench_copy.argtypes = [ctx, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def grid_shape(name, I, J, K):
+    """numpy shape (depth, height, width) of a grid in the reference's Array3d layout (x fastest)."""
+    if name.endswith("_U") or name == "U":
+        return (K, J, I + 1)
+    if name.endswith("_V") or name == "V":
+        return (K, J + 1, I)
+    if name.endswith("_W") or name == "W":
+        return (K + 1, J, I)
+    if name in ("SOLID_PHI", "VISCOSITY"):
+        return (K + 1, J + 1, I + 1)
+    return (K, J, I)
+
+
+def volume_shape(name, I, J, K):
+    return dict(center=(K, J, I), U=(K, J, I + 1), V=(K, J + 1, I), W=(K + 1, J, I), edgeU=(K + 1, J + 1, I),
+                edgeV=(K + 1, J, I + 1), edgeW=(K, J + 1, I + 1))[name]
+
+
+def _F(a):
+    return a.ctypes.data_as(fp)
+
+
+class Context:
+    """Owns one flipv_context (device state of one simulation / one rank)."""
+
+    def __init__(self, I, J, K, dx, device=None):
+        self.L = load()
+        self.I, self.J, self.K = int(I), int(J), int(K)
+        self.dx = float(np.float32(dx))
+        h = C.c_void_p()
+        if device is None:
+            rc = self.L.flipv_create(self.I, self.J, self.K, C.c_float(dx), C.byref(h))
+        else:
+            rc = self.L.flipv_create_on_device(self.I, self.J, self.K, C.c_float(dx), int(device), C.byref(h))
+        if rc != 0:
+            raise FlipvError("flipv_create failed (%d): %s" % (rc, self.L.flipv_last_error(None).decode()))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.flipv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise FlipvError("%s failed (%d): %s" % (what, rc, self.L.flipv_last_error(self.h).decode()))
+        return rc
+
+    # ---- configuration
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._chk(self.L.flipv_device_name(self.h, buf, 256), "flipv_device_name")
+        return buf.value.decode()
+
+    def get_params(self):
+        p = Params()
+        self._chk(self.L.flipv_get_params(self.h, C.byref(p)), "flipv_get_params")
+        return p
+
+    def set_params(self, **kw):
+        p = self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        self._chk(self.L.flipv_set_params(self.h, C.byref(p)), "flipv_set_params")
+
+    def set_gravity(self, gx, gy, gz):
+        self._chk(self.L.flipv_set_gravity(self.h, gx, gy, gz), "flipv_set_gravity")
+
+    def set_solid_sdf(self, nodes):
+        a = np.ascontiguousarray(nodes, np.float32)
+        assert a.shape == grid_shape("SOLID_PHI", self.I, self.J, self.K), a.shape
+        self._chk(self.L.flipv_set_solid_sdf(self.h, _F(a)), "flipv_set_solid_sdf")
+
+    def set_viscosity(self, v):
+        if np.isscalar(v):
+            self._chk(self.L.flipv_set_viscosity_uniform(self.h, float(v)), "flipv_set_viscosity_uniform")
+        else:
+            a = np.ascontiguousarray(v, np.float32)
+            assert a.shape == grid_shape("VISCOSITY", self.I, self.J, self.K), a.shape
+            self._chk(self.L.flipv_set_viscosity(self.h, _F(a)), "flipv_set_viscosity")
+
+    # ---- particles
+    @property
+    def particles(self):
+        n = self.L.flipv_num_particles(self.h)
+        a = np.empty((n, 6), np.float32)
+        got = C.c_size_t()
+        self._chk(self.L.flipv_download_particles(self.h, _F(a), n, C.byref(got)), "flipv_download_particles")
+        return a
+
+    @particles.setter
+    def particles(self, a):
+        a = np.ascontiguousarray(a, np.float32).reshape(-1, 6)
+        self._chk(self.L.flipv_upload_particles(self.h, _F(a), len(a)), "flipv_upload_particles")
+
+    @property
+    def num_particles(self):
+        return self.L.flipv_num_particles(self.h)
+
+    # ---- grids
+    def grid(self, name):
+        a = np.empty(grid_shape(name, self.I, self.J, self.K), np.float32)
+        self._chk(self.L.flipv_read_grid(self.h, GRID_IDS[name], _F(a)), "flipv_read_grid")
+        return a
+
+    def set_grid(self, name, a):
+        a = np.ascontiguousarray(a, np.float32)
+        assert a.shape == grid_shape(name, self.I, self.J, self.K), (name, a.shape)
+        self._chk(self.L.flipv_write_grid(self.h, GRID_IDS[name], _F(a)), "flipv_write_grid")
+
+    def viscosity_volume(self, name):
+        a = np.empty(volume_shape(name, self.I, self.J, self.K), np.float32)
+        self._chk(self.L.flipv_read_viscosity_volume(self.h, VOLUME_IDS[name], _F(a)), "flipv_read_viscosity_volume")
+        return a
+
+    # ---- operators
+    def cfl(self):
+        v = C.c_float()
+        self._chk(self.L.flipv_cfl(self.h, C.byref(v)), "flipv_cfl")
+        return v.value
+
+    def particle_sdf(self):
+        self._chk(self.L.flipv_particle_sdf(self.h), "flipv_particle_sdf")
+
+    def p2g(self):
+        self._chk(self.L.flipv_p2g(self.h), "flipv_p2g")
+
+    def extrapolate(self):
+        self._chk(self.L.flipv_extrapolate(self.h), "flipv_extrapolate")
+
+    def save_velocity(self):
+        self._chk(self.L.flipv_save_velocity(self.h), "flipv_save_velocity")
+
+    def advect_velocity_field(self):
+        self._chk(self.L.flipv_advect_velocity_field(self.h), "flipv_advect_velocity_field")
+
+    def body_force(self, dt):
+        self._chk(self.L.flipv_body_force(self.h, dt), "flipv_body_force")
+
+    def viscosity_solve(self, dt):
+        info = SolveInfo()
+        rc = self._chk(self.L.flipv_viscosity_solve(self.h, dt, C.byref(info)), "flipv_viscosity_solve")
+        d = info.as_dict()
+        d["rc"] = rc
+        return d
+
+    def compute_weights(self):
+        self._chk(self.L.flipv_compute_weights(self.h), "flipv_compute_weights")
+
+    def pressure_solve(self, dt):
+        info = SolveInfo()
+        rc = self._chk(self.L.flipv_pressure_solve(self.h, dt, C.byref(info)), "flipv_pressure_solve")
+        d = info.as_dict()
+        d["rc"] = rc
+        return d
+
+    def apply_pressure(self, dt):
+        self._chk(self.L.flipv_apply_pressure(self.h, dt), "flipv_apply_pressure")
+
+    def constrain(self):
+        self._chk(self.L.flipv_constrain(self.h), "flipv_constrain")
+
+    def update_particle_velocities(self):
+        self._chk(self.L.flipv_update_particle_velocities(self.h), "flipv_update_particle_velocities")
+
+    def advect_particles(self, dt):
+        self._chk(self.L.flipv_advect_particles(self.h, dt), "flipv_advect_particles")
+
+    def substep(self, dt):
+        st = Stats()
+        rc = self._chk(self.L.flipv_substep(self.h, dt, C.byref(st)), "flipv_substep")
+        d = st.as_dict()
+        d["rc"] = rc
+        return d
+
+    def advance(self, dt):
+        st = Stats()
+        rc = self._chk(self.L.flipv_advance(self.h, dt, C.byref(st)), "flipv_advance")
+        d = st.as_dict()
+        d["rc"] = rc
+        return d
+
+    # ---- measurement
+    def kernel_stats_reset(self):
+        self._chk(self.L.flipv_kernel_stats_reset(self.h), "flipv_kernel_stats_reset")
+
+    def kernel_stats(self):
+        ks = KernelStats()
+        self._chk(self.L.flipv_kernel_stats_get(self.h, C.byref(ks)), "flipv_kernel_stats_get")
+        return ks.as_dict()
+
+    def synchronize(self):
+        self._chk(self.L.flipv_synchronize(self.h), "flipv_synchronize")
+
+    def bench_spmv(self, which, reps=50):
+        ms, cells = C.c_double(), C.c_double()
+        self._chk(self.L.flipv_bench_spmv(self.h, 0 if which in (0, "pressure") else 1, reps, C.byref(ms),
+                                          C.byref(cells)), "flipv_bench_spmv")
+        return ms.value, cells.value
+
+    def bench_copy(self, nbytes=1 << 30, reps=10):
+        g = C.c_double()
+        self._chk(self.L.flipv_bench_copy(self.h, nbytes, reps, C.byref(g)), "flipv_bench_copy")
+        return g.value

@@ -1,0 +1,181 @@
+/*
+ * include/flipv.h -- C-ABI of the MI355X-native FLIP substep (libflipv.so).
+ *
+ * The reference (rlguy/FLIPViscosity3D) has no FFI; its seam is the C++ class surface
+ * FluidSimulation (reference fluidsimulation.h:53-63) and the operator parameter structs below
+ * it.  This header is the drop-in boundary a host binds instead: plain pointers and sizes, no
+ * C++/torch types, status codes instead of exceptions/abort().  Every entry point cites the
+ * reference interface it replaces.
+ *
+ * Conventions
+ *  - All grid pointers are HOST pointers in the reference's Array3d layout,
+ *    flat = i + width*(j + height*k) (reference array3d.h:397-400), fp32, caller-owned.
+ *    For an I x J x K grid:  U (I+1,J,K)  V (I,J+1,K)  W (I,J,K+1)  (macvelocityfield.cpp:40-48)
+ *    liquid phi / pressure (I,J,K); solid phi / viscosity nodes (I+1,J+1,K+1).
+ *  - Particles are AoS {px,py,pz,vx,vy,vz} fp32 = FluidParticle (fluidsimulation.h:39-48).
+ *  - Return value: 0 = ok, > 0 = completed with a solver warning (not converged; result is still
+ *    usable, like the reference which only prints), < 0 = error (flipv_last_error()).
+ *    Nothing throws or aborts across this ABI.
+ *  - One context per host thread; contexts are independent (one HIP stream each).
+ *  - There is NO CPU fallback: without a HIP device flipv_create() fails with FLIPV_ERR_NO_DEVICE.
+ */
+#ifndef FLIPV_H
+#define FLIPV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLIPV_VERSION 1
+
+typedef struct flipv_context flipv_context;
+
+enum flipv_status {
+    FLIPV_OK = 0,
+    FLIPV_WARN_NOT_CONVERGED = 1,   /* cap reached, result applied (viscositysolver.cpp:680-683, pressuresolver.cpp:564-566) */
+    FLIPV_WARN_SOLVE_FAILED = 2,    /* viscosity rejected, velocity left untouched (fluidsimulation.cpp:195) */
+    FLIPV_ERR_INVALID = -1,
+    FLIPV_ERR_NO_DEVICE = -2,
+    FLIPV_ERR_HIP = -3,
+    FLIPV_ERR_OOM = -4,
+    FLIPV_ERR_COMM = -5
+};
+
+/* Grid ids for flipv_read_grid / flipv_write_grid.  Valid masks travel as 0/1 floats. */
+enum flipv_grid {
+    FLIPV_GRID_U = 0, FLIPV_GRID_V = 1, FLIPV_GRID_W = 2,                   /* _MACVelocity        fluidsimulation.h:116 */
+    FLIPV_GRID_SAVED_U = 3, FLIPV_GRID_SAVED_V = 4, FLIPV_GRID_SAVED_W = 5, /* _savedVelocityField fluidsimulation.h:117 */
+    FLIPV_GRID_VALID_U = 6, FLIPV_GRID_VALID_V = 7, FLIPV_GRID_VALID_W = 8, /* _validVelocities    fluidsimulation.h:118 */
+    FLIPV_GRID_LIQUID_PHI = 9,                                              /* _liquidSDF          fluidsimulation.h:123 */
+    FLIPV_GRID_SOLID_PHI = 10,                                              /* _solidSDF           fluidsimulation.h:120 */
+    FLIPV_GRID_WEIGHT_U = 11, FLIPV_GRID_WEIGHT_V = 12, FLIPV_GRID_WEIGHT_W = 13, /* _weightGrid   fluidsimulation.h:126 */
+    FLIPV_GRID_VISCOSITY = 14,                                              /* _viscosity          fluidsimulation.h:132 */
+    FLIPV_GRID_PRESSURE = 15,                                               /* PressureSolver::solve result, pressuresolver.h:177 */
+    FLIPV_GRID_COUNT = 16
+};
+
+enum flipv_precision {
+    FLIPV_PRECISION_FP32 = 0, /* solver vectors fp32, every reduction and scalar fp64 (default) */
+    FLIPV_PRECISION_FP64 = 1  /* solver vectors fp64 like the reference's VectorXd / std::vector<double> */
+};
+
+/* Tunables.  Defaults = the reference's private constants (fluidsimulation.h:121,128-130,
+ * pressuresolver.h:224-226, viscositysolver.h:200-202). */
+typedef struct flipv_params {
+    float cfl_number;            /* 5.0   _CFLConditionNumber */
+    float min_frac;              /* 0.01  _minfrac */
+    float pic_ratio;             /* 0.05  _ratioPICtoFLIP */
+    int extrapolation_layers;    /* 0 => ceil(cfl_number)+2 (fluidsimulation.cpp:692) */
+    double pressure_tolerance;   /* 1e-9 absolute inf-norm of the residual (pressuresolver.cpp:544) */
+    double pressure_rel_tolerance; /* additional floor: tol = max(pressure_tolerance, rel * max|b|); fp32 vectors cannot
+                                      reach 1e-9 absolute when |b| ~ 1; default 1e-6 for FP32, 0 for FP64 */
+    int pressure_max_iterations; /* 200 in the reference (MIC(0)); the GPU preconditioner needs more iterations for the
+                                    same residual, default 2000 */
+    double viscosity_tolerance;  /* 1e-6 relative to max|rhs| (pcgsolver.h:259) */
+    int viscosity_max_iterations;/* 700 (viscositysolver.h:202) */
+    double viscosity_accept_tolerance; /* 10.0 (viscositysolver.h:201) */
+    int precision;               /* enum flipv_precision */
+    int kernel_timing;           /* 1 => bracket every SpMV launch with HIP events (flipv_kernel_stats) */
+    int check_every;             /* convergence poll interval in iterations (default 8) */
+    int reserved[8];
+} flipv_params;
+
+typedef struct flipv_solve_info {
+    int iterations;      /* iterations run (count) */
+    double residual;     /* final inf-norm residual */
+    double rhs_norm;     /* max|rhs| */
+    int status;          /* 0 converged, 1 cap reached, 2 failed/rejected, 3 trivial (rhs ~ 0 or skipped) */
+    int rows;            /* unknowns */
+    int active_tiles;    /* tiles swept per launch */
+    int total_tiles;
+} flipv_solve_info;
+
+/* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */
+enum { FLIPV_PHASE_SDF = 0, FLIPV_PHASE_P2G = 1, FLIPV_PHASE_BODYFORCE = 2, FLIPV_PHASE_VISCOSITY = 3,
+       FLIPV_PHASE_PROJECT = 4, FLIPV_PHASE_CONSTRAIN = 5, FLIPV_PHASE_ADVECT = 6, FLIPV_PHASE_COUNT = 7 };
+
+typedef struct flipv_stats {
+    double phase_ms[FLIPV_PHASE_COUNT]; /* GPU time per phase (HIP events on the context stream) */
+    double total_ms;
+    float dt;                           /* substep size taken */
+    int substeps;                       /* flipv_advance only */
+    flipv_solve_info viscosity;
+    flipv_solve_info pressure;
+} flipv_stats;
+
+/* Accumulated HIP-event timings of the two SpMV kernels since the last reset (kernel_timing=1). */
+typedef struct flipv_kernel_stats {
+    double pressure_spmv_ms;   long pressure_spmv_launches;   double pressure_spmv_cells;  /* cells swept, summed over launches */
+    double viscosity_spmv_ms;  long viscosity_spmv_launches;  double viscosity_spmv_cells;
+} flipv_kernel_stats;
+
+/* ---- lifetime: FluidSimulation::initialize (fluidsimulation.cpp:26-43), without the boundary mesh ---- */
+int flipv_create(int isize, int jsize, int ksize, float dx, flipv_context **out);
+int flipv_create_on_device(int isize, int jsize, int ksize, float dx, int hip_device, flipv_context **out);
+int flipv_destroy(flipv_context *ctx);
+const char *flipv_last_error(flipv_context *ctx); /* ctx may be NULL for create-time errors */
+int flipv_device_name(flipv_context *ctx, char *buf, size_t len);
+
+int flipv_default_params(flipv_params *p);
+int flipv_set_params(flipv_context *ctx, const flipv_params *p);
+int flipv_get_params(flipv_context *ctx, flipv_params *p);
+
+/* setGravity (fluidsimulation.cpp:126-132) */
+int flipv_set_gravity(flipv_context *ctx, float gx, float gy, float gz);
+/* _solidSDF contents after addBoundary/resetBoundary (fluidsimulation.cpp:45-62): (I+1)(J+1)(K+1) nodes */
+int flipv_set_solid_sdf(flipv_context *ctx, const float *nodes);
+/* setViscosity(float) / setViscosity(Array3d<float>&) (fluidsimulation.cpp:99-124) */
+int flipv_set_viscosity_uniform(flipv_context *ctx, float value);
+int flipv_set_viscosity(flipv_context *ctx, const float *nodes);
+
+/* the public `particles` vector (fluidsimulation.h:63) */
+int flipv_upload_particles(flipv_context *ctx, const float *aos6, size_t n);
+int flipv_download_particles(flipv_context *ctx, float *aos6, size_t capacity, size_t *n_out);
+size_t flipv_num_particles(flipv_context *ctx);
+
+size_t flipv_grid_elements(flipv_context *ctx, int which);
+int flipv_read_grid(flipv_context *ctx, int which, float *out);
+int flipv_write_grid(flipv_context *ctx, int which, const float *in);
+
+/* ---- per-operator entry points, one per seam of advance() (fluidsimulation.cpp:138-167) ---- */
+int flipv_cfl(flipv_context *ctx, float *dt_out);                 /* _cfl                      fluidsimulation.cpp:241-269 */
+int flipv_particle_sdf(flipv_context *ctx);                       /* ParticleLevelSet::calculateSignedDistanceField particlelevelset.cpp:77-86 */
+int flipv_p2g(flipv_context *ctx);                                /* _advectVelocityFieldU/V/W fluidsimulation.cpp:440-498 */
+int flipv_extrapolate(flipv_context *ctx);                        /* extrapolateVelocityField  macvelocityfield.cpp:689-694 */
+int flipv_save_velocity(flipv_context *ctx);                      /* _savedVelocityField = _MACVelocity  fluidsimulation.cpp:518 */
+int flipv_advect_velocity_field(flipv_context *ctx);              /* _advectVelocityField      fluidsimulation.cpp:500-519 */
+int flipv_body_force(flipv_context *ctx, float dt);               /* _addBodyForce             fluidsimulation.cpp:271-312 */
+int flipv_viscosity_solve(flipv_context *ctx, float dt, flipv_solve_info *info); /* ViscositySolver::applyViscosityToVelocityField viscositysolver.cpp:41-63 */
+int flipv_compute_weights(flipv_context *ctx);                    /* _computeWeights           fluidsimulation.cpp:549-582 */
+int flipv_pressure_solve(flipv_context *ctx, float dt, flipv_solve_info *info);  /* PressureSolver::solve  pressuresolver.cpp:166-194 */
+int flipv_apply_pressure(flipv_context *ctx, float dt);           /* _applyPressure            fluidsimulation.cpp:598-688 */
+int flipv_constrain(flipv_context *ctx);                          /* _constrainVelocityField   fluidsimulation.cpp:696-729 */
+int flipv_update_particle_velocities(flipv_context *ctx);         /* _updateFluidParticleVelocities fluidsimulation.cpp:341-352 */
+int flipv_advect_particles(flipv_context *ctx, float dt);         /* _advectFluidParticles     fluidsimulation.cpp:315-339 */
+
+/* the seven viscosity control-volume lattices (viscositysolver.cpp:135-178), for parity tests;
+ * which: 0 center (I,J,K) 1 U 2 V 3 W 4 edgeU (I,J+1,K+1) 5 edgeV (I+1,J,K+1) 6 edgeW (I+1,J+1,K).
+ * Valid after flipv_viscosity_solve. */
+int flipv_read_viscosity_volume(flipv_context *ctx, int which, float *out);
+
+/* ---- whole substep / frame ---- */
+int flipv_substep(flipv_context *ctx, float dt, flipv_stats *stats);   /* body of the while loop, fluidsimulation.cpp:145-164 */
+int flipv_advance(flipv_context *ctx, float dt, flipv_stats *stats);   /* advance(dt), fluidsimulation.cpp:135-168 */
+
+/* ---- measurement ---- */
+int flipv_kernel_stats_reset(flipv_context *ctx);
+int flipv_kernel_stats_get(flipv_context *ctx, flipv_kernel_stats *out);
+int flipv_synchronize(flipv_context *ctx);
+/* `reps` back-to-back launches of one SpMV kernel on the current system (after a solve), HIP-event timed.
+ * which: 0 pressure, 1 viscosity.  ms_out = average per launch, cells_out = cells swept per launch. */
+int flipv_bench_spmv(flipv_context *ctx, int which, int reps, double *ms_out, double *cells_out);
+/* device-to-device copy bandwidth (attainable HBM peak): bytes moved (read+write) per second */
+int flipv_bench_copy(flipv_context *ctx, size_t bytes, int reps, double *gbps_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLIPV_H */
