@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- MCells/s per FLIP substep on MI355X (BASELINE.json metric), one JSON line on stdout.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--viscosity 5.0]
+
+Workload (N=1): BASELINE.json configs[2] -- 256^3 grid, stanford_bunny.ply dropped inside the inverted
+sphere_large.ply container, viscosity 5 at every node, gravity (0,-9.81,0), 8 jittered particles per cell
+(counter-based RNG, seed 0), full substep: particle SDF + P2G + extrapolation + body force + variational
+viscosity PCG (reference cap 700 iterations, rel. tol 1e-6: "equal-work" mode A of SURVEY.md 8d) +
+pressure PCG + extrapolation + constrain + G2P/RK2 advection.  A "step" is one substep of
+min(CFL step, 0.01 s) exactly as FluidSimulation::advance takes them (fluidsimulation.cpp:138-167).
+Inputs are resident in HBM before the timed region; value = grid cells / wall seconds per substep.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel of the substep (the matrix-free viscosity SpMV, 52 algorithmic bytes
+                  per swept index), duration measured with HIP events on the library's own stream around
+                  every launch inside the timed region.
+  cpu_baseline -- the reference itself (oracle/_ref, kind "reference") or our C restatement (kind "port"),
+                  one thread, timed here on a bounded sample of the same scene.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+MESH = os.path.join(ROOT, "tests", "golden", "meshes")
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+VISC_SPMV_BYTES_PER_INDEX = 52   # 3 diag + 4 factor + 3 x reads, 3 y writes, fp32
+PRES_SPMV_BYTES_PER_CELL = 24    # 4 coefficient + 1 s reads, 1 z write, fp32
+
+
+def build_scene(N, viscosity):
+    """Scene setup on the host (C++ mesh level sets + seeding; not timed)."""
+    from flipviscosity3d_amd import hostapi as H
+    dx = float(np.float32(1.0 / N))
+    sim = H.FluidSimulation()
+    sim.initialize(N, N, N, dx)
+    sim.addBoundary(H.load_ply(os.path.join(MESH, "sphere_large.ply")), True)
+    sim.setSeeding(H.FluidSimulation.SEED_COUNTER, 0)
+    sim.addLiquid(H.load_ply(os.path.join(MESH, "stanford_bunny.ply")))
+    solid = sim.solid_sdf()
+    particles = sim.particles
+    sim.close()
+    return dx, solid, particles
+
+
+def cpu_baseline(viscosity, budget_size):
+    """Reference (or port) timed on the host cores of this box: same scene at a size that costs ~10-30 s."""
+    from flipviscosity3d_amd import hostapi as H
+    N = budget_size
+    dx = float(np.float32(1.0 / N))
+    sim = H.FluidSimulation()
+    sim.initialize(N, N, N, dx)
+    sim.addBoundary(H.load_ply(os.path.join(MESH, "sphere_large.ply")), True)
+    sim.setSeeding(H.FluidSimulation.SEED_COUNTER, 0)
+    sim.addLiquid(H.load_ply(os.path.join(MESH, "stanford_bunny.ply")))
+    solid, particles = sim.solid_sdf(), sim.particles
+    sim.close()
+    nsub = 2
+    try:
+        from oracle import refbind as R
+        use_ref = R.available()
+    except Exception:
+        use_ref = False
+    if use_ref:
+        r = R.RefSim(N, N, N, dx)
+        r.set_grid("SOLID_PHI", solid)
+        r.set_viscosity(viscosity)
+        r.particles = particles
+        t0 = time.perf_counter()
+        for _ in range(nsub):
+            r.substep(0.01)
+        sec = (time.perf_counter() - t0) / nsub
+        st = r.solver_stats()
+        r.close()
+        kind = "reference"
+        its = (st["visc_iters"], st["pres_iters"])
+    else:
+        from oracle import oraclebind as O
+        s = O.OracleSim(N, N, N, dx)
+        s.set_solid(solid)
+        s.set_viscosity(viscosity)
+        s.particles = particles
+        t0 = time.perf_counter()
+        for _ in range(nsub):
+            _, vi, pi = s.substep(0.01)
+        sec = (time.perf_counter() - t0) / nsub
+        s.close()
+        kind = "port"
+        its = (vi["iterations"], pi["iterations"])
+    return {
+        "value": (N ** 3) / 1e6 / sec, "unit": "MCells/s", "cores": 1, "kind": kind,
+        "sample": "same scene (bunny in inverted sphere, viscosity %g) at %d^3 (%d particles), mean of %d substeps of "
+                  "0.01 s from rest, single thread, %.2f s per substep, last viscosity/pressure iterations %d/%d"
+                  % (viscosity, N, len(particles), nsub, sec, its[0], its[1]),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--viscosity", type=float, default=5.0)
+    ap.add_argument("--cpu-size", type=int, default=96, help="grid size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
+            sys.exit(2)
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from flipviscosity3d_amd.capi import Context
+
+    N = args.size
+    dx, solid, particles = build_scene(N, args.viscosity)
+    c = Context(N, N, N, dx, device=local_rank)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(args.viscosity)
+    c.set_gravity(0.0, -9.81, 0.0)
+    c.set_params(precision=args.precision, kernel_timing=1)
+    c.particles = particles
+    dev_name = c.device_name()
+
+    def step():
+        dt = min(c.cfl(), 0.01)
+        return c.substep(dt)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        c.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    c.kernel_stats_reset()
+    barrier()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ks = c.kernel_stats()
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    cells_total = float(N) ** 3 * world  # every rank advances its own 256^3 domain (see config.parallelism)
+    value = cells_total / 1e6 / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel
+    v_ms, v_n, v_cells = ks["viscosity_spmv_ms"], ks["viscosity_spmv_launches"], ks["viscosity_spmv_cells"]
+    p_ms, p_n, p_cells = ks["pressure_spmv_ms"], ks["pressure_spmv_launches"], ks["pressure_spmv_cells"]
+    roof = None
+    if v_n > 0 and v_ms >= p_ms:
+        avg_ms = v_ms / v_n
+        gbs = VISC_SPMV_BYTES_PER_INDEX * (v_cells / v_n) / (avg_ms * 1e-3) / 1e9
+        roof = {"kernel": "k_visc_spmv<float>" if args.precision == 0 else "k_visc_spmv<double>", "bound": "hbm",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": avg_ms * 1e3, "launches": v_n, "indices_per_launch": v_cells / v_n,
+                "bytes_per_index": VISC_SPMV_BYTES_PER_INDEX}
+    elif p_n > 0:
+        avg_ms = p_ms / p_n
+        gbs = PRES_SPMV_BYTES_PER_CELL * (p_cells / p_n) / (avg_ms * 1e-3) / 1e9
+        roof = {"kernel": "k_pressure_spmv<float>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_ms * 1e3, "launches": p_n,
+                "cells_per_launch": p_cells / p_n, "bytes_per_cell": PRES_SPMV_BYTES_PER_CELL}
+    extra = {}
+    if p_n > 0:
+        avg = p_ms / p_n
+        extra["pressure_spmv"] = {"avg_launch_us": avg * 1e3, "launches": p_n,
+                                  "achieved_GBs": PRES_SPMV_BYTES_PER_CELL * (p_cells / p_n) / (avg * 1e-3) / 1e9}
+
+    if rank == 0:
+        last = stats[-1]
+        out = {
+            "metric": "MCells/s per substep (P2G+PCG+viscosity), %d^3 grid" % N,
+            "value": value, "unit": "MCells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == 0 else "f64", "data": "synthetic",
+            "config": {
+                "workload": "%d^3 bunny drop: stanford_bunny.ply liquid in inverted sphere_large.ply, viscosity %g, "
+                            "full variational viscosity + pressure substep (BASELINE.json configs[2])" % (N, args.viscosity),
+                "grid": [N, N, N], "particles": int(len(particles)), "dt": 0.01,
+                "viscosity_cap": 700, "parallelism": "single GPU" if world == 1 else
+                "%d independent replicas of the %d^3 domain (domain decomposition not implemented yet)" % (world, N),
+            },
+            "device": dev_name,
+            "phase_ms": last["phase_ms"],
+            "viscosity": {k: last["viscosity"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
+            "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "active_tiles", "total_tiles")},
+            "roofline": roof,
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.viscosity, args.cpu_size)
+        print(json.dumps(out), flush=True)
+    c.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

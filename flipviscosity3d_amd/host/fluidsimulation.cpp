@@ -1,0 +1,212 @@
+#include "fluidsimulation.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+// Precondition failures print and abort() like FLUIDSIM_ASSERT (reference fluidsimassert.h:24-37).
+#define FLIPV_HOST_ASSERT(cond)                                                                         \
+    do {                                                                                                \
+        if (!(cond)) {                                                                                  \
+            std::fprintf(stderr, "Assertion failed: %s, file %s, line %d\n", #cond, __FILE__, __LINE__); \
+            std::abort();                                                                               \
+        }                                                                                               \
+    } while (0)
+
+#define FLIPV_CALL(call)                                                                                  \
+    do {                                                                                                  \
+        int rc_ = (call);                                                                                 \
+        if (rc_ < 0) {                                                                                    \
+            std::fprintf(stderr, "%s failed (%d): %s\n", #call, rc_, flipv_last_error(_ctx));              \
+            std::abort();                                                                                 \
+        }                                                                                                 \
+    } while (0)
+
+namespace {
+
+struct Box {  // the three AABB operations the simulation uses (reference aabb.cpp:27-29, 118-129, 213-219)
+    vmath::vec3 position;
+    double width = 0, height = 0, depth = 0;
+    Box(double x, double y, double z, double w, double h, double d) : position((float)x, (float)y, (float)z), width(w), height(h), depth(d) {}
+    explicit Box(const std::vector<vmath::vec3> &pts) {  // reference aabb.cpp:50-84
+        if (pts.empty()) return;
+        double minx = pts[0].x, miny = pts[0].y, minz = pts[0].z, maxx = minx, maxy = miny, maxz = minz;
+        for (const vmath::vec3 &p : pts) {
+            minx = std::fmin(p.x, minx); miny = std::fmin(p.y, miny); minz = std::fmin(p.z, minz);
+            maxx = std::fmax(p.x, maxx); maxy = std::fmax(p.y, maxy); maxz = std::fmax(p.z, maxz);
+        }
+        const double eps = 1e-9;
+        position = vmath::vec3((float)minx, (float)miny, (float)minz);
+        width = maxx - minx + eps; height = maxy - miny + eps; depth = maxz - minz + eps;
+    }
+    void expand(double v) {
+        const double h = 0.5 * v;
+        position -= vmath::vec3((float)h, (float)h, (float)h);
+        width += v; height += v; depth += v;
+    }
+    bool isPointInside(vmath::vec3 p) const {
+        return p.x >= position.x && p.y >= position.y && p.z >= position.z && p.x < position.x + width &&
+               p.y < position.y + height && p.z < position.z + depth;
+    }
+    vmath::vec3 minPoint() const { return position; }
+    vmath::vec3 maxPoint() const { return position + vmath::vec3((float)width, (float)height, (float)depth); }
+};
+
+inline unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+}  // namespace
+
+FluidSimulation::FluidSimulation() { std::memset(&_stats, 0, sizeof(_stats)); }
+FluidSimulation::~FluidSimulation() { _destroy(); }
+
+void FluidSimulation::_destroy() {
+    if (_ctx) flipv_destroy(_ctx);
+    _ctx = nullptr;
+}
+
+void FluidSimulation::initialize(int i, int j, int k, float dx) {  // reference fluidsimulation.cpp:26-43
+    _destroy();
+    _isize = i; _jsize = j; _ksize = k; _dx = dx;
+    particles.clear();
+    _viscosityUniform = 1.0f;
+    _viscosityGrid.clear();
+    _gravity = vmath::vec3(0.0f, -9.81f, 0.0f);
+    _solidDirty = _viscosityDirty = _gravityDirty = true;
+    _initializeBoundary();
+}
+
+// The device context is created on first use so that scene setup (mesh level sets, seeding) also works on a
+// host without a GPU; advance() needs one and fails loudly without it (there is no CPU substep).
+void FluidSimulation::_ensureContext() {
+    FLIPV_HOST_ASSERT(_isize > 0 && _jsize > 0 && _ksize > 0);
+    if (!_ctx) {
+        int rc = flipv_create(_isize, _jsize, _ksize, _dx, &_ctx);
+        if (rc != FLIPV_OK) {
+            std::fprintf(stderr, "flipv_create failed (%d): %s\n", rc, flipv_last_error(nullptr));
+            std::abort();
+        }
+        _solidDirty = _viscosityDirty = _gravityDirty = true;
+    }
+    if (_solidDirty) FLIPV_CALL(flipv_set_solid_sdf(_ctx, _solidSDF.getRawArray()));
+    if (_viscosityDirty) {
+        if (_viscosityGrid.empty()) FLIPV_CALL(flipv_set_viscosity_uniform(_ctx, _viscosityUniform));
+        else FLIPV_CALL(flipv_set_viscosity(_ctx, _viscosityGrid.data()));
+    }
+    if (_gravityDirty) FLIPV_CALL(flipv_set_gravity(_ctx, _gravity.x, _gravity.y, _gravity.z));
+    _solidDirty = _viscosityDirty = _gravityDirty = false;
+}
+
+void FluidSimulation::_initializeBoundary() {  // reference fluidsimulation.cpp:198-239
+    const double eps = 1e-6;
+    Box dom(0.0, 0.0, 0.0, _isize * _dx, _jsize * _dx, _ksize * _dx);
+    dom.expand(-3 * _dx - eps);
+    const vmath::vec3 p = dom.position;
+    const float w = (float)dom.width, h = (float)dom.height, d = (float)dom.depth;
+    TriangleMesh m;
+    m.vertices = {vmath::vec3(p.x, p.y, p.z),         vmath::vec3(p.x + w, p.y, p.z),         vmath::vec3(p.x + w, p.y, p.z + d),
+                  vmath::vec3(p.x, p.y, p.z + d),     vmath::vec3(p.x, p.y + h, p.z),         vmath::vec3(p.x + w, p.y + h, p.z),
+                  vmath::vec3(p.x + w, p.y + h, p.z + d), vmath::vec3(p.x, p.y + h, p.z + d)};
+    m.triangles = {Triangle(0, 1, 2), Triangle(0, 2, 3), Triangle(4, 7, 6), Triangle(4, 6, 5), Triangle(0, 3, 7), Triangle(0, 7, 4),
+                   Triangle(1, 5, 6), Triangle(1, 6, 2), Triangle(0, 4, 5), Triangle(0, 5, 1), Triangle(3, 2, 6), Triangle(3, 6, 7)};
+    _solidSDF = MeshLevelSet(_isize, _jsize, _ksize, _dx);
+    _solidSDF.calculateSignedDistanceField(m, _meshLevelSetExactBand);
+    _solidSDF.negate();
+    _solidDirty = true;
+}
+
+void FluidSimulation::addBoundary(TriangleMesh &boundary, bool isInverted) {  // reference fluidsimulation.cpp:45-58
+    Box domain(0.0, 0.0, 0.0, _isize * _dx, _jsize * _dx, _ksize * _dx);
+    Box bbox(boundary.vertices);
+    FLIPV_HOST_ASSERT(domain.isPointInside(bbox.minPoint()) && domain.isPointInside(bbox.maxPoint()));
+    MeshLevelSet sdf(_isize, _jsize, _ksize, _dx);
+    sdf.calculateSignedDistanceField(boundary, _meshLevelSetExactBand);
+    if (isInverted) sdf.negate();
+    _solidSDF.calculateUnion(sdf);
+    _solidDirty = true;
+}
+
+void FluidSimulation::resetBoundary() { _initializeBoundary(); }  // reference fluidsimulation.cpp:60-62
+
+void FluidSimulation::addLiquid(TriangleMesh &mesh) {  // reference fluidsimulation.cpp:64-97
+    Box domain(0.0, 0.0, 0.0, _isize * _dx, _jsize * _dx, _ksize * _dx);
+    Box bbox(mesh.vertices);
+    FLIPV_HOST_ASSERT(domain.isPointInside(bbox.minPoint()) && domain.isPointInside(bbox.maxPoint()));
+    MeshLevelSet meshSDF(_isize, _jsize, _ksize, _dx);
+    meshSDF.calculateSignedDistanceField(mesh, _meshLevelSetExactBand);
+    const double dx = _dx;
+    const float *nodes = meshSDF.getRawArray();
+    const int nw = _isize + 1, nh = _jsize + 1;
+    for (int k = 0; k < _ksize; k++)
+        for (int j = 0; j < _jsize; j++)
+            for (int i = 0; i < _isize; i++) {
+                if (_seedMode == SEED_COUNTER) {
+                    // no sample of this cell can be inside the mesh if all eight corner distances are >= 0
+                    bool anyNeg = false;
+                    for (int c = 0; c < 8 && !anyNeg; c++)
+                        anyNeg = nodes[(size_t)(i + (c & 1)) + (size_t)nw * ((size_t)(j + ((c >> 1) & 1)) + (size_t)nh * (size_t)(k + (c >> 2)))] < 0.0f;
+                    if (!anyNeg) continue;
+                }
+                const vmath::vec3 gpos((float)(i * dx), (float)(j * dx), (float)(k * dx));
+                const unsigned long long cell = (unsigned long long)i + (unsigned long long)_isize * ((unsigned long long)j + (unsigned long long)_jsize * (unsigned long long)k);
+                for (int s = 0; s < 8; s++) {
+                    float jit[3];
+                    for (int a = 0; a < 3; a++) {
+                        double u;
+                        if (_seedMode == SEED_LIBC_RAND) {
+                            // _randomDouble(0, dx) (reference fluidsimulation.h:100-102)
+                            u = 0.0 + (double)std::rand() / ((double)RAND_MAX / (dx - 0.0));
+                        } else {
+                            const unsigned long long hsh = splitmix64(splitmix64(_seed) ^ (cell * 24ull + (unsigned long long)(s * 3 + a)));
+                            u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0) * dx;
+                        }
+                        jit[a] = (float)u;
+                    }
+                    const vmath::vec3 pos = gpos + vmath::vec3(jit[0], jit[1], jit[2]);
+                    if (meshSDF.trilinearInterpolate(pos) < 0.0) {
+                        const float solid_phi = _solidSDF.trilinearInterpolate(pos);
+                        if (solid_phi >= 0) particles.push_back(FluidParticle(pos));
+                    }
+                }
+            }
+}
+
+void FluidSimulation::setViscosity(float value) {  // reference fluidsimulation.cpp:99-108
+    FLIPV_HOST_ASSERT(value >= 0.0);
+    _viscosityUniform = value;
+    _viscosityGrid.clear();
+    _viscosityDirty = true;
+}
+
+void FluidSimulation::setViscosity(Array3d<float> &vgrid) {  // reference fluidsimulation.cpp:110-124
+    FLIPV_HOST_ASSERT(vgrid.width == _isize + 1 && vgrid.height == _jsize + 1 && vgrid.depth == _ksize + 1);
+    const float *raw = vgrid.getRawArray();
+    for (size_t t = 0; t < vgrid.size(); t++) FLIPV_HOST_ASSERT(raw[t] >= 0.0);
+    _viscosityGrid.assign(raw, raw + vgrid.size());
+    _viscosityDirty = true;
+}
+
+void FluidSimulation::setGravity(vmath::vec3 g) {  // reference fluidsimulation.cpp:126-128
+    _gravity = g;
+    _gravityDirty = true;
+}
+void FluidSimulation::setGravity(float gx, float gy, float gz) { setGravity(vmath::vec3(gx, gy, gz)); }
+
+void FluidSimulation::advance(float dt) {  // reference fluidsimulation.cpp:135-168
+    _ensureContext();
+    // `particles` is public and may have been edited since the last frame: it is the source of truth
+    FLIPV_CALL(flipv_upload_particles(_ctx, particles.empty() ? nullptr : &particles[0].position.x, particles.size()));
+    FLIPV_CALL(flipv_advance(_ctx, dt, &_stats));
+    size_t n = 0;
+    FLIPV_CALL(flipv_download_particles(_ctx, particles.empty() ? nullptr : &particles[0].position.x, particles.size(), &n));
+    if (!_quiet) {
+        std::printf("advance(%g): %d substep(s), %.3f ms on the GPU; viscosity %d its (res %.3e), pressure %d its (res %.3e)\n",
+                    dt, _stats.substeps, _stats.total_ms, _stats.viscosity.iterations, _stats.viscosity.residual,
+                    _stats.pressure.iterations, _stats.pressure.residual);
+    }
+}

@@ -129,7 +129,14 @@ def test_pressure_solve(name, precision):
             assert not c.grid("PRESSURE").any()
             continue
         assert info["status"] == 0, info
-        assert rel_maxnorm(c.grid("PRESSURE"), ref) <= PRES_TOL, info
+        # The reference stops at an ABSOLUTE residual of 1e-9 (pressuresolver.cpp:544).  When max|b| is itself
+        # tiny (free fall: the field is almost divergence-free) that is a loose relative tolerance and the
+        # reference's own pressure is only resolved to ~1e-9/max|b|; compare pressures only when it is resolved.
+        if 1e-9 / info["rhs_norm"] < 1e-6:
+            assert rel_maxnorm(c.grid("PRESSURE"), ref) <= PRES_TOL, info
+        # what matters downstream: the projected velocity (fluidsimulation.cpp:598-688)
+        c.apply_pressure(g.dt)
+        assert rel_maxnorm3([c.grid(n) for n in "UVW"], g.uvw(t, "proj")) <= VEL_TOL, info
     c.close()
 
 
