@@ -1,6 +1,6 @@
 // flipv_api.hip -- C-ABI entry points of libflipv.so (include/flipv.h): context lifetime, host<->device
-// transfers in the reference's Array3d layout, and the substep sequencing of
-// FluidSimulation::advance (reference fluidsimulation.cpp:135-168).
+// transfers (reference Array3d layout at the ABI, shared padded index space on the device), and the substep
+// sequencing of FluidSimulation::advance (reference fluidsimulation.cpp:135-168).
 #include "flipv_internal.h"
 
 #include <new>
@@ -8,8 +8,26 @@
 static thread_local std::string g_create_error;
 
 // ------------------------------------------------------------------------------------------------
+// every grid array: guard zone | n entries | guard zone, all zero-initialised; returns the pointer to entry 0
 template <typename T>
-static int dev_alloc(flipv_context *c, T **p, size_t n, bool zero = true) {
+static int grid_alloc(flipv_context *c, T **p, size_t elem_bytes = sizeof(T)) {
+    const size_t n = c->L.n, g = c->L.guard;
+    const size_t bytes = (n + 2 * g) * elem_bytes;
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? FLIPV_ERR_OOM : FLIPV_ERR_HIP;
+    }
+    c->allocs.push_back(q);
+    e = hipMemsetAsync(q, 0, bytes, c->stream);
+    if (e != hipSuccess) { c->err = std::string("hipMemset: ") + hipGetErrorString(e); return FLIPV_ERR_HIP; }
+    *p = (T *)((char *)q + g * elem_bytes);
+    return FLIPV_OK;
+}
+
+template <typename T>
+static int plain_alloc(flipv_context *c, T **p, size_t n) {
     void *q = nullptr;
     const size_t bytes = (n ? n : 1) * sizeof(T);
     hipError_t e = hipMalloc(&q, bytes);
@@ -18,10 +36,8 @@ static int dev_alloc(flipv_context *c, T **p, size_t n, bool zero = true) {
         return e == hipErrorOutOfMemory ? FLIPV_ERR_OOM : FLIPV_ERR_HIP;
     }
     c->allocs.push_back(q);
-    if (zero) {
-        e = hipMemsetAsync(q, 0, bytes, c->stream);
-        if (e != hipSuccess) { c->err = std::string("hipMemset: ") + hipGetErrorString(e); return FLIPV_ERR_HIP; }
-    }
+    e = hipMemsetAsync(q, 0, bytes, c->stream);
+    if (e != hipSuccess) { c->err = std::string("hipMemset: ") + hipGetErrorString(e); return FLIPV_ERR_HIP; }
     *p = (T *)q;
     return FLIPV_OK;
 }
@@ -65,12 +81,19 @@ extern "C" int flipv_create_on_device(int I, int J, int K, float dx, int dev, fl
     }
     flipv_context *c = new (std::nothrow) flipv_context();
     if (!c) return FLIPV_ERR_OOM;
-    c->d.I = I; c->d.J = J; c->d.K = K;
+    Lay &L = c->L;
+    L.I = I; L.J = J; L.K = K;
+    L.PX = ((I + 1 + 3) / 4) * 4; L.PY = J + 1; L.PZ = K + 1;
+    L.sy = L.PX; L.sz = (long)L.PX * L.PY;
+    L.n = (size_t)L.sz * L.PZ;
+    L.guard = (((size_t)L.sz + (size_t)L.sy + 8) + 63) / 64 * 64;
     c->dx = dx;
     c->device = dev;
     c->np = c->pcap = 0;
     c->particles = nullptr;
+    c->stage = nullptr; c->stageCap = 0;
     c->d_scal = nullptr; c->h_scal = nullptr; c->scalCap = 0;
+    c->h_flags = nullptr;
     c->evUsed = 0;
     c->pressureReady = c->viscosityReady = 0;
     c->nActiveP = c->nActiveV = 0;
@@ -79,59 +102,68 @@ extern "C" int flipv_create_on_device(int I, int J, int K, float dx, int dev, fl
     flipv_default_params(&c->prm);
     c->gravity[0] = 0.0f; c->gravity[1] = -9.81f; c->gravity[2] = 0.0f;  // fluidsimulation.cpp:40
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); flipv_destroy(c); return FLIPV_ERR_HIP; } } while (0)
-#define ALLOC(ptr, n) do { int rc_ = dev_alloc(c, &(ptr), (n)); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } } while (0)
+#define GALLOC(ptr) do { int rc_ = grid_alloc(c, &(ptr)); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } } while (0)
+#define VALLOC(ptr) do { double *t_ = nullptr; int rc_ = grid_alloc(c, &t_); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } (ptr) = t_; } while (0)
     c->stream = nullptr;
+    for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) c->phaseEv[q] = nullptr;
     CHK(hipSetDevice(dev));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) c->phaseEv[q] = nullptr;
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) CHK(hipEventCreate(&c->phaseEv[q]));
-    const Dims &d = c->d;
-    const size_t nu = d.nu(), nv = d.nv(), nw = d.nw(), nc = d.nc(), nn = d.nn();
-    ALLOC(c->U, nu); ALLOC(c->V, nv); ALLOC(c->W, nw);
-    ALLOC(c->sU, nu); ALLOC(c->sV, nv); ALLOC(c->sW, nw);
-    ALLOC(c->wU, nu); ALLOC(c->wV, nv); ALLOC(c->wW, nw);
-    ALLOC(c->vU, nu); ALLOC(c->vV, nv); ALLOC(c->vW, nw);
-    ALLOC(c->phi, nc); ALLOC(c->pressure, nc); ALLOC(c->solid, nn); ALLOC(c->visc, nn);
-    ALLOC(c->accU, nu); ALLOC(c->accV, nv); ALLOC(c->accW, nw);
-    ALLOC(c->wgtU, nu); ALLOC(c->wgtV, nv); ALLOC(c->wgtW, nw);
-    ALLOC(c->stampU, nu); ALLOC(c->stampV, nv); ALLOC(c->stampW, nw);
-    ALLOC(c->d_flags, 16);
+    GALLOC(c->U); GALLOC(c->V); GALLOC(c->W);
+    GALLOC(c->sU); GALLOC(c->sV); GALLOC(c->sW);
+    GALLOC(c->wU); GALLOC(c->wV); GALLOC(c->wW);
+    GALLOC(c->vU); GALLOC(c->vV); GALLOC(c->vW);
+    GALLOC(c->phi); GALLOC(c->pressure); GALLOC(c->solid); GALLOC(c->visc);
+    GALLOC(c->accU); GALLOC(c->accV); GALLOC(c->accW);
+    GALLOC(c->wgtU); GALLOC(c->wgtV); GALLOC(c->wgtW);
+    GALLOC(c->stampU); GALLOC(c->stampV); GALLOC(c->stampW);
+    {
+        int rc_ = plain_alloc(c, &c->d_flags, 16);
+        if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
+    }
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
     memset(c->h_flags, 0, 16 * sizeof(int));
-    // solver tiles over the (I+1,J+1,K+1) index space
-    c->tg.ntx = (I + 1 + TX - 1) / TX; c->tg.nty = (J + 1 + TY - 1) / TY; c->tg.ntz = (K + 1 + TZ - 1) / TZ;
-    ALLOC(c->tileListP, (size_t)c->tg.count() + 8);
-    ALLOC(c->tileListV, (size_t)c->tg.count() + 8);
-    ALLOC(c->tileFlag, (size_t)c->tg.count() + 8);
-    // pressure system
-    ALLOC(c->pDiag, nc); ALLOC(c->pPi, nc); ALLOC(c->pPj, nc); ALLOC(c->pPk, nc);
-    double *tmp;
-    ALLOC(tmp, nc); c->pX = tmp; ALLOC(tmp, nc); c->pR = tmp; ALLOC(tmp, nc); c->pZ = tmp; ALLOC(tmp, nc); c->pS = tmp;
-    // viscosity system
-    ALLOC(c->scp, nc);
-    ALLOC(c->volC, nc); ALLOC(c->volU, nu); ALLOC(c->volV, nv); ALLOC(c->volW, nw);
-    const size_t neu = (size_t)I * (J + 1) * (K + 1), nev = (size_t)(I + 1) * J * (K + 1), new_ = (size_t)(I + 1) * (J + 1) * K;
-    ALLOC(c->volEU, neu); ALLOC(c->volEV, nev); ALLOC(c->volEW, new_);
-    ALLOC(c->fC, nc); ALLOC(c->fEU, neu); ALLOC(c->fEV, nev); ALLOC(c->fEW, new_);
-    ALLOC(c->vDiagU, nu); ALLOC(c->vDiagV, nv); ALLOC(c->vDiagW, nw);
-    ALLOC(c->stU, nu); ALLOC(c->stV, nv); ALLOC(c->stW, nw);
-    ALLOC(c->validCells, nn); ALLOC(c->validTmp, nn);
-    const size_t nf[3] = {nu, nv, nw};
-    for (int q = 0; q < 3; q++) {
-        ALLOC(tmp, nf[q]); c->vX[q] = tmp; ALLOC(tmp, nf[q]); c->vR[q] = tmp;
-        ALLOC(tmp, nf[q]); c->vZ[q] = tmp; ALLOC(tmp, nf[q]); c->vS[q] = tmp;
-    }
-    // defaults of initialize(): viscosity 1.0 at every node (fluidsimulation.cpp:39), liquid phi = 3 dx
+    // solver tiles over the shared index space
+    c->tgP.ntx = (L.PX + 64 * VW_P - 1) / (64 * VW_P); c->tgP.nty = (L.PY + TY - 1) / TY; c->tgP.ntz = L.PZ;
+    c->tgV.ntx = (L.PX + 64 * VW_V - 1) / (64 * VW_V); c->tgV.nty = (L.PY + TY - 1) / TY; c->tgV.ntz = L.PZ;
     {
-        std::vector<float> ones(nn, 1.0f);
-        CHK(hipMemcpyAsync(c->visc, ones.data(), nn * 4, hipMemcpyHostToDevice, c->stream));
-        std::vector<float> far(nc, 3.0f * dx);
-        CHK(hipMemcpyAsync(c->phi, far.data(), nc * 4, hipMemcpyHostToDevice, c->stream));
-        CHK(hipStreamSynchronize(c->stream));
+        const size_t ntmax = (size_t)(c->tgP.count() > c->tgV.count() ? c->tgP.count() : c->tgV.count()) + 8;
+        int rc_ = plain_alloc(c, &c->tileListP, ntmax);
+        if (!rc_) rc_ = plain_alloc(c, &c->tileListV, ntmax);
+        if (!rc_) rc_ = plain_alloc(c, &c->tileFlag, ntmax);
+        if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
+    }
+    // pressure system
+    GALLOC(c->pDiag); GALLOC(c->pPi); GALLOC(c->pPj); GALLOC(c->pPk);
+    VALLOC(c->pX); VALLOC(c->pR); VALLOC(c->pZ); VALLOC(c->pS);
+    // viscosity system
+    GALLOC(c->scp);
+    GALLOC(c->volC); GALLOC(c->volU); GALLOC(c->volV); GALLOC(c->volW);
+    GALLOC(c->volEU); GALLOC(c->volEV); GALLOC(c->volEW);
+    GALLOC(c->fC); GALLOC(c->fEU); GALLOC(c->fEV); GALLOC(c->fEW);
+    GALLOC(c->vDiagU); GALLOC(c->vDiagV); GALLOC(c->vDiagW);
+    GALLOC(c->vmU); GALLOC(c->vmV); GALLOC(c->vmW);
+    GALLOC(c->stU); GALLOC(c->stV); GALLOC(c->stW);
+    GALLOC(c->validCells); GALLOC(c->validTmp);
+    for (int q = 0; q < 3; q++) { VALLOC(c->vX[q]); VALLOC(c->vR[q]); VALLOC(c->vZ[q]); VALLOC(c->vS[q]); }
+    // staging buffer for layout conversion: one node-lattice worth of floats
+    {
+        const size_t cap = (size_t)(I + 1) * (J + 1) * (K + 1);
+        int rc_ = plain_alloc(c, &c->stage, cap);
+        if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
+        c->stageCap = cap;
     }
     CHK(hipStreamSynchronize(c->stream));
 #undef CHK
-#undef ALLOC
+#undef GALLOC
+#undef VALLOC
+    // defaults of initialize(): viscosity 1.0 at every node (fluidsimulation.cpp:39), liquid phi = 3 dx
+    int rc = flipv_set_viscosity_uniform(c, 1.0f);
+    if (rc == FLIPV_OK) {
+        rc = fv_fill_cells(c, c->phi, 3.0f * dx);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = FLIPV_ERR_HIP;
+    }
+    if (rc != FLIPV_OK) { g_create_error = c->err; flipv_destroy(c); return rc; }
     *out = c;
     return FLIPV_OK;
 }
@@ -188,76 +220,85 @@ extern "C" int flipv_set_gravity(flipv_context *c, float gx, float gy, float gz)
 }
 
 // ------------------------------------------------------------------------------------------------ grids
-struct GridRef { float *f; uint8_t *m; size_t n; };
+struct GridRef { float *f; uint8_t *m; int lat; };
 static bool grid_ref(flipv_context *c, int which, GridRef *g) {
-    const Dims &d = c->d;
     g->f = nullptr; g->m = nullptr;
     switch (which) {
-        case FLIPV_GRID_U: g->f = c->U; g->n = d.nu(); return true;
-        case FLIPV_GRID_V: g->f = c->V; g->n = d.nv(); return true;
-        case FLIPV_GRID_W: g->f = c->W; g->n = d.nw(); return true;
-        case FLIPV_GRID_SAVED_U: g->f = c->sU; g->n = d.nu(); return true;
-        case FLIPV_GRID_SAVED_V: g->f = c->sV; g->n = d.nv(); return true;
-        case FLIPV_GRID_SAVED_W: g->f = c->sW; g->n = d.nw(); return true;
-        case FLIPV_GRID_VALID_U: g->m = c->vU; g->n = d.nu(); return true;
-        case FLIPV_GRID_VALID_V: g->m = c->vV; g->n = d.nv(); return true;
-        case FLIPV_GRID_VALID_W: g->m = c->vW; g->n = d.nw(); return true;
-        case FLIPV_GRID_LIQUID_PHI: g->f = c->phi; g->n = d.nc(); return true;
-        case FLIPV_GRID_SOLID_PHI: g->f = c->solid; g->n = d.nn(); return true;
-        case FLIPV_GRID_WEIGHT_U: g->f = c->wU; g->n = d.nu(); return true;
-        case FLIPV_GRID_WEIGHT_V: g->f = c->wV; g->n = d.nv(); return true;
-        case FLIPV_GRID_WEIGHT_W: g->f = c->wW; g->n = d.nw(); return true;
-        case FLIPV_GRID_VISCOSITY: g->f = c->visc; g->n = d.nn(); return true;
-        case FLIPV_GRID_PRESSURE: g->f = c->pressure; g->n = d.nc(); return true;
+        case FLIPV_GRID_U: g->f = c->U; g->lat = LAT_U; return true;
+        case FLIPV_GRID_V: g->f = c->V; g->lat = LAT_V; return true;
+        case FLIPV_GRID_W: g->f = c->W; g->lat = LAT_W; return true;
+        case FLIPV_GRID_SAVED_U: g->f = c->sU; g->lat = LAT_U; return true;
+        case FLIPV_GRID_SAVED_V: g->f = c->sV; g->lat = LAT_V; return true;
+        case FLIPV_GRID_SAVED_W: g->f = c->sW; g->lat = LAT_W; return true;
+        case FLIPV_GRID_VALID_U: g->m = c->vU; g->lat = LAT_U; return true;
+        case FLIPV_GRID_VALID_V: g->m = c->vV; g->lat = LAT_V; return true;
+        case FLIPV_GRID_VALID_W: g->m = c->vW; g->lat = LAT_W; return true;
+        case FLIPV_GRID_LIQUID_PHI: g->f = c->phi; g->lat = LAT_CELL; return true;
+        case FLIPV_GRID_SOLID_PHI: g->f = c->solid; g->lat = LAT_NODE; return true;
+        case FLIPV_GRID_WEIGHT_U: g->f = c->wU; g->lat = LAT_U; return true;
+        case FLIPV_GRID_WEIGHT_V: g->f = c->wV; g->lat = LAT_V; return true;
+        case FLIPV_GRID_WEIGHT_W: g->f = c->wW; g->lat = LAT_W; return true;
+        case FLIPV_GRID_VISCOSITY: g->f = c->visc; g->lat = LAT_NODE; return true;
+        case FLIPV_GRID_PRESSURE: g->f = c->pressure; g->lat = LAT_CELL; return true;
     }
     return false;
+}
+static size_t lat_count(const Lay &L, int lat) {
+    int w, h, d;
+    lat_dims(L, lat, w, h, d);
+    return (size_t)w * h * d;
 }
 
 extern "C" size_t flipv_grid_elements(flipv_context *c, int which) {
     GridRef g;
     if (!c || !grid_ref(c, which, &g)) return 0;
-    return g.n;
+    return lat_count(c->L, g.lat);
 }
 
-extern "C" int flipv_read_grid(flipv_context *c, int which, float *out) {
-    GridRef g;
-    if (!c || !out || !grid_ref(c, which, &g)) { if (c) c->err = "flipv_read_grid: bad grid id"; return FLIPV_ERR_INVALID; }
-    if (g.f) {
-        HIPCHK(c, hipMemcpyAsync(out, g.f, g.n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    } else {
-        std::vector<uint8_t> tmp(g.n);
-        HIPCHK(c, hipMemcpyAsync(tmp.data(), g.m, g.n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (size_t t = 0; t < g.n; t++) out[t] = tmp[t] ? 1.0f : 0.0f;
-    }
+static int read_lattice(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, float *out) {
+    const size_t n = lat_count(c->L, lat);
+    int rc = fv_pack(c, lat, srcf, srcb, c->stage);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->stage, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return FLIPV_OK;
+}
+static int write_lattice(flipv_context *c, int lat, const float *in, float *dstf, uint8_t *dstb) {
+    const size_t n = lat_count(c->L, lat);
+    HIPCHK(c, hipMemcpyAsync(c->stage, in, n * 4, hipMemcpyHostToDevice, c->stream));
+    int rc = fv_unpack(c, lat, c->stage, dstf, dstb);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FLIPV_OK;
+}
+
+#define ENTER(c) do { if (!(c)) return FLIPV_ERR_INVALID; hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) { (c)->err = hipGetErrorString(e_); return FLIPV_ERR_HIP; } } while (0)
+#define SYNC_RET(c, rc) do { int rc__ = (rc); hipError_t e_ = hipStreamSynchronize((c)->stream); if (e_ != hipSuccess) { (c)->err = std::string("stream sync: ") + hipGetErrorString(e_); return FLIPV_ERR_HIP; } return rc__; } while (0)
+
+extern "C" int flipv_read_grid(flipv_context *c, int which, float *out) {
+    ENTER(c);
+    GridRef g;
+    if (!out || !grid_ref(c, which, &g)) { c->err = "flipv_read_grid: bad grid id"; return FLIPV_ERR_INVALID; }
+    return read_lattice(c, g.lat, g.f, g.m, out);
 }
 
 extern "C" int flipv_write_grid(flipv_context *c, int which, const float *in) {
+    ENTER(c);
     GridRef g;
-    if (!c || !in || !grid_ref(c, which, &g)) { if (c) c->err = "flipv_write_grid: bad grid id"; return FLIPV_ERR_INVALID; }
-    if (g.f) {
-        HIPCHK(c, hipMemcpyAsync(g.f, in, g.n * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (which == FLIPV_GRID_VISCOSITY) {
-            int nz = 0;
-            for (size_t t = 0; t < g.n; t++) if (in[t] > 0.0f) { nz = 1; break; }
-            c->viscosity_nonzero = nz;
-        }
-    } else {
-        std::vector<uint8_t> tmp(g.n);
-        for (size_t t = 0; t < g.n; t++) tmp[t] = in[t] != 0.0f;
-        HIPCHK(c, hipMemcpyAsync(g.m, tmp.data(), g.n, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!in || !grid_ref(c, which, &g)) { c->err = "flipv_write_grid: bad grid id"; return FLIPV_ERR_INVALID; }
+    if (which == FLIPV_GRID_VISCOSITY) {
+        const size_t n = lat_count(c->L, g.lat);
+        int nz = 0;
+        for (size_t t = 0; t < n; t++) if (in[t] > 0.0f) { nz = 1; break; }
+        c->viscosity_nonzero = nz;
     }
-    return FLIPV_OK;
+    return write_lattice(c, g.lat, in, g.f, g.m);
 }
 
 extern "C" int flipv_set_solid_sdf(flipv_context *c, const float *nodes) { return flipv_write_grid(c, FLIPV_GRID_SOLID_PHI, nodes); }
 extern "C" int flipv_set_viscosity(flipv_context *c, const float *nodes) {
     if (!c || !nodes) return FLIPV_ERR_INVALID;
-    const size_t n = c->d.nn();
+    const size_t n = lat_count(c->L, LAT_NODE);
     for (size_t t = 0; t < n; t++)
         if (!(nodes[t] >= 0.0f)) { c->err = "flipv_set_viscosity: negative viscosity"; return FLIPV_ERR_INVALID; }  // fluidsimulation.cpp:119
     return flipv_write_grid(c, FLIPV_GRID_VISCOSITY, nodes);
@@ -265,13 +306,14 @@ extern "C" int flipv_set_viscosity(flipv_context *c, const float *nodes) {
 extern "C" int flipv_set_viscosity_uniform(flipv_context *c, float value) {
     if (!c) return FLIPV_ERR_INVALID;
     if (!(value >= 0.0f)) { c->err = "flipv_set_viscosity_uniform: negative viscosity"; return FLIPV_ERR_INVALID; }  // fluidsimulation.cpp:100
-    std::vector<float> v(c->d.nn(), value);
+    std::vector<float> v(lat_count(c->L, LAT_NODE), value);
     return flipv_write_grid(c, FLIPV_GRID_VISCOSITY, v.data());
 }
 
 // ------------------------------------------------------------------------------------------------ particles
 extern "C" int flipv_upload_particles(flipv_context *c, const float *aos6, size_t n) {
-    if (!c || (n && !aos6)) return FLIPV_ERR_INVALID;
+    ENTER(c);
+    if (n && !aos6) return FLIPV_ERR_INVALID;
     if (n > c->pcap) {
         if (c->particles) (void)hipFree(c->particles);
         c->particles = nullptr;
@@ -289,7 +331,7 @@ extern "C" int flipv_upload_particles(flipv_context *c, const float *aos6, size_
     return FLIPV_OK;
 }
 extern "C" int flipv_download_particles(flipv_context *c, float *aos6, size_t capacity, size_t *n_out) {
-    if (!c) return FLIPV_ERR_INVALID;
+    ENTER(c);
     if (n_out) *n_out = c->np;
     if (capacity < c->np) { c->err = "flipv_download_particles: buffer too small"; return FLIPV_ERR_INVALID; }
     if (c->np) {
@@ -302,19 +344,16 @@ extern "C" int flipv_download_particles(flipv_context *c, float *aos6, size_t ca
 extern "C" size_t flipv_num_particles(flipv_context *c) { return c ? c->np : 0; }
 
 // ------------------------------------------------------------------------------------------------ operators
-#define ENTER(c) do { if (!(c)) return FLIPV_ERR_INVALID; hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) { (c)->err = hipGetErrorString(e_); return FLIPV_ERR_HIP; } } while (0)
-#define SYNC_RET(c, rc) do { int rc__ = (rc); hipError_t e_ = hipStreamSynchronize((c)->stream); if (e_ != hipSuccess) { (c)->err = std::string("stream sync: ") + hipGetErrorString(e_); return FLIPV_ERR_HIP; } return rc__; } while (0)
-
 extern "C" int flipv_cfl(flipv_context *c, float *dt_out) { ENTER(c); if (!dt_out) return FLIPV_ERR_INVALID; return fv_cfl(c, dt_out); }
 extern "C" int flipv_particle_sdf(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_particle_sdf(c)); }
 extern "C" int flipv_p2g(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_p2g(c)); }
 extern "C" int flipv_extrapolate(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_extrapolate(c)); }
 
 static int save_velocity(flipv_context *c) {
-    const Dims &d = c->d;
-    HIPCHK(c, hipMemcpyAsync(c->sU, c->U, d.nu() * 4, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sV, c->V, d.nv() * 4, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sW, c->W, d.nw() * 4, hipMemcpyDeviceToDevice, c->stream));
+    const size_t bytes = c->L.n * 4;
+    HIPCHK(c, hipMemcpyAsync(c->sU, c->U, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sV, c->V, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sW, c->W, bytes, hipMemcpyDeviceToDevice, c->stream));
     return FLIPV_OK;
 }
 extern "C" int flipv_save_velocity(flipv_context *c) { ENTER(c); SYNC_RET(c, save_velocity(c)); }
@@ -339,13 +378,9 @@ extern "C" int flipv_advect_particles(flipv_context *c, float dt) { ENTER(c); SY
 extern "C" int flipv_read_viscosity_volume(flipv_context *c, int which, float *out) {
     ENTER(c);
     if (!out || which < 0 || which > 6) return FLIPV_ERR_INVALID;
-    const int I = c->d.I, J = c->d.J, K = c->d.K;
     const float *src[7] = {c->volC, c->volU, c->volV, c->volW, c->volEU, c->volEV, c->volEW};
-    const size_t n[7] = {c->d.nc(), c->d.nu(), c->d.nv(), c->d.nw(), (size_t)I * (J + 1) * (K + 1),
-                         (size_t)(I + 1) * J * (K + 1), (size_t)(I + 1) * (J + 1) * K};
-    HIPCHK(c, hipMemcpyAsync(out, src[which], n[which] * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return FLIPV_OK;
+    const int lat[7] = {LAT_CELL, LAT_U, LAT_V, LAT_W, LAT_EU, LAT_EV, LAT_EW};
+    return read_lattice(c, lat[which], src[which], nullptr, out);
 }
 
 // ------------------------------------------------------------------------------------------------ substep
@@ -510,4 +545,23 @@ extern "C" int flipv_bench_copy(flipv_context *c, size_t bytes, int reps, double
     (void)hipFree(b);
     *gbps_out = 2.0 * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
     return FLIPV_OK;
+}
+
+// debug only (not part of the ABI): fold the slot-spread PCG scalars of the LAST solve on the host.
+// out = 5 arrays of n doubles: sig, a, b, c, rmax.
+#include "pcg_common.h"
+extern "C" int fvdbg_pcg_scalars(flipv_context *c, int cap, int n, double *out) {
+    const size_t per = ((size_t)cap + 2) * NSLOT;
+    std::vector<double> h(5 * per);
+    if (hipMemcpy(h.data(), c->d_scal, 5 * per * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int q = 0; q < 5; q++)
+        for (int it = 0; it < n; it++) {
+            double v = 0;
+            for (int s = 0; s < NSLOT; s++) {
+                const double x = h[q * per + (size_t)it * NSLOT + s];
+                v = q == 4 ? (x > v ? x : v) : v + x;
+            }
+            out[(size_t)q * n + it] = v;
+        }
+    return 0;
 }

@@ -13,36 +13,52 @@
 #include "../../include/flipv.h"
 
 // ---------------------------------------------------------------------------------------------
-// geometry
+// Device layout.
+//
+// At the ABI every grid is the reference's Array3d (x fastest, its own width/height).  On the device all
+// lattices of one simulation -- cells (I,J,K), U/V/W faces, nodes (I+1,J+1,K+1) and the three edge
+// families -- live in ONE index space of PX x PY x PZ entries, PX = roundup4(I+1), PY = J+1, PZ = K+1:
+//     g(i,j,k) = i + PX*(j + PY*k)      for every array.
+// Consequences: a single index and a single set of neighbour offsets (1, PX, PX*PY) address every
+// field; rows start 16-byte aligned so a lane can move 4 consecutive i with one dwordx4 access (a wave:
+// 1 KiB per instruction); a k-plane is one contiguous PX*PY block (the halo unit of a slab decomposition).
+// Entries outside a lattice's logical range are zero and never written.  Each allocation carries a guard
+// zone of one plane + one row on both sides so that the +-1 neighbours of any in-range index are valid
+// addresses.  Conversion to/from Array3d happens in flipv_read_grid / flipv_write_grid (k_pack/k_unpack).
 // ---------------------------------------------------------------------------------------------
-struct Dims {
-    int I, J, K;
-    __host__ __device__ size_t nu() const { return (size_t)(I + 1) * J * K; }
-    __host__ __device__ size_t nv() const { return (size_t)I * (J + 1) * K; }
-    __host__ __device__ size_t nw() const { return (size_t)I * J * (K + 1); }
-    __host__ __device__ size_t nc() const { return (size_t)I * J * K; }
-    __host__ __device__ size_t nn() const { return (size_t)(I + 1) * (J + 1) * (K + 1); }
+struct Lay {
+    int I, J, K;     // cells
+    int PX, PY, PZ;  // padded index space
+    long sy, sz;     // strides of j and k
+    size_t n;        // PX*PY*PZ
+    size_t guard;    // floats of guard zone in front of / behind every array
 };
 
-// Solver tiles: TX x TY x TZ indices of the (I+1,J+1,K+1) index space; one 256-thread block per tile,
-// one wave per x-row of 64 consecutive i (coalesced 256-byte lines), TZ planes marched per thread.
-constexpr int TX = 64, TY = 4, TZ = 4;
+__host__ __device__ __forceinline__ size_t gidx(const Lay &L, int i, int j, int k) {
+    return (size_t)i + (size_t)L.PX * ((size_t)j + (size_t)L.PY * (size_t)k);
+}
+
+// lattice ids: logical extents inside the shared index space
+enum { LAT_CELL = 0, LAT_U = 1, LAT_V = 2, LAT_W = 3, LAT_NODE = 4, LAT_EU = 5, LAT_EV = 6, LAT_EW = 7 };
+__host__ __device__ __forceinline__ void lat_dims(const Lay &L, int lat, int &w, int &h, int &d) {
+    w = L.I + (lat == LAT_U || lat == LAT_NODE || lat == LAT_EV || lat == LAT_EW);
+    h = L.J + (lat == LAT_V || lat == LAT_NODE || lat == LAT_EU || lat == LAT_EW);
+    d = L.K + (lat == LAT_W || lat == LAT_NODE || lat == LAT_EU || lat == LAT_EV);
+}
+
+// Solver tiles: 64*N indices along i (one wave: 64 lanes x N consecutive i), TY rows, one k-plane.
+// One 256-thread block per tile; block (64, 4, 1).  N = VW_P for the pressure solve, VW_V for viscosity.
+constexpr int VW_P = 4;          // 7-point stencil, 72 VGPRs: 16-byte accesses
+constexpr int VW_V = 2;          // coupled 15-point stencil: 8-byte accesses keep the kernel under 128 VGPRs
+constexpr int TY = 4;
 
 struct TileGrid {
     int ntx, nty, ntz;
     __host__ __device__ int count() const { return ntx * nty * ntz; }
 };
 
-// ---------------------------------------------------------------------------------------------
-// device memory helpers
-// ---------------------------------------------------------------------------------------------
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
-
 struct flipv_context {
-    Dims d;
+    Lay L;
     float dx;
     int device;
     hipStream_t stream;
@@ -51,42 +67,45 @@ struct flipv_context {
     std::string err;
     std::vector<void *> allocs;
 
-    // persistent grids (Array3d layout)
+    // persistent grids (device layout above)
     float *U, *V, *W, *sU, *sV, *sW, *wU, *wV, *wW, *phi, *solid, *visc, *pressure;
     uint8_t *vU, *vV, *vW;
     // particles
-    float *particles;  // AoS 6 floats
+    float *particles;  // AoS 6 floats, caller's order
     size_t np, pcap;
     // P2G accumulators (value, weight) per component
     float *accU, *accV, *accW, *wgtU, *wgtV, *wgtW;
     // extrapolation stamps
     uint8_t *stampU, *stampV, *stampW;
+    // staging for Array3d <-> device layout conversion
+    float *stage;
+    size_t stageCap;
     // scalars
-    double *d_scal;   // device scalar scratch (see solver)
+    double *d_scal;   // device scalar scratch (PCG)
     double *h_scal;   // pinned host mirror
-    int *d_flags;     // device int scratch
+    size_t scalCap;
+    int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits
     int *h_flags;     // pinned host mirror
     int viscosity_nonzero;  // cached host-side: any viscosity node > 0
 
     // solver tiles
-    TileGrid tg;
-    int *tileListP, *tileListV;  // active tile ids of the pressure / viscosity systems
+    TileGrid tgP, tgV;
+    int *tileListP, *tileListV;
     int *tileFlag;
     int nActiveP, nActiveV;
-    size_t scalCap;
-    float *scp;                  // solid phi at cell centres (viscosity face states)
 
-    // pressure system (dense cell arrays; zero outside pressure cells)
+    // pressure system (zero outside pressure cells)
     float *pDiag, *pPi, *pPj, *pPk;
-    void *pX, *pR, *pZ, *pS;  // vectors (float or double per precision), nc elements
+    void *pX, *pR, *pZ, *pS;  // vectors (float or double per precision)
     // viscosity system
+    float *scp;                                                 // solid phi at cell centres
     float *volC, *volU, *volV, *volW, *volEU, *volEV, *volEW;  // control volumes (kept for parity reads)
-    float *fC, *fEU, *fEV, *fEW;                               // factor arrays
+    float *fC, *fEU, *fEV, *fEW;                               // factor lattices
     float *vDiagU, *vDiagV, *vDiagW;
-    uint8_t *rowU, *rowV, *rowW, *stU, *stV, *stW;
+    float *vmU, *vmV, *vmW;                                    // own volume of a row, -1 elsewhere (SpMV row mask)
+    uint8_t *stU, *stV, *stW;
     void *vX[3], *vR[3], *vZ[3], *vS[3];
-    uint8_t *validCells;  // (I+1,J+1,K+1) dilation mask
-    uint8_t *validTmp;
+    uint8_t *validCells, *validTmp;
 
     // kernel timing
     flipv_kernel_stats kstats;
@@ -96,7 +115,6 @@ struct flipv_context {
     std::vector<EvSpan> evSpans;
     hipEvent_t phaseEv[FLIPV_PHASE_COUNT + 1];
 
-    // last solve (for flipv_bench_spmv)
     float lastDt;
     int pressureReady, viscosityReady;
     int pressurePrec, viscosityPrec;
@@ -113,11 +131,17 @@ struct flipv_context {
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// pointwise kernels: one thread per index of the padded space; a wave = 64 consecutive i of one row
+#define GRID3(L) dim3(cdiv((L).PX, 64), cdiv((L).PY, 4), (unsigned)(L).PZ), dim3(64, 4, 1)
+#define IJK_OR_RETURN(L)                                                                              \
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;   \
+    if (i >= (L).PX || j >= (L).PY) return;                                                            \
+    const size_t c = gidx((L), i, j, k);                                                                \
+    (void)c
+
 // ---------------------------------------------------------------------------------------------
 // device helpers shared by all kernels
 // ---------------------------------------------------------------------------------------------
-#define DIDX(i, j, k, w, h) ((size_t)(i) + (size_t)(w) * ((size_t)(j) + (size_t)(h) * (size_t)(k)))
-
 __device__ __forceinline__ bool d_in_range(int i, int j, int k, int w, int h, int d) {
     return i >= 0 && j >= 0 && k >= 0 && i < w && j < h && k < d;
 }
@@ -167,25 +191,25 @@ __device__ __forceinline__ float d_frac4(float bl, float br, float tl, float tr)
 }
 
 // MeshLevelSet::getDistanceAtCellCenter (reference meshlevelset.cpp:66-76); same summation order
-__device__ __forceinline__ float d_solid_center(const float *__restrict__ s, int i, int j, int k, int I, int J) {
-    const int w = I + 1, h = J + 1;
-    return 0.125f * (s[DIDX(i, j, k, w, h)] + s[DIDX(i + 1, j, k, w, h)] + s[DIDX(i, j + 1, k, w, h)] +
-                     s[DIDX(i + 1, j + 1, k, w, h)] + s[DIDX(i, j, k + 1, w, h)] + s[DIDX(i + 1, j, k + 1, w, h)] +
-                     s[DIDX(i, j + 1, k + 1, w, h)] + s[DIDX(i + 1, j + 1, k + 1, w, h)]);
+__device__ __forceinline__ float d_solid_center(const float *__restrict__ s, const Lay &L, size_t c) {
+    return 0.125f * (s[c] + s[c + 1] + s[c + L.sy] + s[c + 1 + L.sy] + s[c + L.sz] + s[c + 1 + L.sz] +
+                     s[c + L.sy + L.sz] + s[c + 1 + L.sy + L.sz]);
 }
 
-// Grid3d::isFaceBorderingValueU/V/W on the predicate phi<0 (reference grid3d.h:496-530)
-__device__ __forceinline__ bool d_face_borders_fluid(int dir, int i, int j, int k, int I, int J, int K,
+// Grid3d::isFaceBorderingValueU/V/W on the predicate phi<0 (reference grid3d.h:496-530).
+// (i,j,k) must be a valid face index of component dir.
+__device__ __forceinline__ bool d_face_borders_fluid(int dir, int i, int j, int k, const Lay &L,
                                                      const float *__restrict__ phi) {
-    const int n = dir == 0 ? I : (dir == 1 ? J : K);
-    const int c = dir == 0 ? i : (dir == 1 ? j : k);
-    const int di = dir == 0, dj = dir == 1, dk = dir == 2;
-    if (c == n) return phi[DIDX(i - di, j - dj, k - dk, I, J)] < 0.0f;
-    if (c > 0) return phi[DIDX(i, j, k, I, J)] < 0.0f || phi[DIDX(i - di, j - dj, k - dk, I, J)] < 0.0f;
-    return phi[DIDX(i, j, k, I, J)] < 0.0f;
+    const int n = dir == 0 ? L.I : (dir == 1 ? L.J : L.K);
+    const int cd = dir == 0 ? i : (dir == 1 ? j : k);
+    const long back = dir == 0 ? 1 : (dir == 1 ? L.sy : L.sz);
+    const size_t c = gidx(L, i, j, k);
+    if (cd == n) return phi[c - back] < 0.0f;
+    if (cd > 0) return phi[c] < 0.0f || phi[c - back] < 0.0f;
+    return phi[c] < 0.0f;
 }
 
-// wave64 reductions (no LDS): butterfly over the 64 lanes
+// wave64 reductions (no LDS memory): butterfly over the 64 lanes
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -230,8 +254,7 @@ __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
 // contiguous chunk of the (spatially ordered) tile list so that j/k-neighbour tiles share an L2.
 __device__ __forceinline__ int d_tile_slot(int b, int n) {
     const int per = (n + 7) >> 3;
-    const int slot = (b & 7) * per + (b >> 3);
-    return slot;  // may be >= n: caller checks
+    return (b & 7) * per + (b >> 3);  // may be >= n: caller checks
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -249,7 +272,10 @@ int fv_update_particle_velocities(flipv_context *c);
 int fv_advect_particles(flipv_context *c, float dt);
 int fv_pressure_solve(flipv_context *c, float dt, flipv_solve_info *info);
 int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info);
-int fv_bench_spmv(flipv_context *c, int which, int reps, double *ms, double *cells);
+int fv_pack(flipv_context *c, int lat, const float *src_f32, const uint8_t *src_u8, float *linear);   // device -> Array3d order
+int fv_unpack(flipv_context *c, int lat, const float *linear, float *dst_f32, uint8_t *dst_u8);       // Array3d order -> device
+int fv_fill(flipv_context *c, float *p, size_t n, float v);
+int fv_fill_cells(flipv_context *c, float *p, float v);
 
 // event-pool helpers for kernel timing
 void fv_ev_begin(flipv_context *c, int which, double cells);

@@ -17,8 +17,9 @@ __device__ __forceinline__ void atomic_min_f32(float *addr, float v) {
 
 // ------------------------------------------------------------------ K1: liquid SDF from particles
 // reference particlelevelset.cpp:98-125
-__global__ void k_sdf_scatter(const float *__restrict__ aos6, size_t n, float *__restrict__ phi, int I, int J, int K,
-                              float dx, float radius) {
+__global__ void k_sdf_scatter(Lay L, const float *__restrict__ aos6, size_t n, float *__restrict__ phi, float dx,
+                              float radius) {
+    const int I = L.I, J = L.J, K = L.K;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const double dxd = (double)dx, invdx = 1.0 / dxd, hw = 0.5 * dxd;
@@ -33,7 +34,7 @@ __global__ void k_sdf_scatter(const float *__restrict__ aos6, size_t n, float *_
             for (int i = i0; i <= i1; i++) {
                 const float vx = (float)(i * dxd + hw) - px;
                 const float dist = sqrtf(vx * vx + vy * vy + vz * vz) - radius;
-                float *a = &phi[DIDX(i, j, k, I, J)];
+                float *a = &phi[gidx(L, i, j, k)];
                 if (dist < *a) atomic_min_f32(a, dist);  // plain pre-test only skips useless atomics
             }
         }
@@ -43,9 +44,10 @@ __global__ void k_sdf_scatter(const float *__restrict__ aos6, size_t n, float *_
 // ------------------------------------------------------------------ K3: particle -> grid
 // reference fluidsimulation.cpp:364-420 (all three components in one pass over the particles).
 // v1: one thread per particle, global fp32 atomics (hardware global_atomic_add_f32).
-__global__ void k_p2g_scatter(const float *__restrict__ aos6, size_t n, float *__restrict__ accU,
+__global__ void k_p2g_scatter(Lay L, const float *__restrict__ aos6, size_t n, float *__restrict__ accU,
                               float *__restrict__ wgtU, float *__restrict__ accV, float *__restrict__ wgtV,
-                              float *__restrict__ accW, float *__restrict__ wgtW, int I, int J, int K, float dx) {
+                              float *__restrict__ accW, float *__restrict__ wgtW, float dx) {
+    const int I = L.I, J = L.J, K = L.K;
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const double dxd = (double)dx, invdx = 1.0 / dxd;
@@ -77,7 +79,7 @@ __global__ void k_p2g_scatter(const float *__restrict__ aos6, size_t n, float *_
                     const float q = vx * vx + vy * vy + vz * vz;
                     if (q < rsq) {
                         const float weight = 1.0f - coef1 * q * q * q + coef2 * q * q - coef3 * q;
-                        const size_t f = DIDX(i, j, k, w, h);
+                        const size_t f = gidx(L, i, j, k);
                         atomicAdd(&acc[dir][f], weight * vel);
                         atomicAdd(&wgt[dir][f], weight);
                     }
@@ -90,9 +92,9 @@ __global__ void k_p2g_scatter(const float *__restrict__ aos6, size_t n, float *_
 // ------------------------------------------------------------------ K15: grid -> particle
 // MACVelocityField::_interpolateLinearU/V/W (reference macvelocityfield.cpp:455-546): fp64 position,
 // cell origin and weights; out-of-range corners contribute 0; corner order of interpolation.cpp:54-66.
-__device__ __forceinline__ double d_mac_lerp(int dir, double x, double y, double z, double dx, int I, int J, int K,
+__device__ __forceinline__ double d_mac_lerp(int dir, double x, double y, double z, double dx, const Lay &L,
                                              const float *__restrict__ g) {
-    const int w = I + (dir == 0), h = J + (dir == 1), d = K + (dir == 2);
+    const int w = L.I + (dir == 0), h = L.J + (dir == 1), d = L.K + (dir == 2);
     if (dir != 0) x -= 0.5 * dx;
     if (dir != 1) y -= 0.5 * dx;
     if (dir != 2) z -= 0.5 * dx;
@@ -100,40 +102,40 @@ __device__ __forceinline__ double d_mac_lerp(int dir, double x, double y, double
     const int i = (int)floor(x * invdx), j = (int)floor(y * invdx), k = (int)floor(z * invdx);
     const double ix = (x - (double)i * dx) * invdx, iy = (y - (double)j * dx) * invdx, iz = (z - (double)k * dx) * invdx;
     double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
-    if (d_in_range(i, j, k, w, h, d)) p0 = g[DIDX(i, j, k, w, h)];
-    if (d_in_range(i + 1, j, k, w, h, d)) p1 = g[DIDX(i + 1, j, k, w, h)];
-    if (d_in_range(i, j + 1, k, w, h, d)) p2 = g[DIDX(i, j + 1, k, w, h)];
-    if (d_in_range(i, j, k + 1, w, h, d)) p3 = g[DIDX(i, j, k + 1, w, h)];
-    if (d_in_range(i + 1, j, k + 1, w, h, d)) p4 = g[DIDX(i + 1, j, k + 1, w, h)];
-    if (d_in_range(i, j + 1, k + 1, w, h, d)) p5 = g[DIDX(i, j + 1, k + 1, w, h)];
-    if (d_in_range(i + 1, j + 1, k, w, h, d)) p6 = g[DIDX(i + 1, j + 1, k, w, h)];
-    if (d_in_range(i + 1, j + 1, k + 1, w, h, d)) p7 = g[DIDX(i + 1, j + 1, k + 1, w, h)];
+    if (d_in_range(i, j, k, w, h, d)) p0 = g[gidx(L, i, j, k)];
+    if (d_in_range(i + 1, j, k, w, h, d)) p1 = g[gidx(L, i + 1, j, k)];
+    if (d_in_range(i, j + 1, k, w, h, d)) p2 = g[gidx(L, i, j + 1, k)];
+    if (d_in_range(i, j, k + 1, w, h, d)) p3 = g[gidx(L, i, j, k + 1)];
+    if (d_in_range(i + 1, j, k + 1, w, h, d)) p4 = g[gidx(L, i + 1, j, k + 1)];
+    if (d_in_range(i, j + 1, k + 1, w, h, d)) p5 = g[gidx(L, i, j + 1, k + 1)];
+    if (d_in_range(i + 1, j + 1, k, w, h, d)) p6 = g[gidx(L, i + 1, j + 1, k)];
+    if (d_in_range(i + 1, j + 1, k + 1, w, h, d)) p7 = g[gidx(L, i + 1, j + 1, k + 1)];
     return p0 * (1 - ix) * (1 - iy) * (1 - iz) + p1 * ix * (1 - iy) * (1 - iz) + p2 * (1 - ix) * iy * (1 - iz) +
            p3 * (1 - ix) * (1 - iy) * iz + p4 * ix * (1 - iy) * iz + p5 * (1 - ix) * iy * iz + p6 * ix * iy * (1 - iz) +
            p7 * ix * iy * iz;
 }
 
 // evaluateVelocityAtPositionLinear (reference macvelocityfield.cpp:564-578)
-__device__ __forceinline__ void d_mac_velocity(float px, float py, float pz, double dx, int I, int J, int K,
+__device__ __forceinline__ void d_mac_velocity(float px, float py, float pz, double dx, const Lay &L,
                                                const float *__restrict__ U, const float *__restrict__ V,
                                                const float *__restrict__ W, float out[3]) {
     const double x = px, y = py, z = pz;
-    if (!(x >= 0 && y >= 0 && z >= 0 && x < dx * I && y < dx * J && z < dx * K)) {
+    if (!(x >= 0 && y >= 0 && z >= 0 && x < dx * L.I && y < dx * L.J && z < dx * L.K)) {
         out[0] = out[1] = out[2] = 0.0f;
         return;
     }
-    out[0] = (float)d_mac_lerp(0, x, y, z, dx, I, J, K, U);
-    out[1] = (float)d_mac_lerp(1, x, y, z, dx, I, J, K, V);
-    out[2] = (float)d_mac_lerp(2, x, y, z, dx, I, J, K, W);
+    out[0] = (float)d_mac_lerp(0, x, y, z, dx, L, U);
+    out[1] = (float)d_mac_lerp(1, x, y, z, dx, L, V);
+    out[2] = (float)d_mac_lerp(2, x, y, z, dx, L, W);
 }
 
 // _updateFluidParticleVelocities (reference fluidsimulation.cpp:341-352)
-__device__ __forceinline__ void d_update_velocity(float *q, double dx, int I, int J, int K, const float *U,
+__device__ __forceinline__ void d_update_velocity(float *q, double dx, const Lay &L, const float *U,
                                                   const float *V, const float *W, const float *sU, const float *sV,
                                                   const float *sW, float ratio) {
     float vn[3], vo[3];
-    d_mac_velocity(q[0], q[1], q[2], dx, I, J, K, U, V, W, vn);
-    d_mac_velocity(q[0], q[1], q[2], dx, I, J, K, sU, sV, sW, vo);
+    d_mac_velocity(q[0], q[1], q[2], dx, L, U, V, W, vn);
+    d_mac_velocity(q[0], q[1], q[2], dx, L, sU, sV, sW, vo);
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float pic = vn[c];
@@ -142,37 +144,38 @@ __device__ __forceinline__ void d_update_velocity(float *q, double dx, int I, in
     }
 }
 
-__global__ void k_update_velocities(float *__restrict__ aos6, size_t n, const float *__restrict__ U,
+__global__ void k_update_velocities(Lay L, float *__restrict__ aos6, size_t n, const float *__restrict__ U,
                                     const float *__restrict__ V, const float *__restrict__ W,
                                     const float *__restrict__ sU, const float *__restrict__ sV,
-                                    const float *__restrict__ sW, int I, int J, int K, float dx, float ratio) {
+                                    const float *__restrict__ sW, float dx, float ratio) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     float q[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) q[c] = aos6[6 * p + c];
-    d_update_velocity(q, (double)dx, I, J, K, U, V, W, sU, sV, sW, ratio);
+    d_update_velocity(q, (double)dx, L, U, V, W, sU, sV, sW, ratio);
 #pragma unroll
     for (int c = 3; c < 6; c++) aos6[6 * p + c] = q[c];
 }
 
 // scalar-field trilinear value + gradient at a point of the solid node grid
 // (reference interpolation.cpp:68-108 and :122-184): position differences in fp32, weights in fp64.
-__device__ __forceinline__ float d_solid_value_grad(float px, float py, float pz, double dx,
-                                                    const float *__restrict__ g, int w, int h, int d, float grad[3]) {
+__device__ __forceinline__ float d_solid_value_grad(float px, float py, float pz, double dx, const Lay &L,
+                                                    const float *__restrict__ g, float grad[3]) {
+    const int w = L.I + 1, h = L.J + 1, d = L.K + 1;
     const double invdx = 1.0 / dx;
     const int gi = d_pos_index(px, invdx), gj = d_pos_index(py, invdx), gk = d_pos_index(pz, invdx);
     const float gx = (float)(gi * dx), gy = (float)(gj * dx), gz = (float)(gk * dx);
     const double ix = (px - gx) * invdx, iy = (py - gy) * invdx, iz = (pz - gz) * invdx;
     float v000 = 0, v100 = 0, v010 = 0, v001 = 0, v101 = 0, v011 = 0, v110 = 0, v111 = 0;
-    if (d_in_range(gi, gj, gk, w, h, d)) v000 = g[DIDX(gi, gj, gk, w, h)];
-    if (d_in_range(gi + 1, gj, gk, w, h, d)) v100 = g[DIDX(gi + 1, gj, gk, w, h)];
-    if (d_in_range(gi, gj + 1, gk, w, h, d)) v010 = g[DIDX(gi, gj + 1, gk, w, h)];
-    if (d_in_range(gi, gj, gk + 1, w, h, d)) v001 = g[DIDX(gi, gj, gk + 1, w, h)];
-    if (d_in_range(gi + 1, gj, gk + 1, w, h, d)) v101 = g[DIDX(gi + 1, gj, gk + 1, w, h)];
-    if (d_in_range(gi, gj + 1, gk + 1, w, h, d)) v011 = g[DIDX(gi, gj + 1, gk + 1, w, h)];
-    if (d_in_range(gi + 1, gj + 1, gk, w, h, d)) v110 = g[DIDX(gi + 1, gj + 1, gk, w, h)];
-    if (d_in_range(gi + 1, gj + 1, gk + 1, w, h, d)) v111 = g[DIDX(gi + 1, gj + 1, gk + 1, w, h)];
+    if (d_in_range(gi, gj, gk, w, h, d)) v000 = g[gidx(L, gi, gj, gk)];
+    if (d_in_range(gi + 1, gj, gk, w, h, d)) v100 = g[gidx(L, gi + 1, gj, gk)];
+    if (d_in_range(gi, gj + 1, gk, w, h, d)) v010 = g[gidx(L, gi, gj + 1, gk)];
+    if (d_in_range(gi, gj, gk + 1, w, h, d)) v001 = g[gidx(L, gi, gj, gk + 1)];
+    if (d_in_range(gi + 1, gj, gk + 1, w, h, d)) v101 = g[gidx(L, gi + 1, gj, gk + 1)];
+    if (d_in_range(gi, gj + 1, gk + 1, w, h, d)) v011 = g[gidx(L, gi, gj + 1, gk + 1)];
+    if (d_in_range(gi + 1, gj + 1, gk, w, h, d)) v110 = g[gidx(L, gi + 1, gj + 1, gk)];
+    if (d_in_range(gi + 1, gj + 1, gk + 1, w, h, d)) v111 = g[gidx(L, gi + 1, gj + 1, gk + 1)];
     const double val = (double)v000 * (1 - ix) * (1 - iy) * (1 - iz) + (double)v100 * ix * (1 - iy) * (1 - iz) +
                        (double)v010 * (1 - ix) * iy * (1 - iz) + (double)v001 * (1 - ix) * (1 - iy) * iz +
                        (double)v101 * ix * (1 - iy) * iz + (double)v011 * (1 - ix) * iy * iz +
@@ -202,27 +205,27 @@ struct ClampBox {  // AABB boundary(0,0,0,I*dx,J*dx,K*dx).expand(-2*dx-1e-4)  (f
 };
 
 // _advectFluidParticles (reference fluidsimulation.cpp:315-339)
-__global__ void k_advect_particles(float *__restrict__ aos6, size_t n, const float *__restrict__ U,
+__global__ void k_advect_particles(Lay L, float *__restrict__ aos6, size_t n, const float *__restrict__ U,
                                    const float *__restrict__ V, const float *__restrict__ W,
                                    const float *__restrict__ sU, const float *__restrict__ sV,
-                                   const float *__restrict__ sW, const float *__restrict__ solid, int I, int J, int K,
-                                   float dxf, float dt, float ratio, ClampBox box) {
+                                   const float *__restrict__ sW, const float *__restrict__ solid, float dxf, float dt,
+                                   float ratio, ClampBox box) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const double dx = (double)dxf;
     float q[6];
 #pragma unroll
     for (int c = 0; c < 6; c++) q[c] = aos6[6 * p + c];
-    d_update_velocity(q, dx, I, J, K, U, V, W, sU, sV, sW, ratio);
+    d_update_velocity(q, dx, L, U, V, W, sU, sV, sW, ratio);
     // _traceRK2 (fluidsimulation.cpp:535-541)
     float v[3];
-    d_mac_velocity(q[0], q[1], q[2], dx, I, J, K, U, V, W, v);
+    d_mac_velocity(q[0], q[1], q[2], dx, L, U, V, W, v);
     const float hs = 0.5f * dt;
-    d_mac_velocity(q[0] + hs * v[0], q[1] + hs * v[1], q[2] + hs * v[2], dx, I, J, K, U, V, W, v);
+    d_mac_velocity(q[0] + hs * v[0], q[1] + hs * v[1], q[2] + hs * v[2], dx, L, U, V, W, v);
     float x = q[0] + dt * v[0], y = q[1] + dt * v[1], z = q[2] + dt * v[2];
     // solid push-out (fluidsimulation.cpp:326-333)
     float g[3];
-    const float phi_val = d_solid_value_grad(x, y, z, dx, solid, I + 1, J + 1, K + 1, g);
+    const float phi_val = d_solid_value_grad(x, y, z, dx, L, solid, g);
     if (phi_val < 0.0f) {
         const float lsq = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
         if (lsq > 0.0f) {
@@ -247,18 +250,17 @@ __global__ void k_advect_particles(float *__restrict__ aos6, size_t n, const flo
 }
 
 // =================================================================== host launchers
-int fv_fill(flipv_context *c, float *p, size_t n, float v);
+int fv_fill_cells(flipv_context *c, float *p, float v);
 int fv_sdf_finish(flipv_context *c);
 int fv_p2g_finalize(flipv_context *c);
 
 int fv_particle_sdf(flipv_context *c) {
-    const Dims &d = c->d;
-    fv_fill(c, c->phi, d.nc(), 3.0f * (float)(double)c->dx);  // _getMaxDistance (particlelevelset.cpp:94-96)
+    fv_fill_cells(c, c->phi, 3.0f * (float)(double)c->dx);  // _getMaxDistance (particlelevelset.cpp:94-96)
     if (c->np) {
         // _particleRadius (fluidsimulation.cpp:36)
         const float radius = (float)(c->dx * 1.01 * sqrt(3.0) / 2.0);
-        hipLaunchKernelGGL(k_sdf_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->particles, c->np, c->phi,
-                           d.I, d.J, d.K, c->dx, radius);
+        hipLaunchKernelGGL(k_sdf_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
+                           c->phi, c->dx, radius);
     }
     fv_sdf_finish(c);
     HIPCHK(c, hipGetLastError());
@@ -266,32 +268,31 @@ int fv_particle_sdf(flipv_context *c) {
 }
 
 int fv_p2g(flipv_context *c) {
-    const Dims &d = c->d;
-    HIPCHK(c, hipMemsetAsync(c->accU, 0, d.nu() * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->accV, 0, d.nv() * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->accW, 0, d.nw() * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wgtU, 0, d.nu() * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wgtV, 0, d.nv() * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wgtW, 0, d.nw() * 4, c->stream));
+    const size_t bytes = c->L.n * 4;
+    HIPCHK(c, hipMemsetAsync(c->accU, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->accV, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->accW, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->wgtU, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->wgtV, 0, bytes, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->wgtW, 0, bytes, c->stream));
     if (c->np)
-        hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->particles, c->np, c->accU,
-                           c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, d.I, d.J, d.K, c->dx);
+        hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
+                           c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, c->dx);
     fv_p2g_finalize(c);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 
 int fv_update_particle_velocities(flipv_context *c) {
-    const Dims &d = c->d;
     if (c->np)
-        hipLaunchKernelGGL(k_update_velocities, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->particles, c->np,
-                           c->U, c->V, c->W, c->sU, c->sV, c->sW, d.I, d.J, d.K, c->dx, c->prm.pic_ratio);
+        hipLaunchKernelGGL(k_update_velocities, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
+                           c->U, c->V, c->W, c->sU, c->sV, c->sW, c->dx, c->prm.pic_ratio);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 
 int fv_advect_particles(flipv_context *c, float dt) {
-    const Dims &d = c->d;
+    const Lay &d = c->L;
     ClampBox b;
     const float dxf = c->dx;
     double bw = (double)(d.I * dxf), bh = (double)(d.J * dxf), bd = (double)(d.K * dxf);
@@ -299,8 +300,8 @@ int fv_advect_particles(flipv_context *c, float dt) {
     b.bx = b.by = b.bz = 0.0f - (float)eh;
     b.bw = bw + ev; b.bh = bh + ev; b.bd = bd + ev;
     if (c->np)
-        hipLaunchKernelGGL(k_advect_particles, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->particles, c->np,
-                           c->U, c->V, c->W, c->sU, c->sV, c->sW, c->solid, d.I, d.J, d.K, c->dx, dt, c->prm.pic_ratio, b);
+        hipLaunchKernelGGL(k_advect_particles, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
+                           c->U, c->V, c->W, c->sU, c->sV, c->sW, c->solid, c->dx, dt, c->prm.pic_ratio, b);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }

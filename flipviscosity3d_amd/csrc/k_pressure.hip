@@ -2,81 +2,75 @@
 //
 // Data layout: the reference compacts the pressure cells into a list + dense int key map
 // (pressuresolver.cpp:196-225) and stores 4 float coefficients per cell (pressuresolver.h:103-110).
-// Here the system lives on the dense (I,J,K) cell grid in Array3d order so a wave reads 64 consecutive
-// cells = one 256-byte line per stream: four coefficient arrays diag/plusi/plusj/plusk that are ZERO
-// outside the pressure cells (and towards non-pressure neighbours), so the 7-point SpMV needs no index map
-// and no masks.  Only tiles that contain pressure cells are swept (tile list, pcg_common.h).
+// Here the system lives on the dense cell lattice of the shared index space: four coefficient arrays
+// diag/plusi/plusj/plusk that are ZERO outside the pressure cells (and towards non-pressure neighbours), so the
+// 7-point SpMV needs no index map, no masks and no bounds checks (guard zones + zero coefficients).
+// Only tiles that contain pressure cells are swept (tile list, pcg_common.h).
 //
-// Algorithmic traffic of the SpMV: 4 coefficient reads + 1 read of s + 1 write of z = 24 B per swept cell
-// in fp32 (32 B with fp64 vectors); the three "minus" coefficients and the six neighbour values of s are
-// re-used from L1/L2.
+// Algorithmic traffic of the SpMV: 4 coefficient reads + s read, q written = 24 B per swept cell in fp32
+// (SURVEY.md 8d), plus 8 B for the fp64 residual that feeds the fused beta dot products.
 #include "flipv_internal.h"
 #include "pcg_common.h"
 
-#define GRID3(w, h, d) dim3(cdiv((w), 64), cdiv((h), 4), (unsigned)(d)), dim3(64, 4, 1)
-
-__device__ __forceinline__ bool d_is_pcell(const float *__restrict__ phi, int i, int j, int k, int I, int J, int K) {
+__device__ __forceinline__ bool d_is_pcell(const float *__restrict__ phi, const Lay &L, int i, int j, int k) {
     // interior cells with phi < 0 (pressuresolver.cpp:206-216)
-    return i >= 1 && j >= 1 && k >= 1 && i <= I - 2 && j <= J - 2 && k <= K - 2 && phi[DIDX(i, j, k, I, J)] < 0.0f;
+    return i >= 1 && j >= 1 && k >= 1 && i <= L.I - 2 && j <= L.J - 2 && k <= L.K - 2 && phi[gidx(L, i, j, k)] < 0.0f;
 }
 
 // K11: coefficients (pressuresolver.cpp:248-322) and right-hand side (pressuresolver.cpp:227-246)
 template <typename T>
-__global__ void k_pressure_setup(const float *__restrict__ phi, const float *__restrict__ U,
+__global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const float *__restrict__ U,
                                  const float *__restrict__ V, const float *__restrict__ W,
                                  const float *__restrict__ wU, const float *__restrict__ wV,
                                  const float *__restrict__ wW, float *__restrict__ diag, float *__restrict__ pi,
-                                 float *__restrict__ pj, float *__restrict__ pk, T *__restrict__ r, T *__restrict__ x,
-                                 T *__restrict__ s, double *__restrict__ bmax, int I, int J, int K, float dxf, float dtf,
-                                 float minfrac) {
+                                 float *__restrict__ pj, float *__restrict__ pk, double *__restrict__ r, T *__restrict__ x,
+                                 T *__restrict__ s, double *__restrict__ bmax, float dxf, float dtf, float minfrac) {
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     double babs = 0.0;
-    if (i < I && j < J) {
-        const size_t c = DIDX(i, j, k, I, J);
+    if (i < L.PX && j < L.PY) {
+        const size_t c = gidx(L, i, j, k);
         float dg = 0.0f, ci = 0.0f, cj = 0.0f, ck = 0.0f;
         double b = 0.0;
-        if (d_is_pcell(phi, i, j, k, I, J, K)) {
+        if (i < L.I && j < L.J && k < L.K && d_is_pcell(phi, L, i, j, k)) {
             const double dx = (double)dxf, dt = (double)dtf;
             const float scale = (float)(dt / (dx * dx));
+            const long sy = L.sy, sz = L.sz;
             const float pc = phi[c];
-            const size_t uR = DIDX(i + 1, j, k, I + 1, J), uL = DIDX(i, j, k, I + 1, J);
-            const size_t vT = DIDX(i, j + 1, k, I, J + 1), vB = DIDX(i, j, k, I, J + 1);
-            const size_t wF = DIDX(i, j, k + 1, I, J), wN = DIDX(i, j, k, I, J);
             float term, pn;
             // right
-            term = wU[uR] * scale; pn = phi[DIDX(i + 1, j, k, I, J)];
-            if (pn < 0) { dg += term; if (i + 1 <= I - 2) ci = -term; }
+            term = wU[c + 1] * scale; pn = phi[c + 1];
+            if (pn < 0) { dg += term; if (i + 1 <= L.I - 2) ci = -term; }
             else dg += term / fmaxf(d_frac2(pc, pn), minfrac);
             // left
-            term = wU[uL] * scale; pn = phi[DIDX(i - 1, j, k, I, J)];
+            term = wU[c] * scale; pn = phi[c - 1];
             if (pn < 0) dg += term; else dg += term / fmaxf(d_frac2(pn, pc), minfrac);
             // top
-            term = wV[vT] * scale; pn = phi[DIDX(i, j + 1, k, I, J)];
-            if (pn < 0) { dg += term; if (j + 1 <= J - 2) cj = -term; }
+            term = wV[c + sy] * scale; pn = phi[c + sy];
+            if (pn < 0) { dg += term; if (j + 1 <= L.J - 2) cj = -term; }
             else dg += term / fmaxf(d_frac2(pc, pn), minfrac);
             // bottom
-            term = wV[vB] * scale; pn = phi[DIDX(i, j - 1, k, I, J)];
+            term = wV[c] * scale; pn = phi[c - sy];
             if (pn < 0) dg += term; else dg += term / fmaxf(d_frac2(pn, pc), minfrac);
             // far
-            term = wW[wF] * scale; pn = phi[DIDX(i, j, k + 1, I, J)];
-            if (pn < 0) { dg += term; if (k + 1 <= K - 2) ck = -term; }
+            term = wW[c + sz] * scale; pn = phi[c + sz];
+            if (pn < 0) { dg += term; if (k + 1 <= L.K - 2) ck = -term; }
             else dg += term / fmaxf(d_frac2(pc, pn), minfrac);
             // near
-            term = wW[wN] * scale; pn = phi[DIDX(i, j, k - 1, I, J)];
+            term = wW[c] * scale; pn = phi[c - sz];
             if (pn < 0) dg += term; else dg += term / fmaxf(d_frac2(pn, pc), minfrac);
             // negative divergence: float products accumulated in fp64 (pressuresolver.cpp:236-243)
-            b -= (double)(wU[uR] * U[uR]);
-            b += (double)(wU[uL] * U[uL]);
-            b -= (double)(wV[vT] * V[vT]);
-            b += (double)(wV[vB] * V[vB]);
-            b -= (double)(wW[wF] * W[wF]);
-            b += (double)(wW[wN] * W[wN]);
+            b -= (double)(wU[c + 1] * U[c + 1]);
+            b += (double)(wU[c] * U[c]);
+            b -= (double)(wV[c + sy] * V[c + sy]);
+            b += (double)(wV[c] * V[c]);
+            b -= (double)(wW[c + sz] * W[c + sz]);
+            b += (double)(wW[c] * W[c]);
             b /= dx;
             if (dg == 0.0f) b = 0.0;  // a cell with no open face has an all-zero row; keep it out of the system
         }
         diag[c] = dg; pi[c] = ci; pj[c] = cj; pk[c] = ck;
-        r[c] = (T)b;
+        r[c] = b;
         x[c] = (T)0;
         s[c] = (T)0;
         babs = fabs(b);
@@ -85,47 +79,63 @@ __global__ void k_pressure_setup(const float *__restrict__ phi, const float *__r
     if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) atomic_max_nonneg(bmax, bm);
 }
 
-// K12: z = A s with fused s.z  (pressuresolver.cpp:464-499; same term order -i,+i,-j,+j,-k,+k, diagonal)
+// K12: q = A s with the three fused dot products (pressuresolver.cpp:464-499; term order -i,+i,-j,+j,-k,+k, diagonal).
+// No branches on cell type: all coefficients of a non-pressure cell (and of every padding / guard entry) are zero.
 template <typename T>
-__global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg,
+__global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                        const float *__restrict__ diag, const float *__restrict__ pi,
                                                        const float *__restrict__ pj, const float *__restrict__ pk,
-                                                       const T *__restrict__ s, T *__restrict__ z, int I, int J, int K,
-                                                       double *__restrict__ dA, const int *__restrict__ conv) {
-    if (conv && *conv >= 0) return;
-    __shared__ double lds[4];
-    const int slot = d_tile_slot(blockIdx.x, ntiles);
-    double acc = 0.0;
-    if (slot < ntiles) {
-        int i, j, k0;
-        d_tile_coords(tiles[slot], tg, i, j, k0);
-        if (i < I && j < J) {
-            const size_t sy = (size_t)I, sz = (size_t)I * J;
-            const int kend = min(k0 + TZ, K);
-            for (int k = k0; k < kend; k++) {
-                const size_t c = DIDX(i, j, k, I, J);
-                const float dg = diag[c];
-                T y = (T)0;
-                if (dg != 0.0f) {  // unknowns are interior cells: all six neighbours exist
-                    const T sc = s[c];
-                    y = s[c - 1] * (T)pi[c - 1];
-                    y += s[c + 1] * (T)pi[c];
-                    y += s[c - sy] * (T)pj[c - sy];
-                    y += s[c + sy] * (T)pj[c];
-                    y += s[c - sz] * (T)pk[c - sz];
-                    y += s[c + sz] * (T)pk[c];
-                    y += sc * (T)dg;
-                    acc += (double)sc * (double)y;
-                }
-                z[c] = y;
+                                                       const T *__restrict__ s, const double *__restrict__ r,
+                                                       T *__restrict__ q, PcgScal sc, int it) {
+    __shared__ double lds[12];
+    if (d_spmv_stop(sc, it, lds)) return;
+    int i0, j, k;
+    double da = 0.0, db = 0.0, dc = 0.0;
+    const int nvb = ((ntiles + 7) >> 3) << 3;
+    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
+        if (!(d_tile_coords<VW_P>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
+        const size_t c = gidx(L, i0, j, k);
+        const long sy = L.sy, sz = L.sz;
+        const Vec<float, 4> dg = ldv<4>(diag + c), ci = ldv<4>(pi + c), cj = ldv<4>(pj + c), ck = ldv<4>(pk + c);
+        const Vec<float, 4> cjm = ldv<4>(pj + c - sy), ckm = ldv<4>(pk + c - sz);
+        const Vec<T, 4> sc4 = ldv<4>(s + c), sjm = ldv<4>(s + c - sy), sjp = ldv<4>(s + c + sy), skm = ldv<4>(s + c - sz), skp = ldv<4>(s + c + sz);
+        const Vec<double, 4> r4 = ldv<4>(r + c);
+        const T sl = nb_left(sc4, s + c, i0), sr = nb_right(sc4, s + c, i0, L.I);
+        const float cil = nb_left(ci, pi + c, i0);
+        Vec<T, 4> y;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const T sm = e > 0 ? sc4.v[e - 1] : sl;
+            const T sp = e < 3 ? sc4.v[e + 1] : sr;
+            const float cim = e > 0 ? ci.v[e - 1] : cil;
+            T acc = sm * (T)cim;
+            acc += sp * (T)ci.v[e];
+            acc += sjm.v[e] * (T)cjm.v[e];
+            acc += sjp.v[e] * (T)cj.v[e];
+            acc += skm.v[e] * (T)ckm.v[e];
+            acc += skp.v[e] * (T)ck.v[e];
+            acc += sc4.v[e] * (T)dg.v[e];
+            y.v[e] = acc;
+            if (dg.v[e] != 0.0f) {
+                const double yd = (double)acc, inv = 1.0 / (double)dg.v[e];
+                da += (double)sc4.v[e] * yd;
+                db += r4.v[e] * inv * yd;
+                dc += yd * inv * yd;
             }
         }
+        stv(q + c, y);
     }
-    const double tot = block_sum_256(acc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0 && dA) atomicAdd(dA, tot);
+    block_sum3_256(da, db, dc, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.a) {
+        const size_t so = (size_t)it * NSLOT + (blockIdx.x & (NSLOT - 1));
+        if (da != 0.0) atomicAdd(&sc.a[so], da);
+        if (db != 0.0) atomicAdd(&sc.b[so], db);
+        if (dc != 0.0) atomicAdd(&sc.c[so], dc);
+    }
 }
 
-__global__ void k_f64_to_f32(const double *__restrict__ a, float *__restrict__ o, size_t n) {
+template <typename T>
+static __global__ void k_copy_to_f32(const T *__restrict__ a, float *__restrict__ o, size_t n) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; t < n; t += stride) o[t] = (float)a[t];
@@ -133,18 +143,18 @@ __global__ void k_f64_to_f32(const double *__restrict__ a, float *__restrict__ o
 
 // ---- tile activity ----
 // flag[t] = 1 if tile t holds at least one unknown (diag != 0) of any component
-__global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, PcgComps cp, int *__restrict__ flag) {
+__global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, int nc, const float *__restrict__ d0,
+                                                    const float *__restrict__ d1, const float *__restrict__ d2,
+                                                    int *__restrict__ flag) {
     const int tile = blockIdx.x;
-    int i, j, k0;
-    d_tile_coords(tile, tg, i, j, k0);
+    const int tx = tile % tg.ntx, t2 = tile / tg.ntx, ty = t2 % tg.nty, k = t2 / tg.nty;
+    const int i0 = tx * 64 * vw + threadIdx.x * vw, j = ty * TY + threadIdx.y;
     int any = 0;
-    for (int c = 0; c < cp.n; c++) {
-        if (i >= cp.w[c] || j >= cp.h[c]) continue;
-        for (int kk = 0; kk < TZ; kk++) {
-            const int k = k0 + kk;
-            if (k >= cp.d[c]) break;
-            any |= cp.diag[c][DIDX(i, j, k, cp.w[c], cp.h[c])] != 0.0f;
-        }
+    if (i0 < L.PX && j < L.PY) {
+        const size_t c = gidx(L, i0, j, k);
+        const float *dd[3] = {d0, d1, d2};
+        for (int m = 0; m < nc; m++)
+            for (int e = 0; e < vw; e++) any |= dd[m][c + e] != 0.0f;
     }
     const int r = __syncthreads_or(any);
     if (threadIdx.x == 0 && threadIdx.y == 0) flag[tile] = r;
@@ -179,19 +189,32 @@ __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ f
 
 // ------------------------------------------------------------------------------------------------
 int fv_scal_reserve(flipv_context *c, int cap) {
-    const size_t need = (size_t)3 * (cap + 2) + 16;
+    const size_t need = (size_t)5 * (cap + 2) * NSLOT + 16;
     if (c->d_scal && c->h_scal && c->scalCap >= need) return FLIPV_OK;
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
+    c->d_scal = nullptr; c->h_scal = nullptr; c->scalCap = 0;
     HIPCHK(c, hipMalloc((void **)&c->d_scal, need * sizeof(double)));
     HIPCHK(c, hipHostMalloc((void **)&c->h_scal, need * sizeof(double)));
     c->scalCap = need;
     return FLIPV_OK;
 }
 
-int fv_build_tiles(flipv_context *c, const PcgComps &cp, int *list, int *nActive) {
-    const int nt = c->tg.count();
-    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, c->tg, cp, c->tileFlag);
+void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
+    const size_t n = ((size_t)cap + 2) * NSLOT;
+    sc->sig = c->d_scal;
+    sc->a = c->d_scal + n;
+    sc->b = c->d_scal + 2 * n;
+    sc->c = c->d_scal + 3 * n;
+    sc->rmax = c->d_scal + 4 * n;
+    sc->conv = c->d_flags;
+    *extra = c->d_scal + 5 * n;
+}
+
+int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
+                   int *list, int *nActive) {
+    const int nt = tg.count();
+    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, c->tileFlag);
     hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -200,86 +223,78 @@ int fv_build_tiles(flipv_context *c, const PcgComps &cp, int *list, int *nActive
 }
 
 template <typename T>
-static void launch_pressure_spmv(flipv_context *c, double *dA, const int *conv) {
-    const Dims &d = c->d;
-    const int nb = ((c->nActiveP + 7) / 8) * 8;
-    if (c->prm.kernel_timing) fv_ev_begin(c, 0, (double)c->nActiveP * TX * TY * TZ);
-    hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tg,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (T *)c->pZ, d.I, d.J, d.K, dA, conv);
+static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it) {
+    const int nb = pcg_grid(c->nActiveP);
+    if (c->prm.kernel_timing) fv_ev_begin(c, 0, (double)c->nActiveP * (64 * VW_P * TY));
+    hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L,
+                       c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const double *)c->pR, (T *)c->pZ, sc, it);
     if (c->prm.kernel_timing) fv_ev_end(c);
 }
 
 template <typename T>
 static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) {
-    const Dims &d = c->d;
+    const Lay &L = c->L;
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
-    li.total_tiles = c->tg.count();
+    li.total_tiles = c->tgP.count();
     const int cap = c->prm.pressure_max_iterations;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
-    const size_t nscal = (size_t)3 * (cap + 2) + 16;
+    const size_t nscal = (size_t)5 * (cap + 2) * NSLOT + 16;
     HIPCHK(c, hipMemsetAsync(c->d_scal, 0, nscal * sizeof(double), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, 4 * sizeof(int), c->stream));  // conv = -1
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));  // conv = -1
     PcgScal sc;
-    sc.sigma = c->d_scal;
-    sc.dA = c->d_scal + (cap + 2);
-    sc.rmax = c->d_scal + 2 * (cap + 2);
-    double *bmax = c->d_scal + 3 * (cap + 2);
-    sc.conv = c->d_flags;
+    double *bmax;
+    fv_scal_views(c, cap, &sc, &bmax);
     sc.tol_inclusive = 0;
+    sc.tol = 0.0;
 
     // with fp32 vectors x IS the pressure grid
-    T *x = std::is_same<T, float>::value ? (T *)c->pressure : (T *)c->pX;
-    hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(d.I, d.J, d.K), 0, c->stream, c->phi, c->U, c->V, c->W, c->wU, c->wV,
-                       c->wW, c->pDiag, c->pPi, c->pPj, c->pPk, (T *)c->pR, x, (T *)c->pS, bmax, d.I, d.J, d.K, c->dx, dt,
-                       c->prm.min_frac);
+    constexpr bool f32 = std::is_same<T, float>::value;
+    T *x = f32 ? (T *)c->pressure : (T *)c->pX;
+    hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(L), 0, c->stream, L, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
+                       c->pDiag, c->pPi, c->pPj, c->pPk, (double *)c->pR, x, (T *)c->pS, bmax, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PcgComps cp;
-    memset(&cp, 0, sizeof(cp));
-    cp.n = 1; cp.w[0] = d.I; cp.h[0] = d.J; cp.d[0] = d.K; cp.diag[0] = c->pDiag;
-    rc = fv_build_tiles(c, cp, c->tileListP, &c->nActiveP);  // synchronises: h_scal[0] = max|b|
+    rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->tileListP, &c->nActiveP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
     const double bnorm = c->h_scal[0];
     li.rhs_norm = bnorm;
     li.active_tiles = c->nActiveP;
     c->pressureReady = 1;
-    c->pressurePrec = std::is_same<T, float>::value ? 0 : 1;
+    c->pressurePrec = f32 ? 0 : 1;
     c->lastDt = dt;
     // early out (pressuresolver.cpp:173-175): pressure grid is zero
     if (!(bnorm >= c->prm.pressure_tolerance) || c->nActiveP == 0) {
         li.status = 3;
         li.residual = bnorm;
-        if (!std::is_same<T, float>::value)
-            hipLaunchKernelGGL(k_f64_to_f32, dim3(2048), dim3(256), 0, c->stream, (const double *)x, c->pressure, d.nc());
+        if (!f32) hipLaunchKernelGGL(k_copy_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)x, c->pressure, L.n);
         if (info) *info = li;
         return FLIPV_OK;
     }
     sc.tol = fmax(c->prm.pressure_tolerance, c->prm.pressure_rel_tolerance * bnorm);
 
-    PcgVecs<T> v;
-    memset(&v, 0, sizeof(v));
-    v.x[0] = x; v.r[0] = (T *)c->pR; v.z[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
-    const int nb = ((c->nActiveP + 7) / 8) * 8;
+    PcgSys<T, 1> v;
+    v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (double *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
+    const int nb = pcg_grid(c->nActiveP);
     const dim3 blk(64, 4, 1);
-    hipLaunchKernelGGL(k_pcg_init<T>, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tg, cp, v, sc);
+    hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
     int it = 0, conv = -1;
     while (it < cap && conv < 0) {
         const int stop = (it + every < cap) ? it + every : cap;
         for (; it < stop; it++) {
-            launch_pressure_spmv<T>(c, sc.dA + it, sc.conv);
-            hipLaunchKernelGGL(k_pcg_update<T>, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tg, cp, v, sc, it);
-            hipLaunchKernelGGL(k_pcg_dir<T>, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tg, cp, v, sc, it);
+            launch_pressure_spmv<T>(c, sc, it);
+            hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
         }
+        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         conv = c->h_flags[0];
     }
     const int last = conv >= 0 ? conv : cap - 1;
-    HIPCHK(c, hipMemcpyAsync(c->h_scal, sc.rmax + last, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    if (!std::is_same<T, float>::value)
-        hipLaunchKernelGGL(k_f64_to_f32, dim3(2048), dim3(256), 0, c->stream, (const double *)x, c->pressure, d.nc());
+    hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
+    HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (!f32) hipLaunchKernelGGL(k_copy_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)x, c->pressure, L.n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     li.iterations = conv >= 0 ? conv + 1 : cap;
     li.residual = c->h_scal[0];
@@ -301,12 +316,14 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
     HIPCHK(c, hipEventCreate(&b));
     const int saved = c->prm.kernel_timing;
     c->prm.kernel_timing = 0;
+    PcgScal sc;
+    memset(&sc, 0, sizeof(sc));  // no scalars, no stop flag: pure kernel launches
     for (int w = 0; w < 3; w++) {
-        if (c->pressurePrec) launch_pressure_spmv<double>(c, nullptr, nullptr); else launch_pressure_spmv<float>(c, nullptr, nullptr);
+        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0); else launch_pressure_spmv<float>(c, sc, 0);
     }
     HIPCHK(c, hipEventRecord(a, c->stream));
     for (int r = 0; r < reps; r++) {
-        if (c->pressurePrec) launch_pressure_spmv<double>(c, nullptr, nullptr); else launch_pressure_spmv<float>(c, nullptr, nullptr);
+        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0); else launch_pressure_spmv<float>(c, sc, 0);
     }
     HIPCHK(c, hipEventRecord(b, c->stream));
     HIPCHK(c, hipEventSynchronize(b));
@@ -316,6 +333,6 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *ms = (double)t / reps;
-    *cells = (double)c->nActiveP * TX * TY * TZ;
+    *cells = (double)c->nActiveP * (64 * VW_P * TY);
     return FLIPV_OK;
 }

@@ -6,60 +6,60 @@
 // MIC(0)-PCG on it.  Here the operator is never assembled: every coefficient of a row is one of six
 // "factors" f = dt/dx^2 * nu * volume that live on four lattices (cell centres and the three edge
 // families), so the coupled 15-point SpMV over the U, V and W rows of one index (i,j,k) reads
-//   3 diagonals + 4 factor arrays + 3 x  and writes 3 y  = 52 B per swept index in fp32,
-// against ~540 B for the assembled form.  Unknown faces are exactly the faces with a
-// non-zero diagonal; x is kept 0 everywhere else, which reproduces the reference's silent drop of
-// couplings to faces without a matrix row (sparsematrix.h:86-88).
+//   3 own volumes + 4 factor arrays + 3 x (+ 3 fp64 r for the fused beta dots) and writes 3 q
+//   = 52 B (+24 B) per swept index in fp32, against ~540 B for the assembled form.
+// Unknown faces are exactly the faces with a non-zero diagonal; x is kept 0 everywhere else, which reproduces
+// the reference's silent drop of couplings to faces without a matrix row (sparsematrix.h:86-88).
 #include "flipv_internal.h"
 #include "pcg_common.h"
-
-#define GRID3(w, h, d) dim3(cdiv((w), 64), cdiv((h), 4), (unsigned)(d)), dim3(64, 4, 1)
 
 enum { ST_FLUID = 1, ST_SOLID = 2 };
 
 // ------------------------------------------------------------------ face states
 // viscositysolver.cpp:80-133
-__global__ void k_solid_center(const float *__restrict__ solid, float *__restrict__ scp, int I, int J, int K) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= I || j >= J) return;
-    scp[DIDX(i, j, k, I, J)] = d_solid_center(solid, i, j, k, I, J);
+__global__ void k_solid_center(Lay L, const float *__restrict__ solid, float *__restrict__ scp) {
+    IJK_OR_RETURN(L);
+    if (i < L.I && j < L.J && k < L.K) scp[c] = d_solid_center(solid, L, c);
 }
 
-__global__ void k_face_states(int dir, const float *__restrict__ scp, uint8_t *__restrict__ st, int I, int J, int K) {
-    const int w = I + (dir == 0), h = J + (dir == 1);
-    const int n = dir == 0 ? I : (dir == 1 ? J : K);
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= w || j >= h) return;
-    const int cd = dir == 0 ? i : (dir == 1 ? j : k);
-    bool solid = cd == 0 || cd == n;
-    if (!solid) {
-        const float a = scp[DIDX(i - (dir == 0), j - (dir == 1), k - (dir == 2), I, J)];
-        const float b = scp[DIDX(i, j, k, I, J)];
-        solid = a + b <= 0.0f;
+__global__ void k_face_states(Lay L, const float *__restrict__ scp, uint8_t *__restrict__ stU,
+                              uint8_t *__restrict__ stV, uint8_t *__restrict__ stW) {
+    IJK_OR_RETURN(L);
+    uint8_t *st[3] = {stU, stV, stW};
+    const long back[3] = {1, L.sy, L.sz};
+#pragma unroll
+    for (int dir = 0; dir < 3; dir++) {
+        int w, h, d;
+        lat_dims(L, LAT_U + dir, w, h, d);
+        if (i >= w || j >= h || k >= d) continue;
+        const int n = dir == 0 ? L.I : (dir == 1 ? L.J : L.K);
+        const int cd = dir == 0 ? i : (dir == 1 ? j : k);
+        bool solid = cd == 0 || cd == n;
+        if (!solid) solid = scp[c - back[dir]] + scp[c] <= 0.0f;
+        st[dir][c] = solid ? ST_SOLID : ST_FLUID;
     }
-    st[DIDX(i, j, k, w, h)] = solid ? ST_SOLID : ST_FLUID;
 }
 
 // ------------------------------------------------------------------ band mask
 // viscositysolver.cpp:138-168: phi<0 cells on an (I+1,J+1,K+1) mask, then two 6-neighbour dilations
-__global__ void k_valid_init(const float *__restrict__ phi, uint8_t *__restrict__ m, int I, int J, int K) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i > I || j > J) return;
+__global__ void k_valid_init(Lay L, const float *__restrict__ phi, uint8_t *__restrict__ m) {
+    IJK_OR_RETURN(L);
     uint8_t v = 0;
-    if (i < I && j < J && k < K) v = phi[DIDX(i, j, k, I, J)] < 0.0f;
-    m[DIDX(i, j, k, I + 1, J + 1)] = v;
+    if (i < L.I && j < L.J && k < L.K) v = phi[c] < 0.0f;
+    m[c] = v;
 }
-__global__ void k_valid_dilate(const uint8_t *__restrict__ a, uint8_t *__restrict__ b, int w, int h, int d) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= w || j >= h) return;
-    const size_t c = DIDX(i, j, k, w, h);
-    uint8_t v = a[c];
-    if (i > 0) v |= a[c - 1];
-    if (i < w - 1) v |= a[c + 1];
-    if (j > 0) v |= a[c - w];
-    if (j < h - 1) v |= a[c + w];
-    if (k > 0) v |= a[c - (size_t)w * h];
-    if (k < d - 1) v |= a[c + (size_t)w * h];
+__global__ void k_valid_dilate(Lay L, const uint8_t *__restrict__ a, uint8_t *__restrict__ b) {
+    IJK_OR_RETURN(L);
+    uint8_t v = 0;
+    if (i <= L.I && j <= L.J && k <= L.K) {
+        v = a[c];
+        if (i > 0) v |= a[c - 1];
+        if (i < L.I) v |= a[c + 1];
+        if (j > 0) v |= a[c - L.sy];
+        if (j < L.J) v |= a[c + L.sy];
+        if (k > 0) v |= a[c - L.sz];
+        if (k < L.K) v |= a[c + L.sz];
+    }
     b[c] = v;
 }
 
@@ -67,23 +67,21 @@ __global__ void k_valid_dilate(const uint8_t *__restrict__ a, uint8_t *__restric
 // liquid phi sampled like ParticleLevelSet::trilinearInterpolate (particlelevelset.cpp:88-92 ->
 // interpolation.cpp:68-108): float position, fp64 weights, out-of-range corners = 0
 __device__ __forceinline__ float d_liquid_phi_at(float px, float py, float pz, double dx, double invdx, float hdx,
-                                                 const float *__restrict__ phi, int I, int J, int K) {
+                                                 const float *__restrict__ phi, const Lay &L) {
     px -= hdx; py -= hdx; pz -= hdx;
     const int gi = (int)floor((double)px * invdx), gj = (int)floor((double)py * invdx), gk = (int)floor((double)pz * invdx);
     const float gx = (float)(gi * dx), gy = (float)(gj * dx), gz = (float)(gk * dx);
     const double ix = (px - gx) * invdx, iy = (py - gy) * invdx, iz = (pz - gz) * invdx;
-    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
-    if (d_in_range(gi, gj, gk, I, J, K)) p0 = phi[DIDX(gi, gj, gk, I, J)];
-    if (d_in_range(gi + 1, gj, gk, I, J, K)) p1 = phi[DIDX(gi + 1, gj, gk, I, J)];
-    if (d_in_range(gi, gj + 1, gk, I, J, K)) p2 = phi[DIDX(gi, gj + 1, gk, I, J)];
-    if (d_in_range(gi, gj, gk + 1, I, J, K)) p3 = phi[DIDX(gi, gj, gk + 1, I, J)];
-    if (d_in_range(gi + 1, gj, gk + 1, I, J, K)) p4 = phi[DIDX(gi + 1, gj, gk + 1, I, J)];
-    if (d_in_range(gi, gj + 1, gk + 1, I, J, K)) p5 = phi[DIDX(gi, gj + 1, gk + 1, I, J)];
-    if (d_in_range(gi + 1, gj + 1, gk, I, J, K)) p6 = phi[DIDX(gi + 1, gj + 1, gk, I, J)];
-    if (d_in_range(gi + 1, gj + 1, gk + 1, I, J, K)) p7 = phi[DIDX(gi + 1, gj + 1, gk + 1, I, J)];
-    return (float)(p0 * (1 - ix) * (1 - iy) * (1 - iz) + p1 * ix * (1 - iy) * (1 - iz) + p2 * (1 - ix) * iy * (1 - iz) +
-                   p3 * (1 - ix) * (1 - iy) * iz + p4 * ix * (1 - iy) * iz + p5 * (1 - ix) * iy * iz +
-                   p6 * ix * iy * (1 - iz) + p7 * ix * iy * iz);
+    double p[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {  // corner order of interpolation.cpp:54-66: 000,100,010,001,101,011,110,111
+        const int oi = (q == 1 || q == 4 || q == 6 || q == 7), oj = (q == 2 || q == 5 || q == 6 || q == 7),
+                  ok = (q == 3 || q == 4 || q == 5 || q == 7);
+        p[q] = d_in_range(gi + oi, gj + oj, gk + ok, L.I, L.J, L.K) ? (double)phi[gidx(L, gi + oi, gj + oj, gk + ok)] : 0.0;
+    }
+    return (float)(p[0] * (1 - ix) * (1 - iy) * (1 - iz) + p[1] * ix * (1 - iy) * (1 - iz) + p[2] * (1 - ix) * iy * (1 - iz) +
+                   p[3] * (1 - ix) * (1 - iy) * iz + p[4] * ix * (1 - iy) * iz + p[5] * (1 - ix) * iy * iz +
+                   p[6] * ix * iy * (1 - iz) + p[7] * ix * iy * iz);
 }
 
 __device__ __forceinline__ float d_tet(float a, float b, float c, float d) { return a * a * a / ((a - b) * (a - c) * (a - d)); }
@@ -112,221 +110,182 @@ __device__ __forceinline__ float d_cube_fraction(float p000, float p100, float p
            12.0f;
 }
 
-// _estimateVolumeFractions (viscositysolver.cpp:180-270) for one lattice of dims (w,h,d) whose sample
-// centre is centerStart + cellCentre(i,j,k)
-__global__ void k_volume_lattice(const float *__restrict__ phi, const uint8_t *__restrict__ valid,
-                                 float *__restrict__ vol, int w, int h, int d, float csx, float csy, float csz, int I,
-                                 int J, int K, float dxf) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= w || j >= h) return;
+// _estimateVolumeFractions (viscositysolver.cpp:180-270) for lattice `lat` whose sample centre is
+// centerStart + cellCentre(i,j,k)
+__global__ void k_volume_lattice(Lay L, int lat, const float *__restrict__ phi, const uint8_t *__restrict__ valid,
+                                 float *__restrict__ vol, float csx, float csy, float csz, float dxf) {
+    IJK_OR_RETURN(L);
+    int w, h, d;
+    lat_dims(L, lat, w, h, d);
+    if (i >= w || j >= h || k >= d) return;
     float out = 0.0f;
-    if (valid[DIDX(i, j, k, I + 1, J + 1)]) {
+    if (valid[c]) {
         const double dx = (double)dxf, invdx = 1.0 / dx, hw = 0.5 * dx;
         const float hdx = 0.5f * dxf;          // viscositysolver.cpp:188
         const float hoff = (float)(0.5 * dx);  // particlelevelset.cpp:89
         const float cx = csx + (float)(i * dx + hw), cy = csy + (float)(j * dx + hw), cz = csz + (float)(k * dx + hw);
         float p[8];
+        int neg = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) {  // q = 4*oi + 2*oj + ok
             const float sx = cx + ((q & 4) ? hdx : -hdx), sy = cy + ((q & 2) ? hdx : -hdx), sz = cz + ((q & 1) ? hdx : -hdx);
-            p[q] = d_liquid_phi_at(sx, sy, sz, dx, invdx, hoff, phi, I, J, K);
+            p[q] = d_liquid_phi_at(sx, sy, sz, dx, invdx, hoff, phi, L);
+            neg += p[q] < 0.0f;
         }
-        const float p000 = p[0], p001 = p[1], p010 = p[2], p011 = p[3], p100 = p[4], p101 = p[5], p110 = p[6], p111 = p[7];
-        int neg = 0;
-#pragma unroll
-        for (int q = 0; q < 8; q++) neg += p[q] < 0.0f;
         if (neg == 8) out = 1.0f;
         else if (neg == 0) out = 0.0f;
-        else out = d_cube_fraction(p000, p100, p010, p110, p001, p101, p011, p111);
+        else out = d_cube_fraction(p[0], p[4], p[2], p[6], p[1], p[5], p[3], p[7]);  // 000,100,010,110,001,101,011,111
     }
-    vol[DIDX(i, j, k, w, h)] = out;
+    vol[c] = out;
 }
 
 // ------------------------------------------------------------------ factors
 // f = dt/dx^2 * nu * volume on the four coefficient lattices (viscositysolver.cpp:394-427 and the V/W
 // analogues :492-525, :590-623).  nu is node-sampled; the edge lattices use the 4-node mean.
-#define NU(i, j, k) visc[DIDX(i, j, k, I + 1, J + 1)]
-__global__ void k_visc_factors(const float *__restrict__ visc, const float *__restrict__ volC,
+__global__ void k_visc_factors(Lay L, const float *__restrict__ nu, const float *__restrict__ volC,
                                const float *__restrict__ volEU, const float *__restrict__ volEV,
                                const float *__restrict__ volEW, float *__restrict__ fC, float *__restrict__ fEU,
-                               float *__restrict__ fEV, float *__restrict__ fEW, int I, int J, int K, float factor) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i > I || j > J) return;
-    if (i < I && j < J && k < K) {
-        const size_t c = DIDX(i, j, k, I, J);
-        fC[c] = 2 * factor * NU(i, j, k) * volC[c];
-    }
-    if (i < I && k <= K) {  // edgeU (I,J+1,K+1): nodes (i,j-1..j,k-1..k)
+                               float *__restrict__ fEV, float *__restrict__ fEW, float factor) {
+    IJK_OR_RETURN(L);
+    const long sy = L.sy, sz = L.sz;
+    const int I = L.I, J = L.J, K = L.K;
+    if (i > I || j > J || k > K) return;
+    if (i < I && j < J && k < K) fC[c] = 2 * factor * nu[c] * volC[c];
+    if (i < I) {  // edgeU (I,J+1,K+1): nodes (i, j-1..j, k-1..k)
         float f = 0.0f;
-        if (j >= 1 && k >= 1)
-            f = factor * (0.25f * (NU(i, j - 1, k) + NU(i, j - 1, k - 1) + NU(i, j, k) + NU(i, j, k - 1))) *
-                volEU[DIDX(i, j, k, I, J + 1)];
-        fEU[DIDX(i, j, k, I, J + 1)] = f;
+        if (j >= 1 && k >= 1) f = factor * (0.25f * (nu[c - sy] + nu[c - sy - sz] + nu[c] + nu[c - sz])) * volEU[c];
+        fEU[c] = f;
     }
-    if (j < J && k <= K) {  // edgeV (I+1,J,K+1): nodes (i-1..i,j,k-1..k)
+    if (j < J) {  // edgeV (I+1,J,K+1): nodes (i-1..i, j, k-1..k)
         float f = 0.0f;
-        if (i >= 1 && k >= 1)
-            f = factor * (0.25f * (NU(i - 1, j, k) + NU(i - 1, j, k - 1) + NU(i, j, k) + NU(i, j, k - 1))) *
-                volEV[DIDX(i, j, k, I + 1, J)];
-        fEV[DIDX(i, j, k, I + 1, J)] = f;
+        if (i >= 1 && k >= 1) f = factor * (0.25f * (nu[c - 1] + nu[c - 1 - sz] + nu[c] + nu[c - sz])) * volEV[c];
+        fEV[c] = f;
     }
-    if (k < K) {  // edgeW (I+1,J+1,K): nodes (i-1..i,j-1..j,k)
+    if (k < K) {  // edgeW (I+1,J+1,K): nodes (i-1..i, j-1..j, k)
         float f = 0.0f;
-        if (i >= 1 && j >= 1)
-            f = factor * (0.25f * (NU(i - 1, j, k) + NU(i - 1, j - 1, k) + NU(i, j, k) + NU(i, j - 1, k))) *
-                volEW[DIDX(i, j, k, I + 1, J + 1)];
-        fEW[DIDX(i, j, k, I + 1, J + 1)] = f;
+        if (i >= 1 && j >= 1) f = factor * (0.25f * (nu[c - 1] + nu[c - 1 - sy] + nu[c] + nu[c - sy])) * volEW[c];
+        fEW[c] = f;
     }
 }
 
-// ------------------------------------------------------------------ the coupled stencil
-// Coefficients of the rows at index (i,j,k).  FC/FEU/FEV/FEW index the factor lattices.
-#define FC(i, j, k) fC[DIDX(i, j, k, I, J)]
-#define FEU(i, j, k) fEU[DIDX(i, j, k, I, J + 1)]
-#define FEV(i, j, k) fEV[DIDX(i, j, k, I + 1, J)]
-#define FEW(i, j, k) fEW[DIDX(i, j, k, I + 1, J + 1)]
-#define XU(i, j, k) xu[DIDX(i, j, k, I + 1, J)]
-#define XV(i, j, k) xv[DIDX(i, j, k, I, J + 1)]
-#define XW(i, j, k) xw[DIDX(i, j, k, I, J)]
-
+// ------------------------------------------------------------------ K8: diagonal + rhs + row selection
 // row eligibility: the reference loops 1 <= i < I, 1 <= j < J, 1 <= k < K for all three components
 // (viscositysolver.cpp:284-354).  A row whose stencil would leave the arrays (j = J-1 or k = K-1 for U,
 // etc.) makes the reference throw std::out_of_range; with any closed solid boundary those faces are SOLID
-// and never rows.  They are excluded here so the kernels need no bounds checks.
-__device__ __forceinline__ bool d_row_range(int dir, int i, int j, int k, int I, int J, int K) {
+// and never rows.  They are excluded here.
+__device__ __forceinline__ bool d_row_range(int dir, int i, int j, int k, const Lay &L) {
     if (i < 1 || j < 1 || k < 1) return false;
-    if (dir == 0) return i <= I - 1 && j <= J - 2 && k <= K - 2;
-    if (dir == 1) return i <= I - 2 && j <= J - 1 && k <= K - 2;
-    return i <= I - 2 && j <= J - 2 && k <= K - 1;
+    if (dir == 0) return i <= L.I - 1 && j <= L.J - 2 && k <= L.K - 2;
+    if (dir == 1) return i <= L.I - 2 && j <= L.J - 1 && k <= L.K - 2;
+    return i <= L.I - 2 && j <= L.J - 2 && k <= L.K - 1;
 }
 
-// K8: diagonal + right-hand side + row selection, one thread per index (i,j,k) of the (I+1,J+1,K+1) space.
 // rhs follows viscositysolver.cpp:448-465 (and :546-563, :644-659): own volume * velocity minus the
 // couplings to SOLID-state neighbours, accumulated in fp32 in the reference's order.
+#define RHS(st, vel, coef) do { if ((st) == ST_SOLID) rval -= (coef) * (vel); } while (0)
 template <typename T>
-__global__ void k_visc_setup(const float *__restrict__ U, const float *__restrict__ V, const float *__restrict__ W,
-                             const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV,
-                             const uint8_t *__restrict__ stW, const float *__restrict__ volU,
-                             const float *__restrict__ volV, const float *__restrict__ volW,
-                             const float *__restrict__ volC, const float *__restrict__ volEU,
-                             const float *__restrict__ volEV, const float *__restrict__ volEW,
-                             const float *__restrict__ fC, const float *__restrict__ fEU,
-                             const float *__restrict__ fEV, const float *__restrict__ fEW, float *__restrict__ dgU,
-                             float *__restrict__ dgV, float *__restrict__ dgW, PcgVecs<T> v, double *__restrict__ bmax,
-                             int *__restrict__ nrows, int I, int J, int K) {
+__global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__restrict__ V,
+                             const float *__restrict__ W, const uint8_t *__restrict__ SU,
+                             const uint8_t *__restrict__ SV, const uint8_t *__restrict__ SW,
+                             const float *__restrict__ volU, const float *__restrict__ volV,
+                             const float *__restrict__ volW, const float *__restrict__ VC,
+                             const float *__restrict__ VEU, const float *__restrict__ VEV,
+                             const float *__restrict__ VEW, const float *__restrict__ fC,
+                             const float *__restrict__ fEU, const float *__restrict__ fEV,
+                             const float *__restrict__ fEW, float *__restrict__ dgU, float *__restrict__ dgV,
+                             float *__restrict__ dgW, float *__restrict__ vmU, float *__restrict__ vmV,
+                             float *__restrict__ vmW, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
     double babs = 0.0;
     int rows = 0;
-#define SU(i, j, k) stU[DIDX(i, j, k, I + 1, J)]
-#define SV(i, j, k) stV[DIDX(i, j, k, I, J + 1)]
-#define SW(i, j, k) stW[DIDX(i, j, k, I, J)]
-#define VELU(i, j, k) U[DIDX(i, j, k, I + 1, J)]
-#define VELV(i, j, k) V[DIDX(i, j, k, I, J + 1)]
-#define VELW(i, j, k) W[DIDX(i, j, k, I, J)]
-#define VC(i, j, k) volC[DIDX(i, j, k, I, J)]
-#define VEU(i, j, k) volEU[DIDX(i, j, k, I, J + 1)]
-#define VEV(i, j, k) volEV[DIDX(i, j, k, I + 1, J)]
-#define VEW(i, j, k) volEW[DIDX(i, j, k, I + 1, J + 1)]
-#define RHS(st, vel, coef) do { if ((st) == ST_SOLID) rval -= (coef) * (vel); } while (0)
-    if (i <= I && j < J && k < K) {  // ---- U face
-        const size_t f = DIDX(i, j, k, I + 1, J);
-        float dg = 0.0f, rval = 0.0f;
-        if (d_row_range(0, i, j, k, I, J, K) && SU(i, j, k) == ST_FLUID) {
-            const float vol = volU[f];
-            if (vol > 0.0f || VC(i, j, k) > 0.0f || VC(i - 1, j, k) > 0.0f || VEW(i, j + 1, k) > 0.0f ||
-                VEW(i, j, k) > 0.0f || VEV(i, j, k + 1) > 0.0f || VEV(i, j, k) > 0.0f) {
-                const float fR = FC(i, j, k), fL = FC(i - 1, j, k), fT = FEW(i, j + 1, k), fB = FEW(i, j, k),
-                            fF = FEV(i, j, k + 1), fK = FEV(i, j, k);
-                dg = vol + fR + fL + fT + fB + fF + fK;
-                rval = vol * VELU(i, j, k);
-                RHS(SU(i + 1, j, k), VELU(i + 1, j, k), -fR);
-                RHS(SU(i - 1, j, k), VELU(i - 1, j, k), -fL);
-                RHS(SU(i, j + 1, k), VELU(i, j + 1, k), -fT);
-                RHS(SU(i, j - 1, k), VELU(i, j - 1, k), -fB);
-                RHS(SU(i, j, k + 1), VELU(i, j, k + 1), -fF);
-                RHS(SU(i, j, k - 1), VELU(i, j, k - 1), -fK);
-                RHS(SV(i, j + 1, k), VELV(i, j + 1, k), -fT);
-                RHS(SV(i - 1, j + 1, k), VELV(i - 1, j + 1, k), fT);
-                RHS(SV(i, j, k), VELV(i, j, k), fB);
-                RHS(SV(i - 1, j, k), VELV(i - 1, j, k), -fB);
-                RHS(SW(i, j, k + 1), VELW(i, j, k + 1), -fF);
-                RHS(SW(i - 1, j, k + 1), VELW(i - 1, j, k + 1), fF);
-                RHS(SW(i, j, k), VELW(i, j, k), fK);
-                RHS(SW(i - 1, j, k), VELW(i - 1, j, k), -fK);
-                if (dg == 0.0f) rval = 0.0f;
-                rows += dg != 0.0f;
+    if (i < L.PX && j < L.PY) {
+        const size_t c = gidx(L, i, j, k);
+        const long sy = L.sy, sz = L.sz;
+        float dg[3] = {0.0f, 0.0f, 0.0f}, rv[3] = {0.0f, 0.0f, 0.0f}, vm[3] = {-1.0f, -1.0f, -1.0f};
+        if (d_row_range(0, i, j, k, L) && SU[c] == ST_FLUID) {  // ---- U face (viscositysolver.cpp:374-470)
+            const float vol = volU[c];
+            if (vol > 0.0f || VC[c] > 0.0f || VC[c - 1] > 0.0f || VEW[c + sy] > 0.0f || VEW[c] > 0.0f || VEV[c + sz] > 0.0f ||
+                VEV[c] > 0.0f) {
+                const float fR = fC[c], fL = fC[c - 1], fT = fEW[c + sy], fB = fEW[c], fF = fEV[c + sz], fK = fEV[c];
+                float rval = vol * U[c];
+                RHS(SU[c + 1], U[c + 1], -fR);
+                RHS(SU[c - 1], U[c - 1], -fL);
+                RHS(SU[c + sy], U[c + sy], -fT);
+                RHS(SU[c - sy], U[c - sy], -fB);
+                RHS(SU[c + sz], U[c + sz], -fF);
+                RHS(SU[c - sz], U[c - sz], -fK);
+                RHS(SV[c + sy], V[c + sy], -fT);
+                RHS(SV[c - 1 + sy], V[c - 1 + sy], fT);
+                RHS(SV[c], V[c], fB);
+                RHS(SV[c - 1], V[c - 1], -fB);
+                RHS(SW[c + sz], W[c + sz], -fF);
+                RHS(SW[c - 1 + sz], W[c - 1 + sz], fF);
+                RHS(SW[c], W[c], fK);
+                RHS(SW[c - 1], W[c - 1], -fK);
+                dg[0] = vol + fR + fL + fT + fB + fF + fK;
+                rv[0] = dg[0] != 0.0f ? rval : 0.0f;
+                if (dg[0] != 0.0f) vm[0] = vol;
             }
         }
-        dgU[f] = dg;
-        v.r[0][f] = (T)rval; v.x[0][f] = (T)0; v.s[0][f] = (T)0;
-        babs = fmax(babs, fabs((double)rval));
-    }
-    if (i < I && j <= J && k < K) {  // ---- V face
-        const size_t f = DIDX(i, j, k, I, J + 1);
-        float dg = 0.0f, rval = 0.0f;
-        if (d_row_range(1, i, j, k, I, J, K) && SV(i, j, k) == ST_FLUID) {
-            const float vol = volV[f];
-            if (vol > 0.0f || VEW(i + 1, j, k) > 0.0f || VEW(i, j, k) > 0.0f || VC(i, j, k) > 0.0f ||
-                VC(i, j - 1, k) > 0.0f || VEU(i, j, k + 1) > 0.0f || VEU(i, j, k) > 0.0f) {
-                const float fR = FEW(i + 1, j, k), fL = FEW(i, j, k), fT = FC(i, j, k), fB = FC(i, j - 1, k),
-                            fF = FEU(i, j, k + 1), fK = FEU(i, j, k);
-                dg = vol + fR + fL + fT + fB + fF + fK;
-                rval = vol * VELV(i, j, k);
-                RHS(SV(i + 1, j, k), VELV(i + 1, j, k), -fR);
-                RHS(SV(i - 1, j, k), VELV(i - 1, j, k), -fL);
-                RHS(SV(i, j + 1, k), VELV(i, j + 1, k), -fT);
-                RHS(SV(i, j - 1, k), VELV(i, j - 1, k), -fB);
-                RHS(SV(i, j, k + 1), VELV(i, j, k + 1), -fF);
-                RHS(SV(i, j, k - 1), VELV(i, j, k - 1), -fK);
-                RHS(SU(i + 1, j, k), VELU(i + 1, j, k), -fR);
-                RHS(SU(i + 1, j - 1, k), VELU(i + 1, j - 1, k), fR);
-                RHS(SU(i, j, k), VELU(i, j, k), fL);
-                RHS(SU(i, j - 1, k), VELU(i, j - 1, k), -fL);
-                RHS(SW(i, j, k + 1), VELW(i, j, k + 1), -fF);
-                RHS(SW(i, j - 1, k + 1), VELW(i, j - 1, k + 1), fF);
-                RHS(SW(i, j, k), VELW(i, j, k), fK);
-                RHS(SW(i, j - 1, k), VELW(i, j - 1, k), -fK);
-                if (dg == 0.0f) rval = 0.0f;
-                rows += dg != 0.0f;
+        if (d_row_range(1, i, j, k, L) && SV[c] == ST_FLUID) {  // ---- V face (viscositysolver.cpp:472-568)
+            const float vol = volV[c];
+            if (vol > 0.0f || VEW[c + 1] > 0.0f || VEW[c] > 0.0f || VC[c] > 0.0f || VC[c - sy] > 0.0f || VEU[c + sz] > 0.0f ||
+                VEU[c] > 0.0f) {
+                const float fR = fEW[c + 1], fL = fEW[c], fT = fC[c], fB = fC[c - sy], fF = fEU[c + sz], fK = fEU[c];
+                float rval = vol * V[c];
+                RHS(SV[c + 1], V[c + 1], -fR);
+                RHS(SV[c - 1], V[c - 1], -fL);
+                RHS(SV[c + sy], V[c + sy], -fT);
+                RHS(SV[c - sy], V[c - sy], -fB);
+                RHS(SV[c + sz], V[c + sz], -fF);
+                RHS(SV[c - sz], V[c - sz], -fK);
+                RHS(SU[c + 1], U[c + 1], -fR);
+                RHS(SU[c + 1 - sy], U[c + 1 - sy], fR);
+                RHS(SU[c], U[c], fL);
+                RHS(SU[c - sy], U[c - sy], -fL);
+                RHS(SW[c + sz], W[c + sz], -fF);
+                RHS(SW[c - sy + sz], W[c - sy + sz], fF);
+                RHS(SW[c], W[c], fK);
+                RHS(SW[c - sy], W[c - sy], -fK);
+                dg[1] = vol + fR + fL + fT + fB + fF + fK;
+                rv[1] = dg[1] != 0.0f ? rval : 0.0f;
+                if (dg[1] != 0.0f) vm[1] = vol;
             }
         }
-        dgV[f] = dg;
-        v.r[1][f] = (T)rval; v.x[1][f] = (T)0; v.s[1][f] = (T)0;
-        babs = fmax(babs, fabs((double)rval));
-    }
-    if (i < I && j < J && k <= K) {  // ---- W face
-        const size_t f = DIDX(i, j, k, I, J);
-        float dg = 0.0f, rval = 0.0f;
-        if (d_row_range(2, i, j, k, I, J, K) && SW(i, j, k) == ST_FLUID) {
-            const float vol = volW[f];
-            if (vol > 0.0f || VEV(i + 1, j, k) > 0.0f || VEV(i, j, k) > 0.0f || VEU(i, j + 1, k) > 0.0f ||
-                VEU(i, j, k) > 0.0f || VC(i, j, k) > 0.0f || VC(i, j, k - 1) > 0.0f) {
-                const float fR = FEV(i + 1, j, k), fL = FEV(i, j, k), fT = FEU(i, j + 1, k), fB = FEU(i, j, k),
-                            fF = FC(i, j, k), fK = FC(i, j, k - 1);
-                dg = vol + fR + fL + fT + fB + fF + fK;
-                rval = vol * VELW(i, j, k);
-                RHS(SW(i + 1, j, k), VELW(i + 1, j, k), -fR);
-                RHS(SW(i - 1, j, k), VELW(i - 1, j, k), -fL);
-                RHS(SW(i, j + 1, k), VELW(i, j + 1, k), -fT);
-                RHS(SW(i, j - 1, k), VELW(i, j - 1, k), -fB);
-                RHS(SW(i, j, k + 1), VELW(i, j, k + 1), -fF);
-                RHS(SW(i, j, k - 1), VELW(i, j, k - 1), -fK);
-                RHS(SU(i + 1, j, k), VELU(i + 1, j, k), -fR);
-                RHS(SU(i + 1, j, k - 1), VELU(i + 1, j, k - 1), fR);
-                RHS(SU(i, j, k), VELU(i, j, k), fL);
-                RHS(SU(i, j, k - 1), VELU(i, j, k - 1), -fL);
-                RHS(SV(i, j + 1, k), VELV(i, j + 1, k), -fT);
-                RHS(SV(i, j + 1, k - 1), VELV(i, j + 1, k - 1), fT);
-                RHS(SV(i, j, k), VELV(i, j, k), fB);
-                RHS(SV(i, j, k - 1), VELV(i, j, k - 1), -fB);
-                if (dg == 0.0f) rval = 0.0f;
-                rows += dg != 0.0f;
+        if (d_row_range(2, i, j, k, L) && SW[c] == ST_FLUID) {  // ---- W face (viscositysolver.cpp:570-664)
+            const float vol = volW[c];
+            if (vol > 0.0f || VEV[c + 1] > 0.0f || VEV[c] > 0.0f || VEU[c + sy] > 0.0f || VEU[c] > 0.0f || VC[c] > 0.0f ||
+                VC[c - sz] > 0.0f) {
+                const float fR = fEV[c + 1], fL = fEV[c], fT = fEU[c + sy], fB = fEU[c], fF = fC[c], fK = fC[c - sz];
+                float rval = vol * W[c];
+                RHS(SW[c + 1], W[c + 1], -fR);
+                RHS(SW[c - 1], W[c - 1], -fL);
+                RHS(SW[c + sy], W[c + sy], -fT);
+                RHS(SW[c - sy], W[c - sy], -fB);
+                RHS(SW[c + sz], W[c + sz], -fF);
+                RHS(SW[c - sz], W[c - sz], -fK);
+                RHS(SU[c + 1], U[c + 1], -fR);
+                RHS(SU[c + 1 - sz], U[c + 1 - sz], fR);
+                RHS(SU[c], U[c], fL);
+                RHS(SU[c - sz], U[c - sz], -fL);
+                RHS(SV[c + sy], V[c + sy], -fT);
+                RHS(SV[c + sy - sz], V[c + sy - sz], fT);
+                RHS(SV[c], V[c], fB);
+                RHS(SV[c - sz], V[c - sz], -fB);
+                dg[2] = vol + fR + fL + fT + fB + fF + fK;
+                rv[2] = dg[2] != 0.0f ? rval : 0.0f;
+                if (dg[2] != 0.0f) vm[2] = vol;
             }
         }
-        dgW[f] = dg;
-        v.r[2][f] = (T)rval; v.x[2][f] = (T)0; v.s[2][f] = (T)0;
-        babs = fmax(babs, fabs((double)rval));
+        dgU[c] = dg[0]; dgV[c] = dg[1]; dgW[c] = dg[2];
+        vmU[c] = vm[0]; vmV[c] = vm[1]; vmW[c] = vm[2];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            v.r[m][c] = (double)rv[m]; v.x[m][c] = (T)0; v.s[m][c] = (T)0;
+            babs = fmax(babs, fabs((double)rv[m]));
+            rows += dg[m] != 0.0f;
+        }
     }
     const double bm = block_max_256(babs, lds);
     const double nr = block_sum_256((double)rows, lds);
@@ -336,82 +295,122 @@ __global__ void k_visc_setup(const float *__restrict__ U, const float *__restric
     }
 }
 
-// K9 SpMV: z = A s over the active tiles, fused s.z.  Row = index whose diagonal is non-zero; x is 0 on
-// every other face so neighbour values need no masks (coupling signs: SURVEY.md A.6b).
+// ------------------------------------------------------------------ K9 SpMV
+// q = A s over the active tiles with the three fused dot products, in DIFFERENCE form: a row is its own control
+// volume times x minus the divergence of the viscous stresses, and every stress is a factor times a sum of
+// differences of neighbouring velocities (the Batty-Bridson discretisation the reference assembles into CSR,
+// viscositysolver.cpp:394-446 and the V/W analogues; signs: SURVEY.md A.6b):
+//   U: vol*u - [fR(u(i+1)-u) - fL(u-u(i-1))] - [fT((u(j+1)-u)+(v(i,j+1)-v(i-1,j+1))) - fB((u-u(j-1))+(v(i,j)-v(i-1,j)))]
+//            - [fF((u(k+1)-u)+(w(i,k+1)-w(i-1,k+1))) - fK((u-u(k-1))+(w(i,k)-w(i-1,k)))]
+// Algebraically identical to diag*x - sum(coef*x_nbr), but the fp32 evaluation no longer subtracts two numbers of
+// size diag*|x| to obtain one of size vol*|x| (diag/vol ~ 1e3..1e4 when nu*dt/dx^2 is large), which is what limits
+// the attainable residual of an fp32 solve of this system.
+// vm = own control volume for rows, -1 for every other index (x stays 0 there, q must too).
+#define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
+#define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
 template <typename T>
-__global__ __launch_bounds__(256) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg,
-                                                   const float *__restrict__ dgU, const float *__restrict__ dgV,
-                                                   const float *__restrict__ dgW, const float *__restrict__ fC,
+__global__ __launch_bounds__(256) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
+                                                   const float *__restrict__ vmU, const float *__restrict__ vmV,
+                                                   const float *__restrict__ vmW, const float *__restrict__ fC,
                                                    const float *__restrict__ fEU, const float *__restrict__ fEV,
-                                                   const float *__restrict__ fEW, const T *__restrict__ xu,
-                                                   const T *__restrict__ xv, const T *__restrict__ xw,
-                                                   T *__restrict__ yu, T *__restrict__ yv, T *__restrict__ yw, int I,
-                                                   int J, int K, double *__restrict__ dA, const int *__restrict__ conv) {
-    if (conv && *conv >= 0) return;
-    __shared__ double lds[4];
-    const int slot = d_tile_slot(blockIdx.x, ntiles);
-    double acc = 0.0;
-    if (slot < ntiles) {
-        int i, j, k0;
-        d_tile_coords(tiles[slot], tg, i, j, k0);
-        const int kend = min(k0 + TZ, K + 1);
-        for (int k = k0; k < kend; k++) {
-            if (i <= I && j < J && k < K) {
-                const size_t f = DIDX(i, j, k, I + 1, J);
-                const float dg = dgU[f];
+                                                   const float *__restrict__ fEW, PcgSys<T, 3> v, PcgScal sc, int it) {
+    __shared__ double lds[12];
+    if (d_spmv_stop(sc, it, lds)) return;
+    int i0, j, k;
+    double da = 0.0, db = 0.0, dc = 0.0;
+    constexpr int NV = VW_V;
+    const int nvb = ((ntiles + 7) >> 3) << 3;
+    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
+        if (!(d_tile_coords<NV>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
+        const size_t c = gidx(L, i0, j, k);
+        const long sy = L.sy, sz = L.sz;
+        const int I = L.I;
+        const T *__restrict__ xu = v.s[0], *__restrict__ xv = v.s[1], *__restrict__ xw = v.s[2];
+        // ---- factors
+        const Vec<float, NV> C0 = ldv<NV>(fC + c), Cjm = ldv<NV>(fC + c - sy), Ckm = ldv<NV>(fC + c - sz);
+        const Vec<float, NV> EW0 = ldv<NV>(fEW + c), EWjp = ldv<NV>(fEW + c + sy);
+        const Vec<float, NV> EV0 = ldv<NV>(fEV + c), EVkp = ldv<NV>(fEV + c + sz);
+        const Vec<float, NV> EU0 = ldv<NV>(fEU + c), EUjp = ldv<NV>(fEU + c + sy), EUkp = ldv<NV>(fEU + c + sz);
+        const float C0l = nb_left(C0, fC + c, i0);
+        const float EW0r = nb_right(EW0, fEW + c, i0, I), EV0r = nb_right(EV0, fEV + c, i0, I);
+        // ---- x
+        const Vec<T, NV> U0 = ldv<NV>(xu + c), Ujm = ldv<NV>(xu + c - sy), Ujp = ldv<NV>(xu + c + sy), Ukm = ldv<NV>(xu + c - sz), Ukp = ldv<NV>(xu + c + sz);
+        const Vec<T, NV> V0 = ldv<NV>(xv + c), Vjm = ldv<NV>(xv + c - sy), Vjp = ldv<NV>(xv + c + sy), Vkm = ldv<NV>(xv + c - sz), Vkp = ldv<NV>(xv + c + sz);
+        const Vec<T, NV> W0 = ldv<NV>(xw + c), Wjm = ldv<NV>(xw + c - sy), Wjp = ldv<NV>(xw + c + sy), Wkm = ldv<NV>(xw + c - sz), Wkp = ldv<NV>(xw + c + sz);
+        const Vec<T, NV> Vjpkm = ldv<NV>(xv + c + sy - sz), Wjmkp = ldv<NV>(xw + c - sy + sz);
+        const T U0l = nb_left(U0, xu + c, i0), U0r = nb_right(U0, xu + c, i0, I);
+        const T V0l = nb_left(V0, xv + c, i0), V0r = nb_right(V0, xv + c, i0, I);
+        const T W0l = nb_left(W0, xw + c, i0), W0r = nb_right(W0, xw + c, i0, I);
+        const T Vjpl = nb_left(Vjp, xv + c + sy, i0), Wkpl = nb_left(Wkp, xw + c + sz, i0);
+        const T Ujmr = nb_right(Ujm, xu + c - sy, i0, I), Ukmr = nb_right(Ukm, xu + c - sz, i0, I);
+        // ---- own volumes (row masks) and residuals
+        const Vec<float, NV> MU = ldv<NV>(vmU + c), MV = ldv<NV>(vmV + c), MW = ldv<NV>(vmW + c);
+        const Vec<double, NV> RU = ldv<NV>(v.r[0] + c), RV = ldv<NV>(v.r[1] + c), RW = ldv<NV>(v.r[2] + c);
+        Vec<T, NV> yU, yV, yW;
+#pragma unroll
+        for (int e = 0; e < NV; e++) {
+            const T uc = U0.v[e], vc = V0.v[e], wc = W0.v[e];
+            const T ur = RSH(U0, U0r, e), ul = LSH(U0, U0l, e);
+            const T vr = RSH(V0, V0r, e), vl = LSH(V0, V0l, e);
+            const T wr = RSH(W0, W0r, e), wl = LSH(W0, W0l, e);
+            {   // U row
+                const float fR = C0.v[e], fL = LSH(C0, C0l, e), fT = EWjp.v[e], fB = EW0.v[e], fF = EVkp.v[e], fK = EV0.v[e];
                 T y = (T)0;
-                if (dg != 0.0f) {
-                    const T fR = (T)FC(i, j, k), fL = (T)FC(i - 1, j, k), fT = (T)FEW(i, j + 1, k), fB = (T)FEW(i, j, k),
-                            fF = (T)FEV(i, j, k + 1), fK = (T)FEV(i, j, k);
-                    const T xc = XU(i, j, k);
-                    y = (T)dg * xc - fR * XU(i + 1, j, k) - fL * XU(i - 1, j, k) - fT * XU(i, j + 1, k) -
-                        fB * XU(i, j - 1, k) - fF * XU(i, j, k + 1) - fK * XU(i, j, k - 1);
-                    y += fT * (XV(i - 1, j + 1, k) - XV(i, j + 1, k)) + fB * (XV(i, j, k) - XV(i - 1, j, k));
-                    y += fF * (XW(i - 1, j, k + 1) - XW(i, j, k + 1)) + fK * (XW(i, j, k) - XW(i - 1, j, k));
-                    acc += (double)xc * (double)y;
+                if (MU.v[e] >= 0.0f) {
+                    const T txx = (T)fR * (ur - uc) - (T)fL * (uc - ul);
+                    const T txy = (T)fT * ((Ujp.v[e] - uc) + (Vjp.v[e] - LSH(Vjp, Vjpl, e))) - (T)fB * ((uc - Ujm.v[e]) + (vc - vl));
+                    const T txz = (T)fF * ((Ukp.v[e] - uc) + (Wkp.v[e] - LSH(Wkp, Wkpl, e))) - (T)fK * ((uc - Ukm.v[e]) + (wc - wl));
+                    y = (T)MU.v[e] * uc - txx - txy - txz;
+                    const float dg = MU.v[e] + fR + fL + fT + fB + fF + fK;  // same order as k_visc_setup
+                    const double yd = (double)y, inv = 1.0 / (double)dg;
+                    da += (double)uc * yd; db += RU.v[e] * inv * yd; dc += yd * inv * yd;
                 }
-                yu[f] = y;
+                yU.v[e] = y;
             }
-            if (i < I && j <= J && k < K) {
-                const size_t f = DIDX(i, j, k, I, J + 1);
-                const float dg = dgV[f];
+            {   // V row
+                const float fR = RSH(EW0, EW0r, e), fL = EW0.v[e], fT = C0.v[e], fB = Cjm.v[e], fF = EUkp.v[e], fK = EU0.v[e];
                 T y = (T)0;
-                if (dg != 0.0f) {
-                    const T fR = (T)FEW(i + 1, j, k), fL = (T)FEW(i, j, k), fT = (T)FC(i, j, k), fB = (T)FC(i, j - 1, k),
-                            fF = (T)FEU(i, j, k + 1), fK = (T)FEU(i, j, k);
-                    const T xc = XV(i, j, k);
-                    y = (T)dg * xc - fR * XV(i + 1, j, k) - fL * XV(i - 1, j, k) - fT * XV(i, j + 1, k) -
-                        fB * XV(i, j - 1, k) - fF * XV(i, j, k + 1) - fK * XV(i, j, k - 1);
-                    y += fR * (XU(i + 1, j - 1, k) - XU(i + 1, j, k)) + fL * (XU(i, j, k) - XU(i, j - 1, k));
-                    y += fF * (XW(i, j - 1, k + 1) - XW(i, j, k + 1)) + fK * (XW(i, j, k) - XW(i, j - 1, k));
-                    acc += (double)xc * (double)y;
+                if (MV.v[e] >= 0.0f) {
+                    const T tyy = (T)fT * (Vjp.v[e] - vc) - (T)fB * (vc - Vjm.v[e]);
+                    const T txy = (T)fR * ((vr - vc) + (ur - RSH(Ujm, Ujmr, e))) - (T)fL * ((vc - vl) + (uc - Ujm.v[e]));
+                    const T tyz = (T)fF * ((Vkp.v[e] - vc) + (Wkp.v[e] - Wjmkp.v[e])) - (T)fK * ((vc - Vkm.v[e]) + (wc - Wjm.v[e]));
+                    y = (T)MV.v[e] * vc - tyy - txy - tyz;
+                    const float dg = MV.v[e] + fR + fL + fT + fB + fF + fK;
+                    const double yd = (double)y, inv = 1.0 / (double)dg;
+                    da += (double)vc * yd; db += RV.v[e] * inv * yd; dc += yd * inv * yd;
                 }
-                yv[f] = y;
+                yV.v[e] = y;
             }
-            if (i < I && j < J && k <= K) {
-                const size_t f = DIDX(i, j, k, I, J);
-                const float dg = dgW[f];
+            {   // W row
+                const float fR = RSH(EV0, EV0r, e), fL = EV0.v[e], fT = EUjp.v[e], fB = EU0.v[e], fF = C0.v[e], fK = Ckm.v[e];
                 T y = (T)0;
-                if (dg != 0.0f) {
-                    const T fR = (T)FEV(i + 1, j, k), fL = (T)FEV(i, j, k), fT = (T)FEU(i, j + 1, k), fB = (T)FEU(i, j, k),
-                            fF = (T)FC(i, j, k), fK = (T)FC(i, j, k - 1);
-                    const T xc = XW(i, j, k);
-                    y = (T)dg * xc - fR * XW(i + 1, j, k) - fL * XW(i - 1, j, k) - fT * XW(i, j + 1, k) -
-                        fB * XW(i, j - 1, k) - fF * XW(i, j, k + 1) - fK * XW(i, j, k - 1);
-                    y += fR * (XU(i + 1, j, k - 1) - XU(i + 1, j, k)) + fL * (XU(i, j, k) - XU(i, j, k - 1));
-                    y += fT * (XV(i, j + 1, k - 1) - XV(i, j + 1, k)) + fB * (XV(i, j, k) - XV(i, j, k - 1));
-                    acc += (double)xc * (double)y;
+                if (MW.v[e] >= 0.0f) {
+                    const T tzz = (T)fF * (Wkp.v[e] - wc) - (T)fK * (wc - Wkm.v[e]);
+                    const T txz = (T)fR * ((wr - wc) + (ur - RSH(Ukm, Ukmr, e))) - (T)fL * ((wc - wl) + (uc - Ukm.v[e]));
+                    const T tyz = (T)fT * ((Wjp.v[e] - wc) + (Vjp.v[e] - Vjpkm.v[e])) - (T)fB * ((wc - Wjm.v[e]) + (vc - Vkm.v[e]));
+                    y = (T)MW.v[e] * wc - tzz - txz - tyz;
+                    const float dg = MW.v[e] + fR + fL + fT + fB + fF + fK;
+                    const double yd = (double)y, inv = 1.0 / (double)dg;
+                    da += (double)wc * yd; db += RW.v[e] * inv * yd; dc += yd * inv * yd;
                 }
-                yw[f] = y;
+                yW.v[e] = y;
             }
         }
+        stv(v.q[0] + c, yU);
+        stv(v.q[1] + c, yV);
+        stv(v.q[2] + c, yW);
     }
-    const double tot = block_sum_256(acc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0 && dA) atomicAdd(dA, tot);
+    block_sum3_256(da, db, dc, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.a) {
+        const size_t so = (size_t)it * NSLOT + (blockIdx.x & (NSLOT - 1));
+        if (da != 0.0) atomicAdd(&sc.a[so], da);
+        if (db != 0.0) atomicAdd(&sc.b[so], db);
+        if (dc != 0.0) atomicAdd(&sc.c[so], dc);
+    }
 }
 
 template <typename T>
-__global__ void k_vec_to_f32(const T *__restrict__ a, float *__restrict__ o, size_t n) {
+static __global__ void k_vec_to_f32(const T *__restrict__ a, float *__restrict__ o, size_t n) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; t < n; t += stride) o[t] = (float)a[t];
@@ -419,24 +418,28 @@ __global__ void k_vec_to_f32(const T *__restrict__ a, float *__restrict__ o, siz
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-static void launch_visc_spmv(flipv_context *c, double *dA, const int *conv) {
-    const Dims &d = c->d;
-    const int nb = ((c->nActiveV + 7) / 8) * 8;
-    if (c->prm.kernel_timing) fv_ev_begin(c, 1, (double)c->nActiveV * TX * TY * TZ);
-    hipLaunchKernelGGL(k_visc_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tg,
-                       c->vDiagU, c->vDiagV, c->vDiagW, c->fC, c->fEU, c->fEV, c->fEW, (const T *)c->vS[0],
-                       (const T *)c->vS[1], (const T *)c->vS[2], (T *)c->vZ[0], (T *)c->vZ[1], (T *)c->vZ[2], d.I, d.J,
-                       d.K, dA, conv);
+static PcgSys<T, 3> visc_sys(flipv_context *c) {
+    PcgSys<T, 3> v;
+    v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
+    for (int m = 0; m < 3; m++) { v.x[m] = (T *)c->vX[m]; v.r[m] = (double *)c->vR[m]; v.q[m] = (T *)c->vZ[m]; v.s[m] = (T *)c->vS[m]; }
+    return v;
+}
+
+template <typename T>
+static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it) {
+    const int nb = pcg_grid(c->nActiveV);
+    if (c->prm.kernel_timing) fv_ev_begin(c, 1, (double)c->nActiveV * (64 * VW_V * TY));
+    hipLaunchKernelGGL(k_visc_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L,
+                       c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
     if (c->prm.kernel_timing) fv_ev_end(c);
 }
 
 template <typename T>
 static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info) {
-    const Dims &d = c->d;
-    const int I = d.I, J = d.J, K = d.K;
+    const Lay &L = c->L;
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
-    li.total_tiles = c->tg.count();
+    li.total_tiles = c->tgV.count();
     if (!c->viscosity_nonzero) {  // fluidsimulation.cpp:171-184
         li.status = 3;
         if (info) *info = li;
@@ -445,54 +448,41 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const int cap = c->prm.viscosity_max_iterations;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
-    const size_t nscal = (size_t)3 * (cap + 2) + 16;
+    const size_t nscal = (size_t)5 * (cap + 2) * NSLOT + 16;
     HIPCHK(c, hipMemsetAsync(c->d_scal, 0, nscal * sizeof(double), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, 4 * sizeof(int), c->stream));  // conv = -1
-    HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));     // row counter
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));   // conv = -1
+    HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));  // row counter
     PcgScal sc;
-    sc.sigma = c->d_scal;
-    sc.dA = c->d_scal + (cap + 2);
-    sc.rmax = c->d_scal + 2 * (cap + 2);
-    double *bmax = c->d_scal + 3 * (cap + 2);
-    sc.conv = c->d_flags;
+    double *bmax;
+    fv_scal_views(c, cap, &sc, &bmax);
     sc.tol_inclusive = 1;
+    sc.tol = 0.0;
 
     // face states
-    hipLaunchKernelGGL(k_solid_center, GRID3(I, J, K), 0, c->stream, c->solid, c->scp, I, J, K);
-    uint8_t *st[3] = {c->stU, c->stV, c->stW};
-    for (int dir = 0; dir < 3; dir++)
-        hipLaunchKernelGGL(k_face_states, GRID3(I + (dir == 0), J + (dir == 1), K + (dir == 2)), 0, c->stream, dir, c->scp,
-                           st[dir], I, J, K);
+    hipLaunchKernelGGL(k_solid_center, GRID3(L), 0, c->stream, L, c->solid, c->scp);
+    hipLaunchKernelGGL(k_face_states, GRID3(L), 0, c->stream, L, c->scp, c->stU, c->stV, c->stW);
     // band mask + the seven volume lattices (viscositysolver.cpp:135-178)
-    hipLaunchKernelGGL(k_valid_init, GRID3(I + 1, J + 1, K + 1), 0, c->stream, c->phi, c->validCells, I, J, K);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(I + 1, J + 1, K + 1), 0, c->stream, c->validCells, c->validTmp, I + 1, J + 1, K + 1);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(I + 1, J + 1, K + 1), 0, c->stream, c->validTmp, c->validCells, I + 1, J + 1, K + 1);
+    hipLaunchKernelGGL(k_valid_init, GRID3(L), 0, c->stream, L, c->phi, c->validCells);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(L), 0, c->stream, L, c->validCells, c->validTmp);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(L), 0, c->stream, L, c->validTmp, c->validCells);
     const float h = (float)(0.5 * c->dx);
-    struct { float *v; int w, hh, dd; float cx, cy, cz; } lat[7] = {
-        {c->volC, I, J, K, h, h, h},         {c->volU, I + 1, J, K, 0, h, h},     {c->volV, I, J + 1, K, h, 0, h},
-        {c->volW, I, J, K + 1, h, h, 0},     {c->volEU, I, J + 1, K + 1, h, 0, 0}, {c->volEV, I + 1, J, K + 1, 0, h, 0},
-        {c->volEW, I + 1, J + 1, K, 0, 0, h}};
+    struct { float *v; int lat; float cx, cy, cz; } lat[7] = {
+        {c->volC, LAT_CELL, h, h, h}, {c->volU, LAT_U, 0, h, h},  {c->volV, LAT_V, h, 0, h}, {c->volW, LAT_W, h, h, 0},
+        {c->volEU, LAT_EU, h, 0, 0},  {c->volEV, LAT_EV, 0, h, 0}, {c->volEW, LAT_EW, 0, 0, h}};
     for (int q = 0; q < 7; q++)
-        hipLaunchKernelGGL(k_volume_lattice, GRID3(lat[q].w, lat[q].hh, lat[q].dd), 0, c->stream, c->phi, c->validCells,
-                           lat[q].v, lat[q].w, lat[q].hh, lat[q].dd, lat[q].cx, lat[q].cy, lat[q].cz, I, J, K, c->dx);
+        hipLaunchKernelGGL(k_volume_lattice, GRID3(L), 0, c->stream, L, lat[q].lat, c->phi, c->validCells, lat[q].v, lat[q].cx,
+                           lat[q].cy, lat[q].cz, c->dx);
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
-    hipLaunchKernelGGL(k_visc_factors, GRID3(I + 1, J + 1, K + 1), 0, c->stream, c->visc, c->volC, c->volEU, c->volEV,
-                       c->volEW, c->fC, c->fEU, c->fEV, c->fEW, I, J, K, factor);
-    PcgVecs<T> v;
-    for (int q = 0; q < 3; q++) { v.x[q] = (T *)c->vX[q]; v.r[q] = (T *)c->vR[q]; v.z[q] = (T *)c->vZ[q]; v.s[q] = (T *)c->vS[q]; }
-    hipLaunchKernelGGL(k_visc_setup<T>, GRID3(I + 1, J + 1, K + 1), 0, c->stream, c->U, c->V, c->W, c->stU, c->stV, c->stW,
-                       c->volU, c->volV, c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW,
-                       c->vDiagU, c->vDiagV, c->vDiagW, v, bmax, c->d_flags + 2, I, J, K);
+    hipLaunchKernelGGL(k_visc_factors, GRID3(L), 0, c->stream, L, c->visc, c->volC, c->volEU, c->volEV, c->volEW, c->fC,
+                       c->fEU, c->fEV, c->fEW, factor);
+    PcgSys<T, 3> v = visc_sys<T>(c);
+    hipLaunchKernelGGL(k_visc_setup<T>, GRID3(L), 0, c->stream, L, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
+                       c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
+                       c->vDiagW, c->vmU, c->vmV, c->vmW, v, bmax, c->d_flags + 2);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PcgComps cp;
-    memset(&cp, 0, sizeof(cp));
-    cp.n = 3;
-    cp.w[0] = I + 1; cp.h[0] = J; cp.d[0] = K; cp.diag[0] = c->vDiagU;
-    cp.w[1] = I; cp.h[1] = J + 1; cp.d[1] = K; cp.diag[1] = c->vDiagV;
-    cp.w[2] = I; cp.h[2] = J; cp.d[2] = K + 1; cp.diag[2] = c->vDiagW;
-    rc = fv_build_tiles(c, cp, c->tileListV, &c->nActiveV);
+    rc = fv_build_tiles(c, c->tgV, VW_V, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->tileListV, &c->nActiveV);
     if (rc) return rc;
     const double bnorm = c->h_scal[0];
     li.rhs_norm = bnorm;
@@ -508,24 +498,25 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         success = true;
     } else {
         sc.tol = c->prm.viscosity_tolerance * bnorm;
-        const int nb = ((c->nActiveV + 7) / 8) * 8;
+        const int nb = pcg_grid(c->nActiveV);
         const dim3 blk(64, 4, 1);
-        hipLaunchKernelGGL(k_pcg_init<T>, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tg, cp, v, sc);
+        hipLaunchKernelGGL((k_pcg_init<T, 3, VW_V>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc);
         const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
         int it = 0;
         while (it < cap && conv < 0) {
             const int stop = (it + every < cap) ? it + every : cap;
             for (; it < stop; it++) {
-                launch_visc_spmv<T>(c, sc.dA + it, sc.conv);
-                hipLaunchKernelGGL(k_pcg_update<T>, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tg, cp, v, sc, it);
-                hipLaunchKernelGGL(k_pcg_dir<T>, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tg, cp, v, sc, it);
+                launch_visc_spmv<T>(c, sc, it);
+                hipLaunchKernelGGL((k_pcg_update<T, 3, VW_V>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
             }
+            hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
             HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             conv = c->h_flags[0];
         }
         const int last = conv >= 0 ? conv : cap - 1;
-        HIPCHK(c, hipMemcpyAsync(c->h_scal, sc.rmax + last, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
+        HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         res = c->h_scal[0];
         iters = conv >= 0 ? conv + 1 : cap;
@@ -537,9 +528,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool accepted = success || (iters == cap && res < c->prm.viscosity_accept_tolerance);
     li.status = success ? (iters == 0 ? 3 : 0) : (accepted ? 1 : 2);
     if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[0], c->U, d.nu());
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[1], c->V, d.nv());
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[2], c->W, d.nw());
+        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[0], c->U, L.n);
+        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[1], c->V, L.n);
+        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[2], c->W, L.n);
     }
     HIPCHK(c, hipGetLastError());
     if (c->prm.kernel_timing) fv_ev_collect(c);
@@ -559,12 +550,14 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
     HIPCHK(c, hipEventCreate(&b));
     const int saved = c->prm.kernel_timing;
     c->prm.kernel_timing = 0;
+    PcgScal sc;
+    memset(&sc, 0, sizeof(sc));
     for (int w = 0; w < 3; w++) {
-        if (c->viscosityPrec) launch_visc_spmv<double>(c, nullptr, nullptr); else launch_visc_spmv<float>(c, nullptr, nullptr);
+        if (c->viscosityPrec) launch_visc_spmv<double>(c, sc, 0); else launch_visc_spmv<float>(c, sc, 0);
     }
     HIPCHK(c, hipEventRecord(a, c->stream));
     for (int r = 0; r < reps; r++) {
-        if (c->viscosityPrec) launch_visc_spmv<double>(c, nullptr, nullptr); else launch_visc_spmv<float>(c, nullptr, nullptr);
+        if (c->viscosityPrec) launch_visc_spmv<double>(c, sc, 0); else launch_visc_spmv<float>(c, sc, 0);
     }
     HIPCHK(c, hipEventRecord(b, c->stream));
     HIPCHK(c, hipEventSynchronize(b));
@@ -574,6 +567,6 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *ms = (double)t / reps;
-    *cells = (double)c->nActiveV * TX * TY * TZ;
+    *cells = (double)c->nActiveV * (64 * VW_V * TY);
     return FLIPV_OK;
 }

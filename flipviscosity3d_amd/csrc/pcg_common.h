@@ -2,156 +2,297 @@
 // pressure (1 component, cell-centred) and viscosity (3 components, face-centred) solves.
 //
 // Algorithm = the reference's PCG loops (pressuresolver.cpp:521-567, pcgsolver.h:241-295) with the
-// sequential MIC(0) triangular solves replaced by a diagonal preconditioner M = diag(A), which is the
-// only part of the reference algorithm that does not parallelise.  Everything stays on the
-// device: alpha/beta are formed inside the kernels from fp64 dot products accumulated with one fp64
-// atomic per block, indexed by iteration so nothing has to be reset inside the loop, and a device flag
-// stops all later launches once max|r| passes the tolerance, so the host only polls every few iterations.
+// sequential MIC(0) triangular solves replaced by the diagonal preconditioner M = diag(A) -- the only part of
+// the reference algorithm that does not parallelise.  One iteration is TWO kernels:
 //
-//   init   : z = r/diag ; s = z ; sigma[0] = z.r
-//   spmv   : z = A s                    ; dA[it]    = s.z          (kernel supplied by the caller)
-//   update : alpha = sigma[it]/dA[it]   ; x += alpha s ; r -= alpha z ; rmax[it] = max|r| ;
-//            sigma[it+1] = (r/diag).r
-//   dir    : if rmax[it] passes tol -> conv = it, stop ; beta = sigma[it+1]/sigma[it] ; s = r/diag + beta s
+//   spmv   (K1): q = A s ;  a = s.q ;  b = (r/d).q ;  c = (q/d).q            (kernel supplied by the solver)
+//   update (K2): alpha = sigma/a ; x += alpha s ; r -= alpha q ;
+//                beta = (sigma - 2 alpha b + alpha^2 c)/sigma ;  s = r/d + beta s ;
+//                sigma' = (r/d).r ; rmax = max|r|
+//
+// (r',z') = (r - alpha q, (r - alpha q)/d) expands to sigma - 2 alpha b + alpha^2 c, so beta is known as soon as the
+// SpMV's three dot products are, and the classic third kernel (s = z + beta s after a second reduction) folds into
+// the update.  The next iteration's alpha uses sigma' recomputed from the actual vectors, so nothing drifts.
+// Everything stays on the device: the scalars are fp64 sums accumulated with one atomic per block into slots
+// indexed by iteration (nothing is reset inside the loop); K1 stops the solve by setting a device flag once
+// rmax of the previous iteration passes the tolerance, after which every launch returns immediately, so the
+// host only polls every few iterations.
+//
+// Work decomposition: tiles of (64 N) x 4 x 1 indices of the shared index space (flipv_internal.h); a lane owns N
+// consecutive i (N = 4 pressure, N = 2 viscosity) and moves them with one 16- or 8-byte access per array;
+// i-neighbours come from the adjacent lane (ds_bpermute), j/k-neighbours from aligned loads of the adjacent rows.
 #pragma once
 #include "flipv_internal.h"
 
-struct PcgComps {   // up to 3 components, each its own Array3d-layout grid
-    int n;
-    int w[3], h[3], d[3];
-    const float *diag[3];
-};
+// N consecutive i of one lane (N = 4: one dwordx4 access for fp32; N = 2: dwordx2)
+template <typename T, int N> struct Vec { T v[N]; };
 
-template <typename T>
-struct PcgVecs {
-    T *x[3], *r[3], *z[3], *s[3];
-};
+template <int N> __device__ __forceinline__ Vec<float, N> ldv(const float *__restrict__ p);
+template <> __device__ __forceinline__ Vec<float, 4> ldv<4>(const float *__restrict__ p) {
+    const float4 q = *reinterpret_cast<const float4 *>(p);
+    Vec<float, 4> r;
+    r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+    return r;
+}
+template <> __device__ __forceinline__ Vec<float, 2> ldv<2>(const float *__restrict__ p) {
+    const float2 q = *reinterpret_cast<const float2 *>(p);
+    Vec<float, 2> r;
+    r.v[0] = q.x; r.v[1] = q.y;
+    return r;
+}
+template <int N> __device__ __forceinline__ Vec<double, N> ldv(const double *__restrict__ p);
+template <> __device__ __forceinline__ Vec<double, 4> ldv<4>(const double *__restrict__ p) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    Vec<double, 4> r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    return r;
+}
+template <> __device__ __forceinline__ Vec<double, 2> ldv<2>(const double *__restrict__ p) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    Vec<double, 2> r;
+    r.v[0] = a.x; r.v[1] = a.y;
+    return r;
+}
+__device__ __forceinline__ void stv(float *__restrict__ p, const Vec<float, 4> &r) {
+    *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+}
+__device__ __forceinline__ void stv(float *__restrict__ p, const Vec<float, 2> &r) {
+    *reinterpret_cast<float2 *>(p) = make_float2(r.v[0], r.v[1]);
+}
+__device__ __forceinline__ void stv(double *__restrict__ p, const Vec<double, 4> &r) {
+    *reinterpret_cast<double2 *>(p) = make_double2(r.v[0], r.v[1]);
+    *reinterpret_cast<double2 *>(p + 2) = make_double2(r.v[2], r.v[3]);
+}
+__device__ __forceinline__ void stv(double *__restrict__ p, const Vec<double, 2> &r) {
+    *reinterpret_cast<double2 *>(p) = make_double2(r.v[0], r.v[1]);
+}
 
-struct PcgScal {    // views into ctx->d_scal
-    double *sigma;  // [cap+1]
-    double *dA;     // [cap]
-    double *rmax;   // [cap]
+// value at i0-1 (the previous lane's last element) / at i0+N (the next lane's first element).
+// `p` points at this lane's first element; the wave-edge lanes read memory when the neighbour index is inside
+// the lattice width w, else 0 (wave-uniform condition: only grids wider than one wave ever take it).
+template <typename T, int N>
+__device__ __forceinline__ T nb_left(const Vec<T, N> &a, const T *__restrict__ p, int i0) {
+    T v = __shfl_up(a.v[N - 1], 1, 64);
+    if ((threadIdx.x & 63) == 0) v = i0 > 0 ? p[-1] : (T)0;
+    return v;
+}
+template <typename T, int N>
+__device__ __forceinline__ T nb_right(const Vec<T, N> &a, const T *__restrict__ p, int i0, int w) {
+    T v = __shfl_down(a.v[0], 1, 64);
+    if ((threadIdx.x & 63) == 63) v = i0 + N < w ? p[N] : (T)0;
+    return v;
+}
+
+// Every reduced scalar of iteration `it` is spread over NSLOT partial sums (slot = blockIdx & (NSLOT-1)) so that the
+// one-atomic-per-block accumulation does not serialise on a single L2 address (thousands of blocks per launch);
+// the consuming kernel folds the NSLOT partials with one wave.
+constexpr int NSLOT = 32;
+struct PcgScal {    // views into ctx->d_scal, each [(cap+2) * NSLOT]
+    double *sig;    // sig[it] = (r,z) entering iteration it
+    double *a, *b, *c;
+    double *rmax;   // rmax[it] = max|r| after iteration it
     int *conv;      // converged-at iteration, -1 while running
     double tol;
     int tol_inclusive;  // 1: res <= tol (pcgsolver.h:270), 0: res < tol (pressuresolver.cpp:548)
 };
 
-__device__ __forceinline__ void d_tile_coords(int tile, const TileGrid &tg, int &i, int &j, int &k0) {
+__device__ __forceinline__ int d_tid256() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
+
+// fold the NSLOT partials of up to four scalars (sum) -- executed by every thread of the block, one barrier
+__device__ __forceinline__ void d_fold_sums(const double *p0, const double *p1, const double *p2, const double *p3,
+                                            double out[4], double *lds8) {
+    const int tid = d_tid256();
+    if (tid < 64) {
+        const int sl = tid & (NSLOT - 1);
+        const double *p = (tid < NSLOT) ? p0 : p1;
+        double v0 = p ? p[sl] : 0.0;
+        const double *pp = (tid < NSLOT) ? p2 : p3;
+        double v1 = pp ? pp[sl] : 0.0;
+        // lanes 0..31 hold p0/p2 partials, lanes 32..63 hold p1/p3 partials: reduce the two halves separately
+#pragma unroll
+        for (int off = NSLOT / 2; off > 0; off >>= 1) {
+            v0 += __shfl_down(v0, off, NSLOT);
+            v1 += __shfl_down(v1, off, NSLOT);
+        }
+        if (tid == 0) { lds8[0] = v0; lds8[2] = v1; }
+        if (tid == NSLOT) { lds8[1] = v0; lds8[3] = v1; }
+    }
+    __syncthreads();
+    out[0] = lds8[0]; out[1] = lds8[1]; out[2] = lds8[2]; out[3] = lds8[3];
+    __syncthreads();
+}
+__device__ __forceinline__ double d_fold_max(const double *p, double *lds8) {
+    const int tid = d_tid256();
+    if (tid < NSLOT) {
+        double v = p[tid];
+#pragma unroll
+        for (int off = NSLOT / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, NSLOT));
+        if (tid == 0) lds8[0] = v;
+    }
+    __syncthreads();
+    const double r = lds8[0];
+    __syncthreads();
+    return r;
+}
+
+// block-wide sum of three values with a single barrier pair; result valid in thread 0
+__device__ __forceinline__ void block_sum3_256(double &a, double &b, double &c, double *lds12) {
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    const int tid = d_tid256();
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) { lds12[wv] = a; lds12[4 + wv] = b; lds12[8 + wv] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        a = lds12[0] + lds12[1] + lds12[2] + lds12[3];
+        b = lds12[4] + lds12[5] + lds12[6] + lds12[7];
+        c = lds12[8] + lds12[9] + lds12[10] + lds12[11];
+    }
+    __syncthreads();
+}
+
+// x, s (search direction), q = A s are stored in T (fp32 by default); the residual r is ALWAYS fp64: with an exact
+// residual recurrence the fused beta below is as stable as the classic three-kernel CG (an fp32 r makes the
+// recurrence drift from the stored vectors -- the known attainable-accuracy loss of pipelined CG variants).
+template <typename T, int NC>
+struct PcgSys {
+    const float *diag[NC];
+    T *x[NC], *q[NC], *s[NC];
+    double *r[NC];
+};
+
+// Blocks loop over tiles with a grid stride (grids are capped at MAX_PCG_BLOCKS so a launch never issues more than
+// that many scalar atomics); `b` is the virtual block index b = blockIdx.x + n*gridDim.x.
+constexpr int MAX_PCG_BLOCKS = 2048;
+template <int N>
+__device__ __forceinline__ bool d_tile_coords(int b, const int *__restrict__ tiles, int ntiles, const TileGrid &tg, int &i0,
+                                              int &j, int &k) {
+    const int slot = d_tile_slot(b, ntiles);
+    if (slot >= ntiles) return false;
+    const int tile = tiles[slot];
     const int tx = tile % tg.ntx;
     const int t2 = tile / tg.ntx;
     const int ty = t2 % tg.nty;
-    const int tz = t2 / tg.nty;
-    i = tx * TX + threadIdx.x;
+    k = t2 / tg.nty;
+    i0 = tx * (64 * N) + threadIdx.x * N;
     j = ty * TY + threadIdx.y;
-    k0 = tz * TZ;
+    return true;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ tiles, int ntiles, TileGrid tg, PcgComps cp,
-                                                  PcgVecs<T> v, PcgScal sc) {
+__device__ __forceinline__ bool d_pass(const PcgScal &sc, double res) { return sc.tol_inclusive ? (res <= sc.tol) : (res < sc.tol); }
+
+// K1 prologue shared by both SpMV kernels: returns true if the launch must do nothing
+__device__ __forceinline__ bool d_spmv_stop(const PcgScal &sc, int it, double *lds8) {
+    if (!sc.conv) return false;  // benchmark launches
+    if (*sc.conv >= 0) return true;
+    if (it > 0 && d_pass(sc, d_fold_max(sc.rmax + (size_t)(it - 1) * NSLOT, lds8))) {
+        // every block takes the same decision from the same completed value; one of them records it
+        if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it - 1;
+        return true;
+    }
+    return false;
+}
+
+template <typename T, int NC, int N>
+__global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
+                                                  PcgSys<T, NC> v, PcgScal sc) {
     __shared__ double lds[4];
-    const int slot = d_tile_slot(blockIdx.x, ntiles);
+    int i0, j, k;
     double acc = 0.0;
-    if (slot < ntiles) {
-        int i, j, k0;
-        d_tile_coords(tiles[slot], tg, i, j, k0);
-        for (int c = 0; c < cp.n; c++) {
-            if (i >= cp.w[c] || j >= cp.h[c]) continue;
-            for (int kk = 0; kk < TZ; kk++) {
-                const int k = k0 + kk;
-                if (k >= cp.d[c]) break;
-                const size_t f = DIDX(i, j, k, cp.w[c], cp.h[c]);
-                const float dg = cp.diag[c][f];
-                const T r = v.r[c][f];
-                const T z = dg != 0.0f ? r / (T)dg : (T)0;
-                v.s[c][f] = z;
-                acc += (double)z * (double)r;
+    const int nvb = ((ntiles + 7) >> 3) << 3;
+    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
+        if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
+        const size_t c = gidx(L, i0, j, k);
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+            const Vec<float, N> d = ldv<N>(v.diag[m] + c);
+            const Vec<double, N> r = ldv<N>(v.r[m] + c);
+            Vec<T, N> z;
+#pragma unroll
+            for (int e = 0; e < N; e++) {
+                const double zd = d.v[e] != 0.0f ? r.v[e] / (double)d.v[e] : 0.0;
+                z.v[e] = (T)zd;
+                acc += zd * r.v[e];
             }
+            stv(v.s[m] + c, z);
         }
     }
     const double tot = block_sum_256(acc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(&sc.sigma[0], tot);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(&sc.sig[blockIdx.x & (NSLOT - 1)], tot);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tiles, int ntiles, TileGrid tg, PcgComps cp,
-                                                    PcgVecs<T> v, PcgScal sc, int it) {
+template <typename T, int NC, int N>
+__global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
+                                                    PcgSys<T, NC> v, PcgScal sc, int it) {
     if (*sc.conv >= 0) return;
-    __shared__ double lds[4];
-    const double dA = sc.dA[it];
-    const double alpha_d = dA != 0.0 ? sc.sigma[it] / dA : 0.0;
+    __shared__ double lds[8];
+    double f[4];
+    const size_t so = (size_t)it * NSLOT;
+    d_fold_sums(sc.sig + so, sc.a + so, sc.b + so, sc.c + so, f, lds);
+    const double sg = f[0], a = f[1];
+    const double alpha_d = a != 0.0 ? sg / a : 0.0;
+    double est = sg - 2.0 * alpha_d * f[2] + alpha_d * alpha_d * f[3];
+    if (!(est > 0.0)) est = 0.0;
     const T alpha = (T)alpha_d;
-    const int slot = d_tile_slot(blockIdx.x, ntiles);
+    const double beta_d = sg != 0.0 ? est / sg : 0.0;
+    int i0, j, k;
     double acc = 0.0, mx = 0.0;
-    if (slot < ntiles) {
-        int i, j, k0;
-        d_tile_coords(tiles[slot], tg, i, j, k0);
-        for (int c = 0; c < cp.n; c++) {
-            if (i >= cp.w[c] || j >= cp.h[c]) continue;
-            for (int kk = 0; kk < TZ; kk++) {
-                const int k = k0 + kk;
-                if (k >= cp.d[c]) break;
-                const size_t f = DIDX(i, j, k, cp.w[c], cp.h[c]);
-                const float dg = cp.diag[c][f];
-                if (dg == 0.0f) continue;  // not an unknown: x, r, s stay 0
-                const T s = v.s[c][f], z = v.z[c][f];
-                v.x[c][f] += alpha * s;
-                const T r = v.r[c][f] - alpha * z;
-                v.r[c][f] = r;
-                mx = fmax(mx, fabs((double)r));
-                acc += ((double)r / (double)dg) * (double)r;
+    const int nvb = ((ntiles + 7) >> 3) << 3;
+    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
+        if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
+        const size_t c = gidx(L, i0, j, k);
+#pragma unroll
+        for (int m = 0; m < NC; m++) {
+            const Vec<float, N> d = ldv<N>(v.diag[m] + c);
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < N; e++) any = any || d.v[e] != 0.0f;
+            if (!any) continue;  // no unknowns here
+            Vec<T, N> x = ldv<N>(v.x[m] + c), s = ldv<N>(v.s[m] + c);
+            Vec<double, N> r = ldv<N>(v.r[m] + c);
+            const Vec<T, N> q = ldv<N>(v.q[m] + c);
+#pragma unroll
+            for (int e = 0; e < N; e++) {
+                if (d.v[e] != 0.0f) {
+                    x.v[e] += alpha * s.v[e];
+                    const double rn = r.v[e] - alpha_d * (double)q.v[e];
+                    const double zn = rn / (double)d.v[e];
+                    r.v[e] = rn;
+                    s.v[e] = (T)(zn + beta_d * (double)s.v[e]);
+                    mx = fmax(mx, fabs(rn));
+                    acc += zn * rn;
+                }
             }
+            stv(v.x[m] + c, x);
+            stv(v.r[m] + c, r);
+            stv(v.s[m] + c, s);
         }
     }
     const double tot = block_sum_256(acc, lds);
     const double bm = block_max_256(mx, lds);
     if (threadIdx.x == 0 && threadIdx.y == 0) {
-        if (tot != 0.0) atomicAdd(&sc.sigma[it + 1], tot);
-        if (bm > 0.0) atomic_max_nonneg(&sc.rmax[it], bm);
+        const int sl = blockIdx.x & (NSLOT - 1);
+        if (tot != 0.0) atomicAdd(&sc.sig[so + NSLOT + sl], tot);
+        if (bm > 0.0) atomic_max_nonneg(&sc.rmax[so + sl], bm);
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_pcg_dir(const int *__restrict__ tiles, int ntiles, TileGrid tg, PcgComps cp,
-                                                 PcgVecs<T> v, PcgScal sc, int it) {
-    if (*sc.conv >= 0) return;
-    const double res = sc.rmax[it];
-    const bool done = sc.tol_inclusive ? (res <= sc.tol) : (res < sc.tol);
-    if (done) {
-        // every block takes the same decision from the same completed value; one of them records it
-        if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it;
-        return;
-    }
-    const double sg = sc.sigma[it];
-    const T beta = (T)(sg != 0.0 ? sc.sigma[it + 1] / sg : 0.0);
-    const int slot = d_tile_slot(blockIdx.x, ntiles);
-    if (slot >= ntiles) return;
-    int i, j, k0;
-    d_tile_coords(tiles[slot], tg, i, j, k0);
-    for (int c = 0; c < cp.n; c++) {
-        if (i >= cp.w[c] || j >= cp.h[c]) continue;
-        for (int kk = 0; kk < TZ; kk++) {
-            const int k = k0 + kk;
-            if (k >= cp.d[c]) break;
-            const size_t f = DIDX(i, j, k, cp.w[c], cp.h[c]);
-            const float dg = cp.diag[c][f];
-            if (dg == 0.0f) continue;
-            v.s[c][f] = v.r[c][f] / (T)dg + beta * v.s[c][f];
-        }
-    }
+// after a chunk of iterations: record convergence of the chunk's last iteration (K1 of the next iteration would)
+static __global__ void k_pcg_check(PcgScal sc, int it_last) {  // <<<1, 64>>>
+    __shared__ double lds[8];
+    const double res = d_fold_max(sc.rmax + (size_t)it_last * NSLOT, lds);
+    if (threadIdx.x == 0 && *sc.conv < 0 && d_pass(sc, res)) *sc.conv = it_last;
+}
+// final residual of iteration `it` into out[0]
+static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<1, 64>>>
+    __shared__ double lds[8];
+    const double res = d_fold_max(sc.rmax + (size_t)it * NSLOT, lds);
+    if (threadIdx.x == 0) out[0] = res;
 }
 
-// Race note for k_pcg_dir: block 0 writes *conv while other blocks of the SAME launch may still read it at
-// their top.  They read either -1 (and then take the same `done` branch from rmax[it]) or `it` (return) --
-// both leave s untouched, so the outcome is identical.
-
-// ---- host-side driver --------------------------------------------------------------------------
-struct PcgHost {
-    flipv_context *c;
-    PcgComps cp;
-    PcgScal sc;
-    int cap;
-};
-
-int fv_scal_reserve(flipv_context *c, int cap);             // makes d_scal hold 3*(cap+2) doubles
-int fv_build_tiles(flipv_context *c, const PcgComps &cp, int *list, int *nActive);
+// ---- host-side helpers (k_pressure.hip) ----
+int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT+16 doubles
+static inline int pcg_grid(int ntiles) { const int nb = ((ntiles + 7) / 8) * 8; return nb < MAX_PCG_BLOCKS ? nb : MAX_PCG_BLOCKS; }
+int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
+                   int *list, int *nActive);
+void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
