@@ -23,7 +23,7 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
                                  const float *__restrict__ V, const float *__restrict__ W,
                                  const float *__restrict__ wU, const float *__restrict__ wV,
                                  const float *__restrict__ wW, float *__restrict__ diag, float *__restrict__ pi,
-                                 float *__restrict__ pj, float *__restrict__ pk, double *__restrict__ r, T *__restrict__ x,
+                                 float *__restrict__ pj, float *__restrict__ pk, RT<T> *__restrict__ r, T *__restrict__ x,
                                  T *__restrict__ s, double *__restrict__ bmax, float dxf, float dtf, float minfrac) {
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
@@ -70,7 +70,7 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
             if (dg == 0.0f) b = 0.0;  // a cell with no open face has an all-zero row; keep it out of the system
         }
         diag[c] = dg; pi[c] = ci; pj[c] = cj; pk[c] = ck;
-        r[c] = b;
+        r[c] = (RT<T>)b;
         x[c] = (T)0;
         s[c] = (T)0;
         babs = fabs(b);
@@ -85,7 +85,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                        const float *__restrict__ diag, const float *__restrict__ pi,
                                                        const float *__restrict__ pj, const float *__restrict__ pk,
-                                                       const T *__restrict__ s, const double *__restrict__ r,
+                                                       const T *__restrict__ s, const RT<T> *__restrict__ r,
                                                        T *__restrict__ q, PcgScal sc, int it) {
     __shared__ double lds[12];
     if (d_spmv_stop(sc, it, lds)) return;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
         const Vec<float, 4> dg = ldv<4>(diag + c), ci = ldv<4>(pi + c), cj = ldv<4>(pj + c), ck = ldv<4>(pk + c);
         const Vec<float, 4> cjm = ldv<4>(pj + c - sy), ckm = ldv<4>(pk + c - sz);
         const Vec<T, 4> sc4 = ldv<4>(s + c), sjm = ldv<4>(s + c - sy), sjp = ldv<4>(s + c + sy), skm = ldv<4>(s + c - sz), skp = ldv<4>(s + c + sz);
-        const Vec<double, 4> r4 = ldv<4>(r + c);
+        const Vec<RT<T>, 4> r4 = ldv<4>(r + c);
         const T sl = nb_left(sc4, s + c, i0), sr = nb_right(sc4, s + c, i0, L.I);
         const float cil = nb_left(ci, pi + c, i0);
         Vec<T, 4> y;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
             if (dg.v[e] != 0.0f) {
                 const double yd = (double)acc, inv = 1.0 / (double)dg.v[e];
                 da += (double)sc4.v[e] * yd;
-                db += r4.v[e] * inv * yd;
+                db += (double)r4.v[e] * inv * yd;
                 dc += yd * inv * yd;
             }
         }
@@ -227,7 +227,7 @@ static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it) {
     const int nb = pcg_grid(c->nActiveP);
     if (c->prm.kernel_timing) fv_ev_begin(c, 0, (double)c->nActiveP * (64 * VW_P * TY));
     hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const double *)c->pR, (T *)c->pZ, sc, it);
+                       c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it);
     if (c->prm.kernel_timing) fv_ev_end(c);
 }
 
@@ -253,7 +253,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     constexpr bool f32 = std::is_same<T, float>::value;
     T *x = f32 ? (T *)c->pressure : (T *)c->pX;
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(L), 0, c->stream, L, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, (double *)c->pR, x, (T *)c->pS, bmax, c->dx, dt, c->prm.min_frac);
+                       c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, bmax, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->tileListP, &c->nActiveP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
@@ -274,7 +274,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     sc.tol = fmax(c->prm.pressure_tolerance, c->prm.pressure_rel_tolerance * bnorm);
 
     PcgSys<T, 1> v;
-    v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (double *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
+    v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
     const int nb = pcg_grid(c->nActiveP);
     const dim3 blk(64, 4, 1);
     hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);

@@ -282,7 +282,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
         vmU[c] = vm[0]; vmV[c] = vm[1]; vmW[c] = vm[2];
 #pragma unroll
         for (int m = 0; m < 3; m++) {
-            v.r[m][c] = (double)rv[m]; v.x[m][c] = (T)0; v.s[m][c] = (T)0;
+            v.r[m][c] = (RT<T>)rv[m]; v.x[m][c] = (T)0; v.s[m][c] = (T)0;
             babs = fmax(babs, fabs((double)rv[m]));
             rows += dg[m] != 0.0f;
         }
@@ -309,7 +309,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
 #define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
 #define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
 template <typename T>
-__global__ __launch_bounds__(256) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
+__global__ __launch_bounds__(256, 4) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                    const float *__restrict__ vmU, const float *__restrict__ vmV,
                                                    const float *__restrict__ vmW, const float *__restrict__ fC,
                                                    const float *__restrict__ fEU, const float *__restrict__ fEV,
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_visc_spmv(const int *__restrict__ tiles
         const T Ujmr = nb_right(Ujm, xu + c - sy, i0, I), Ukmr = nb_right(Ukm, xu + c - sz, i0, I);
         // ---- own volumes (row masks) and residuals
         const Vec<float, NV> MU = ldv<NV>(vmU + c), MV = ldv<NV>(vmV + c), MW = ldv<NV>(vmW + c);
-        const Vec<double, NV> RU = ldv<NV>(v.r[0] + c), RV = ldv<NV>(v.r[1] + c), RW = ldv<NV>(v.r[2] + c);
+        const Vec<RT<T>, NV> RU = ldv<NV>(v.r[0] + c), RV = ldv<NV>(v.r[1] + c), RW = ldv<NV>(v.r[2] + c);
         Vec<T, NV> yU, yV, yW;
 #pragma unroll
         for (int e = 0; e < NV; e++) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_visc_spmv(const int *__restrict__ tiles
                     y = (T)MU.v[e] * uc - txx - txy - txz;
                     const float dg = MU.v[e] + fR + fL + fT + fB + fF + fK;  // same order as k_visc_setup
                     const double yd = (double)y, inv = 1.0 / (double)dg;
-                    da += (double)uc * yd; db += RU.v[e] * inv * yd; dc += yd * inv * yd;
+                    da += (double)uc * yd; db += (double)RU.v[e] * inv * yd; dc += yd * inv * yd;
                 }
                 yU.v[e] = y;
             }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_visc_spmv(const int *__restrict__ tiles
                     y = (T)MV.v[e] * vc - tyy - txy - tyz;
                     const float dg = MV.v[e] + fR + fL + fT + fB + fF + fK;
                     const double yd = (double)y, inv = 1.0 / (double)dg;
-                    da += (double)vc * yd; db += RV.v[e] * inv * yd; dc += yd * inv * yd;
+                    da += (double)vc * yd; db += (double)RV.v[e] * inv * yd; dc += yd * inv * yd;
                 }
                 yV.v[e] = y;
             }
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_visc_spmv(const int *__restrict__ tiles
                     y = (T)MW.v[e] * wc - tzz - txz - tyz;
                     const float dg = MW.v[e] + fR + fL + fT + fB + fF + fK;
                     const double yd = (double)y, inv = 1.0 / (double)dg;
-                    da += (double)wc * yd; db += RW.v[e] * inv * yd; dc += yd * inv * yd;
+                    da += (double)wc * yd; db += (double)RW.v[e] * inv * yd; dc += yd * inv * yd;
                 }
                 yW.v[e] = y;
             }
@@ -421,7 +421,7 @@ template <typename T>
 static PcgSys<T, 3> visc_sys(flipv_context *c) {
     PcgSys<T, 3> v;
     v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
-    for (int m = 0; m < 3; m++) { v.x[m] = (T *)c->vX[m]; v.r[m] = (double *)c->vR[m]; v.q[m] = (T *)c->vZ[m]; v.s[m] = (T *)c->vS[m]; }
+    for (int m = 0; m < 3; m++) { v.x[m] = (T *)c->vX[m]; v.r[m] = (RT<T> *)c->vR[m]; v.q[m] = (T *)c->vZ[m]; v.s[m] = (T *)c->vS[m]; }
     return v;
 }
 

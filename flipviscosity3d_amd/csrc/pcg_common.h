@@ -151,14 +151,23 @@ __device__ __forceinline__ void block_sum3_256(double &a, double &b, double &c, 
     __syncthreads();
 }
 
-// x, s (search direction), q = A s are stored in T (fp32 by default); the residual r is ALWAYS fp64: with an exact
-// residual recurrence the fused beta below is as stable as the classic three-kernel CG (an fp32 r makes the
-// recurrence drift from the stored vectors -- the known attainable-accuracy loss of pipelined CG variants).
+// x, s (search direction), q = A s and the residual r are stored in T (fp32 by default, fp64 with
+// flipv_params.precision = 1).  -DFLIPV_R64=1 keeps r in fp64 even for T = float (measured: no gain in attainable
+// accuracy once the SpMV is evaluated in difference form, 9 % slower).
+#ifndef FLIPV_R64
+#define FLIPV_R64 0
+#endif
+#if FLIPV_R64
+template <typename T> using RT = double;
+#else
+template <typename T> using RT = T;
+#endif
+
 template <typename T, int NC>
 struct PcgSys {
     const float *diag[NC];
     T *x[NC], *q[NC], *s[NC];
-    double *r[NC];
+    RT<T> *r[NC];
 };
 
 // Blocks loop over tiles with a grid stride (grids are capped at MAX_PCG_BLOCKS so a launch never issues more than
@@ -206,13 +215,13 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ tiles,
 #pragma unroll
         for (int m = 0; m < NC; m++) {
             const Vec<float, N> d = ldv<N>(v.diag[m] + c);
-            const Vec<double, N> r = ldv<N>(v.r[m] + c);
+            const Vec<RT<T>, N> r = ldv<N>(v.r[m] + c);
             Vec<T, N> z;
 #pragma unroll
             for (int e = 0; e < N; e++) {
-                const double zd = d.v[e] != 0.0f ? r.v[e] / (double)d.v[e] : 0.0;
+                const double zd = d.v[e] != 0.0f ? (double)r.v[e] / (double)d.v[e] : 0.0;
                 z.v[e] = (T)zd;
-                acc += zd * r.v[e];
+                acc += zd * (double)r.v[e];
             }
             stv(v.s[m] + c, z);
         }
@@ -249,15 +258,16 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
             for (int e = 0; e < N; e++) any = any || d.v[e] != 0.0f;
             if (!any) continue;  // no unknowns here
             Vec<T, N> x = ldv<N>(v.x[m] + c), s = ldv<N>(v.s[m] + c);
-            Vec<double, N> r = ldv<N>(v.r[m] + c);
+            Vec<RT<T>, N> r = ldv<N>(v.r[m] + c);
             const Vec<T, N> q = ldv<N>(v.q[m] + c);
 #pragma unroll
             for (int e = 0; e < N; e++) {
                 if (d.v[e] != 0.0f) {
                     x.v[e] += alpha * s.v[e];
-                    const double rn = r.v[e] - alpha_d * (double)q.v[e];
+                    const RT<T> rn_t = (RT<T>)((double)r.v[e] - alpha_d * (double)q.v[e]);
+                    const double rn = (double)rn_t;
                     const double zn = rn / (double)d.v[e];
-                    r.v[e] = rn;
+                    r.v[e] = rn_t;
                     s.v[e] = (T)(zn + beta_d * (double)s.v[e]);
                     mx = fmax(mx, fabs(rn));
                     acc += zn * rn;
