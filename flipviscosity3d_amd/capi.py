@@ -20,7 +20,7 @@ VOLUME_IDS = dict(center=0, U=1, V=2, W=3, edgeU=4, edgeV=5, edgeW=6)
 
 # every symbol include/flipv.h declares (tests/test_abi.py checks the header against this and the .so)
 SYMBOLS = [
-    "flipv_create", "flipv_create_on_device", "flipv_destroy", "flipv_last_error", "flipv_device_name",
+    "flipv_create", "flipv_create_on_device", "flipv_create_slab", "flipv_slab_range", "flipv_destroy", "flipv_last_error", "flipv_device_name",
     "flipv_default_params", "flipv_set_params", "flipv_get_params", "flipv_set_gravity",
     "flipv_set_solid_sdf", "flipv_set_viscosity_uniform", "flipv_set_viscosity",
     "flipv_upload_particles", "flipv_download_particles", "flipv_num_particles",
@@ -31,6 +31,8 @@ SYMBOLS = [
     "flipv_advect_particles", "flipv_read_viscosity_volume", "flipv_substep", "flipv_advance",
     "flipv_kernel_stats_reset", "flipv_kernel_stats_get", "flipv_synchronize", "flipv_bench_spmv",
     "flipv_bench_copy",
+    "flipv_comm_unique_id_bytes", "flipv_comm_get_unique_id", "flipv_comm_init_rccl", "flipv_comm_init_local",
+    "flipv_comm_finalize",
 ]
 
 
@@ -89,6 +91,12 @@ def load():
     ctx = C.c_void_p
     L.flipv_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.POINTER(ctx)]
     L.flipv_create_on_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(ctx)]
+    L.flipv_create_slab.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(ctx)]
+    L.flipv_slab_range.argtypes = [ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.flipv_comm_get_unique_id.argtypes = [C.c_void_p]
+    L.flipv_comm_init_rccl.argtypes = [ctx, C.c_void_p, C.c_int, C.c_int]
+    L.flipv_comm_init_local.argtypes = [C.POINTER(ctx), C.c_int]
+    L.flipv_comm_finalize.argtypes = [ctx]
     L.flipv_destroy.argtypes = [ctx]
     L.flipv_last_error.restype = C.c_char_p
     L.flipv_last_error.argtypes = [ctx]
@@ -152,12 +160,17 @@ def _F(a):
 class Context:
     """Owns one flipv_context (device state of one simulation / one rank)."""
 
-    def __init__(self, I, J, K, dx, device=None):
+    def __init__(self, I, J, K, dx, device=None, slab=None):
+        """slab = (k_begin, k_end): one rank of a slab decomposition along k (global grid I x J x K)."""
         self.L = load()
         self.I, self.J, self.K = int(I), int(J), int(K)
         self.dx = float(np.float32(dx))
+        self.slab = slab
         h = C.c_void_p()
-        if device is None:
+        if slab is not None:
+            rc = self.L.flipv_create_slab(self.I, self.J, self.K, C.c_float(dx), int(device or 0), int(slab[0]), int(slab[1]),
+                                          C.byref(h))
+        elif device is None:
             rc = self.L.flipv_create(self.I, self.J, self.K, C.c_float(dx), C.byref(h))
         else:
             rc = self.L.flipv_create_on_device(self.I, self.J, self.K, C.c_float(dx), int(device), C.byref(h))
@@ -180,6 +193,14 @@ class Context:
         if rc < 0:
             raise FlipvError("%s failed (%d): %s" % (what, rc, self.L.flipv_last_error(self.h).decode()))
         return rc
+
+    # ---- multi-GPU
+    def comm_init_rccl(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self.L.flipv_comm_init_rccl(self.h, buf, rank, nranks), "flipv_comm_init_rccl")
+
+    def comm_finalize(self):
+        self._chk(self.L.flipv_comm_finalize(self.h), "flipv_comm_finalize")
 
     # ---- configuration
     def device_name(self):
@@ -339,3 +360,22 @@ class Context:
         g = C.c_double()
         self._chk(self.L.flipv_bench_copy(self.h, nbytes, reps, C.byref(g)), "flipv_bench_copy")
         return g.value
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0 only); returns 128 bytes to broadcast."""
+    L = load()
+    buf = C.create_string_buffer(128)
+    rc = L.flipv_comm_get_unique_id(buf)
+    if rc != 0:
+        raise FlipvError("flipv_comm_get_unique_id failed (%d)" % rc)
+    return buf.raw
+
+
+def comm_init_local(contexts):
+    """Attach the in-process verification communicator to N slab contexts of this process."""
+    L = load()
+    arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    rc = L.flipv_comm_init_local(arr, len(contexts))
+    if rc != 0:
+        raise FlipvError("flipv_comm_init_local failed (%d)" % rc)

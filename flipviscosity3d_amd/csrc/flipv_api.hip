@@ -2,6 +2,7 @@
 // transfers (reference Array3d layout at the ABI, shared padded index space on the device), and the substep
 // sequencing of FluidSimulation::advance (reference fluidsimulation.cpp:135-168).
 #include "flipv_internal.h"
+#include "flipv_comm.h"
 
 #include <new>
 
@@ -63,11 +64,15 @@ extern "C" int flipv_default_params(flipv_params *p) {
 
 extern "C" const char *flipv_last_error(flipv_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-extern "C" int flipv_create_on_device(int I, int J, int K, float dx, int dev, flipv_context **out) {
+extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbegin, int kend, flipv_context **out) {
     if (!out) return FLIPV_ERR_INVALID;
     *out = nullptr;
     if (I < 1 || J < 1 || K < 1 || !(dx > 0.0f)) {
         g_create_error = "flipv_create: grid dimensions must be >= 1 and dx > 0";
+        return FLIPV_ERR_INVALID;
+    }
+    if (kbegin < 0 || kend > K || kbegin >= kend) {
+        g_create_error = "flipv_create_slab: need 0 <= k_begin < k_end <= K";
         return FLIPV_ERR_INVALID;
     }
     int ndev = 0;
@@ -87,6 +92,13 @@ extern "C" int flipv_create_on_device(int I, int J, int K, float dx, int dev, fl
     L.sy = L.PX; L.sz = (long)L.PX * L.PY;
     L.n = (size_t)L.sz * L.PZ;
     L.guard = (((size_t)L.sz + (size_t)L.sy + 8) + 63) / 64 * 64;
+    L.kb = 0; L.ke = L.PZ;
+    c->k0 = kbegin;
+    c->k1 = kend == K ? L.PZ : kend;  // the last slab also owns the closing plane of W faces / nodes
+    c->comm = nullptr;
+    c->pScratch = nullptr; c->pScratchCap = 0;
+    c->haloBuf = nullptr; c->haloCap = 0;
+    c->d_scal_small = nullptr;
     c->dx = dx;
     c->device = dev;
     c->np = c->pcap = 0;
@@ -119,6 +131,7 @@ extern "C" int flipv_create_on_device(int I, int J, int K, float dx, int dev, fl
     GALLOC(c->stampU); GALLOC(c->stampV); GALLOC(c->stampW);
     {
         int rc_ = plain_alloc(c, &c->d_flags, 16);
+        if (!rc_) rc_ = plain_alloc(c, &c->d_scal_small, 64);
         if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
     }
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
@@ -160,12 +173,21 @@ extern "C" int flipv_create_on_device(int I, int J, int K, float dx, int dev, fl
     // defaults of initialize(): viscosity 1.0 at every node (fluidsimulation.cpp:39), liquid phi = 3 dx
     int rc = flipv_set_viscosity_uniform(c, 1.0f);
     if (rc == FLIPV_OK) {
-        rc = fv_fill_cells(c, c->phi, 3.0f * dx);
+        Lay all = c->L;
+        (void)all;
+        const int k0s = c->k0, k1s = c->k1;
+        c->k0 = 0; c->k1 = c->L.PZ;            // the initial liquid SDF is "far" everywhere
+        rc = fv_fill_cells(c, c->phi, 3.0f * dx, 0);
+        c->k0 = k0s; c->k1 = k1s;
         if (hipStreamSynchronize(c->stream) != hipSuccess) rc = FLIPV_ERR_HIP;
     }
     if (rc != FLIPV_OK) { g_create_error = c->err; flipv_destroy(c); return rc; }
     *out = c;
     return FLIPV_OK;
+}
+
+extern "C" int flipv_create_on_device(int I, int J, int K, float dx, int dev, flipv_context **out) {
+    return flipv_create_slab(I, J, K, dx, dev, 0, K, out);
 }
 
 extern "C" int flipv_create(int I, int J, int K, float dx, flipv_context **out) {
@@ -174,12 +196,22 @@ extern "C" int flipv_create(int I, int J, int K, float dx, flipv_context **out) 
     return flipv_create_on_device(I, J, K, dx, dev, out);
 }
 
+extern "C" int flipv_slab_range(flipv_context *c, int *kbegin, int *kend) {
+    if (!c || !kbegin || !kend) return FLIPV_ERR_INVALID;
+    *kbegin = c->k0;
+    *kend = c->k1 >= c->L.PZ ? c->L.K : c->k1;
+    return FLIPV_OK;
+}
+
 extern "C" int flipv_destroy(flipv_context *c) {
     if (!c) return FLIPV_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { delete c->comm; c->comm = nullptr; }
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->particles) (void)hipFree(c->particles);
+    if (c->pScratch) (void)hipFree(c->pScratch);
+    if (c->haloBuf) (void)hipFree(c->haloBuf);
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
@@ -350,10 +382,11 @@ extern "C" int flipv_p2g(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_p2g(c)); }
 extern "C" int flipv_extrapolate(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_extrapolate(c)); }
 
 static int save_velocity(flipv_context *c) {
-    const size_t bytes = c->L.n * 4;
-    HIPCHK(c, hipMemcpyAsync(c->sU, c->U, bytes, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sV, c->V, bytes, hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->sW, c->W, bytes, hipMemcpyDeviceToDevice, c->stream));
+    const Lay R = fv_range(c, 1);
+    const size_t off = (size_t)R.kb * c->L.sz, bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
+    HIPCHK(c, hipMemcpyAsync(c->sU + off, c->U + off, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sV + off, c->V + off, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->sW + off, c->W + off, bytes, hipMemcpyDeviceToDevice, c->stream));
     return FLIPV_OK;
 }
 extern "C" int flipv_save_velocity(flipv_context *c) { ENTER(c); SYNC_RET(c, save_velocity(c)); }

@@ -1,0 +1,43 @@
+// flipv_comm.h -- communication layer of the slab decomposition (the reference is single-process,
+// there is nothing to translate).
+//
+// Decomposition: slabs along k, the slowest axis of the Array3d layout, so a halo is a whole number of
+// contiguous PX*PY planes.  Every rank indexes the GLOBAL grid (its arrays span the whole index space, only its
+// own planes [k0,k1) plus a few halo planes ever hold data), which keeps every kernel identical to the single-GPU
+// one; 288 GB per GPU makes the replicated allocation affordable (8 x 256^3 stacked: ~50 GB per rank).
+//
+// Three exchange patterns, all enqueued on the context's stream:
+//   halo copy    owner -> neighbour copies of the H boundary planes of a set of arrays      (s before every SpMV,
+//                velocities/valid masks per extrapolation layer, phi, pressure, ...)
+//   halo reduce  neighbour -> owner contributions on planes a rank scattered into but does not own, combined
+//                with min (particle SDF) or + (P2G accumulators)
+//   all-reduce   the PCG scalars.  Ranks accumulate into DISJOINT slots of the per-iteration slot block, so one
+//                sum all-reduce merges sums and maxima alike: 2 small all-reduces per PCG iteration
+//   migration    particles that left the slab go to the neighbour owning their cell (counts first, then records)
+//
+// Backends: RCCL (one process per GPU, ncclSend/ncclRecv grouped per exchange, ncclAllReduce; librccl is
+// dlopen'ed on first use so single-GPU runs never load it) and an in-process backend (N contexts in one process on
+// one device, one host thread per rank, rendezvous through host memory) that exists so the decomposition can be
+// verified against the single-domain result on a one-GPU box.
+#pragma once
+#include "flipv_internal.h"
+
+struct Comm {
+    int rank = 0, nranks = 1;
+    virtual ~Comm() {}
+    virtual int begin(flipv_context *c) = 0;   // open a group of point-to-point operations
+    // exchange with rank `peer` (rank-1 or rank+1): device buffers; either side may be empty (bytes == 0)
+    virtual int sendrecv(flipv_context *c, int peer, const void *sendbuf, size_t sbytes, void *recvbuf, size_t rbytes) = 0;
+    virtual int end(flipv_context *c) = 0;     // close the group: after it returns the operations are enqueued
+    virtual int allreduce_sum(flipv_context *c, double *dev, size_t n) = 0;
+    virtual int barrier(flipv_context *c) = 0;
+};
+
+// halo helpers (flipv_comm.hip)
+struct HaloArray { void *p; size_t elem; };
+int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H);
+enum { HALO_MIN_F32 = 0, HALO_ADD_F32 = 1 };
+int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op);
+int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n);
+int fv_migrate_particles(flipv_context *c);
+int fv_allreduce_max_f32(flipv_context *c, float *value);  // host value in/out (synchronises)

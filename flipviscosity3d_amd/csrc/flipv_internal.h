@@ -27,11 +27,12 @@
 // addresses.  Conversion to/from Array3d happens in flipv_read_grid / flipv_write_grid (k_pack/k_unpack).
 // ---------------------------------------------------------------------------------------------
 struct Lay {
-    int I, J, K;     // cells
+    int I, J, K;     // cells (GLOBAL grid: every rank of a slab decomposition indexes the whole domain)
     int PX, PY, PZ;  // padded index space
     long sy, sz;     // strides of j and k
     size_t n;        // PX*PY*PZ
     size_t guard;    // floats of guard zone in front of / behind every array
+    int kb, ke;      // k-planes [kb, ke) a pointwise launch covers (GRID3 / IJK_OR_RETURN)
 };
 
 __host__ __device__ __forceinline__ size_t gidx(const Lay &L, int i, int j, int k) {
@@ -57,8 +58,13 @@ struct TileGrid {
     __host__ __device__ int count() const { return ntx * nty * ntz; }
 };
 
+struct Comm;
+
 struct flipv_context {
-    Lay L;
+    Lay L;           // kb/ke = the whole index space; per-launch ranges come from fv_range()
+    // slab decomposition along k: this rank owns index planes [k0, k1) (k1 = PZ on the last rank).  Single GPU: [0, PZ).
+    int k0, k1;
+    Comm *comm;      // nullptr on a single GPU
     float dx;
     int device;
     hipStream_t stream;
@@ -73,6 +79,10 @@ struct flipv_context {
     // particles
     float *particles;  // AoS 6 floats, caller's order
     size_t np, pcap;
+    float *pScratch;   // migration staging (same capacity)
+    size_t pScratchCap;
+    float *haloBuf;    // receive staging for halo reductions
+    size_t haloCap;
     // P2G accumulators (value, weight) per component
     float *accU, *accV, *accW, *wgtU, *wgtV, *wgtW;
     // extrapolation stamps
@@ -82,6 +92,7 @@ struct flipv_context {
     size_t stageCap;
     // scalars
     double *d_scal;   // device scalar scratch (PCG)
+    double *d_scal_small;  // 64 doubles: communication scratch (counts, CFL max, barrier)
     double *h_scal;   // pinned host mirror
     size_t scalCap;
     int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits
@@ -131,10 +142,18 @@ struct flipv_context {
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
+// launch range: the owned planes widened by `halo` planes on each side, clipped to the index space
+static inline Lay fv_range(const flipv_context *c, int halo) {
+    Lay L = c->L;
+    L.kb = c->k0 - halo < 0 ? 0 : c->k0 - halo;
+    L.ke = c->k1 + halo > L.PZ ? L.PZ : c->k1 + halo;
+    return L;
+}
+
 // pointwise kernels: one thread per index of the padded space; a wave = 64 consecutive i of one row
-#define GRID3(L) dim3(cdiv((L).PX, 64), cdiv((L).PY, 4), (unsigned)(L).PZ), dim3(64, 4, 1)
+#define GRID3(L) dim3(cdiv((L).PX, 64), cdiv((L).PY, 4), (unsigned)((L).ke - (L).kb)), dim3(64, 4, 1)
 #define IJK_OR_RETURN(L)                                                                              \
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;   \
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + (L).kb;   \
     if (i >= (L).PX || j >= (L).PY) return;                                                            \
     const size_t c = gidx((L), i, j, k);                                                                \
     (void)c
@@ -275,7 +294,7 @@ int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info);
 int fv_pack(flipv_context *c, int lat, const float *src_f32, const uint8_t *src_u8, float *linear);   // device -> Array3d order
 int fv_unpack(flipv_context *c, int lat, const float *linear, float *dst_f32, uint8_t *dst_u8);       // Array3d order -> device
 int fv_fill(flipv_context *c, float *p, size_t n, float v);
-int fv_fill_cells(flipv_context *c, float *p, float v);
+int fv_fill_cells(flipv_context *c, float *p, float v, int halo);
 
 // event-pool helpers for kernel timing
 void fv_ev_begin(flipv_context *c, int which, double cells);

@@ -5,6 +5,7 @@
 // a whole number of aligned 256-byte lines and no integer division is needed to recover (i,j,k).
 // All of these are HBM-bound with 5..20 B per face.
 #include "flipv_internal.h"
+#include "flipv_comm.h"
 
 // ------------------------------------------------------------------ Array3d <-> device layout
 // linear = the reference's Array3d order for lattice `lat` (flat = i + w*(j + h*k), array3d.h:397-400)
@@ -232,6 +233,7 @@ __global__ void k_absmax3(const float *__restrict__ a, const float *__restrict__
 }
 
 // =================================================================== host launchers
+// Ranges: fv_range(c, h) = the planes this rank owns widened by h halo planes (the whole index space on one GPU).
 static unsigned grid1d(size_t n) {
     size_t b = (n + 255) / 256;
     return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));
@@ -249,7 +251,8 @@ int fv_pack(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, f
 }
 
 int fv_sdf_finish(flipv_context *c) {
-    hipLaunchKernelGGL(k_sdf_into_solids, GRID3(c->L), 0, c->stream, c->L, c->phi, c->solid, c->dx);
+    const Lay R = fv_range(c, 0);
+    hipLaunchKernelGGL(k_sdf_into_solids, GRID3(R), 0, c->stream, R, c->phi, c->solid, c->dx);
     return FLIPV_OK;
 }
 
@@ -257,65 +260,82 @@ int fv_fill(flipv_context *c, float *p, size_t n, float v) {
     hipLaunchKernelGGL(k_fill_f32, dim3(grid1d(n)), dim3(256), 0, c->stream, p, n, v);
     return FLIPV_OK;
 }
-int fv_fill_cells(flipv_context *c, float *p, float v) {
-    hipLaunchKernelGGL(k_fill_cells, GRID3(c->L), 0, c->stream, c->L, p, v);
+int fv_fill_cells(flipv_context *c, float *p, float v, int halo) {
+    const Lay R = fv_range(c, halo);
+    hipLaunchKernelGGL(k_fill_cells, GRID3(R), 0, c->stream, R, p, v);
     return FLIPV_OK;
 }
 
 int fv_p2g_finalize(flipv_context *c) {
-    hipLaunchKernelGGL(k_p2g_finalize, GRID3(c->L), 0, c->stream, c->L, c->accU, c->wgtU, c->accV, c->wgtV, c->accW,
-                       c->wgtW, c->phi, c->U, c->V, c->W, c->vU, c->vV, c->vW);
+    const Lay R = fv_range(c, 0);
+    hipLaunchKernelGGL(k_p2g_finalize, GRID3(R), 0, c->stream, R, c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, c->phi,
+                       c->U, c->V, c->W, c->vU, c->vV, c->vW);
     return FLIPV_OK;
 }
 
 int fv_extrapolate(flipv_context *c) {
     const int layers = c->prm.extrapolation_layers > 0 ? c->prm.extrapolation_layers : (int)ceilf(c->prm.cfl_number) + 2;
-    hipLaunchKernelGGL(k_extrap_init, GRID3(c->L), 0, c->stream, c->L, c->vU, c->vV, c->vW, c->stampU, c->stampV, c->stampW);
-    for (int q = 0; q < layers; q++)
-        hipLaunchKernelGGL(k_extrap_layer, GRID3(c->L), 0, c->stream, c->L, c->U, c->V, c->W, c->stampU, c->stampV,
-                           c->stampW, q);
+    const HaloArray in[6] = {{c->U, 4}, {c->V, 4}, {c->W, 4}, {c->vU, 1}, {c->vV, 1}, {c->vW, 1}};
+    int rc = fv_halo_copy(c, in, 6, 1);
+    if (rc) return rc;
+    const Lay R1 = fv_range(c, 1), R0 = fv_range(c, 0);
+    hipLaunchKernelGGL(k_extrap_init, GRID3(R1), 0, c->stream, R1, c->vU, c->vV, c->vW, c->stampU, c->stampV, c->stampW);
+    const HaloArray lay[6] = {{c->U, 4}, {c->V, 4}, {c->W, 4}, {c->stampU, 1}, {c->stampV, 1}, {c->stampW, 1}};
+    for (int q = 0; q < layers; q++) {
+        hipLaunchKernelGGL(k_extrap_layer, GRID3(R0), 0, c->stream, R0, c->U, c->V, c->W, c->stampU, c->stampV, c->stampW, q);
+        rc = fv_halo_copy(c, lay, 6, 1);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 
 int fv_body_force(flipv_context *c, float dt) {
-    hipLaunchKernelGGL(k_body_force, GRID3(c->L), 0, c->stream, c->L, c->U, c->V, c->W, c->phi, c->gravity[0] * dt,
-                       c->gravity[1] * dt, c->gravity[2] * dt);
+    const Lay R = fv_range(c, 1);
+    hipLaunchKernelGGL(k_body_force, GRID3(R), 0, c->stream, R, c->U, c->V, c->W, c->phi, c->gravity[0] * dt, c->gravity[1] * dt,
+                       c->gravity[2] * dt);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 
 int fv_compute_weights(flipv_context *c) {
-    hipLaunchKernelGGL(k_weights, GRID3(c->L), 0, c->stream, c->L, c->solid, c->wU, c->wV, c->wW);
+    const Lay R = fv_range(c, 2);
+    hipLaunchKernelGGL(k_weights, GRID3(R), 0, c->stream, R, c->solid, c->wU, c->wV, c->wW);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 
 int fv_apply_pressure(flipv_context *c, float dt) {
-    hipLaunchKernelGGL(k_apply_pressure, GRID3(c->L), 0, c->stream, c->L, c->U, c->V, c->W, c->vU, c->vV, c->vW, c->wU,
-                       c->wV, c->wW, c->pressure, c->phi, c->dx, dt, c->prm.min_frac);
+    const Lay R = fv_range(c, 0);
+    hipLaunchKernelGGL(k_apply_pressure, GRID3(R), 0, c->stream, R, c->U, c->V, c->W, c->vU, c->vV, c->vW, c->wU, c->wV, c->wW,
+                       c->pressure, c->phi, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 
 int fv_constrain(flipv_context *c) {
-    const size_t n = c->L.n;
-    hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wU, c->U, c->sU, n);
-    hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wV, c->V, c->sV, n);
-    hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wW, c->W, c->sW, n);
+    const Lay R = fv_range(c, 1);
+    const size_t off = (size_t)R.kb * c->L.sz, n = (size_t)(R.ke - R.kb) * c->L.sz;
+    hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wU + off, c->U + off, c->sU + off, n);
+    hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wV + off, c->V + off, c->sV + off, n);
+    hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wW + off, c->W + off, c->sW + off, n);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 
 int fv_cfl(flipv_context *c, float *dt_out) {
     unsigned *bits = (unsigned *)(c->d_flags + 3);
+    const Lay R = fv_range(c, 0);
+    const size_t off = (size_t)R.kb * c->L.sz, n = (size_t)(R.ke - R.kb) * c->L.sz;
     HIPCHK(c, hipMemsetAsync(bits, 0, sizeof(unsigned), c->stream));
-    hipLaunchKernelGGL(k_absmax3, dim3(grid1d(c->L.n)), dim3(256), 0, c->stream, c->U, c->V, c->W, c->L.n, bits);
+    hipLaunchKernelGGL(k_absmax3, dim3(grid1d(n)), dim3(256), 0, c->stream, c->U + off, c->V + off, c->W + off, n, bits);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 3, bits, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     unsigned b = *(unsigned *)(c->h_flags + 3);
     float maxvel;
     memcpy(&maxvel, &b, 4);
+    int rc = fv_allreduce_max_f32(c, &maxvel);
+    if (rc) return rc;
     // (float)((_CFLConditionNumber * _dx) / maxvel): +inf on a zero field (fluidsimulation.cpp:268)
     *dt_out = (float)((c->prm.cfl_number * c->dx) / maxvel);
     return FLIPV_OK;

@@ -1,6 +1,7 @@
 // k_particles.hip -- particle <-> grid kernels (gfx950): liquid SDF scatter-min (K1), P2G scatter-add
 // (K3), G2P + FLIP/PIC update + RK2 advection + solid push-out (K15).
 #include "flipv_internal.h"
+#include "flipv_comm.h"
 
 // Grid3d::positionToGridIndex(vec3, double dx): float coordinate promoted, times 1/dx, floor
 // (reference grid3d.h:60-65).  Done in fp64 exactly like the reference so that a particle lands in the
@@ -250,34 +251,37 @@ __global__ void k_advect_particles(Lay L, float *__restrict__ aos6, size_t n, co
 }
 
 // =================================================================== host launchers
-int fv_fill_cells(flipv_context *c, float *p, float v);
 int fv_sdf_finish(flipv_context *c);
 int fv_p2g_finalize(flipv_context *c);
 
 int fv_particle_sdf(flipv_context *c) {
-    fv_fill_cells(c, c->phi, 3.0f * (float)(double)c->dx);  // _getMaxDistance (particlelevelset.cpp:94-96)
+    fv_fill_cells(c, c->phi, 3.0f * (float)(double)c->dx, 1);  // _getMaxDistance (particlelevelset.cpp:94-96)
     if (c->np) {
         // _particleRadius (fluidsimulation.cpp:36)
         const float radius = (float)(c->dx * 1.01 * sqrt(3.0) / 2.0);
         hipLaunchKernelGGL(k_sdf_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
                            c->phi, c->dx, radius);
     }
+    // contributions to the neighbours' boundary planes (a particle reaches one cell beyond its own)
+    float *parr[1] = {c->phi};
+    int rc = fv_halo_reduce(c, parr, 1, 1, 1, HALO_MIN_F32);
+    if (rc) return rc;
     fv_sdf_finish(c);
     HIPCHK(c, hipGetLastError());
-    return FLIPV_OK;
+    const HaloArray ph[1] = {{c->phi, 4}};
+    return fv_halo_copy(c, ph, 1, 4);  // P2G masks, volumes (trilinear +-1.5 cells, 2 dilation layers) read phi across the cut
 }
 
 int fv_p2g(flipv_context *c) {
-    const size_t bytes = c->L.n * 4;
-    HIPCHK(c, hipMemsetAsync(c->accU, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->accV, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->accW, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wgtU, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wgtV, 0, bytes, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->wgtW, 0, bytes, c->stream));
+    const Lay R = fv_range(c, 2);  // planes this rank's particles can reach
+    const size_t off = (size_t)R.kb * c->L.sz, bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
+    float *acc[6] = {c->accU, c->accV, c->accW, c->wgtU, c->wgtV, c->wgtW};
+    for (int q = 0; q < 6; q++) HIPCHK(c, hipMemsetAsync(acc[q] + off, 0, bytes, c->stream));
     if (c->np)
         hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
                            c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, c->dx);
+    int rc = fv_halo_reduce(c, acc, 6, 2, 2, HALO_ADD_F32);
+    if (rc) return rc;
     fv_p2g_finalize(c);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
@@ -299,9 +303,13 @@ int fv_advect_particles(flipv_context *c, float dt) {
     const double ev = -2 * dxf - 1e-4, eh = 0.5 * ev;  // AABB::expand (aabb.cpp:118-124)
     b.bx = b.by = b.bz = 0.0f - (float)eh;
     b.bw = bw + ev; b.bh = bh + ev; b.bd = bd + ev;
+    // a particle samples the fields up to CFL (5) cells + the trilinear support away from its cell
+    const HaloArray vel[6] = {{c->U, 4}, {c->V, 4}, {c->W, 4}, {c->sU, 4}, {c->sV, 4}, {c->sW, 4}};
+    int rc = fv_halo_copy(c, vel, 6, (int)ceilf(c->prm.cfl_number) + 3);
+    if (rc) return rc;
     if (c->np)
         hipLaunchKernelGGL(k_advect_particles, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
                            c->U, c->V, c->W, c->sU, c->sV, c->sW, c->solid, c->dx, dt, c->prm.pic_ratio, b);
     HIPCHK(c, hipGetLastError());
-    return FLIPV_OK;
+    return fv_migrate_particles(c);
 }

@@ -11,6 +11,7 @@
 // (SURVEY.md 8d), plus 8 B for the fp64 residual that feeds the fused beta dot products.
 #include "flipv_internal.h"
 #include "pcg_common.h"
+#include "flipv_comm.h"
 
 __device__ __forceinline__ bool d_is_pcell(const float *__restrict__ phi, const Lay &L, int i, int j, int k) {
     // interior cells with phi < 0 (pressuresolver.cpp:206-216)
@@ -26,7 +27,7 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
                                  float *__restrict__ pj, float *__restrict__ pk, RT<T> *__restrict__ r, T *__restrict__ x,
                                  T *__restrict__ s, double *__restrict__ bmax, float dxf, float dtf, float minfrac) {
     __shared__ double lds[4];
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     double babs = 0.0;
     if (i < L.PX && j < L.PY) {
         const size_t c = gidx(L, i, j, k);
@@ -126,11 +127,11 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
         stv(q + c, y);
     }
     block_sum3_256(da, db, dc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.a) {
-        const size_t so = (size_t)it * NSLOT + (blockIdx.x & (NSLOT - 1));
-        if (da != 0.0) atomicAdd(&sc.a[so], da);
-        if (db != 0.0) atomicAdd(&sc.b[so], db);
-        if (dc != 0.0) atomicAdd(&sc.c[so], dc);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
+        const int sl = sc.my_slot();
+        if (da != 0.0) atomicAdd(sc.a(it) + sl, da);
+        if (db != 0.0) atomicAdd(sc.b(it) + sl, db);
+        if (dc != 0.0) atomicAdd(sc.c(it) + sl, dc);
     }
 }
 
@@ -145,8 +146,8 @@ static __global__ void k_copy_to_f32(const T *__restrict__ a, float *__restrict_
 // flag[t] = 1 if tile t holds at least one unknown (diag != 0) of any component
 __global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, int nc, const float *__restrict__ d0,
                                                     const float *__restrict__ d1, const float *__restrict__ d2,
-                                                    int *__restrict__ flag) {
-    const int tile = blockIdx.x;
+                                                    int *__restrict__ flag, int tile0) {
+    const int tile = blockIdx.x + tile0;  // only the tiles of the owned planes are launched
     const int tx = tile % tg.ntx, t2 = tile / tg.ntx, ty = t2 % tg.nty, k = t2 / tg.nty;
     const int i0 = tx * 64 * vw + threadIdx.x * vw, j = ty * TY + threadIdx.y;
     int any = 0;
@@ -157,12 +158,12 @@ __global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, 
             for (int e = 0; e < vw; e++) any |= dd[m][c + e] != 0.0f;
     }
     const int r = __syncthreads_or(any);
-    if (threadIdx.x == 0 && threadIdx.y == 0) flag[tile] = r;
+    if (threadIdx.x == 0 && threadIdx.y == 0) flag[tile - tile0] = r;
 }
 
 // ordered compaction of the flagged tiles by one block (tile counts are 1e4..1e5)
 __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ flag, int ntiles, int *__restrict__ list,
-                                                       int *__restrict__ count) {
+                                                       int *__restrict__ count, int tile0) {
     __shared__ int wsum[16];
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ f
         for (int q = 0; q < wv; q++) woff += wsum[q];
         int total = 0;
         for (int q = 0; q < 16; q++) total += wsum[q];
-        if (f) list[base + woff + before] = t;
+        if (f) list[base + woff + before] = t + tile0;
         __syncthreads();
         if (threadIdx.x == 0) base += total;
         __syncthreads();
@@ -202,20 +203,20 @@ int fv_scal_reserve(flipv_context *c, int cap) {
 
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     const size_t n = ((size_t)cap + 2) * NSLOT;
-    sc->sig = c->d_scal;
-    sc->a = c->d_scal + n;
-    sc->b = c->d_scal + 2 * n;
-    sc->c = c->d_scal + 3 * n;
-    sc->rmax = c->d_scal + 4 * n;
+    sc->base = c->d_scal;
     sc->conv = c->d_flags;
+    const int nr = c->comm ? c->comm->nranks : 1, rk = c->comm ? c->comm->rank : 0;
+    sc->nslot = NSLOT / nr > 0 ? NSLOT / nr : 1;   // disjoint slot ranges per rank (nranks <= NSLOT)
+    sc->slot0 = rk * sc->nslot;
     *extra = c->d_scal + 5 * n;
 }
 
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    int *list, int *nActive) {
-    const int nt = tg.count();
-    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, c->tileFlag);
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1);
+    const int perPlane = tg.ntx * tg.nty;
+    const int tile0 = c->k0 * perPlane, nt = (c->k1 - c->k0) * perPlane;  // tiles are plane-major: owned planes are contiguous
+    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, c->tileFlag, tile0);
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tile0);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nActive = c->h_flags[1];
@@ -252,11 +253,18 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     // with fp32 vectors x IS the pressure grid
     constexpr bool f32 = std::is_same<T, float>::value;
     T *x = f32 ? (T *)c->pressure : (T *)c->pX;
-    hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(L), 0, c->stream, L, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
+    const Lay R1 = fv_range(c, 1);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
+    hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, bmax, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->tileListP, &c->nActiveP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
+    {
+        float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)
+        double bd = c->h_scal[0];
+        if (c->comm && c->comm->nranks > 1) { rc = fv_allreduce_max_f32(c, &bn); if (rc) return rc; bd = (double)bn; }
+        c->h_scal[0] = bd;
+    }
     const double bnorm = c->h_scal[0];
     li.rhs_norm = bnorm;
     li.active_tiles = c->nActiveP;
@@ -264,7 +272,9 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     c->pressurePrec = f32 ? 0 : 1;
     c->lastDt = dt;
     // early out (pressuresolver.cpp:173-175): pressure grid is zero
-    if (!(bnorm >= c->prm.pressure_tolerance) || c->nActiveP == 0) {
+    int anyActive = c->nActiveP;
+    if (c->comm && c->comm->nranks > 1) { float f = (float)anyActive; rc = fv_allreduce_max_f32(c, &f); if (rc) return rc; anyActive = (int)f; }
+    if (!(bnorm >= c->prm.pressure_tolerance) || anyActive == 0) {
         li.status = 3;
         li.residual = bnorm;
         if (!f32) hipLaunchKernelGGL(k_copy_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)x, c->pressure, L.n);
@@ -277,14 +287,19 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
     const int nb = pcg_grid(c->nActiveP);
     const dim3 blk(64, 4, 1);
+    const HaloArray sh[1] = {{c->pS, sizeof(T)}};
     hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);
+    if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
     int it = 0, conv = -1;
     while (it < cap && conv < 0) {
         const int stop = (it + every < cap) ? it + every : cap;
         for (; it < stop; it++) {
+            if ((rc = fv_halo_copy(c, sh, 1, 1))) return rc;                          // s on the neighbours' boundary planes
             launch_pressure_spmv<T>(c, sc, it);
+            if ((rc = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return rc;        // a, b, c
             hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
+            if ((rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;     // rmax[it], sig[it+1]
         }
         hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -301,6 +316,10 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     li.status = conv >= 0 ? 0 : 1;
     if (c->prm.kernel_timing) fv_ev_collect(c);
     if (info) *info = li;
+    {
+        const HaloArray ph[1] = {{c->pressure, 4}};  // the gradient at plane k0 reads p(k0-1)
+        if ((rc = fv_halo_copy(c, ph, 1, 1))) return rc;
+    }
     return conv >= 0 ? FLIPV_OK : FLIPV_WARN_NOT_CONVERGED;
 }
 

@@ -12,6 +12,7 @@
 // the reference's silent drop of couplings to faces without a matrix row (sparsematrix.h:86-88).
 #include "flipv_internal.h"
 #include "pcg_common.h"
+#include "flipv_comm.h"
 
 enum { ST_FLUID = 1, ST_SOLID = 2 };
 
@@ -196,7 +197,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                              float *__restrict__ dgW, float *__restrict__ vmU, float *__restrict__ vmV,
                              float *__restrict__ vmW, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {
     __shared__ double lds[4];
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     double babs = 0.0;
     int rows = 0;
     if (i < L.PX && j < L.PY) {
@@ -401,11 +402,11 @@ __global__ __launch_bounds__(256, 4) void k_visc_spmv(const int *__restrict__ ti
         stv(v.q[2] + c, yW);
     }
     block_sum3_256(da, db, dc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.a) {
-        const size_t so = (size_t)it * NSLOT + (blockIdx.x & (NSLOT - 1));
-        if (da != 0.0) atomicAdd(&sc.a[so], da);
-        if (db != 0.0) atomicAdd(&sc.b[so], db);
-        if (dc != 0.0) atomicAdd(&sc.c[so], dc);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
+        const int sl = sc.my_slot();
+        if (da != 0.0) atomicAdd(sc.a(it) + sl, da);
+        if (db != 0.0) atomicAdd(sc.b(it) + sl, db);
+        if (dc != 0.0) atomicAdd(sc.c(it) + sl, dc);
     }
 }
 
@@ -458,32 +459,41 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     sc.tol_inclusive = 1;
     sc.tol = 0.0;
 
+    // Everything up to the factors is evaluated redundantly on the halo planes a neighbour-owned row would need
+    // (inputs: phi with a 4-plane halo, the replicated solid SDF), so the setup needs no exchange of its own.
+    const Lay R0 = fv_range(c, 0), R1 = fv_range(c, 1), R2 = fv_range(c, 2), R3 = fv_range(c, 3);
     // face states
-    hipLaunchKernelGGL(k_solid_center, GRID3(L), 0, c->stream, L, c->solid, c->scp);
-    hipLaunchKernelGGL(k_face_states, GRID3(L), 0, c->stream, L, c->scp, c->stU, c->stV, c->stW);
+    hipLaunchKernelGGL(k_solid_center, GRID3(R2), 0, c->stream, R2, c->solid, c->scp);
+    hipLaunchKernelGGL(k_face_states, GRID3(R1), 0, c->stream, R1, c->scp, c->stU, c->stV, c->stW);
     // band mask + the seven volume lattices (viscositysolver.cpp:135-178)
-    hipLaunchKernelGGL(k_valid_init, GRID3(L), 0, c->stream, L, c->phi, c->validCells);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(L), 0, c->stream, L, c->validCells, c->validTmp);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(L), 0, c->stream, L, c->validTmp, c->validCells);
+    hipLaunchKernelGGL(k_valid_init, GRID3(R3), 0, c->stream, R3, c->phi, c->validCells);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validCells, c->validTmp);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(R1), 0, c->stream, R1, c->validTmp, c->validCells);
     const float h = (float)(0.5 * c->dx);
     struct { float *v; int lat; float cx, cy, cz; } lat[7] = {
         {c->volC, LAT_CELL, h, h, h}, {c->volU, LAT_U, 0, h, h},  {c->volV, LAT_V, h, 0, h}, {c->volW, LAT_W, h, h, 0},
         {c->volEU, LAT_EU, h, 0, 0},  {c->volEV, LAT_EV, 0, h, 0}, {c->volEW, LAT_EW, 0, 0, h}};
     for (int q = 0; q < 7; q++)
-        hipLaunchKernelGGL(k_volume_lattice, GRID3(L), 0, c->stream, L, lat[q].lat, c->phi, c->validCells, lat[q].v, lat[q].cx,
+        hipLaunchKernelGGL(k_volume_lattice, GRID3(R1), 0, c->stream, R1, lat[q].lat, c->phi, c->validCells, lat[q].v, lat[q].cx,
                            lat[q].cy, lat[q].cz, c->dx);
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
-    hipLaunchKernelGGL(k_visc_factors, GRID3(L), 0, c->stream, L, c->visc, c->volC, c->volEU, c->volEV, c->volEW, c->fC,
+    hipLaunchKernelGGL(k_visc_factors, GRID3(R1), 0, c->stream, R1, c->visc, c->volC, c->volEU, c->volEV, c->volEW, c->fC,
                        c->fEU, c->fEV, c->fEW, factor);
     PcgSys<T, 3> v = visc_sys<T>(c);
-    hipLaunchKernelGGL(k_visc_setup<T>, GRID3(L), 0, c->stream, L, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
+    // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane)
+    hipLaunchKernelGGL(k_visc_setup<T>, GRID3(R0), 0, c->stream, R0, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                        c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                        c->vDiagW, c->vmU, c->vmV, c->vmW, v, bmax, c->d_flags + 2);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, c->tgV, VW_V, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->tileListV, &c->nActiveV);
     if (rc) return rc;
+    if (c->comm && c->comm->nranks > 1) {
+        float bn = (float)c->h_scal[0];
+        if ((rc = fv_allreduce_max_f32(c, &bn))) return rc;
+        c->h_scal[0] = (double)bn;
+    }
     const double bnorm = c->h_scal[0];
     li.rhs_norm = bnorm;
     li.rows = c->h_flags[2];
@@ -494,20 +504,27 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     int conv = -1, iters = 0;
     double res = bnorm;
     bool success = false;
-    if (bnorm == 0.0 || c->nActiveV == 0) {  // pcgsolver.h:254-258: zero rhs -> zero solution, success
+    int anyActive = c->nActiveV;
+    if (c->comm && c->comm->nranks > 1) { float f = (float)anyActive; if ((rc = fv_allreduce_max_f32(c, &f))) return rc; anyActive = (int)f; }
+    if (bnorm == 0.0 || anyActive == 0) {  // pcgsolver.h:254-258: zero rhs -> zero solution, success
         success = true;
     } else {
         sc.tol = c->prm.viscosity_tolerance * bnorm;
         const int nb = pcg_grid(c->nActiveV);
         const dim3 blk(64, 4, 1);
+        const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
         hipLaunchKernelGGL((k_pcg_init<T, 3, VW_V>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc);
+        if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
         const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
         int it = 0;
         while (it < cap && conv < 0) {
             const int stop = (it + every < cap) ? it + every : cap;
             for (; it < stop; it++) {
+                if ((rc = fv_halo_copy(c, sh, 3, 1))) return rc;                          // s on the neighbours' boundary planes
                 launch_visc_spmv<T>(c, sc, it);
+                if ((rc = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return rc;        // a, b, c
                 hipLaunchKernelGGL((k_pcg_update<T, 3, VW_V>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
+                if ((rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;     // rmax[it], sig[it+1]
             }
             hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
             HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -528,9 +545,12 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool accepted = success || (iters == cap && res < c->prm.viscosity_accept_tolerance);
     li.status = success ? (iters == 0 ? 3 : 0) : (accepted ? 1 : 2);
     if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[0], c->U, L.n);
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[1], c->V, L.n);
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[2], c->W, L.n);
+        const size_t off = (size_t)R0.kb * L.sz, cnt = (size_t)(R0.ke - R0.kb) * L.sz;
+        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[0] + off, c->U + off, cnt);
+        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[1] + off, c->V + off, cnt);
+        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[2] + off, c->W + off, cnt);
+        const HaloArray uv[3] = {{c->U, 4}, {c->V, 4}, {c->W, 4}};
+        if ((rc = fv_halo_copy(c, uv, 3, 1))) return rc;  // the pressure rhs at plane k1-1 reads W(k1)
     }
     HIPCHK(c, hipGetLastError());
     if (c->prm.kernel_timing) fv_ev_collect(c);

@@ -88,13 +88,22 @@ __device__ __forceinline__ T nb_right(const Vec<T, N> &a, const T *__restrict__ 
 // one-atomic-per-block accumulation does not serialise on a single L2 address (thousands of blocks per launch);
 // the consuming kernel folds the NSLOT partials with one wave.
 constexpr int NSLOT = 32;
-struct PcgScal {    // views into ctx->d_scal, each [(cap+2) * NSLOT]
-    double *sig;    // sig[it] = (r,z) entering iteration it
-    double *a, *b, *c;
-    double *rmax;   // rmax[it] = max|r| after iteration it
-    int *conv;      // converged-at iteration, -1 while running
+// Layout of ctx->d_scal: block `it` = [sig | a | b | c | rmax] x NSLOT doubles.  a,b,c of one iteration are
+// contiguous (one all-reduce after the SpMV) and rmax[it] is followed by sig[it+1] (one all-reduce after the update).
+// In a multi-rank run rank r accumulates only into slots [slot0, slot0 + nslot): the slots are disjoint between
+// ranks, so a SUM all-reduce merges sums and maxima alike.
+struct PcgScal {
+    double *base;
+    int *conv;      // converged-at iteration, -1 while running (nullptr: benchmark launch, no scalars)
     double tol;
     int tol_inclusive;  // 1: res <= tol (pcgsolver.h:270), 0: res < tol (pressuresolver.cpp:548)
+    int slot0, nslot;
+    __host__ __device__ double *sig(int it) const { return base + (size_t)it * 5 * NSLOT; }          // (r,z) entering iteration it
+    __host__ __device__ double *a(int it) const { return base + (size_t)it * 5 * NSLOT + NSLOT; }
+    __host__ __device__ double *b(int it) const { return base + (size_t)it * 5 * NSLOT + 2 * NSLOT; }
+    __host__ __device__ double *c(int it) const { return base + (size_t)it * 5 * NSLOT + 3 * NSLOT; }
+    __host__ __device__ double *rmax(int it) const { return base + (size_t)it * 5 * NSLOT + 4 * NSLOT; }  // max|r| after iteration it
+    __device__ int my_slot() const { return slot0 + (int)(blockIdx.x % (unsigned)nslot); }
 };
 
 __device__ __forceinline__ int d_tid256() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
@@ -194,7 +203,7 @@ __device__ __forceinline__ bool d_pass(const PcgScal &sc, double res) { return s
 __device__ __forceinline__ bool d_spmv_stop(const PcgScal &sc, int it, double *lds8) {
     if (!sc.conv) return false;  // benchmark launches
     if (*sc.conv >= 0) return true;
-    if (it > 0 && d_pass(sc, d_fold_max(sc.rmax + (size_t)(it - 1) * NSLOT, lds8))) {
+    if (it > 0 && d_pass(sc, d_fold_max(sc.rmax(it - 1), lds8))) {
         // every block takes the same decision from the same completed value; one of them records it
         if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it - 1;
         return true;
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ tiles,
         }
     }
     const double tot = block_sum_256(acc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(&sc.sig[blockIdx.x & (NSLOT - 1)], tot);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(sc.sig(0) + sc.my_slot(), tot);
 }
 
 template <typename T, int NC, int N>
@@ -236,8 +245,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     if (*sc.conv >= 0) return;
     __shared__ double lds[8];
     double f[4];
-    const size_t so = (size_t)it * NSLOT;
-    d_fold_sums(sc.sig + so, sc.a + so, sc.b + so, sc.c + so, f, lds);
+    d_fold_sums(sc.sig(it), sc.a(it), sc.b(it), sc.c(it), f, lds);
     const double sg = f[0], a = f[1];
     const double alpha_d = a != 0.0 ? sg / a : 0.0;
     double est = sg - 2.0 * alpha_d * f[2] + alpha_d * alpha_d * f[3];
@@ -281,28 +289,29 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     const double tot = block_sum_256(acc, lds);
     const double bm = block_max_256(mx, lds);
     if (threadIdx.x == 0 && threadIdx.y == 0) {
-        const int sl = blockIdx.x & (NSLOT - 1);
-        if (tot != 0.0) atomicAdd(&sc.sig[so + NSLOT + sl], tot);
-        if (bm > 0.0) atomic_max_nonneg(&sc.rmax[so + sl], bm);
+        const int sl = sc.my_slot();
+        if (tot != 0.0) atomicAdd(sc.sig(it + 1) + sl, tot);
+        if (bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sl, bm);
     }
 }
 
 // after a chunk of iterations: record convergence of the chunk's last iteration (K1 of the next iteration would)
 static __global__ void k_pcg_check(PcgScal sc, int it_last) {  // <<<1, 64>>>
     __shared__ double lds[8];
-    const double res = d_fold_max(sc.rmax + (size_t)it_last * NSLOT, lds);
+    const double res = d_fold_max(sc.rmax(it_last), lds);
     if (threadIdx.x == 0 && *sc.conv < 0 && d_pass(sc, res)) *sc.conv = it_last;
 }
 // final residual of iteration `it` into out[0]
 static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<1, 64>>>
     __shared__ double lds[8];
-    const double res = d_fold_max(sc.rmax + (size_t)it * NSLOT, lds);
+    const double res = d_fold_max(sc.rmax(it), lds);
     if (threadIdx.x == 0) out[0] = res;
 }
 
 // ---- host-side helpers (k_pressure.hip) ----
 int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT+16 doubles
-static inline int pcg_grid(int ntiles) { const int nb = ((ntiles + 7) / 8) * 8; return nb < MAX_PCG_BLOCKS ? nb : MAX_PCG_BLOCKS; }
+// never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
+static inline int pcg_grid(int ntiles) { const int nb = ((ntiles + 7) / 8) * 8; return nb < 8 ? 8 : (nb < MAX_PCG_BLOCKS ? nb : MAX_PCG_BLOCKS); }
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    int *list, int *nActive);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);

@@ -1,0 +1,56 @@
+"""Host-side helpers of the slab decomposition along k: slab ranges, particle ownership,
+stacked weak-scaling scenes.  Pure index arithmetic, no computation of the simulation itself."""
+import numpy as np
+
+
+def slab_ranges(K, nranks):
+    """Split K cell planes into nranks contiguous slabs [k_begin, k_end), as evenly as possible."""
+    if nranks < 1 or nranks > K:
+        raise ValueError("need 1 <= nranks <= K")
+    base, rem = divmod(K, nranks)
+    out, k = [], 0
+    for r in range(nranks):
+        n = base + (1 if r < rem else 0)
+        out.append((k, k + n))
+        k += n
+    return out
+
+
+def particle_owner(particles, dx, ranges):
+    """rank owning each particle = slab containing the k index of its cell, floor(z / dx) in fp64 like
+    Grid3d::positionToGridIndex (reference grid3d.h:60-65); out-of-domain particles go to the end ranks."""
+    z = np.asarray(particles)[:, 2].astype(np.float64)
+    k = np.floor(z * (1.0 / float(np.float32(dx)))).astype(np.int64)
+    starts = np.array([r[0] for r in ranges[1:]], np.int64)
+    return np.searchsorted(starts, k, side="right")
+
+
+def split_particles(particles, dx, ranges):
+    owner = particle_owner(particles, dx, ranges)
+    return [np.ascontiguousarray(np.asarray(particles)[owner == r]) for r in range(len(ranges))]
+
+
+def gather_owned(ranks_grids, ranges, K):
+    """Assemble a global grid (numpy (depth, h, w)) from the planes each rank owns; the last rank also owns the closing
+    plane of W faces / nodes when the array is K+1 deep."""
+    out = np.array(ranks_grids[0], copy=True)
+    depth = out.shape[0]
+    for r, (g, (k0, k1)) in enumerate(zip(ranks_grids, ranges)):
+        hi = depth if r == len(ranges) - 1 else k1
+        out[k0:hi] = g[k0:hi]
+    return out
+
+
+def stack_scene(solid_nodes, particles, copies, K, dx):
+    """Weak-scaling scene: `copies` instances of one closed K-deep scene stacked along k.  Node plane m*K is taken from
+    the bottom plane of copy m (both candidates are inside the solid for a closed container)."""
+    solid_nodes = np.asarray(solid_nodes)
+    body = solid_nodes[:K]
+    g = np.concatenate([body] * copies + [solid_nodes[K:K + 1]], axis=0)
+    height = float(np.float32(dx)) * K
+    parts = []
+    for m in range(copies):
+        p = np.array(particles, np.float32, copy=True)
+        p[:, 2] = (p[:, 2].astype(np.float64) + m * height).astype(np.float32)
+        parts.append(p)
+    return np.ascontiguousarray(g), parts

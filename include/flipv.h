@@ -115,6 +115,12 @@ typedef struct flipv_kernel_stats {
 /* ---- lifetime: FluidSimulation::initialize (fluidsimulation.cpp:26-43), without the boundary mesh ---- */
 int flipv_create(int isize, int jsize, int ksize, float dx, flipv_context **out);
 int flipv_create_on_device(int isize, int jsize, int ksize, float dx, int hip_device, flipv_context **out);
+/* One rank of a slab decomposition along k (no reference counterpart: the reference is single-process).
+ * The context indexes the GLOBAL I x J x K grid -- every grid passed to or read from it is full size -- but owns and
+ * computes only cell planes [k_begin, k_end); particles uploaded to it must lie in those planes.  A communicator
+ * must be attached (flipv_comm_init_*) before the first substep when there is more than one rank. */
+int flipv_create_slab(int isize, int jsize, int ksize, float dx, int hip_device, int k_begin, int k_end, flipv_context **out);
+int flipv_slab_range(flipv_context *ctx, int *k_begin, int *k_end);
 int flipv_destroy(flipv_context *ctx);
 const char *flipv_last_error(flipv_context *ctx); /* ctx may be NULL for create-time errors */
 int flipv_device_name(flipv_context *ctx, char *buf, size_t len);
@@ -174,6 +180,18 @@ int flipv_synchronize(flipv_context *ctx);
 int flipv_bench_spmv(flipv_context *ctx, int which, int reps, double *ms_out, double *cells_out);
 /* device-to-device copy bandwidth (attainable HBM peak): bytes moved (read+write) per second */
 int flipv_bench_copy(flipv_context *ctx, size_t bytes, int reps, double *gbps_out);
+
+/* ---- multi-GPU: communicator of a slab decomposition (one context per rank) ----
+ * RCCL backend: rank 0 calls flipv_comm_get_unique_id (ncclGetUniqueId), the host broadcasts the 128 bytes
+ * (torch.distributed / MPI / a file), every rank calls flipv_comm_init_rccl.  Halo planes travel with grouped
+ * ncclSend/ncclRecv, the PCG scalars with ncclAllReduce, all on the context's own stream.
+ * Local backend: all ranks are contexts of ONE process on one device, each driven by its own host thread; it exists to
+ * verify the decomposition against the single-domain result on a one-GPU machine. */
+int flipv_comm_unique_id_bytes(void);
+int flipv_comm_get_unique_id(void *id_out);
+int flipv_comm_init_rccl(flipv_context *ctx, const void *unique_id, int rank, int nranks);
+int flipv_comm_init_local(flipv_context **ctxs, int nranks);
+int flipv_comm_finalize(flipv_context *ctx);
 
 #ifdef __cplusplus
 }
