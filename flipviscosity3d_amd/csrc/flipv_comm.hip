@@ -42,7 +42,7 @@ static unsigned grid1d(size_t n) {
 // ================================================================================================ halo helpers
 int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
     Comm *cm = c->comm;
-    if (!cm || cm->nranks == 1 || H <= 0) return FLIPV_OK;
+    if (!cm || H <= 0) return FLIPV_OK;
     const Lay &L = c->L;
     const size_t plane = (size_t)L.sz;
     int rc = cm->begin(c);
@@ -66,7 +66,7 @@ int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
 
 int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op) {
     Comm *cm = c->comm;
-    if (!cm || cm->nranks == 1) return FLIPV_OK;
+    if (!cm) return FLIPV_OK;
     const Lay &L = c->L;
     const size_t plane = (size_t)L.sz;
     // staging: per array [Hhi planes from prev | Hlo planes from next]
@@ -110,13 +110,13 @@ int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi,
 
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n) {
     Comm *cm = c->comm;
-    if (!cm || cm->nranks == 1) return FLIPV_OK;
+    if (!cm) return FLIPV_OK;
     return cm->allreduce_sum(c, dev, n);
 }
 
 int fv_allreduce_max_f32(flipv_context *c, float *value) {
     Comm *cm = c->comm;
-    if (!cm || cm->nranks == 1) return FLIPV_OK;
+    if (!cm) return FLIPV_OK;
     // one slot per rank, merged by a sum all-reduce
     double *buf = c->d_scal_small;
     std::vector<double> h((size_t)cm->nranks, 0.0);
@@ -136,7 +136,7 @@ int fv_allreduce_max_f32(flipv_context *c, float *value) {
 // substep, slabs are much thicker, so only the two neighbours can be destinations)
 int fv_migrate_particles(flipv_context *c) {
     Comm *cm = c->comm;
-    if (!cm || cm->nranks == 1) return FLIPV_OK;
+    if (!cm) return FLIPV_OK;
     const Lay &L = c->L;
     const size_t np = c->np;
     const size_t need = 3 * (np + 1024) * 6;

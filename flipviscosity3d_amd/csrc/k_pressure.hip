@@ -262,7 +262,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     {
         float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)
         double bd = c->h_scal[0];
-        if (c->comm && c->comm->nranks > 1) { rc = fv_allreduce_max_f32(c, &bn); if (rc) return rc; bd = (double)bn; }
+        if (c->comm) { rc = fv_allreduce_max_f32(c, &bn); if (rc) return rc; bd = (double)bn; }
         c->h_scal[0] = bd;
     }
     const double bnorm = c->h_scal[0];
@@ -273,7 +273,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     c->lastDt = dt;
     // early out (pressuresolver.cpp:173-175): pressure grid is zero
     int anyActive = c->nActiveP;
-    if (c->comm && c->comm->nranks > 1) { float f = (float)anyActive; rc = fv_allreduce_max_f32(c, &f); if (rc) return rc; anyActive = (int)f; }
+    if (c->comm) { float f = (float)anyActive; rc = fv_allreduce_max_f32(c, &f); if (rc) return rc; anyActive = (int)f; }
     if (!(bnorm >= c->prm.pressure_tolerance) || anyActive == 0) {
         li.status = 3;
         li.residual = bnorm;

@@ -489,7 +489,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, c->tgV, VW_V, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->tileListV, &c->nActiveV);
     if (rc) return rc;
-    if (c->comm && c->comm->nranks > 1) {
+    if (c->comm) {
         float bn = (float)c->h_scal[0];
         if ((rc = fv_allreduce_max_f32(c, &bn))) return rc;
         c->h_scal[0] = (double)bn;
@@ -505,7 +505,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     double res = bnorm;
     bool success = false;
     int anyActive = c->nActiveV;
-    if (c->comm && c->comm->nranks > 1) { float f = (float)anyActive; if ((rc = fv_allreduce_max_f32(c, &f))) return rc; anyActive = (int)f; }
+    if (c->comm) { float f = (float)anyActive; if ((rc = fv_allreduce_max_f32(c, &f))) return rc; anyActive = (int)f; }
     if (bnorm == 0.0 || anyActive == 0) {  // pcgsolver.h:254-258: zero rhs -> zero solution, success
         success = true;
     } else {
