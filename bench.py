@@ -132,12 +132,28 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
+    from flipviscosity3d_amd import capi, partition
     from flipviscosity3d_amd.capi import Context
 
     N = args.size
     dx, solid, particles = build_scene(N, args.viscosity)
-    c = Context(N, N, N, dx, device=local_rank)
-    c.set_solid_sdf(solid)
+    if world == 1:
+        c = Context(N, N, N, dx, device=local_rank)
+        c.set_solid_sdf(solid)
+    else:
+        # weak scaling: `world` copies of the closed 256^3 scene stacked along k form ONE domain of N x N x (N*world)
+        # cells, decomposed into one slab per rank.  The copies do not interact physically, but they are solved as one
+        # system: every PCG iteration exchanges the halo planes of the search direction and all-reduces its scalars,
+        # every extrapolation layer / P2G / SDF exchanges halos, particles migrate between slabs.
+        solid_g, parts = partition.stack_scene(solid, particles, world, N, dx)
+        ranges = partition.slab_ranges(N * world, world)
+        c = Context(N, N, N * world, dx, device=local_rank, slab=ranges[rank])
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        c.comm_init_rccl(uid[0], rank, world)
+        c.set_solid_sdf(solid_g)
+        particles = parts[rank]
+        del solid_g, parts
     c.set_viscosity(args.viscosity)
     c.set_gravity(0.0, -9.81, 0.0)
     c.set_params(precision=args.precision, kernel_timing=1)
@@ -171,7 +187,7 @@ def main():
     ks = c.kernel_stats()
 
     ms_per_step = elapsed * 1e3 / args.steps
-    cells_total = float(N) ** 3 * world  # every rank advances its own 256^3 domain (see config.parallelism)
+    cells_total = float(N) ** 3 * world  # N x N x (N*world) cells, one N^3 slab per rank
     value = cells_total / 1e6 / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel
@@ -207,9 +223,10 @@ def main():
             "config": {
                 "workload": "%d^3 bunny drop: stanford_bunny.ply liquid in inverted sphere_large.ply, viscosity %g, "
                             "full variational viscosity + pressure substep (BASELINE.json configs[2])" % (N, args.viscosity),
-                "grid": [N, N, N], "particles": int(len(particles)), "dt": 0.01,
+                "grid": [N, N, N * world], "particles_per_rank": int(len(particles)), "dt": 0.01,
                 "viscosity_cap": 700, "parallelism": "single GPU" if world == 1 else
-                "%d independent replicas of the %d^3 domain (domain decomposition not implemented yet)" % (world, N),
+                "%d slabs along k of a %dx%dx%d domain (%d stacked copies of the scene), RCCL halo exchange + PCG scalar "
+                "all-reduce + particle migration" % (world, N, N, N * world, world),
             },
             "device": dev_name,
             "phase_ms": last["phase_ms"],
@@ -221,9 +238,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.viscosity, args.cpu_size)
         print(json.dumps(out), flush=True)
-    c.close()
     if dist is not None:
         dist.barrier()
+        c.comm_finalize()
+    c.close()
+    if dist is not None:
         dist.destroy_process_group()
 
 
