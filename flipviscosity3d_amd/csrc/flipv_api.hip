@@ -140,7 +140,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->tgP.ntx = (L.PX + 64 * VW_P - 1) / (64 * VW_P); c->tgP.nty = (L.PY + TY - 1) / TY; c->tgP.ntz = L.PZ;
     c->tgV.ntx = (L.PX + 64 * VW_V - 1) / (64 * VW_V); c->tgV.nty = (L.PY + TY - 1) / TY; c->tgV.ntz = L.PZ;
     {
-        const size_t ntmax = (size_t)(c->tgP.count() > c->tgV.count() ? c->tgP.count() : c->tgV.count()) + 8;
+        const size_t ntmax = (size_t)(c->tgP.count() > c->tgV.count() ? c->tgP.count() : c->tgV.count()) * 2 + 64;  // virtual enumeration pads nty to a multiple of 4
         int rc_ = plain_alloc(c, &c->tileListP, ntmax);
         if (!rc_) rc_ = plain_alloc(c, &c->tileListV, ntmax);
         if (!rc_) rc_ = plain_alloc(c, &c->tileFlag, ntmax);

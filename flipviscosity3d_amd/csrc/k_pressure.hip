@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
                                                        const float *__restrict__ diag, const float *__restrict__ pi,
                                                        const float *__restrict__ pj, const float *__restrict__ pk,
                                                        const T *__restrict__ s, const RT<T> *__restrict__ r,
-                                                       T *__restrict__ q, PcgScal sc, int it) {
+                                                       T *__restrict__ q, PcgScal sc, int it_arg) {
     __shared__ double lds[12];
+    const int it = d_iter_spmv(sc, it_arg);
     if (d_spmv_stop(sc, it, lds)) return;
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
         if (!(d_tile_coords<VW_P>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
         const size_t c = gidx(L, i0, j, k);
         const long sy = L.sy, sz = L.sz;
-        const Vec<float, 4> dg = ldv<4>(diag + c), ci = ldv<4>(pi + c), cj = ldv<4>(pj + c), ck = ldv<4>(pk + c);
+        const Vec<float, 4> dg = ldv<4>(diag + c);
+        // a wave without pressure cells has nothing to do (q is only read where diag != 0)
+        if (!__any(dg.v[0] != 0.0f || dg.v[1] != 0.0f || dg.v[2] != 0.0f || dg.v[3] != 0.0f)) continue;
+        const Vec<float, 4> ci = ldv<4>(pi + c), cj = ldv<4>(pj + c), ck = ldv<4>(pk + c);
         const Vec<float, 4> cjm = ldv<4>(pj + c - sy), ckm = ldv<4>(pk + c - sz);
         const Vec<T, 4> sc4 = ldv<4>(s + c), sjm = ldv<4>(s + c - sy), sjp = ldv<4>(s + c + sy), skm = ldv<4>(s + c - sz), skp = ldv<4>(s + c + sz);
         const Vec<RT<T>, 4> r4 = ldv<4>(r + c);
@@ -143,27 +147,45 @@ static __global__ void k_copy_to_f32(const T *__restrict__ a, float *__restrict_
 }
 
 // ---- tile activity ----
-// flag[t] = 1 if tile t holds at least one unknown (diag != 0) of any component
+// Tiles are enumerated (and therefore listed, and therefore scheduled) column by column: a column is JCH tile rows
+// (16 grid rows) wide in j and runs through all owned k-planes.  Consecutive blocks of an XCD then work on consecutive
+// planes of the same narrow column, so the k+-1 planes every stencil row re-reads are still in that XCD's 4 MiB L2
+// (a whole k-plane of the ~19 arrays the viscosity SpMV touches is ~5 MB and would not be).
+constexpr int JCH = 4;
+__device__ __forceinline__ int d_virtual_tile(int v, const TileGrid &tg, int k0, int nk) {
+    const int tx = v % tg.ntx;
+    int r = v / tg.ntx;
+    const int tyi = r % JCH;
+    r /= JCH;
+    const int kk = r % nk, chunk = r / nk;
+    const int ty = chunk * JCH + tyi;
+    if (ty >= tg.nty) return -1;
+    return tx + tg.ntx * (ty + tg.nty * (k0 + kk));
+}
+
+// flag[v] = 1 if virtual tile v holds at least one unknown (diag != 0) of any component
 __global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, int nc, const float *__restrict__ d0,
                                                     const float *__restrict__ d1, const float *__restrict__ d2,
-                                                    int *__restrict__ flag, int tile0) {
-    const int tile = blockIdx.x + tile0;  // only the tiles of the owned planes are launched
-    const int tx = tile % tg.ntx, t2 = tile / tg.ntx, ty = t2 % tg.nty, k = t2 / tg.nty;
-    const int i0 = tx * 64 * vw + threadIdx.x * vw, j = ty * TY + threadIdx.y;
+                                                    int *__restrict__ flag, int k0, int nk) {
+    const int tile = d_virtual_tile(blockIdx.x, tg, k0, nk);
     int any = 0;
-    if (i0 < L.PX && j < L.PY) {
-        const size_t c = gidx(L, i0, j, k);
-        const float *dd[3] = {d0, d1, d2};
-        for (int m = 0; m < nc; m++)
-            for (int e = 0; e < vw; e++) any |= dd[m][c + e] != 0.0f;
+    if (tile >= 0) {
+        const int tx = tile % tg.ntx, t2 = tile / tg.ntx, ty = t2 % tg.nty, k = t2 / tg.nty;
+        const int i0 = tx * 64 * vw + threadIdx.x * vw, j = ty * TY + threadIdx.y;
+        if (i0 < L.PX && j < L.PY) {
+            const size_t c = gidx(L, i0, j, k);
+            const float *dd[3] = {d0, d1, d2};
+            for (int m = 0; m < nc; m++)
+                for (int e = 0; e < vw; e++) any |= dd[m][c + e] != 0.0f;
+        }
     }
     const int r = __syncthreads_or(any);
-    if (threadIdx.x == 0 && threadIdx.y == 0) flag[tile - tile0] = r;
+    if (threadIdx.x == 0 && threadIdx.y == 0) flag[blockIdx.x] = r;
 }
 
 // ordered compaction of the flagged tiles by one block (tile counts are 1e4..1e5)
 __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ flag, int ntiles, int *__restrict__ list,
-                                                       int *__restrict__ count, int tile0) {
+                                                       int *__restrict__ count, TileGrid tg, int k0, int nk) {
     __shared__ int wsum[16];
     __shared__ int base;
     if (threadIdx.x == 0) base = 0;
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ f
         for (int q = 0; q < wv; q++) woff += wsum[q];
         int total = 0;
         for (int q = 0; q < 16; q++) total += wsum[q];
-        if (f) list[base + woff + before] = t + tile0;
+        if (f) list[base + woff + before] = d_virtual_tile(t, tg, k0, nk);
         __syncthreads();
         if (threadIdx.x == 0) base += total;
         __syncthreads();
@@ -208,15 +230,18 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     const int nr = c->comm ? c->comm->nranks : 1, rk = c->comm ? c->comm->rank : 0;
     sc->nslot = NSLOT / nr > 0 ? NSLOT / nr : 1;   // disjoint slot ranges per rank (nranks <= NSLOT)
     sc->slot0 = rk * sc->nslot;
+    sc->cap = cap;
+    sc->itA = c->d_flags + 4;
+    sc->itB = c->d_flags + 5;
     *extra = c->d_scal + 5 * n;
 }
 
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    int *list, int *nActive) {
-    const int perPlane = tg.ntx * tg.nty;
-    const int tile0 = c->k0 * perPlane, nt = (c->k1 - c->k0) * perPlane;  // tiles are plane-major: owned planes are contiguous
-    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, c->tileFlag, tile0);
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tile0);
+    const int nk = c->k1 - c->k0, nchunks = (tg.nty + JCH - 1) / JCH;
+    const int nt = tg.ntx * JCH * nk * nchunks;  // virtual tiles of the owned planes (column-major enumeration)
+    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, c->tileFlag, c->k0, nk);
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nActive = c->h_flags[1];
@@ -226,10 +251,11 @@ int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const f
 template <typename T>
 static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it) {
     const int nb = pcg_grid(c->nActiveP);
-    if (c->prm.kernel_timing) fv_ev_begin(c, 0, (double)c->nActiveP * (64 * VW_P * TY));
+    const bool timed = c->prm.kernel_timing && (it & 7) == 0;  // HIP events around every 8th launch
+    if (timed) fv_ev_begin(c, 0, (double)c->nActiveP * (64 * VW_P * TY));
     hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it);
-    if (c->prm.kernel_timing) fv_ev_end(c);
+    if (timed) fv_ev_end(c);
 }
 
 template <typename T>
@@ -290,22 +316,17 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const HaloArray sh[1] = {{c->pS, sizeof(T)}};
     hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);
     if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
-    const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
-    int it = 0, conv = -1;
-    while (it < cap && conv < 0) {
-        const int stop = (it + every < cap) ? it + every : cap;
-        for (; it < stop; it++) {
-            if ((rc = fv_halo_copy(c, sh, 1, 1))) return rc;                          // s on the neighbours' boundary planes
-            launch_pressure_spmv<T>(c, sc, it);
-            if ((rc = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return rc;        // a, b, c
-            hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
-            if ((rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;     // rmax[it], sig[it+1]
-        }
-        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
-        HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        conv = c->h_flags[0];
-    }
+    int conv = -1;
+    auto launch_iter = [&](int it) -> int {
+        int r;
+        if ((r = fv_halo_copy(c, sh, 1, 1))) return r;                                            // s on the neighbours' boundary planes
+        launch_pressure_spmv<T>(c, sc, it);
+        if (c->comm && (r = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return r;              // a, b, c
+        hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
+        if (c->comm && (r = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return r;           // rmax[it], sig[it+1]
+        return FLIPV_OK;
+    };
+    if ((rc = pcg_iterate(c, sc, cap, launch_iter, &conv))) return rc;
     const int last = conv >= 0 ? conv : cap - 1;
     hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -310,12 +310,13 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
 #define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
 #define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
 template <typename T>
-__global__ __launch_bounds__(256, 4) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
+__global__ __launch_bounds__(256, VW_V == 2 ? 4 : 2) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                    const float *__restrict__ vmU, const float *__restrict__ vmV,
                                                    const float *__restrict__ vmW, const float *__restrict__ fC,
                                                    const float *__restrict__ fEU, const float *__restrict__ fEV,
-                                                   const float *__restrict__ fEW, PcgSys<T, 3> v, PcgScal sc, int it) {
+                                                   const float *__restrict__ fEW, PcgSys<T, 3> v, PcgScal sc, int it_arg) {
     __shared__ double lds[12];
+    const int it = d_iter_spmv(sc, it_arg);
     if (d_spmv_stop(sc, it, lds)) return;
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
@@ -327,6 +328,14 @@ __global__ __launch_bounds__(256, 4) void k_visc_spmv(const int *__restrict__ ti
         const long sy = L.sy, sz = L.sz;
         const int I = L.I;
         const T *__restrict__ xu = v.s[0], *__restrict__ xv = v.s[1], *__restrict__ xw = v.s[2];
+        // ---- own volumes = row masks.  A lane without a row has nothing to compute and nothing to store (q is only
+        // ever read where the diagonal is non-zero); in the sparse scenes of the reference that is most lanes of a tile.
+        const Vec<float, NV> MU = ldv<NV>(vmU + c), MV = ldv<NV>(vmV + c), MW = ldv<NV>(vmW + c);
+        bool anyrow = false;
+#pragma unroll
+        for (int e = 0; e < NV; e++) anyrow = anyrow || MU.v[e] >= 0.0f || MV.v[e] >= 0.0f || MW.v[e] >= 0.0f;
+        // the lane shuffles below need every lane of the wave: only skip when the whole wave is idle
+        if (!__any(anyrow)) continue;
         // ---- factors
         const Vec<float, NV> C0 = ldv<NV>(fC + c), Cjm = ldv<NV>(fC + c - sy), Ckm = ldv<NV>(fC + c - sz);
         const Vec<float, NV> EW0 = ldv<NV>(fEW + c), EWjp = ldv<NV>(fEW + c + sy);
@@ -344,8 +353,7 @@ __global__ __launch_bounds__(256, 4) void k_visc_spmv(const int *__restrict__ ti
         const T W0l = nb_left(W0, xw + c, i0), W0r = nb_right(W0, xw + c, i0, I);
         const T Vjpl = nb_left(Vjp, xv + c + sy, i0), Wkpl = nb_left(Wkp, xw + c + sz, i0);
         const T Ujmr = nb_right(Ujm, xu + c - sy, i0, I), Ukmr = nb_right(Ukm, xu + c - sz, i0, I);
-        // ---- own volumes (row masks) and residuals
-        const Vec<float, NV> MU = ldv<NV>(vmU + c), MV = ldv<NV>(vmV + c), MW = ldv<NV>(vmW + c);
+        // ---- residuals
         const Vec<RT<T>, NV> RU = ldv<NV>(v.r[0] + c), RV = ldv<NV>(v.r[1] + c), RW = ldv<NV>(v.r[2] + c);
         Vec<T, NV> yU, yV, yW;
 #pragma unroll
@@ -429,10 +437,11 @@ static PcgSys<T, 3> visc_sys(flipv_context *c) {
 template <typename T>
 static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it) {
     const int nb = pcg_grid(c->nActiveV);
-    if (c->prm.kernel_timing) fv_ev_begin(c, 1, (double)c->nActiveV * (64 * VW_V * TY));
+    const bool timed = c->prm.kernel_timing && (it & 7) == 0;  // HIP events around every 8th launch
+    if (timed) fv_ev_begin(c, 1, (double)c->nActiveV * (64 * VW_V * TY));
     hipLaunchKernelGGL(k_visc_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L,
                        c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
-    if (c->prm.kernel_timing) fv_ev_end(c);
+    if (timed) fv_ev_end(c);
 }
 
 template <typename T>
@@ -515,22 +524,16 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
         hipLaunchKernelGGL((k_pcg_init<T, 3, VW_V>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc);
         if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
-        const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
-        int it = 0;
-        while (it < cap && conv < 0) {
-            const int stop = (it + every < cap) ? it + every : cap;
-            for (; it < stop; it++) {
-                if ((rc = fv_halo_copy(c, sh, 3, 1))) return rc;                          // s on the neighbours' boundary planes
-                launch_visc_spmv<T>(c, sc, it);
-                if ((rc = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return rc;        // a, b, c
-                hipLaunchKernelGGL((k_pcg_update<T, 3, VW_V>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
-                if ((rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;     // rmax[it], sig[it+1]
-            }
-            hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
-            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            conv = c->h_flags[0];
-        }
+        auto launch_iter = [&](int it) -> int {
+            int r;
+            if ((r = fv_halo_copy(c, sh, 3, 1))) return r;                                            // s on the neighbours' boundary planes
+            launch_visc_spmv<T>(c, sc, it);
+            if (c->comm && (r = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return r;              // a, b, c
+            hipLaunchKernelGGL((k_pcg_update<T, 3, VW_V>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
+            if (c->comm && (r = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return r;           // rmax[it], sig[it+1]
+            return FLIPV_OK;
+        };
+        if ((rc = pcg_iterate(c, sc, cap, launch_iter, &conv))) return rc;
         const int last = conv >= 0 ? conv : cap - 1;
         hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
