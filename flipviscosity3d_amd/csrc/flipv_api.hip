@@ -109,6 +109,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->evUsed = 0;
     c->pressureReady = c->viscosityReady = 0;
     c->nActiveP = c->nActiveV = 0;
+    c->vwV = 2;
     c->viscosity_nonzero = 1;
     memset(&c->kstats, 0, sizeof(c->kstats));
     flipv_default_params(&c->prm);

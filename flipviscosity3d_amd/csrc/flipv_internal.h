@@ -50,7 +50,7 @@ __host__ __device__ __forceinline__ void lat_dims(const Lay &L, int lat, int &w,
 // Solver tiles: 64*N indices along i (one wave: 64 lanes x N consecutive i), TY rows, one k-plane.
 // One 256-thread block per tile; block (64, 4, 1).  N = VW_P for the pressure solve, VW_V for viscosity.
 constexpr int VW_P = 4;          // 7-point stencil, 72 VGPRs: 16-byte accesses
-constexpr int VW_V = 4;          // coupled 15-point stencil: measured 15 % faster than 8-byte accesses on the filled box despite 2 waves/SIMD
+constexpr int VW_V = 2;          // narrowest lane width of the viscosity kernels (2 or 4 is chosen per solve)
 constexpr int TY = 4;
 
 struct TileGrid {
@@ -104,6 +104,7 @@ struct flipv_context {
     int *tileListP, *tileListV;
     int *tileFlag;
     int nActiveP, nActiveV;
+    int vwV;         // lane width chosen for the current viscosity solve (2 or 4)
 
     // pressure system (zero outside pressure cells)
     float *pDiag, *pPi, *pPj, *pPk;
