@@ -207,6 +207,8 @@ def main():
         roof = {"kernel": "k_pressure_spmv<float>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_ms * 1e3, "launches": p_n,
                 "cells_per_launch": p_cells / p_n, "bytes_per_cell": PRES_SPMV_BYTES_PER_CELL}
+    if roof is not None:
+        roof.update(committed_profile(roof["kernel"].split("<")[0], N, args, world))
     extra = {}
     if p_n > 0:
         avg = p_ms / p_n
@@ -244,6 +246,38 @@ def main():
     c.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def committed_profile(kernel, N, args, world):
+    """HBM traffic per launch of `kernel` from the committed PMC summary of this very workload (FETCH_SIZE x2 + WRITE_SIZE,
+    separate rocprofv3 --pmc passes, tools/profile_round.sh), and rocprofv3's kernel-only average duration next to the
+    HIP-event figure measured in this run.  Counters cannot be collected from inside the process, so the numbers
+    are the newest profiles/r*/bench<N>_v*_ files; null when this run is a different workload."""
+    import csv
+    import glob
+    import re
+    out = {"traffic": None}
+    if world != 1 or args.precision != 0 or abs(args.viscosity - 5.0) > 1e-12:
+        return out
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    key = lambda p: [int(x) for x in re.findall(r"\d+", os.path.relpath(p, root))]
+    pmc = sorted(glob.glob(os.path.join(root, "r*", "bench%d_v*_pmc_traffic.json" % N)), key=key)
+    if pmc:
+        d = json.load(open(pmc[-1]))
+        for name, v in d.items():
+            if name.startswith(kernel + "<") or name == kernel:
+                out["traffic"] = v["hbm_bytes_per_launch"]
+                out["traffic_unit"] = "bytes per launch (HBM read + write, PMC)"
+                out["traffic_source"] = os.path.relpath(pmc[-1], os.path.dirname(root))
+                break
+    st = sorted(glob.glob(os.path.join(root, "r*", "bench%d_v*_kernel_stats.csv" % N)), key=key)
+    if st:
+        for r in csv.DictReader(open(st[-1])):
+            if r["Name"].replace("void ", "").startswith(kernel + "<") or r["Name"].startswith(kernel + "("):
+                out["rocprof_avg_launch_us"] = float(r["AverageNs"]) / 1e3
+                out["rocprof_source"] = os.path.relpath(st[-1], os.path.dirname(root))
+                break
+    return out
 
 
 if __name__ == "__main__":
