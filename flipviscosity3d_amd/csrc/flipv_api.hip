@@ -117,10 +117,20 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); flipv_destroy(c); return FLIPV_ERR_HIP; } } while (0)
 #define GALLOC(ptr) do { int rc_ = grid_alloc(c, &(ptr)); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } } while (0)
 #define VALLOC(ptr) do { double *t_ = nullptr; int rc_ = grid_alloc(c, &t_); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } (ptr) = t_; } while (0)
-    c->stream = nullptr;
+    c->stream = c->xs = c->commStream = nullptr;
+    c->evMain = c->evHalo = nullptr;
+    c->nIntP = c->nIntV = 0;
+    {
+        const char *e = getenv("FLIPV_COMM_OVERLAP");
+        c->commOverlap = !(e && e[0] == '0');
+    }
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) c->phaseEv[q] = nullptr;
     CHK(hipSetDevice(dev));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CHK(hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
+    CHK(hipEventCreateWithFlags(&c->evMain, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming));
+    c->xs = c->stream;
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) CHK(hipEventCreate(&c->phaseEv[q]));
     GALLOC(c->U); GALLOC(c->V); GALLOC(c->W);
     GALLOC(c->sU); GALLOC(c->sV); GALLOC(c->sW);
@@ -207,6 +217,7 @@ extern "C" int flipv_slab_range(flipv_context *c, int *kbegin, int *kend) {
 extern "C" int flipv_destroy(flipv_context *c) {
     if (!c) return FLIPV_OK;
     (void)hipSetDevice(c->device);
+    if (c->commStream) (void)hipStreamSynchronize(c->commStream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { delete c->comm; c->comm = nullptr; }
     for (void *p : c->allocs) (void)hipFree(p);
@@ -218,6 +229,9 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) if (c->phaseEv[q]) (void)hipEventDestroy(c->phaseEv[q]);
+    if (c->evMain) (void)hipEventDestroy(c->evMain);
+    if (c->evHalo) (void)hipEventDestroy(c->evHalo);
+    if (c->commStream) (void)hipStreamDestroy(c->commStream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return FLIPV_OK;

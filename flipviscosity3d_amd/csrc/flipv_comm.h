@@ -12,7 +12,7 @@
 //   halo reduce  neighbour -> owner contributions on planes a rank scattered into but does not own, combined
 //                with min (particle SDF) or + (P2G accumulators)
 //   all-reduce   the PCG scalars.  Ranks accumulate into DISJOINT slots of the per-iteration slot block, so one
-//                sum all-reduce merges sums and maxima alike: 2 small all-reduces per PCG iteration
+//                sum all-reduce merges sums and maxima alike: ONE small all-reduce per PCG iteration (pcg_common.h)
 //   migration    particles that left the slab go to the neighbour owning their cell (counts first, then records)
 //
 // Backends: RCCL (one process per GPU, ncclSend/ncclRecv grouped per exchange, ncclAllReduce; librccl is
@@ -36,6 +36,8 @@ struct Comm {
 // halo helpers (flipv_comm.hip)
 struct HaloArray { void *p; size_t elem; };
 int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H);
+int fv_halo_copy_begin(flipv_context *c, const HaloArray *arr, int n, int H);  // on the communication stream, overlapping c->stream
+int fv_halo_wait(flipv_context *c);                                             // c->stream waits for that exchange
 enum { HALO_MIN_F32 = 0, HALO_ADD_F32 = 1 };
 int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op);
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n);

@@ -64,6 +64,26 @@ int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
     return cm->end(c);
 }
 
+// The same exchange on the communication stream: it starts once everything enqueued on c->stream so far has finished and
+// runs beside whatever c->stream is given next; fv_halo_wait() makes c->stream wait for it.
+int fv_halo_copy_begin(flipv_context *c, const HaloArray *arr, int n, int H) {
+    if (!c->comm || H <= 0) return FLIPV_OK;
+    if (!c->commOverlap) return fv_halo_copy(c, arr, n, H);
+    HIPCHK(c, hipEventRecord(c->evMain, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->commStream, c->evMain, 0));
+    c->xs = c->commStream;
+    const int rc = fv_halo_copy(c, arr, n, H);
+    c->xs = c->stream;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->evHalo, c->commStream));
+    return FLIPV_OK;
+}
+int fv_halo_wait(flipv_context *c) {
+    if (!c->comm || !c->commOverlap) return FLIPV_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));
+    return FLIPV_OK;
+}
+
 int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op) {
     Comm *cm = c->comm;
     if (!cm) return FLIPV_OK;
@@ -242,8 +262,8 @@ struct RcclComm : Comm {
     }
     int begin(flipv_context *c) override { return chk(c, g_rccl.GroupStart(), "ncclGroupStart"); }
     int sendrecv(flipv_context *c, int peer, const void *sb, size_t sbytes, void *rb, size_t rbytes) override {
-        if (sbytes) { int rc = chk(c, g_rccl.Send(sb, sbytes, NCCL_CHAR, peer, comm, c->stream), "ncclSend"); if (rc) return rc; }
-        if (rbytes) { int rc = chk(c, g_rccl.Recv(rb, rbytes, NCCL_CHAR, peer, comm, c->stream), "ncclRecv"); if (rc) return rc; }
+        if (sbytes) { int rc = chk(c, g_rccl.Send(sb, sbytes, NCCL_CHAR, peer, comm, c->xs), "ncclSend"); if (rc) return rc; }
+        if (rbytes) { int rc = chk(c, g_rccl.Recv(rb, rbytes, NCCL_CHAR, peer, comm, c->xs), "ncclRecv"); if (rc) return rc; }
         return FLIPV_OK;
     }
     int end(flipv_context *c) override { return chk(c, g_rccl.GroupEnd(), "ncclGroupEnd"); }
@@ -291,7 +311,7 @@ struct LocalComm : Comm {
         return FLIPV_OK;
     }
     int end(flipv_context *c) override {
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // my send buffers are complete
+        HIPCHK(c, hipStreamSynchronize(c->xs));  // my send buffers are complete
         g->ops[rank] = mine;
         g->wait();
         // pull: my m-th operation towards peer p matches p's m-th operation towards me
@@ -304,11 +324,11 @@ struct LocalComm : Comm {
             for (const auto &po : g->ops[op.peer])
                 if (po.peer == rank && cnt++ == m) { match = &po; break; }
             if (!match || match->sbytes != op.rbytes) { c->err = "local comm: unmatched sendrecv"; rc = FLIPV_ERR_COMM; continue; }
-            if (op.rbytes && hipMemcpyAsync(op.rb, match->sb, op.rbytes, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) {
+            if (op.rbytes && hipMemcpyAsync(op.rb, match->sb, op.rbytes, hipMemcpyDeviceToDevice, c->xs) != hipSuccess) {
                 c->err = "local comm: hipMemcpyAsync failed"; rc = FLIPV_ERR_HIP;
             }
         }
-        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = FLIPV_ERR_HIP;
+        if (hipStreamSynchronize(c->xs) != hipSuccess) rc = FLIPV_ERR_HIP;
         g->wait();  // everybody has read: send buffers may be reused
         return rc;
     }

@@ -65,6 +65,11 @@ struct flipv_context {
     // slab decomposition along k: this rank owns index planes [k0, k1) (k1 = PZ on the last rank).  Single GPU: [0, PZ).
     int k0, k1;
     Comm *comm;      // nullptr on a single GPU
+    // communication stream state: point-to-point operations are enqueued on `xs` (normally = stream; = commStream
+    // while a halo exchange overlaps interior work, see pcg_common.h), the scalar all-reduces always on `stream`
+    hipStream_t xs, commStream;
+    hipEvent_t evMain, evHalo;
+    int commOverlap;  // 1: halo exchange of the PCG search direction overlaps the interior SpMV (FLIPV_COMM_OVERLAP=0 disables)
     float dx;
     int device;
     hipStream_t stream;
@@ -95,7 +100,7 @@ struct flipv_context {
     double *d_scal_small;  // 64 doubles: communication scratch (counts, CFL max, barrier)
     double *h_scal;   // pinned host mirror
     size_t scalCap;
-    int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits
+    int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits, [4,5] graph iteration counters, [6] interior tile count
     int *h_flags;     // pinned host mirror
     int viscosity_nonzero;  // cached host-side: any viscosity node > 0
 
@@ -104,6 +109,7 @@ struct flipv_context {
     int *tileListP, *tileListV;
     int *tileFlag;
     int nActiveP, nActiveV;
+    int nIntP, nIntV;  // multi-rank: the first nInt* list entries are tiles of interior planes, the rest of the slab's two boundary planes
     int vwV;         // lane width chosen for the current viscosity solve (2 or 4)
 
     // pressure system (zero outside pressure cells)

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
                                                        T *__restrict__ q, PcgScal sc, int it_arg) {
     __shared__ double lds[12];
     const int it = d_iter_spmv(sc, it_arg);
-    if (d_spmv_stop(sc, it, lds)) return;
+    if (d_spmv_stop(sc, it)) return;
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
     const int nvb = ((ntiles + 7) >> 3) << 3;
@@ -184,16 +184,24 @@ __global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, 
 }
 
 // ordered compaction of the flagged tiles by one block (tile counts are 1e4..1e5)
+// mode 0: every flagged tile; 1: only tiles of the interior planes (k0 < k < k0+nk-1); 2: only tiles of the two boundary
+// planes, appended after *prev entries (multi-rank: the SpMV of the interior tiles overlaps the halo exchange)
 __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ flag, int ntiles, int *__restrict__ list,
-                                                       int *__restrict__ count, TileGrid tg, int k0, int nk) {
+                                                       int *__restrict__ count, TileGrid tg, int k0, int nk, int mode,
+                                                       const int *__restrict__ prev) {
     __shared__ int wsum[16];
     __shared__ int base;
-    if (threadIdx.x == 0) base = 0;
+    if (threadIdx.x == 0) base = prev ? *prev : 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int start = 0; start < ntiles; start += 1024) {
         const int t = start + threadIdx.x;
-        const int f = (t < ntiles) ? (flag[t] != 0) : 0;
+        int f = (t < ntiles) ? (flag[t] != 0) : 0;
+        if (f && mode) {
+            const int kk = (t / (tg.ntx * JCH)) % nk;  // plane of virtual tile t (d_virtual_tile)
+            const bool boundary = kk == 0 || kk == nk - 1;
+            f = (mode == 2) == boundary;
+        }
         const unsigned long long m = __ballot(f);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[wv] = __popcll(m);
@@ -237,23 +245,37 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
 }
 
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   int *list, int *nActive) {
+                   int *list, int *nActive, int *nInterior) {
     const int nk = c->k1 - c->k0, nchunks = (tg.nty + JCH - 1) / JCH;
     const int nt = tg.ntx * JCH * nk * nchunks;  // virtual tiles of the owned planes (column-major enumeration)
     hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, c->tileFlag, c->k0, nk);
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk);
+    if (!c->comm) {
+        hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 0,
+                           (const int *)nullptr);
+        HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *nActive = *nInterior = c->h_flags[1];
+        return FLIPV_OK;
+    }
+    // list = [tiles of the interior planes | tiles of the slab's first and last plane]
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 6, tg, c->k0, nk, 1,
+                       (const int *)nullptr);
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 2,
+                       (const int *)(c->d_flags + 6));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_flags + 6, c->d_flags + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *nActive = c->h_flags[1];
+    *nInterior = c->h_flags[6];
     return FLIPV_OK;
 }
 
 template <typename T>
-static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it) {
-    const int nb = pcg_grid(c->nActiveP);
-    const bool timed = c->prm.kernel_timing && (it & 7) == 0;  // HIP events around every 8th launch
-    if (timed) fv_ev_begin(c, 0, (double)c->nActiveP * (64 * VW_P * TY));
-    hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L,
+static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
+    const int nb = pcg_grid(count);
+    const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
+    if (timed) fv_ev_begin(c, 0, (double)count * (64 * VW_P * TY));
+    hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it);
     if (timed) fv_ev_end(c);
 }
@@ -283,7 +305,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, bmax, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->tileListP, &c->nActiveP);  // synchronises: h_scal[0] = max|b|
+    rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
     {
         float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)
@@ -317,16 +339,11 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);
     if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     int conv = -1;
-    auto launch_iter = [&](int it) -> int {
-        int r;
-        if ((r = fv_halo_copy(c, sh, 1, 1))) return r;                                            // s on the neighbours' boundary planes
-        launch_pressure_spmv<T>(c, sc, it);
-        if (c->comm && (r = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return r;              // a, b, c
+    auto spmv = [&](int first, int count, int it) { launch_pressure_spmv<T>(c, sc, it, first, count); };
+    auto update = [&](int it) {
         hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
-        if (c->comm && (r = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return r;           // rmax[it], sig[it+1]
-        return FLIPV_OK;
     };
-    if ((rc = pcg_iterate(c, sc, cap, launch_iter, &conv))) return rc;
+    if ((rc = pcg_run(c, sc, cap, sh, 1, c->nIntP, c->nActiveP, spmv, update, &conv))) return rc;
     const int last = conv >= 0 ? conv : cap - 1;
     hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -359,11 +376,11 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
     PcgScal sc;
     memset(&sc, 0, sizeof(sc));  // no scalars, no stop flag: pure kernel launches
     for (int w = 0; w < 3; w++) {
-        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0); else launch_pressure_spmv<float>(c, sc, 0);
+        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0, 0, c->nActiveP); else launch_pressure_spmv<float>(c, sc, 0, 0, c->nActiveP);
     }
     HIPCHK(c, hipEventRecord(a, c->stream));
     for (int r = 0; r < reps; r++) {
-        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0); else launch_pressure_spmv<float>(c, sc, 0);
+        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0, 0, c->nActiveP); else launch_pressure_spmv<float>(c, sc, 0, 0, c->nActiveP);
     }
     HIPCHK(c, hipEventRecord(b, c->stream));
     HIPCHK(c, hipEventSynchronize(b));

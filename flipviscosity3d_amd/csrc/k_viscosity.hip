@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, NV == 2 ? 4 : 2) void k_visc_spmv(const int *_
                                                    const float *__restrict__ fEW, PcgSys<T, 3> v, PcgScal sc, int it_arg) {
     __shared__ double lds[12];
     const int it = d_iter_spmv(sc, it_arg);
-    if (d_spmv_stop(sc, it, lds)) return;
+    if (d_spmv_stop(sc, it)) return;
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
     const int nvb = ((ntiles + 7) >> 3) << 3;
@@ -434,11 +434,11 @@ static PcgSys<T, 3> visc_sys(flipv_context *c) {
 }
 
 template <typename T, int NV>
-static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it) {
-    const int nb = pcg_grid(c->nActiveV);
-    const bool timed = c->prm.kernel_timing && (it & 7) == 0;  // HIP events around every 8th launch
-    if (timed) fv_ev_begin(c, 1, (double)c->nActiveV * (64 * NV * TY));
-    hipLaunchKernelGGL((k_visc_spmv<T, NV>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L,
+static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
+    const int nb = pcg_grid(count);
+    const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
+    if (timed) fv_ev_begin(c, 1, (double)count * (64 * NV * TY));
+    hipLaunchKernelGGL((k_visc_spmv<T, NV>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
                        c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
     if (timed) fv_ev_end(c);
 }
@@ -502,7 +502,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const double fill = (double)c->h_flags[2] / (3.0 * (double)(c->k1 - c->k0) * (double)L.PX * (double)L.PY);
     c->vwV = fill > 0.35 ? 4 : 2;
     c->tgV.ntx = (L.PX + 64 * c->vwV - 1) / (64 * c->vwV);
-    rc = fv_build_tiles(c, c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->tileListV, &c->nActiveV);
+    rc = fv_build_tiles(c, c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->tileListV, &c->nActiveV, &c->nIntV);
     if (rc) return rc;
     if (c->comm) {
         float bn = (float)c->h_scal[0];
@@ -533,19 +533,16 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         else
             hipLaunchKernelGGL((k_pcg_init<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc);
         if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
-        auto launch_iter = [&](int it) -> int {
-            int r;
-            if ((r = fv_halo_copy(c, sh, 3, 1))) return r;                                            // s on the neighbours' boundary planes
-            if (c->vwV == 4) launch_visc_spmv<T, 4>(c, sc, it); else launch_visc_spmv<T, 2>(c, sc, it);
-            if (c->comm && (r = fv_allreduce_scalars(c, sc.a(it), 3 * NSLOT))) return r;              // a, b, c
+        auto spmv = [&](int first, int count, int it) {
+            if (c->vwV == 4) launch_visc_spmv<T, 4>(c, sc, it, first, count); else launch_visc_spmv<T, 2>(c, sc, it, first, count);
+        };
+        auto update = [&](int it) {
             if (c->vwV == 4)
                 hipLaunchKernelGGL((k_pcg_update<T, 3, 4>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
             else
                 hipLaunchKernelGGL((k_pcg_update<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
-            if (c->comm && (r = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return r;           // rmax[it], sig[it+1]
-            return FLIPV_OK;
         };
-        if ((rc = pcg_iterate(c, sc, cap, launch_iter, &conv))) return rc;
+        if ((rc = pcg_run(c, sc, cap, sh, 3, c->nIntV, c->nActiveV, spmv, update, &conv))) return rc;
         const int last = conv >= 0 ? conv : cap - 1;
         hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -588,13 +585,13 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
     PcgScal sc;
     memset(&sc, 0, sizeof(sc));
     for (int w = 0; w < 3; w++) {
-        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0); else launch_visc_spmv<float, 4>(c, sc, 0); }
-        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0); else launch_visc_spmv<float, 2>(c, sc, 0); }
+        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 4>(c, sc, 0, 0, c->nActiveV); }
+        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 2>(c, sc, 0, 0, c->nActiveV); }
     }
     HIPCHK(c, hipEventRecord(a, c->stream));
     for (int r = 0; r < reps; r++) {
-        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0); else launch_visc_spmv<float, 4>(c, sc, 0); }
-        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0); else launch_visc_spmv<float, 2>(c, sc, 0); }
+        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 4>(c, sc, 0, 0, c->nActiveV); }
+        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 2>(c, sc, 0, 0, c->nActiveV); }
     }
     HIPCHK(c, hipEventRecord(b, c->stream));
     HIPCHK(c, hipEventSynchronize(b));

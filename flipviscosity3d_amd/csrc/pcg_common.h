@@ -14,7 +14,7 @@
 // SpMV's three dot products are, and the classic third kernel (s = z + beta s after a second reduction) folds into
 // the update.  The next iteration's alpha uses sigma' recomputed from the actual vectors, so nothing drifts.
 // Everything stays on the device: the scalars are fp64 sums accumulated with one atomic per block into slots
-// indexed by iteration (nothing is reset inside the loop); K1 stops the solve by setting a device flag once
+// indexed by iteration (nothing is reset inside the loop); K2 stops the solve by setting a device flag once
 // rmax of the previous iteration passes the tolerance, after which every launch returns immediately, so the
 // host only polls every few iterations.
 //
@@ -23,6 +23,7 @@
 // i-neighbours come from the adjacent lane (ds_bpermute), j/k-neighbours from aligned loads of the adjacent rows.
 #pragma once
 #include "flipv_internal.h"
+#include "flipv_comm.h"
 
 // N consecutive i of one lane (N = 4: one dwordx4 access for fp32; N = 2: dwordx2)
 template <typename T, int N> struct Vec { T v[N]; };
@@ -88,8 +89,8 @@ __device__ __forceinline__ T nb_right(const Vec<T, N> &a, const T *__restrict__ 
 // one-atomic-per-block accumulation does not serialise on a single L2 address (thousands of blocks per launch);
 // the consuming kernel folds the NSLOT partials with one wave.
 constexpr int NSLOT = 32;
-// Layout of ctx->d_scal: block `it` = [sig | a | b | c | rmax] x NSLOT doubles.  a,b,c of one iteration are
-// contiguous (one all-reduce after the SpMV) and rmax[it] is followed by sig[it+1] (one all-reduce after the update).
+// Layout of ctx->d_scal: block `it` = [sig | a | b | c | rmax] x NSLOT doubles.  rmax[it-1], sig[it] (both left by
+// update it-1) and a,b,c[it] (left by SpMV it) are contiguous: ONE all-reduce per iteration, between SpMV and update.
 // In a multi-rank run rank r accumulates only into slots [slot0, slot0 + nslot): the slots are disjoint between
 // ranks, so a SUM all-reduce merges sums and maxima alike.
 struct PcgScal {
@@ -211,15 +212,9 @@ __device__ __forceinline__ int d_iter_spmv(const PcgScal &sc, int it_arg) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.itB = it;
     return it;
 }
-__device__ __forceinline__ bool d_spmv_stop(const PcgScal &sc, int it, double *lds8) {
+__device__ __forceinline__ bool d_spmv_stop(const PcgScal &sc, int it) {
     if (!sc.conv) return false;  // benchmark launches
-    if (*sc.conv >= 0 || it >= sc.cap) return true;
-    if (it > 0 && d_pass(sc, d_fold_max(sc.rmax(it - 1), lds8))) {
-        // every block takes the same decision from the same completed value; one of them records it
-        if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it - 1;
-        return true;
-    }
-    return false;
+    return *sc.conv >= 0 || it >= sc.cap;
 }
 
 template <typename T, int NC, int N>
@@ -257,6 +252,13 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     const int it = it_arg >= 0 ? it_arg : *sc.itB;
     if (it >= sc.cap) return;
     __shared__ double lds[8];
+    // stop test on the residual the previous update left (in a multi-rank run its partial maxima were merged by the
+    // all-reduce that precedes this launch): every block takes the same decision from the same completed value, one
+    // of them records it.  x is not touched again, so the solution is the one after iteration it-1.
+    if (it > 0 && d_pass(sc, d_fold_max(sc.rmax(it - 1), lds))) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it - 1;
+        return;
+    }
     double f[4];
     d_fold_sums(sc.sig(it), sc.a(it), sc.b(it), sc.c(it), f, lds);
     const double sg = f[0], a = f[1];
@@ -329,18 +331,39 @@ int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT
 // never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
 static inline int pcg_grid(int ntiles) { const int nb = ((ntiles + 7) / 8) * 8; return nb < 8 ? 8 : (nb < MAX_PCG_BLOCKS ? nb : MAX_PCG_BLOCKS); }
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   int *list, int *nActive);
+                   int *list, int *nActive, int *nInterior);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
 
-// The iteration loop shared by both solves.  launch_iter(it_arg) enqueues one iteration (halo copy, SpMV, scalar
-// all-reduce, update, scalar all-reduce) on c->stream; it_arg = -1 selects the device-side iteration counters.
+// The iteration loop shared by both solves.
+//   spmv(first, count, it)  enqueues K1 over list entries [first, first+count) on c->stream
+//   update(it)              enqueues K2 over the whole list
+// it = -1 selects the device-side iteration counters (hipGraph replay).
+//
 // Single GPU without per-launch event timing: `every` iterations + the convergence check + the flag read-back are
-// captured once into a hipGraph and replayed (launch gaps between the ~20-40 us kernels otherwise cost ~25 % of the
-// solve).  With a communicator (RCCL calls on the stream) or kernel timing the iterations are launched directly.
-template <class LaunchIter>
-static int pcg_iterate(flipv_context *c, const PcgScal &sc, int cap, LaunchIter launch_iter, int *conv_out) {
+// captured once into a hipGraph and replayed.
+//
+// Multi-rank (one slab per rank): per iteration
+//   communication stream:  halo exchange of s (starts when update it-1 has finished)
+//   c->stream:             K1 over the tiles of the interior planes  |  wait for the halo  |  K1 over the tiles of the
+//                          two boundary planes  |  ONE all-reduce [rmax(it-1) sig(it) a b c(it)]  |  K2
+// so the exchange hides behind the interior SpMV and the only exposed communication is one 1.3 KB all-reduce.
+template <class Spmv, class Update>
+static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray *sh, int nsh, int nInt, int nAct, Spmv spmv,
+                   Update update, int *conv_out) {
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
     int conv = -1, rc;
+    auto launch_iter = [&](int it) -> int {
+        int r;
+        if (!c->comm) { spmv(0, nAct, it); update(it); return FLIPV_OK; }
+        if ((r = fv_halo_copy_begin(c, sh, nsh, 1))) return r;
+        if (nInt > 0) spmv(0, nInt, it);
+        if ((r = fv_halo_wait(c))) return r;
+        if (nAct > nInt) spmv(nInt, nAct - nInt, it);
+        r = it == 0 ? fv_allreduce_scalars(c, sc.a(0), 3 * NSLOT) : fv_allreduce_scalars(c, sc.rmax(it - 1), 5 * NSLOT);
+        if (r) return r;
+        update(it);
+        return FLIPV_OK;
+    };
     const bool graph = !c->comm && !c->prm.kernel_timing && !c->prm.reserved[0];
     if (graph) {
         HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
@@ -354,7 +377,7 @@ static int pcg_iterate(flipv_context *c, const PcgScal &sc, int cap, LaunchIter 
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
         if (rc != FLIPV_OK || e1 != hipSuccess || e2 != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
-            c->err = "pcg_iterate: stream capture failed";
+            c->err = "pcg_run: stream capture failed";
             return rc != FLIPV_OK ? rc : FLIPV_ERR_HIP;
         }
         hipError_t e3 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
@@ -373,7 +396,16 @@ static int pcg_iterate(flipv_context *c, const PcgScal &sc, int cap, LaunchIter 
             const int stop = (it + every < cap) ? it + every : cap;
             for (; it < stop; it++)
                 if ((rc = launch_iter(it))) return rc;
-            hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
+            // single rank: test the chunk's last iteration now; multi-rank: its partial maxima are merged by the next
+            // iteration's all-reduce and the next update records the stop (seen one poll later)
+            if (!c->comm) hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, it - 1);
+            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            conv = c->h_flags[0];
+        }
+        if (c->comm && conv < 0) {  // cap reached: the last iteration's residual has not been merged or tested yet
+            if ((rc = fv_allreduce_scalars(c, sc.rmax(cap - 1), NSLOT))) return rc;
+            hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, cap - 1);
             HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             conv = c->h_flags[0];
