@@ -97,6 +97,9 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->k1 = kend == K ? L.PZ : kend;  // the last slab also owns the closing plane of W faces / nodes
     c->comm = nullptr;
     c->pScratch = nullptr; c->pScratchCap = 0;
+    c->binIdx = nullptr; c->binIdxCap = 0;
+    c->binCnt = c->binOff = c->binCur = c->binList = c->binNList = nullptr;
+    c->binTilesCap = 0; c->nbx = c->nby = c->nbz = 0; c->binsValid = 0;
     c->haloBuf = nullptr; c->haloCap = 0;
     c->d_scal_small = nullptr;
     c->dx = dx;
@@ -143,6 +146,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     {
         int rc_ = plain_alloc(c, &c->d_flags, 16);
         if (!rc_) rc_ = plain_alloc(c, &c->d_scal_small, 64);
+        if (!rc_) rc_ = plain_alloc(c, &c->actFlags, (size_t)2 * ((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8));
         if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
     }
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
@@ -223,6 +227,8 @@ extern "C" int flipv_destroy(flipv_context *c) {
     for (void *p : c->allocs) (void)hipFree(p);
     if (c->particles) (void)hipFree(c->particles);
     if (c->pScratch) (void)hipFree(c->pScratch);
+    if (c->binIdx) (void)hipFree(c->binIdx);
+    if (c->binCnt) (void)hipFree(c->binCnt);
     if (c->haloBuf) (void)hipFree(c->haloBuf);
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -375,6 +381,7 @@ extern "C" int flipv_upload_particles(flipv_context *c, const float *aos6, size_
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->np = n;
+    c->binsValid = 0;
     return FLIPV_OK;
 }
 extern "C" int flipv_download_particles(flipv_context *c, float *aos6, size_t capacity, size_t *n_out) {

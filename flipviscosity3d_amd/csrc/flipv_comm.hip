@@ -203,6 +203,7 @@ int fv_migrate_particles(flipv_context *c) {
     rc = cm->end(c);
     if (rc) return rc;
     c->np = nNew;
+    c->binsValid = 0;
     return FLIPV_OK;
 }
 

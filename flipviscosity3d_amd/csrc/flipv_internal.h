@@ -88,9 +88,18 @@ struct flipv_context {
     size_t pScratchCap;
     float *haloBuf;    // receive staging for halo reductions
     size_t haloCap;
+    // particle bins (k_particles.hip): particle indices grouped by tile of BIN_T^3 cells, rebuilt by fv_bin_particles
+    unsigned *binIdx;      // np particle indices, tile by tile
+    size_t binIdxCap;
+    int *binCnt, *binOff, *binCur, *binList;  // per tile: count, first entry, fill cursor; compacted list of non-empty tiles
+    int *binNList;         // device: number of non-empty tiles
+    int binTilesCap;
+    int nbx, nby, nbz;     // tile grid of the owned slab
+    int binsValid;         // bins match the current particle positions
     // P2G accumulators (value, weight) per component
     float *accU, *accV, *accW, *wgtU, *wgtV, *wgtW;
-    // extrapolation stamps
+    // extrapolation stamps + activity blocks (2 x ceil(PX/8) ceil(PY/8) ceil(PZ/8) bytes)
+    uint8_t *actFlags;
     uint8_t *stampU, *stampV, *stampW;
     // staging for Array3d <-> device layout conversion
     float *stage;

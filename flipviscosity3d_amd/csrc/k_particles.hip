@@ -90,6 +90,264 @@ __global__ void k_p2g_scatter(Lay L, const float *__restrict__ aos6, size_t n, f
     }
 }
 
+// ------------------------------------------------------------------ particle bins
+// Particles are grouped (indices only, the caller's particle order is never changed) by tile of BIN_T^3 cells of the
+// owned slab: count per tile -> exclusive scan + list of non-empty tiles (one block) -> fill.  The scatter kernels
+// below then give one workgroup a tile, accumulate its particles in LDS (ds_add_f32 / ds_min) and touch global memory
+// once per tile node instead of up to 162 times per particle.
+constexpr int BIN_T = 8;
+struct BinGrid { int nbx, nby, nbz, kc0, kc1; };  // kc0/kc1: cell-plane range of the slab the tiles cover
+
+__device__ __forceinline__ int d_bin_of(const BinGrid &B, const Lay &L, float px, float py, float pz, double invdx) {
+    int gi = d_pos_index(px, invdx), gj = d_pos_index(py, invdx), gk = d_pos_index(pz, invdx);
+    gi = min(max(gi, 0), L.I - 1); gj = min(max(gj, 0), L.J - 1); gk = min(max(gk, B.kc0), B.kc1 - 1);
+    return gi / BIN_T + B.nbx * (gj / BIN_T + B.nby * ((gk - B.kc0) / BIN_T));
+}
+
+// Particles that are neighbours in the caller's order are mostly neighbours in space: the lanes of a wave that hit the
+// same tile are merged into ONE atomic (4096 particles per tile would otherwise serialise on one L2 address).
+// Returns this lane's rank among the wave's lanes with the same tile, the group size and whether it is the group's leader.
+__device__ __forceinline__ void d_wave_group(bool valid, int t, int &rank, int &size, int &leader) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    rank = 0; size = 0; leader = -1;
+    while (todo) {
+        const int lead = __ffsll((long long)todo) - 1;
+        const int tl = __shfl(t, lead, 64);
+        const unsigned long long m = __ballot(valid && t == tl);
+        if (valid && t == tl) {
+            rank = __popcll(m & ((1ull << lane) - 1ull));
+            size = __popcll(m);
+            leader = lead;
+        }
+        todo &= ~m;
+    }
+}
+
+__global__ void k_bin_count(BinGrid B, Lay L, const float *__restrict__ aos6, size_t n, int *__restrict__ cnt, float dx) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = p < n;
+    const int t = valid ? d_bin_of(B, L, aos6[6 * p], aos6[6 * p + 1], aos6[6 * p + 2], 1.0 / (double)dx) : -1;
+    int rank, size, leader;
+    d_wave_group(valid, t, rank, size, leader);
+    if (valid && rank == 0) atomicAdd(&cnt[t], size);
+}
+
+// exclusive scan of the tile counts + ordered list of the non-empty tiles, one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_bin_scan(const int *__restrict__ cnt, int ntiles, int *__restrict__ off,
+                                                   int *__restrict__ cur, int *__restrict__ list, int *__restrict__ nlist) {
+    __shared__ int wsum[16], wne[16];
+    __shared__ int base, nbase;
+    if (threadIdx.x == 0) { base = 0; nbase = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int start = 0; start < ntiles; start += 1024) {
+        const int t = start + threadIdx.x;
+        const int v = t < ntiles ? cnt[t] : 0;
+        int incl = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        const unsigned long long m = __ballot(v > 0);
+        if (lane == 63) wsum[wv] = incl;
+        if (lane == 0) wne[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, noff = 0, total = 0, ntot = 0;
+        for (int q = 0; q < 16; q++) {
+            if (q < wv) { woff += wsum[q]; noff += wne[q]; }
+            total += wsum[q]; ntot += wne[q];
+        }
+        if (t < ntiles) {
+            const int o = base + woff + incl - v;
+            off[t] = o;
+            cur[t] = o;
+            if (v > 0) list[nbase + noff + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { base += total; nbase += ntot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nlist = nbase;
+}
+
+__global__ void k_bin_fill(BinGrid B, Lay L, const float *__restrict__ aos6, size_t n, int *__restrict__ cur,
+                           unsigned *__restrict__ idx, float dx) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = p < n;
+    const int t = valid ? d_bin_of(B, L, aos6[6 * p], aos6[6 * p + 1], aos6[6 * p + 2], 1.0 / (double)dx) : -1;
+    int rank, size, leader;
+    d_wave_group(valid, t, rank, size, leader);
+    int base = 0;
+    if (valid && rank == 0) base = atomicAdd(&cur[t], size);
+    base = __shfl(base, leader < 0 ? 0 : leader, 64);
+    if (valid) idx[base + rank] = (unsigned)p;
+}
+
+// K1 on bins: LDS min over the tile's particles, then one global atomic-min per touched cell.  min is order-free:
+// bit-identical to k_sdf_scatter.
+constexpr int SDF_R = BIN_T + 2;  // a particle reaches its cell +-1
+__global__ __launch_bounds__(256) void k_sdf_tiles(BinGrid B, Lay L, const float *__restrict__ aos6,
+                                                   const unsigned *__restrict__ idx, const int *__restrict__ off,
+                                                   const int *__restrict__ cnt, const int *__restrict__ list,
+                                                   const int *__restrict__ nlist, float *__restrict__ phi, float dx,
+                                                   float radius, float maxd) {
+    __shared__ float sh[SDF_R * SDF_R * SDF_R];
+    const int I = L.I, J = L.J, K = L.K;
+    const double dxd = (double)dx, invdx = 1.0 / dxd, hw = 0.5 * dxd;
+    const int nl = *nlist;
+    for (int tt = blockIdx.x; tt < nl; tt += gridDim.x) {
+        const int tile = list[tt];
+        const int tx = tile % B.nbx, ty = (tile / B.nbx) % B.nby, tz = tile / (B.nbx * B.nby);
+        const int bi = tx * BIN_T - 1, bj = ty * BIN_T - 1, bk = B.kc0 + tz * BIN_T - 1;
+        for (int e = threadIdx.x; e < SDF_R * SDF_R * SDF_R; e += 256) sh[e] = maxd;
+        __syncthreads();
+        const int start = off[tile], n = cnt[tile];
+        for (int q = threadIdx.x; q < n; q += 256) {
+            const size_t p = idx[start + q];
+            const float px = aos6[6 * p], py = aos6[6 * p + 1], pz = aos6[6 * p + 2];
+            const int gi = d_pos_index(px, invdx), gj = d_pos_index(py, invdx), gk = d_pos_index(pz, invdx);
+            const int i0 = max(0, gi - 1), j0 = max(0, gj - 1), k0 = max(0, gk - 1);
+            const int i1 = min(gi + 1, I - 1), j1 = min(gj + 1, J - 1), k1 = min(gk + 1, K - 1);
+            for (int k = k0; k <= k1; k++) {
+                const float vz = (float)(k * dxd + hw) - pz;
+                for (int j = j0; j <= j1; j++) {
+                    const float vy = (float)(j * dxd + hw) - py;
+                    for (int i = i0; i <= i1; i++) {
+                        const float vx = (float)(i * dxd + hw) - px;
+                        const float dist = sqrtf(vx * vx + vy * vy + vz * vz) - radius;
+                        const int li = i - bi, lj = j - bj, lk = k - bk;
+                        if ((unsigned)li < (unsigned)SDF_R && (unsigned)lj < (unsigned)SDF_R && (unsigned)lk < (unsigned)SDF_R) {
+                            float *a = &sh[li + SDF_R * (lj + SDF_R * lk)];
+                            if (dist < *a) {
+                                if (dist >= 0.0f) atomicMin((int *)a, __float_as_int(dist));
+                                else atomicMax((unsigned *)a, __float_as_uint(dist));
+                            }
+                        } else {  // particle outside its clamped tile (never for particles inside the domain)
+                            float *a = &phi[gidx(L, i, j, k)];
+                            if (dist < *a) atomic_min_f32(a, dist);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < SDF_R * SDF_R * SDF_R; e += 256) {
+            const float v = sh[e];
+            if (v < maxd) {
+                const int li = e % SDF_R, lj = (e / SDF_R) % SDF_R, lk = e / (SDF_R * SDF_R);
+                float *a = &phi[gidx(L, bi + li, bj + lj, bk + lk)];
+                if (v < *a) atomic_min_f32(a, v);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// K3 on bins ("LDS-binned atomic P2G"): value and weight accumulators of the three components for the tile's reach
+// (cells -2..+1 around the tile: the half-cell shift of the transverse axes moves the stencil centre down by one) live in
+// LDS; the particles of the tile are accumulated with ds_add_f32, then every touched node is added to the global
+// accumulators once.
+constexpr int P2G_R = BIN_T + 3;
+constexpr int P2G_RN = P2G_R * P2G_R * P2G_R;
+__global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float *__restrict__ aos6,
+                                                   const unsigned *__restrict__ idx, const int *__restrict__ off,
+                                                   const int *__restrict__ cnt, const int *__restrict__ list,
+                                                   const int *__restrict__ nlist, float *__restrict__ accU,
+                                                   float *__restrict__ wgtU, float *__restrict__ accV, float *__restrict__ wgtV,
+                                                   float *__restrict__ accW, float *__restrict__ wgtW, float dx) {
+    __shared__ float sh[6 * P2G_RN];  // [dir][value|weight][node]
+    const int I = L.I, J = L.J, K = L.K;
+    const double dxd = (double)dx, invdx = 1.0 / dxd;
+    const float hdx = (float)(0.5 * dx);
+    const float r = dx, rsq = r * r;
+    const float coef1 = (4.0f / 9.0f) * (1.0f / (r * r * r * r * r * r));
+    const float coef2 = (17.0f / 9.0f) * (1.0f / (r * r * r * r));
+    const float coef3 = (22.0f / 9.0f) * (1.0f / (r * r));
+    float *gacc[6] = {accU, wgtU, accV, wgtV, accW, wgtW};
+    const int nl = *nlist;
+    for (int tt = blockIdx.x; tt < nl; tt += gridDim.x) {
+        const int tile = list[tt];
+        const int tx = tile % B.nbx, ty = (tile / B.nbx) % B.nby, tz = tile / (B.nbx * B.nby);
+        const int bi = tx * BIN_T - 2, bj = ty * BIN_T - 2, bk = B.kc0 + tz * BIN_T - 2;
+        for (int e = threadIdx.x; e < 6 * P2G_RN; e += 256) sh[e] = 0.0f;
+        __syncthreads();
+        const int start = off[tile], n = cnt[tile];
+        for (int q = threadIdx.x; q < n; q += 256) {
+            const size_t p = idx[start + q];
+            const float P[3] = {aos6[6 * p], aos6[6 * p + 1], aos6[6 * p + 2]};
+            const float Vv[3] = {aos6[6 * p + 3], aos6[6 * p + 4], aos6[6 * p + 5]};
+#pragma unroll
+            for (int dir = 0; dir < 3; dir++) {
+                const int w = I + (dir == 0), h = J + (dir == 1), d = K + (dir == 2);
+                const float px = P[0] - (dir == 0 ? 0.0f : hdx);
+                const float py = P[1] - (dir == 1 ? 0.0f : hdx);
+                const float pz = P[2] - (dir == 2 ? 0.0f : hdx);
+                const float vel = Vv[dir];
+                const int gi = d_pos_index(px, invdx), gj = d_pos_index(py, invdx), gk = d_pos_index(pz, invdx);
+                const int i0 = max(gi - 1, 0), j0 = max(gj - 1, 0), k0 = max(gk - 1, 0);
+                const int i1 = min(gi + 1, w - 1), j1 = min(gj + 1, h - 1), k1 = min(gk + 1, d - 1);
+                float *sv = sh + (2 * dir) * P2G_RN, *sw = sv + P2G_RN;
+                // per-axis offsets once (the fp64 index->position products of the reference), then 27 fp32 combinations
+                float ox[3], oy[3], oz[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    ox[t] = (float)((gi - 1 + t) * dxd) - px;
+                    oy[t] = (float)((gj - 1 + t) * dxd) - py;
+                    oz[t] = (float)((gk - 1 + t) * dxd) - pz;
+                }
+#pragma unroll
+                for (int tk = 0; tk < 3; tk++) {
+                    const int k = gk - 1 + tk;
+                    if (k < k0 || k > k1) continue;
+#pragma unroll
+                    for (int tj = 0; tj < 3; tj++) {
+                        const int j = gj - 1 + tj;
+                        if (j < j0 || j > j1) continue;
+                        const float q2 = oy[tj] * oy[tj];
+#pragma unroll
+                        for (int ti = 0; ti < 3; ti++) {
+                            const int i = gi - 1 + ti;
+                            if (i < i0 || i > i1) continue;
+                            const float qq = ox[ti] * ox[ti] + q2 + oz[tk] * oz[tk];
+                            if (qq < rsq) {
+                                const float weight = 1.0f - coef1 * qq * qq * qq + coef2 * qq * qq - coef3 * qq;
+                                const int li = i - bi, lj = j - bj, lk = k - bk;
+                                if ((unsigned)li < (unsigned)P2G_R && (unsigned)lj < (unsigned)P2G_R && (unsigned)lk < (unsigned)P2G_R) {
+                                    const int l = li + P2G_R * (lj + P2G_R * lk);
+                                    atomicAdd(&sv[l], weight * vel);
+                                    atomicAdd(&sw[l], weight);
+                                } else {  // particle outside its clamped tile (never for particles inside the domain)
+                                    const size_t f = gidx(L, i, j, k);
+                                    atomicAdd(&gacc[2 * dir][f], weight * vel);
+                                    atomicAdd(&gacc[2 * dir + 1][f], weight);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < P2G_RN; e += 256) {
+            const int li = e % P2G_R, lj = (e / P2G_R) % P2G_R, lk = e / (P2G_R * P2G_R);
+            size_t f = 0;
+            bool have = false;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float wv = sh[(2 * a + 1) * P2G_RN + e], vv = sh[(2 * a) * P2G_RN + e];
+                if (wv != 0.0f || vv != 0.0f) {  // an untouched node holds exactly 0
+                    if (!have) { f = gidx(L, bi + li, bj + lj, bk + lk); have = true; }
+                    atomicAdd(&gacc[2 * a][f], vv);
+                    atomicAdd(&gacc[2 * a + 1][f], wv);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ K15: grid -> particle
 // MACVelocityField::_interpolateLinearU/V/W (reference macvelocityfield.cpp:455-546): fp64 position,
 // cell origin and weights; out-of-range corners contribute 0; corner order of interpolation.cpp:54-66.
@@ -254,13 +512,67 @@ __global__ void k_advect_particles(Lay L, float *__restrict__ aos6, size_t n, co
 int fv_sdf_finish(flipv_context *c);
 int fv_p2g_finalize(flipv_context *c);
 
+static BinGrid bin_grid(const flipv_context *c) {
+    BinGrid B;
+    B.kc0 = c->k0;
+    B.kc1 = c->k1 < c->L.K ? c->k1 : c->L.K;
+    if (B.kc1 <= B.kc0) B.kc1 = B.kc0 + 1;
+    B.nbx = (c->L.I + BIN_T - 1) / BIN_T;
+    B.nby = (c->L.J + BIN_T - 1) / BIN_T;
+    B.nbz = (B.kc1 - B.kc0 + BIN_T - 1) / BIN_T;
+    return B;
+}
+
+// (re)build the particle bins if the particles moved since the last build
+int fv_bin_particles(flipv_context *c) {
+    if (c->binsValid || !c->np) return FLIPV_OK;
+    const BinGrid B = bin_grid(c);
+    const int nt = B.nbx * B.nby * B.nbz;
+    if (nt > c->binTilesCap) {
+        if (c->binCnt) (void)hipFree(c->binCnt);
+        c->binCnt = nullptr; c->binTilesCap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->binCnt, ((size_t)4 * nt + 16) * sizeof(int)));
+        c->binOff = c->binCnt + nt; c->binCur = c->binOff + nt; c->binList = c->binCur + nt; c->binNList = c->binList + nt;
+        c->binTilesCap = nt;
+    }
+    if (c->np > c->binIdxCap) {
+        if (c->binIdx) (void)hipFree(c->binIdx);
+        c->binIdx = nullptr; c->binIdxCap = 0;
+        const size_t cap = c->pcap > c->np ? c->pcap : c->np;
+        HIPCHK(c, hipMalloc((void **)&c->binIdx, cap * sizeof(unsigned)));
+        c->binIdxCap = cap;
+    }
+    c->nbx = B.nbx; c->nby = B.nby; c->nbz = B.nbz;
+    HIPCHK(c, hipMemsetAsync(c->binCnt, 0, (size_t)nt * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_bin_count, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, B, c->L, c->particles, c->np, c->binCnt, c->dx);
+    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, c->stream, c->binCnt, nt, c->binOff, c->binCur, c->binList, c->binNList);
+    hipLaunchKernelGGL(k_bin_fill, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, B, c->L, c->particles, c->np, c->binCur, c->binIdx,
+                       c->dx);
+    HIPCHK(c, hipGetLastError());
+    c->binsValid = 1;
+    return FLIPV_OK;
+}
+
+static unsigned bin_blocks(const flipv_context *c) {
+    const int nt = c->nbx * c->nby * c->nbz;
+    return (unsigned)(nt < 4096 ? (nt > 0 ? nt : 1) : 4096);
+}
+
 int fv_particle_sdf(flipv_context *c) {
-    fv_fill_cells(c, c->phi, 3.0f * (float)(double)c->dx, 1);  // _getMaxDistance (particlelevelset.cpp:94-96)
+    const float maxd = 3.0f * (float)(double)c->dx;
+    fv_fill_cells(c, c->phi, maxd, 1);  // _getMaxDistance (particlelevelset.cpp:94-96)
     if (c->np) {
         // _particleRadius (fluidsimulation.cpp:36)
         const float radius = (float)(c->dx * 1.01 * sqrt(3.0) / 2.0);
-        hipLaunchKernelGGL(k_sdf_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
-                           c->phi, c->dx, radius);
+        if (c->prm.reserved[1]) {  // un-binned scatter (kept for A/B measurements)
+            hipLaunchKernelGGL(k_sdf_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
+                               c->phi, c->dx, radius);
+        } else {
+            int rcb = fv_bin_particles(c);
+            if (rcb) return rcb;
+            hipLaunchKernelGGL(k_sdf_tiles, dim3(bin_blocks(c)), dim3(256), 0, c->stream, bin_grid(c), c->L, c->particles, c->binIdx,
+                               c->binOff, c->binCnt, c->binList, c->binNList, c->phi, c->dx, radius, maxd);
+        }
     }
     // contributions to the neighbours' boundary planes (a particle reaches one cell beyond its own)
     float *parr[1] = {c->phi};
@@ -277,9 +589,18 @@ int fv_p2g(flipv_context *c) {
     const size_t off = (size_t)R.kb * c->L.sz, bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
     float *acc[6] = {c->accU, c->accV, c->accW, c->wgtU, c->wgtV, c->wgtW};
     for (int q = 0; q < 6; q++) HIPCHK(c, hipMemsetAsync(acc[q] + off, 0, bytes, c->stream));
-    if (c->np)
-        hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
-                           c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, c->dx);
+    if (c->np) {
+        if (c->prm.reserved[1]) {  // un-binned scatter (kept for A/B measurements)
+            hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
+                               c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, c->dx);
+        } else {
+            int rcb = fv_bin_particles(c);
+            if (rcb) return rcb;
+            hipLaunchKernelGGL(k_p2g_tiles, dim3(bin_blocks(c)), dim3(256), 0, c->stream, bin_grid(c), c->L, c->particles, c->binIdx,
+                               c->binOff, c->binCnt, c->binList, c->binNList, c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW,
+                               c->dx);
+        }
+    }
     int rc = fv_halo_reduce(c, acc, 6, 2, 2, HALO_ADD_F32);
     if (rc) return rc;
     fv_p2g_finalize(c);
@@ -311,5 +632,6 @@ int fv_advect_particles(flipv_context *c, float dt) {
         hipLaunchKernelGGL(k_advect_particles, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
                            c->U, c->V, c->W, c->sU, c->sV, c->sW, c->solid, c->dx, dt, c->prm.pic_ratio, b);
     HIPCHK(c, hipGetLastError());
+    c->binsValid = 0;
     return fv_migrate_particles(c);
 }

@@ -113,31 +113,38 @@ __device__ __forceinline__ float d_cube_fraction(float p000, float p100, float p
 
 // _estimateVolumeFractions (viscositysolver.cpp:180-270) for lattice `lat` whose sample centre is
 // centerStart + cellCentre(i,j,k)
-__global__ void k_volume_lattice(Lay L, int lat, const float *__restrict__ phi, const uint8_t *__restrict__ valid,
-                                 float *__restrict__ vol, float csx, float csy, float csz, float dxf) {
+struct VolLattices { float *vol[7]; int lat[7]; float cs[7][3]; };
+// all seven lattices in one sweep (one read of the band mask, one pass over the index space instead of seven)
+__global__ void k_volume_lattice(Lay L, VolLattices Q, const float *__restrict__ phi, const uint8_t *__restrict__ valid,
+                                 float dxf) {
     IJK_OR_RETURN(L);
-    int w, h, d;
-    lat_dims(L, lat, w, h, d);
-    if (i >= w || j >= h || k >= d) return;
-    float out = 0.0f;
-    if (valid[c]) {
-        const double dx = (double)dxf, invdx = 1.0 / dx, hw = 0.5 * dx;
-        const float hdx = 0.5f * dxf;          // viscositysolver.cpp:188
-        const float hoff = (float)(0.5 * dx);  // particlelevelset.cpp:89
-        const float cx = csx + (float)(i * dx + hw), cy = csy + (float)(j * dx + hw), cz = csz + (float)(k * dx + hw);
-        float p[8];
-        int neg = 0;
+    const bool band = valid[c] != 0;
+    const double dx = (double)dxf, invdx = 1.0 / dx, hw = 0.5 * dx;
+    const float hdx = 0.5f * dxf;          // viscositysolver.cpp:188
+    const float hoff = (float)(0.5 * dx);  // particlelevelset.cpp:89
+    const float ccx = (float)(i * dx + hw), ccy = (float)(j * dx + hw), ccz = (float)(k * dx + hw);
+#pragma unroll 1
+    for (int m = 0; m < 7; m++) {
+        int w, h, d;
+        lat_dims(L, Q.lat[m], w, h, d);
+        if (i >= w || j >= h || k >= d) continue;
+        float out = 0.0f;
+        if (band) {
+            const float cx = Q.cs[m][0] + ccx, cy = Q.cs[m][1] + ccy, cz = Q.cs[m][2] + ccz;
+            float p[8];
+            int neg = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {  // q = 4*oi + 2*oj + ok
-            const float sx = cx + ((q & 4) ? hdx : -hdx), sy = cy + ((q & 2) ? hdx : -hdx), sz = cz + ((q & 1) ? hdx : -hdx);
-            p[q] = d_liquid_phi_at(sx, sy, sz, dx, invdx, hoff, phi, L);
-            neg += p[q] < 0.0f;
+            for (int q = 0; q < 8; q++) {  // q = 4*oi + 2*oj + ok
+                const float sx = cx + ((q & 4) ? hdx : -hdx), sy = cy + ((q & 2) ? hdx : -hdx), sz = cz + ((q & 1) ? hdx : -hdx);
+                p[q] = d_liquid_phi_at(sx, sy, sz, dx, invdx, hoff, phi, L);
+                neg += p[q] < 0.0f;
+            }
+            if (neg == 8) out = 1.0f;
+            else if (neg == 0) out = 0.0f;
+            else out = d_cube_fraction(p[0], p[4], p[2], p[6], p[1], p[5], p[3], p[7]);  // 000,100,010,110,001,101,011,111
         }
-        if (neg == 8) out = 1.0f;
-        else if (neg == 0) out = 0.0f;
-        else out = d_cube_fraction(p[0], p[4], p[2], p[6], p[1], p[5], p[3], p[7]);  // 000,100,010,110,001,101,011,111
+        Q.vol[m][c] = out;
     }
-    vol[c] = out;
 }
 
 // ------------------------------------------------------------------ factors
@@ -478,12 +485,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validCells, c->validTmp);
     hipLaunchKernelGGL(k_valid_dilate, GRID3(R1), 0, c->stream, R1, c->validTmp, c->validCells);
     const float h = (float)(0.5 * c->dx);
-    struct { float *v; int lat; float cx, cy, cz; } lat[7] = {
-        {c->volC, LAT_CELL, h, h, h}, {c->volU, LAT_U, 0, h, h},  {c->volV, LAT_V, h, 0, h}, {c->volW, LAT_W, h, h, 0},
-        {c->volEU, LAT_EU, h, 0, 0},  {c->volEV, LAT_EV, 0, h, 0}, {c->volEW, LAT_EW, 0, 0, h}};
-    for (int q = 0; q < 7; q++)
-        hipLaunchKernelGGL(k_volume_lattice, GRID3(R1), 0, c->stream, R1, lat[q].lat, c->phi, c->validCells, lat[q].v, lat[q].cx,
-                           lat[q].cy, lat[q].cz, c->dx);
+    {
+        VolLattices Q;
+        float *vols[7] = {c->volC, c->volU, c->volV, c->volW, c->volEU, c->volEV, c->volEW};
+        const int lats[7] = {LAT_CELL, LAT_U, LAT_V, LAT_W, LAT_EU, LAT_EV, LAT_EW};
+        const float cs[7][3] = {{h, h, h}, {0, h, h}, {h, 0, h}, {h, h, 0}, {h, 0, 0}, {0, h, 0}, {0, 0, h}};  // viscositysolver.cpp:171-177
+        for (int q = 0; q < 7; q++) { Q.vol[q] = vols[q]; Q.lat[q] = lats[q]; Q.cs[q][0] = cs[q][0]; Q.cs[q][1] = cs[q][1]; Q.cs[q][2] = cs[q][2]; }
+        hipLaunchKernelGGL(k_volume_lattice, GRID3(R1), 0, c->stream, R1, Q, c->phi, c->validCells, c->dx);
+    }
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
     hipLaunchKernelGGL(k_visc_factors, GRID3(R1), 0, c->stream, R1, c->visc, c->volC, c->volEU, c->volEV, c->volEW, c->fC,

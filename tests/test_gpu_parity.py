@@ -62,6 +62,31 @@ def test_p2g_and_extrapolation(name):
 
 
 @pytest.mark.parametrize("name", SCENES)
+def test_binned_scatters_match_global_atomic_scatters(name):
+    """The LDS-tile scatters (default) against the one-thread-per-particle global-atomic kernels
+    (flipv_params.reserved[1] = 1): the SDF is a min (bit-exact), P2G differs in summation order only."""
+    import ctypes as C
+    g = Golden(name)
+    out = []
+    for unbinned in (0, 1):
+        c = make_ctx(g)
+        p = c.get_params()
+        p.reserved[1] = unbinned
+        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.particles = g.particles_before(g.nsub - 1)
+        c.particle_sdf()
+        phi = c.grid("LIQUID_PHI")
+        c.advect_velocity_field()
+        out.append((phi, [c.grid(n) for n in "UVW"], [c.grid("VALID_" + n) for n in "UVW"]))
+        c.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][0], g["s%d_phi" % (g.nsub - 1)])
+    assert rel_maxnorm3(out[0][1], out[1][1]) <= P2G_TOL
+    for a, b in zip(out[0][2], out[1][2]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", SCENES)
 def test_extrapolation_bit_exact(name, oracle):
     g = Golden(name)
     c = make_ctx(g)
