@@ -130,6 +130,7 @@ struct flipv_context {
     float *fC, *fEU, *fEV, *fEW;                               // factor lattices
     float *vDiagU, *vDiagV, *vDiagW;
     float *vmU, *vmV, *vmW;                                    // own volume of a row, -1 elsewhere (SpMV row mask)
+    uint8_t *vRowMask;                                         // bit m set: component m has a row at this index
     uint8_t *stU, *stV, *stW;
     void *vX[3], *vR[3], *vZ[3], *vS[3];
     uint8_t *validCells, *validTmp;

@@ -99,14 +99,22 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
         const size_t c = gidx(L, i0, j, k);
         const long sy = L.sy, sz = L.sz;
         const Vec<float, 4> dg = ldv<4>(diag + c);
-        // a wave without pressure cells has nothing to do (q is only read where diag != 0)
-        if (!__any(dg.v[0] != 0.0f || dg.v[1] != 0.0f || dg.v[2] != 0.0f || dg.v[3] != 0.0f)) continue;
-        const Vec<float, 4> ci = ldv<4>(pi + c), cj = ldv<4>(pj + c), ck = ldv<4>(pk + c);
-        const Vec<float, 4> cjm = ldv<4>(pj + c - sy), ckm = ldv<4>(pk + c - sz);
-        const Vec<T, 4> sc4 = ldv<4>(s + c), sjm = ldv<4>(s + c - sy), sjp = ldv<4>(s + c + sy), skm = ldv<4>(s + c - sz), skp = ldv<4>(s + c + sz);
-        const Vec<RT<T>, 4> r4 = ldv<4>(r + c);
-        const T sl = nb_left(sc4, s + c, i0), sr = nb_right(sc4, s + c, i0, L.I);
-        const float cil = nb_left(ci, pi + c, i0);
+        // a lane without pressure cells has nothing to compute or store (q is only read where diag != 0, s is 0 off the
+        // pressure cells); it only has to load if a neighbouring lane, which takes its i+-1 values from it, has cells
+        const bool mine = dg.v[0] != 0.0f || dg.v[1] != 0.0f || dg.v[2] != 0.0f || dg.v[3] != 0.0f;
+        if (!__any(mine)) continue;
+        const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // outside any short-circuit
+        const bool on = mine || mleft != 0 || mright != 0;
+#define LDP(T_, p) (on ? ldv<4>(p) : Vec<T_, 4>{})
+        const Vec<float, 4> ci = LDP(float, pi + c), cj = LDP(float, pj + c), ck = LDP(float, pk + c);
+        const Vec<float, 4> cjm = LDP(float, pj + c - sy), ckm = LDP(float, pk + c - sz);
+        const Vec<T, 4> sc4 = LDP(T, s + c), sjm = LDP(T, s + c - sy), sjp = LDP(T, s + c + sy), skm = LDP(T, s + c - sz), skp = LDP(T, s + c + sz);
+        const Vec<RT<T>, 4> r4 = LDP(RT<T>, r + c);
+#undef LDP
+        T sl = __shfl_up(sc4.v[3], 1, 64), sr = __shfl_down(sc4.v[0], 1, 64);
+        float cil = __shfl_up(ci.v[3], 1, 64);
+        if ((threadIdx.x & 63) == 0) { sl = (on && i0 > 0) ? s[c - 1] : (T)0; cil = (on && i0 > 0) ? pi[c - 1] : 0.0f; }
+        if ((threadIdx.x & 63) == 63) sr = (on && i0 + 4 < L.I) ? s[c + 4] : (T)0;
         Vec<T, 4> y;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
                 dc += yd * inv * yd;
             }
         }
-        stv(q + c, y);
+        if (mine) stv(q + c, y);
     }
     block_sum3_256(da, db, dc, lds);
     if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
@@ -332,6 +340,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     sc.tol = fmax(c->prm.pressure_tolerance, c->prm.pressure_rel_tolerance * bnorm);
 
     PcgSys<T, 1> v;
+    v.mask = nullptr;
     v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
     const int nb = pcg_grid(c->nActiveP);
     const dim3 blk(64, 4, 1);

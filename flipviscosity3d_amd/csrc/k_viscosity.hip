@@ -202,7 +202,8 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                              const float *__restrict__ fEU, const float *__restrict__ fEV,
                              const float *__restrict__ fEW, float *__restrict__ dgU, float *__restrict__ dgV,
                              float *__restrict__ dgW, float *__restrict__ vmU, float *__restrict__ vmV,
-                             float *__restrict__ vmW, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {
+                             float *__restrict__ vmW, uint8_t *__restrict__ rowmask, PcgSys<T, 3> v,
+                             double *__restrict__ bmax, int *__restrict__ nrows) {
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     double babs = 0.0;
@@ -288,6 +289,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
         }
         dgU[c] = dg[0]; dgV[c] = dg[1]; dgW[c] = dg[2];
         vmU[c] = vm[0]; vmV[c] = vm[1]; vmW[c] = vm[2];
+        rowmask[c] = (uint8_t)((dg[0] != 0.0f) | ((dg[1] != 0.0f) << 1) | ((dg[2] != 0.0f) << 2));
 #pragma unroll
         for (int m = 0; m < 3; m++) {
             v.r[m][c] = (RT<T>)rv[m]; v.x[m][c] = (T)0; v.s[m][c] = (T)0;
@@ -314,10 +316,30 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
 // size diag*|x| to obtain one of size vol*|x| (diag/vol ~ 1e3..1e4 when nu*dt/dx^2 is large), which is what limits
 // the attainable residual of an fp32 solve of this system.
 // vm = own control volume for rows, -1 for every other index (x stays 0 there, q must too).
+// i-neighbour helpers with a load predicate: lanes that are `on` carry loaded values, every other lane zeros
+template <int N> __device__ __forceinline__ Vec<float, N> vneg() {
+    Vec<float, N> r;
+#pragma unroll
+    for (int e = 0; e < N; e++) r.v[e] = -1.0f;
+    return r;
+}
+template <typename T, int N>
+__device__ __forceinline__ T nbl(const Vec<T, N> &a, const T *__restrict__ p, int i0, bool on) {
+    T v = __shfl_up(a.v[N - 1], 1, 64);
+    if ((threadIdx.x & 63) == 0) v = (on && i0 > 0) ? p[-1] : (T)0;
+    return v;
+}
+template <typename T, int N>
+__device__ __forceinline__ T nbr(const Vec<T, N> &a, const T *__restrict__ p, int i0, int w, bool on) {
+    T v = __shfl_down(a.v[0], 1, 64);
+    if ((threadIdx.x & 63) == 63) v = (on && i0 + N < w) ? p[N] : (T)0;
+    return v;
+}
 #define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
 #define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
-template <typename T, int NV>
-__global__ __launch_bounds__(256, NV == 2 ? 4 : 2) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
+// PRED: per-lane load predication from the row mask (sparse liquids); the dense variant loads unconditionally
+template <typename T, int NV, bool PRED>
+__global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                    const float *__restrict__ vmU, const float *__restrict__ vmV,
                                                    const float *__restrict__ vmW, const float *__restrict__ fC,
                                                    const float *__restrict__ fEU, const float *__restrict__ fEV,
@@ -334,33 +356,37 @@ __global__ __launch_bounds__(256, NV == 2 ? 4 : 2) void k_visc_spmv(const int *_
         const long sy = L.sy, sz = L.sz;
         const int I = L.I;
         const T *__restrict__ xu = v.s[0], *__restrict__ xv = v.s[1], *__restrict__ xw = v.s[2];
-        // ---- own volumes = row masks.  A lane without a row has nothing to compute and nothing to store (q is only
-        // ever read where the diagonal is non-zero); in the sparse scenes of the reference that is most lanes of a tile.
-        const Vec<float, NV> MU = ldv<NV>(vmU + c), MV = ldv<NV>(vmV + c), MW = ldv<NV>(vmW + c);
-        bool anyrow = false;
-#pragma unroll
-        for (int e = 0; e < NV; e++) anyrow = anyrow || MU.v[e] >= 0.0f || MV.v[e] >= 0.0f || MW.v[e] >= 0.0f;
-        // the lane shuffles below need every lane of the wave: only skip when the whole wave is idle
-        if (!__any(anyrow)) continue;
+        // ---- which lanes have rows.  A lane without a row has nothing to compute and nothing to store (q is only ever
+        // read where the diagonal is non-zero), and it only has to LOAD if a neighbouring lane, which takes its i+-1
+        // values from it, has one: in the sparse scenes of the reference that leaves most lanes of a tile without any
+        // memory access beyond the mask bytes.
+        const bool mine = ld_mask<NV>(v.mask + c) != 0u;
+        if (!__any(mine)) continue;  // the lane shuffles below need every lane of the wave
+        const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // (not inside a short-circuit: every lane must execute the shuffles)
+        const bool on = !PRED || mine || mleft != 0 || mright != 0;
+#define LDP(T_, p) (on ? ldv<NV>(p) : Vec<T_, NV>{})
+        const Vec<float, NV> MU = on ? ldv<NV>(vmU + c) : vneg<NV>(), MV = on ? ldv<NV>(vmV + c) : vneg<NV>(),
+                             MW = on ? ldv<NV>(vmW + c) : vneg<NV>();
         // ---- factors
-        const Vec<float, NV> C0 = ldv<NV>(fC + c), Cjm = ldv<NV>(fC + c - sy), Ckm = ldv<NV>(fC + c - sz);
-        const Vec<float, NV> EW0 = ldv<NV>(fEW + c), EWjp = ldv<NV>(fEW + c + sy);
-        const Vec<float, NV> EV0 = ldv<NV>(fEV + c), EVkp = ldv<NV>(fEV + c + sz);
-        const Vec<float, NV> EU0 = ldv<NV>(fEU + c), EUjp = ldv<NV>(fEU + c + sy), EUkp = ldv<NV>(fEU + c + sz);
-        const float C0l = nb_left(C0, fC + c, i0);
-        const float EW0r = nb_right(EW0, fEW + c, i0, I), EV0r = nb_right(EV0, fEV + c, i0, I);
+        const Vec<float, NV> C0 = LDP(float, fC + c), Cjm = LDP(float, fC + c - sy), Ckm = LDP(float, fC + c - sz);
+        const Vec<float, NV> EW0 = LDP(float, fEW + c), EWjp = LDP(float, fEW + c + sy);
+        const Vec<float, NV> EV0 = LDP(float, fEV + c), EVkp = LDP(float, fEV + c + sz);
+        const Vec<float, NV> EU0 = LDP(float, fEU + c), EUjp = LDP(float, fEU + c + sy), EUkp = LDP(float, fEU + c + sz);
+        const float C0l = nbl(C0, fC + c, i0, on);
+        const float EW0r = nbr(EW0, fEW + c, i0, I, on), EV0r = nbr(EV0, fEV + c, i0, I, on);
         // ---- x
-        const Vec<T, NV> U0 = ldv<NV>(xu + c), Ujm = ldv<NV>(xu + c - sy), Ujp = ldv<NV>(xu + c + sy), Ukm = ldv<NV>(xu + c - sz), Ukp = ldv<NV>(xu + c + sz);
-        const Vec<T, NV> V0 = ldv<NV>(xv + c), Vjm = ldv<NV>(xv + c - sy), Vjp = ldv<NV>(xv + c + sy), Vkm = ldv<NV>(xv + c - sz), Vkp = ldv<NV>(xv + c + sz);
-        const Vec<T, NV> W0 = ldv<NV>(xw + c), Wjm = ldv<NV>(xw + c - sy), Wjp = ldv<NV>(xw + c + sy), Wkm = ldv<NV>(xw + c - sz), Wkp = ldv<NV>(xw + c + sz);
-        const Vec<T, NV> Vjpkm = ldv<NV>(xv + c + sy - sz), Wjmkp = ldv<NV>(xw + c - sy + sz);
-        const T U0l = nb_left(U0, xu + c, i0), U0r = nb_right(U0, xu + c, i0, I);
-        const T V0l = nb_left(V0, xv + c, i0), V0r = nb_right(V0, xv + c, i0, I);
-        const T W0l = nb_left(W0, xw + c, i0), W0r = nb_right(W0, xw + c, i0, I);
-        const T Vjpl = nb_left(Vjp, xv + c + sy, i0), Wkpl = nb_left(Wkp, xw + c + sz, i0);
-        const T Ujmr = nb_right(Ujm, xu + c - sy, i0, I), Ukmr = nb_right(Ukm, xu + c - sz, i0, I);
+        const Vec<T, NV> U0 = LDP(T, xu + c), Ujm = LDP(T, xu + c - sy), Ujp = LDP(T, xu + c + sy), Ukm = LDP(T, xu + c - sz), Ukp = LDP(T, xu + c + sz);
+        const Vec<T, NV> V0 = LDP(T, xv + c), Vjm = LDP(T, xv + c - sy), Vjp = LDP(T, xv + c + sy), Vkm = LDP(T, xv + c - sz), Vkp = LDP(T, xv + c + sz);
+        const Vec<T, NV> W0 = LDP(T, xw + c), Wjm = LDP(T, xw + c - sy), Wjp = LDP(T, xw + c + sy), Wkm = LDP(T, xw + c - sz), Wkp = LDP(T, xw + c + sz);
+        const Vec<T, NV> Vjpkm = LDP(T, xv + c + sy - sz), Wjmkp = LDP(T, xw + c - sy + sz);
+        const T U0l = nbl(U0, xu + c, i0, on), U0r = nbr(U0, xu + c, i0, I, on);
+        const T V0l = nbl(V0, xv + c, i0, on), V0r = nbr(V0, xv + c, i0, I, on);
+        const T W0l = nbl(W0, xw + c, i0, on), W0r = nbr(W0, xw + c, i0, I, on);
+        const T Vjpl = nbl(Vjp, xv + c + sy, i0, on), Wkpl = nbl(Wkp, xw + c + sz, i0, on);
+        const T Ujmr = nbr(Ujm, xu + c - sy, i0, I, on), Ukmr = nbr(Ukm, xu + c - sz, i0, I, on);
         // ---- residuals
-        const Vec<RT<T>, NV> RU = ldv<NV>(v.r[0] + c), RV = ldv<NV>(v.r[1] + c), RW = ldv<NV>(v.r[2] + c);
+        const Vec<RT<T>, NV> RU = LDP(RT<T>, v.r[0] + c), RV = LDP(RT<T>, v.r[1] + c), RW = LDP(RT<T>, v.r[2] + c);
+#undef LDP
         Vec<T, NV> yU, yV, yW;
 #pragma unroll
         for (int e = 0; e < NV; e++) {
@@ -411,9 +437,11 @@ __global__ __launch_bounds__(256, NV == 2 ? 4 : 2) void k_visc_spmv(const int *_
                 yW.v[e] = y;
             }
         }
-        stv(v.q[0] + c, yU);
-        stv(v.q[1] + c, yV);
-        stv(v.q[2] + c, yW);
+        if (!PRED || mine) {
+            stv(v.q[0] + c, yU);
+            stv(v.q[1] + c, yV);
+            stv(v.q[2] + c, yW);
+        }
     }
     block_sum3_256(da, db, dc, lds);
     if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
@@ -435,6 +463,7 @@ static __global__ void k_vec_to_f32(const T *__restrict__ a, float *__restrict__
 template <typename T>
 static PcgSys<T, 3> visc_sys(flipv_context *c) {
     PcgSys<T, 3> v;
+    v.mask = c->vRowMask;
     v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
     for (int m = 0; m < 3; m++) { v.x[m] = (T *)c->vX[m]; v.r[m] = (RT<T> *)c->vR[m]; v.q[m] = (T *)c->vZ[m]; v.s[m] = (T *)c->vS[m]; }
     return v;
@@ -445,7 +474,7 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     const int nb = pcg_grid(count);
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 1, (double)count * (64 * NV * TY));
-    hipLaunchKernelGGL((k_visc_spmv<T, NV>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
+    hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
                        c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
     if (timed) fv_ev_end(c);
 }
@@ -501,7 +530,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane)
     hipLaunchKernelGGL(k_visc_setup<T>, GRID3(R0), 0, c->stream, R0, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                        c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
-                       c->vDiagW, c->vmU, c->vmV, c->vmW, v, bmax, c->d_flags + 2);
+                       c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, v, bmax, c->d_flags + 2);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // lane width of the solver kernels: 4 consecutive i per lane (16-byte accesses, 2 waves/SIMD) when most of the

@@ -183,7 +183,14 @@ struct PcgSys {
     const float *diag[NC];
     T *x[NC], *q[NC], *s[NC];
     RT<T> *r[NC];
+    const uint8_t *mask;  // optional (nullptr: none): non-zero where any component has an unknown at the index; a lane whose
+                          // N indices are all zero skips every load (sparse liquids: most lanes of an active tile)
 };
+
+// the N mask bytes of a lane as one integer (N = 2: 2-byte load, N = 4: 4-byte load; the index is a multiple of N)
+template <int N> __device__ __forceinline__ unsigned ld_mask(const uint8_t *__restrict__ p);
+template <> __device__ __forceinline__ unsigned ld_mask<2>(const uint8_t *__restrict__ p) { return *reinterpret_cast<const unsigned short *>(p); }
+template <> __device__ __forceinline__ unsigned ld_mask<4>(const uint8_t *__restrict__ p) { return *reinterpret_cast<const unsigned *>(p); }
 
 // Blocks loop over tiles with a grid stride (grids are capped at MAX_PCG_BLOCKS so a launch never issues more than
 // that many scalar atomics); `b` is the virtual block index b = blockIdx.x + n*gridDim.x.
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ tiles,
     for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
         if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
         const size_t c = gidx(L, i0, j, k);
+        if (v.mask && ld_mask<N>(v.mask + c) == 0u) continue;
 #pragma unroll
         for (int m = 0; m < NC; m++) {
             const Vec<float, N> d = ldv<N>(v.diag[m] + c);
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
         if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
         const size_t c = gidx(L, i0, j, k);
+        if (v.mask && ld_mask<N>(v.mask + c) == 0u) continue;
 #pragma unroll
         for (int m = 0; m < NC; m++) {
             const Vec<float, N> d = ldv<N>(v.diag[m] + c);

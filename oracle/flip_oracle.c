@@ -11,6 +11,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <time.h>
 
@@ -898,6 +899,15 @@ static int rowW(const vsys *s, int i, int j, int k) { return s->table[s->woff + 
         if ((STATE) == FS_SOLID) rval -= (coef) * (VEL);     \
     } while (0)
 
+static const char *g_visc_dump = NULL;
+/* research hook: externally supplied control volumes (center,U,V,W,edgeU,edgeV,edgeW) and face states (U,V,W) replace
+ * the ones oracle_viscosity_solve derives from phi / the solid SDF; NULL restores the normal path */
+static const float *const *g_vol_override = NULL;
+static const uint8_t *const *g_state_override = NULL;
+void oracle_viscosity_override(const float *const *vols7, const uint8_t *const *states3) { g_vol_override = vols7; g_state_override = states3; }
+/* when set (non-NULL path), the next oracle_viscosity_solve calls also write their assembled system to that file */
+void oracle_viscosity_dump_to(const char *path) { g_visc_dump = path; }
+
 void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U, float *V, float *W,
                             const float *phi, const float *solid, const float *visc, double tol, int maxiter,
                             double accept_tol, oracle_solve_info *info) {
@@ -942,9 +952,22 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
                 }
         free(scp);
     }
+    if (g_state_override) {
+        memcpy(s.sU, g_state_override[0], nu); memcpy(s.sV, g_state_override[1], nv); memcpy(s.sW, g_state_override[2], nw);
+    }
     volgrids g;
     alloc_volgrids(I, J, K, &g);
-    compute_volume_grids(I, J, K, (double)dxf, phi, &g);
+    if (g_vol_override) {
+        memcpy(g.c, g_vol_override[0], (size_t)I * J * K * sizeof(float));
+        memcpy(g.U, g_vol_override[1], nu * sizeof(float));
+        memcpy(g.V, g_vol_override[2], nv * sizeof(float));
+        memcpy(g.W, g_vol_override[3], nw * sizeof(float));
+        memcpy(g.eU, g_vol_override[4], (size_t)I * (J + 1) * (K + 1) * sizeof(float));
+        memcpy(g.eV, g_vol_override[5], (size_t)(I + 1) * J * (K + 1) * sizeof(float));
+        memcpy(g.eW, g_vol_override[6], (size_t)(I + 1) * (J + 1) * K * sizeof(float));
+    } else {
+        compute_volume_grids(I, J, K, (double)dxf, phi, &g);
+    }
 #define VC(i, j, k) g.c[IDX(i, j, k, I, J)]
 #define VU(i, j, k) g.U[IDX(i, j, k, I + 1, J)]
 #define VV(i, j, k) g.V[IDX(i, j, k, I, J + 1)]
@@ -1143,6 +1166,19 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
             }
     free_volgrids(&g);
     for (int r = 0; r < n; r++) li.nnz += M.cnt[r];
+    if (g_visc_dump) { /* solver research hook (oracle_viscosity_dump_to): the assembled system as raw binary */
+        FILE *f = fopen(g_visc_dump, "wb");
+        if (f) {
+            long long hdr[4] = {n, ROWCAP, (long long)dim, 0};
+            fwrite(hdr, sizeof(hdr), 1, f);
+            fwrite(M.cnt, sizeof(int), (size_t)n, f);
+            fwrite(M.col, sizeof(unsigned), (size_t)n * ROWCAP, f);
+            fwrite(M.val, sizeof(double), (size_t)n * ROWCAP, f);
+            fwrite(rhs, sizeof(double), (size_t)n, f);
+            fwrite(s.table, sizeof(int), dim, f);
+            fclose(f);
+        }
+    }
 
     /* ---- PCGSolver<double>::solve (pcgsolver.h:241-295) ---- */
     double *x = (double *)calloc((size_t)n + 1, sizeof(double));

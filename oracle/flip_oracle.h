@@ -92,6 +92,11 @@ void oracle_viscosity_solve(int I, int J, int K, float dx, float dt, float *U, f
 /* The seven volume-fraction lattices of ViscositySolver::_computeVolumeGrid
  * (viscositysolver.cpp:135-270); outputs sized center (I,J,K), U (I+1,J,K), V, W,
  * edgeU (I,J+1,K+1), edgeV (I+1,J,K+1), edgeW (I+1,J+1,K).  Any output may be NULL. */
+/* research hook: path != NULL makes oracle_viscosity_solve also dump the assembled system (header {rows, ROWCAP, faces, 0}
+ * as int64, then counts, columns, values, rhs, face->row table); the pointer must stay valid */
+void oracle_viscosity_dump_to(const char *path);
+/* research hook: replace the derived control volumes (7 grids) / face states (3 grids, 1 = FLUID, 2 = SOLID) */
+void oracle_viscosity_override(const float *const *vols7, const unsigned char *const *states3);
 void oracle_viscosity_volumes(int I, int J, int K, float dx, const float *phi, float *center, float *volU,
                               float *volV, float *volW, float *edgeU, float *edgeV, float *edgeW);
 
