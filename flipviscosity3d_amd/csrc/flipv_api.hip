@@ -98,6 +98,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->comm = nullptr;
     c->pScratch = nullptr; c->pScratchCap = 0;
     c->binIdx = nullptr; c->binIdxCap = 0;
+    c->surfList = nullptr;
     c->binCnt = c->binOff = c->binCur = c->binList = c->binNList = nullptr;
     c->binTilesCap = 0; c->nbx = c->nby = c->nbz = 0; c->binsValid = 0;
     c->haloBuf = nullptr; c->haloCap = 0;
@@ -111,6 +112,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->h_flags = nullptr;
     c->evUsed = 0;
     c->pressureReady = c->viscosityReady = 0;
+    c->viscStateValid = 0; c->viscStatePrec = 0;
     c->nActiveP = c->nActiveV = 0;
     c->vwV = 2;
     c->viscosity_nonzero = 1;
@@ -229,6 +231,7 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->particles) (void)hipFree(c->particles);
     if (c->pScratch) (void)hipFree(c->pScratch);
     if (c->binIdx) (void)hipFree(c->binIdx);
+    if (c->surfList) (void)hipFree(c->surfList);
     if (c->binCnt) (void)hipFree(c->binCnt);
     if (c->haloBuf) (void)hipFree(c->haloBuf);
     if (c->d_scal) (void)hipFree(c->d_scal);

@@ -134,6 +134,7 @@ struct flipv_context {
     uint8_t *stU, *stV, *stW;
     void *vX[3], *vR[3], *vZ[3], *vS[3];
     uint8_t *validCells, *validTmp;
+    unsigned *surfList;  // indices whose control volumes need the sampling path (+ the counter at [L.n]); allocated on first use
 
     // kernel timing
     flipv_kernel_stats kstats;
@@ -145,6 +146,7 @@ struct flipv_context {
 
     float lastDt;
     int pressureReady, viscosityReady;
+    int viscStateValid, viscStatePrec;  // k_visc_setup's off-row values are in place for this vector precision
     int pressurePrec, viscosityPrec;
 };
 

@@ -174,7 +174,7 @@ __device__ __forceinline__ int d_virtual_tile(int v, const TileGrid &tg, int k0,
 // flag[v] = 1 if virtual tile v holds at least one unknown (diag != 0) of any component
 __global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, int nc, const float *__restrict__ d0,
                                                     const float *__restrict__ d1, const float *__restrict__ d2,
-                                                    int *__restrict__ flag, int k0, int nk) {
+                                                    const uint8_t *__restrict__ mask, int *__restrict__ flag, int k0, int nk) {
     const int tile = d_virtual_tile(blockIdx.x, tg, k0, nk);
     int any = 0;
     if (tile >= 0) {
@@ -183,8 +183,12 @@ __global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, 
         if (i0 < L.PX && j < L.PY) {
             const size_t c = gidx(L, i0, j, k);
             const float *dd[3] = {d0, d1, d2};
-            for (int m = 0; m < nc; m++)
-                for (int e = 0; e < vw; e++) any |= dd[m][c + e] != 0.0f;
+            if (mask) {  // one byte per index instead of nc floats
+                for (int e = 0; e < vw; e++) any |= mask[c + e] != 0;
+            } else {
+                for (int m = 0; m < nc; m++)
+                    for (int e = 0; e < vw; e++) any |= dd[m][c + e] != 0.0f;
+            }
         }
     }
     const int r = __syncthreads_or(any);
@@ -253,10 +257,10 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
 }
 
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   int *list, int *nActive, int *nInterior) {
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior) {
     const int nk = c->k1 - c->k0, nchunks = (tg.nty + JCH - 1) / JCH;
     const int nt = tg.ntx * JCH * nk * nchunks;  // virtual tiles of the owned planes (column-major enumeration)
-    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, c->tileFlag, c->k0, nk);
+    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, mask, c->tileFlag, c->k0, nk);
     if (!c->comm) {
         hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 0,
                            (const int *)nullptr);
@@ -313,7 +317,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, bmax, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP);  // synchronises: h_scal[0] = max|b|
+    rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
     {
         float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)

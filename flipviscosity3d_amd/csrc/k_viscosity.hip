@@ -114,36 +114,79 @@ __device__ __forceinline__ float d_cube_fraction(float p000, float p100, float p
 // _estimateVolumeFractions (viscositysolver.cpp:180-270) for lattice `lat` whose sample centre is
 // centerStart + cellCentre(i,j,k)
 struct VolLattices { float *vol[7]; int lat[7]; float cs[7][3]; };
-// all seven lattices in one sweep (one read of the band mask, one pass over the index space instead of seven)
-__global__ void k_volume_lattice(Lay L, VolLattices Q, const float *__restrict__ phi, const uint8_t *__restrict__ valid,
-                                 float dxf) {
-    IJK_OR_RETURN(L);
-    const bool band = valid[c] != 0;
+// Pass 1, all seven lattices in one sweep.  Every corner sample of the seven cubes of index (i,j,k) interpolates liquid
+// phi of cells i-1..i+2 (x j-1..j+2 x k-1..k+2) with weights in [0,1]: if all 64 are negative every corner is (all
+// eight negative -> 1, viscositysolver.cpp:254-259), if none is no corner is (-> 0).  Only indices at the liquid surface
+// need the sampling path; they are appended to a list so that pass 2 runs it with full waves (a surface crosses
+// nearly every 64-wide row of the band, which made one fused kernel pay the sampling path for every band wave).
+__global__ void k_volume_classify(Lay L, VolLattices Q, const float *__restrict__ phi, const uint8_t *__restrict__ valid,
+                                  unsigned *__restrict__ list, unsigned *__restrict__ nlist) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    const bool inside = i < L.PX && j < L.PY;
+    const size_t c = inside ? gidx(L, i, j, k) : 0;
+    float out = 0.0f;
+    bool sample = false;
+    if (inside && valid[c]) {
+        sample = true;
+        if (i >= 1 && j >= 1 && k >= 1 && i + 2 < L.I && j + 2 < L.J && k + 2 < L.K) {
+            int nn = 0;
+            for (int dk = -1; dk <= 2; dk++)
+                for (int dj = -1; dj <= 2; dj++) {
+                    const float *row = phi + gidx(L, i - 1, j + dj, k + dk);
+                    nn += (row[0] < 0.0f) + (row[1] < 0.0f) + (row[2] < 0.0f) + (row[3] < 0.0f);
+                }
+            if (nn == 64) { out = 1.0f; sample = false; }
+            else if (nn == 0) { out = 0.0f; sample = false; }
+        }
+    }
+    if (inside) {
+#pragma unroll
+        for (int m = 0; m < 7; m++) {
+            int w, h, d;
+            lat_dims(L, Q.lat[m], w, h, d);
+            if (i < w && j < h && k < d) Q.vol[m][c] = out;  // surface indices are overwritten by pass 2
+        }
+    }
+    // wave-aggregated append
+    const unsigned long long m = __ballot(sample);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        const int lead = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane == lead) base = atomicAdd(nlist, (unsigned)__popcll(m));
+        base = __shfl(base, lead, 64);
+        if (sample) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(i + L.PX * (j + L.PY * k));
+    }
+}
+
+// Pass 2: _estimateVolumeFractions (viscositysolver.cpp:180-270) for the listed indices, one thread per (index, lattice)
+__global__ void k_volume_sample(Lay L, VolLattices Q, const float *__restrict__ phi, const unsigned *__restrict__ list,
+                                const unsigned *__restrict__ nlist, float dxf) {
+    const unsigned n = *nlist;
     const double dx = (double)dxf, invdx = 1.0 / dx, hw = 0.5 * dx;
     const float hdx = 0.5f * dxf;          // viscositysolver.cpp:188
     const float hoff = (float)(0.5 * dx);  // particlelevelset.cpp:89
-    const float ccx = (float)(i * dx + hw), ccy = (float)(j * dx + hw), ccz = (float)(k * dx + hw);
-#pragma unroll 1
-    for (int m = 0; m < 7; m++) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)n * 7; t += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(t / n);  // lattice-major: a wave works on one lattice
+        const unsigned id = list[t - (size_t)m * n];
+        const int i = (int)(id % (unsigned)L.PX), j = (int)((id / (unsigned)L.PX) % (unsigned)L.PY), k = (int)(id / ((unsigned)L.PX * (unsigned)L.PY));
         int w, h, d;
         lat_dims(L, Q.lat[m], w, h, d);
         if (i >= w || j >= h || k >= d) continue;
-        float out = 0.0f;
-        if (band) {
-            const float cx = Q.cs[m][0] + ccx, cy = Q.cs[m][1] + ccy, cz = Q.cs[m][2] + ccz;
-            float p[8];
-            int neg = 0;
+        const float cx = Q.cs[m][0] + (float)(i * dx + hw), cy = Q.cs[m][1] + (float)(j * dx + hw), cz = Q.cs[m][2] + (float)(k * dx + hw);
+        float p[8];
+        int neg = 0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {  // q = 4*oi + 2*oj + ok
-                const float sx = cx + ((q & 4) ? hdx : -hdx), sy = cy + ((q & 2) ? hdx : -hdx), sz = cz + ((q & 1) ? hdx : -hdx);
-                p[q] = d_liquid_phi_at(sx, sy, sz, dx, invdx, hoff, phi, L);
-                neg += p[q] < 0.0f;
-            }
-            if (neg == 8) out = 1.0f;
-            else if (neg == 0) out = 0.0f;
-            else out = d_cube_fraction(p[0], p[4], p[2], p[6], p[1], p[5], p[3], p[7]);  // 000,100,010,110,001,101,011,111
+        for (int q = 0; q < 8; q++) {  // q = 4*oi + 2*oj + ok
+            const float sx = cx + ((q & 4) ? hdx : -hdx), sy = cy + ((q & 2) ? hdx : -hdx), sz = cz + ((q & 1) ? hdx : -hdx);
+            p[q] = d_liquid_phi_at(sx, sy, sz, dx, invdx, hoff, phi, L);
+            neg += p[q] < 0.0f;
         }
-        Q.vol[m][c] = out;
+        float out;
+        if (neg == 8) out = 1.0f;
+        else if (neg == 0) out = 0.0f;
+        else out = d_cube_fraction(p[0], p[4], p[2], p[6], p[1], p[5], p[3], p[7]);  // 000,100,010,110,001,101,011,111
+        Q.vol[m][gidx(L, i, j, k)] = out;
     }
 }
 
@@ -202,8 +245,8 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                              const float *__restrict__ fEU, const float *__restrict__ fEV,
                              const float *__restrict__ fEW, float *__restrict__ dgU, float *__restrict__ dgV,
                              float *__restrict__ dgW, float *__restrict__ vmU, float *__restrict__ vmV,
-                             float *__restrict__ vmW, uint8_t *__restrict__ rowmask, PcgSys<T, 3> v,
-                             double *__restrict__ bmax, int *__restrict__ nrows) {
+                             float *__restrict__ vmW, uint8_t *__restrict__ rowmask, const uint8_t *__restrict__ band,
+                             int full, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     double babs = 0.0;
@@ -212,6 +255,12 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
         const size_t c = gidx(L, i, j, k);
         const long sy = L.sy, sz = L.sz;
         float dg[3] = {0.0f, 0.0f, 0.0f}, rv[3] = {0.0f, 0.0f, 0.0f}, vm[3] = {-1.0f, -1.0f, -1.0f};
+        // every control volume is zero off the band mask (k_volume_lattice), and a row needs a non-zero volume at its own
+        // index or at an index one step down/up an axis: no band there, no row here
+        const bool near = band[c] || band[c - 1] || band[c + 1] || band[c - sy] || band[c + sy] || band[c - sz] || band[c + sz];
+        const uint8_t prev = rowmask[c];
+        if (!near && !prev && !full) goto done;  // no row now, none in the previous solve: every array already holds its off-row value
+        if (!near) goto store;
         if (d_row_range(0, i, j, k, L) && SU[c] == ST_FLUID) {  // ---- U face (viscositysolver.cpp:374-470)
             const float vol = volU[c];
             if (vol > 0.0f || VC[c] > 0.0f || VC[c - 1] > 0.0f || VEW[c + sy] > 0.0f || VEW[c] > 0.0f || VEV[c + sz] > 0.0f ||
@@ -287,15 +336,22 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 if (dg[2] != 0.0f) vm[2] = vol;
             }
         }
-        dgU[c] = dg[0]; dgV[c] = dg[1]; dgW[c] = dg[2];
-        vmU[c] = vm[0]; vmV[c] = vm[1]; vmW[c] = vm[2];
-        rowmask[c] = (uint8_t)((dg[0] != 0.0f) | ((dg[1] != 0.0f) << 1) | ((dg[2] != 0.0f) << 2));
+    store:
+        {
+            const uint8_t now = (uint8_t)((dg[0] != 0.0f) | ((dg[1] != 0.0f) << 1) | ((dg[2] != 0.0f) << 2));
+            if (now || prev || full) {  // off-row values (diag 0, volume -1, x = s = 0) persist between solves where nothing was a row
+                dgU[c] = dg[0]; dgV[c] = dg[1]; dgW[c] = dg[2];
+                vmU[c] = vm[0]; vmV[c] = vm[1]; vmW[c] = vm[2];
+                rowmask[c] = now;
 #pragma unroll
-        for (int m = 0; m < 3; m++) {
-            v.r[m][c] = (RT<T>)rv[m]; v.x[m][c] = (T)0; v.s[m][c] = (T)0;
-            babs = fmax(babs, fabs((double)rv[m]));
-            rows += dg[m] != 0.0f;
+                for (int m = 0; m < 3; m++) {
+                    v.r[m][c] = (RT<T>)rv[m]; v.x[m][c] = (T)0; v.s[m][c] = (T)0;
+                    babs = fmax(babs, fabs((double)rv[m]));
+                    rows += dg[m] != 0.0f;
+                }
+            }
         }
+    done:;
     }
     const double bm = block_max_256(babs, lds);
     const double nr = block_sum_256((double)rows, lds);
@@ -520,17 +576,29 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const int lats[7] = {LAT_CELL, LAT_U, LAT_V, LAT_W, LAT_EU, LAT_EV, LAT_EW};
         const float cs[7][3] = {{h, h, h}, {0, h, h}, {h, 0, h}, {h, h, 0}, {h, 0, 0}, {0, h, 0}, {0, 0, h}};  // viscositysolver.cpp:171-177
         for (int q = 0; q < 7; q++) { Q.vol[q] = vols[q]; Q.lat[q] = lats[q]; Q.cs[q][0] = cs[q][0]; Q.cs[q][1] = cs[q][1]; Q.cs[q][2] = cs[q][2]; }
-        hipLaunchKernelGGL(k_volume_lattice, GRID3(R1), 0, c->stream, R1, Q, c->phi, c->validCells, c->dx);
+        if (!c->surfList) {
+            hipError_t e = hipMalloc((void **)&c->surfList, (L.n + 64) * sizeof(unsigned));
+            if (e != hipSuccess) { c->err = std::string("hipMalloc(surface list): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
+        }
+        unsigned *nlist = c->surfList + L.n;
+        HIPCHK(c, hipMemsetAsync(nlist, 0, sizeof(unsigned), c->stream));
+        hipLaunchKernelGGL(k_volume_classify, GRID3(R1), 0, c->stream, R1, Q, c->phi, c->validCells, c->surfList, nlist);
+        hipLaunchKernelGGL(k_volume_sample, dim3(4096), dim3(256), 0, c->stream, c->L, Q, c->phi, c->surfList, nlist, c->dx);
     }
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
     hipLaunchKernelGGL(k_visc_factors, GRID3(R1), 0, c->stream, R1, c->visc, c->volC, c->volEU, c->volEV, c->volEW, c->fC,
                        c->fEU, c->fEV, c->fEW, factor);
     PcgSys<T, 3> v = visc_sys<T>(c);
+    // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers are
+    // shared) or of the slab make it store everywhere
+    const int precNow = std::is_same<T, float>::value ? 0 : 1;
+    const int full = (c->viscStateValid && c->viscStatePrec == precNow) ? 0 : 1;
+    c->viscStateValid = 1; c->viscStatePrec = precNow;
     // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane)
     hipLaunchKernelGGL(k_visc_setup<T>, GRID3(R0), 0, c->stream, R0, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                        c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
-                       c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, v, bmax, c->d_flags + 2);
+                       c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, c->validCells, full, v, bmax, c->d_flags + 2);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // lane width of the solver kernels: 4 consecutive i per lane (16-byte accesses, 2 waves/SIMD) when most of the
@@ -540,7 +608,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const double fill = (double)c->h_flags[2] / (3.0 * (double)(c->k1 - c->k0) * (double)L.PX * (double)L.PY);
     c->vwV = fill > 0.35 ? 4 : 2;
     c->tgV.ntx = (L.PX + 64 * c->vwV - 1) / (64 * c->vwV);
-    rc = fv_build_tiles(c, c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->tileListV, &c->nActiveV, &c->nIntV);
+    rc = fv_build_tiles(c, c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV);
     if (rc) return rc;
     if (c->comm) {
         float bn = (float)c->h_scal[0];

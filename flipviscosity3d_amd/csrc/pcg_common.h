@@ -281,14 +281,24 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
         if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
         const size_t c = gidx(L, i0, j, k);
-        if (v.mask && ld_mask<N>(v.mask + c) == 0u) continue;
+        // which components have unknowns among this lane's N indices: from the mask bytes (bit m = component m) when there
+        // is a mask, so that the diagonal is fetched together with the vectors instead of ahead of them
+        unsigned bits = 0xffu;
+        if (v.mask) {
+            const unsigned mk = ld_mask<N>(v.mask + c);
+            if (mk == 0u) continue;
+            bits = mk | (mk >> 8) | (mk >> 16) | (mk >> 24);
+        }
 #pragma unroll
         for (int m = 0; m < NC; m++) {
+            if (!((bits >> m) & 1u)) continue;
             const Vec<float, N> d = ldv<N>(v.diag[m] + c);
-            bool any = false;
+            if (!v.mask) {
+                bool any = false;
 #pragma unroll
-            for (int e = 0; e < N; e++) any = any || d.v[e] != 0.0f;
-            if (!any) continue;  // no unknowns here
+                for (int e = 0; e < N; e++) any = any || d.v[e] != 0.0f;
+                if (!any) continue;  // no unknowns here
+            }
             Vec<T, N> x = ldv<N>(v.x[m] + c), s = ldv<N>(v.s[m] + c);
             Vec<RT<T>, N> r = ldv<N>(v.r[m] + c);
             const Vec<T, N> q = ldv<N>(v.q[m] + c);
@@ -340,7 +350,7 @@ int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT
 // never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
 static inline int pcg_grid(int ntiles) { const int nb = ((ntiles + 7) / 8) * 8; return nb < 8 ? 8 : (nb < MAX_PCG_BLOCKS ? nb : MAX_PCG_BLOCKS); }
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   int *list, int *nActive, int *nInterior);
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
 
 // The iteration loop shared by both solves.
