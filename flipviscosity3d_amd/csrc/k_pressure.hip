@@ -105,16 +105,25 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
         if (!__any(mine)) continue;
         const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // outside any short-circuit
         const bool on = mine || mleft != 0 || mright != 0;
-#define LDP(T_, p) (on ? ldv<4>(p) : Vec<T_, 4>{})
-        const Vec<float, 4> ci = LDP(float, pi + c), cj = LDP(float, pj + c), ck = LDP(float, pk + c);
-        const Vec<float, 4> cjm = LDP(float, pj + c - sy), ckm = LDP(float, pk + c - sz);
-        const Vec<T, 4> sc4 = LDP(T, s + c), sjm = LDP(T, s + c - sy), sjp = LDP(T, s + c + sy), skm = LDP(T, s + c - sz), skp = LDP(T, s + c + sz);
-        const Vec<RT<T>, 4> r4 = LDP(RT<T>, r + c);
-#undef LDP
+        // every load of the tile in one predicated block (the kernel is latency-bound on the reference's scenes)
+        Vec<float, 4> ci{}, cj{}, ck{}, cjm{}, ckm{};
+        Vec<T, 4> sc4{}, sjm{}, sjp{}, skm{}, skp{};
+        Vec<RT<T>, 4> r4{};
+        T esl = (T)0, esr = (T)0;
+        float ecil = 0.0f;
+        if (on) {
+            ci = ldv<4>(pi + c); cj = ldv<4>(pj + c); ck = ldv<4>(pk + c);
+            cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
+            sc4 = ldv<4>(s + c); sjm = ldv<4>(s + c - sy); sjp = ldv<4>(s + c + sy); skm = ldv<4>(s + c - sz); skp = ldv<4>(s + c + sz);
+            r4 = ldv<4>(r + c);
+            const int lane = threadIdx.x & 63;
+            if (lane == 0 && i0 > 0) { esl = s[c - 1]; ecil = pi[c - 1]; }
+            if (lane == 63 && i0 + 4 < L.I) esr = s[c + 4];
+        }
         T sl = __shfl_up(sc4.v[3], 1, 64), sr = __shfl_down(sc4.v[0], 1, 64);
         float cil = __shfl_up(ci.v[3], 1, 64);
-        if ((threadIdx.x & 63) == 0) { sl = (on && i0 > 0) ? s[c - 1] : (T)0; cil = (on && i0 > 0) ? pi[c - 1] : 0.0f; }
-        if ((threadIdx.x & 63) == 63) sr = (on && i0 + 4 < L.I) ? s[c + 4] : (T)0;
+        if ((threadIdx.x & 63) == 0) { sl = esl; cil = ecil; }
+        if ((threadIdx.x & 63) == 63) sr = esr;
         Vec<T, 4> y;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
             acc += sc4.v[e] * (T)dg.v[e];
             y.v[e] = acc;
             if (dg.v[e] != 0.0f) {
-                const double yd = (double)acc, inv = 1.0 / (double)dg.v[e];
+                const double yd = (double)acc, inv = (double)__builtin_amdgcn_rcpf(dg.v[e]);
                 da += (double)sc4.v[e] * yd;
                 db += (double)r4.v[e] * inv * yd;
                 dc += yd * inv * yd;

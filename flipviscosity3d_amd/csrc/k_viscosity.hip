@@ -391,6 +391,17 @@ __device__ __forceinline__ T nbr(const Vec<T, N> &a, const T *__restrict__ p, in
     if ((threadIdx.x & 63) == 63) v = (on && i0 + N < w) ? p[N] : (T)0;
     return v;
 }
+// i-neighbour across lanes; `edge` is the value lane 0 (left) / lane 63 (right) fetched from memory beforehand
+template <typename T, int N>
+__device__ __forceinline__ T nbl2(const Vec<T, N> &a, T edge) {
+    const T v = __shfl_up(a.v[N - 1], 1, 64);
+    return (threadIdx.x & 63) == 0 ? edge : v;
+}
+template <typename T, int N>
+__device__ __forceinline__ T nbr2(const Vec<T, N> &a, T edge) {
+    const T v = __shfl_down(a.v[0], 1, 64);
+    return (threadIdx.x & 63) == 63 ? edge : v;
+}
 #define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
 #define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
 // PRED: per-lane load predication from the row mask (sparse liquids); the dense variant loads unconditionally
@@ -420,29 +431,45 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
         if (!__any(mine)) continue;  // the lane shuffles below need every lane of the wave
         const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // (not inside a short-circuit: every lane must execute the shuffles)
         const bool on = !PRED || mine || mleft != 0 || mright != 0;
-#define LDP(T_, p) (on ? ldv<NV>(p) : Vec<T_, NV>{})
-        const Vec<float, NV> MU = on ? ldv<NV>(vmU + c) : vneg<NV>(), MV = on ? ldv<NV>(vmV + c) : vneg<NV>(),
-                             MW = on ? ldv<NV>(vmW + c) : vneg<NV>();
-        // ---- factors
-        const Vec<float, NV> C0 = LDP(float, fC + c), Cjm = LDP(float, fC + c - sy), Ckm = LDP(float, fC + c - sz);
-        const Vec<float, NV> EW0 = LDP(float, fEW + c), EWjp = LDP(float, fEW + c + sy);
-        const Vec<float, NV> EV0 = LDP(float, fEV + c), EVkp = LDP(float, fEV + c + sz);
-        const Vec<float, NV> EU0 = LDP(float, fEU + c), EUjp = LDP(float, fEU + c + sy), EUkp = LDP(float, fEU + c + sz);
-        const float C0l = nbl(C0, fC + c, i0, on);
-        const float EW0r = nbr(EW0, fEW + c, i0, I, on), EV0r = nbr(EV0, fEV + c, i0, I, on);
-        // ---- x
-        const Vec<T, NV> U0 = LDP(T, xu + c), Ujm = LDP(T, xu + c - sy), Ujp = LDP(T, xu + c + sy), Ukm = LDP(T, xu + c - sz), Ukp = LDP(T, xu + c + sz);
-        const Vec<T, NV> V0 = LDP(T, xv + c), Vjm = LDP(T, xv + c - sy), Vjp = LDP(T, xv + c + sy), Vkm = LDP(T, xv + c - sz), Vkp = LDP(T, xv + c + sz);
-        const Vec<T, NV> W0 = LDP(T, xw + c), Wjm = LDP(T, xw + c - sy), Wjp = LDP(T, xw + c + sy), Wkm = LDP(T, xw + c - sz), Wkp = LDP(T, xw + c + sz);
-        const Vec<T, NV> Vjpkm = LDP(T, xv + c + sy - sz), Wjmkp = LDP(T, xw + c - sy + sz);
-        const T U0l = nbl(U0, xu + c, i0, on), U0r = nbr(U0, xu + c, i0, I, on);
-        const T V0l = nbl(V0, xv + c, i0, on), V0r = nbr(V0, xv + c, i0, I, on);
-        const T W0l = nbl(W0, xw + c, i0, on), W0r = nbr(W0, xw + c, i0, I, on);
-        const T Vjpl = nbl(Vjp, xv + c + sy, i0, on), Wkpl = nbl(Wkp, xw + c + sz, i0, on);
-        const T Ujmr = nbr(Ujm, xu + c - sy, i0, I, on), Ukmr = nbr(Ukm, xu + c - sz, i0, I, on);
-        // ---- residuals
-        const Vec<RT<T>, NV> RU = LDP(RT<T>, v.r[0] + c), RV = LDP(RT<T>, v.r[1] + c), RW = LDP(RT<T>, v.r[2] + c);
-#undef LDP
+        // All loads of the tile are issued in one predicated block (one exec-mask region, no dependent waits in between):
+        // the kernel is latency-bound at the sizes of the reference's scenes, not bandwidth-bound.
+        Vec<float, NV> MU = vneg<NV>(), MV = vneg<NV>(), MW = vneg<NV>();
+        Vec<float, NV> C0{}, Cjm{}, Ckm{}, EW0{}, EWjp{}, EV0{}, EVkp{}, EU0{}, EUjp{}, EUkp{};
+        Vec<T, NV> U0{}, Ujm{}, Ujp{}, Ukm{}, Ukp{}, V0{}, Vjm{}, Vjp{}, Vkm{}, Vkp{}, W0{}, Wjm{}, Wjp{}, Wkm{}, Wkp{}, Vjpkm{}, Wjmkp{};
+        Vec<RT<T>, NV> RU{}, RV{}, RW{};
+        // values beyond the wave's ends (lane 0 / lane 63 read them from memory, the other lanes shuffle)
+        float eC0l = 0.0f, eEW0r = 0.0f, eEV0r = 0.0f;
+        T eU0l = (T)0, eU0r = (T)0, eV0l = (T)0, eV0r = (T)0, eW0l = (T)0, eW0r = (T)0, eVjpl = (T)0, eWkpl = (T)0, eUjmr = (T)0, eUkmr = (T)0;
+        if (on) {
+            MU = ldv<NV>(vmU + c); MV = ldv<NV>(vmV + c); MW = ldv<NV>(vmW + c);
+            C0 = ldv<NV>(fC + c); Cjm = ldv<NV>(fC + c - sy); Ckm = ldv<NV>(fC + c - sz);
+            EW0 = ldv<NV>(fEW + c); EWjp = ldv<NV>(fEW + c + sy);
+            EV0 = ldv<NV>(fEV + c); EVkp = ldv<NV>(fEV + c + sz);
+            EU0 = ldv<NV>(fEU + c); EUjp = ldv<NV>(fEU + c + sy); EUkp = ldv<NV>(fEU + c + sz);
+            U0 = ldv<NV>(xu + c); Ujm = ldv<NV>(xu + c - sy); Ujp = ldv<NV>(xu + c + sy); Ukm = ldv<NV>(xu + c - sz); Ukp = ldv<NV>(xu + c + sz);
+            V0 = ldv<NV>(xv + c); Vjm = ldv<NV>(xv + c - sy); Vjp = ldv<NV>(xv + c + sy); Vkm = ldv<NV>(xv + c - sz); Vkp = ldv<NV>(xv + c + sz);
+            W0 = ldv<NV>(xw + c); Wjm = ldv<NV>(xw + c - sy); Wjp = ldv<NV>(xw + c + sy); Wkm = ldv<NV>(xw + c - sz); Wkp = ldv<NV>(xw + c + sz);
+            Vjpkm = ldv<NV>(xv + c + sy - sz); Wjmkp = ldv<NV>(xw + c - sy + sz);
+            RU = ldv<NV>(v.r[0] + c); RV = ldv<NV>(v.r[1] + c); RW = ldv<NV>(v.r[2] + c);
+            const int lane = threadIdx.x & 63;
+            if (lane == 0 && i0 > 0) {
+                eC0l = fC[c - 1];
+                eU0l = xu[c - 1]; eV0l = xv[c - 1]; eW0l = xw[c - 1];
+                eVjpl = xv[c + sy - 1]; eWkpl = xw[c + sz - 1];
+            }
+            if (lane == 63 && i0 + NV < I) {
+                eEW0r = fEW[c + NV]; eEV0r = fEV[c + NV];
+                eU0r = xu[c + NV]; eV0r = xv[c + NV]; eW0r = xw[c + NV];
+                eUjmr = xu[c - sy + NV]; eUkmr = xu[c - sz + NV];
+            }
+        }
+        const float C0l = nbl2(C0, eC0l);
+        const float EW0r = nbr2(EW0, eEW0r), EV0r = nbr2(EV0, eEV0r);
+        const T U0l = nbl2(U0, eU0l), U0r = nbr2(U0, eU0r);
+        const T V0l = nbl2(V0, eV0l), V0r = nbr2(V0, eV0r);
+        const T W0l = nbl2(W0, eW0l), W0r = nbr2(W0, eW0r);
+        const T Vjpl = nbl2(Vjp, eVjpl), Wkpl = nbl2(Wkp, eWkpl);
+        const T Ujmr = nbr2(Ujm, eUjmr), Ukmr = nbr2(Ukm, eUkmr);
         Vec<T, NV> yU, yV, yW;
 #pragma unroll
         for (int e = 0; e < NV; e++) {
@@ -459,7 +486,7 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
                     const T txz = (T)fF * ((Ukp.v[e] - uc) + (Wkp.v[e] - LSH(Wkp, Wkpl, e))) - (T)fK * ((uc - Ukm.v[e]) + (wc - wl));
                     y = (T)MU.v[e] * uc - txx - txy - txz;
                     const float dg = MU.v[e] + fR + fL + fT + fB + fF + fK;  // same order as k_visc_setup
-                    const double yd = (double)y, inv = 1.0 / (double)dg;
+                    const double yd = (double)y, inv = (double)__builtin_amdgcn_rcpf(dg);
                     da += (double)uc * yd; db += (double)RU.v[e] * inv * yd; dc += yd * inv * yd;
                 }
                 yU.v[e] = y;
@@ -473,7 +500,7 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
                     const T tyz = (T)fF * ((Vkp.v[e] - vc) + (Wkp.v[e] - Wjmkp.v[e])) - (T)fK * ((vc - Vkm.v[e]) + (wc - Wjm.v[e]));
                     y = (T)MV.v[e] * vc - tyy - txy - tyz;
                     const float dg = MV.v[e] + fR + fL + fT + fB + fF + fK;
-                    const double yd = (double)y, inv = 1.0 / (double)dg;
+                    const double yd = (double)y, inv = (double)__builtin_amdgcn_rcpf(dg);
                     da += (double)vc * yd; db += (double)RV.v[e] * inv * yd; dc += yd * inv * yd;
                 }
                 yV.v[e] = y;
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
                     const T tyz = (T)fT * ((Wjp.v[e] - wc) + (Vjp.v[e] - Vjpkm.v[e])) - (T)fB * ((wc - Wjm.v[e]) + (vc - Vkm.v[e]));
                     y = (T)MW.v[e] * wc - tzz - txz - tyz;
                     const float dg = MW.v[e] + fR + fL + fT + fB + fF + fK;
-                    const double yd = (double)y, inv = 1.0 / (double)dg;
+                    const double yd = (double)y, inv = (double)__builtin_amdgcn_rcpf(dg);
                     da += (double)wc * yd; db += (double)RW.v[e] * inv * yd; dc += yd * inv * yd;
                 }
                 yW.v[e] = y;

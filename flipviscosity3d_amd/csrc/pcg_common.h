@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     const T alpha = (T)alpha_d;
     const double beta_d = sg != 0.0 ? est / sg : 0.0;
     int i0, j, k;
-    double acc = 0.0, mx = 0.0;
+    double acc = 0.0;
+    float mxf = 0.0f;  // max|r| over this thread's rows, tracked in the storage precision of r
+    double mxd = 0.0;
     const int nvb = ((ntiles + 7) >> 3) << 3;
     for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
         if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
@@ -308,10 +310,11 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
                     x.v[e] += alpha * s.v[e];
                     const RT<T> rn_t = (RT<T>)((double)r.v[e] - alpha_d * (double)q.v[e]);
                     const double rn = (double)rn_t;
-                    const double zn = rn / (double)d.v[e];
+                    // z = r/d in the storage precision (correctly rounded division; an fp64 quotient of fp32 data buys nothing)
+                    const double zn = sizeof(RT<T>) == 4 ? (double)((float)rn_t / d.v[e]) : rn / (double)d.v[e];
                     r.v[e] = rn_t;
                     s.v[e] = (T)(zn + beta_d * (double)s.v[e]);
-                    mx = fmax(mx, fabs(rn));
+                    if (sizeof(RT<T>) == 4) mxf = fmaxf(mxf, fabsf((float)rn_t)); else mxd = fmax(mxd, fabs(rn));
                     acc += zn * rn;
                 }
             }
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
         }
     }
     const double tot = block_sum_256(acc, lds);
-    const double bm = block_max_256(mx, lds);
+    const double bm = block_max_256(fmax((double)mxf, mxd), lds);
     if (threadIdx.x == 0 && threadIdx.y == 0) {
         const int sl = sc.my_slot();
         if (tot != 0.0) atomicAdd(sc.sig(it + 1) + sl, tot);
