@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
             if (lane == 0 && i0 > 0) { esl = s[c - 1]; ecil = pi[c - 1]; }
             if (lane == 63 && i0 + 4 < L.I) esr = s[c + 4];
         }
-        T sl = __shfl_up(sc4.v[3], 1, 64), sr = __shfl_down(sc4.v[0], 1, 64);
-        float cil = __shfl_up(ci.v[3], 1, 64);
+        T sl = wave_up1(sc4.v[3]), sr = wave_down1(sc4.v[0]);
+        float cil = wave_up1(ci.v[3]);
         if ((threadIdx.x & 63) == 0) { sl = esl; cil = ecil; }
         if ((threadIdx.x & 63) == 63) sr = esr;
         Vec<T, 4> y;
@@ -293,7 +293,7 @@ int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const f
 
 template <typename T>
 static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
-    const int nb = pcg_grid(count);
+    const int nb = pcg_grid(c, count);
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 0, (double)count * (64 * VW_P * TY));
     hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
@@ -355,7 +355,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     PcgSys<T, 1> v;
     v.mask = nullptr;
     v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
-    const int nb = pcg_grid(c->nActiveP);
+    const int nb = pcg_grid(c, c->nActiveP);
     const dim3 blk(64, 4, 1);
     const HaloArray sh[1] = {{c->pS, sizeof(T)}};
     hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);

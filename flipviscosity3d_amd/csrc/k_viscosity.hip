@@ -394,12 +394,12 @@ __device__ __forceinline__ T nbr(const Vec<T, N> &a, const T *__restrict__ p, in
 // i-neighbour across lanes; `edge` is the value lane 0 (left) / lane 63 (right) fetched from memory beforehand
 template <typename T, int N>
 __device__ __forceinline__ T nbl2(const Vec<T, N> &a, T edge) {
-    const T v = __shfl_up(a.v[N - 1], 1, 64);
+    const T v = wave_up1(a.v[N - 1]);
     return (threadIdx.x & 63) == 0 ? edge : v;
 }
 template <typename T, int N>
 __device__ __forceinline__ T nbr2(const Vec<T, N> &a, T edge) {
-    const T v = __shfl_down(a.v[0], 1, 64);
+    const T v = wave_down1(a.v[0]);
     return (threadIdx.x & 63) == 63 ? edge : v;
 }
 #define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
@@ -554,7 +554,7 @@ static PcgSys<T, 3> visc_sys(flipv_context *c) {
 
 template <typename T, int NV>
 static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
-    const int nb = pcg_grid(count);
+    const int nb = pcg_grid(c, count);
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 1, (double)count * (64 * NV * TY));
     hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
@@ -658,7 +658,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         success = true;
     } else {
         sc.tol = c->prm.viscosity_tolerance * bnorm;
-        const int nb = pcg_grid(c->nActiveV);
+        const int nb = pcg_grid(c, c->nActiveV);
         const dim3 blk(64, 4, 1);
         const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
         if (c->vwV == 4)

@@ -69,18 +69,38 @@ __device__ __forceinline__ void stv(double *__restrict__ p, const Vec<double, 2>
     *reinterpret_cast<double2 *>(p) = make_double2(r.v[0], r.v[1]);
 }
 
+// lane i <- lane i-1 / lane i+1 of the wave as a DPP move (wave_shr:1 / wave_shl:1 exist on gfx9-family ISAs, gfx950
+// included): one VALU instruction instead of a ds_bpermute round trip through the LDS pipe.  Lane 0 / lane 63 keep
+// their own value; callers overwrite those lanes with the value fetched from memory.
+__device__ __forceinline__ int d_dpp_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }    // wave_shr:1
+__device__ __forceinline__ int d_dpp_down1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+__device__ __forceinline__ float wave_up1(float v) { return __int_as_float(d_dpp_up1(__float_as_int(v))); }
+__device__ __forceinline__ float wave_down1(float v) { return __int_as_float(d_dpp_down1(__float_as_int(v))); }
+__device__ __forceinline__ int wave_up1(int v) { return d_dpp_up1(v); }
+__device__ __forceinline__ int wave_down1(int v) { return d_dpp_down1(v); }
+__device__ __forceinline__ double wave_up1(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)d_dpp_up1((int)(unsigned)b), hi = (unsigned)d_dpp_up1((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_down1(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)d_dpp_down1((int)(unsigned)b), hi = (unsigned)d_dpp_down1((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // value at i0-1 (the previous lane's last element) / at i0+N (the next lane's first element).
 // `p` points at this lane's first element; the wave-edge lanes read memory when the neighbour index is inside
 // the lattice width w, else 0 (wave-uniform condition: only grids wider than one wave ever take it).
 template <typename T, int N>
 __device__ __forceinline__ T nb_left(const Vec<T, N> &a, const T *__restrict__ p, int i0) {
-    T v = __shfl_up(a.v[N - 1], 1, 64);
+    T v = wave_up1(a.v[N - 1]);
     if ((threadIdx.x & 63) == 0) v = i0 > 0 ? p[-1] : (T)0;
     return v;
 }
 template <typename T, int N>
 __device__ __forceinline__ T nb_right(const Vec<T, N> &a, const T *__restrict__ p, int i0, int w) {
-    T v = __shfl_down(a.v[0], 1, 64);
+    T v = wave_down1(a.v[0]);
     if ((threadIdx.x & 63) == 63) v = i0 + N < w ? p[N] : (T)0;
     return v;
 }
@@ -351,7 +371,12 @@ static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<
 // ---- host-side helpers (k_pressure.hip) ----
 int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT+16 doubles
 // never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
-static inline int pcg_grid(int ntiles) { const int nb = ((ntiles + 7) / 8) * 8; return nb < 8 ? 8 : (nb < MAX_PCG_BLOCKS ? nb : MAX_PCG_BLOCKS); }
+static inline int pcg_grid(const flipv_context *c, int ntiles) {
+    int cap = c->prm.reserved[2] > 0 ? ((c->prm.reserved[2] + 7) / 8) * 8 : MAX_PCG_BLOCKS;  // test hook: small grids make every block walk many tiles
+    if (cap > MAX_PCG_BLOCKS) cap = MAX_PCG_BLOCKS;
+    const int nb = ((ntiles + 7) / 8) * 8;
+    return nb < 8 ? 8 : (nb < cap ? nb : cap);
+}
 int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    const uint8_t *mask, int *list, int *nActive, int *nInterior);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);

@@ -61,6 +61,26 @@ def test_p2g_and_extrapolation(name):
     c.close()
 
 
+@pytest.mark.parametrize("name", ["bunny32_viscous", "twobody20_varvisc"])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_solvers_with_many_tiles_per_block(name, precision):
+    """The PCG kernels walk their tile lists with a grid stride; at the fixture sizes a block normally sees one tile.
+    flipv_params.reserved[2] caps the grid at 8 blocks so that every block loops over many tiles, as at 256^3."""
+    import ctypes as C
+    g = Golden(name)
+    c = make_ctx(g, precision=precision, viscosity_max_iterations=5000, viscosity_tolerance=1e-7,
+                 pressure_rel_tolerance=1e-7 if precision == 0 else 0.0)
+    p = c.get_params()
+    p.reserved[2] = 8
+    c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+    c.particles = g["particles0"]
+    for t in range(g.nsub):
+        st = c.substep(g.dt)
+        assert st["viscosity"]["status"] in (0, 3) and st["pressure"]["status"] in (0, 3)
+        assert rel_maxnorm3([c.grid(n) for n in "UVW"], g.uvw(t, "final")) <= 1e-4
+    c.close()
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_binned_scatters_match_global_atomic_scatters(name):
     """The LDS-tile scatters (default) against the one-thread-per-particle global-atomic kernels
