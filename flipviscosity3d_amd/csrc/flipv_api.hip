@@ -175,6 +175,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     GALLOC(c->vmU); GALLOC(c->vmV); GALLOC(c->vmW);
     GALLOC(c->stU); GALLOC(c->stV); GALLOC(c->stW);
     GALLOC(c->vRowMask);
+    GALLOC(c->pMask);
     GALLOC(c->validCells); GALLOC(c->validTmp);
     for (int q = 0; q < 3; q++) { VALLOC(c->vX[q]); VALLOC(c->vR[q]); VALLOC(c->vZ[q]); VALLOC(c->vS[q]); }
     // staging buffer for layout conversion: one node-lattice worth of floats

@@ -123,6 +123,7 @@ struct flipv_context {
 
     // pressure system (zero outside pressure cells)
     float *pDiag, *pPi, *pPj, *pPk;
+    uint8_t *pMask;  // 1 where the cell is a pressure cell
     void *pX, *pR, *pZ, *pS;  // vectors (float or double per precision)
     // viscosity system
     float *scp;                                                 // solid phi at cell centres

@@ -25,7 +25,8 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
                                  const float *__restrict__ wU, const float *__restrict__ wV,
                                  const float *__restrict__ wW, float *__restrict__ diag, float *__restrict__ pi,
                                  float *__restrict__ pj, float *__restrict__ pk, RT<T> *__restrict__ r, T *__restrict__ x,
-                                 T *__restrict__ s, double *__restrict__ bmax, float dxf, float dtf, float minfrac) {
+                                 T *__restrict__ s, uint8_t *__restrict__ cellmask, double *__restrict__ bmax, float dxf,
+                                 float dtf, float minfrac) {
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     double babs = 0.0;
@@ -71,6 +72,7 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
             if (dg == 0.0f) b = 0.0;  // a cell with no open face has an all-zero row; keep it out of the system
         }
         diag[c] = dg; pi[c] = ci; pj[c] = cj; pk[c] = ck;
+        cellmask[c] = (uint8_t)(dg != 0.0f);
         r[c] = (RT<T>)b;
         x[c] = (T)0;
         s[c] = (T)0;
@@ -86,32 +88,38 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                        const float *__restrict__ diag, const float *__restrict__ pi,
                                                        const float *__restrict__ pj, const float *__restrict__ pk,
-                                                       const T *__restrict__ s, const RT<T> *__restrict__ r,
-                                                       T *__restrict__ q, PcgScal sc, int it_arg) {
+                                                       const uint8_t *__restrict__ cellmask, const T *__restrict__ s,
+                                                       const RT<T> *__restrict__ r, T *__restrict__ q, PcgScal sc, int it_arg) {
     __shared__ double lds[12];
     const int it = d_iter_spmv(sc, it_arg);
     if (d_spmv_stop(sc, it)) return;
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
     const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
-        if (!(d_tile_coords<VW_P>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
-        const size_t c = gidx(L, i0, j, k);
-        const long sy = L.sy, sz = L.sz;
-        const Vec<float, 4> dg = ldv<4>(diag + c);
+    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
+      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
+      unsigned mks[TBATCH];
+      d_fetch_masks<VW_P>(B, tg, L, cellmask, mks);
+#pragma unroll 1
+      for (int t = 0; t < TBATCH; t++) {
         // a lane without pressure cells has nothing to compute or store (q is only read where diag != 0, s is 0 off the
         // pressure cells); it only has to load if a neighbouring lane, which takes its i+-1 values from it, has cells
-        const bool mine = dg.v[0] != 0.0f || dg.v[1] != 0.0f || dg.v[2] != 0.0f || dg.v[3] != 0.0f;
+        const bool inside = d_tile_decode<VW_P>(d_pick(B.id, t), tg, L, i0, j, k);
+        const bool mine = inside && d_pick(mks, t) != 0u;
         if (!__any(mine)) continue;
+        if (!inside) continue;
+        const size_t c = gidx(L, i0, j, k);
+        const long sy = L.sy, sz = L.sz;
         const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // outside any short-circuit
         const bool on = mine || mleft != 0 || mright != 0;
         // every load of the tile in one predicated block (the kernel is latency-bound on the reference's scenes)
-        Vec<float, 4> ci{}, cj{}, ck{}, cjm{}, ckm{};
+        Vec<float, 4> dg{}, ci{}, cj{}, ck{}, cjm{}, ckm{};
         Vec<T, 4> sc4{}, sjm{}, sjp{}, skm{}, skp{};
         Vec<RT<T>, 4> r4{};
         T esl = (T)0, esr = (T)0;
         float ecil = 0.0f;
         if (on) {
+            dg = ldv<4>(diag + c);
             ci = ldv<4>(pi + c); cj = ldv<4>(pj + c); ck = ldv<4>(pk + c);
             cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
             sc4 = ldv<4>(s + c); sjm = ldv<4>(s + c - sy); sjp = ldv<4>(s + c + sy); skm = ldv<4>(s + c - sz); skp = ldv<4>(s + c + sz);
@@ -146,6 +154,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
             }
         }
         if (mine) stv(q + c, y);
+      }
     }
     block_sum3_256(da, db, dc, lds);
     if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
@@ -297,7 +306,7 @@ static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, in
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 0, (double)count * (64 * VW_P * TY));
     hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it);
+                       c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it);
     if (timed) fv_ev_end(c);
 }
 
@@ -324,7 +333,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     T *x = f32 ? (T *)c->pressure : (T *)c->pX;
     const Lay R1 = fv_range(c, 1);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, bmax, c->dx, dt, c->prm.min_frac);
+                       c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
@@ -353,7 +362,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     sc.tol = fmax(c->prm.pressure_tolerance, c->prm.pressure_rel_tolerance * bnorm);
 
     PcgSys<T, 1> v;
-    v.mask = nullptr;
+    v.mask = c->pMask;
     v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
     const int nb = pcg_grid(c, c->nActiveP);
     const dim3 blk(64, 4, 1);

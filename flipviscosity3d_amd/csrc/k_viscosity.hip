@@ -417,8 +417,16 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
     const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
-        if (!(d_tile_coords<NV>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
+    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
+      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
+      unsigned mks[TBATCH];
+      d_fetch_masks<NV>(B, tg, L, v.mask, mks);
+#pragma unroll 1
+      for (int t = 0; t < TBATCH; t++) {
+        const bool inside = d_tile_decode<NV>(d_pick(B.id, t), tg, L, i0, j, k);
+        const bool mine = inside && d_pick(mks, t) != 0u;
+        if (!__any(mine)) continue;  // the lane shuffles below need every lane of the wave
+        if (!inside) continue;
         const size_t c = gidx(L, i0, j, k);
         const long sy = L.sy, sz = L.sz;
         const int I = L.I;
@@ -427,8 +435,6 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
         // read where the diagonal is non-zero), and it only has to LOAD if a neighbouring lane, which takes its i+-1
         // values from it, has one: in the sparse scenes of the reference that leaves most lanes of a tile without any
         // memory access beyond the mask bytes.
-        const bool mine = ld_mask<NV>(v.mask + c) != 0u;
-        if (!__any(mine)) continue;  // the lane shuffles below need every lane of the wave
         const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // (not inside a short-circuit: every lane must execute the shuffles)
         const bool on = !PRED || mine || mleft != 0 || mright != 0;
         // All loads of the tile are issued in one predicated block (one exec-mask region, no dependent waits in between):
@@ -525,6 +531,7 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
             stv(v.q[1] + c, yV);
             stv(v.q[2] + c, yW);
         }
+      }
     }
     block_sum3_256(da, db, dc, lds);
     if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {

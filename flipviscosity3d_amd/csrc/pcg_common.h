@@ -214,7 +214,7 @@ template <> __device__ __forceinline__ unsigned ld_mask<4>(const uint8_t *__rest
 
 // Blocks loop over tiles with a grid stride (grids are capped at MAX_PCG_BLOCKS so a launch never issues more than
 // that many scalar atomics); `b` is the virtual block index b = blockIdx.x + n*gridDim.x.
-constexpr int MAX_PCG_BLOCKS = 2048;
+constexpr int MAX_PCG_BLOCKS = 1024;  // 4 blocks per CU: one resident round at the SpMV kernels' occupancy (measured best of 128..2048 at 256^3)
 template <int N>
 __device__ __forceinline__ bool d_tile_coords(int b, const int *__restrict__ tiles, int ntiles, const TileGrid &tg, int &i0,
                                               int &j, int &k) {
@@ -229,6 +229,47 @@ __device__ __forceinline__ bool d_tile_coords(int b, const int *__restrict__ til
     j = ty * TY + threadIdx.y;
     return true;
 }
+
+// Tile look-ahead.  The kernels are latency-bound on the reference's scenes (a wave spends most of its life parked on
+// dependent loads: tile id -> mask -> data), so a block fetches the ids of its next TBATCH tiles with independent loads,
+// then their masks with independent loads, and only then walks them: 2 + TBATCH dependent round trips per TBATCH
+// tiles instead of 3 per tile.
+constexpr int TBATCH = 4;
+struct TileBatch { int id[TBATCH]; };  // -1: no tile
+__device__ __forceinline__ TileBatch d_fetch_tiles(int base, int nvb, const int *__restrict__ tiles, int ntiles) {
+    TileBatch B;
+#pragma unroll
+    for (int t = 0; t < TBATCH; t++) {
+        const int b = base + t * (int)gridDim.x;
+        const int slot = d_tile_slot(b, ntiles);
+        B.id[t] = (b < nvb && slot < ntiles) ? tiles[slot] : -1;
+    }
+    return B;
+}
+// this lane's first index of tile `tile`, or false if the lane lies outside the index space
+template <int N>
+__device__ __forceinline__ bool d_tile_decode(int tile, const TileGrid &tg, const Lay &L, int &i0, int &j, int &k) {
+    if (tile < 0) return false;
+    const int tx = tile % tg.ntx;
+    const int t2 = tile / tg.ntx;
+    const int ty = t2 % tg.nty;
+    k = t2 / tg.nty;
+    i0 = tx * (64 * N) + threadIdx.x * N;
+    j = ty * TY + threadIdx.y;
+    return i0 < L.PX && j < L.PY;
+}
+// the mask words of this lane for the TBATCH tiles (0 where the lane is outside / there is no tile)
+template <int N>
+__device__ __forceinline__ void d_fetch_masks(const TileBatch &B, const TileGrid &tg, const Lay &L, const uint8_t *__restrict__ mask,
+                                              unsigned mk[TBATCH]) {
+#pragma unroll
+    for (int t = 0; t < TBATCH; t++) {
+        int i0, j, k;
+        mk[t] = d_tile_decode<N>(B.id[t], tg, L, i0, j, k) ? ld_mask<N>(mask + gidx(L, i0, j, k)) : 0u;
+    }
+}
+__device__ __forceinline__ int d_pick(const int v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
+__device__ __forceinline__ unsigned d_pick(const unsigned v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 
 __device__ __forceinline__ bool d_pass(const PcgScal &sc, double res) { return sc.tol_inclusive ? (res <= sc.tol) : (res < sc.tol); }
 
@@ -300,14 +341,19 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     float mxf = 0.0f;  // max|r| over this thread's rows, tracked in the storage precision of r
     double mxd = 0.0;
     const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
-        if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
+    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
+      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
+      unsigned mks[TBATCH] = {0xffu, 0xffu, 0xffu, 0xffu};
+      if (v.mask) d_fetch_masks<N>(B, tg, L, v.mask, mks);
+#pragma unroll 1
+      for (int t = 0; t < TBATCH; t++) {
+        if (!d_tile_decode<N>(d_pick(B.id, t), tg, L, i0, j, k)) continue;
         const size_t c = gidx(L, i0, j, k);
         // which components have unknowns among this lane's N indices: from the mask bytes (bit m = component m) when there
         // is a mask, so that the diagonal is fetched together with the vectors instead of ahead of them
         unsigned bits = 0xffu;
         if (v.mask) {
-            const unsigned mk = ld_mask<N>(v.mask + c);
+            const unsigned mk = d_pick(mks, t);
             if (mk == 0u) continue;
             bits = mk | (mk >> 8) | (mk >> 16) | (mk >> 24);
         }
@@ -342,6 +388,7 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
             stv(v.r[m] + c, r);
             stv(v.s[m] + c, s);
         }
+      }
     }
     const double tot = block_sum_256(acc, lds);
     const double bm = block_max_256(fmax((double)mxf, mxd), lds);

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 PEAK = 8000.0
 
 
-def run(N, precision, reps, viscosity=5.0):
+def run(N, precision, reps, viscosity=5.0, gridcap=0):
     from flipviscosity3d_amd import hostapi as H
     from flipviscosity3d_amd.capi import Context
     dx = float(np.float32(1.0 / N))
@@ -27,6 +27,11 @@ def run(N, precision, reps, viscosity=5.0):
     c.set_solid_sdf(solid)
     c.set_viscosity(viscosity)
     c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4)
+    if gridcap:
+        import ctypes as C
+        p = c.get_params()
+        p.reserved[2] = gridcap
+        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
     rng = np.random.default_rng(0)
     c.set_grid("LIQUID_PHI", np.full((N, N, N), -0.5 * dx, np.float32))
     for n in "UVW":
@@ -35,7 +40,7 @@ def run(N, precision, reps, viscosity=5.0):
     c.compute_weights()
     vi = c.viscosity_solve(0.01)
     pi = c.pressure_solve(0.01)
-    out = {"size": N, "precision": "f32" if precision == 0 else "f64", "device": c.device_name(),
+    out = {"gridcap": gridcap, "size": N, "precision": "f32" if precision == 0 else "f64", "device": c.device_name(),
            "copy_GBs": c.bench_copy(1 << 30, 10)}
     bpc = {0: (24, 52), 1: (32, 76)}[precision]  # fp64 vectors: s,z (pressure) / x,y (viscosity) double
     for which, name, b, info in ((0, "pressure_spmv", bpc[0], pi), (1, "viscosity_spmv", bpc[1], vi)):
@@ -52,6 +57,7 @@ if __name__ == "__main__":
     ap.add_argument("--sizes", type=int, nargs="+", default=[256, 384])
     ap.add_argument("--precision", type=int, default=0)
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--gridcap", type=int, default=0, help="cap of the PCG kernels' grids (flipv_params.reserved[2]); 0 = library default")
     a = ap.parse_args()
     for N in a.sizes:
-        print(json.dumps(run(N, a.precision, a.reps)), flush=True)
+        print(json.dumps(run(N, a.precision, a.reps, gridcap=a.gridcap)), flush=True)
