@@ -120,6 +120,7 @@ struct flipv_context {
     int nActiveP, nActiveV;
     int nIntP, nIntV;  // multi-rank: the first nInt* list entries are tiles of interior planes, the rest of the slab's two boundary planes
     int vwV;         // lane width chosen for the current viscosity solve (2 or 4)
+    int vPred;       // sparse liquid: the SpMV predicates its loads per lane
 
     // pressure system (zero outside pressure cells)
     float *pDiag, *pPi, *pPj, *pPk;

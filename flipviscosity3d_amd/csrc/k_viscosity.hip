@@ -564,6 +564,10 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     const int nb = pcg_grid(c, count);
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 1, (double)count * (64 * NV * TY));
+    if (NV == 4 && c->vPred)
+        hipLaunchKernelGGL((k_visc_spmv<T, 4, true>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
+                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
+    else
     hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
                        c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
     if (timed) fv_ev_end(c);
@@ -635,12 +639,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                        c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, c->validCells, full, v, bmax, c->d_flags + 2);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    // lane width of the solver kernels: 4 consecutive i per lane (16-byte accesses, 2 waves/SIMD) when most of the
-    // index space holds rows, 2 (8-byte accesses, 4 waves/SIMD, half as many idle lanes per tile) for sparse liquids;
-    // measured: 240 vs 280 us on the filled 256^3 box, 50 vs 38 us on the 256^3 bunny
+    // Lane width of the solver kernels: 4 consecutive i per lane (16-byte accesses).  With per-lane load predication the
+    // narrow variant (2 per lane, twice the waves) no longer wins on sparse liquids (256^3 bunny: 40.7 vs 42.7 ms per
+    // solve); it stays selectable for measurements.  Sparse liquids (row fill <= 0.35) use the predicated SpMV.
     HIPCHK(c, hipStreamSynchronize(c->stream));  // h_flags[2] = row count
     const double fill = (double)c->h_flags[2] / (3.0 * (double)(c->k1 - c->k0) * (double)L.PX * (double)L.PY);
-    c->vwV = fill > 0.35 ? 4 : 2;
+    c->vwV = 4;
+    if (c->prm.reserved[3] == 2 || c->prm.reserved[3] == 4) c->vwV = c->prm.reserved[3];  // measurement switch: forced lane width
+    c->vPred = fill <= 0.35;
     c->tgV.ntx = (L.PX + 64 * c->vwV - 1) / (64 * c->vwV);
     rc = fv_build_tiles(c, c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV);
     if (rc) return rc;

@@ -82,7 +82,8 @@ typedef struct flipv_params {
     int check_every;             /* convergence poll interval in iterations (default 8) */
     int reserved[8];             /* measurement switches, all 0 by default: [0]=1 no hipGraph replay of the PCG loop;
                                     [1]=1 un-binned particle scatters (global atomics instead of LDS tiles);
-                                    [2]=n>0 caps the PCG kernels' grids at n blocks (tests: every block walks many tiles) */
+                                    [2]=n>0 caps the PCG kernels' grids at n blocks (tests: every block walks many tiles);
+                                    [3]=2|4 forces the lane width of the viscosity solver kernels */
 } flipv_params;
 
 typedef struct flipv_solve_info {
