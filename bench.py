@@ -12,9 +12,15 @@ min(CFL step, 0.01 s) exactly as FluidSimulation::advance takes them (fluidsimul
 Inputs are resident in HBM before the timed region; value = grid cells / wall seconds per substep.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel of the substep (the matrix-free viscosity SpMV, 52 algorithmic bytes
-                  per swept index), duration measured with HIP events on the library's own stream around
-                  every launch inside the timed region.
+  roofline     -- the dominant kernel of the substep, the matrix-free viscosity SpMV.  Unit = one MAC cell's worth of
+                  unknowns (3 rows), 52 algorithmic bytes per unit (DESIGN.md 3); units per launch = rows of the system / 3;
+                  duration measured with HIP events on the library's own stream around every 8th launch inside the
+                  timed region.  On this scene the liquid fills 4 % of the box and a launch moves ~40 MB: the kernel is
+                  latency-bound, not HBM-bound, and the fraction says so.
+  roofline_dense -- the same two SpMV kernels on a completely filled 256^3 box (SURVEY.md 8d "pure kernel roofline
+                  runs"), where a launch streams 0.4-0.9 GB and the HBM bound is the relevant one; measured live.
+  cpu_baseline -- the reference itself (oracle/_ref, kind "reference") or our C restatement (kind "port"),
+                  one thread, timed here on a bounded sample of the same scene.
   cpu_baseline -- the reference itself (oracle/_ref, kind "reference") or our C restatement (kind "port"),
                   one thread, timed here on a bounded sample of the same scene.
 """
@@ -112,6 +118,7 @@ def main():
     ap.add_argument("--viscosity", type=float, default=5.0)
     ap.add_argument("--cpu-size", type=int, default=96, help="grid size of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense", action="store_true", help="skip the filled-box SpMV roofline measurement")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
     args = ap.parse_args()
 
@@ -190,33 +197,38 @@ def main():
     cells_total = float(N) ** 3 * world  # N x N x (N*world) cells, one N^3 slab per rank
     value = cells_total / 1e6 / (elapsed / args.steps)
 
-    # ---- roofline of the dominant kernel
+    # ---- roofline of the dominant kernel.  Units processed per launch: unknowns of the system in cells' worth
+    # (viscosity: rows / 3; pressure: pressure cells); the swept index positions of the tile lists are reported beside it.
     v_ms, v_n, v_cells = ks["viscosity_spmv_ms"], ks["viscosity_spmv_launches"], ks["viscosity_spmv_cells"]
     p_ms, p_n, p_cells = ks["pressure_spmv_ms"], ks["pressure_spmv_launches"], ks["pressure_spmv_cells"]
+    last = stats[-1]
     roof = None
     if v_n > 0 and v_ms >= p_ms:
         avg_ms = v_ms / v_n
-        gbs = VISC_SPMV_BYTES_PER_INDEX * (v_cells / v_n) / (avg_ms * 1e-3) / 1e9
+        units = last["viscosity"]["rows"] / 3.0
+        gbs = VISC_SPMV_BYTES_PER_INDEX * units / (avg_ms * 1e-3) / 1e9
         roof = {"kernel": "k_visc_spmv<float>" if args.precision == 0 else "k_visc_spmv<double>", "bound": "hbm",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                "avg_launch_us": avg_ms * 1e3, "launches": v_n, "indices_per_launch": v_cells / v_n,
-                "bytes_per_index": VISC_SPMV_BYTES_PER_INDEX}
+                "avg_launch_us": avg_ms * 1e3, "launches": v_n, "units_per_launch": units, "bytes_per_unit": VISC_SPMV_BYTES_PER_INDEX,
+                "unit_definition": "one cell's worth of unknowns = 3 rows of the viscosity system",
+                "swept_indices_per_launch": v_cells / v_n}
     elif p_n > 0:
         avg_ms = p_ms / p_n
-        gbs = PRES_SPMV_BYTES_PER_CELL * (p_cells / p_n) / (avg_ms * 1e-3) / 1e9
+        units = float(last["pressure"]["rows"])
+        gbs = PRES_SPMV_BYTES_PER_CELL * units / (avg_ms * 1e-3) / 1e9
         roof = {"kernel": "k_pressure_spmv<float>", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_ms * 1e3, "launches": p_n,
-                "cells_per_launch": p_cells / p_n, "bytes_per_cell": PRES_SPMV_BYTES_PER_CELL}
+                "units_per_launch": units, "bytes_per_unit": PRES_SPMV_BYTES_PER_CELL, "unit_definition": "pressure cell",
+                "swept_indices_per_launch": p_cells / p_n}
     if roof is not None:
         roof.update(committed_profile(roof["kernel"].split("<")[0], N, args, world))
     extra = {}
     if p_n > 0:
         avg = p_ms / p_n
-        extra["pressure_spmv"] = {"avg_launch_us": avg * 1e3, "launches": p_n,
-                                  "achieved_GBs": PRES_SPMV_BYTES_PER_CELL * (p_cells / p_n) / (avg * 1e-3) / 1e9}
+        extra["pressure_spmv"] = {"avg_launch_us": avg * 1e3, "launches": p_n, "cells_per_launch": last["pressure"]["rows"],
+                                  "achieved_GBs": PRES_SPMV_BYTES_PER_CELL * last["pressure"]["rows"] / (avg * 1e-3) / 1e9}
 
     if rank == 0:
-        last = stats[-1]
         out = {
             "metric": "MCells/s per substep (P2G+PCG+viscosity), %d^3 grid" % N,
             "value": value, "unit": "MCells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -233,19 +245,58 @@ def main():
             "device": dev_name,
             "phase_ms": last["phase_ms"],
             "viscosity": {k: last["viscosity"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
-            "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "active_tiles", "total_tiles")},
+            "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "roofline": roof,
         }
         out.update(extra)
+        if world == 1 and not args.no_dense:
+            c.close()
+            c = None
+            out["roofline_dense"] = dense_roofline(N, args.precision)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.viscosity, args.cpu_size)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         c.comm_finalize()
-    c.close()
+    if c is not None:
+        c.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dense_roofline(N, precision, reps=50):
+    """The two SpMV kernels on a completely filled N^3 box (every interior cell liquid): active ~ swept cells, a launch
+    streams hundreds of MB, so achieved GB/s against the HBM peak measures the kernels themselves.  flipv_bench_spmv
+    launches the solver's own kernel `reps` times back to back between two HIP events on the library's stream."""
+    from flipviscosity3d_amd import hostapi as H
+    from flipviscosity3d_amd.capi import Context
+    dx = float(np.float32(1.0 / N))
+    sim = H.FluidSimulation()
+    sim.initialize(N, N, N, dx)
+    solid = sim.solid_sdf()   # the default box boundary (fluidsimulation.cpp:206-239)
+    sim.close()
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(5.0)
+    c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4)
+    rng = np.random.default_rng(0)
+    c.set_grid("LIQUID_PHI", np.full((N, N, N), -0.5 * dx, np.float32))
+    for n, shp in (("U", (N, N, N + 1)), ("V", (N, N + 1, N)), ("W", (N + 1, N, N))):
+        c.set_grid(n, rng.uniform(-1, 1, shp).astype(np.float32))
+    c.compute_weights()
+    vi = c.viscosity_solve(0.01)
+    pi = c.pressure_solve(0.01)
+    out = {"workload": "filled %d^3 box, every interior cell liquid" % N, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "device_copy_GBs": c.bench_copy(1 << 30, 10)}
+    for which, name, b, units in ((0, "pressure_spmv", PRES_SPMV_BYTES_PER_CELL, float(pi["rows"])),
+                                  (1, "viscosity_spmv", VISC_SPMV_BYTES_PER_INDEX, vi["rows"] / 3.0)):
+        ms, swept = c.bench_spmv(which, reps)
+        gbs = b * units / (ms * 1e-3) / 1e9
+        out[name] = {"avg_launch_us": ms * 1e3, "units_per_launch": units, "bytes_per_unit": b, "achieved": gbs,
+                     "frac": gbs / HBM_PEAK_GBS, "swept_indices_per_launch": swept}
+    c.close()
+    return out
 
 
 def committed_profile(kernel, N, args, world):

@@ -25,11 +25,12 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
                                  const float *__restrict__ wU, const float *__restrict__ wV,
                                  const float *__restrict__ wW, float *__restrict__ diag, float *__restrict__ pi,
                                  float *__restrict__ pj, float *__restrict__ pk, RT<T> *__restrict__ r, T *__restrict__ x,
-                                 T *__restrict__ s, uint8_t *__restrict__ cellmask, double *__restrict__ bmax, float dxf,
-                                 float dtf, float minfrac) {
+                                 T *__restrict__ s, uint8_t *__restrict__ cellmask, double *__restrict__ bmax,
+                                 int *__restrict__ ncells, int k0own, int k1own, float dxf, float dtf, float minfrac) {
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     double babs = 0.0;
+    int cells = 0;
     if (i < L.PX && j < L.PY) {
         const size_t c = gidx(L, i, j, k);
         float dg = 0.0f, ci = 0.0f, cj = 0.0f, ck = 0.0f;
@@ -73,13 +74,18 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
         }
         diag[c] = dg; pi[c] = ci; pj[c] = cj; pk[c] = ck;
         cellmask[c] = (uint8_t)(dg != 0.0f);
+        cells = dg != 0.0f && k >= k0own && k < k1own;
         r[c] = (RT<T>)b;
         x[c] = (T)0;
         s[c] = (T)0;
         babs = fabs(b);
     }
     const double bm = block_max_256(babs, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) atomic_max_nonneg(bmax, bm);
+    const double nc = block_sum_256((double)cells, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        if (bm > 0.0) atomic_max_nonneg(bmax, bm);
+        if (nc > 0.0) atomicAdd(ncells, (int)nc);
+    }
 }
 
 // K12: q = A s with the three fused dot products (pressuresolver.cpp:464-499; term order -i,+i,-j,+j,-k,+k, diagonal).
@@ -322,6 +328,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const size_t nscal = (size_t)5 * (cap + 2) * NSLOT + 16;
     HIPCHK(c, hipMemsetAsync(c->d_scal, 0, nscal * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));  // conv = -1
+    HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));  // pressure-cell counter
     PcgScal sc;
     double *bmax;
     fv_scal_views(c, cap, &sc, &bmax);
@@ -333,7 +340,8 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     T *x = f32 ? (T *)c->pressure : (T *)c->pX;
     const Lay R1 = fv_range(c, 1);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->dx, dt, c->prm.min_frac);
+                       c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->k0, c->k1, c->dx, dt, c->prm.min_frac);
+    HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
@@ -346,6 +354,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const double bnorm = c->h_scal[0];
     li.rhs_norm = bnorm;
     li.active_tiles = c->nActiveP;
+    li.rows = c->h_flags[2];  // pressure cells of this rank
     c->pressureReady = 1;
     c->pressurePrec = f32 ? 0 : 1;
     c->lastDt = dt;
