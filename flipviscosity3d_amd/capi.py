@@ -31,6 +31,7 @@ SYMBOLS = [
     "flipv_advect_particles", "flipv_read_viscosity_volume", "flipv_substep", "flipv_advance",
     "flipv_kernel_stats_reset", "flipv_kernel_stats_get", "flipv_synchronize", "flipv_bench_spmv",
     "flipv_bench_copy",
+    "flipv_mesh_level_set", "flipv_add_boundary_mesh", "flipv_reset_boundary", "flipv_add_liquid_mesh",
     "flipv_comm_unique_id_bytes", "flipv_comm_get_unique_id", "flipv_comm_init_rccl", "flipv_comm_init_local",
     "flipv_comm_finalize",
 ]
@@ -108,6 +109,11 @@ def load():
     L.flipv_set_solid_sdf.argtypes = [ctx, fp]
     L.flipv_set_viscosity_uniform.argtypes = [ctx, C.c_float]
     L.flipv_set_viscosity.argtypes = [ctx, fp]
+    ip = C.POINTER(C.c_int)
+    L.flipv_mesh_level_set.argtypes = [ctx, fp, C.c_size_t, ip, C.c_size_t, C.c_int, fp, ip]
+    L.flipv_add_boundary_mesh.argtypes = [ctx, fp, C.c_size_t, ip, C.c_size_t, C.c_int]
+    L.flipv_reset_boundary.argtypes = [ctx]
+    L.flipv_add_liquid_mesh.argtypes = [ctx, fp, C.c_size_t, ip, C.c_size_t, C.c_ulonglong, C.POINTER(C.c_size_t)]
     L.flipv_upload_particles.argtypes = [ctx, fp, C.c_size_t]
     L.flipv_download_particles.argtypes = [ctx, fp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.flipv_num_particles.restype = C.c_size_t
@@ -193,6 +199,36 @@ class Context:
         if rc < 0:
             raise FlipvError("%s failed (%d): %s" % (what, rc, self.L.flipv_last_error(self.h).decode()))
         return rc
+
+    # ---- scene setup on the device
+    @staticmethod
+    def _mesh(mesh):
+        v = np.ascontiguousarray(mesh[0], np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(mesh[1], np.int32).reshape(-1, 3)
+        return v, t, v.ctypes.data_as(C.POINTER(C.c_float)), len(v), t.ctypes.data_as(C.POINTER(C.c_int)), len(t)
+
+    def mesh_level_set(self, mesh, band=3, want_closest=False):
+        """MeshLevelSet::calculateSignedDistanceField on the device -> phi (K+1,J+1,I+1) [, closest]."""
+        v, t, vp, nv, tp, nt = self._mesh(mesh)
+        phi = np.empty((self.K + 1, self.J + 1, self.I + 1), np.float32)
+        clo = np.empty((self.K + 1, self.J + 1, self.I + 1), np.int32) if want_closest else None
+        self._chk(self.L.flipv_mesh_level_set(self.h, vp, nv, tp, nt, band, phi.ctypes.data_as(C.POINTER(C.c_float)),
+                                              clo.ctypes.data_as(C.POINTER(C.c_int)) if want_closest else None),
+                  "flipv_mesh_level_set")
+        return (phi, clo) if want_closest else phi
+
+    def add_boundary_mesh(self, mesh, inverted=False):
+        v, t, vp, nv, tp, nt = self._mesh(mesh)
+        self._chk(self.L.flipv_add_boundary_mesh(self.h, vp, nv, tp, nt, int(bool(inverted))), "flipv_add_boundary_mesh")
+
+    def reset_boundary(self):
+        self._chk(self.L.flipv_reset_boundary(self.h), "flipv_reset_boundary")
+
+    def add_liquid_mesh(self, mesh, seed=0):
+        v, t, vp, nv, tp, nt = self._mesh(mesh)
+        added = C.c_size_t()
+        self._chk(self.L.flipv_add_liquid_mesh(self.h, vp, nv, tp, nt, seed, C.byref(added)), "flipv_add_liquid_mesh")
+        return added.value
 
     # ---- multi-GPU
     def comm_init_rccl(self, unique_id, rank, nranks):

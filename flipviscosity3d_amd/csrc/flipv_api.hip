@@ -368,6 +368,101 @@ extern "C" int flipv_set_viscosity_uniform(flipv_context *c, float value) {
     return flipv_write_grid(c, FLIPV_GRID_VISCOSITY, v.data());
 }
 
+// ------------------------------------------------------------------------------------------------ scene setup (k_meshsdf.hip)
+int fv_mesh_level_set(flipv_context *c, const float *verts, size_t nverts, const int *tris, size_t ntris, int band, float *phi,
+                      int *closest_out);
+int fv_mesh_negate(flipv_context *c, float *phi);
+int fv_mesh_union(flipv_context *c, float *into, const float *other);
+int fv_seed_particles(flipv_context *c, const float *meshphi, unsigned long long seed, size_t *added);
+
+namespace {
+// a temporary grid in the shared index space (guard zones included), zero-initialised
+struct TempGrid {
+    void *base = nullptr;
+    float *p = nullptr;
+    int alloc(flipv_context *c) {
+        const size_t tot = c->L.n + 2 * c->L.guard;
+        hipError_t e = hipMalloc(&base, tot * 4);
+        if (e != hipSuccess) { c->err = std::string("hipMalloc(temporary grid): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
+        e = hipMemsetAsync(base, 0, tot * 4, c->stream);
+        if (e != hipSuccess) { c->err = hipGetErrorString(e); return FLIPV_ERR_HIP; }
+        p = (float *)base + c->L.guard;
+        return FLIPV_OK;
+    }
+    ~TempGrid() { if (base) (void)hipFree(base); }
+};
+int mesh_inside_domain(flipv_context *c, const float *v, size_t nverts, const char *who) {  // fluidsimulation.cpp:46-49, 65-68
+    if (c->comm) { c->err = std::string(who) + ": scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
+    if (!v || nverts == 0) { c->err = std::string(who) + ": empty mesh"; return FLIPV_ERR_INVALID; }
+    float lo[3] = {v[0], v[1], v[2]}, hi[3] = {v[0], v[1], v[2]};
+    for (size_t t = 0; t < nverts; t++)
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], v[3 * t + a]); hi[a] = fmaxf(hi[a], v[3 * t + a]); }
+    const double ext[3] = {c->L.I * (double)c->dx, c->L.J * (double)c->dx, c->L.K * (double)c->dx};
+    for (int a = 0; a < 3; a++)
+        if (!(lo[a] >= 0.0 && hi[a] < ext[a])) { c->err = std::string(who) + ": mesh bounding box outside the domain"; return FLIPV_ERR_INVALID; }
+    return FLIPV_OK;
+}
+}  // namespace
+
+extern "C" int flipv_mesh_level_set(flipv_context *c, const float *vertices, size_t nvertices, const int *triangles, size_t ntriangles,
+                                    int bandwidth, float *phi_out, int *closest_out) {
+    ENTER(c);
+    if (!phi_out) return FLIPV_ERR_INVALID;
+    if (c->comm) { c->err = "flipv_mesh_level_set: scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
+    TempGrid phi, clo;
+    int rc = phi.alloc(c);
+    if (rc) return rc;
+    if (closest_out && (rc = clo.alloc(c))) return rc;
+    rc = fv_mesh_level_set(c, vertices, nvertices, triangles, ntriangles, bandwidth, phi.p, closest_out ? (int *)clo.p : nullptr);
+    if (rc) return rc;
+    rc = read_lattice(c, LAT_NODE, phi.p, nullptr, phi_out);
+    if (rc) return rc;
+    if (closest_out) rc = read_lattice(c, LAT_NODE, clo.p, nullptr, (float *)closest_out);  // 4-byte values, copied bit for bit
+    return rc;
+}
+
+extern "C" int flipv_add_boundary_mesh(flipv_context *c, const float *vertices, size_t nvertices, const int *triangles,
+                                       size_t ntriangles, int inverted) {
+    ENTER(c);
+    int rc = mesh_inside_domain(c, vertices, nvertices, "flipv_add_boundary_mesh");
+    if (rc) return rc;
+    TempGrid phi;
+    if ((rc = phi.alloc(c))) return rc;
+    if ((rc = fv_mesh_level_set(c, vertices, nvertices, triangles, ntriangles, 3, phi.p, nullptr))) return rc;  // _meshLevelSetExactBand (fluidsimulation.h:121)
+    if (inverted && (rc = fv_mesh_negate(c, phi.p))) return rc;
+    rc = fv_mesh_union(c, c->solid, phi.p);
+    SYNC_RET(c, rc);
+}
+
+extern "C" int flipv_reset_boundary(flipv_context *c) {  // _initializeBoundary (fluidsimulation.cpp:198-239)
+    ENTER(c);
+    if (c->comm) { c->err = "flipv_reset_boundary: scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
+    const double dx = (double)c->dx, eps = 1e-6;
+    // AABB(0,0,0, I dx, J dx, K dx).expand(-3 dx - eps): the constructor and expand() work in double, the corners are
+    // stored as float (aabb.cpp:118-124)
+    const double v = -3 * dx - eps, hh = 0.5 * v;
+    const float px = (float)(0.0 - hh), py = (float)(0.0 - hh), pz = (float)(0.0 - hh);
+    const float w = (float)(c->L.I * dx + v), h = (float)(c->L.J * dx + v), d = (float)(c->L.K * dx + v);
+    const float verts[24] = {px, py, pz,         px + w, py, pz,         px + w, py, pz + d,     px, py, pz + d,
+                             px, py + h, pz,     px + w, py + h, pz,     px + w, py + h, pz + d, px, py + h, pz + d};
+    const int tris[36] = {0, 1, 2, 0, 2, 3, 4, 7, 6, 4, 6, 5, 0, 3, 7, 0, 7, 4, 1, 5, 6, 1, 6, 2, 0, 4, 5, 0, 5, 1, 3, 2, 6, 3, 6, 7};
+    int rc = fv_mesh_level_set(c, verts, 8, tris, 12, 3, c->solid, nullptr);
+    if (rc) return rc;
+    rc = fv_mesh_negate(c, c->solid);
+    SYNC_RET(c, rc);
+}
+
+extern "C" int flipv_add_liquid_mesh(flipv_context *c, const float *vertices, size_t nvertices, const int *triangles,
+                                     size_t ntriangles, unsigned long long seed, size_t *added_out) {
+    ENTER(c);
+    int rc = mesh_inside_domain(c, vertices, nvertices, "flipv_add_liquid_mesh");
+    if (rc) return rc;
+    TempGrid phi;
+    if ((rc = phi.alloc(c))) return rc;
+    if ((rc = fv_mesh_level_set(c, vertices, nvertices, triangles, ntriangles, 3, phi.p, nullptr))) return rc;
+    return fv_seed_particles(c, phi.p, seed, added_out);
+}
+
 // ------------------------------------------------------------------------------------------------ particles
 extern "C" int flipv_upload_particles(flipv_context *c, const float *aos6, size_t n) {
     ENTER(c);

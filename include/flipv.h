@@ -165,6 +165,32 @@ int flipv_constrain(flipv_context *ctx);                          /* _constrainV
 int flipv_update_particle_velocities(flipv_context *ctx);         /* _updateFluidParticleVelocities fluidsimulation.cpp:341-352 */
 int flipv_advect_particles(flipv_context *ctx, float dt);         /* _advectFluidParticles     fluidsimulation.cpp:315-339 */
 
+/* ---- scene setup on the device (single-domain contexts) ----------------------------
+ * Meshes are passed as in TriangleMesh (trianglemesh.h:36-37): `vertices` = nvertices x {x,y,z} floats, `triangles` =
+ * ntriangles x 3 vertex indices; closed, consistently wound surfaces.
+ *
+ * flipv_mesh_level_set   MeshLevelSet::calculateSignedDistanceField (meshlevelset.cpp:138-150): signed distance on the
+ *                        (I+1,J+1,K+1) nodes, Array3d order, into phi_out; closest_out (optional) = closest triangle.
+ *                        Inside the exact band (`bandwidth` nodes around each triangle's box) and in sign the result is
+ *                        bit-identical to the CPU algorithm; farther out the reference's single breadth-first pass is
+ *                        replaced by its fixed point (values mostly smaller, i.e. closer to the true distance; within 1 % otherwise).
+ * flipv_add_boundary_mesh FluidSimulation::addBoundary (fluidsimulation.cpp:45-58): level set (band 3), negated if
+ *                        `inverted`, min-union into the solid SDF held by the context.
+ * flipv_reset_boundary   FluidSimulation::resetBoundary / _initializeBoundary (fluidsimulation.cpp:60-62, 198-239): the
+ *                        default box, 3 dx + 1e-6 inside the domain.
+ * flipv_add_liquid_mesh  FluidSimulation::addLiquid (fluidsimulation.cpp:64-97): 8 jittered samples per cell, kept where
+ *                        the mesh SDF is negative and the solid SDF is not; particles (velocity 0) are APPENDED to the
+ *                        context's particles in cell order.  The jitter is the counter-based generator of the host
+ *                        mirror's SEED_COUNTER mode (splitmix64 of seed, cell, sample, axis), not libc rand().
+ *                        added_out (optional) = number of particles added. */
+int flipv_mesh_level_set(flipv_context *ctx, const float *vertices, size_t nvertices, const int *triangles, size_t ntriangles,
+                         int bandwidth, float *phi_out, int *closest_out);
+int flipv_add_boundary_mesh(flipv_context *ctx, const float *vertices, size_t nvertices, const int *triangles, size_t ntriangles,
+                            int inverted);
+int flipv_reset_boundary(flipv_context *ctx);
+int flipv_add_liquid_mesh(flipv_context *ctx, const float *vertices, size_t nvertices, const int *triangles, size_t ntriangles,
+                          unsigned long long seed, size_t *added_out);
+
 /* the seven viscosity control-volume lattices (viscositysolver.cpp:135-178), for parity tests;
  * which: 0 center (I,J,K) 1 U 2 V 3 W 4 edgeU (I,J+1,K+1) 5 edgeV (I+1,J,K+1) 6 edgeW (I+1,J+1,K).
  * Valid after flipv_viscosity_solve. */
