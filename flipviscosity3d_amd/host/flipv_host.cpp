@@ -31,13 +31,18 @@ bool insideDomain(FluidSimulation &s, const TriangleMesh &m) {  // the check add
 
 extern "C" {
 
-flipvh_sim *flipvh_create(int I, int J, int K, float dx) {
+flipvh_sim *flipvh_create_ex(int I, int J, int K, float dx, int setup_on_device) {
     if (I < 1 || J < 1 || K < 1 || !(dx > 0)) return nullptr;
     flipvh_sim *s = new flipvh_sim();
     s->sim.setQuiet(true);
+    if (setup_on_device) {
+        s->sim.setSetupOnDevice(true);
+        s->sim.setSeeding(FluidSimulation::SEED_COUNTER, 0);
+    }
     s->sim.initialize(I, J, K, dx);
     return s;
 }
+flipvh_sim *flipvh_create(int I, int J, int K, float dx) { return flipvh_create_ex(I, J, K, dx, 0); }
 void flipvh_destroy(flipvh_sim *s) { delete s; }
 
 int flipvh_add_boundary(flipvh_sim *s, const float *verts, int nv, const int *tris, int nt, int inverted) {

@@ -13,6 +13,7 @@ extern "C" {
 typedef struct flipvh_sim flipvh_sim;
 
 flipvh_sim *flipvh_create(int isize, int jsize, int ksize, float dx);      /* FluidSimulation::initialize */
+flipvh_sim *flipvh_create_ex(int isize, int jsize, int ksize, float dx, int setup_on_device); /* + setSetupOnDevice (needs a GPU; counter seeding) */
 void flipvh_destroy(flipvh_sim *s);
 /* 0 ok, -1 mesh bounding box outside the domain (the reference asserts, fluidsimulation.cpp:46-49) */
 int flipvh_add_boundary(flipvh_sim *s, const float *verts, int nv, const int *tris, int nt, int inverted);

@@ -102,7 +102,23 @@ void FluidSimulation::_ensureContext() {
     _solidDirty = _viscosityDirty = _gravityDirty = false;
 }
 
+MeshLevelSet &FluidSimulation::solidSDF() {
+    if (_solidHostStale) {
+        FLIPV_CALL(flipv_read_grid(_ctx, FLIPV_GRID_SOLID_PHI, _solidSDF.getRawArray()));
+        _solidHostStale = false;
+    }
+    return _solidSDF;
+}
+
 void FluidSimulation::_initializeBoundary() {  // reference fluidsimulation.cpp:198-239
+    if (_setupOnDevice) {
+        _solidSDF = MeshLevelSet(_isize, _jsize, _ksize, _dx);
+        _solidDirty = false;
+        _ensureContext();
+        FLIPV_CALL(flipv_reset_boundary(_ctx));
+        _solidHostStale = true;
+        return;
+    }
     const double eps = 1e-6;
     Box dom(0.0, 0.0, 0.0, _isize * _dx, _jsize * _dx, _ksize * _dx);
     dom.expand(-3 * _dx - eps);
@@ -124,6 +140,14 @@ void FluidSimulation::addBoundary(TriangleMesh &boundary, bool isInverted) {  //
     Box domain(0.0, 0.0, 0.0, _isize * _dx, _jsize * _dx, _ksize * _dx);
     Box bbox(boundary.vertices);
     FLIPV_HOST_ASSERT(domain.isPointInside(bbox.minPoint()) && domain.isPointInside(bbox.maxPoint()));
+    if (_setupOnDevice) {
+        FLIPV_HOST_ASSERT(!_solidDirty);  // solidSDF() was not edited by hand since the last device operation
+        _ensureContext();
+        FLIPV_CALL(flipv_add_boundary_mesh(_ctx, &boundary.vertices[0].x, boundary.vertices.size(), &boundary.triangles[0].tri[0],
+                                           boundary.triangles.size(), isInverted ? 1 : 0));
+        _solidHostStale = true;
+        return;
+    }
     MeshLevelSet sdf(_isize, _jsize, _ksize, _dx);
     sdf.calculateSignedDistanceField(boundary, _meshLevelSetExactBand);
     if (isInverted) sdf.negate();
@@ -137,6 +161,17 @@ void FluidSimulation::addLiquid(TriangleMesh &mesh) {  // reference fluidsimulat
     Box domain(0.0, 0.0, 0.0, _isize * _dx, _jsize * _dx, _ksize * _dx);
     Box bbox(mesh.vertices);
     FLIPV_HOST_ASSERT(domain.isPointInside(bbox.minPoint()) && domain.isPointInside(bbox.maxPoint()));
+    if (_setupOnDevice) {
+        FLIPV_HOST_ASSERT(_seedMode == SEED_COUNTER);
+        _ensureContext();  // uploads a hand-edited solid SDF if there is one
+        FLIPV_CALL(flipv_upload_particles(_ctx, particles.empty() ? nullptr : &particles[0].position.x, particles.size()));
+        size_t added = 0, n = 0;
+        FLIPV_CALL(flipv_add_liquid_mesh(_ctx, &mesh.vertices[0].x, mesh.vertices.size(), &mesh.triangles[0].tri[0], mesh.triangles.size(),
+                                         _seed, &added));
+        particles.resize(particles.size() + added);
+        FLIPV_CALL(flipv_download_particles(_ctx, particles.empty() ? nullptr : &particles[0].position.x, particles.size(), &n));
+        return;
+    }
     MeshLevelSet meshSDF(_isize, _jsize, _ksize, _dx);
     meshSDF.calculateSignedDistanceField(mesh, _meshLevelSetExactBand);
     const double dx = _dx;

@@ -53,10 +53,15 @@ public:
         SEED_COUNTER = 1     // counter-based hash of (seed, cell, sample, axis): platform independent, skips empty cells
     };
     void setSeeding(SeedingMode mode, unsigned long long seed = 0) { _seedMode = mode; _seed = seed; }
+    // Scene setup on the device (flipv_reset_boundary / flipv_add_boundary_mesh / flipv_add_liquid_mesh): mesh level
+    // sets and seeding run as HIP kernels instead of host C++.  Call before initialize().  Needs SEED_COUNTER seeding
+    // (libc rand() has no device counterpart); band values, signs and the seeded particles are identical to the host
+    // path, far-field distances of the solid SDF are the relaxed ones (include/flipv.h).
+    void setSetupOnDevice(bool on) { _setupOnDevice = on; }
     void setQuiet(bool q) { _quiet = q; }                  // the reference prints phase banners on stdout
     const flipv_stats &lastStats() const { return _stats; }
     flipv_context *context() { _ensureContext(); return _ctx; }   // created lazily: setup needs no GPU, advance() does
-    MeshLevelSet &solidSDF() { return _solidSDF; }
+    MeshLevelSet &solidSDF();
     void getGridDimensions(int *i, int *j, int *k) const { *i = _isize; *j = _jsize; *k = _ksize; }
     float getCellSize() const { return _dx; }
     void markSolidDirty() { _solidDirty = true; }          // after editing solidSDF() by hand
@@ -75,6 +80,8 @@ private:
     SeedingMode _seedMode = SEED_LIBC_RAND;
     unsigned long long _seed = 0;
     bool _quiet = false;
+    bool _setupOnDevice = false;
+    bool _solidHostStale = false;   // device setup: the context holds the solid SDF, the host copy is fetched on demand
     bool _solidDirty = true, _viscosityDirty = true, _gravityDirty = true;
     float _viscosityUniform = 1.0f;          // reference fluidsimulation.cpp:39
     std::vector<float> _viscosityGrid;       // non-empty after setViscosity(Array3d<float>&)

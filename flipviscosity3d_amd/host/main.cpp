@@ -2,7 +2,7 @@
 // spherical container, viscosity 5, gravity -9.81 y, 300 frames of 0.01 s, one particle dump per frame) on
 // top of the MI355X-native FluidSimulation.  Usage:
 //   fluidsim_mi355x [--size N] [--frames F] [--dt T] [--viscosity V] [--boundary file.ply[:inverted]]
-//                   [--liquid file.ply] [--mesh-dir DIR] [--no-export] [--ply]
+//                   [--liquid file.ply] [--mesh-dir DIR] [--no-export] [--ply] [--gpu-setup]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
     int size = 64, frames = 300;
     float timestep = 0.01f, viscosity = 5.0f;
     std::string meshDir = "sample_meshes", boundary = "sphere_large.ply", liquid = "stanford_bunny.ply";
-    bool inverted = true, exportObj = true, exportPly = false;
+    bool inverted = true, exportObj = true, exportPly = false, gpuSetup = false;
     for (int a = 1; a < argc; a++) {
         const std::string s = argv[a];
         auto next = [&]() -> const char * { return a + 1 < argc ? argv[++a] : ""; };
@@ -44,10 +44,15 @@ int main(int argc, char **argv) {
             if (inverted) boundary = boundary.substr(0, c);
         } else if (s == "--no-export") exportObj = exportPly = false;
         else if (s == "--ply") { exportPly = true; exportObj = false; }
+        else if (s == "--gpu-setup") gpuSetup = true;  // mesh level sets + seeding as HIP kernels (counter-based jitter)
         else { std::fprintf(stderr, "unknown option %s\n", s.c_str()); return 2; }
     }
     const float dx = 1.0f / (float)size;  // reference main.cpp:53
     FluidSimulation fluidsim;
+    if (gpuSetup) {
+        fluidsim.setSetupOnDevice(true);
+        fluidsim.setSeeding(FluidSimulation::SEED_COUNTER, 0);
+    }
     fluidsim.initialize(size, size, size, dx);
 
     TriangleMesh boundaryMesh;

@@ -18,7 +18,7 @@ from . import capi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libflipv_host.so")
-SYMBOLS = ["flipvh_create", "flipvh_destroy", "flipvh_add_boundary", "flipvh_reset_boundary", "flipvh_set_seeding",
+SYMBOLS = ["flipvh_create", "flipvh_create_ex", "flipvh_destroy", "flipvh_add_boundary", "flipvh_reset_boundary", "flipvh_set_seeding",
            "flipvh_add_liquid", "flipvh_set_viscosity", "flipvh_set_viscosity_grid", "flipvh_set_gravity",
            "flipvh_num_particles", "flipvh_get_particles", "flipvh_set_particles", "flipvh_get_solid_sdf",
            "flipvh_advance", "flipvh_context", "flipvh_mesh_sdf", "flipvh_load_ply"]
@@ -39,6 +39,8 @@ def load():
     h = C.c_void_p
     L.flipvh_create.restype = h
     L.flipvh_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float]
+    L.flipvh_create_ex.restype = h
+    L.flipvh_create_ex.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
     L.flipvh_destroy.argtypes = [h]
     L.flipvh_add_boundary.argtypes = [h, fp, C.c_int, ip, C.c_int, C.c_int]
     L.flipvh_reset_boundary.argtypes = [h]
@@ -96,10 +98,12 @@ class FluidSimulation:
         self.L = load()
         self.h = None
 
-    def initialize(self, i, j, k, dx):
+    def initialize(self, i, j, k, dx, setup_on_device=False):
+        """setup_on_device: mesh level sets and seeding run as HIP kernels (needs a GPU; counter-based seeding, seed 0
+        unless setSeeding is called)."""
         self.close()
         self.I, self.J, self.K, self.dx = int(i), int(j), int(k), float(np.float32(dx))
-        self.h = self.L.flipvh_create(self.I, self.J, self.K, C.c_float(dx))
+        self.h = self.L.flipvh_create_ex(self.I, self.J, self.K, C.c_float(dx), int(bool(setup_on_device)))
         if not self.h:
             raise ValueError("initialize: bad grid dimensions")
 

@@ -120,6 +120,32 @@ def test_substep_on_device_built_scene_equals_host_built_scene():
     b.close()
 
 
+def test_host_class_with_device_setup():
+    """FluidSimulation (host C++ mirror) with setSetupOnDevice: same particles and near-surface solid SDF as the host path."""
+    from flipviscosity3d_amd import hostapi as H
+    N = 32
+    dx = float(np.float32(1.0 / N))
+    sphere = H.load_ply(os.path.join(MESH, "sphere_large.ply"))
+    bunny = H.load_ply(os.path.join(MESH, "stanford_bunny.ply"))
+    out = []
+    for dev in (False, True):
+        s = H.FluidSimulation()
+        s.initialize(N, N, N, dx, setup_on_device=dev)
+        s.addBoundary(sphere, True)
+        s.setSeeding(H.FluidSimulation.SEED_COUNTER, 3)
+        s.addLiquid(bunny)
+        out.append((s.solid_sdf(), s.particles))
+        if dev:
+            s.setViscosity(5.0)
+            st = s.advance(0.01)
+            assert st["substeps"] >= 1 and len(s.particles) == len(out[0][1])
+        s.close()
+    (sa, pa), (sb, pb) = out
+    near = np.abs(sa) <= 2.5 * dx
+    assert np.array_equal(sa[near], sb[near]) and np.array_equal(np.signbit(sa), np.signbit(sb))
+    assert np.array_equal(pa, pb)
+
+
 def test_setup_rejects_bad_input():
     from flipviscosity3d_amd import capi
     c = capi.Context(16, 16, 16, 1.0 / 16)
