@@ -1,0 +1,111 @@
+"""Size-independent properties at BASELINE.json's full size (256^3 bunny drop, the bench workload), where the oracle
+would take minutes per substep: binned scatters = un-binned scatters, P2G reproduces a uniform field, the projected
+velocity field is discretely divergence-free to the solver tolerance, the viscosity step obeys its cap/acceptance rule
+and both precisions agree."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N = 256
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from bench import build_scene
+    return build_scene(N, 5.0)
+
+
+def ctx(scene, **params):
+    from flipviscosity3d_amd import capi
+    dx, solid, P = scene
+    c = capi.Context(N, N, N, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(5.0)
+    if params:
+        c.set_params(**params)
+    c.particles = P
+    return c
+
+
+def test_fullsize_scatters(scene):
+    dx, solid, P = scene
+    Q = P.copy()
+    Q[:, 3:] = np.array([0.25, -1.5, 0.75], np.float32)     # uniform particle velocity
+    out = []
+    for unbinned in (0, 1):
+        c = ctx(scene)
+        p = c.get_params()
+        p.reserved[1] = unbinned
+        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.particles = Q
+        c.particle_sdf()
+        phi = c.grid("LIQUID_PHI")
+        c.p2g()
+        out.append((phi, [c.grid(n) for n in "UVW"], [c.grid("VALID_" + n) for n in "UVW"]))
+        c.close()
+    assert np.array_equal(out[0][0], out[1][0])                        # particle SDF: min is order-free
+    assert (out[0][0] < 0).sum() > 500000
+    for (a, b, va, vb, want) in zip(out[0][1], out[1][1], out[0][2], out[1][2], (0.25, -1.5, 0.75)):
+        assert np.array_equal(va, vb)
+        m = va != 0
+        assert m.sum() > 500000
+        # a weighted mean of equal values is that value (to rounding); both scatter kernels
+        assert np.abs(a[m] - want).max() <= 2e-6 * abs(want) and np.abs(b[m] - want).max() <= 2e-6 * abs(want)
+        assert not a[~m].any()
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_fullsize_projection_is_divergence_free(scene, precision):
+    """After _project the weighted divergence of every pressure cell equals the PCG residual of the pressure solve
+    (pressuresolver.cpp:227-243 defines b = -div; fluidsimulation.cpp:611-657 subtracts the gradient the matrix encodes)."""
+    dx, solid, P = scene
+    c = ctx(scene, precision=precision, pressure_rel_tolerance=1e-6 if precision == 0 else 0.0)
+    st = c.substep(0.01)
+    assert st["pressure"]["status"] == 0
+    # the reference accepts the capped, unconverged viscosity solve when the residual is below 10 (viscositysolver.cpp:676-689)
+    assert st["viscosity"]["iterations"] == 700 and st["viscosity"]["status"] == 1 and st["viscosity"]["residual"] < 10.0
+    U, V, W = (c.grid(n).astype(np.float64) for n in "UVW")
+    wU, wV, wW = (c.grid("WEIGHT_" + n).astype(np.float64) for n in "UVW")
+    phi = c.grid("LIQUID_PHI")
+    div = ((wU * U)[:, :, 1:] - (wU * U)[:, :, :-1] + (wV * V)[:, 1:, :] - (wV * V)[:, :-1, :] + (wW * W)[1:, :, :] - (wW * W)[:-1, :, :]) / dx
+    cells = np.zeros_like(phi, bool)
+    cells[1:-1, 1:-1, 1:-1] = phi[1:-1, 1:-1, 1:-1] < 0               # pressure cells (pressuresolver.cpp:196-225)
+    open_ = (wU[:, :, 1:] + wU[:, :, :-1] + wV[:, 1:, :] + wV[:, :-1, :] + wW[1:, :, :] + wW[:-1, :, :]) > 0
+    cells &= open_
+    assert cells.sum() == st["pressure"]["rows"]
+    tol = max(1e-9, (1e-6 if precision == 0 else 0.0) * st["pressure"]["rhs_norm"])
+    assert st["pressure"]["residual"] <= tol
+    # fp32 velocities: the update u -= dt grad p / (dx theta) rounds each face to 1 ulp of |u| ~ 0.1
+    slack = 2e-8 / dx * 6 if precision == 0 else 0.0
+    slack += 2e-8 / dx * 6   # the grids are stored in fp32 in both modes
+    assert np.abs(div[cells]).max() <= st["pressure"]["residual"] * 1.01 + slack, (np.abs(div[cells]).max(), st["pressure"])
+    c.close()
+
+
+def test_fullsize_precisions_agree_on_pressure_only_step(scene):
+    """viscosity off (fluidsimulation.cpp:171-184): everything converges, so fp32 and fp64 vectors must give the same
+    velocities to the north_star tolerance at full size"""
+    from flipviscosity3d_amd import capi
+    dx, solid, P = scene
+    res = []
+    for precision in (0, 1):
+        c = capi.Context(N, N, N, dx)
+        c.set_solid_sdf(solid)
+        c.set_viscosity(0.0)
+        c.set_params(precision=precision, pressure_rel_tolerance=1e-7 if precision == 0 else 0.0)
+        Q = P.copy()
+        Q[:, 3] = 0.3 * np.sin(6.0 * Q[:, 1])                        # a shear so that the projection has work to do
+        c.particles = Q
+        for t in range(2):
+            st = c.substep(0.01)
+            assert st["viscosity"]["status"] == 3 and st["pressure"]["status"] == 0
+        res.append([c.grid(n) for n in "UVW"])
+        c.close()
+    scale = max(np.abs(g).max() for g in res[1])
+    assert max(np.abs(a - b).max() for a, b in zip(*res)) <= 1e-4 * scale

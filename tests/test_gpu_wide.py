@@ -1,0 +1,66 @@
+"""Parity on a domain wider than one solver tile (256 indices in i): the liquid spans the tile boundary, so the
+wave-edge exchange of the SpMV kernels (lane 0 / lane 63 fetch their i-neighbour from memory) and the tile lists with
+more than one tile per row are exercised against the oracle.  The cubic fixtures are all narrower than a tile."""
+import numpy as np
+import pytest
+
+from helpers import rel_maxnorm3
+
+pytestmark = pytest.mark.gpu
+
+
+def box_mesh(lo, hi):
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    v = np.array([[x0, y0, z0], [x1, y0, z0], [x1, y0, z1], [x0, y0, z1], [x0, y1, z0], [x1, y1, z0], [x1, y1, z1], [x0, y1, z1]], np.float32)
+    t = np.array([[0, 1, 2], [0, 2, 3], [4, 7, 6], [4, 6, 5], [0, 3, 7], [0, 7, 4], [1, 5, 6], [1, 6, 2], [0, 4, 5], [0, 5, 1], [3, 2, 6], [3, 6, 7]], np.int32)
+    return v, t
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_wide_domain_substeps_match_oracle(oracle, precision):
+    from flipviscosity3d_amd import capi, hostapi as H
+    I, J, K = 288, 20, 24
+    dx = float(np.float32(1.0 / I))
+    s = H.FluidSimulation()
+    s.initialize(I, J, K, dx)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 11)
+    s.addLiquid(box_mesh((0.2, 3.2 * dx, 4.3 * dx), (0.955, 13.1 * dx, 19.6 * dx)))   # i = 57 .. 275: across i = 256
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    x = P[:, 0]
+    P[:, 3] = 0.4 * np.sin(4 * np.pi * x)
+    P[:, 4] = 0.12 * np.cos(6 * np.pi * x)
+    P[:, 5] = 0.08 * np.sin(2 * np.pi * x)
+    assert len(P) > 100000 and x.min() < 0.25 and x.max() > 0.93
+    nu, dt = 2.0, 0.005
+    c = capi.Context(I, J, K, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(nu)
+    c.set_params(precision=precision, viscosity_max_iterations=20000, viscosity_tolerance=1e-7,
+                 pressure_rel_tolerance=1e-7 if precision == 0 else 0.0)
+    c.particles = P
+    o = oracle.OracleSim(I, J, K, dx)
+    o.set_solid(solid)
+    o.set_viscosity(nu)
+    o.set_solver_limits(vmaxiter=20000)
+    o.particles = P
+    for t in range(3):
+        # every substep starts from the oracle's particles: a 1e-6 difference in a position can flip a discrete decision
+        # (a cell centre entering the liquid, a face losing its last particle) and the two runs then differ locally by
+        # 1e-3 one substep later -- sensitivity of the method, not of the kernels (measured: chained 1.9e-3, this way 1e-5)
+        c.particles = o.particles
+        st = c.substep(dt)
+        sec, vi, pi = o.substep(dt)
+        assert st["viscosity"]["status"] == 0 and vi["status"] == 0
+        assert st["viscosity"]["rows"] == vi["rows"]
+        # the tile lists really have more than one tile per row
+        assert st["viscosity"]["total_tiles"] >= 2 * ((J + 1 + 3) // 4) * (K + 1)
+        got = [c.grid(n) for n in "UVW"]
+        ref = [o.grid(n) for n in "UVW"]
+        assert np.abs(ref[0][:, :, 250:265]).max() > 0        # liquid on both sides of the tile boundary
+        assert rel_maxnorm3(got, ref) <= 1e-4, (t, rel_maxnorm3(got, ref), st["viscosity"], vi)
+        assert np.array_equal(c.grid("LIQUID_PHI"), o.grid("LIQUID_PHI"))
+        assert np.abs(c.particles[:, :3] - o.particles[:, :3]).max() <= 2e-7
+    c.close()
+    o.close()
