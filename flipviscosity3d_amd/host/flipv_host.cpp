@@ -90,6 +90,9 @@ void flipvh_get_solid_sdf(flipvh_sim *s, float *nodes) {
     s->sim.getGridDimensions(&I, &J, &K);
     std::memcpy(nodes, s->sim.solidSDF().getRawArray(), (size_t)(I + 1) * (J + 1) * (K + 1) * sizeof(float));
 }
+void flipvh_get_dims(flipvh_sim *s, int *ijk) { s->sim.getGridDimensions(&ijk[0], &ijk[1], &ijk[2]); }
+int flipvh_save_state(flipvh_sim *s, const char *path) { return s->sim.saveState(path) ? 0 : -1; }
+int flipvh_load_state(flipvh_sim *s, const char *path) { return s->sim.loadState(path) ? 0 : -1; }
 int flipvh_advance(flipvh_sim *s, float dt, flipv_stats *stats) {
     s->sim.advance(dt);
     if (stats) *stats = s->sim.lastStats();

@@ -27,6 +27,9 @@ size_t flipvh_num_particles(flipvh_sim *s);
 void flipvh_get_particles(flipvh_sim *s, float *aos6);
 void flipvh_set_particles(flipvh_sim *s, const float *aos6, size_t n);
 void flipvh_get_solid_sdf(flipvh_sim *s, float *nodes);                   /* (I+1)(J+1)(K+1) */
+void flipvh_get_dims(flipvh_sim *s, int *ijk3);
+int flipvh_save_state(flipvh_sim *s, const char *path);                    /* FluidSimulation::saveState: 0 ok */
+int flipvh_load_state(flipvh_sim *s, const char *path);                    /* FluidSimulation::loadState: 0 ok */
 int flipvh_advance(flipvh_sim *s, float dt, flipv_stats *stats);          /* FluidSimulation::advance; needs a GPU */
 flipv_context *flipvh_context(flipvh_sim *s);                             /* the underlying C-ABI context; needs a GPU */
 

@@ -211,6 +211,62 @@ void FluidSimulation::addLiquid(TriangleMesh &mesh) {  // reference fluidsimulat
             }
 }
 
+// ---- checkpoint file: "FLIPVCK1", int32 I,J,K, float dx, float gravity[3], int32 viscosity kind (0 uniform, 1 grid),
+// float uniform viscosity, uint64 particle count, then solid SDF nodes, [viscosity nodes], particles (6 floats each)
+bool FluidSimulation::saveState(const std::string &path) {
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const MeshLevelSet &sdf = solidSDF();
+    const size_t nodes = (size_t)(_isize + 1) * (_jsize + 1) * (_ksize + 1);
+    const int dims[3] = {_isize, _jsize, _ksize};
+    const float g[3] = {_gravity.x, _gravity.y, _gravity.z};
+    const int kind = _viscosityGrid.empty() ? 0 : 1;
+    const unsigned long long np = particles.size();
+    bool ok = std::fwrite("FLIPVCK1", 1, 8, f) == 8 && std::fwrite(dims, sizeof(int), 3, f) == 3 && std::fwrite(&_dx, sizeof(float), 1, f) == 1 &&
+              std::fwrite(g, sizeof(float), 3, f) == 3 && std::fwrite(&kind, sizeof(int), 1, f) == 1 &&
+              std::fwrite(&_viscosityUniform, sizeof(float), 1, f) == 1 && std::fwrite(&np, sizeof(np), 1, f) == 1;
+    ok = ok && std::fwrite(sdf.getRawArray(), sizeof(float), nodes, f) == nodes;
+    if (kind) ok = ok && std::fwrite(_viscosityGrid.data(), sizeof(float), nodes, f) == nodes;
+    if (np) ok = ok && std::fwrite(&particles[0].position.x, sizeof(FluidParticle), (size_t)np, f) == (size_t)np;
+    return std::fclose(f) == 0 && ok;
+}
+
+bool FluidSimulation::loadState(const std::string &path) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[8];
+    int dims[3], kind = 0;
+    float dx = 0, g[3], nu = 0;
+    unsigned long long np = 0;
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "FLIPVCK1", 8) == 0 && std::fread(dims, sizeof(int), 3, f) == 3 &&
+              std::fread(&dx, sizeof(float), 1, f) == 1 && std::fread(g, sizeof(float), 3, f) == 3 && std::fread(&kind, sizeof(int), 1, f) == 1 &&
+              std::fread(&nu, sizeof(float), 1, f) == 1 && std::fread(&np, sizeof(np), 1, f) == 1;
+    ok = ok && dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dx > 0 && (kind == 0 || kind == 1) && nu >= 0;
+    if (!ok) { std::fclose(f); return false; }
+    const size_t nodes = (size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1);
+    std::vector<float> solid(nodes), visc(kind ? nodes : 0);
+    std::vector<FluidParticle> parts((size_t)np);
+    ok = std::fread(solid.data(), sizeof(float), nodes, f) == nodes;
+    if (kind) ok = ok && std::fread(visc.data(), sizeof(float), nodes, f) == nodes;
+    if (np) ok = ok && std::fread(&parts[0].position.x, sizeof(FluidParticle), (size_t)np, f) == (size_t)np;
+    std::fclose(f);
+    if (!ok) return false;
+    const bool dev = _setupOnDevice;
+    _setupOnDevice = false;  // the solid SDF comes from the file, no boundary to build
+    _destroy();
+    _isize = dims[0]; _jsize = dims[1]; _ksize = dims[2]; _dx = dx;
+    _solidSDF = MeshLevelSet(_isize, _jsize, _ksize, _dx);
+    std::memcpy(_solidSDF.getRawArray(), solid.data(), nodes * sizeof(float));
+    _solidHostStale = false;
+    _viscosityUniform = nu;
+    _viscosityGrid.swap(visc);
+    _gravity = vmath::vec3(g[0], g[1], g[2]);
+    particles.swap(parts);
+    _solidDirty = _viscosityDirty = _gravityDirty = true;
+    _setupOnDevice = dev;
+    return true;
+}
+
 void FluidSimulation::setViscosity(float value) {  // reference fluidsimulation.cpp:99-108
     FLIPV_HOST_ASSERT(value >= 0.0);
     _viscosityUniform = value;

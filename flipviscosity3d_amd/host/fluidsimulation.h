@@ -6,6 +6,7 @@
 // (reference main.cpp:42-90) -- compiles and runs unchanged against this header.  Setup-time geometry
 // (mesh level sets, seeding) is host C++; every per-substep phase runs on the GPU through the C-ABI.
 #pragma once
+#include <string>
 #include <vector>
 
 #include "../../include/flipv.h"
@@ -58,6 +59,12 @@ public:
     // (libc rand() has no device counterpart); band values, signs and the seeded particles are identical to the host
     // path, far-field distances of the solid SDF are the relaxed ones (include/flipv.h).
     void setSetupOnDevice(bool on) { _setupOnDevice = on; }
+    // Checkpoint (the reference cannot stop and resume a run): grid size, cell width, gravity, viscosity,
+    // solid SDF and the particles (positions + velocities) in one little-endian binary file.  loadState() re-initialises
+    // the simulation from the file; a run resumed from a checkpoint continues exactly like the uninterrupted one
+    // (the substep has no other state).  Both return false on I/O or format errors.
+    bool saveState(const std::string &path);
+    bool loadState(const std::string &path);
     void setQuiet(bool q) { _quiet = q; }                  // the reference prints phase banners on stdout
     const flipv_stats &lastStats() const { return _stats; }
     flipv_context *context() { _ensureContext(); return _ctx; }   // created lazily: setup needs no GPU, advance() does

@@ -18,7 +18,7 @@ from . import capi
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libflipv_host.so")
-SYMBOLS = ["flipvh_create", "flipvh_create_ex", "flipvh_destroy", "flipvh_add_boundary", "flipvh_reset_boundary", "flipvh_set_seeding",
+SYMBOLS = ["flipvh_create", "flipvh_create_ex", "flipvh_save_state", "flipvh_load_state", "flipvh_get_dims", "flipvh_destroy", "flipvh_add_boundary", "flipvh_reset_boundary", "flipvh_set_seeding",
            "flipvh_add_liquid", "flipvh_set_viscosity", "flipvh_set_viscosity_grid", "flipvh_set_gravity",
            "flipvh_num_particles", "flipvh_get_particles", "flipvh_set_particles", "flipvh_get_solid_sdf",
            "flipvh_advance", "flipvh_context", "flipvh_mesh_sdf", "flipvh_load_ply"]
@@ -55,6 +55,9 @@ def load():
     L.flipvh_set_particles.argtypes = [h, fp, C.c_size_t]
     L.flipvh_get_solid_sdf.argtypes = [h, fp]
     L.flipvh_advance.argtypes = [h, C.c_float, C.POINTER(capi.Stats)]
+    L.flipvh_save_state.argtypes = [h, C.c_char_p]
+    L.flipvh_load_state.argtypes = [h, C.c_char_p]
+    L.flipvh_get_dims.argtypes = [h, C.POINTER(C.c_int)]
     L.flipvh_context.restype = h
     L.flipvh_context.argtypes = [h]
     L.flipvh_mesh_sdf.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, fp, C.c_int, ip, C.c_int, C.c_int, fp, ip]
@@ -169,6 +172,17 @@ class FluidSimulation:
         a = np.empty((self.K + 1, self.J + 1, self.I + 1), np.float32)
         self.L.flipvh_get_solid_sdf(self.h, a.ctypes.data_as(fp))
         return a
+
+    def saveState(self, path):
+        if self.L.flipvh_save_state(self.h, str(path).encode()) != 0:
+            raise IOError("saveState: cannot write %s" % path)
+
+    def loadState(self, path):
+        if self.L.flipvh_load_state(self.h, str(path).encode()) != 0:
+            raise IOError("loadState: cannot read %s" % path)
+        d = (C.c_int * 3)()
+        self.L.flipvh_get_dims(self.h, d)
+        self.I, self.J, self.K = d[0], d[1], d[2]
 
     def advance(self, dt):
         st = capi.Stats()

@@ -121,3 +121,34 @@ def test_mesh_level_set_bit_exact_vs_reference(mesh, N):
     a, ac = H.mesh_sdf(N, N // 2 + 5, N - 7, dx, (m[0] * np.float32(0.45), m[1]), 2)
     b, bc = R.mesh_sdf(N, N // 2 + 5, N - 7, dx, m[0] * np.float32(0.45), m[1], 2)
     assert np.array_equal(a, b) and np.array_equal(ac, bc)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """saveState / loadState: the file restores grid size, solid SDF, viscosity and particles exactly"""
+    from flipviscosity3d_amd import hostapi as H
+    N = 20
+    dx = float(np.float32(1.0 / N))
+    s = H.FluidSimulation()
+    s.initialize(N, N, N, dx)
+    s.addBoundary(H.load_ply(os.path.join(MESH, "sphere_large.ply")), True)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 5)
+    s.addLiquid(H.load_ply(os.path.join(MESH, "stanford_bunny.ply")))
+    P = s.particles
+    P[:, 3:] = np.random.default_rng(0).uniform(-1, 1, (len(P), 3)).astype(np.float32)
+    s.particles = P
+    solid = s.solid_sdf()
+    path = str(tmp_path / "state.flipv")
+    s.saveState(path)
+    s.close()
+    r = H.FluidSimulation()
+    r.initialize(8, 8, 8, 0.125)         # different size on purpose: loadState re-initialises
+    r.loadState(path)
+    assert (r.I, r.J, r.K) == (N, N, N)
+    assert np.array_equal(r.solid_sdf(), solid) and np.array_equal(r.particles, P)
+    with pytest.raises(IOError):
+        r.loadState(str(tmp_path / "missing.flipv"))
+    with open(path, "r+b") as f:
+        f.write(b"XXXXXXXX")
+    with pytest.raises(IOError):
+        r.loadState(path)
+    r.close()
