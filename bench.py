@@ -288,7 +288,8 @@ def dense_roofline(N, precision, reps=50):
     vi = c.viscosity_solve(0.01)
     pi = c.pressure_solve(0.01)
     out = {"workload": "filled %d^3 box, every interior cell liquid" % N, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "device_copy_GBs": c.bench_copy(1 << 30, 10)}
+           "device_copy_GBs": c.bench_copy(1 << 30, 10),
+           "attainable_GBs": {"read": c.bench_stream(0), "copy": c.bench_stream(1), "write": c.bench_stream(2)}}
     for which, name, b, units in ((0, "pressure_spmv", PRES_SPMV_BYTES_PER_CELL, float(pi["rows"])),
                                   (1, "viscosity_spmv", VISC_SPMV_BYTES_PER_INDEX, vi["rows"] / 3.0)):
         ms, swept = c.bench_spmv(which, reps)

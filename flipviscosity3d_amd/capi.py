@@ -30,7 +30,7 @@ SYMBOLS = [
     "flipv_pressure_solve", "flipv_apply_pressure", "flipv_constrain", "flipv_update_particle_velocities",
     "flipv_advect_particles", "flipv_read_viscosity_volume", "flipv_substep", "flipv_advance",
     "flipv_kernel_stats_reset", "flipv_kernel_stats_get", "flipv_synchronize", "flipv_bench_spmv",
-    "flipv_bench_copy",
+    "flipv_bench_copy", "flipv_bench_stream",
     "flipv_mesh_level_set", "flipv_add_boundary_mesh", "flipv_reset_boundary", "flipv_add_liquid_mesh",
     "flipv_comm_unique_id_bytes", "flipv_comm_get_unique_id", "flipv_comm_init_rccl", "flipv_comm_init_local",
     "flipv_comm_finalize",
@@ -137,6 +137,7 @@ def load():
     L.flipv_kernel_stats_get.argtypes = [ctx, C.POINTER(KernelStats)]
     L.flipv_bench_spmv.argtypes = [ctx, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.flipv_bench_copy.argtypes = [ctx, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    L.flipv_bench_stream.argtypes = [ctx, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -391,6 +392,12 @@ class Context:
         self._chk(self.L.flipv_bench_spmv(self.h, 0 if which in (0, "pressure") else 1, reps, C.byref(ms),
                                           C.byref(cells)), "flipv_bench_spmv")
         return ms.value, cells.value
+
+    def bench_stream(self, mode, nbytes=1 << 30, reps=10):
+        """plain streaming kernel: mode 0 read-only, 1 copy, 2 write-only -> GB/s of bytes moved"""
+        g = C.c_double()
+        self._chk(self.L.flipv_bench_stream(self.h, C.c_size_t(nbytes), reps, mode, C.byref(g)), "flipv_bench_stream")
+        return g.value
 
     def bench_copy(self, nbytes=1 << 30, reps=10):
         g = C.c_double()

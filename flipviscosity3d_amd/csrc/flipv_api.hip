@@ -702,6 +702,48 @@ extern "C" int flipv_bench_copy(flipv_context *c, size_t bytes, int reps, double
     return FLIPV_OK;
 }
 
+// Attainable HBM rates with plain streaming kernels ("measure the attainable peak ... and quote both"):
+// mode 0 = read-only (sum of 16-byte loads), 1 = copy (16-byte loads + stores), 2 = write-only.  GB/s counts the bytes moved.
+__global__ __launch_bounds__(256) void k_stream(const float4 *__restrict__ a, float4 *__restrict__ b, size_t n, int mode, float *__restrict__ sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float acc = 0.0f;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        if (mode == 2) { b[t] = make_float4(1.0f, 2.0f, 3.0f, 4.0f); continue; }
+        const float4 v = a[t];
+        if (mode == 1) b[t] = v;
+        else acc += v.x + v.y + v.z + v.w;
+    }
+    if (mode == 0 && acc == 123.456f) *sink = acc;  // keeps the loads alive
+}
+extern "C" int flipv_bench_stream(flipv_context *c, size_t bytes, int reps, int mode, double *gbps_out) {
+    ENTER(c);
+    if (!gbps_out || reps < 1 || bytes < 4096 || mode < 0 || mode > 2) return FLIPV_ERR_INVALID;
+    void *a = nullptr, *b = nullptr;
+    HIPCHK(c, hipMalloc(&a, bytes));
+    if (hipMalloc(&b, bytes + 64) != hipSuccess) { (void)hipFree(a); c->err = "flipv_bench_stream: out of memory"; return FLIPV_ERR_OOM; }
+    (void)hipMemsetAsync(a, 0, bytes, c->stream);
+    (void)hipMemsetAsync(b, 0, bytes + 64, c->stream);
+    const size_t n = bytes / 16;
+    const unsigned grid = 256 * 8 * 4;  // 32 blocks per CU
+    float *sink = (float *)((char *)b + bytes);
+    hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n, mode, sink);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n, mode, sink);
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    *gbps_out = (mode == 1 ? 2.0 : 1.0) * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    return FLIPV_OK;
+}
+
 // debug only (not part of the ABI): fold the slot-spread PCG scalars of the LAST solve on the host.
 // out = 5 arrays of n doubles: sig, a, b, c, rmax.
 #include "pcg_common.h"

@@ -209,6 +209,8 @@ int flipv_synchronize(flipv_context *ctx);
 int flipv_bench_spmv(flipv_context *ctx, int which, int reps, double *ms_out, double *cells_out);
 /* device-to-device copy bandwidth (attainable HBM peak): bytes moved (read+write) per second */
 int flipv_bench_copy(flipv_context *ctx, size_t bytes, int reps, double *gbps_out);
+/* plain streaming kernels on `bytes` of device memory: mode 0 read-only, 1 copy, 2 write-only; GB/s of bytes moved */
+int flipv_bench_stream(flipv_context *ctx, size_t bytes, int reps, int mode, double *gbps_out);
 
 /* ---- multi-GPU: communicator of a slab decomposition (one context per rank) ----
  * RCCL backend: rank 0 calls flipv_comm_get_unique_id (ncclGetUniqueId), the host broadcasts the 128 bytes
