@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
         if ((threadIdx.x & 63) == 0) { sl = esl; cil = ecil; }
         if ((threadIdx.x & 63) == 63) sr = esr;
         Vec<T, 4> y;
+        T ta = (T)0, tb = (T)0, tc = (T)0;  // this lane's four cells in the vector precision, folded into fp64 once per tile
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const T sm = e > 0 ? sc4.v[e - 1] : sl;
@@ -153,12 +154,13 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
             acc += sc4.v[e] * (T)dg.v[e];
             y.v[e] = acc;
             if (dg.v[e] != 0.0f) {
-                const double yd = (double)acc, inv = (double)__builtin_amdgcn_rcpf(dg.v[e]);
-                da += (double)sc4.v[e] * yd;
-                db += (double)r4.v[e] * inv * yd;
-                dc += yd * inv * yd;
+                const T yi = acc * d_recip<T>(dg.v[e]);
+                ta += sc4.v[e] * acc;
+                tb += (T)r4.v[e] * yi;
+                tc += acc * yi;
             }
         }
+        da += (double)ta; db += (double)tb; dc += (double)tc;
         if (mine) stv(q + c, y);
       }
     }

@@ -69,6 +69,11 @@ __device__ __forceinline__ void stv(double *__restrict__ p, const Vec<double, 2>
     *reinterpret_cast<double2 *>(p) = make_double2(r.v[0], r.v[1]);
 }
 
+// 1/d for the preconditioned dot products: hardware reciprocal (1 ulp) with fp32 vectors, a division with fp64 vectors
+template <typename T> __device__ __forceinline__ T d_recip(float d);
+template <> __device__ __forceinline__ float d_recip<float>(float d) { return __builtin_amdgcn_rcpf(d); }
+template <> __device__ __forceinline__ double d_recip<double>(float d) { return 1.0 / (double)d; }
+
 // lane i <- lane i-1 / lane i+1 of the wave as a DPP move (wave_shr:1 / wave_shl:1 exist on gfx9-family ISAs, gfx950
 // included): one VALU instruction instead of a ds_bpermute round trip through the LDS pipe.  Lane 0 / lane 63 keep
 // their own value; callers overwrite those lanes with the value fetched from memory.
