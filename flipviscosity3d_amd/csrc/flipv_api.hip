@@ -58,7 +58,7 @@ extern "C" int flipv_default_params(flipv_params *p) {
     p->viscosity_accept_tolerance = 10.0;
     p->precision = FLIPV_PRECISION_FP32;
     p->kernel_timing = 0;
-    p->check_every = 8;
+    p->check_every = 0;
     return FLIPV_OK;
 }
 
@@ -113,6 +113,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->evUsed = 0;
     c->pressureReady = c->viscosityReady = 0;
     c->viscStateValid = 0; c->viscStatePrec = 0;
+    c->solidVersion = 1; c->weightsVersion = 0; c->faceStateVersion = 0;
     c->nActiveP = c->nActiveV = 0;
     c->vwV = 2;
     c->viscosity_nonzero = 1;
@@ -344,6 +345,8 @@ extern "C" int flipv_write_grid(flipv_context *c, int which, const float *in) {
     ENTER(c);
     GridRef g;
     if (!in || !grid_ref(c, which, &g)) { c->err = "flipv_write_grid: bad grid id"; return FLIPV_ERR_INVALID; }
+    if (which == FLIPV_GRID_SOLID_PHI) c->solidVersion++;
+    if (which == FLIPV_GRID_WEIGHT_U || which == FLIPV_GRID_WEIGHT_V || which == FLIPV_GRID_WEIGHT_W) c->weightsVersion = -1;
     if (which == FLIPV_GRID_VISCOSITY) {
         const size_t n = lat_count(c->L, g.lat);
         int nz = 0;
@@ -431,6 +434,7 @@ extern "C" int flipv_add_boundary_mesh(flipv_context *c, const float *vertices, 
     if ((rc = fv_mesh_level_set(c, vertices, nvertices, triangles, ntriangles, 3, phi.p, nullptr))) return rc;  // _meshLevelSetExactBand (fluidsimulation.h:121)
     if (inverted && (rc = fv_mesh_negate(c, phi.p))) return rc;
     rc = fv_mesh_union(c, c->solid, phi.p);
+    c->solidVersion++;
     SYNC_RET(c, rc);
 }
 
@@ -449,6 +453,7 @@ extern "C" int flipv_reset_boundary(flipv_context *c) {  // _initializeBoundary 
     int rc = fv_mesh_level_set(c, verts, 8, tris, 12, 3, c->solid, nullptr);
     if (rc) return rc;
     rc = fv_mesh_negate(c, c->solid);
+    c->solidVersion++;
     SYNC_RET(c, rc);
 }
 
@@ -556,7 +561,12 @@ static int substep(flipv_context *c, float dt, flipv_stats *st) {
     if ((rc = fv_viscosity_solve(c, dt, &vi)) < 0) return rc;
     if (rc > warn) warn = rc;
     MARK(4);
-    if ((rc = fv_compute_weights(c)) < 0) return rc;
+    // the face weights depend on the solid SDF only: the reference recomputes them every substep (fluidsimulation.cpp:585),
+    // here they are kept until the solid SDF (or, through flipv_write_grid, a weight grid) changes
+    if (c->weightsVersion != c->solidVersion) {
+        if ((rc = fv_compute_weights(c)) < 0) return rc;
+        c->weightsVersion = c->solidVersion;
+    }
     if ((rc = fv_pressure_solve(c, dt, &pi)) < 0) return rc;
     if (rc > warn) warn = rc;
     if ((rc = fv_apply_pressure(c, dt)) < 0) return rc;

@@ -148,6 +148,7 @@ struct flipv_context {
 
     float lastDt;
     int pressureReady, viscosityReady;
+    int solidVersion, weightsVersion, faceStateVersion;  // products of the solid SDF (weights; solid phi at cell centres + face states) are reused while it is unchanged
     int viscStateValid, viscStatePrec;  // k_visc_setup's off-row values are in place for this vector precision
     int pressurePrec, viscosityPrec;
 };

@@ -606,8 +606,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // (inputs: phi with a 4-plane halo, the replicated solid SDF), so the setup needs no exchange of its own.
     const Lay R0 = fv_range(c, 0), R1 = fv_range(c, 1), R2 = fv_range(c, 2), R3 = fv_range(c, 3);
     // face states
-    hipLaunchKernelGGL(k_solid_center, GRID3(R2), 0, c->stream, R2, c->solid, c->scp);
-    hipLaunchKernelGGL(k_face_states, GRID3(R1), 0, c->stream, R1, c->scp, c->stU, c->stV, c->stW);
+    if (c->faceStateVersion != c->solidVersion) {  // functions of the solid SDF only
+        hipLaunchKernelGGL(k_solid_center, GRID3(R2), 0, c->stream, R2, c->solid, c->scp);
+        hipLaunchKernelGGL(k_face_states, GRID3(R1), 0, c->stream, R1, c->scp, c->stU, c->stV, c->stW);
+        c->faceStateVersion = c->solidVersion;
+    }
     // band mask + the seven volume lattices (viscositysolver.cpp:135-178)
     hipLaunchKernelGGL(k_valid_init, GRID3(R3), 0, c->stream, R3, c->phi, c->validCells);
     hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validCells, c->validTmp);

@@ -449,7 +449,9 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
 template <class Spmv, class Update>
 static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray *sh, int nsh, int nInt, int nAct, Spmv spmv,
                    Update update, int *conv_out) {
-    const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
+    // poll interval: an iteration after the stop costs two empty launches (~6 us) on one GPU but a halo exchange and an
+    // all-reduce in a multi-rank run; a poll costs a read-back and a host wake-up (~14 us)
+    const int every = c->prm.check_every > 0 ? c->prm.check_every : (c->comm ? 8 : 32);
     int conv = -1, rc;
     auto launch_iter = [&](int it) -> int {
         int r;

@@ -79,7 +79,7 @@ typedef struct flipv_params {
     double viscosity_accept_tolerance; /* 10.0 (viscositysolver.h:201) */
     int precision;               /* enum flipv_precision */
     int kernel_timing;           /* 1 => bracket every SpMV launch with HIP events (flipv_kernel_stats) */
-    int check_every;             /* convergence poll interval in iterations (default 8) */
+    int check_every;             /* convergence poll interval in iterations; 0 (default) = 32 on one GPU, 8 with a communicator */
     int reserved[8];             /* measurement switches, all 0 by default: [0]=1 no hipGraph replay of the PCG loop;
                                     [1]=1 un-binned particle scatters (global atomics instead of LDS tiles);
                                     [2]=n>0 caps the PCG kernels' grids at n blocks (tests: every block walks many tiles);
