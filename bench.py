@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--viscosity", type=float, default=5.0)
-    ap.add_argument("--cpu-size", type=int, default=96, help="grid size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-size", type=int, default=128, help="grid size of the bounded CPU-baseline sample (128: ~15-20 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the filled-box SpMV roofline measurement")
     ap.add_argument("--gpu-setup", action="store_true", help="build the scene with the device setup kernels (for sizes where the host path takes minutes)")
