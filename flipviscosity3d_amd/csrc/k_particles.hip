@@ -249,6 +249,33 @@ __global__ __launch_bounds__(256) void k_sdf_tiles(BinGrid B, Lay L, const float
 // (cells -2..+1 around the tile: the half-cell shift of the transverse axes moves the stencil centre down by one) live in
 // LDS; the particles of the tile are accumulated with ds_add_f32, then every touched node is added to the global
 // accumulators once.
+// one component of one particle with global atomics: the un-binned scatter's inner loops (fluidsimulation.cpp:384-417),
+// used by the tile kernel for the (never expected) particle whose stencil leaves its tile's LDS box
+__device__ __noinline__ void d_p2g_global(Lay L, int dir, float px, float py, float pz, float vel, double dxd, double invdx,
+                                          float *__restrict__ acc, float *__restrict__ wgt, float rsq, float coef1, float coef2,
+                                          float coef3) {
+    const int w = L.I + (dir == 0), h = L.J + (dir == 1), d = L.K + (dir == 2);
+    const int gi = d_pos_index(px, invdx), gj = d_pos_index(py, invdx), gk = d_pos_index(pz, invdx);
+    const int i0 = max(gi - 1, 0), j0 = max(gj - 1, 0), k0 = max(gk - 1, 0);
+    const int i1 = min(gi + 1, w - 1), j1 = min(gj + 1, h - 1), k1 = min(gk + 1, d - 1);
+    for (int k = k0; k <= k1; k++) {
+        const float vz = (float)(k * dxd) - pz;
+        for (int j = j0; j <= j1; j++) {
+            const float vy = (float)(j * dxd) - py;
+            for (int i = i0; i <= i1; i++) {
+                const float vx = (float)(i * dxd) - px;
+                const float q = vx * vx + vy * vy + vz * vz;
+                if (q < rsq) {
+                    const float weight = 1.0f - coef1 * q * q * q + coef2 * q * q - coef3 * q;
+                    const size_t f = gidx(L, i, j, k);
+                    atomicAdd(&acc[f], weight * vel);
+                    atomicAdd(&wgt[f], weight);
+                }
+            }
+        }
+    }
+}
+
 constexpr int P2G_R = BIN_T + 3;
 constexpr int P2G_RN = P2G_R * P2G_R * P2G_R;
 __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float *__restrict__ aos6,
@@ -289,40 +316,44 @@ __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float
                 const int i0 = max(gi - 1, 0), j0 = max(gj - 1, 0), k0 = max(gk - 1, 0);
                 const int i1 = min(gi + 1, w - 1), j1 = min(gj + 1, h - 1), k1 = min(gk + 1, d - 1);
                 float *sv = sh + (2 * dir) * P2G_RN, *sw = sv + P2G_RN;
-                // per-axis offsets once (the fp64 index->position products of the reference), then 27 fp32 combinations
-                float ox[3], oy[3], oz[3];
+                // per-axis offsets once (the fp64 index->position products of the reference), then 27 fp32 combinations;
+                // q = (ox^2 + oy^2) + oz^2 in the reference's order, rows of the stencil that cannot reach the kernel radius
+                // are skipped as a whole (squares are non-negative: ox^2 + oy^2 >= oy^2)
+                float ox2[3], oy2[3], oz2[3];
 #pragma unroll
                 for (int t = 0; t < 3; t++) {
-                    ox[t] = (float)((gi - 1 + t) * dxd) - px;
-                    oy[t] = (float)((gj - 1 + t) * dxd) - py;
-                    oz[t] = (float)((gk - 1 + t) * dxd) - pz;
+                    const float ax = (float)((gi - 1 + t) * dxd) - px, ay = (float)((gj - 1 + t) * dxd) - py, az = (float)((gk - 1 + t) * dxd) - pz;
+                    ox2[t] = ax * ax; oy2[t] = ay * ay; oz2[t] = az * az;
+                }
+                const int lbase = (gi - 1 - bi) + P2G_R * ((gj - 1 - bj) + P2G_R * (gk - 1 - bk));
+                const bool inbox = (unsigned)(gi - 1 - bi) <= (unsigned)(P2G_R - 3) && (unsigned)(gj - 1 - bj) <= (unsigned)(P2G_R - 3) &&
+                                   (unsigned)(gk - 1 - bk) <= (unsigned)(P2G_R - 3);  // the whole 3x3x3 stencil lies in the tile's LDS box
+                if (!inbox) {  // particle outside its clamped tile (never for particles inside the domain): global atomics
+                    d_p2g_global(L, dir, px, py, pz, vel, dxd, invdx, gacc[2 * dir], gacc[2 * dir + 1], rsq, coef1, coef2, coef3);
+                    continue;
+                }
+                // per-axis validity of the three stencil offsets (the stencil is clamped to the lattice, :395-401)
+                bool vi[3], vj[3], vk[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    vi[t] = gi - 1 + t >= i0 && gi - 1 + t <= i1;
+                    vj[t] = gj - 1 + t >= j0 && gj - 1 + t <= j1;
+                    vk[t] = gk - 1 + t >= k0 && gk - 1 + t <= k1 && oz2[t] < rsq;
                 }
 #pragma unroll
                 for (int tk = 0; tk < 3; tk++) {
-                    const int k = gk - 1 + tk;
-                    if (k < k0 || k > k1) continue;
+                    if (!vk[tk]) continue;
 #pragma unroll
                     for (int tj = 0; tj < 3; tj++) {
-                        const int j = gj - 1 + tj;
-                        if (j < j0 || j > j1) continue;
-                        const float q2 = oy[tj] * oy[tj];
+                        if (!vj[tj] || !(oy2[tj] + oz2[tk] < rsq)) continue;
 #pragma unroll
                         for (int ti = 0; ti < 3; ti++) {
-                            const int i = gi - 1 + ti;
-                            if (i < i0 || i > i1) continue;
-                            const float qq = ox[ti] * ox[ti] + q2 + oz[tk] * oz[tk];
-                            if (qq < rsq) {
+                            const float qq = ox2[ti] + oy2[tj] + oz2[tk];
+                            if (vi[ti] && qq < rsq) {
                                 const float weight = 1.0f - coef1 * qq * qq * qq + coef2 * qq * qq - coef3 * qq;
-                                const int li = i - bi, lj = j - bj, lk = k - bk;
-                                if ((unsigned)li < (unsigned)P2G_R && (unsigned)lj < (unsigned)P2G_R && (unsigned)lk < (unsigned)P2G_R) {
-                                    const int l = li + P2G_R * (lj + P2G_R * lk);
-                                    atomicAdd(&sv[l], weight * vel);
-                                    atomicAdd(&sw[l], weight);
-                                } else {  // particle outside its clamped tile (never for particles inside the domain)
-                                    const size_t f = gidx(L, i, j, k);
-                                    atomicAdd(&gacc[2 * dir][f], weight * vel);
-                                    atomicAdd(&gacc[2 * dir + 1][f], weight);
-                                }
+                                const int l = lbase + ti + P2G_R * (tj + P2G_R * tk);
+                                atomicAdd(&sv[l], weight * vel);
+                                atomicAdd(&sw[l], weight);
                             }
                         }
                     }
