@@ -613,6 +613,7 @@ extern "C" int flipv_advance(flipv_context *c, float dt, flipv_stats *st) {
         float sub;
         int rc = fv_cfl(c, &sub);
         if (rc < 0) return rc;
+        if (!(sub > 0.0f)) { c->err = "flipv_advance: CFL substep is not positive (non-finite velocities?)"; return FLIPV_ERR_INVALID; }
         if (t + sub > dt) sub = dt - t;
         rc = substep(c, sub, &one);
         if (rc < 0) return rc;
