@@ -326,15 +326,30 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     const int it = it_arg >= 0 ? it_arg : *sc.itB;
     if (it >= sc.cap) return;
     __shared__ double lds[8];
-    // stop test on the residual the previous update left (in a multi-rank run its partial maxima were merged by the
+    // One prologue fetch: rmax(it-1), sig(it), a(it), b(it), c(it) are 5 x NSLOT contiguous doubles (for it = 0 there is no
+    // rmax).  160 threads load one partial each, every 32-lane group folds its scalar with shuffles, ONE barrier.
+    // Stop test on the residual the previous update left (in a multi-rank run its partial maxima were merged by the
     // all-reduce that precedes this launch): every block takes the same decision from the same completed value, one
     // of them records it.  x is not touched again, so the solution is the one after iteration it-1.
-    if (it > 0 && d_pass(sc, d_fold_max(sc.rmax(it - 1), lds))) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it - 1;
-        return;
-    }
     double f[4];
-    d_fold_sums(sc.sig(it), sc.a(it), sc.b(it), sc.c(it), f, lds);
+    {
+        const int tid = d_tid256();
+        const int grp = tid >> 5;  // 0 rmax(it-1), 1 sig, 2 a, 3 b, 4 c
+        double v = 0.0;
+        if (grp < 5 && (it > 0 || grp > 0)) v = (sc.sig(it) - NSLOT)[tid];
+#pragma unroll
+        for (int off = NSLOT / 2; off > 0; off >>= 1) {
+            const double o = __shfl_down(v, off, NSLOT);
+            v = grp == 0 ? fmax(v, o) : v + o;
+        }
+        if (grp < 5 && (tid & (NSLOT - 1)) == 0) lds[grp] = v;
+        __syncthreads();
+        if (it > 0 && d_pass(sc, lds[0])) {
+            if (blockIdx.x == 0 && tid == 0) *sc.conv = it - 1;
+            return;
+        }
+        f[0] = lds[1]; f[1] = lds[2]; f[2] = lds[3]; f[3] = lds[4];
+    }
     const double sg = f[0], a = f[1];
     const double alpha_d = a != 0.0 ? sg / a : 0.0;
     double est = sg - 2.0 * alpha_d * f[2] + alpha_d * alpha_d * f[3];
@@ -395,8 +410,18 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
         }
       }
     }
-    const double tot = block_sum_256(acc, lds);
-    const double bm = block_max_256(fmax((double)mxf, mxd), lds);
+    // sum and max of the block with one barrier pair (lds[5..7] still hold this launch's scalars: use a second array)
+    __shared__ double red[8];
+    double tot = wave_sum(acc), bm = wave_max(fmax((double)mxf, mxd));
+    {
+        const int tid = d_tid256();
+        if ((tid & 63) == 0) { red[tid >> 6] = tot; red[4 + (tid >> 6)] = bm; }
+        __syncthreads();
+        if (tid == 0) {
+            tot = red[0] + red[1] + red[2] + red[3];
+            bm = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+        }
+    }
     if (threadIdx.x == 0 && threadIdx.y == 0) {
         const int sl = sc.my_slot();
         if (tot != 0.0) atomicAdd(sc.sig(it + 1) + sl, tot);
