@@ -516,17 +516,44 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         (void)hipGraphExecDestroy(ge);
         (void)hipGraphDestroy(g);
     } else {
+        // Chunks of `every` iterations, each followed by a read-back of the stop flag into its own pinned slot.  The next
+        // chunk is enqueued BEFORE the host waits for the previous chunk's flag, so the GPU never drains while the host
+        // polls; if that flag says "converged" the chunk already in flight returns launch by launch at once.
+        // (h_flags[8], h_flags[9] are the two slots; evMain/evHalo double as their events on a single GPU, a multi-rank
+        // run needs those for the halo stream and polls synchronously.)
         int it = 0;
-        while (it < cap && conv < 0) {
-            const int stop = (it + every < cap) ? it + every : cap;
-            for (; it < stop; it++)
-                if ((rc = launch_iter(it))) return rc;
-            // the stop is recorded by the update kernel of the NEXT iteration (in a multi-rank run after the all-reduce that
-            // merges the partial maxima), so a solve that converges on a chunk's last iteration is seen one poll later;
-            // a separate check launch per chunk cost more (0.6 ms per substep at 256^3) than that costs once per solve
-            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            conv = c->h_flags[0];
+        if (c->comm) {
+            while (it < cap && conv < 0) {
+                const int stop = (it + every < cap) ? it + every : cap;
+                for (; it < stop; it++)
+                    if ((rc = launch_iter(it))) return rc;
+                // the stop is recorded by the update kernel of the NEXT iteration, after the all-reduce that merges the
+                // partial maxima: a solve that converges on a chunk's last iteration is seen one poll later
+                HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                conv = c->h_flags[0];
+            }
+        } else {
+            hipEvent_t ev[2] = {c->evMain, c->evHalo};
+            int pending = -1;  // slot whose read-back has been enqueued but not yet waited for
+            int slot = 0;
+            while (it < cap && conv < 0) {
+                const int stop = (it + every < cap) ? it + every : cap;
+                for (; it < stop; it++)
+                    if ((rc = launch_iter(it))) return rc;
+                HIPCHK(c, hipMemcpyAsync(c->h_flags + 8 + slot, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipEventRecord(ev[slot], c->stream));
+                if (pending >= 0) {
+                    HIPCHK(c, hipEventSynchronize(ev[pending]));
+                    conv = c->h_flags[8 + pending];
+                }
+                pending = slot;
+                slot ^= 1;
+            }
+            if (conv < 0 && pending >= 0) {
+                HIPCHK(c, hipEventSynchronize(ev[pending]));
+                conv = c->h_flags[8 + pending];
+            }
         }
     }
     {
