@@ -52,7 +52,8 @@ class Params(C.Structure):
 
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("rhs_norm", C.c_double),
-                ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int)]
+                ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
+                ("preconditioner", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

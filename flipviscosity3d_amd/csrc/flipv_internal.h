@@ -136,6 +136,7 @@ struct flipv_context {
     uint8_t *stU, *stV, *stW;
     void *vX[3], *vR[3], *vZ[3], *vS[3];
     uint8_t *validCells, *validTmp;
+    void *mgState;       // pressure multigrid hierarchy (k_pressure_mg.hip), created on first use
     unsigned *surfList;  // indices whose control volumes need the sampling path (+ the counter at [L.n]); allocated on first use
 
     // kernel timing
@@ -301,6 +302,7 @@ __device__ __forceinline__ int d_tile_slot(int b, int n) {
 // ---------------------------------------------------------------------------------------------
 // cross-file entry points (host side)
 // ---------------------------------------------------------------------------------------------
+void fv_mg_free(flipv_context *c);
 int fv_particle_sdf(flipv_context *c);
 int fv_p2g(flipv_context *c);
 int fv_extrapolate(flipv_context *c);

@@ -318,6 +318,8 @@ static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, in
     if (timed) fv_ev_end(c);
 }
 
+int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv)(flipv_context *, const PcgScal &, int), int *conv_out);
+
 template <typename T>
 static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) {
     const Lay &L = c->L;
@@ -372,20 +374,30 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     }
     sc.tol = fmax(c->prm.pressure_tolerance, c->prm.pressure_rel_tolerance * bnorm);
 
-    PcgSys<T, 1> v;
-    v.mask = c->pMask;
-    v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
-    const int nb = pcg_grid(c, c->nActiveP);
-    const dim3 blk(64, 4, 1);
-    const HaloArray sh[1] = {{c->pS, sizeof(T)}};
-    hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);
-    if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     int conv = -1;
-    auto spmv = [&](int first, int count, int it) { launch_pressure_spmv<T>(c, sc, it, first, count); };
-    auto update = [&](int it) {
-        hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
-    };
-    if ((rc = pcg_run(c, sc, cap, sh, 1, c->nIntP, c->nActiveP, spmv, update, &conv))) return rc;
+    // preconditioner: aggregation multigrid on one GPU with fp32 vectors (k_pressure_mg.hip), the diagonal otherwise
+    // (slab-decomposed runs, fp64 vectors, or flipv_params.reserved[4] = 1)
+    const bool useMg = f32 && !c->comm && c->prm.reserved[4] != 1;
+    li.preconditioner = useMg ? 1 : 0;
+    if (useMg) {
+        if ((rc = fv_pressure_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s, int it) { launch_pressure_spmv<float>(cc, s, it, 0, cc->nActiveP); },
+                                     &conv)))
+            return rc;
+    } else {
+        PcgSys<T, 1> v;
+        v.mask = c->pMask;
+        v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
+        const int nb = pcg_grid(c, c->nActiveP);
+        const dim3 blk(64, 4, 1);
+        const HaloArray sh[1] = {{c->pS, sizeof(T)}};
+        hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);
+        if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
+        auto spmv = [&](int first, int count, int it) { launch_pressure_spmv<T>(c, sc, it, first, count); };
+        auto update = [&](int it) {
+            hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
+        };
+        if ((rc = pcg_run(c, sc, cap, sh, 1, c->nIntP, c->nActiveP, spmv, update, &conv))) return rc;
+    }
     const int last = conv >= 0 ? conv : cap - 1;
     hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -83,7 +83,8 @@ typedef struct flipv_params {
     int reserved[8];             /* measurement switches, all 0 by default: [0]=1 no hipGraph replay of the PCG loop;
                                     [1]=1 un-binned particle scatters (global atomics instead of LDS tiles);
                                     [2]=n>0 caps the PCG kernels' grids at n blocks (tests: every block walks many tiles);
-                                    [3]=2|4 forces the lane width of the viscosity solver kernels */
+                                    [3]=2|4 forces the lane width of the viscosity solver kernels;
+                                    [4]=1 diagonal preconditioner for the pressure PCG also where multigrid would be used */
 } flipv_params;
 
 typedef struct flipv_solve_info {
@@ -94,6 +95,7 @@ typedef struct flipv_solve_info {
     int rows;            /* unknowns */
     int active_tiles;    /* tiles swept per launch */
     int total_tiles;
+    int preconditioner;  /* 0 diagonal, 1 aggregation multigrid (pressure on one GPU with fp32 vectors) */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */
