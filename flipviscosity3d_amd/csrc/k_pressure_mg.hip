@@ -7,7 +7,7 @@
 //               M-matrix stored as diag + three "plus" couplings per cell (pressuresolver.h:103-108); with this P the
 //               coarse operator is again a 7-point M-matrix in the same storage: diag_c = sum of the aggregate's
 //               diagonals + twice its internal couplings, plus_c = sum of the couplings that cross the aggregate's face.
-//   cycle       V(1,1) with damped Jacobi (omega 0.8), zero initial guess, coarse correction scaled by 1.5 (plain
+//   cycle       V(1,1) with damped Jacobi (omega 0.9), zero initial guess, coarse correction scaled by 1.8 (plain
 //               aggregation under-corrects), 16 Jacobi sweeps on the coarsest level: a symmetric positive definite
 //               operator, as CG needs.
 //   measured    (scipy prototype on the oracle's 256^3 bunny matrix) 13 iterations against 76 with the diagonal for a
@@ -20,8 +20,10 @@
 
 namespace {
 
-constexpr float MG_OMEGA = 0.8f;
-constexpr float MG_OVER = 1.5f;
+// smoothing weight and over-correction of the coarse-grid term; in __constant__ memory so that FLIPV_MG_OMEGA /
+// FLIPV_MG_OVER can override them for parameter scans (read once, at the first solve)
+__constant__ float MG_OMEGA = 0.9f;   // scan at 256^3 (omega, over -> iterations): (0.8,1.0) 38, (0.8,1.5) 25, (0.8,1.8) 24, (0.9,1.5) 22,
+__constant__ float MG_OVER = 1.8f;    // (0.9,1.8) 20, (1.0,1.5) 84
 constexpr int MG_COARSEST_SWEEPS = 16;
 
 struct MgLevel {
@@ -137,39 +139,77 @@ __global__ void k_mg_up(Lay L, Lay C, const float *__restrict__ d, const float *
     if (i >= L.I || j >= L.J || k >= L.K) return;
     out[gidx(L, i, j, k)] = d_mg_up_cell(L, C, i, j, k, d, pi, pj, pk, b, x, xc);
 }
-// coarsest level: Jacobi sweeps by one workgroup (a few hundred cells), result in t
-__global__ __launch_bounds__(1024) void k_mg_coarsest(Lay L, const float *__restrict__ d, const float *__restrict__ pi,
-                                                      const float *__restrict__ pj, const float *__restrict__ pk,
-                                                      const float *__restrict__ b, float *__restrict__ x, float *__restrict__ t) {
-    const int n = L.I * L.J * L.K;
-    float *cur = x, *nxt = t;
-    for (int q = threadIdx.x; q < n; q += blockDim.x) {
-        const int i = q % L.I, j = (q / L.I) % L.J, k = q / (L.I * L.J);
-        const size_t c = gidx(L, i, j, k);
-        cur[c] = d[c] != 0.0f ? MG_OMEGA * b[c] / d[c] : 0.0f;
-    }
-    __syncthreads();
-    for (int s = 0; s < MG_COARSEST_SWEEPS; s++) {  // even count: the last sweep writes t
-        for (int q = threadIdx.x; q < n; q += blockDim.x) {
-            const int i = q % L.I, j = (q / L.I) % L.J, k = q / (L.I * L.J);
-            const size_t c = gidx(L, i, j, k);
-            const float dd = d[c];
-            float v = 0.0f;
-            if (dd != 0.0f) {
-                const float ax = dd * cur[c] + pi[c] * cur[c + 1] + pi[c - 1] * cur[c - 1] + pj[c] * cur[c + L.sy] + pj[c - L.sy] * cur[c - L.sy] +
-                                 pk[c] * cur[c + L.sz] + pk[c - L.sz] * cur[c - L.sz];
-                v = cur[c] + MG_OMEGA * (b[c] - ax) / dd;
-            }
-            nxt[c] = v;
+// The tail of the hierarchy (every level of at most MG_TAIL_CELLS cells, i.e. 16^3 and coarser; measured: with 32^3 included the single workgroup is slower than the launches it saves) in ONE
+// workgroup: down-sweeps, coarsest-level Jacobi, up-sweeps, separated by workgroup barriers instead of kernel
+// boundaries (each of those levels is a few thousand cells: a launch costs more than its work).
+constexpr int MG_MAX_TAIL = 6;
+constexpr long MG_TAIL_CELLS = 18 * 18 * 18;
+struct MgTail { int n; MgLevel lev[MG_MAX_TAIL]; };
+__device__ __forceinline__ void d_cell_of(const Lay &L, int q, int &i, int &j, int &k) { i = q % L.I; j = (q / L.I) % L.J; k = q / (L.I * L.J); }
+__global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
+    for (int l = 0; l + 1 < T.n; l++) {  // down
+        const MgLevel &F = T.lev[l];
+        const MgLevel &C = T.lev[l + 1];
+        const int nf = F.L.I * F.L.J * F.L.K, nc = C.L.I * C.L.J * C.L.K;
+        for (int q = threadIdx.x; q < nf; q += blockDim.x) {
+            int i, j, k;
+            d_cell_of(F.L, q, i, j, k);
+            d_mg_pre_cell(F.L, gidx(F.L, i, j, k), F.diag, F.pi, F.pj, F.pk, F.b, F.x, F.t);
         }
         __syncthreads();
-        float *tmp = cur; cur = nxt; nxt = tmp;
+        for (int q = threadIdx.x; q < nc; q += blockDim.x) {
+            int I, J, K;
+            d_cell_of(C.L, q, I, J, K);
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int i = 2 * I + (e & 1), j = 2 * J + ((e >> 1) & 1), k = 2 * K + (e >> 2);
+                if (i < F.L.I && j < F.L.J && k < F.L.K) s += F.t[gidx(F.L, i, j, k)];
+            }
+            C.b[gidx(C.L, I, J, K)] = s;
+        }
+        __syncthreads();
     }
-    // MG_COARSEST_SWEEPS is even: cur == x again; copy to t
-    for (int q = threadIdx.x; q < n; q += blockDim.x) {
-        const int i = q % L.I, j = (q / L.I) % L.J, k = q / (L.I * L.J);
-        const size_t c = gidx(L, i, j, k);
-        t[c] = cur[c];
+    {   // coarsest level: Jacobi sweeps from a zero guess, result in t
+        const MgLevel &B = T.lev[T.n - 1];
+        const Lay &L = B.L;
+        const int n = L.I * L.J * L.K;
+        float *cur = B.x, *nxt = B.t;
+        for (int q = threadIdx.x; q < n; q += blockDim.x) {
+            int i, j, k;
+            d_cell_of(L, q, i, j, k);
+            const size_t c = gidx(L, i, j, k);
+            cur[c] = B.diag[c] != 0.0f ? MG_OMEGA * B.b[c] / B.diag[c] : 0.0f;
+        }
+        __syncthreads();
+        for (int s = 0; s < MG_COARSEST_SWEEPS + 1; s++) {  // odd count: the last sweep writes t
+            for (int q = threadIdx.x; q < n; q += blockDim.x) {
+                int i, j, k;
+                d_cell_of(L, q, i, j, k);
+                const size_t c = gidx(L, i, j, k);
+                const float dd = B.diag[c];
+                float v = 0.0f;
+                if (dd != 0.0f) {
+                    const float ax = dd * cur[c] + B.pi[c] * cur[c + 1] + B.pi[c - 1] * cur[c - 1] + B.pj[c] * cur[c + L.sy] +
+                                     B.pj[c - L.sy] * cur[c - L.sy] + B.pk[c] * cur[c + L.sz] + B.pk[c - L.sz] * cur[c - L.sz];
+                    v = cur[c] + MG_OMEGA * (B.b[c] - ax) / dd;
+                }
+                nxt[c] = v;
+            }
+            __syncthreads();
+            float *tmp = cur; cur = nxt; nxt = tmp;
+        }
+    }
+    for (int l = T.n - 2; l >= 0; l--) {  // up
+        const MgLevel &F = T.lev[l];
+        const MgLevel &C = T.lev[l + 1];
+        const int nf = F.L.I * F.L.J * F.L.K;
+        for (int q = threadIdx.x; q < nf; q += blockDim.x) {
+            int i, j, k;
+            d_cell_of(F.L, q, i, j, k);
+            F.t[gidx(F.L, i, j, k)] = d_mg_up_cell(F.L, C.L, i, j, k, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t);
+        }
+        __syncthreads();
     }
 }
 
@@ -291,6 +331,7 @@ __global__ __launch_bounds__(256) void k_mgp_p(const int *__restrict__ tiles, in
 
 struct MgState {
     std::vector<MgLevel> lev;
+    int tailFirst = 0;  // first level handled by k_mg_tail
     std::vector<void *> allocs;
     int I = 0, J = 0, K = 0;
     ~MgState() { for (void *p : allocs) (void)hipFree(p); }
@@ -320,6 +361,8 @@ void fv_mg_free(flipv_context *c) {
 static int mg_setup(flipv_context *c, MgState **out) {
     MgState *s = (MgState *)c->mgState;
     if (!s) {
+        if (const char *e = getenv("FLIPV_MG_OMEGA")) { const float v = (float)atof(e); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OMEGA), &v, sizeof(float))); }
+        if (const char *e = getenv("FLIPV_MG_OVER")) { const float v = (float)atof(e); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OVER), &v, sizeof(float))); }
         s = new MgState();
         c->mgState = s;
         MgLevel l0;
@@ -339,6 +382,13 @@ static int mg_setup(flipv_context *c, MgState **out) {
             for (auto a : arr) if ((rc = mg_alloc(c, s, l.L, a))) return rc;
             s->lev.push_back(l);
         }
+        // the tail: the coarsest levels that are small enough for one workgroup (at least the last one, at most MG_MAX_TAIL);
+        // level 0 always runs on the tile list
+        s->tailFirst = (int)s->lev.size() - 1;
+        while (s->tailFirst > 1 && (int)s->lev.size() - (s->tailFirst - 1) <= MG_MAX_TAIL &&
+               (long)s->lev[s->tailFirst - 1].L.I * s->lev[s->tailFirst - 1].L.J * s->lev[s->tailFirst - 1].L.K <= MG_TAIL_CELLS)
+            s->tailFirst--;
+        if (s->lev.size() == 1) s->tailFirst = 0;
     }
     for (size_t l = 0; l + 1 < s->lev.size(); l++) {
         const MgLevel &F = s->lev[l];
@@ -354,19 +404,24 @@ static int mg_setup(flipv_context *c, MgState **out) {
 static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_next) {
     const int nl = (int)s->lev.size();
     const int nb = pcg_grid(c, c->nActiveP);
-    for (int l = 0; l + 1 < nl; l++) {
+    const int t0 = s->tailFirst;  // levels [t0, nl) run inside k_mg_tail
+    for (int l = 0; l < t0; l++) {  // down: level l -> right-hand side of level l+1
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
-        if (l == 0)
+        if (l == 0) {
             hipLaunchKernelGGL(k_mg_pre_tiles, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, F.diag, F.pi,
                                F.pj, F.pk, F.b, F.x, F.t);
-        else
+            hipLaunchKernelGGL(k_mg_restrict, MGGRID(C.L), 0, c->stream, F.L, C.L, F.t, C.b);
+        } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
             hipLaunchKernelGGL(k_mg_pre, MGGRID(F.L), 0, c->stream, F.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, F.t);
-        hipLaunchKernelGGL(k_mg_restrict, MGGRID(C.L), 0, c->stream, F.L, C.L, F.t, C.b);
+            hipLaunchKernelGGL(k_mg_restrict, MGGRID(C.L), 0, c->stream, F.L, C.L, F.t, C.b);
+        }
     }
-    const MgLevel &B = s->lev[nl - 1];
-    hipLaunchKernelGGL(k_mg_coarsest, dim3(1), dim3(1024), 0, c->stream, B.L, B.diag, B.pi, B.pj, B.pk, B.b, B.x, B.t);
-    for (int l = nl - 2; l >= 0; l--) {
+    MgTail T;
+    T.n = nl - t0;
+    for (int l = t0; l < nl; l++) T.lev[l - t0] = s->lev[l];
+    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, c->stream, T);
+    for (int l = t0 - 1; l >= 0; l--) {
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0)
