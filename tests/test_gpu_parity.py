@@ -82,6 +82,38 @@ def test_solvers_with_many_tiles_per_block(name, precision):
 
 
 @pytest.mark.parametrize("name", SCENES)
+def test_pressure_preconditioners_agree(name):
+    """fp32 pressure solve on one GPU: aggregation multigrid (default) against the diagonal preconditioner
+    (flipv_params.reserved[4] = 1) -- same pressure to the solver tolerance, far fewer iterations"""
+    import ctypes as C
+    g = Golden(name)
+    t = g.nsub - 1
+    if int(g["s%d_pres_iters" % t]) < 0:
+        pytest.skip("the fixture's last substep has a zero right-hand side")
+    out = []
+    for diagonal in (0, 1):
+        c = make_ctx(g, pressure_rel_tolerance=1e-7)
+        p = c.get_params()
+        p.reserved[4] = diagonal
+        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.set_grid("LIQUID_PHI", g["s%d_phi" % t])
+        load_uvw(c, g.uvw(t, "visc"))
+        c.compute_weights()
+        info = c.pressure_solve(g.dt)
+        assert info["status"] == 0 and info["preconditioner"] == (0 if diagonal else 1)
+        pres = c.grid("PRESSURE")
+        c.apply_pressure(g.dt)
+        out.append((info, pres, [c.grid(n) for n in "UVW"]))
+        c.close()
+    (i_mg, p_mg, v_mg), (i_d, p_d, v_d) = out
+    assert i_mg["iterations"] < i_d["iterations"]
+    if 1e-9 / i_mg["rhs_norm"] < 1e-6:   # the pressure itself is only resolved when max|b| is not tiny (see test_pressure_solve)
+        assert rel_maxnorm(p_mg, p_d) <= PRES_TOL
+    assert rel_maxnorm3(v_mg, v_d) <= VEL_TOL
+    assert rel_maxnorm3(v_mg, g.uvw(t, "proj")) <= VEL_TOL
+
+
+@pytest.mark.parametrize("name", SCENES)
 def test_binned_scatters_match_global_atomic_scatters(name):
     """The LDS-tile scatters (default) against the one-thread-per-particle global-atomic kernels
     (flipv_params.reserved[1] = 1): the SDF is a min (bit-exact), P2G differs in summation order only."""
