@@ -13,8 +13,11 @@
 //   measured    (scipy prototype on the oracle's 256^3 bunny matrix) 13 iterations against 76 with the diagonal for a
 //               random right-hand side, 13 against 96 (128^3) for a smooth one.
 // Everything is matrix-free on the levels' own dense index spaces (same layout rules as the fine grid); level 0 walks the
-// solver's tile list.  Coarse levels are launch-bound (a few microseconds per kernel), which is why this pays on one
-// GPU and why a slab-decomposed run keeps the diagonal preconditioner (a halo exchange per level and sweep would not).
+// solver's tile list.  Coarse levels are launch-bound (a few microseconds per kernel).
+// Slab-decomposed runs: the V-cycle is RANK-LOCAL (block-Jacobi multigrid): every rank builds the hierarchy of its own
+// planes, with the couplings across the slab faces dropped, and cycles it without any exchange; the CG around it uses
+// the true operator (halo exchange of p, two scalar all-reduces per iteration).  A block-diagonal SPD preconditioner:
+// same fixed point, a few more iterations than the global cycle, no halo traffic per level and sweep.
 #include "flipv_comm.h"
 #include "pcg_common.h"
 
@@ -39,7 +42,8 @@ static Lay coarse_lay(const Lay &F) {
     C.sy = C.PX; C.sz = (long)C.PX * C.PY;
     C.n = (size_t)C.sz * C.PZ;
     C.guard = (((size_t)C.sz + (size_t)C.sy + 8) + 63) / 64 * 64;
-    C.kb = 0; C.ke = C.PZ;
+    C.kb = F.kb >> 1;                 // cell planes [kb, ke) of this level that hold the rank's cells
+    C.ke = ((F.ke - 1) >> 1) + 1;
     return C;
 }
 
@@ -93,21 +97,21 @@ __device__ __forceinline__ float d_mg_up_cell(const Lay &L, const Lay &C, int i,
 __global__ void k_mg_coarsen(Lay F, Lay C, const float *__restrict__ df, const float *__restrict__ pif, const float *__restrict__ pjf,
                              const float *__restrict__ pkf, float *__restrict__ dc, float *__restrict__ pic, float *__restrict__ pjc,
                              float *__restrict__ pkc) {
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y, K = blockIdx.z;
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y, K = blockIdx.z + C.kb;
     if (I >= C.PX || J >= C.PY) return;
     const size_t cc = gidx(C, I, J, K);
     float ds = 0.0f, si = 0.0f, sj = 0.0f, sk = 0.0f;
-    if (I < C.I && J < C.J && K < C.K) {
+    if (I < C.I && J < C.J && K < C.ke) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int a = q & 1, b = (q >> 1) & 1, e = q >> 2;
             const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + e;
-            if (i >= F.I || j >= F.J || k >= F.K) continue;
+            if (i >= F.I || j >= F.J || k < F.kb || k >= F.ke) continue;   // only the rank's own planes
             const size_t c = gidx(F, i, j, k);
             ds += df[c];
             if (a == 0) ds += 2.0f * pif[c]; else si += pif[c];   // coupling to i+1: inside the aggregate / across its face
             if (b == 0) ds += 2.0f * pjf[c]; else sj += pjf[c];
-            if (e == 0) ds += 2.0f * pkf[c]; else sk += pkf[c];
+            if (k + 1 < F.ke) { if (e == 0) ds += 2.0f * pkf[c]; else sk += pkf[c]; }   // the coupling across the slab face is dropped
         }
         // an odd fine extent leaves the last aggregate one cell thick: its a == 0 coupling points outside the grid and is 0
     }
@@ -117,26 +121,26 @@ __global__ void k_mg_coarsen(Lay F, Lay C, const float *__restrict__ df, const f
 // ---- coarse levels: dense sweeps over the level's index space
 __global__ void k_mg_pre(Lay L, const float *__restrict__ d, const float *__restrict__ pi, const float *__restrict__ pj,
                          const float *__restrict__ pk, const float *__restrict__ b, float *__restrict__ x, float *__restrict__ t) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= L.I || j >= L.J || k >= L.K) return;
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    if (i >= L.I || j >= L.J || k >= L.ke) return;
     d_mg_pre_cell(L, gidx(L, i, j, k), d, pi, pj, pk, b, x, t);
 }
 __global__ void k_mg_restrict(Lay F, Lay C, const float *__restrict__ tf, float *__restrict__ bc) {
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y, K = blockIdx.z;
-    if (I >= C.I || J >= C.J || K >= C.K) return;
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y, K = blockIdx.z + C.kb;
+    if (I >= C.I || J >= C.J || K >= C.ke) return;
     float s = 0.0f;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int i = 2 * I + (q & 1), j = 2 * J + ((q >> 1) & 1), k = 2 * K + (q >> 2);
-        if (i < F.I && j < F.J && k < F.K) s += tf[gidx(F, i, j, k)];
+        if (i < F.I && j < F.J && k >= F.kb && k < F.ke) s += tf[gidx(F, i, j, k)];
     }
     bc[gidx(C, I, J, K)] = s;
 }
 __global__ void k_mg_up(Lay L, Lay C, const float *__restrict__ d, const float *__restrict__ pi, const float *__restrict__ pj,
                         const float *__restrict__ pk, const float *__restrict__ b, const float *__restrict__ x,
                         const float *__restrict__ xc, float *__restrict__ out) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= L.I || j >= L.J || k >= L.K) return;
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    if (i >= L.I || j >= L.J || k >= L.ke) return;
     out[gidx(L, i, j, k)] = d_mg_up_cell(L, C, i, j, k, d, pi, pj, pk, b, x, xc);
 }
 // The tail of the hierarchy (every level of at most MG_TAIL_CELLS cells, i.e. 16^3 and coarser; measured: with 32^3 included the single workgroup is slower than the launches it saves) in ONE
@@ -145,12 +149,13 @@ __global__ void k_mg_up(Lay L, Lay C, const float *__restrict__ d, const float *
 constexpr int MG_MAX_TAIL = 6;
 constexpr long MG_TAIL_CELLS = 18 * 18 * 18;
 struct MgTail { int n; MgLevel lev[MG_MAX_TAIL]; };
-__device__ __forceinline__ void d_cell_of(const Lay &L, int q, int &i, int &j, int &k) { i = q % L.I; j = (q / L.I) % L.J; k = q / (L.I * L.J); }
+__device__ __forceinline__ void d_cell_of(const Lay &L, int q, int &i, int &j, int &k) { i = q % L.I; j = (q / L.I) % L.J; k = L.kb + q / (L.I * L.J); }
+__device__ __forceinline__ int d_ncells(const Lay &L) { return L.I * L.J * (L.ke - L.kb); }
 __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
     for (int l = 0; l + 1 < T.n; l++) {  // down
         const MgLevel &F = T.lev[l];
         const MgLevel &C = T.lev[l + 1];
-        const int nf = F.L.I * F.L.J * F.L.K, nc = C.L.I * C.L.J * C.L.K;
+        const int nf = d_ncells(F.L), nc = d_ncells(C.L);
         for (int q = threadIdx.x; q < nf; q += blockDim.x) {
             int i, j, k;
             d_cell_of(F.L, q, i, j, k);
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int i = 2 * I + (e & 1), j = 2 * J + ((e >> 1) & 1), k = 2 * K + (e >> 2);
-                if (i < F.L.I && j < F.L.J && k < F.L.K) s += F.t[gidx(F.L, i, j, k)];
+                if (i < F.L.I && j < F.L.J && k >= F.L.kb && k < F.L.ke) s += F.t[gidx(F.L, i, j, k)];
             }
             C.b[gidx(C.L, I, J, K)] = s;
         }
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
     {   // coarsest level: Jacobi sweeps from a zero guess, result in t
         const MgLevel &B = T.lev[T.n - 1];
         const Lay &L = B.L;
-        const int n = L.I * L.J * L.K;
+        const int n = d_ncells(L);
         float *cur = B.x, *nxt = B.t;
         for (int q = threadIdx.x; q < n; q += blockDim.x) {
             int i, j, k;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
     for (int l = T.n - 2; l >= 0; l--) {  // up
         const MgLevel &F = T.lev[l];
         const MgLevel &C = T.lev[l + 1];
-        const int nf = F.L.I * F.L.J * F.L.K;
+        const int nf = d_ncells(F.L);
         for (int q = threadIdx.x; q < nf; q += blockDim.x) {
             int i, j, k;
             d_cell_of(F.L, q, i, j, k);
@@ -257,6 +262,8 @@ __global__ __launch_bounds__(256) void k_mg_down0(const int *__restrict__ tiles,
             dg = ldv<4>(diag + c);
             ci = ldv<4>(pi + c); cj = ldv<4>(pj + c); ck = ldv<4>(pk + c);
             cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
+            if (k - 1 < L.kb) ckm = Vec<float, 4>{};   // rank-local operator: no coupling across the slab faces
+            if (k + 1 >= L.ke) ck = Vec<float, 4>{};
             xc4 = ldv<4>(x0 + c); xjm = ldv<4>(x0 + c - sy); xjp = ldv<4>(x0 + c + sy); xkm = ldv<4>(x0 + c - sz); xkp = ldv<4>(x0 + c + sz);
             r4 = ldv<4>(r + c);
             if (lane == 0 && i0 > 0) { exl = x0[c - 1]; ecil = pi[c - 1]; }
@@ -325,6 +332,8 @@ __global__ __launch_bounds__(256) void k_mg_up0(const int *__restrict__ tiles, i
             dg = ldv<4>(diag + c);
             ci = ldv<4>(pi + c); cj = ldv<4>(pj + c); ck = ldv<4>(pk + c);
             cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
+            if (k - 1 < L.kb) ckm = Vec<float, 4>{};   // rank-local operator: no coupling across the slab faces
+            if (k + 1 >= L.ke) ck = Vec<float, 4>{};
             r4 = ldv<4>(r + c);
             // the five rows of y: x0 (16-byte load) + over * parent (two coarse values per lane and row)
             const int ic = i0 >> 1, jc = j >> 1, kc = k >> 1;
@@ -465,7 +474,7 @@ static int mg_alloc(flipv_context *c, MgState *s, const Lay &L, float **p) {
     return FLIPV_OK;
 }
 
-#define MGGRID(Lv) dim3(cdiv((Lv).PX, 64), cdiv((Lv).PY, 4), (unsigned)(Lv).PZ), dim3(64, 4, 1)
+#define MGGRID(Lv) dim3(cdiv((Lv).PX, 64), cdiv((Lv).PY, 4), (unsigned)((Lv).ke - (Lv).kb)), dim3(64, 4, 1)
 
 }  // namespace
 
@@ -484,6 +493,8 @@ static int mg_setup(flipv_context *c, MgState **out) {
         c->mgState = s;
         MgLevel l0;
         l0.L = c->L;
+        l0.L.kb = c->k0;                                   // the rank's cell planes (all of them on a single GPU)
+        l0.L.ke = c->k1 < c->L.K ? c->k1 : c->L.K;
         l0.diag = c->pDiag; l0.pi = c->pPi; l0.pj = c->pPj; l0.pk = c->pPk;
         l0.b = (float *)c->pR;
         int rc;
@@ -503,7 +514,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
         // level 0 always runs on the tile list
         s->tailFirst = (int)s->lev.size() - 1;
         while (s->tailFirst > 1 && (int)s->lev.size() - (s->tailFirst - 1) <= MG_MAX_TAIL &&
-               (long)s->lev[s->tailFirst - 1].L.I * s->lev[s->tailFirst - 1].L.J * s->lev[s->tailFirst - 1].L.K <= MG_TAIL_CELLS)
+               (long)s->lev[s->tailFirst - 1].L.I * s->lev[s->tailFirst - 1].L.J * (s->lev[s->tailFirst - 1].L.ke - s->lev[s->tailFirst - 1].L.kb) <= MG_TAIL_CELLS)
             s->tailFirst--;
         if (s->lev.size() == 1) s->tailFirst = 0;
     }
@@ -526,7 +537,7 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0) {  // x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
-            (void)hipMemsetAsync(C.b - C.L.guard, 0, (C.L.n + 2 * C.L.guard) * sizeof(float), c->stream);
+            (void)hipMemsetAsync(C.b + (size_t)C.L.kb * C.L.sz, 0, (size_t)(C.L.ke - C.L.kb) * C.L.sz * sizeof(float), c->stream);
             hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
                                F.pj, F.pk, c->pMask, F.x, F.b, C.b);
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
@@ -559,17 +570,23 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
     const dim3 blk(64, 4, 1);
     float *x = c->pressure, *r = (float *)c->pR, *q = (float *)c->pZ, *p = (float *)c->pS, *z = s->lev[0].t;
     float *x0 = s->lev[0].x;
+    const HaloArray ph[1] = {{p, sizeof(float)}};
     hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, -1);
     mg_vcycle(c, s, sc, 0);
+    if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, -1);
+    // an iteration after the stop is a full V-cycle (plus, multi-rank, three exchanges): poll often
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 4;
     int conv = -1, it = 0;
     while (it < cap && conv < 0) {
         const int stop = it + every < cap ? it + every : cap;
         for (; it < stop; it++) {
+            if ((rc = fv_halo_copy(c, ph, 1, 1))) return rc;                                   // p on the neighbours' boundary planes
             spmv(c, sc, it);
+            if (c->comm && (rc = fv_allreduce_scalars(c, sc.a(it), NSLOT))) return rc;          // p.q
             hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, it);
             mg_vcycle(c, s, sc, it + 1);
+            if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;   // max|r| of this iteration, (r,z) of the next
             hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, it);
         }
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -95,7 +95,7 @@ typedef struct flipv_solve_info {
     int rows;            /* unknowns */
     int active_tiles;    /* tiles swept per launch */
     int total_tiles;
-    int preconditioner;  /* 0 diagonal, 1 aggregation multigrid (pressure on one GPU with fp32 vectors) */
+    int preconditioner;  /* 0 diagonal, 1 aggregation multigrid (pressure with fp32 vectors; rank-local V-cycle under slabs) */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */
