@@ -1,3 +1,6 @@
+"""Manual parity run at a size of your choice (not collected by pytest): HIP path against the oracle on the bunny scene.
+    python tests/parity_vs_oracle.py <N> <substeps> [precision]
+Lives under tests/ because it calls the oracle (test infrastructure)."""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
