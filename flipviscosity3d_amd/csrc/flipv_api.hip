@@ -114,6 +114,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->evUsed = 0;
     c->pressureReady = c->viscosityReady = 0;
     c->viscStateValid = 0; c->viscStatePrec = 0;
+    c->bandPrevValid = 0;
     c->solidVersion = 1; c->weightsVersion = 0; c->faceStateVersion = 0;
     c->nActiveP = c->nActiveV = 0;
     c->vwV = 2;
@@ -177,6 +178,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     GALLOC(c->vmU); GALLOC(c->vmV); GALLOC(c->vmW);
     GALLOC(c->stU); GALLOC(c->stV); GALLOC(c->stW);
     GALLOC(c->vRowMask);
+    GALLOC(c->bandPrev);
     GALLOC(c->pMask);
     GALLOC(c->validCells); GALLOC(c->validTmp);
     for (int q = 0; q < 3; q++) { VALLOC(c->vX[q]); VALLOC(c->vR[q]); VALLOC(c->vZ[q]); VALLOC(c->vS[q]); }

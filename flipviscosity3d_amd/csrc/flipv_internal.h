@@ -136,6 +136,8 @@ struct flipv_context {
     uint8_t *stU, *stV, *stW;
     void *vX[3], *vR[3], *vZ[3], *vS[3];
     uint8_t *validCells, *validTmp;
+    uint8_t *bandPrev;   // validCells of the previous viscosity solve
+    int bandPrevValid;
     void *mgState;       // pressure multigrid hierarchy (k_pressure_mg.hip), created on first use
     unsigned *surfList;  // indices whose control volumes need the sampling path (+ the counter at [L.n]); allocated on first use
 

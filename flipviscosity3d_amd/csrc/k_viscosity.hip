@@ -120,7 +120,8 @@ struct VolLattices { float *vol[7]; int lat[7]; float cs[7][3]; };
 // need the sampling path; they are appended to a list so that pass 2 runs it with full waves (a surface crosses
 // nearly every 64-wide row of the band, which made one fused kernel pay the sampling path for every band wave).
 __global__ void k_volume_classify(Lay L, VolLattices Q, const float *__restrict__ phi, const uint8_t *__restrict__ valid,
-                                  unsigned *__restrict__ list, unsigned *__restrict__ nlist) {
+                                  const uint8_t *__restrict__ prevband, int full, unsigned *__restrict__ list,
+                                  unsigned *__restrict__ nlist) {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     const bool inside = i < L.PX && j < L.PY;
     const size_t c = inside ? gidx(L, i, j, k) : 0;
@@ -139,7 +140,8 @@ __global__ void k_volume_classify(Lay L, VolLattices Q, const float *__restrict_
             else if (nn == 0) { out = 0.0f; sample = false; }
         }
     }
-    if (inside) {
+    // the volumes are zero off the band and stay zero between solves: store only where the band is or was
+    if (inside && (full || valid[c] || prevband[c])) {
 #pragma unroll
         for (int m = 0; m < 7; m++) {
             int w, h, d;
@@ -196,8 +198,10 @@ __global__ void k_volume_sample(Lay L, VolLattices Q, const float *__restrict__ 
 __global__ void k_visc_factors(Lay L, const float *__restrict__ nu, const float *__restrict__ volC,
                                const float *__restrict__ volEU, const float *__restrict__ volEV,
                                const float *__restrict__ volEW, float *__restrict__ fC, float *__restrict__ fEU,
-                               float *__restrict__ fEV, float *__restrict__ fEW, float factor) {
+                               float *__restrict__ fEV, float *__restrict__ fEW, float factor, const uint8_t *__restrict__ band,
+                               const uint8_t *__restrict__ prevband, int full) {
     IJK_OR_RETURN(L);
+    if (!full && !band[c] && !prevband[c]) return;  // a factor is a volume of the same index times viscosity: zero off the band, and it stays zero
     const long sy = L.sy, sz = L.sz;
     const int I = L.I, J = L.J, K = L.K;
     if (i > I || j > J || k > K) return;
@@ -616,6 +620,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validCells, c->validTmp);
     hipLaunchKernelGGL(k_valid_dilate, GRID3(R1), 0, c->stream, R1, c->validTmp, c->validCells);
     const float h = (float)(0.5 * c->dx);
+    const int fullVol = c->bandPrevValid ? 0 : 1;  // volumes and factors are stored only where the band is or was in the previous solve
     {
         VolLattices Q;
         float *vols[7] = {c->volC, c->volU, c->volV, c->volW, c->volEU, c->volEV, c->volEW};
@@ -628,13 +633,18 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         }
         unsigned *nlist = c->surfList + L.n;
         HIPCHK(c, hipMemsetAsync(nlist, 0, sizeof(unsigned), c->stream));
-        hipLaunchKernelGGL(k_volume_classify, GRID3(R1), 0, c->stream, R1, Q, c->phi, c->validCells, c->surfList, nlist);
+        hipLaunchKernelGGL(k_volume_classify, GRID3(R1), 0, c->stream, R1, Q, c->phi, c->validCells, c->bandPrev, fullVol, c->surfList, nlist);
         hipLaunchKernelGGL(k_volume_sample, dim3(4096), dim3(256), 0, c->stream, c->L, Q, c->phi, c->surfList, nlist, c->dx);
     }
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
     hipLaunchKernelGGL(k_visc_factors, GRID3(R1), 0, c->stream, R1, c->visc, c->volC, c->volEU, c->volEV, c->volEW, c->fC,
-                       c->fEU, c->fEV, c->fEW, factor);
+                       c->fEU, c->fEV, c->fEW, factor, c->validCells, c->bandPrev, fullVol);
+    {
+        const size_t off = (size_t)R1.kb * L.sz, cnt = (size_t)(R1.ke - R1.kb) * L.sz;
+        HIPCHK(c, hipMemcpyAsync(c->bandPrev + off, c->validCells + off, cnt, hipMemcpyDeviceToDevice, c->stream));
+        c->bandPrevValid = 1;
+    }
     PcgSys<T, 3> v = visc_sys<T>(c);
     // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers are
     // shared) or of the slab make it store everywhere
