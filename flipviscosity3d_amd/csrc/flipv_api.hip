@@ -127,6 +127,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
 #define VALLOC(ptr) do { double *t_ = nullptr; int rc_ = grid_alloc(c, &t_); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } (ptr) = t_; } while (0)
     c->stream = c->xs = c->commStream = nullptr;
     c->evMain = c->evHalo = nullptr;
+    c->evPoll[0] = c->evPoll[1] = nullptr;
     c->nIntP = c->nIntV = 0;
     {
         const char *e = getenv("FLIPV_COMM_OVERLAP");
@@ -138,6 +139,8 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     CHK(hipStreamCreateWithFlags(&c->commStream, hipStreamNonBlocking));
     CHK(hipEventCreateWithFlags(&c->evMain, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&c->evHalo, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&c->evPoll[0], hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&c->evPoll[1], hipEventDisableTiming));
     c->xs = c->stream;
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) CHK(hipEventCreate(&c->phaseEv[q]));
     GALLOC(c->U); GALLOC(c->V); GALLOC(c->W);
@@ -247,6 +250,7 @@ extern "C" int flipv_destroy(flipv_context *c) {
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) if (c->phaseEv[q]) (void)hipEventDestroy(c->phaseEv[q]);
     if (c->evMain) (void)hipEventDestroy(c->evMain);
     if (c->evHalo) (void)hipEventDestroy(c->evHalo);
+    for (int q = 0; q < 2; q++) if (c->evPoll[q]) (void)hipEventDestroy(c->evPoll[q]);
     if (c->commStream) (void)hipStreamDestroy(c->commStream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

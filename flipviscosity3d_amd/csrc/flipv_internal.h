@@ -69,6 +69,7 @@ struct flipv_context {
     // while a halo exchange overlaps interior work, see pcg_common.h), the scalar all-reduces always on `stream`
     hipStream_t xs, commStream;
     hipEvent_t evMain, evHalo;
+    hipEvent_t evPoll[2];  // stop-flag read-backs of the PCG loop (two in flight)
     int commOverlap;  // 1: halo exchange of the PCG search direction overlaps the interior SpMV (FLIPV_COMM_OVERLAP=0 disables)
     float dx;
     int device;

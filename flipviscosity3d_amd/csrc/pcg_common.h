@@ -519,28 +519,19 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         // Chunks of `every` iterations, each followed by a read-back of the stop flag into its own pinned slot.  The next
         // chunk is enqueued BEFORE the host waits for the previous chunk's flag, so the GPU never drains while the host
         // polls; if that flag says "converged" the chunk already in flight returns launch by launch at once.
-        // (h_flags[8], h_flags[9] are the two slots; evMain/evHalo double as their events on a single GPU, a multi-rank
-        // run needs those for the halo stream and polls synchronously.)
+        // (h_flags[8], h_flags[9] are the two slots.)  Every rank reads the same all-reduced values, so all ranks leave the
+        // loop after the same chunk.
         int it = 0;
-        if (c->comm) {
-            while (it < cap && conv < 0) {
-                const int stop = (it + every < cap) ? it + every : cap;
-                for (; it < stop; it++)
-                    if ((rc = launch_iter(it))) return rc;
-                // the stop is recorded by the update kernel of the NEXT iteration, after the all-reduce that merges the
-                // partial maxima: a solve that converges on a chunk's last iteration is seen one poll later
-                HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                conv = c->h_flags[0];
-            }
-        } else {
-            hipEvent_t ev[2] = {c->evMain, c->evHalo};
+        {
+            hipEvent_t ev[2] = {c->evPoll[0], c->evPoll[1]};
             int pending = -1;  // slot whose read-back has been enqueued but not yet waited for
             int slot = 0;
             while (it < cap && conv < 0) {
                 const int stop = (it + every < cap) ? it + every : cap;
                 for (; it < stop; it++)
                     if ((rc = launch_iter(it))) return rc;
+                // (the stop is recorded by the update kernel of the NEXT iteration -- in a multi-rank run after the all-reduce
+                // that merges the partial maxima -- so a solve that converges on a chunk's last iteration is seen one poll later)
                 HIPCHK(c, hipMemcpyAsync(c->h_flags + 8 + slot, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipEventRecord(ev[slot], c->stream));
                 if (pending >= 0) {
