@@ -570,7 +570,11 @@ static PcgSys<T, 3> visc_sys(flipv_context *c) {
 
 template <typename T, int NV>
 static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
-    const int nb = pcg_grid(c, count);
+    // one resident round: the 4-wide kernel holds 189 VGPRs = 2 waves per SIMD = 2 blocks per CU = 512 blocks (measured over
+    // 512..1024 at 256^3: 37.2 ms per solve at 512, 38.1 at 1024, 40.8-43.6 in between); reserved[5] overrides
+    int nb = pcg_grid(c, count);
+    const int cap = c->prm.reserved[5] > 0 ? c->prm.reserved[5] : (NV == 4 ? 512 : 1024);
+    if (nb > cap) nb = cap;
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 1, (double)count * (64 * NV * TY));
     if (NV == 4 && c->vPred)
@@ -689,7 +693,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         success = true;
     } else {
         sc.tol = c->prm.viscosity_tolerance * bnorm;
-        const int nb = pcg_grid(c, c->nActiveV);
+        int nb = pcg_grid(c, c->nActiveV);
+        if (c->prm.reserved[6] > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.reserved[6]) nb = c->prm.reserved[6]; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
         const dim3 blk(64, 4, 1);
         const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
         if (c->vwV == 4)

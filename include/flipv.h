@@ -84,7 +84,8 @@ typedef struct flipv_params {
                                     [1]=1 un-binned particle scatters (global atomics instead of LDS tiles);
                                     [2]=n>0 caps the PCG kernels' grids at n blocks (tests: every block walks many tiles);
                                     [3]=2|4 forces the lane width of the viscosity solver kernels;
-                                    [4]=1 diagonal preconditioner for the pressure PCG also where multigrid would be used */
+                                    [4]=1 diagonal preconditioner for the pressure PCG also where multigrid would be used;
+                                    [5]=n>0 grid cap of the viscosity SpMV kernel alone; [6]=n>0 of its init/update kernels */
 } flipv_params;
 
 typedef struct flipv_solve_info {
