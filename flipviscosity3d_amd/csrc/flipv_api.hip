@@ -100,6 +100,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     c->binIdx = nullptr; c->binIdxCap = 0;
     c->surfList = nullptr;
     c->mgState = nullptr;
+    c->vmgState = nullptr;
     c->binCnt = c->binOff = c->binCur = c->binList = c->binNList = nullptr;
     c->binTilesCap = 0; c->nbx = c->nby = c->nbz = 0; c->binsValid = 0;
     c->haloBuf = nullptr; c->haloCap = 0;
@@ -241,6 +242,7 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->binIdx) (void)hipFree(c->binIdx);
     if (c->surfList) (void)hipFree(c->surfList);
     fv_mg_free(c);
+    fv_vmg_free(c);
     if (c->binCnt) (void)hipFree(c->binCnt);
     if (c->haloBuf) (void)hipFree(c->haloBuf);
     if (c->d_scal) (void)hipFree(c->d_scal);

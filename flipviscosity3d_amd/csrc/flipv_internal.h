@@ -140,6 +140,7 @@ struct flipv_context {
     uint8_t *bandPrev;   // validCells of the previous viscosity solve
     int bandPrevValid;
     void *mgState;       // pressure multigrid hierarchy (k_pressure_mg.hip), created on first use
+    void *vmgState;      // viscosity multigrid hierarchy (k_viscosity_mg.hip), created on first use
     unsigned *surfList;  // indices whose control volumes need the sampling path (+ the counter at [L.n]); allocated on first use
 
     // kernel timing
@@ -306,6 +307,7 @@ __device__ __forceinline__ int d_tile_slot(int b, int n) {
 // cross-file entry points (host side)
 // ---------------------------------------------------------------------------------------------
 void fv_mg_free(flipv_context *c);
+void fv_vmg_free(flipv_context *c);
 int fv_particle_sdf(flipv_context *c);
 int fv_p2g(flipv_context *c);
 int fv_extrapolate(flipv_context *c);

@@ -568,8 +568,10 @@ static PcgSys<T, 3> visc_sys(flipv_context *c) {
     return v;
 }
 
+int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv)(flipv_context *, const PcgScal &, int), int *conv_out);
+
 template <typename T, int NV>
-static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
+static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count, const PcgSys<T, 3> *sys = nullptr) {
     // one resident round: the 4-wide kernel holds 189 VGPRs = 2 waves per SIMD = 2 blocks per CU = 512 blocks (measured over
     // 512..1024 at 256^3: 37.2 ms per solve at 512, 38.1 at 1024, 40.8-43.6 in between); reserved[5] overrides
     int nb = pcg_grid(c, count);
@@ -579,10 +581,10 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     if (timed) fv_ev_begin(c, 1, (double)count * (64 * NV * TY));
     if (NV == 4 && c->vPred)
         hipLaunchKernelGGL((k_visc_spmv<T, 4, true>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
+                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it);
     else
     hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                       c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, visc_sys<T>(c), sc, it);
+                       c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it);
     if (timed) fv_ev_end(c);
 }
 
@@ -697,6 +699,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (c->prm.reserved[6] > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.reserved[6]) nb = c->prm.reserved[6]; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
         const dim3 blk(64, 4, 1);
         const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
+        const bool useMg = std::is_same<T, float>::value && !c->comm && c->prm.reserved[7] == 1 && c->vwV == 4;
+        li.preconditioner = useMg ? 1 : 0;
+        if (useMg) {
+            if ((rc = fv_viscosity_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); },
+                                          &conv)))
+                return rc;
+        } else {
         if (c->vwV == 4)
             hipLaunchKernelGGL((k_pcg_init<T, 3, 4>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc);
         else
@@ -712,6 +721,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                 hipLaunchKernelGGL((k_pcg_update<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
         };
         if ((rc = pcg_run(c, sc, cap, sh, 3, c->nIntV, c->nActiveV, spmv, update, &conv))) return rc;
+        }
         const int last = conv >= 0 ? conv : cap - 1;
         hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -737,6 +747,18 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     if (c->prm.kernel_timing) fv_ev_collect(c);
     if (info) *info = li;
     return success ? FLIPV_OK : (accepted ? FLIPV_WARN_NOT_CONVERGED : FLIPV_WARN_SOLVE_FAILED);
+}
+
+// out = A in for arbitrary fp32 vectors (zero off the rows), with the solver's SpMV kernel and no dot products
+void fv_visc_apply_f32(flipv_context *c, float *const in[3], float *const out[3]) {
+    PcgSys<float, 3> v = visc_sys<float>(c);
+    for (int m = 0; m < 3; m++) { v.s[m] = in[m]; v.q[m] = out[m]; }
+    PcgScal none;
+    memset(&none, 0, sizeof(none));
+    const int saved = c->prm.kernel_timing;
+    c->prm.kernel_timing = 0;
+    launch_visc_spmv<float, 4>(c, none, 0, 0, c->nActiveV, &v);
+    c->prm.kernel_timing = saved;
 }
 
 int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) {

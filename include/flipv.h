@@ -85,7 +85,9 @@ typedef struct flipv_params {
                                     [2]=n>0 caps the PCG kernels' grids at n blocks (tests: every block walks many tiles);
                                     [3]=2|4 forces the lane width of the viscosity solver kernels;
                                     [4]=1 diagonal preconditioner for the pressure PCG also where multigrid would be used;
-                                    [5]=n>0 grid cap of the viscosity SpMV kernel alone; [6]=n>0 of its init/update kernels */
+                                    [5]=n>0 grid cap of the viscosity SpMV kernel alone; [6]=n>0 of its init/update kernels;
+                                    [7]=1 Galerkin multigrid preconditioner for the viscosity PCG (fp32, one rank; experimental:
+                                    fewer iterations but slower than the diagonal) */
 } flipv_params;
 
 typedef struct flipv_solve_info {

@@ -247,6 +247,37 @@ def test_viscosity_solve(name, precision, oracle):
     c.close()
 
 
+@pytest.mark.parametrize("name", ["bunny32_viscous", "twobody20_varvisc"])
+def test_viscosity_multigrid_preconditioner_agrees(name):
+    """the opt-in Galerkin multigrid preconditioner of the viscosity PCG (flipv_params.reserved[7] = 1, k_viscosity_mg.hip):
+    same velocities as the golden reference output, several times fewer iterations than the diagonal"""
+    import ctypes as C
+    g = Golden(name)
+    its = []
+    for mg in (0, 1):
+        c = make_ctx(g, viscosity_max_iterations=5000, viscosity_tolerance=1e-7)
+        p = c.get_params()
+        p.reserved[7] = mg
+        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        n = 0
+        for t in range(g.nsub):
+            phi = g["s%d_phi" % t]
+            c.set_grid("LIQUID_PHI", phi)
+            load_uvw(c, g.uvw(t, "force"))
+            info = c.viscosity_solve(g.dt)
+            assert info["status"] == 0 and info["preconditioner"] == mg, info
+            n += info["iterations"]
+            got = [c.grid(k) for k in "UVW"]
+            ref = g.uvw(t, "visc")
+            masks = fluid_face_masks(phi)
+            num = max(np.abs((a - b)[m]).max() for a, b, m in zip(got, ref, masks))
+            den = max(np.abs(b[m]).max() for b, m in zip(ref, masks))
+            assert num / den <= VEL_TOL, (mg, num / den, info)
+        its.append(n)
+        c.close()
+    assert its[1] * 3 < its[0], its
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_particle_advection(name):
     g = Golden(name)
