@@ -161,8 +161,8 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
     memset(c->h_flags, 0, 16 * sizeof(int));
     // solver tiles over the shared index space
-    c->tgP.ntx = (L.PX + 64 * VW_P - 1) / (64 * VW_P); c->tgP.nty = (L.PY + TY - 1) / TY; c->tgP.ntz = L.PZ;
-    c->tgV.ntx = (L.PX + 64 * VW_V - 1) / (64 * VW_V); c->tgV.nty = (L.PY + TY - 1) / TY; c->tgV.ntz = L.PZ;
+    c->tgP.ntx = (L.PX + ROWL * VW_P - 1) / (ROWL * VW_P); c->tgP.nty = (L.PY + TY - 1) / TY; c->tgP.ntz = L.PZ;
+    c->tgV.ntx = (L.PX + ROWL * VW_V - 1) / (ROWL * VW_V); c->tgV.nty = (L.PY + TY - 1) / TY; c->tgV.ntz = L.PZ;
     {
         const size_t ntmax = (size_t)(c->tgP.count() > c->tgV.count() ? c->tgP.count() : c->tgV.count()) * 2 + 64;  // virtual enumeration pads nty to a multiple of 4
         int rc_ = plain_alloc(c, &c->tileListP, ntmax);

@@ -97,15 +97,21 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
                                                        const uint8_t *__restrict__ cellmask, const T *__restrict__ s,
                                                        const RT<T> *__restrict__ r, T *__restrict__ q, PcgScal sc, int it_arg) {
     __shared__ double lds[12];
-    const int it = d_iter_spmv(sc, it_arg);
-    if (d_spmv_stop(sc, it)) return;
+    const int nvb = ((ntiles + 7) >> 3) << 3;
+    const int stride = TBATCH * (int)gridDim.x;
+    TileWalk<VW_P> cur;
+    cur.fetch(blockIdx.x, nvb, tiles, ntiles, tg, L, cellmask);
+    bool stop;
+    const int it = d_iter_spmv(sc, it_arg, stop);
+    if (stop) return;
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
-      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
-      unsigned mks[TBATCH];
-      d_fetch_masks<VW_P>(B, tg, L, cellmask, mks);
+    for (int base = blockIdx.x; base < nvb; base += stride) {
+      TileWalk<VW_P> nxt;
+      nxt.fetch(base + stride, nvb, tiles, ntiles, tg, L, cellmask);
+      const TileBatch B = cur.B;
+      const unsigned mks[TBATCH] = {cur.mk[0], cur.mk[1], cur.mk[2], cur.mk[3]};
+      cur = nxt;
 #pragma unroll 1
       for (int t = 0; t < TBATCH; t++) {
         // a lane without pressure cells has nothing to compute or store (q is only read where diag != 0, s is 0 off the
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
         if (!inside) continue;
         const size_t c = gidx(L, i0, j, k);
         const long sy = L.sy, sz = L.sz;
-        const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // outside any short-circuit
+        const int mleft = __shfl_up((int)mine, 1, ROWL), mright = __shfl_down((int)mine, 1, ROWL);  // outside any short-circuit
         const bool on = mine || mleft != 0 || mright != 0;
         // every load of the tile in one predicated block (the kernel is latency-bound on the reference's scenes)
         Vec<float, 4> dg{}, ci{}, cj{}, ck{}, cjm{}, ckm{};
@@ -130,14 +136,13 @@ __global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ t
             cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
             sc4 = ldv<4>(s + c); sjm = ldv<4>(s + c - sy); sjp = ldv<4>(s + c + sy); skm = ldv<4>(s + c - sz); skp = ldv<4>(s + c + sz);
             r4 = ldv<4>(r + c);
-            const int lane = threadIdx.x & 63;
-            if (lane == 0 && i0 > 0) { esl = s[c - 1]; ecil = pi[c - 1]; }
-            if (lane == 63 && i0 + 4 < L.I) esr = s[c + 4];
+            if (d_row_first() && i0 > 0) { esl = s[c - 1]; ecil = pi[c - 1]; }
+            if (d_row_last() && i0 + 4 < L.I) esr = s[c + 4];
         }
         T sl = wave_up1(sc4.v[3]), sr = wave_down1(sc4.v[0]);
         float cil = wave_up1(ci.v[3]);
-        if ((threadIdx.x & 63) == 0) { sl = esl; cil = ecil; }
-        if ((threadIdx.x & 63) == 63) sr = esr;
+        if (d_row_first()) { sl = esl; cil = ecil; }
+        if (d_row_last()) sr = esr;
         Vec<T, 4> y;
         T ta = (T)0, tb = (T)0, tc = (T)0;  // this lane's four cells in the vector precision, folded into fp64 once per tile
 #pragma unroll
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, 
     int any = 0;
     if (tile >= 0) {
         const int tx = tile % tg.ntx, t2 = tile / tg.ntx, ty = t2 % tg.nty, k = t2 / tg.nty;
-        const int i0 = tx * 64 * vw + threadIdx.x * vw, j = ty * TY + threadIdx.y;
+        const int i0 = tx * ROWL * vw + d_tcol() * vw, j = ty * TY + d_trow();
         if (i0 < L.PX && j < L.PY) {
             const size_t c = gidx(L, i0, j, k);
             const float *dd[3] = {d0, d1, d2};
@@ -312,7 +317,7 @@ template <typename T>
 static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
     const int nb = pcg_grid(c, count);
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
-    if (timed) fv_ev_begin(c, 0, (double)count * (64 * VW_P * TY));
+    if (timed) fv_ev_begin(c, 0, (double)count * (ROWL * VW_P * TY));
     hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
                        c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it);
     if (timed) fv_ev_end(c);
@@ -444,6 +449,6 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *ms = (double)t / reps;
-    *cells = (double)c->nActiveP * (64 * VW_P * TY);
+    *cells = (double)c->nActiveP * (ROWL * VW_P * TY);
     return FLIPV_OK;
 }

@@ -218,16 +218,6 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
     }
 }
 
-// ---- level 0 over the solver's tile list (tiles of 256 x 4 cells; a thread takes cells lane, lane+64, lane+128, lane+192)
-__device__ __forceinline__ bool d_tile_base(int tile, const TileGrid &tg, int &ib, int &j, int &k) {
-    if (tile < 0) return false;
-    const int tx = tile % tg.ntx;
-    const int t2 = tile / tg.ntx;
-    k = t2 / tg.nty;
-    j = (t2 % tg.nty) * TY + threadIdx.y;
-    ib = tx * (64 * VW_P);
-    return true;
-}
 // ---- level 0, vectorised like the SpMV kernel (4 consecutive cells per lane, 16-byte loads, i-neighbours by DPP, lanes
 // without cells predicated off).  The pre-smoothed iterate x0 = omega r/d is written by the PCG's vector kernels.
 // down: t = r - A x0 is never stored: it goes straight into the coarse right-hand side (8 children per aggregate, the two
@@ -251,10 +241,10 @@ __global__ __launch_bounds__(256) void k_mg_down0(const int *__restrict__ tiles,
         if (!inside) continue;
         const size_t c = gidx(L, i0, j, k);
         const long sy = L.sy, sz = L.sz;
-        const int lane = threadIdx.x & 63;
+        const bool lfirst = d_row_first(), llast = d_row_last();
         int mleft = wave_up1((int)mine), mright = wave_down1((int)mine);
-        if (lane == 0) mleft = 0;
-        if (lane == 63) mright = 0;
+        if (lfirst) mleft = 0;
+        if (llast) mright = 0;
         const bool on = mine || mleft != 0 || mright != 0;
         Vec<float, 4> dg{}, ci{}, cj{}, ck{}, cjm{}, ckm{}, xc4{}, xjm{}, xjp{}, xkm{}, xkp{}, r4{};
         float exl = 0.0f, exr = 0.0f, ecil = 0.0f;
@@ -266,12 +256,12 @@ __global__ __launch_bounds__(256) void k_mg_down0(const int *__restrict__ tiles,
             if (k + 1 >= L.ke) ck = Vec<float, 4>{};
             xc4 = ldv<4>(x0 + c); xjm = ldv<4>(x0 + c - sy); xjp = ldv<4>(x0 + c + sy); xkm = ldv<4>(x0 + c - sz); xkp = ldv<4>(x0 + c + sz);
             r4 = ldv<4>(r + c);
-            if (lane == 0 && i0 > 0) { exl = x0[c - 1]; ecil = pi[c - 1]; }
-            if (lane == 63 && i0 + 4 < L.I) exr = x0[c + 4];
+            if (lfirst && i0 > 0) { exl = x0[c - 1]; ecil = pi[c - 1]; }
+            if (llast && i0 + 4 < L.I) exr = x0[c + 4];
         }
         float xl = wave_up1(xc4.v[3]), xr = wave_down1(xc4.v[0]), cil = wave_up1(ci.v[3]);
-        if (lane == 0) { xl = exl; cil = ecil; }
-        if (lane == 63) xr = exr;
+        if (lfirst) { xl = exl; cil = ecil; }
+        if (llast) xr = exr;
         float res[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -321,10 +311,10 @@ __global__ __launch_bounds__(256) void k_mg_up0(const int *__restrict__ tiles, i
         if (!inside) continue;
         const size_t c = gidx(L, i0, j, k);
         const long sy = L.sy, sz = L.sz;
-        const int lane = threadIdx.x & 63;
+        const bool lfirst = d_row_first(), llast = d_row_last();
         int mleft = wave_up1((int)mine), mright = wave_down1((int)mine);
-        if (lane == 0) mleft = 0;
-        if (lane == 63) mright = 0;
+        if (lfirst) mleft = 0;
+        if (llast) mright = 0;
         const bool on = mine || mleft != 0 || mright != 0;
         Vec<float, 4> dg{}, ci{}, cj{}, ck{}, cjm{}, ckm{}, y0{}, yjm{}, yjp{}, ykm{}, ykp{}, r4{};
         float eyl = 0.0f, eyr = 0.0f, ecil = 0.0f;
@@ -351,12 +341,12 @@ __global__ __launch_bounds__(256) void k_mg_up0(const int *__restrict__ tiles, i
             YROW(ykm, -sz, jc, km)
             YROW(ykp, sz, jc, kp)
 #undef YROW
-            if (lane == 0 && i0 > 0) { eyl = x0[c - 1] + over * xc[gidx(C, (i0 - 1) >> 1, jc, kc)]; ecil = pi[c - 1]; }
-            if (lane == 63 && i0 + 4 < L.I) eyr = x0[c + 4] + over * xc[gidx(C, (i0 + 4) >> 1, jc, kc)];
+            if (lfirst && i0 > 0) { eyl = x0[c - 1] + over * xc[gidx(C, (i0 - 1) >> 1, jc, kc)]; ecil = pi[c - 1]; }
+            if (llast && i0 + 4 < L.I) eyr = x0[c + 4] + over * xc[gidx(C, (i0 + 4) >> 1, jc, kc)];
         }
         float yl = wave_up1(y0.v[3]), yr = wave_down1(y0.v[0]), cil = wave_up1(ci.v[3]);
-        if (lane == 0) { yl = eyl; cil = ecil; }
-        if (lane == 63) yr = eyr;
+        if (lfirst) { yl = eyl; cil = ecil; }
+        if (llast) yr = eyr;
         Vec<float, 4> zz;
         float trz = 0.0f;
 #pragma unroll
@@ -386,7 +376,7 @@ __global__ __launch_bounds__(256) void k_mg_up0(const int *__restrict__ tiles, i
     if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(sc.sig(it_next) + sc.my_slot(), tot);
 }
 
-// ---- PCG vector kernels (tile list; a thread takes cells lane, lane+64, lane+128, lane+192 of its tile row)
+// ---- PCG vector kernels (tile list, one cell per thread and pass: d_tile_cell)
 // x += alpha p ; r -= alpha q ; rmax(it) = max|r|          alpha = sig(it) / a(it)
 __global__ __launch_bounds__(256) void k_mgp_xr(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                 const float *__restrict__ d, float *__restrict__ x, float *__restrict__ r,
@@ -402,12 +392,11 @@ __global__ __launch_bounds__(256) void k_mgp_xr(const int *__restrict__ tiles, i
     const int nvb = ((ntiles + 7) >> 3) << 3;
     for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
         const int slot = d_tile_slot(bb, ntiles);
-        int ib, j, k;
-        if (!d_tile_base(slot < ntiles ? tiles[slot] : -1, tg, ib, j, k) || j >= L.J || k >= L.K) continue;
+        const int tile = slot < ntiles ? tiles[slot] : -1;
 #pragma unroll
         for (int e = 0; e < VW_P; e++) {
-            const int i = ib + e * 64 + threadIdx.x;
-            if (i >= L.I) continue;
+            int i, j, k;
+            if (!d_tile_cell<VW_P>(tile, tg, e, i, j, k) || i >= L.I || j >= L.J || k >= L.K) continue;
             const size_t c = gidx(L, i, j, k);
             if (d[c] == 0.0f) continue;
             float rn = r[c];
@@ -442,12 +431,11 @@ __global__ __launch_bounds__(256) void k_mgp_p(const int *__restrict__ tiles, in
     const int nvb = ((ntiles + 7) >> 3) << 3;
     for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
         const int slot = d_tile_slot(bb, ntiles);
-        int ib, j, k;
-        if (!d_tile_base(slot < ntiles ? tiles[slot] : -1, tg, ib, j, k) || j >= L.J || k >= L.K) continue;
+        const int tile = slot < ntiles ? tiles[slot] : -1;
 #pragma unroll
         for (int e = 0; e < VW_P; e++) {
-            const int i = ib + e * 64 + threadIdx.x;
-            if (i >= L.I) continue;
+            int i, j, k;
+            if (!d_tile_cell<VW_P>(tile, tg, e, i, j, k) || i >= L.I || j >= L.J || k >= L.K) continue;
             const size_t c = gidx(L, i, j, k);
             if (d[c] == 0.0f) continue;
             p[c] = it >= 0 ? z[c] + beta * p[c] : z[c];

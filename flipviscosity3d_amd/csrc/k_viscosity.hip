@@ -385,26 +385,26 @@ template <int N> __device__ __forceinline__ Vec<float, N> vneg() {
 }
 template <typename T, int N>
 __device__ __forceinline__ T nbl(const Vec<T, N> &a, const T *__restrict__ p, int i0, bool on) {
-    T v = __shfl_up(a.v[N - 1], 1, 64);
-    if ((threadIdx.x & 63) == 0) v = (on && i0 > 0) ? p[-1] : (T)0;
+    T v = __shfl_up(a.v[N - 1], 1, ROWL);
+    if (d_row_first()) v = (on && i0 > 0) ? p[-1] : (T)0;
     return v;
 }
 template <typename T, int N>
 __device__ __forceinline__ T nbr(const Vec<T, N> &a, const T *__restrict__ p, int i0, int w, bool on) {
-    T v = __shfl_down(a.v[0], 1, 64);
-    if ((threadIdx.x & 63) == 63) v = (on && i0 + N < w) ? p[N] : (T)0;
+    T v = __shfl_down(a.v[0], 1, ROWL);
+    if (d_row_last()) v = (on && i0 + N < w) ? p[N] : (T)0;
     return v;
 }
 // i-neighbour across lanes; `edge` is the value lane 0 (left) / lane 63 (right) fetched from memory beforehand
 template <typename T, int N>
 __device__ __forceinline__ T nbl2(const Vec<T, N> &a, T edge) {
     const T v = wave_up1(a.v[N - 1]);
-    return (threadIdx.x & 63) == 0 ? edge : v;
+    return d_row_first() ? edge : v;
 }
 template <typename T, int N>
 __device__ __forceinline__ T nbr2(const Vec<T, N> &a, T edge) {
     const T v = wave_down1(a.v[0]);
-    return (threadIdx.x & 63) == 63 ? edge : v;
+    return d_row_last() ? edge : v;
 }
 #define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
 #define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
@@ -416,15 +416,21 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
                                                    const float *__restrict__ fEU, const float *__restrict__ fEV,
                                                    const float *__restrict__ fEW, PcgSys<T, 3> v, PcgScal sc, int it_arg) {
     __shared__ double lds[12];
-    const int it = d_iter_spmv(sc, it_arg);
-    if (d_spmv_stop(sc, it)) return;
+    const int nvb = ((ntiles + 7) >> 3) << 3;
+    const int stride = TBATCH * (int)gridDim.x;
+    TileWalk<NV> cur;
+    cur.fetch(blockIdx.x, nvb, tiles, ntiles, tg, L, v.mask);
+    bool stop;
+    const int it = d_iter_spmv(sc, it_arg, stop);
+    if (stop) return;
     int i0, j, k;
     double da = 0.0, db = 0.0, dc = 0.0;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
-      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
-      unsigned mks[TBATCH];
-      d_fetch_masks<NV>(B, tg, L, v.mask, mks);
+    for (int base = blockIdx.x; base < nvb; base += stride) {
+      TileWalk<NV> nxt;
+      nxt.fetch(base + stride, nvb, tiles, ntiles, tg, L, v.mask);
+      const TileBatch B = cur.B;
+      const unsigned mks[TBATCH] = {cur.mk[0], cur.mk[1], cur.mk[2], cur.mk[3]};
+      cur = nxt;
 #pragma unroll 1
       for (int t = 0; t < TBATCH; t++) {
         const bool inside = d_tile_decode<NV>(d_pick(B.id, t), tg, L, i0, j, k);
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
         // read where the diagonal is non-zero), and it only has to LOAD if a neighbouring lane, which takes its i+-1
         // values from it, has one: in the sparse scenes of the reference that leaves most lanes of a tile without any
         // memory access beyond the mask bytes.
-        const int mleft = __shfl_up((int)mine, 1, 64), mright = __shfl_down((int)mine, 1, 64);  // (not inside a short-circuit: every lane must execute the shuffles)
+        const int mleft = __shfl_up((int)mine, 1, ROWL), mright = __shfl_down((int)mine, 1, ROWL);  // (not inside a short-circuit: every lane must execute the shuffles)
         const bool on = !PRED || mine || mleft != 0 || mright != 0;
         // All loads of the tile are issued in one predicated block (one exec-mask region, no dependent waits in between):
         // the kernel is latency-bound at the sizes of the reference's scenes, not bandwidth-bound.
@@ -461,13 +467,12 @@ __global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_vi
             W0 = ldv<NV>(xw + c); Wjm = ldv<NV>(xw + c - sy); Wjp = ldv<NV>(xw + c + sy); Wkm = ldv<NV>(xw + c - sz); Wkp = ldv<NV>(xw + c + sz);
             Vjpkm = ldv<NV>(xv + c + sy - sz); Wjmkp = ldv<NV>(xw + c - sy + sz);
             RU = ldv<NV>(v.r[0] + c); RV = ldv<NV>(v.r[1] + c); RW = ldv<NV>(v.r[2] + c);
-            const int lane = threadIdx.x & 63;
-            if (lane == 0 && i0 > 0) {
+            if (d_row_first() && i0 > 0) {
                 eC0l = fC[c - 1];
                 eU0l = xu[c - 1]; eV0l = xv[c - 1]; eW0l = xw[c - 1];
                 eVjpl = xv[c + sy - 1]; eWkpl = xw[c + sz - 1];
             }
-            if (lane == 63 && i0 + NV < I) {
+            if (d_row_last() && i0 + NV < I) {
                 eEW0r = fEW[c + NV]; eEV0r = fEV[c + NV];
                 eU0r = xu[c + NV]; eV0r = xv[c + NV]; eW0r = xw[c + NV];
                 eUjmr = xu[c - sy + NV]; eUkmr = xu[c - sz + NV];
@@ -578,7 +583,7 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     const int cap = c->prm.reserved[5] > 0 ? c->prm.reserved[5] : (NV == 4 ? 512 : 1024);
     if (nb > cap) nb = cap;
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
-    if (timed) fv_ev_begin(c, 1, (double)count * (64 * NV * TY));
+    if (timed) fv_ev_begin(c, 1, (double)count * (ROWL * NV * TY));
     if (NV == 4 && c->vPred)
         hipLaunchKernelGGL((k_visc_spmv<T, 4, true>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
                            c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it);
@@ -671,7 +676,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     c->vwV = 4;
     if (c->prm.reserved[3] == 2 || c->prm.reserved[3] == 4) c->vwV = c->prm.reserved[3];  // measurement switch: forced lane width
     c->vPred = fill <= 0.35;
-    c->tgV.ntx = (L.PX + 64 * c->vwV - 1) / (64 * c->vwV);
+    c->tgV.ntx = (L.PX + ROWL * c->vwV - 1) / (ROWL * c->vwV);
     rc = fv_build_tiles(c, c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV);
     if (rc) return rc;
     if (c->comm) {
@@ -792,6 +797,6 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *ms = (double)t / reps;
-    *cells = (double)c->nActiveV * (64 * c->vwV * TY);
+    *cells = (double)c->nActiveV * (ROWL * c->vwV * TY);
     return FLIPV_OK;
 }

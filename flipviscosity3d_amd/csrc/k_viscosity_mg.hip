@@ -133,12 +133,9 @@ __global__ __launch_bounds__(256) void k_vmg_rap_fine(const int *__restrict__ ti
         const int slot = d_tile_slot(bb, ntiles);
         if (slot >= ntiles) continue;
         const int tile = tiles[slot];
-        const int tx = tile % tg.ntx, t2 = tile / tg.ntx;
-        const int k = t2 / tg.nty, j = (t2 % tg.nty) * TY + threadIdx.y;
-        if (j >= L.PY) continue;
         for (int e = 0; e < 4; e++) {
-            const int i = tx * 256 + e * 64 + threadIdx.x;
-            if (i >= L.PX) continue;
+            int i, j, k;
+            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
             const size_t ci = gidx(L, i, j, k);
             const unsigned m = A.mask[ci];
             if (!m) continue;
@@ -282,13 +279,10 @@ __global__ __launch_bounds__(256) void k_vmg_fine(const int *__restrict__ tiles,
         const int slot = d_tile_slot(bb, ntiles);
         if (slot >= ntiles) continue;
         const int tile = tiles[slot];
-        const int tx = tile % tg.ntx, t2 = tile / tg.ntx;
-        const int k = t2 / tg.nty, j = (t2 % tg.nty) * TY + threadIdx.y;
-        if (j >= L.PY) continue;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int i = tx * 256 + e * 64 + threadIdx.x;
-            if (i >= L.PX) continue;
+            int i, j, k;
+            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
             const size_t ci = gidx(L, i, j, k);
             const unsigned m = mask[ci];
             if (!m) continue;
@@ -328,13 +322,10 @@ __global__ __launch_bounds__(256) void k_vpcg_xr(const int *__restrict__ tiles, 
         const int slot = d_tile_slot(bb, ntiles);
         if (slot >= ntiles) continue;
         const int tile = tiles[slot];
-        const int tx = tile % tg.ntx, t2 = tile / tg.ntx;
-        const int k = t2 / tg.nty, j = (t2 % tg.nty) * TY + threadIdx.y;
-        if (j >= L.PY) continue;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int i = tx * 256 + e * 64 + threadIdx.x;
-            if (i >= L.PX) continue;
+            int i, j, k;
+            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
             const size_t ci = gidx(L, i, j, k);
             const unsigned m = mask[ci];
             if (!m) continue;
@@ -371,13 +362,10 @@ __global__ __launch_bounds__(256) void k_vpcg_p(const int *__restrict__ tiles, i
         const int slot = d_tile_slot(bb, ntiles);
         if (slot >= ntiles) continue;
         const int tile = tiles[slot];
-        const int tx = tile % tg.ntx, t2 = tile / tg.ntx;
-        const int k = t2 / tg.nty, j = (t2 % tg.nty) * TY + threadIdx.y;
-        if (j >= L.PY) continue;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const int i = tx * 256 + e * 64 + threadIdx.x;
-            if (i >= L.PX) continue;
+            int i, j, k;
+            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
             const size_t ci = gidx(L, i, j, k);
             const unsigned m = mask[ci];
             if (!m) continue;

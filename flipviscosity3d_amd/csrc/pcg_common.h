@@ -77,8 +77,9 @@ template <> __device__ __forceinline__ double d_recip<double>(float d) { return 
 // lane i <- lane i-1 / lane i+1 of the wave as a DPP move (wave_shr:1 / wave_shl:1 exist on gfx9-family ISAs, gfx950
 // included): one VALU instruction instead of a ds_bpermute round trip through the LDS pipe.  Lane 0 / lane 63 keep
 // their own value; callers overwrite those lanes with the value fetched from memory.
-__device__ __forceinline__ int d_dpp_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }    // wave_shr:1
-__device__ __forceinline__ int d_dpp_down1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }  // wave_shl:1
+// With 16-lane rows the same thing per row: row_shr:1 / row_shl:1, the first / last lane of each row keeps its value.
+__device__ __forceinline__ int d_dpp_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, ROWL == 64 ? 0x138 : 0x111, 0xf, 0xf, false); }    // wave_shr:1 | row_shr:1
+__device__ __forceinline__ int d_dpp_down1(int v) { return __builtin_amdgcn_update_dpp(v, v, ROWL == 64 ? 0x130 : 0x101, 0xf, 0xf, false); }  // wave_shl:1 | row_shl:1
 __device__ __forceinline__ float wave_up1(float v) { return __int_as_float(d_dpp_up1(__float_as_int(v))); }
 __device__ __forceinline__ float wave_down1(float v) { return __int_as_float(d_dpp_down1(__float_as_int(v))); }
 __device__ __forceinline__ int wave_up1(int v) { return d_dpp_up1(v); }
@@ -100,13 +101,13 @@ __device__ __forceinline__ double wave_down1(double v) {
 template <typename T, int N>
 __device__ __forceinline__ T nb_left(const Vec<T, N> &a, const T *__restrict__ p, int i0) {
     T v = wave_up1(a.v[N - 1]);
-    if ((threadIdx.x & 63) == 0) v = i0 > 0 ? p[-1] : (T)0;
+    if (d_row_first()) v = i0 > 0 ? p[-1] : (T)0;
     return v;
 }
 template <typename T, int N>
 __device__ __forceinline__ T nb_right(const Vec<T, N> &a, const T *__restrict__ p, int i0, int w) {
     T v = wave_down1(a.v[0]);
-    if ((threadIdx.x & 63) == 63) v = i0 + N < w ? p[N] : (T)0;
+    if (d_row_last()) v = i0 + N < w ? p[N] : (T)0;
     return v;
 }
 
@@ -230,8 +231,8 @@ __device__ __forceinline__ bool d_tile_coords(int b, const int *__restrict__ til
     const int t2 = tile / tg.ntx;
     const int ty = t2 % tg.nty;
     k = t2 / tg.nty;
-    i0 = tx * (64 * N) + threadIdx.x * N;
-    j = ty * TY + threadIdx.y;
+    i0 = tx * (ROWL * N) + d_tcol() * N;
+    j = ty * TY + d_trow();
     return true;
 }
 
@@ -259,9 +260,21 @@ __device__ __forceinline__ bool d_tile_decode(int tile, const TileGrid &tg, cons
     const int t2 = tile / tg.ntx;
     const int ty = t2 % tg.nty;
     k = t2 / tg.nty;
-    i0 = tx * (64 * N) + threadIdx.x * N;
-    j = ty * TY + threadIdx.y;
+    i0 = tx * (ROWL * N) + d_tcol() * N;
+    j = ty * TY + d_trow();
     return i0 < L.PX && j < L.PY;
+}
+// a block walking a tile index by index (N indices per thread, consecutive threads take consecutive i): index e of this thread
+template <int N>
+__device__ __forceinline__ bool d_tile_cell(int tile, const TileGrid &tg, int e, int &i, int &j, int &k) {
+    if (tile < 0) return false;
+    constexpr int TW = ROWL * N;  // TW x TY = 256 N indices
+    const int tx = tile % tg.ntx, t2 = tile / tg.ntx;
+    const int idx = e * 256 + (int)(threadIdx.y * 64 + threadIdx.x);
+    k = t2 / tg.nty;
+    j = (t2 % tg.nty) * TY + idx / TW;
+    i = tx * TW + idx % TW;
+    return true;
 }
 // the mask words of this lane for the TBATCH tiles (0 where the lane is outside / there is no tile)
 template <int N>
@@ -273,21 +286,43 @@ __device__ __forceinline__ void d_fetch_masks(const TileBatch &B, const TileGrid
         mk[t] = d_tile_decode<N>(B.id[t], tg, L, i0, j, k) ? ld_mask<N>(mask + gidx(L, i0, j, k)) : 0u;
     }
 }
+// One batch of look-ahead on top: the ids and masks of a block's FIRST batch are requested before the kernel's scalar
+// prologue (iteration number, stop flag, dot products -- none of which the tile list depends on), those of the next
+// batch before the current one is walked.
+template <int N>
+struct TileWalk {
+    TileBatch B;
+    unsigned mk[TBATCH];
+    __device__ __forceinline__ void fetch(int base, int nvb, const int *__restrict__ tiles, int ntiles, const TileGrid &tg, const Lay &L,
+                                          const uint8_t *__restrict__ mask) {
+        if (base < nvb) {
+            B = d_fetch_tiles(base, nvb, tiles, ntiles);
+            if (mask) d_fetch_masks<N>(B, tg, L, mask, mk);
+            else { mk[0] = mk[1] = mk[2] = mk[3] = 0xffu; }
+        } else {
+            B.id[0] = B.id[1] = B.id[2] = B.id[3] = -1;
+            mk[0] = mk[1] = mk[2] = mk[3] = 0u;
+        }
+    }
+};
 __device__ __forceinline__ int d_pick(const int v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ unsigned d_pick(const unsigned v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 
 __device__ __forceinline__ bool d_pass(const PcgScal &sc, double res) { return sc.tol_inclusive ? (res <= sc.tol) : (res < sc.tol); }
 
 // K1 prologue shared by both SpMV kernels: returns true if the launch must do nothing
-__device__ __forceinline__ int d_iter_spmv(const PcgScal &sc, int it_arg) {
-    if (it_arg >= 0 || !sc.conv) return it_arg < 0 ? 0 : it_arg;
-    const int it = *sc.itA;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.itB = it;
+// (the stop flag and the iteration counter are fetched together, not one after the other)
+__device__ __forceinline__ int d_iter_spmv(const PcgScal &sc, int it_arg, bool &stop) {
+    stop = false;
+    if (!sc.conv) return it_arg < 0 ? 0 : it_arg;  // benchmark launches
+    const int conv = *sc.conv;
+    int it = it_arg;
+    if (it_arg < 0) {
+        it = *sc.itA;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.itB = it;
+    }
+    stop = conv >= 0 || it >= sc.cap;
     return it;
-}
-__device__ __forceinline__ bool d_spmv_stop(const PcgScal &sc, int it) {
-    if (!sc.conv) return false;  // benchmark launches
-    return *sc.conv >= 0 || it >= sc.cap;
 }
 
 template <typename T, int NC, int N>
@@ -322,8 +357,13 @@ __global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ tiles,
 template <typename T, int NC, int N>
 __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
                                                     PcgSys<T, NC> v, PcgScal sc, int it_arg) {
-    if (*sc.conv >= 0) return;
-    const int it = it_arg >= 0 ? it_arg : *sc.itB;
+    const int nvb = ((ntiles + 7) >> 3) << 3;
+    const int stride = TBATCH * (int)gridDim.x;
+    TileWalk<N> cur;
+    cur.fetch(blockIdx.x, nvb, tiles, ntiles, tg, L, v.mask);
+    const int conv_now = *sc.conv, itB_now = it_arg >= 0 ? it_arg : *sc.itB;   // two independent loads
+    if (conv_now >= 0) return;
+    const int it = itB_now;
     if (it >= sc.cap) return;
     __shared__ double lds[8];
     // One prologue fetch: rmax(it-1), sig(it), a(it), b(it), c(it) are 5 x NSLOT contiguous doubles (for it = 0 there is no
@@ -360,11 +400,12 @@ __global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tile
     double acc = 0.0;
     float mxf = 0.0f;  // max|r| over this thread's rows, tracked in the storage precision of r
     double mxd = 0.0;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
-      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
-      unsigned mks[TBATCH] = {0xffu, 0xffu, 0xffu, 0xffu};
-      if (v.mask) d_fetch_masks<N>(B, tg, L, v.mask, mks);
+    for (int base = blockIdx.x; base < nvb; base += stride) {
+      TileWalk<N> nxt;
+      nxt.fetch(base + stride, nvb, tiles, ntiles, tg, L, v.mask);
+      const TileBatch B = cur.B;
+      unsigned mks[TBATCH] = {cur.mk[0], cur.mk[1], cur.mk[2], cur.mk[3]};
+      cur = nxt;
 #pragma unroll 1
       for (int t = 0; t < TBATCH; t++) {
         if (!d_tile_decode<N>(d_pick(B.id, t), tg, L, i0, j, k)) continue;
