@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libflipv.so")
+LIB_PATH = os.environ.get("FLIPV_LIB") or os.path.join(_PKG, "libflipv.so")   # FLIPV_LIB: A/B builds (tools/ab_lib.sh)
 
 GRID_IDS = dict(U=0, V=1, W=2, SAVED_U=3, SAVED_V=4, SAVED_W=5, VALID_U=6, VALID_V=7, VALID_W=8,
                 LIQUID_PHI=9, SOLID_PHI=10, WEIGHT_U=11, WEIGHT_V=12, WEIGHT_W=13, VISCOSITY=14,

@@ -161,10 +161,22 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
     memset(c->h_flags, 0, 16 * sizeof(int));
     // solver tiles over the shared index space
-    c->tgP.ntx = (L.PX + ROWL * VW_P - 1) / (ROWL * VW_P); c->tgP.nty = (L.PY + TY - 1) / TY; c->tgP.ntz = L.PZ;
-    c->tgV.ntx = (L.PX + ROWL * VW_V - 1) / (ROWL * VW_V); c->tgV.nty = (L.PY + TY - 1) / TY; c->tgV.ntz = L.PZ;
+    // the geometry is chosen per solve (fv_build_tiles); FLIPV_ROWL = 16 | 64 pins it (tests, A/B measurements)
     {
-        const size_t ntmax = (size_t)(c->tgP.count() > c->tgV.count() ? c->tgP.count() : c->tgV.count()) * 2 + 64;  // virtual enumeration pads nty to a multiple of 4
+        const char *e = getenv("FLIPV_ROWL");
+        c->forceRowl = e ? atoi(e) : 0;
+        if (c->forceRowl != 16 && c->forceRowl != 64) c->forceRowl = 0;
+    }
+    c->tgP = make_tile_grid(L, c->forceRowl ? c->forceRowl : 64, VW_P);
+    c->tgV = make_tile_grid(L, c->forceRowl ? c->forceRowl : 64, VW_V);
+    {
+        size_t ntmax = 0;   // the largest tile grid of any geometry and lane width; the virtual enumeration pads nty to a multiple of 4
+        for (int rl = 16; rl <= 64; rl *= 4)
+            for (int vw = 2; vw <= 4; vw *= 2) {
+                const TileGrid g = make_tile_grid(L, rl, vw);
+                const size_t n = (size_t)g.ntx * (size_t)((g.nty + 3) / 4 * 4) * (size_t)g.ntz + 64;
+                if (n > ntmax) ntmax = n;
+            }
         int rc_ = plain_alloc(c, &c->tileListP, ntmax);
         if (!rc_) rc_ = plain_alloc(c, &c->tileListV, ntmax);
         if (!rc_) rc_ = plain_alloc(c, &c->tileFlag, ntmax);

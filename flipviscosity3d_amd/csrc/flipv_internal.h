@@ -47,30 +47,25 @@ __host__ __device__ __forceinline__ void lat_dims(const Lay &L, int lat, int &w,
     d = L.K + (lat == LAT_W || lat == LAT_NODE || lat == LAT_EU || lat == LAT_EV);
 }
 
-// Solver tiles: (ROWL N) x TY x 1 indices, one 256-thread block (64, 4, 1) per tile.  A lane owns N consecutive i
-// (one 16-byte access for N = 4); a wave is ROWL lanes along i by WROWS = 64/ROWL rows along j, the block's four waves
-// stack along j.  ROWL = 16 (tiles of 64 x 16 indices for N = 4) keeps the tiles of a compact liquid body twice as
-// full as ROWL = 64 (256 x 4) does -- the kernels are bound by the number of tiles a block walks, not by bytes -- and
-// the i-neighbour exchange is a DPP row shift either way.  N = VW_P for the pressure solve, VW_V..4 for viscosity.
-#ifndef FLIPV_ROWL
-#define FLIPV_ROWL 16
-#endif
-constexpr int ROWL = FLIPV_ROWL;
-static_assert(ROWL == 16 || ROWL == 64, "a wave is 16 x 4 or 64 x 1 lanes");
-constexpr int WROWS = 64 / ROWL;
-constexpr int TY = 4 * WROWS;
+// Solver tiles: (ROWL N) x TY x 1 indices, one 256-thread block (64, 4, 1) per tile; see pcg_geo.inc.  ROWL (16 or 64 lanes
+// of a wave along i) is chosen per solve from how full the tiles are; TY = 4 * 64 / ROWL.
 constexpr int VW_P = 4;          // 7-point stencil, 72 VGPRs: 16-byte accesses
 constexpr int VW_V = 2;          // narrowest lane width of the viscosity kernels (2 or 4 is chosen per solve)
-// this lane's column (in units of N indices) and row inside its tile; first / last lane of a row of the wave
-__device__ __forceinline__ int d_tcol() { return (int)threadIdx.x & (ROWL - 1); }
-__device__ __forceinline__ int d_trow() { return (int)threadIdx.y * WROWS + ((int)threadIdx.x / ROWL); }
-__device__ __forceinline__ bool d_row_first() { return ((int)threadIdx.x & (ROWL - 1)) == 0; }
-__device__ __forceinline__ bool d_row_last() { return ((int)threadIdx.x & (ROWL - 1)) == ROWL - 1; }
+static inline int geo_ty(int rowl) { return 4 * (64 / rowl); }
 
 struct TileGrid {
     int ntx, nty, ntz;
+    int rowl;   // 16 or 64: which geometry the grid (and the tile list built on it) belongs to
     __host__ __device__ int count() const { return ntx * nty * ntz; }
 };
+static inline TileGrid make_tile_grid(const Lay &L, int rowl, int vw) {
+    TileGrid tg;
+    tg.rowl = rowl;
+    tg.ntx = (L.PX + rowl * vw - 1) / (rowl * vw);
+    tg.nty = (L.PY + geo_ty(rowl) - 1) / geo_ty(rowl);
+    tg.ntz = L.PZ;
+    return tg;
+}
 
 struct Comm;
 
@@ -130,6 +125,7 @@ struct flipv_context {
 
     // solver tiles
     TileGrid tgP, tgV;
+    int forceRowl = 0;   // FLIPV_ROWL: 16 or 64 pins the tile geometry, 0 = chosen per solve
     int *tileListP, *tileListV;
     int *tileFlag;
     int nActiveP, nActiveV;

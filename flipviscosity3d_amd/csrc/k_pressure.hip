@@ -88,96 +88,6 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
     }
 }
 
-// K12: q = A s with the three fused dot products (pressuresolver.cpp:464-499; term order -i,+i,-j,+j,-k,+k, diagonal).
-// No branches on cell type: all coefficients of a non-pressure cell (and of every padding / guard entry) are zero.
-template <typename T>
-__global__ __launch_bounds__(256) void k_pressure_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
-                                                       const float *__restrict__ diag, const float *__restrict__ pi,
-                                                       const float *__restrict__ pj, const float *__restrict__ pk,
-                                                       const uint8_t *__restrict__ cellmask, const T *__restrict__ s,
-                                                       const RT<T> *__restrict__ r, T *__restrict__ q, PcgScal sc, int it_arg) {
-    __shared__ double lds[12];
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    const int stride = TBATCH * (int)gridDim.x;
-    TileWalk<VW_P> cur;
-    cur.fetch(blockIdx.x, nvb, tiles, ntiles, tg, L, cellmask);
-    bool stop;
-    const int it = d_iter_spmv(sc, it_arg, stop);
-    if (stop) return;
-    int i0, j, k;
-    double da = 0.0, db = 0.0, dc = 0.0;
-    for (int base = blockIdx.x; base < nvb; base += stride) {
-      TileWalk<VW_P> nxt;
-      nxt.fetch(base + stride, nvb, tiles, ntiles, tg, L, cellmask);
-      const TileBatch B = cur.B;
-      const unsigned mks[TBATCH] = {cur.mk[0], cur.mk[1], cur.mk[2], cur.mk[3]};
-      cur = nxt;
-#pragma unroll 1
-      for (int t = 0; t < TBATCH; t++) {
-        // a lane without pressure cells has nothing to compute or store (q is only read where diag != 0, s is 0 off the
-        // pressure cells); it only has to load if a neighbouring lane, which takes its i+-1 values from it, has cells
-        const bool inside = d_tile_decode<VW_P>(d_pick(B.id, t), tg, L, i0, j, k);
-        const bool mine = inside && d_pick(mks, t) != 0u;
-        if (!__any(mine)) continue;
-        if (!inside) continue;
-        const size_t c = gidx(L, i0, j, k);
-        const long sy = L.sy, sz = L.sz;
-        const int mleft = __shfl_up((int)mine, 1, ROWL), mright = __shfl_down((int)mine, 1, ROWL);  // outside any short-circuit
-        const bool on = mine || mleft != 0 || mright != 0;
-        // every load of the tile in one predicated block (the kernel is latency-bound on the reference's scenes)
-        Vec<float, 4> dg{}, ci{}, cj{}, ck{}, cjm{}, ckm{};
-        Vec<T, 4> sc4{}, sjm{}, sjp{}, skm{}, skp{};
-        Vec<RT<T>, 4> r4{};
-        T esl = (T)0, esr = (T)0;
-        float ecil = 0.0f;
-        if (on) {
-            dg = ldv<4>(diag + c);
-            ci = ldv<4>(pi + c); cj = ldv<4>(pj + c); ck = ldv<4>(pk + c);
-            cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
-            sc4 = ldv<4>(s + c); sjm = ldv<4>(s + c - sy); sjp = ldv<4>(s + c + sy); skm = ldv<4>(s + c - sz); skp = ldv<4>(s + c + sz);
-            r4 = ldv<4>(r + c);
-            if (d_row_first() && i0 > 0) { esl = s[c - 1]; ecil = pi[c - 1]; }
-            if (d_row_last() && i0 + 4 < L.I) esr = s[c + 4];
-        }
-        T sl = wave_up1(sc4.v[3]), sr = wave_down1(sc4.v[0]);
-        float cil = wave_up1(ci.v[3]);
-        if (d_row_first()) { sl = esl; cil = ecil; }
-        if (d_row_last()) sr = esr;
-        Vec<T, 4> y;
-        T ta = (T)0, tb = (T)0, tc = (T)0;  // this lane's four cells in the vector precision, folded into fp64 once per tile
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const T sm = e > 0 ? sc4.v[e - 1] : sl;
-            const T sp = e < 3 ? sc4.v[e + 1] : sr;
-            const float cim = e > 0 ? ci.v[e - 1] : cil;
-            T acc = sm * (T)cim;
-            acc += sp * (T)ci.v[e];
-            acc += sjm.v[e] * (T)cjm.v[e];
-            acc += sjp.v[e] * (T)cj.v[e];
-            acc += skm.v[e] * (T)ckm.v[e];
-            acc += skp.v[e] * (T)ck.v[e];
-            acc += sc4.v[e] * (T)dg.v[e];
-            y.v[e] = acc;
-            if (dg.v[e] != 0.0f) {
-                const T yi = acc * d_recip<T>(dg.v[e]);
-                ta += sc4.v[e] * acc;
-                tb += (T)r4.v[e] * yi;
-                tc += acc * yi;
-            }
-        }
-        da += (double)ta; db += (double)tb; dc += (double)tc;
-        if (mine) stv(q + c, y);
-      }
-    }
-    block_sum3_256(da, db, dc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
-        const int sl = sc.my_slot();
-        if (da != 0.0) atomicAdd(sc.a(it) + sl, da);
-        if (db != 0.0) atomicAdd(sc.b(it) + sl, db);
-        if (dc != 0.0) atomicAdd(sc.c(it) + sl, dc);
-    }
-}
-
 template <typename T>
 static __global__ void k_copy_to_f32(const T *__restrict__ a, float *__restrict__ o, size_t n) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,7 +100,10 @@ static __global__ void k_copy_to_f32(const T *__restrict__ a, float *__restrict_
 // (16 grid rows) wide in j and runs through all owned k-planes.  Consecutive blocks of an XCD then work on consecutive
 // planes of the same narrow column, so the k+-1 planes every stencil row re-reads are still in that XCD's 4 MiB L2
 // (a whole k-plane of the ~19 arrays the viscosity SpMV touches is ~5 MB and would not be).
-constexpr int JCH = 4;
+#ifndef FLIPV_JCH
+#define FLIPV_JCH 4
+#endif
+constexpr int JCH = FLIPV_JCH;
 __device__ __forceinline__ int d_virtual_tile(int v, const TileGrid &tg, int k0, int nk) {
     const int tx = v % tg.ntx;
     int r = v / tg.ntx;
@@ -202,29 +115,17 @@ __device__ __forceinline__ int d_virtual_tile(int v, const TileGrid &tg, int k0,
     return tx + tg.ntx * (ty + tg.nty * (k0 + kk));
 }
 
-// flag[v] = 1 if virtual tile v holds at least one unknown (diag != 0) of any component
-__global__ __launch_bounds__(256) void k_tile_flags(TileGrid tg, Lay L, int vw, int nc, const float *__restrict__ d0,
-                                                    const float *__restrict__ d1, const float *__restrict__ d2,
-                                                    const uint8_t *__restrict__ mask, int *__restrict__ flag, int k0, int nk) {
-    const int tile = d_virtual_tile(blockIdx.x, tg, k0, nk);
-    int any = 0;
-    if (tile >= 0) {
-        const int tx = tile % tg.ntx, t2 = tile / tg.ntx, ty = t2 % tg.nty, k = t2 / tg.nty;
-        const int i0 = tx * ROWL * vw + d_tcol() * vw, j = ty * TY + d_trow();
-        if (i0 < L.PX && j < L.PY) {
-            const size_t c = gidx(L, i0, j, k);
-            const float *dd[3] = {d0, d1, d2};
-            if (mask) {  // one byte per index instead of nc floats
-                for (int e = 0; e < vw; e++) any |= mask[c + e] != 0;
-            } else {
-                for (int m = 0; m < nc; m++)
-                    for (int e = 0; e < vw; e++) any |= dd[m][c + e] != 0.0f;
-            }
-        }
-    }
-    const int r = __syncthreads_or(any);
-    if (threadIdx.x == 0 && threadIdx.y == 0) flag[blockIdx.x] = r;
-}
+// ---- the kernels that depend on the tile geometry, once per geometry (pcg_geo.inc)
+namespace g16 {
+constexpr int ROWL = 16;
+#include "pcg_geo.inc"
+#include "k_pressure_geo.inc"
+}  // namespace g16
+namespace g64 {
+constexpr int ROWL = 64;
+#include "pcg_geo.inc"
+#include "k_pressure_geo.inc"
+}  // namespace g64
 
 // ordered compaction of the flagged tiles by one block (tile counts are 1e4..1e5)
 // mode 0: every flagged tile; 1: only tiles of the interior planes (k0 < k < k0+nk-1); 2: only tiles of the two boundary
@@ -287,11 +188,11 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     *extra = c->d_scal + 5 * n;
 }
 
-int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   const uint8_t *mask, int *list, int *nActive, int *nInterior) {
+static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
+                            const uint8_t *mask, int *list, int *nActive, int *nInterior) {
     const int nk = c->k1 - c->k0, nchunks = (tg.nty + JCH - 1) / JCH;
     const int nt = tg.ntx * JCH * nk * nchunks;  // virtual tiles of the owned planes (column-major enumeration)
-    hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, mask, c->tileFlag, c->k0, nk);
+    GEO_RUN(tg.rowl, hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, mask, c->tileFlag, c->k0, nk));
     if (!c->comm) {
         hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 0,
                            (const int *)nullptr);
@@ -313,13 +214,27 @@ int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const f
     return FLIPV_OK;
 }
 
+int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex) {
+    int rowl = c->forceRowl ? c->forceRowl : tg->rowl;
+    *tg = make_tile_grid(c->L, rowl, vw);
+    int rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior);
+    if (rc || c->forceRowl || *nActive <= 0) return rc;
+    // how full the tiles are: indices with unknowns / indices of the listed tiles (256 vw each, either geometry)
+    const double fill = ((double)*hostCount / perIndex) / ((double)*nActive * 256.0 * vw);
+    const int want = (rowl == 64 && fill < 0.45) ? 16 : ((rowl == 16 && fill > 0.80) ? 64 : rowl);
+    if (want == rowl) return FLIPV_OK;
+    *tg = make_tile_grid(c->L, want, vw);
+    return build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior);
+}
+
 template <typename T>
 static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
     const int nb = pcg_grid(c, count);
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
-    if (timed) fv_ev_begin(c, 0, (double)count * (ROWL * VW_P * TY));
-    hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it);
+    if (timed) fv_ev_begin(c, 0, (double)count * (256 * VW_P));
+    GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
+                       c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it));
     if (timed) fv_ev_end(c);
 }
 
@@ -330,7 +245,6 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const Lay &L = c->L;
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
-    li.total_tiles = c->tgP.count();
     const int cap = c->prm.pressure_max_iterations;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
@@ -352,7 +266,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->k0, c->k1, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    rc = fv_build_tiles(c, c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP);  // synchronises: h_scal[0] = max|b|
+    rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
     {
         float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)
@@ -363,6 +277,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const double bnorm = c->h_scal[0];
     li.rhs_norm = bnorm;
     li.active_tiles = c->nActiveP;
+    li.total_tiles = c->tgP.count();
     li.rows = c->h_flags[2];  // pressure cells of this rank
     c->pressureReady = 1;
     c->pressurePrec = f32 ? 0 : 1;
@@ -395,11 +310,11 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
         const int nb = pcg_grid(c, c->nActiveP);
         const dim3 blk(64, 4, 1);
         const HaloArray sh[1] = {{c->pS, sizeof(T)}};
-        hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc);
+        GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc));
         if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
         auto spmv = [&](int first, int count, int it) { launch_pressure_spmv<T>(c, sc, it, first, count); };
         auto update = [&](int it) {
-            hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it));
         };
         if ((rc = pcg_run(c, sc, cap, sh, 1, c->nIntP, c->nActiveP, spmv, update, &conv))) return rc;
     }
@@ -449,6 +364,6 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *ms = (double)t / reps;
-    *cells = (double)c->nActiveP * (ROWL * VW_P * TY);
+    *cells = (double)c->nActiveP * (256 * VW_P);
     return FLIPV_OK;
 }

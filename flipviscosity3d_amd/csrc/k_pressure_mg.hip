@@ -218,230 +218,17 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
     }
 }
 
-// ---- level 0, vectorised like the SpMV kernel (4 consecutive cells per lane, 16-byte loads, i-neighbours by DPP, lanes
-// without cells predicated off).  The pre-smoothed iterate x0 = omega r/d is written by the PCG's vector kernels.
-// down: t = r - A x0 is never stored: it goes straight into the coarse right-hand side (8 children per aggregate, the two
-// i-neighbours of a lane are pre-added: 2 atomics per lane)
-__global__ __launch_bounds__(256) void k_mg_down0(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L, Lay C,
-                                                  const float *__restrict__ diag, const float *__restrict__ pi,
-                                                  const float *__restrict__ pj, const float *__restrict__ pk,
-                                                  const uint8_t *__restrict__ cellmask, const float *__restrict__ x0,
-                                                  const float *__restrict__ r, float *__restrict__ bc) {
-    int i0, j, k;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
-      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
-      unsigned mks[TBATCH];
-      d_fetch_masks<VW_P>(B, tg, L, cellmask, mks);
-#pragma unroll 1
-      for (int t = 0; t < TBATCH; t++) {
-        const bool inside = d_tile_decode<VW_P>(d_pick(B.id, t), tg, L, i0, j, k);
-        const bool mine = inside && d_pick(mks, t) != 0u;
-        if (!__any(mine)) continue;
-        if (!inside) continue;
-        const size_t c = gidx(L, i0, j, k);
-        const long sy = L.sy, sz = L.sz;
-        const bool lfirst = d_row_first(), llast = d_row_last();
-        int mleft = wave_up1((int)mine), mright = wave_down1((int)mine);
-        if (lfirst) mleft = 0;
-        if (llast) mright = 0;
-        const bool on = mine || mleft != 0 || mright != 0;
-        Vec<float, 4> dg{}, ci{}, cj{}, ck{}, cjm{}, ckm{}, xc4{}, xjm{}, xjp{}, xkm{}, xkp{}, r4{};
-        float exl = 0.0f, exr = 0.0f, ecil = 0.0f;
-        if (on) {
-            dg = ldv<4>(diag + c);
-            ci = ldv<4>(pi + c); cj = ldv<4>(pj + c); ck = ldv<4>(pk + c);
-            cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
-            if (k - 1 < L.kb) ckm = Vec<float, 4>{};   // rank-local operator: no coupling across the slab faces
-            if (k + 1 >= L.ke) ck = Vec<float, 4>{};
-            xc4 = ldv<4>(x0 + c); xjm = ldv<4>(x0 + c - sy); xjp = ldv<4>(x0 + c + sy); xkm = ldv<4>(x0 + c - sz); xkp = ldv<4>(x0 + c + sz);
-            r4 = ldv<4>(r + c);
-            if (lfirst && i0 > 0) { exl = x0[c - 1]; ecil = pi[c - 1]; }
-            if (llast && i0 + 4 < L.I) exr = x0[c + 4];
-        }
-        float xl = wave_up1(xc4.v[3]), xr = wave_down1(xc4.v[0]), cil = wave_up1(ci.v[3]);
-        if (lfirst) { xl = exl; cil = ecil; }
-        if (llast) xr = exr;
-        float res[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float xm = e > 0 ? xc4.v[e - 1] : xl;
-            const float xp = e < 3 ? xc4.v[e + 1] : xr;
-            const float cim = e > 0 ? ci.v[e - 1] : cil;
-            float acc = xm * cim;
-            acc += xp * ci.v[e];
-            acc += xjm.v[e] * cjm.v[e];
-            acc += xjp.v[e] * cj.v[e];
-            acc += xkm.v[e] * ckm.v[e];
-            acc += xkp.v[e] * ck.v[e];
-            acc += xc4.v[e] * dg.v[e];
-            res[e] = dg.v[e] != 0.0f ? r4.v[e] - acc : 0.0f;
-        }
-        if (mine) {
-            const size_t pc = gidx(C, i0 >> 1, j >> 1, k >> 1);
-            const float s01 = res[0] + res[1], s23 = res[2] + res[3];
-            if (s01 != 0.0f) atomicAdd(bc + pc, s01);
-            if (s23 != 0.0f) atomicAdd(bc + pc + 1, s23);
-        }
-      }
-    }
-}
-
-// up: y = x0 + over * xc[parent], z = y + omega (r - A y)/d: the preconditioned residual, with (r, z) for the PCG
-__global__ __launch_bounds__(256) void k_mg_up0(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L, Lay C,
-                                                const float *__restrict__ diag, const float *__restrict__ pi,
-                                                const float *__restrict__ pj, const float *__restrict__ pk,
-                                                const uint8_t *__restrict__ cellmask, const float *__restrict__ x0,
-                                                const float *__restrict__ r, const float *__restrict__ xc, float *__restrict__ z,
-                                                PcgScal sc, int it_next) {
-    __shared__ double lds[4];
-    double acc_rz = 0.0;
-    int i0, j, k;
-    const float over = MG_OVER, omega = MG_OMEGA;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int base = blockIdx.x; base < nvb; base += TBATCH * (int)gridDim.x) {
-      const TileBatch B = d_fetch_tiles(base, nvb, tiles, ntiles);
-      unsigned mks[TBATCH];
-      d_fetch_masks<VW_P>(B, tg, L, cellmask, mks);
-#pragma unroll 1
-      for (int t = 0; t < TBATCH; t++) {
-        const bool inside = d_tile_decode<VW_P>(d_pick(B.id, t), tg, L, i0, j, k);
-        const bool mine = inside && d_pick(mks, t) != 0u;
-        if (!__any(mine)) continue;
-        if (!inside) continue;
-        const size_t c = gidx(L, i0, j, k);
-        const long sy = L.sy, sz = L.sz;
-        const bool lfirst = d_row_first(), llast = d_row_last();
-        int mleft = wave_up1((int)mine), mright = wave_down1((int)mine);
-        if (lfirst) mleft = 0;
-        if (llast) mright = 0;
-        const bool on = mine || mleft != 0 || mright != 0;
-        Vec<float, 4> dg{}, ci{}, cj{}, ck{}, cjm{}, ckm{}, y0{}, yjm{}, yjp{}, ykm{}, ykp{}, r4{};
-        float eyl = 0.0f, eyr = 0.0f, ecil = 0.0f;
-        if (on) {
-            dg = ldv<4>(diag + c);
-            ci = ldv<4>(pi + c); cj = ldv<4>(pj + c); ck = ldv<4>(pk + c);
-            cjm = ldv<4>(pj + c - sy); ckm = ldv<4>(pk + c - sz);
-            if (k - 1 < L.kb) ckm = Vec<float, 4>{};   // rank-local operator: no coupling across the slab faces
-            if (k + 1 >= L.ke) ck = Vec<float, 4>{};
-            r4 = ldv<4>(r + c);
-            // the five rows of y: x0 (16-byte load) + over * parent (two coarse values per lane and row)
-            const int ic = i0 >> 1, jc = j >> 1, kc = k >> 1;
-            const int jm = (j > 0 ? j - 1 : 0) >> 1, jp = (j + 1) >> 1, km = (k > 0 ? k - 1 : 0) >> 1, kp = (k + 1) >> 1;
-#define YROW(dst, off, JC, KC)                                                                   \
-            {                                                                                    \
-                const Vec<float, 4> xv = ldv<4>(x0 + c + (off));                                 \
-                const Vec<float, 2> pv = ldv<2>(xc + gidx(C, ic, (JC), (KC)));                   \
-                dst.v[0] = xv.v[0] + over * pv.v[0]; dst.v[1] = xv.v[1] + over * pv.v[0];        \
-                dst.v[2] = xv.v[2] + over * pv.v[1]; dst.v[3] = xv.v[3] + over * pv.v[1];        \
-            }
-            YROW(y0, 0, jc, kc)
-            YROW(yjm, -sy, jm, kc)
-            YROW(yjp, sy, jp, kc)
-            YROW(ykm, -sz, jc, km)
-            YROW(ykp, sz, jc, kp)
-#undef YROW
-            if (lfirst && i0 > 0) { eyl = x0[c - 1] + over * xc[gidx(C, (i0 - 1) >> 1, jc, kc)]; ecil = pi[c - 1]; }
-            if (llast && i0 + 4 < L.I) eyr = x0[c + 4] + over * xc[gidx(C, (i0 + 4) >> 1, jc, kc)];
-        }
-        float yl = wave_up1(y0.v[3]), yr = wave_down1(y0.v[0]), cil = wave_up1(ci.v[3]);
-        if (lfirst) { yl = eyl; cil = ecil; }
-        if (llast) yr = eyr;
-        Vec<float, 4> zz;
-        float trz = 0.0f;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const float ym = e > 0 ? y0.v[e - 1] : yl;
-            const float yp = e < 3 ? y0.v[e + 1] : yr;
-            const float cim = e > 0 ? ci.v[e - 1] : cil;
-            float ay = ym * cim;
-            ay += yp * ci.v[e];
-            ay += yjm.v[e] * cjm.v[e];
-            ay += yjp.v[e] * cj.v[e];
-            ay += ykm.v[e] * ckm.v[e];
-            ay += ykp.v[e] * ck.v[e];
-            ay += y0.v[e] * dg.v[e];
-            float zv = 0.0f;
-            if (dg.v[e] != 0.0f) {
-                zv = y0.v[e] + omega * (r4.v[e] - ay) / dg.v[e];
-                trz += zv * r4.v[e];
-            }
-            zz.v[e] = zv;
-        }
-        acc_rz += (double)trz;
-        if (mine) stv(z + c, zz);
-      }
-    }
-    const double tot = block_sum_256(acc_rz, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(sc.sig(it_next) + sc.my_slot(), tot);
-}
-
-// ---- PCG vector kernels (tile list, one cell per thread and pass: d_tile_cell)
-// x += alpha p ; r -= alpha q ; rmax(it) = max|r|          alpha = sig(it) / a(it)
-__global__ __launch_bounds__(256) void k_mgp_xr(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
-                                                const float *__restrict__ d, float *__restrict__ x, float *__restrict__ r,
-                                                const float *__restrict__ p, const float *__restrict__ q, float *__restrict__ x0, PcgScal sc,
-                                                int it) {
-    if (*sc.conv >= 0) return;
-    __shared__ double lds[8];
-    double f[4] = {0.0, 0.0, 0.0, 0.0};
-    if (it >= 0) d_fold_sums(sc.sig(it), sc.a(it), nullptr, nullptr, f, lds);  // it = -1: only x0 = omega r/d (before the first V-cycle)
-    const double alpha_d = f[1] != 0.0 ? f[0] / f[1] : 0.0;
-    const float alpha = (float)alpha_d;
-    float mx = 0.0f;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
-        const int slot = d_tile_slot(bb, ntiles);
-        const int tile = slot < ntiles ? tiles[slot] : -1;
-#pragma unroll
-        for (int e = 0; e < VW_P; e++) {
-            int i, j, k;
-            if (!d_tile_cell<VW_P>(tile, tg, e, i, j, k) || i >= L.I || j >= L.J || k >= L.K) continue;
-            const size_t c = gidx(L, i, j, k);
-            if (d[c] == 0.0f) continue;
-            float rn = r[c];
-            if (it >= 0) {
-                x[c] += alpha * p[c];
-                rn = (float)((double)rn - alpha_d * (double)q[c]);
-                r[c] = rn;
-                mx = fmaxf(mx, fabsf(rn));
-            }
-            x0[c] = MG_OMEGA * rn / d[c];  // the V-cycle's pre-smoothed level-0 iterate (damped Jacobi from a zero guess)
-        }
-    }
-    if (it < 0) return;
-    const double bm = block_max_256((double)mx, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sc.my_slot(), bm);
-}
-// stop test on rmax(it) ; beta = sig(it+1)/sig(it) ; p = z + beta p       (it = -1: p = z)
-__global__ __launch_bounds__(256) void k_mgp_p(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L, const float *__restrict__ d,
-                                               const float *__restrict__ z, float *__restrict__ p, PcgScal sc, int it) {
-    if (*sc.conv >= 0) return;
-    __shared__ double lds[8];
-    float beta = 0.0f;
-    if (it >= 0) {
-        if (d_pass(sc, d_fold_max(sc.rmax(it), lds))) {
-            if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it;
-            return;
-        }
-        double f[4];
-        d_fold_sums(sc.sig(it + 1), sc.sig(it), nullptr, nullptr, f, lds);
-        beta = f[1] != 0.0 ? (float)(f[0] / f[1]) : 0.0f;
-    }
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
-        const int slot = d_tile_slot(bb, ntiles);
-        const int tile = slot < ntiles ? tiles[slot] : -1;
-#pragma unroll
-        for (int e = 0; e < VW_P; e++) {
-            int i, j, k;
-            if (!d_tile_cell<VW_P>(tile, tg, e, i, j, k) || i >= L.I || j >= L.J || k >= L.K) continue;
-            const size_t c = gidx(L, i, j, k);
-            if (d[c] == 0.0f) continue;
-            p[c] = it >= 0 ? z[c] + beta * p[c] : z[c];
-        }
-    }
-}
+// ---- the level-0 kernels walk the solver's tile list: once per tile geometry (pcg_geo.inc)
+namespace g16 {
+constexpr int ROWL = 16;
+#include "pcg_geo.inc"
+#include "k_pressure_mg_geo.inc"
+}  // namespace g16
+namespace g64 {
+constexpr int ROWL = 64;
+#include "pcg_geo.inc"
+#include "k_pressure_mg_geo.inc"
+}  // namespace g64
 
 struct MgState {
     std::vector<MgLevel> lev;
@@ -526,8 +313,8 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &C = s->lev[l + 1];
         if (l == 0) {  // x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
             (void)hipMemsetAsync(C.b + (size_t)C.L.kb * C.L.sz, 0, (size_t)(C.L.ke - C.L.kb) * C.L.sz * sizeof(float), c->stream);
-            hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, C.b);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
+                               F.pj, F.pk, c->pMask, F.x, F.b, C.b));
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
             hipLaunchKernelGGL(k_mg_pre, MGGRID(F.L), 0, c->stream, F.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, F.t);
             hipLaunchKernelGGL(k_mg_restrict, MGGRID(C.L), 0, c->stream, F.L, C.L, F.t, C.b);
@@ -541,8 +328,8 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0)
-            hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, sc, it_next);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
+                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, sc, it_next));
         else
             hipLaunchKernelGGL(k_mg_up, MGGRID(F.L), 0, c->stream, F.L, C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
     }
@@ -559,10 +346,10 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
     float *x = c->pressure, *r = (float *)c->pR, *q = (float *)c->pZ, *p = (float *)c->pS, *z = s->lev[0].t;
     float *x0 = s->lev[0].x;
     const HaloArray ph[1] = {{p, sizeof(float)}};
-    hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, -1);
+    GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, -1));
     mg_vcycle(c, s, sc, 0);
     if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
-    hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, -1);
+    GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, -1));
     // an iteration after the stop is a full V-cycle (plus, multi-rank, three exchanges): poll often
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 4;
     int conv = -1, it = 0;
@@ -572,10 +359,10 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
             if ((rc = fv_halo_copy(c, ph, 1, 1))) return rc;                                   // p on the neighbours' boundary planes
             spmv(c, sc, it);
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.a(it), NSLOT))) return rc;          // p.q
-            hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, it);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, it));
             mg_vcycle(c, s, sc, it + 1);
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;   // max|r| of this iteration, (r,z) of the next
-            hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, it);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, it));
         }
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -365,196 +365,17 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
     }
 }
 
-// ------------------------------------------------------------------ K9 SpMV
-// q = A s over the active tiles with the three fused dot products, in DIFFERENCE form: a row is its own control
-// volume times x minus the divergence of the viscous stresses, and every stress is a factor times a sum of
-// differences of neighbouring velocities (the Batty-Bridson discretisation the reference assembles into CSR,
-// viscositysolver.cpp:394-446 and the V/W analogues; signs: SURVEY.md A.6b):
-//   U: vol*u - [fR(u(i+1)-u) - fL(u-u(i-1))] - [fT((u(j+1)-u)+(v(i,j+1)-v(i-1,j+1))) - fB((u-u(j-1))+(v(i,j)-v(i-1,j)))]
-//            - [fF((u(k+1)-u)+(w(i,k+1)-w(i-1,k+1))) - fK((u-u(k-1))+(w(i,k)-w(i-1,k)))]
-// Algebraically identical to diag*x - sum(coef*x_nbr), but the fp32 evaluation no longer subtracts two numbers of
-// size diag*|x| to obtain one of size vol*|x| (diag/vol ~ 1e3..1e4 when nu*dt/dx^2 is large), which is what limits
-// the attainable residual of an fp32 solve of this system.
-// vm = own control volume for rows, -1 for every other index (x stays 0 there, q must too).
-// i-neighbour helpers with a load predicate: lanes that are `on` carry loaded values, every other lane zeros
-template <int N> __device__ __forceinline__ Vec<float, N> vneg() {
-    Vec<float, N> r;
-#pragma unroll
-    for (int e = 0; e < N; e++) r.v[e] = -1.0f;
-    return r;
-}
-template <typename T, int N>
-__device__ __forceinline__ T nbl(const Vec<T, N> &a, const T *__restrict__ p, int i0, bool on) {
-    T v = __shfl_up(a.v[N - 1], 1, ROWL);
-    if (d_row_first()) v = (on && i0 > 0) ? p[-1] : (T)0;
-    return v;
-}
-template <typename T, int N>
-__device__ __forceinline__ T nbr(const Vec<T, N> &a, const T *__restrict__ p, int i0, int w, bool on) {
-    T v = __shfl_down(a.v[0], 1, ROWL);
-    if (d_row_last()) v = (on && i0 + N < w) ? p[N] : (T)0;
-    return v;
-}
-// i-neighbour across lanes; `edge` is the value lane 0 (left) / lane 63 (right) fetched from memory beforehand
-template <typename T, int N>
-__device__ __forceinline__ T nbl2(const Vec<T, N> &a, T edge) {
-    const T v = wave_up1(a.v[N - 1]);
-    return d_row_first() ? edge : v;
-}
-template <typename T, int N>
-__device__ __forceinline__ T nbr2(const Vec<T, N> &a, T edge) {
-    const T v = wave_down1(a.v[0]);
-    return d_row_last() ? edge : v;
-}
-#define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
-#define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
-// PRED: per-lane load predication from the row mask (sparse liquids); the dense variant loads unconditionally
-template <typename T, int NV, bool PRED>
-__global__ __launch_bounds__(256, (NV == 2 && sizeof(T) == 4) ? 4 : 2) void k_visc_spmv(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
-                                                   const float *__restrict__ vmU, const float *__restrict__ vmV,
-                                                   const float *__restrict__ vmW, const float *__restrict__ fC,
-                                                   const float *__restrict__ fEU, const float *__restrict__ fEV,
-                                                   const float *__restrict__ fEW, PcgSys<T, 3> v, PcgScal sc, int it_arg) {
-    __shared__ double lds[12];
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    const int stride = TBATCH * (int)gridDim.x;
-    TileWalk<NV> cur;
-    cur.fetch(blockIdx.x, nvb, tiles, ntiles, tg, L, v.mask);
-    bool stop;
-    const int it = d_iter_spmv(sc, it_arg, stop);
-    if (stop) return;
-    int i0, j, k;
-    double da = 0.0, db = 0.0, dc = 0.0;
-    for (int base = blockIdx.x; base < nvb; base += stride) {
-      TileWalk<NV> nxt;
-      nxt.fetch(base + stride, nvb, tiles, ntiles, tg, L, v.mask);
-      const TileBatch B = cur.B;
-      const unsigned mks[TBATCH] = {cur.mk[0], cur.mk[1], cur.mk[2], cur.mk[3]};
-      cur = nxt;
-#pragma unroll 1
-      for (int t = 0; t < TBATCH; t++) {
-        const bool inside = d_tile_decode<NV>(d_pick(B.id, t), tg, L, i0, j, k);
-        const bool mine = inside && d_pick(mks, t) != 0u;
-        if (!__any(mine)) continue;  // the lane shuffles below need every lane of the wave
-        if (!inside) continue;
-        const size_t c = gidx(L, i0, j, k);
-        const long sy = L.sy, sz = L.sz;
-        const int I = L.I;
-        const T *__restrict__ xu = v.s[0], *__restrict__ xv = v.s[1], *__restrict__ xw = v.s[2];
-        // ---- which lanes have rows.  A lane without a row has nothing to compute and nothing to store (q is only ever
-        // read where the diagonal is non-zero), and it only has to LOAD if a neighbouring lane, which takes its i+-1
-        // values from it, has one: in the sparse scenes of the reference that leaves most lanes of a tile without any
-        // memory access beyond the mask bytes.
-        const int mleft = __shfl_up((int)mine, 1, ROWL), mright = __shfl_down((int)mine, 1, ROWL);  // (not inside a short-circuit: every lane must execute the shuffles)
-        const bool on = !PRED || mine || mleft != 0 || mright != 0;
-        // All loads of the tile are issued in one predicated block (one exec-mask region, no dependent waits in between):
-        // the kernel is latency-bound at the sizes of the reference's scenes, not bandwidth-bound.
-        Vec<float, NV> MU = vneg<NV>(), MV = vneg<NV>(), MW = vneg<NV>();
-        Vec<float, NV> C0{}, Cjm{}, Ckm{}, EW0{}, EWjp{}, EV0{}, EVkp{}, EU0{}, EUjp{}, EUkp{};
-        Vec<T, NV> U0{}, Ujm{}, Ujp{}, Ukm{}, Ukp{}, V0{}, Vjm{}, Vjp{}, Vkm{}, Vkp{}, W0{}, Wjm{}, Wjp{}, Wkm{}, Wkp{}, Vjpkm{}, Wjmkp{};
-        Vec<RT<T>, NV> RU{}, RV{}, RW{};
-        // values beyond the wave's ends (lane 0 / lane 63 read them from memory, the other lanes shuffle)
-        float eC0l = 0.0f, eEW0r = 0.0f, eEV0r = 0.0f;
-        T eU0l = (T)0, eU0r = (T)0, eV0l = (T)0, eV0r = (T)0, eW0l = (T)0, eW0r = (T)0, eVjpl = (T)0, eWkpl = (T)0, eUjmr = (T)0, eUkmr = (T)0;
-        if (on) {
-            MU = ldv<NV>(vmU + c); MV = ldv<NV>(vmV + c); MW = ldv<NV>(vmW + c);
-            C0 = ldv<NV>(fC + c); Cjm = ldv<NV>(fC + c - sy); Ckm = ldv<NV>(fC + c - sz);
-            EW0 = ldv<NV>(fEW + c); EWjp = ldv<NV>(fEW + c + sy);
-            EV0 = ldv<NV>(fEV + c); EVkp = ldv<NV>(fEV + c + sz);
-            EU0 = ldv<NV>(fEU + c); EUjp = ldv<NV>(fEU + c + sy); EUkp = ldv<NV>(fEU + c + sz);
-            U0 = ldv<NV>(xu + c); Ujm = ldv<NV>(xu + c - sy); Ujp = ldv<NV>(xu + c + sy); Ukm = ldv<NV>(xu + c - sz); Ukp = ldv<NV>(xu + c + sz);
-            V0 = ldv<NV>(xv + c); Vjm = ldv<NV>(xv + c - sy); Vjp = ldv<NV>(xv + c + sy); Vkm = ldv<NV>(xv + c - sz); Vkp = ldv<NV>(xv + c + sz);
-            W0 = ldv<NV>(xw + c); Wjm = ldv<NV>(xw + c - sy); Wjp = ldv<NV>(xw + c + sy); Wkm = ldv<NV>(xw + c - sz); Wkp = ldv<NV>(xw + c + sz);
-            Vjpkm = ldv<NV>(xv + c + sy - sz); Wjmkp = ldv<NV>(xw + c - sy + sz);
-            RU = ldv<NV>(v.r[0] + c); RV = ldv<NV>(v.r[1] + c); RW = ldv<NV>(v.r[2] + c);
-            if (d_row_first() && i0 > 0) {
-                eC0l = fC[c - 1];
-                eU0l = xu[c - 1]; eV0l = xv[c - 1]; eW0l = xw[c - 1];
-                eVjpl = xv[c + sy - 1]; eWkpl = xw[c + sz - 1];
-            }
-            if (d_row_last() && i0 + NV < I) {
-                eEW0r = fEW[c + NV]; eEV0r = fEV[c + NV];
-                eU0r = xu[c + NV]; eV0r = xv[c + NV]; eW0r = xw[c + NV];
-                eUjmr = xu[c - sy + NV]; eUkmr = xu[c - sz + NV];
-            }
-        }
-        const float C0l = nbl2(C0, eC0l);
-        const float EW0r = nbr2(EW0, eEW0r), EV0r = nbr2(EV0, eEV0r);
-        const T U0l = nbl2(U0, eU0l), U0r = nbr2(U0, eU0r);
-        const T V0l = nbl2(V0, eV0l), V0r = nbr2(V0, eV0r);
-        const T W0l = nbl2(W0, eW0l), W0r = nbr2(W0, eW0r);
-        const T Vjpl = nbl2(Vjp, eVjpl), Wkpl = nbl2(Wkp, eWkpl);
-        const T Ujmr = nbr2(Ujm, eUjmr), Ukmr = nbr2(Ukm, eUkmr);
-        Vec<T, NV> yU, yV, yW;
-        // the three dot products: this lane's <= 3 NV rows are summed in the vector precision, then folded into the fp64
-        // accumulators once per tile (12 fp32 FMAs instead of ~100 fp64 operations per tile and lane; every sum across
-        // lanes, tiles and blocks stays fp64)
-        T ta = (T)0, tb = (T)0, tc = (T)0;
-#pragma unroll
-        for (int e = 0; e < NV; e++) {
-            const T uc = U0.v[e], vc = V0.v[e], wc = W0.v[e];
-            const T ur = RSH(U0, U0r, e), ul = LSH(U0, U0l, e);
-            const T vr = RSH(V0, V0r, e), vl = LSH(V0, V0l, e);
-            const T wr = RSH(W0, W0r, e), wl = LSH(W0, W0l, e);
-            {   // U row
-                const float fR = C0.v[e], fL = LSH(C0, C0l, e), fT = EWjp.v[e], fB = EW0.v[e], fF = EVkp.v[e], fK = EV0.v[e];
-                T y = (T)0;
-                if (MU.v[e] >= 0.0f) {
-                    const T txx = (T)fR * (ur - uc) - (T)fL * (uc - ul);
-                    const T txy = (T)fT * ((Ujp.v[e] - uc) + (Vjp.v[e] - LSH(Vjp, Vjpl, e))) - (T)fB * ((uc - Ujm.v[e]) + (vc - vl));
-                    const T txz = (T)fF * ((Ukp.v[e] - uc) + (Wkp.v[e] - LSH(Wkp, Wkpl, e))) - (T)fK * ((uc - Ukm.v[e]) + (wc - wl));
-                    y = (T)MU.v[e] * uc - txx - txy - txz;
-                    const float dg = MU.v[e] + fR + fL + fT + fB + fF + fK;  // same order as k_visc_setup
-                    const T yi = y * d_recip<T>(dg);
-                    ta += uc * y; tb += (T)RU.v[e] * yi; tc += y * yi;
-                }
-                yU.v[e] = y;
-            }
-            {   // V row
-                const float fR = RSH(EW0, EW0r, e), fL = EW0.v[e], fT = C0.v[e], fB = Cjm.v[e], fF = EUkp.v[e], fK = EU0.v[e];
-                T y = (T)0;
-                if (MV.v[e] >= 0.0f) {
-                    const T tyy = (T)fT * (Vjp.v[e] - vc) - (T)fB * (vc - Vjm.v[e]);
-                    const T txy = (T)fR * ((vr - vc) + (ur - RSH(Ujm, Ujmr, e))) - (T)fL * ((vc - vl) + (uc - Ujm.v[e]));
-                    const T tyz = (T)fF * ((Vkp.v[e] - vc) + (Wkp.v[e] - Wjmkp.v[e])) - (T)fK * ((vc - Vkm.v[e]) + (wc - Wjm.v[e]));
-                    y = (T)MV.v[e] * vc - tyy - txy - tyz;
-                    const float dg = MV.v[e] + fR + fL + fT + fB + fF + fK;
-                    const T yi = y * d_recip<T>(dg);
-                    ta += vc * y; tb += (T)RV.v[e] * yi; tc += y * yi;
-                }
-                yV.v[e] = y;
-            }
-            {   // W row
-                const float fR = RSH(EV0, EV0r, e), fL = EV0.v[e], fT = EUjp.v[e], fB = EU0.v[e], fF = C0.v[e], fK = Ckm.v[e];
-                T y = (T)0;
-                if (MW.v[e] >= 0.0f) {
-                    const T tzz = (T)fF * (Wkp.v[e] - wc) - (T)fK * (wc - Wkm.v[e]);
-                    const T txz = (T)fR * ((wr - wc) + (ur - RSH(Ukm, Ukmr, e))) - (T)fL * ((wc - wl) + (uc - Ukm.v[e]));
-                    const T tyz = (T)fT * ((Wjp.v[e] - wc) + (Vjp.v[e] - Vjpkm.v[e])) - (T)fB * ((wc - Wjm.v[e]) + (vc - Vkm.v[e]));
-                    y = (T)MW.v[e] * wc - tzz - txz - tyz;
-                    const float dg = MW.v[e] + fR + fL + fT + fB + fF + fK;
-                    const T yi = y * d_recip<T>(dg);
-                    ta += wc * y; tb += (T)RW.v[e] * yi; tc += y * yi;
-                }
-                yW.v[e] = y;
-            }
-        }
-        da += (double)ta; db += (double)tb; dc += (double)tc;
-        if (!PRED || mine) {
-            stv(v.q[0] + c, yU);
-            stv(v.q[1] + c, yV);
-            stv(v.q[2] + c, yW);
-        }
-      }
-    }
-    block_sum3_256(da, db, dc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
-        const int sl = sc.my_slot();
-        if (da != 0.0) atomicAdd(sc.a(it) + sl, da);
-        if (db != 0.0) atomicAdd(sc.b(it) + sl, db);
-        if (dc != 0.0) atomicAdd(sc.c(it) + sl, dc);
-    }
-}
+// ---- the SpMV kernel (and the shared PCG kernels it is paired with) depend on the tile geometry: once per geometry
+namespace g16 {
+constexpr int ROWL = 16;
+#include "pcg_geo.inc"
+#include "k_viscosity_geo.inc"
+}  // namespace g16
+namespace g64 {
+constexpr int ROWL = 64;
+#include "pcg_geo.inc"
+#include "k_viscosity_geo.inc"
+}  // namespace g64
 
 template <typename T>
 static __global__ void k_vec_to_f32(const T *__restrict__ a, float *__restrict__ o, size_t n) {
@@ -583,13 +404,13 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     const int cap = c->prm.reserved[5] > 0 ? c->prm.reserved[5] : (NV == 4 ? 512 : 1024);
     if (nb > cap) nb = cap;
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
-    if (timed) fv_ev_begin(c, 1, (double)count * (ROWL * NV * TY));
+    if (timed) fv_ev_begin(c, 1, (double)count * (256 * NV));
     if (NV == 4 && c->vPred)
-        hipLaunchKernelGGL((k_visc_spmv<T, 4, true>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it);
+        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, 4, true>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
+                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it));
     else
-    hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                       c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it);
+    GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
+                       c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it));
     if (timed) fv_ev_end(c);
 }
 
@@ -598,7 +419,6 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const Lay &L = c->L;
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
-    li.total_tiles = c->tgV.count();
     if (!c->viscosity_nonzero) {  // fluidsimulation.cpp:171-184
         li.status = 3;
         if (info) *info = li;
@@ -676,8 +496,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     c->vwV = 4;
     if (c->prm.reserved[3] == 2 || c->prm.reserved[3] == 4) c->vwV = c->prm.reserved[3];  // measurement switch: forced lane width
     c->vPred = fill <= 0.35;
-    c->tgV.ntx = (L.PX + ROWL * c->vwV - 1) / (ROWL * c->vwV);
-    rc = fv_build_tiles(c, c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV);
+    rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3);
     if (rc) return rc;
     if (c->comm) {
         float bn = (float)c->h_scal[0];
@@ -688,6 +507,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     li.rhs_norm = bnorm;
     li.rows = c->h_flags[2];
     li.active_tiles = c->nActiveV;
+    li.total_tiles = c->tgV.count();
     c->viscosityReady = 1;
     c->viscosityPrec = std::is_same<T, float>::value ? 0 : 1;
 
@@ -712,18 +532,18 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                 return rc;
         } else {
         if (c->vwV == 4)
-            hipLaunchKernelGGL((k_pcg_init<T, 3, 4>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc);
+            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_pcg_init<T, 3, 4>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc));
         else
-            hipLaunchKernelGGL((k_pcg_init<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc);
+            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_pcg_init<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc));
         if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
         auto spmv = [&](int first, int count, int it) {
             if (c->vwV == 4) launch_visc_spmv<T, 4>(c, sc, it, first, count); else launch_visc_spmv<T, 2>(c, sc, it, first, count);
         };
         auto update = [&](int it) {
             if (c->vwV == 4)
-                hipLaunchKernelGGL((k_pcg_update<T, 3, 4>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
+                GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_pcg_update<T, 3, 4>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it));
             else
-                hipLaunchKernelGGL((k_pcg_update<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it);
+                GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_pcg_update<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it));
         };
         if ((rc = pcg_run(c, sc, cap, sh, 3, c->nIntV, c->nActiveV, spmv, update, &conv))) return rc;
         }
@@ -797,6 +617,6 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     *ms = (double)t / reps;
-    *cells = (double)c->nActiveV * (ROWL * c->vwV * TY);
+    *cells = (double)c->nActiveV * (256 * c->vwV);
     return FLIPV_OK;
 }

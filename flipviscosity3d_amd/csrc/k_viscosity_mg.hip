@@ -124,59 +124,6 @@ __device__ __forceinline__ void d_rap_entry(const VLevelDev &C, int c, const int
         for (int b = 0; b < nj; b++) d_coarse_add(C, c, PI[a], c2, PJ[b], wi[a] * v * wj[b]);
 }
 
-// ---- level 0 -> level 1: entries of the matrix-free fine rows (viscositysolver.cpp:394-465 and the V/W analogues)
-__global__ __launch_bounds__(256) void k_vmg_rap_fine(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L, FineOp A, VLevelDev C) {
-    const long st[3] = {1, L.sy, L.sz};
-    const float *fE[3] = {A.fE[0], A.fE[1], A.fE[2]};
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
-        const int slot = d_tile_slot(bb, ntiles);
-        if (slot >= ntiles) continue;
-        const int tile = tiles[slot];
-        for (int e = 0; e < 4; e++) {
-            int i, j, k;
-            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
-            const size_t ci = gidx(L, i, j, k);
-            const unsigned m = A.mask[ci];
-            if (!m) continue;
-            const int p[3] = {i, j, k};
-            for (int c = 0; c < 3; c++) {
-                if (!((m >> c) & 1u)) continue;
-                float diag = A.vm[c][ci];
-                for (int a = 0; a < 3; a++) {
-                    float fP, fM;
-                    if (a == c) { fP = A.fC[ci]; fM = A.fC[ci - st[c]]; }
-                    else { const int mth = 3 - c - a; fP = fE[mth][ci + st[a]]; fM = fE[mth][ci]; }
-                    diag += fP + fM;
-                    int q[3];
-                    // same component, +-1 along a
-                    q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
-                    q[a] = p[a] + 1;
-                    if (fP != 0.0f && ((A.mask[ci + st[a]] >> c) & 1u)) d_rap_entry(C, c, p, c, q, -fP);
-                    q[a] = p[a] - 1;
-                    if (fM != 0.0f && ((A.mask[ci - st[a]] >> c) & 1u)) d_rap_entry(C, c, p, c, q, -fM);
-                    if (a == c) continue;
-                    // component a: p + e_a (-fP), p + e_a - e_c (+fP), p (+fM), p - e_c (-fM)
-                    if (fP != 0.0f) {
-                        q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
-                        q[a] = p[a] + 1;
-                        if ((A.mask[ci + st[a]] >> a) & 1u) d_rap_entry(C, c, p, a, q, -fP);
-                        q[c] = p[c] - 1;
-                        if ((A.mask[ci + st[a] - st[c]] >> a) & 1u) d_rap_entry(C, c, p, a, q, fP);
-                    }
-                    if (fM != 0.0f) {
-                        q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
-                        if ((m >> a) & 1u) d_rap_entry(C, c, p, a, q, fM);
-                        q[c] = p[c] - 1;
-                        if ((A.mask[ci - st[c]] >> a) & 1u) d_rap_entry(C, c, p, a, q, -fM);
-                    }
-                }
-                d_rap_entry(C, c, p, c, p, diag);
-            }
-        }
-    }
-}
-
 // ---- level l -> level l+1 (l >= 1): every stored entry of the dense-slot operator
 __global__ void k_vmg_rap(VLevelDev F, VLevelDev C) {
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
@@ -268,115 +215,17 @@ __global__ void k_vmg_prolong(Lay F, Lay C, Vec3p xf, Vec3p xc, const uint8_t *_
     }
 }
 
-// ---- level 0 pointwise kernels over the tile list
-// mode 0: z = omega r/d          1: z += omega (r - q)/d          2: q = r - q (residual)          3: as 1, plus (r, z) -> sig(it_next)
-__global__ __launch_bounds__(256) void k_vmg_fine(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L, const uint8_t *__restrict__ mask,
-                                                  Vec3p d, Vec3p r, Vec3p z, Vec3p q, int mode, PcgScal sc, int it_next) {
-    __shared__ double lds[4];
-    double acc = 0.0;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
-        const int slot = d_tile_slot(bb, ntiles);
-        if (slot >= ntiles) continue;
-        const int tile = tiles[slot];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int i, j, k;
-            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
-            const size_t ci = gidx(L, i, j, k);
-            const unsigned m = mask[ci];
-            if (!m) continue;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                if (!((m >> c) & 1u)) continue;
-                const float dd = d.p[c][ci], rr = r.p[c][ci];
-                if (mode == 0) z.p[c][ci] = VMG_OMEGA * rr / dd;
-                else if (mode == 2) q.p[c][ci] = rr - q.p[c][ci];
-                else {
-                    const float zn = z.p[c][ci] + VMG_OMEGA * (rr - q.p[c][ci]) / dd;
-                    z.p[c][ci] = zn;
-                    if (mode == 3) acc += (double)zn * (double)rr;
-                }
-            }
-        }
-    }
-    if (mode == 3) {
-        const double tot = block_sum_256(acc, lds);
-        if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(sc.sig(it_next) + sc.my_slot(), tot);
-    }
-}
-
-// ---- PCG vector kernels
-// x += alpha p ; r -= alpha q ; rmax(it)           alpha = sig(it)/a(it)
-__global__ __launch_bounds__(256) void k_vpcg_xr(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L, const uint8_t *__restrict__ mask,
-                                                 Vec3p x, Vec3p r, Vec3p p, Vec3p q, PcgScal sc, int it) {
-    if (*sc.conv >= 0) return;
-    __shared__ double lds[8];
-    double f[4];
-    d_fold_sums(sc.sig(it), sc.a(it), nullptr, nullptr, f, lds);
-    const double alpha_d = f[1] != 0.0 ? f[0] / f[1] : 0.0;
-    const float alpha = (float)alpha_d;
-    float mx = 0.0f;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
-        const int slot = d_tile_slot(bb, ntiles);
-        if (slot >= ntiles) continue;
-        const int tile = tiles[slot];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int i, j, k;
-            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
-            const size_t ci = gidx(L, i, j, k);
-            const unsigned m = mask[ci];
-            if (!m) continue;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                if (!((m >> c) & 1u)) continue;
-                x.p[c][ci] += alpha * p.p[c][ci];
-                const float rn = (float)((double)r.p[c][ci] - alpha_d * (double)q.p[c][ci]);
-                r.p[c][ci] = rn;
-                mx = fmaxf(mx, fabsf(rn));
-            }
-        }
-    }
-    const double bm = block_max_256((double)mx, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sc.my_slot(), bm);
-}
-// stop test on rmax(it) ; beta = sig(it+1)/sig(it) ; p = z + beta p          (it = -1: p = z)
-__global__ __launch_bounds__(256) void k_vpcg_p(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L, const uint8_t *__restrict__ mask,
-                                                Vec3p z, Vec3p p, PcgScal sc, int it) {
-    if (*sc.conv >= 0) return;
-    __shared__ double lds[8];
-    float beta = 0.0f;
-    if (it >= 0) {
-        if (d_pass(sc, d_fold_max(sc.rmax(it), lds))) {
-            if (blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.conv = it;
-            return;
-        }
-        double f[4];
-        d_fold_sums(sc.sig(it + 1), sc.sig(it), nullptr, nullptr, f, lds);
-        beta = f[1] != 0.0 ? (float)(f[0] / f[1]) : 0.0f;
-    }
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int bb = blockIdx.x; bb < nvb; bb += gridDim.x) {
-        const int slot = d_tile_slot(bb, ntiles);
-        if (slot >= ntiles) continue;
-        const int tile = tiles[slot];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int i, j, k;
-            if (!d_tile_cell<4>(tile, tg, e, i, j, k) || i >= L.PX || j >= L.PY) continue;
-            const size_t ci = gidx(L, i, j, k);
-            const unsigned m = mask[ci];
-            if (!m) continue;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                if (!((m >> c) & 1u)) continue;
-                p.p[c][ci] = it >= 0 ? z.p[c][ci] + beta * p.p[c][ci] : z.p[c][ci];
-            }
-        }
-    }
-}
+// ---- the kernels that walk the solver's tile list: once per tile geometry (pcg_geo.inc)
+namespace g16 {
+constexpr int ROWL = 16;
+#include "pcg_geo.inc"
+#include "k_viscosity_mg_geo.inc"
+}  // namespace g16
+namespace g64 {
+constexpr int ROWL = 64;
+#include "pcg_geo.inc"
+#include "k_viscosity_mg_geo.inc"
+}  // namespace g64
 
 struct VmgState {
     std::vector<VLevel> lev;     // coarse levels 1..
@@ -456,8 +305,8 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         A.vm[0] = c->vmU; A.vm[1] = c->vmV; A.vm[2] = c->vmW;
         A.fC = c->fC; A.fE[0] = c->fEU; A.fE[1] = c->fEV; A.fE[2] = c->fEW;
         A.mask = c->vRowMask;
-        hipLaunchKernelGGL(k_vmg_rap_fine, dim3(pcg_grid(c, c->nActiveV)), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A,
-                           dev_of(s->lev[0]));
+        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_rap_fine, dim3(pcg_grid(c, c->nActiveV)), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A,
+                           dev_of(s->lev[0])));
         for (size_t l = 0; l + 1 < s->lev.size(); l++)
             hipLaunchKernelGGL(k_vmg_rap, LGRID(s->lev[l].L), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
     }
@@ -497,7 +346,7 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
     float *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
     PcgScal none;
     memset(&none, 0, sizeof(none));
-#define FINE(mode, scal, itn) hipLaunchKernelGGL(k_vmg_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(dg), v3(r), v3(s->z), v3(s->q2), mode, scal, itn)
+#define FINE(mode, scal, itn) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(dg), v3(r), v3(s->z), v3(s->q2), mode, scal, itn))
     FINE(0, none, 0);                                  // z = omega r/d
     fv_visc_apply_f32(c, s->z, s->q2); FINE(1, none, 0);   // second pre-sweep
     if (!s->lev.empty()) {
@@ -523,16 +372,16 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spm
     float *x[3] = {(float *)c->vX[0], (float *)c->vX[1], (float *)c->vX[2]}, *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
     float *p[3] = {(float *)c->vS[0], (float *)c->vS[1], (float *)c->vS[2]}, *q[3] = {(float *)c->vZ[0], (float *)c->vZ[1], (float *)c->vZ[2]};
     vmg_vcycle(c, s, sc, 0);
-    hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(s->z), v3(p), sc, -1);
+    GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(s->z), v3(p), sc, -1));
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 4;
     int conv = -1, it = 0;
     while (it < cap && conv < 0) {
         const int stop = it + every < cap ? it + every : cap;
         for (; it < stop; it++) {
             spmv(c, sc, it);
-            hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(x), v3(r), v3(p), v3(q), sc, it);
+            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(x), v3(r), v3(p), v3(q), sc, it));
             vmg_vcycle(c, s, sc, it + 1);
-            hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(s->z), v3(p), sc, it);
+            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(s->z), v3(p), sc, it));
         }
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

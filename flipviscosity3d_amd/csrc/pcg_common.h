@@ -18,9 +18,11 @@
 // rmax of the previous iteration passes the tolerance, after which every launch returns immediately, so the
 // host only polls every few iterations.
 //
-// Work decomposition: tiles of (64 N) x 4 x 1 indices of the shared index space (flipv_internal.h); a lane owns N
-// consecutive i (N = 4 pressure, N = 2 viscosity) and moves them with one 16- or 8-byte access per array;
-// i-neighbours come from the adjacent lane (ds_bpermute), j/k-neighbours from aligned loads of the adjacent rows.
+// Work decomposition: tiles of (ROWL N) x TY x 1 indices of the shared index space in one of two geometries (pcg_geo.inc:
+// 16-lane rows = 64 x 16 tiles for sparse liquids, 64-lane rows = 256 x 4 tiles for full ones, picked per solve by
+// fv_build_tiles); a lane owns N consecutive i (N = 4, or 2) and moves them with one 16- or 8-byte access per array;
+// i-neighbours come from the adjacent lane (DPP row / wave shift), j/k-neighbours from aligned loads of the adjacent rows.
+// This header holds everything that does not depend on the geometry; kernels live in the *_geo.inc files.
 #pragma once
 #include "flipv_internal.h"
 #include "flipv_comm.h"
@@ -74,42 +76,6 @@ template <typename T> __device__ __forceinline__ T d_recip(float d);
 template <> __device__ __forceinline__ float d_recip<float>(float d) { return __builtin_amdgcn_rcpf(d); }
 template <> __device__ __forceinline__ double d_recip<double>(float d) { return 1.0 / (double)d; }
 
-// lane i <- lane i-1 / lane i+1 of the wave as a DPP move (wave_shr:1 / wave_shl:1 exist on gfx9-family ISAs, gfx950
-// included): one VALU instruction instead of a ds_bpermute round trip through the LDS pipe.  Lane 0 / lane 63 keep
-// their own value; callers overwrite those lanes with the value fetched from memory.
-// With 16-lane rows the same thing per row: row_shr:1 / row_shl:1, the first / last lane of each row keeps its value.
-__device__ __forceinline__ int d_dpp_up1(int v) { return __builtin_amdgcn_update_dpp(v, v, ROWL == 64 ? 0x138 : 0x111, 0xf, 0xf, false); }    // wave_shr:1 | row_shr:1
-__device__ __forceinline__ int d_dpp_down1(int v) { return __builtin_amdgcn_update_dpp(v, v, ROWL == 64 ? 0x130 : 0x101, 0xf, 0xf, false); }  // wave_shl:1 | row_shl:1
-__device__ __forceinline__ float wave_up1(float v) { return __int_as_float(d_dpp_up1(__float_as_int(v))); }
-__device__ __forceinline__ float wave_down1(float v) { return __int_as_float(d_dpp_down1(__float_as_int(v))); }
-__device__ __forceinline__ int wave_up1(int v) { return d_dpp_up1(v); }
-__device__ __forceinline__ int wave_down1(int v) { return d_dpp_down1(v); }
-__device__ __forceinline__ double wave_up1(double v) {
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)d_dpp_up1((int)(unsigned)b), hi = (unsigned)d_dpp_up1((int)(unsigned)(b >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__device__ __forceinline__ double wave_down1(double v) {
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned)d_dpp_down1((int)(unsigned)b), hi = (unsigned)d_dpp_down1((int)(unsigned)(b >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// value at i0-1 (the previous lane's last element) / at i0+N (the next lane's first element).
-// `p` points at this lane's first element; the wave-edge lanes read memory when the neighbour index is inside
-// the lattice width w, else 0 (wave-uniform condition: only grids wider than one wave ever take it).
-template <typename T, int N>
-__device__ __forceinline__ T nb_left(const Vec<T, N> &a, const T *__restrict__ p, int i0) {
-    T v = wave_up1(a.v[N - 1]);
-    if (d_row_first()) v = i0 > 0 ? p[-1] : (T)0;
-    return v;
-}
-template <typename T, int N>
-__device__ __forceinline__ T nb_right(const Vec<T, N> &a, const T *__restrict__ p, int i0, int w) {
-    T v = wave_down1(a.v[0]);
-    if (d_row_last()) v = i0 + N < w ? p[N] : (T)0;
-    return v;
-}
 
 // Every reduced scalar of iteration `it` is spread over NSLOT partial sums (slot = blockIdx & (NSLOT-1)) so that the
 // one-atomic-per-block accumulation does not serialise on a single L2 address (thousands of blocks per launch);
@@ -221,20 +187,6 @@ template <> __device__ __forceinline__ unsigned ld_mask<4>(const uint8_t *__rest
 // Blocks loop over tiles with a grid stride (grids are capped at MAX_PCG_BLOCKS so a launch never issues more than
 // that many scalar atomics); `b` is the virtual block index b = blockIdx.x + n*gridDim.x.
 constexpr int MAX_PCG_BLOCKS = 1024;  // 4 blocks per CU: one resident round at the SpMV kernels' occupancy (measured best of 128..2048 at 256^3)
-template <int N>
-__device__ __forceinline__ bool d_tile_coords(int b, const int *__restrict__ tiles, int ntiles, const TileGrid &tg, int &i0,
-                                              int &j, int &k) {
-    const int slot = d_tile_slot(b, ntiles);
-    if (slot >= ntiles) return false;
-    const int tile = tiles[slot];
-    const int tx = tile % tg.ntx;
-    const int t2 = tile / tg.ntx;
-    const int ty = t2 % tg.nty;
-    k = t2 / tg.nty;
-    i0 = tx * (ROWL * N) + d_tcol() * N;
-    j = ty * TY + d_trow();
-    return true;
-}
 
 // Tile look-ahead.  The kernels are latency-bound on the reference's scenes (a wave spends most of its life parked on
 // dependent loads: tile id -> mask -> data), so a block fetches the ids of its next TBATCH tiles with independent loads,
@@ -252,59 +204,6 @@ __device__ __forceinline__ TileBatch d_fetch_tiles(int base, int nvb, const int 
     }
     return B;
 }
-// this lane's first index of tile `tile`, or false if the lane lies outside the index space
-template <int N>
-__device__ __forceinline__ bool d_tile_decode(int tile, const TileGrid &tg, const Lay &L, int &i0, int &j, int &k) {
-    if (tile < 0) return false;
-    const int tx = tile % tg.ntx;
-    const int t2 = tile / tg.ntx;
-    const int ty = t2 % tg.nty;
-    k = t2 / tg.nty;
-    i0 = tx * (ROWL * N) + d_tcol() * N;
-    j = ty * TY + d_trow();
-    return i0 < L.PX && j < L.PY;
-}
-// a block walking a tile index by index (N indices per thread, consecutive threads take consecutive i): index e of this thread
-template <int N>
-__device__ __forceinline__ bool d_tile_cell(int tile, const TileGrid &tg, int e, int &i, int &j, int &k) {
-    if (tile < 0) return false;
-    constexpr int TW = ROWL * N;  // TW x TY = 256 N indices
-    const int tx = tile % tg.ntx, t2 = tile / tg.ntx;
-    const int idx = e * 256 + (int)(threadIdx.y * 64 + threadIdx.x);
-    k = t2 / tg.nty;
-    j = (t2 % tg.nty) * TY + idx / TW;
-    i = tx * TW + idx % TW;
-    return true;
-}
-// the mask words of this lane for the TBATCH tiles (0 where the lane is outside / there is no tile)
-template <int N>
-__device__ __forceinline__ void d_fetch_masks(const TileBatch &B, const TileGrid &tg, const Lay &L, const uint8_t *__restrict__ mask,
-                                              unsigned mk[TBATCH]) {
-#pragma unroll
-    for (int t = 0; t < TBATCH; t++) {
-        int i0, j, k;
-        mk[t] = d_tile_decode<N>(B.id[t], tg, L, i0, j, k) ? ld_mask<N>(mask + gidx(L, i0, j, k)) : 0u;
-    }
-}
-// One batch of look-ahead on top: the ids and masks of a block's FIRST batch are requested before the kernel's scalar
-// prologue (iteration number, stop flag, dot products -- none of which the tile list depends on), those of the next
-// batch before the current one is walked.
-template <int N>
-struct TileWalk {
-    TileBatch B;
-    unsigned mk[TBATCH];
-    __device__ __forceinline__ void fetch(int base, int nvb, const int *__restrict__ tiles, int ntiles, const TileGrid &tg, const Lay &L,
-                                          const uint8_t *__restrict__ mask) {
-        if (base < nvb) {
-            B = d_fetch_tiles(base, nvb, tiles, ntiles);
-            if (mask) d_fetch_masks<N>(B, tg, L, mask, mk);
-            else { mk[0] = mk[1] = mk[2] = mk[3] = 0xffu; }
-        } else {
-            B.id[0] = B.id[1] = B.id[2] = B.id[3] = -1;
-            mk[0] = mk[1] = mk[2] = mk[3] = 0u;
-        }
-    }
-};
 __device__ __forceinline__ int d_pick(const int v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ unsigned d_pick(const unsigned v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 
@@ -325,151 +224,6 @@ __device__ __forceinline__ int d_iter_spmv(const PcgScal &sc, int it_arg, bool &
     return it;
 }
 
-template <typename T, int NC, int N>
-__global__ __launch_bounds__(256) void k_pcg_init(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
-                                                  PcgSys<T, NC> v, PcgScal sc) {
-    __shared__ double lds[4];
-    int i0, j, k;
-    double acc = 0.0;
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    for (int b = blockIdx.x; b < nvb; b += gridDim.x) {
-        if (!(d_tile_coords<N>(b, tiles, ntiles, tg, i0, j, k) && i0 < L.PX && j < L.PY)) continue;
-        const size_t c = gidx(L, i0, j, k);
-        if (v.mask && ld_mask<N>(v.mask + c) == 0u) continue;
-#pragma unroll
-        for (int m = 0; m < NC; m++) {
-            const Vec<float, N> d = ldv<N>(v.diag[m] + c);
-            const Vec<RT<T>, N> r = ldv<N>(v.r[m] + c);
-            Vec<T, N> z;
-#pragma unroll
-            for (int e = 0; e < N; e++) {
-                const double zd = d.v[e] != 0.0f ? (double)r.v[e] / (double)d.v[e] : 0.0;
-                z.v[e] = (T)zd;
-                acc += zd * (double)r.v[e];
-            }
-            stv(v.s[m] + c, z);
-        }
-    }
-    const double tot = block_sum_256(acc, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(sc.sig(0) + sc.my_slot(), tot);
-}
-
-template <typename T, int NC, int N>
-__global__ __launch_bounds__(256) void k_pcg_update(const int *__restrict__ tiles, int ntiles, TileGrid tg, Lay L,
-                                                    PcgSys<T, NC> v, PcgScal sc, int it_arg) {
-    const int nvb = ((ntiles + 7) >> 3) << 3;
-    const int stride = TBATCH * (int)gridDim.x;
-    TileWalk<N> cur;
-    cur.fetch(blockIdx.x, nvb, tiles, ntiles, tg, L, v.mask);
-    const int conv_now = *sc.conv, itB_now = it_arg >= 0 ? it_arg : *sc.itB;   // two independent loads
-    if (conv_now >= 0) return;
-    const int it = itB_now;
-    if (it >= sc.cap) return;
-    __shared__ double lds[8];
-    // One prologue fetch: rmax(it-1), sig(it), a(it), b(it), c(it) are 5 x NSLOT contiguous doubles (for it = 0 there is no
-    // rmax).  160 threads load one partial each, every 32-lane group folds its scalar with shuffles, ONE barrier.
-    // Stop test on the residual the previous update left (in a multi-rank run its partial maxima were merged by the
-    // all-reduce that precedes this launch): every block takes the same decision from the same completed value, one
-    // of them records it.  x is not touched again, so the solution is the one after iteration it-1.
-    double f[4];
-    {
-        const int tid = d_tid256();
-        const int grp = tid >> 5;  // 0 rmax(it-1), 1 sig, 2 a, 3 b, 4 c
-        double v = 0.0;
-        if (grp < 5 && (it > 0 || grp > 0)) v = (sc.sig(it) - NSLOT)[tid];
-#pragma unroll
-        for (int off = NSLOT / 2; off > 0; off >>= 1) {
-            const double o = __shfl_down(v, off, NSLOT);
-            v = grp == 0 ? fmax(v, o) : v + o;
-        }
-        if (grp < 5 && (tid & (NSLOT - 1)) == 0) lds[grp] = v;
-        __syncthreads();
-        if (it > 0 && d_pass(sc, lds[0])) {
-            if (blockIdx.x == 0 && tid == 0) *sc.conv = it - 1;
-            return;
-        }
-        f[0] = lds[1]; f[1] = lds[2]; f[2] = lds[3]; f[3] = lds[4];
-    }
-    const double sg = f[0], a = f[1];
-    const double alpha_d = a != 0.0 ? sg / a : 0.0;
-    double est = sg - 2.0 * alpha_d * f[2] + alpha_d * alpha_d * f[3];
-    if (!(est > 0.0)) est = 0.0;
-    const T alpha = (T)alpha_d;
-    const double beta_d = sg != 0.0 ? est / sg : 0.0;
-    int i0, j, k;
-    double acc = 0.0;
-    float mxf = 0.0f;  // max|r| over this thread's rows, tracked in the storage precision of r
-    double mxd = 0.0;
-    for (int base = blockIdx.x; base < nvb; base += stride) {
-      TileWalk<N> nxt;
-      nxt.fetch(base + stride, nvb, tiles, ntiles, tg, L, v.mask);
-      const TileBatch B = cur.B;
-      unsigned mks[TBATCH] = {cur.mk[0], cur.mk[1], cur.mk[2], cur.mk[3]};
-      cur = nxt;
-#pragma unroll 1
-      for (int t = 0; t < TBATCH; t++) {
-        if (!d_tile_decode<N>(d_pick(B.id, t), tg, L, i0, j, k)) continue;
-        const size_t c = gidx(L, i0, j, k);
-        // which components have unknowns among this lane's N indices: from the mask bytes (bit m = component m) when there
-        // is a mask, so that the diagonal is fetched together with the vectors instead of ahead of them
-        unsigned bits = 0xffu;
-        if (v.mask) {
-            const unsigned mk = d_pick(mks, t);
-            if (mk == 0u) continue;
-            bits = mk | (mk >> 8) | (mk >> 16) | (mk >> 24);
-        }
-#pragma unroll
-        for (int m = 0; m < NC; m++) {
-            if (!((bits >> m) & 1u)) continue;
-            const Vec<float, N> d = ldv<N>(v.diag[m] + c);
-            if (!v.mask) {
-                bool any = false;
-#pragma unroll
-                for (int e = 0; e < N; e++) any = any || d.v[e] != 0.0f;
-                if (!any) continue;  // no unknowns here
-            }
-            Vec<T, N> x = ldv<N>(v.x[m] + c), s = ldv<N>(v.s[m] + c);
-            Vec<RT<T>, N> r = ldv<N>(v.r[m] + c);
-            const Vec<T, N> q = ldv<N>(v.q[m] + c);
-#pragma unroll
-            for (int e = 0; e < N; e++) {
-                if (d.v[e] != 0.0f) {
-                    x.v[e] += alpha * s.v[e];
-                    const RT<T> rn_t = (RT<T>)((double)r.v[e] - alpha_d * (double)q.v[e]);
-                    const double rn = (double)rn_t;
-                    // z = r/d in the storage precision (correctly rounded division; an fp64 quotient of fp32 data buys nothing)
-                    const double zn = sizeof(RT<T>) == 4 ? (double)((float)rn_t / d.v[e]) : rn / (double)d.v[e];
-                    r.v[e] = rn_t;
-                    s.v[e] = (T)(zn + beta_d * (double)s.v[e]);
-                    if (sizeof(RT<T>) == 4) mxf = fmaxf(mxf, fabsf((float)rn_t)); else mxd = fmax(mxd, fabs(rn));
-                    acc += zn * rn;
-                }
-            }
-            stv(v.x[m] + c, x);
-            stv(v.r[m] + c, r);
-            stv(v.s[m] + c, s);
-        }
-      }
-    }
-    // sum and max of the block with one barrier pair (lds[5..7] still hold this launch's scalars: use a second array)
-    __shared__ double red[8];
-    double tot = wave_sum(acc), bm = wave_max(fmax((double)mxf, mxd));
-    {
-        const int tid = d_tid256();
-        if ((tid & 63) == 0) { red[tid >> 6] = tot; red[4 + (tid >> 6)] = bm; }
-        __syncthreads();
-        if (tid == 0) {
-            tot = red[0] + red[1] + red[2] + red[3];
-            bm = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-        }
-    }
-    if (threadIdx.x == 0 && threadIdx.y == 0) {
-        const int sl = sc.my_slot();
-        if (tot != 0.0) atomicAdd(sc.sig(it + 1) + sl, tot);
-        if (bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sl, bm);
-        if (it_arg < 0 && blockIdx.x == 0) *sc.itA = it + 1;
-    }
-}
 
 // after a chunk of iterations: record convergence of the chunk's last iteration (K1 of the next iteration would)
 static __global__ void k_pcg_check(PcgScal sc, int it_last_arg) {  // <<<1, 64>>>
@@ -486,6 +240,13 @@ static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<
     if (threadIdx.x == 0) out[0] = res;
 }
 
+// Run a statement with the kernels of one geometry in scope:  GEO_RUN(tg.rowl, hipLaunchKernelGGL((k_pcg_update<T, 3, 4>), ...));
+#define GEO_RUN(rowl, ...)                                                  \
+    do {                                                                    \
+        if ((rowl) == 16) { using namespace g16; __VA_ARGS__; }             \
+        else { using namespace g64; __VA_ARGS__; }                          \
+    } while (0)
+
 // ---- host-side helpers (k_pressure.hip) ----
 int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT+16 doubles
 // never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
@@ -495,8 +256,11 @@ static inline int pcg_grid(const flipv_context *c, int ntiles) {
     const int nb = ((ntiles + 7) / 8) * 8;
     return nb < 8 ? 8 : (nb < cap ? nb : cap);
 }
-int fv_build_tiles(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   const uint8_t *mask, int *list, int *nActive, int *nInterior);
+// Builds the tile list and picks the geometry: starts from *tg's (the previous solve's), and switches when the tiles come out
+// less than 45 % full with 64-lane rows / more than 80 % full with 16-lane rows.  `hostCount` (read after the internal
+// synchronisation) = unknowns of this rank, `perIndex` unknowns per index (1 pressure, 3 viscosity).
+int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
 
 // The iteration loop shared by both solves.

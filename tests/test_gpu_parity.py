@@ -314,6 +314,25 @@ def test_full_substeps_velocity_parity(name, precision):
     c.close()
 
 
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("rowl", [16, 64])
+def test_full_substeps_with_either_tile_geometry(name, rowl, monkeypatch):
+    """the solver kernels exist for two tile geometries (16-lane rows: 64 x 16 tiles, 64-lane rows: 256 x 4 tiles;
+    csrc/pcg_geo.inc), chosen per solve from how full the tiles are; FLIPV_ROWL pins one.  Both must give the reference's
+    velocities, and the tile grids must really differ."""
+    g = Golden(name)
+    monkeypatch.setenv("FLIPV_ROWL", str(rowl))
+    c = make_ctx(g, viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+    c.particles = g["particles0"]
+    for t in range(g.nsub):
+        st = c.substep(g.dt)
+        assert st["rc"] == 0, st
+        assert rel_maxnorm3([c.grid(n) for n in "UVW"], g.uvw(t, "final")) <= VEL_TOL
+        ty = 4 * (64 // rowl)
+        assert st["pressure"]["total_tiles"] == -(-(4 * ((g.I + 1 + 3) // 4)) // (4 * rowl)) * -(-(g.J + 1) // ty) * (g.K + 1), st["pressure"]
+    c.close()
+
+
 def test_advance_takes_reference_substeps(oracle):
     """advance(dt) = CFL loop (fluidsimulation.cpp:135-168): same number of substeps and same end state as the oracle"""
     g = Golden("cube24_inviscid")
