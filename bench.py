@@ -344,6 +344,7 @@ def committed_profile(kernel, N, args, world):
     if pmc:
         d = json.load(open(pmc[-1]))
         for name, v in d.items():
+            name = re.sub(r"^g\d+::", "", name)   # tile-geometry namespace (csrc/pcg_geo.inc)
             if name.startswith(kernel + "<") or name == kernel:
                 out["traffic"] = v["hbm_bytes_per_launch"]
                 out["traffic_unit"] = "bytes per launch (HBM read + write, PMC)"
@@ -352,7 +353,8 @@ def committed_profile(kernel, N, args, world):
     st = sorted(glob.glob(os.path.join(root, "r*", "bench%d_v*_kernel_stats.csv" % N)), key=key)
     if st:
         for r in csv.DictReader(open(st[-1])):
-            if r["Name"].replace("void ", "").startswith(kernel + "<") or r["Name"].startswith(kernel + "("):
+            nm = re.sub(r"^(void )?(g\d+::)?", "", r["Name"])
+            if nm.startswith(kernel + "<") or nm.startswith(kernel + "("):
                 out["rocprof_avg_launch_us"] = float(r["AverageNs"]) / 1e3
                 out["rocprof_source"] = os.path.relpath(st[-1], os.path.dirname(root))
                 break
