@@ -102,9 +102,11 @@ def test_fullsize_precisions_agree_on_pressure_only_step(scene):
         Q = P.copy()
         Q[:, 3] = 0.3 * np.sin(6.0 * Q[:, 1])                        # a shear so that the projection has work to do
         c.particles = Q
-        for t in range(2):
-            st = c.substep(0.01)
-            assert st["viscosity"]["status"] == 3 and st["pressure"]["status"] == 0
+        # ONE substep: a second one would start from particle positions that differ by 1e-7 between the two runs, and a face
+        # whose last particle leaves (a discrete decision) then differs by 1e-4 locally -- sensitivity of the method, not
+        # of the kernels (tests/test_gpu_wide.py); seen once in ~10 runs
+        st = c.substep(0.01)
+        assert st["viscosity"]["status"] == 3 and st["pressure"]["status"] == 0
         res.append([c.grid(n) for n in "UVW"])
         c.close()
     scale = max(np.abs(g).max() for g in res[1])
