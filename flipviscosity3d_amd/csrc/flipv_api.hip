@@ -88,7 +88,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     if (!c) return FLIPV_ERR_OOM;
     Lay &L = c->L;
     L.I = I; L.J = J; L.K = K;
-    L.PX = ((I + 1 + 3) / 4) * 4; L.PY = J + 1; L.PZ = K + 1;
+    L.PX = ((I + 1 + 7) / 8) * 8; L.PY = ((J + 1 + 3) / 4) * 4; L.PZ = K + 1;   // 8 | PX and 4 | PY: the swizzled plane layout (sidx) needs whole 8 x 4 patches
     L.sy = L.PX; L.sz = (long)L.PX * L.PY;
     L.n = (size_t)L.sz * L.PZ;
     L.guard = (((size_t)L.sz + (size_t)L.sy + 8) + 63) / 64 * 64;
@@ -165,6 +165,8 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     {
         const char *e = getenv("FLIPV_ROWL");
         c->forceRowl = e ? atoi(e) : 0;
+        const char *z = getenv("FLIPV_SWZ");
+        c->allowSwz = !(z && atoi(z) == 0);
         if (c->forceRowl != 16 && c->forceRowl != 64) c->forceRowl = 0;
     }
     c->tgP = make_tile_grid(L, c->forceRowl ? c->forceRowl : 64, VW_P);

@@ -305,6 +305,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
             return rc;
     } else {
         PcgSys<T, 1> v;
+        v.swz = 0;
         v.mask = c->pMask;
         v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
         const int nb = pcg_grid(c, c->nActiveP);

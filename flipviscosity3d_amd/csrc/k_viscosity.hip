@@ -250,7 +250,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                              const float *__restrict__ fEW, float *__restrict__ dgU, float *__restrict__ dgV,
                              float *__restrict__ dgW, float *__restrict__ vmU, float *__restrict__ vmV,
                              float *__restrict__ vmW, uint8_t *__restrict__ rowmask, const uint8_t *__restrict__ band,
-                             int full, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {
+                             int full, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {   // v.swz: layout of diag, vm, r, x
     __shared__ double lds[4];
     const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
     double babs = 0.0;
@@ -344,12 +344,13 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
         {
             const uint8_t now = (uint8_t)((dg[0] != 0.0f) | ((dg[1] != 0.0f) << 1) | ((dg[2] != 0.0f) << 2));
             if (now || prev || full) {  // off-row values (diag 0, volume -1, x = s = 0) persist between solves where nothing was a row
-                dgU[c] = dg[0]; dgV[c] = dg[1]; dgW[c] = dg[2];
-                vmU[c] = vm[0]; vmV[c] = vm[1]; vmW[c] = vm[2];
+                const size_t cs = v.swz ? sidx(L, i, j, k) : c;
+                dgU[cs] = dg[0]; dgV[cs] = dg[1]; dgW[cs] = dg[2];
+                vmU[cs] = vm[0]; vmV[cs] = vm[1]; vmW[cs] = vm[2];
                 rowmask[c] = now;
 #pragma unroll
                 for (int m = 0; m < 3; m++) {
-                    v.r[m][c] = (RT<T>)rv[m]; v.x[m][c] = (T)0; v.s[m][c] = (T)0;
+                    v.r[m][cs] = (RT<T>)rv[m]; v.x[m][cs] = (T)0; v.s[m][c] = (T)0;
                     babs = fmax(babs, fabs((double)rv[m]));
                     rows += dg[m] != 0.0f;
                 }
@@ -384,10 +385,18 @@ static __global__ void k_vec_to_f32(const T *__restrict__ a, float *__restrict__
     for (; t < n; t += stride) o[t] = (float)a[t];
 }
 
+// x in the swizzled plane layout -> velocity grid
+template <typename T>
+static __global__ void k_unswizzle_to_f32(Lay L, const T *__restrict__ a, float *__restrict__ o) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    if (i < L.PX && j < L.PY) o[gidx(L, i, j, k)] = (float)a[sidx(L, i, j, k)];
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 static PcgSys<T, 3> visc_sys(flipv_context *c) {
     PcgSys<T, 3> v;
+    v.swz = c->vSwz;
     v.mask = c->vRowMask;
     v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
     for (int m = 0; m < 3; m++) { v.x[m] = (T *)c->vX[m]; v.r[m] = (RT<T> *)c->vR[m]; v.q[m] = (T *)c->vZ[m]; v.s[m] = (T *)c->vS[m]; }
@@ -476,18 +485,30 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         HIPCHK(c, hipMemcpyAsync(c->bandPrev + off, c->validCells + off, cnt, hipMemcpyDeviceToDevice, c->stream));
         c->bandPrevValid = 1;
     }
-    PcgSys<T, 3> v = visc_sys<T>(c);
-    // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers are
-    // shared) or of the slab make it store everywhere
+    // Layout of x, r, q and the diagonal -- the arrays that are only ever read at a lane's own indices: swizzled 8 x 4
+    // patches (sidx) go with the 16-lane tile geometry; s, which the SpMV reads with its halo (and slabs exchange), stays
+    // plain, and so does everything under the opt-in multigrid.  The geometry is only known once the tiles are built,
+    // so the setup kernel runs in the layout of the previous solve's geometry and is repeated on the rare solve where
+    // the geometry changes.
+    const bool swzOk = c->allowSwz && c->prm.reserved[7] != 1;
     const int precNow = std::is_same<T, float>::value ? 0 : 1;
-    const int full = (c->viscStateValid && c->viscStatePrec == precNow) ? 0 : 1;
-    c->viscStateValid = 1; c->viscStatePrec = precNow;
-    // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane)
-    hipLaunchKernelGGL(k_visc_setup<T>, GRID3(R0), 0, c->stream, R0, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
-                       c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
-                       c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, c->validCells, full, v, bmax, c->d_flags + 2);
-    HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    auto run_setup = [&](int swz) -> int {
+        // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers
+        // are shared), of the layout or of the slab make it store everywhere
+        const int full = (c->viscStateValid && c->viscStatePrec == precNow && c->vSwz == swz) ? 0 : 1;
+        c->viscStateValid = 1; c->viscStatePrec = precNow; c->vSwz = swz;
+        PcgSys<T, 3> vs = visc_sys<T>(c);
+        HIPCHK(c, hipMemsetAsync(bmax, 0, sizeof(double), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));
+        // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane)
+        hipLaunchKernelGGL(k_visc_setup<T>, GRID3(R0), 0, c->stream, R0, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
+                           c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
+                           c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2);
+        HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        return FLIPV_OK;
+    };
+    if ((rc = run_setup(swzOk && (c->forceRowl ? c->forceRowl : c->tgV.rowl) == 16 ? 1 : 0))) return rc;
     // Lane width of the solver kernels: 4 consecutive i per lane (16-byte accesses).  With per-lane load predication the
     // narrow variant (2 per lane, twice the waves) no longer wins on sparse liquids (256^3 bunny: 40.7 vs 42.7 ms per
     // solve); it stays selectable for measurements.  Sparse liquids (row fill <= 0.35) use the predicated SpMV.
@@ -498,6 +519,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     c->vPred = fill <= 0.35;
     rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3);
     if (rc) return rc;
+    if (c->vSwz != (swzOk && c->tgV.rowl == 16 ? 1 : 0)) {  // the geometry changed: the vectors go into the other layout
+        if ((rc = run_setup(1 - c->vSwz))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    PcgSys<T, 3> v = visc_sys<T>(c);
     if (c->comm) {
         float bn = (float)c->h_scal[0];
         if ((rc = fv_allreduce_max_f32(c, &bn))) return rc;
@@ -562,9 +588,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     li.status = success ? (iters == 0 ? 3 : 0) : (accepted ? 1 : 2);
     if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
         const size_t off = (size_t)R0.kb * L.sz, cnt = (size_t)(R0.ke - R0.kb) * L.sz;
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[0] + off, c->U + off, cnt);
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[1] + off, c->V + off, cnt);
-        hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[2] + off, c->W + off, cnt);
+        float *uvw[3] = {c->U, c->V, c->W};
+        for (int m = 0; m < 3; m++) {
+            if (c->vSwz) hipLaunchKernelGGL(k_unswizzle_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);
+            else hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[m] + off, uvw[m] + off, cnt);
+        }
         const HaloArray uv[3] = {{c->U, 4}, {c->V, 4}, {c->W, 4}};
         if ((rc = fv_halo_copy(c, uv, 3, 1))) return rc;  // the pressure rhs at plane k1-1 reads W(k1)
     }

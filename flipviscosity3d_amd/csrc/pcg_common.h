@@ -175,6 +175,7 @@ struct PcgSys {
     const float *diag[NC];
     T *x[NC], *q[NC], *s[NC];
     RT<T> *r[NC];
+    int swz;              // 1: diag, x, q, r are stored in the swizzled plane layout (sidx, flipv_internal.h); s and the mask never are
     const uint8_t *mask;  // optional (nullptr: none): non-zero where any component has an unknown at the index; a lane whose
                           // N indices are all zero skips every load (sparse liquids: most lanes of an active tile)
 };
