@@ -17,7 +17,7 @@
 //
 // At the ABI every grid is the reference's Array3d (x fastest, its own width/height).  On the device all
 // lattices of one simulation -- cells (I,J,K), U/V/W faces, nodes (I+1,J+1,K+1) and the three edge
-// families -- live in ONE index space of PX x PY x PZ entries, PX = roundup4(I+1), PY = J+1, PZ = K+1:
+// families -- live in ONE index space of PX x PY x PZ entries, PX = roundup8(I+1), PY = roundup4(J+1), PZ = K+1:
 //     g(i,j,k) = i + PX*(j + PY*k)      for every array.
 // Consequences: a single index and a single set of neighbour offsets (1, PX, PX*PY) address every
 // field; rows start 16-byte aligned so a lane can move 4 consecutive i with one dwordx4 access (a wave:
