@@ -255,6 +255,8 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->pScratch) (void)hipFree(c->pScratch);
     if (c->binIdx) (void)hipFree(c->binIdx);
     if (c->surfList) (void)hipFree(c->surfList);
+    if (c->mlistP) (void)hipFree(c->mlistP);
+    if (c->mlistV) (void)hipFree(c->mlistV);
     fv_mg_free(c);
     fv_vmg_free(c);
     if (c->binCnt) (void)hipFree(c->binCnt);

@@ -146,6 +146,8 @@ struct flipv_context {
     // pressure system (zero outside pressure cells)
     float *pDiag, *pPi, *pPj, *pPk;
     uint8_t *pMask;  // 1 where the cell is a pressure cell
+    unsigned *mlistP = nullptr, *mlistV = nullptr;   // mask words of the listed tiles in list order (256 per tile), grown on demand
+    size_t mlistCapP = 0, mlistCapV = 0;             // capacity in tiles
     void *pX, *pR, *pZ, *pS;  // vectors (float or double per precision)
     // viscosity system
     float *scp;                                                 // solid phi at cell centres

@@ -214,18 +214,39 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
     return FLIPV_OK;
 }
 
+// the lanes' mask words of the listed tiles, in list order: the PCG kernels then fetch ids and masks side by side
+static int gather_masks(flipv_context *c, const TileGrid &tg, int vw, const uint8_t *mask, const int *list, int nActive, unsigned **mlist,
+                        size_t *cap) {
+    if (!mask || !mlist || nActive <= 0) return FLIPV_OK;
+    if ((size_t)nActive > *cap) {
+        if (*mlist) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(*mlist); *mlist = nullptr; *cap = 0; }
+        const size_t want = (size_t)nActive + (size_t)nActive / 4 + 64;
+        hipError_t e = hipMalloc((void **)mlist, want * 256 * sizeof(unsigned));
+        if (e != hipSuccess) { c->err = std::string("hipMalloc(mask list): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
+        *cap = want;
+    }
+    const int nb = nActive < 4096 ? nActive : 4096;
+    if (vw == 4) GEO_RUN(tg.rowl, hipLaunchKernelGGL(k_mask_gather<4>, dim3(nb), dim3(64, 4, 1), 0, c->stream, list, nActive, tg, c->L, mask, *mlist));
+    else GEO_RUN(tg.rowl, hipLaunchKernelGGL(k_mask_gather<2>, dim3(nb), dim3(64, 4, 1), 0, c->stream, list, nActive, tg, c->L, mask, *mlist));
+    return FLIPV_OK;
+}
+
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex) {
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap) {
     int rowl = c->forceRowl ? c->forceRowl : tg->rowl;
     *tg = make_tile_grid(c->L, rowl, vw);
     int rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior);
-    if (rc || c->forceRowl || *nActive <= 0) return rc;
-    // how full the tiles are: indices with unknowns / indices of the listed tiles (256 vw each, either geometry)
-    const double fill = ((double)*hostCount / perIndex) / ((double)*nActive * 256.0 * vw);
-    const int want = (rowl == 64 && fill < 0.45) ? 16 : ((rowl == 16 && fill > 0.80) ? 64 : rowl);
-    if (want == rowl) return FLIPV_OK;
-    *tg = make_tile_grid(c->L, want, vw);
-    return build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior);
+    if (rc) return rc;
+    if (!c->forceRowl && *nActive > 0) {
+        // how full the tiles are: indices with unknowns / indices of the listed tiles (256 vw each, either geometry)
+        const double fill = ((double)*hostCount / perIndex) / ((double)*nActive * 256.0 * vw);
+        const int want = (rowl == 64 && fill < 0.45) ? 16 : ((rowl == 16 && fill > 0.80) ? 64 : rowl);
+        if (want != rowl) {
+            *tg = make_tile_grid(c->L, want, vw);
+            if ((rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior))) return rc;
+        }
+    }
+    return gather_masks(c, *tg, vw, mask, list, *nActive, mlist, mlistCap);
 }
 
 template <typename T>
@@ -234,7 +255,7 @@ static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, in
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 0, (double)count * (256 * VW_P));
     GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it));
+                       c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, c->mlistP ? c->mlistP + (size_t)first * 256 : (const unsigned *)nullptr, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it));
     if (timed) fv_ev_end(c);
 }
 
@@ -266,7 +287,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->k0, c->k1, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, nullptr, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1);  // synchronises: h_scal[0] = max|b|
+    rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->pMask, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1, &c->mlistP, &c->mlistCapP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
     {
         float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)
@@ -307,6 +328,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
         PcgSys<T, 1> v;
         v.swz = 0;
         v.mask = c->pMask;
+        v.mlist = c->mlistP;
         v.diag[0] = c->pDiag; v.x[0] = x; v.r[0] = (RT<T> *)c->pR; v.q[0] = (T *)c->pZ; v.s[0] = (T *)c->pS;
         const int nb = pcg_grid(c, c->nActiveP);
         const dim3 blk(64, 4, 1);

@@ -398,6 +398,7 @@ static PcgSys<T, 3> visc_sys(flipv_context *c) {
     PcgSys<T, 3> v;
     v.swz = c->vSwz;
     v.mask = c->vRowMask;
+    v.mlist = c->mlistV;
     v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
     for (int m = 0; m < 3; m++) { v.x[m] = (T *)c->vX[m]; v.r[m] = (RT<T> *)c->vR[m]; v.q[m] = (T *)c->vZ[m]; v.s[m] = (T *)c->vS[m]; }
     return v;
@@ -414,12 +415,14 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     if (nb > cap) nb = cap;
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 1, (double)count * (256 * NV));
+    PcgSys<T, 3> vv = sys ? *sys : visc_sys<T>(c);
+    if (vv.mlist) vv.mlist += (size_t)first * 256;   // the mask words are in list order
     if (NV == 4 && c->vPred)
         GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, 4, true>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it));
+                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it));
     else
-    GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                       c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, sys ? *sys : visc_sys<T>(c), sc, it));
+        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
+                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it));
     if (timed) fv_ev_end(c);
 }
 
@@ -517,7 +520,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     c->vwV = 4;
     if (c->prm.reserved[3] == 2 || c->prm.reserved[3] == 4) c->vwV = c->prm.reserved[3];  // measurement switch: forced lane width
     c->vPred = fill <= 0.35;
-    rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3);
+    rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3, &c->mlistV, &c->mlistCapV);
     if (rc) return rc;
     if (c->vSwz != (swzOk && c->tgV.rowl == 16 ? 1 : 0)) {  // the geometry changed: the vectors go into the other layout
         if ((rc = run_setup(1 - c->vSwz))) return rc;

@@ -176,6 +176,7 @@ struct PcgSys {
     T *x[NC], *q[NC], *s[NC];
     RT<T> *r[NC];
     int swz;              // 1: diag, x, q, r are stored in the swizzled plane layout (sidx, flipv_internal.h); s and the mask never are
+    const unsigned *mlist;  // optional: the mask words of the listed tiles in list order (fv_build_tiles); must match the list the kernel is given
     const uint8_t *mask;  // optional (nullptr: none): non-zero where any component has an unknown at the index; a lane whose
                           // N indices are all zero skips every load (sparse liquids: most lanes of an active tile)
 };
@@ -261,7 +262,7 @@ static inline int pcg_grid(const flipv_context *c, int ntiles) {
 // less than 45 % full with 64-lane rows / more than 80 % full with 16-lane rows.  `hostCount` (read after the internal
 // synchronisation) = unknowns of this rank, `perIndex` unknowns per index (1 pressure, 3 viscosity).
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex);
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
 
 // The iteration loop shared by both solves.
