@@ -155,7 +155,8 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     {
         int rc_ = plain_alloc(c, &c->d_flags, 16);
         if (!rc_) rc_ = plain_alloc(c, &c->d_scal_small, 64);
-        if (!rc_) rc_ = plain_alloc(c, &c->actFlags, (size_t)2 * ((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8));
+        if (!rc_) rc_ = plain_alloc(c, &c->actFlags, (size_t)3 * ((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8));
+        if (!rc_) rc_ = plain_alloc(c, &c->actList, (size_t)((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8) + 16);
         if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
     }
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));

@@ -118,6 +118,7 @@ struct flipv_context {
     float *accU, *accV, *accW, *wgtU, *wgtV, *wgtW;
     // extrapolation stamps + activity blocks (2 x ceil(PX/8) ceil(PY/8) ceil(PZ/8) bytes)
     uint8_t *actFlags;
+    int *actList = nullptr;   // active extrapolation blocks, compacted ([0] = count, ids from [1])
     uint8_t *stampU, *stampV, *stampW;
     // staging for Array3d <-> device layout conversion
     float *stage;

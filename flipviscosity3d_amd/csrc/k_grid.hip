@@ -99,11 +99,11 @@ __device__ __forceinline__ int d_act_index(const ActGrid &A, int i, int j, int k
 
 __global__ void k_extrap_init(Lay L, ActGrid A, const uint8_t *__restrict__ vU, const uint8_t *__restrict__ vV,
                               const uint8_t *__restrict__ vW, uint8_t *__restrict__ sU, uint8_t *__restrict__ sV,
-                              uint8_t *__restrict__ sW, uint8_t *__restrict__ act) {
+                              uint8_t *__restrict__ sW, uint8_t *__restrict__ act, uint8_t *__restrict__ unk) {
     IJK_OR_RETURN(L);
     const uint8_t *val[3] = {vU, vV, vW};
     uint8_t *st[3] = {sU, sV, sW};
-    bool any = false;
+    bool any = false, fillable = false;
 #pragma unroll
     for (int dir = 0; dir < 3; dir++) {
         int w, h, d;
@@ -112,9 +112,11 @@ __global__ void k_extrap_init(Lay L, ActGrid A, const uint8_t *__restrict__ vU, 
         const bool border = i == 0 || j == 0 || k == 0 || i == w - 1 || j == h - 1 || k == d - 1;
         const bool v = val[dir][c] != 0;
         any = any || v;
+        fillable = fillable || (!v && !border);
         st[dir][c] = v ? 0 : (border ? 254 : 255);
     }
     if (any) act[d_act_index(A, i, j, k)] = 1;  // same value from every writer
+    if (fillable) unk[d_act_index(A, i, j, k)] = 1;   // blocks without a single unknown face (the liquid's interior) have nothing to fill
 }
 
 // 3x3x3 dilation; in a multi-rank run every block within ACT_B planes of an interior slab boundary is active as well
@@ -136,42 +138,79 @@ __global__ void k_act_dilate(ActGrid A, const uint8_t *__restrict__ in, uint8_t 
     out[t] = (uint8_t)any;
 }
 
-// grid: (PX/64, PY/4, activity planes of the range); a thread walks the ACT_B planes of its activity block
-__global__ void k_extrap_layer(Lay L, ActGrid A, const uint8_t *__restrict__ act, float *__restrict__ U, float *__restrict__ V,
+// the active blocks that hold planes of [kb, ke), compacted by one workgroup: list[0] = count, ids from list[1]
+__global__ __launch_bounds__(1024) void k_act_compact(ActGrid A, const uint8_t *__restrict__ act, const uint8_t *__restrict__ unk, int kb, int ke,
+                                                      int *__restrict__ list) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    const int n = A.nx * A.ny * A.nz;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int t = start + (int)threadIdx.x;
+        int f = 0;
+        if (t < n && act[t] && unk[t]) {
+            const int bz = t / (A.nx * A.ny);
+            f = bz * ACT_B < ke && bz * ACT_B + ACT_B > kb;
+        }
+        const unsigned long long m = __ballot(f);
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int q = 0; q < 16; q++) { if (q < wv) woff += wsum[q]; total += wsum[q]; }
+        if (f) list[1 + base + woff + __popcll(m & ((1ull << lane) - 1ull))] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) list[0] = base;
+}
+
+// One workgroup per active block (grid-stride over the compacted list): 8 x 8 lanes in (i, j), four planes at a time.  A
+// layer only reads stamps <= layer and writes layer + 1, so the order of the cells within a layer does not matter.
+__global__ __launch_bounds__(256) void k_extrap_layer(Lay L, ActGrid A, const int *__restrict__ list, float *__restrict__ U, float *__restrict__ V,
                                float *__restrict__ W, uint8_t *__restrict__ sU, uint8_t *__restrict__ sV, uint8_t *__restrict__ sW,
-                               int layer, int z0) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, bz = blockIdx.z + z0;
-    if (i >= L.PX || j >= L.PY) return;
-    if (!act[(i / ACT_B) + A.nx * ((j / ACT_B) + A.ny * bz)]) return;
+                               int layer) {
     float *g[3] = {U, V, W};
     uint8_t *st[3] = {sU, sV, sW};
     const long off[6] = {-1, 1, -L.sy, L.sy, -L.sz, L.sz};
-    const int kb = max(bz * ACT_B, L.kb), ke = min(bz * ACT_B + ACT_B, L.ke);
-    for (int k = kb; k < ke; k++) {
-        const size_t c = gidx(L, i, j, k);
+    const int count = list[0];
+    const int lx = threadIdx.x & 7, ly = (threadIdx.x >> 3) & 7, lz = threadIdx.x >> 6;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const int id = list[1 + b];
+        const int bx = id % A.nx, by = (id / A.nx) % A.ny, bz = id / (A.nx * A.ny);
+        const int i = bx * ACT_B + lx, j = by * ACT_B + ly;
+        if (i >= L.PX || j >= L.PY) continue;
 #pragma unroll
-        for (int dir = 0; dir < 3; dir++) {
-            int w, h, d;
-            lat_dims(L, LAT_U + dir, w, h, d);
-            if (i >= w || j >= h || k >= d) continue;
-            if (st[dir][c] != 255) continue;  // only unknown, non-border cells are ever filled (so all six neighbours exist)
-            // a neighbour can only trigger this cell if it is an interior cell of the array (:604-606)
-            const bool nin[6] = {i - 1 >= 1, i + 1 <= w - 2, j - 1 >= 1, j + 1 <= h - 2, k - 1 >= 1, k + 1 <= d - 2};
-            float sum = 0.0f;
-            int count = 0;
-            bool trigger = false;
+        for (int p = 0; p < ACT_B; p += 4) {
+            const int k = bz * ACT_B + p + lz;
+            if (k < L.kb || k >= L.ke) continue;
+            const size_t c = gidx(L, i, j, k);
 #pragma unroll
-            for (int q = 0; q < 6; q++) {  // order -i,+i,-j,+j,-k,+k (:671-676)
-                const size_t nb = (size_t)((long)c + off[q]);
-                if (st[dir][nb] <= layer) {
-                    sum += g[dir][nb];
-                    count++;
-                    trigger = trigger || nin[q];
+            for (int dir = 0; dir < 3; dir++) {
+                int w, h, d;
+                lat_dims(L, LAT_U + dir, w, h, d);
+                if (i >= w || j >= h || k >= d) continue;
+                if (st[dir][c] != 255) continue;  // only unknown, non-border cells are ever filled (so all six neighbours exist)
+                // a neighbour can only trigger this cell if it is an interior cell of the array (:604-606)
+                const bool nin[6] = {i - 1 >= 1, i + 1 <= w - 2, j - 1 >= 1, j + 1 <= h - 2, k - 1 >= 1, k + 1 <= d - 2};
+                float sum = 0.0f;
+                int cnt = 0;
+                bool trigger = false;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {  // order -i,+i,-j,+j,-k,+k (:671-676)
+                    const size_t nb = (size_t)((long)c + off[q]);
+                    if (st[dir][nb] <= layer) {
+                        sum += g[dir][nb];
+                        cnt++;
+                        trigger = trigger || nin[q];
+                    }
                 }
-            }
-            if (trigger) {
-                g[dir][c] = sum / (float)count;
-                st[dir][c] = (uint8_t)(layer + 1);
+                if (trigger) {
+                    g[dir][c] = sum / (float)cnt;
+                    st[dir][c] = (uint8_t)(layer + 1);
+                }
             }
         }
     }
@@ -323,19 +362,21 @@ int fv_extrapolate(flipv_context *c) {
     ActGrid A;
     A.nx = (c->L.PX + ACT_B - 1) / ACT_B; A.ny = (c->L.PY + ACT_B - 1) / ACT_B; A.nz = (c->L.PZ + ACT_B - 1) / ACT_B;
     const int nact = A.nx * A.ny * A.nz;
-    uint8_t *actA = c->actFlags, *actB = c->actFlags + nact;
+    uint8_t *actA = c->actFlags, *actB = c->actFlags + nact, *unk = c->actFlags + 2 * (size_t)nact;
     HIPCHK(c, hipMemsetAsync(actA, 0, (size_t)nact, c->stream));
-    hipLaunchKernelGGL(k_extrap_init, GRID3(R1), 0, c->stream, R1, A, c->vU, c->vV, c->vW, c->stampU, c->stampV, c->stampW, actA);
+    HIPCHK(c, hipMemsetAsync(unk, 0, (size_t)nact, c->stream));
+    hipLaunchKernelGGL(k_extrap_init, GRID3(R1), 0, c->stream, R1, A, c->vU, c->vV, c->vW, c->stampU, c->stampV, c->stampW, actA, unk);
     for (int q = 0; q < (layers + ACT_B - 1) / ACT_B; q++) {
         hipLaunchKernelGGL(k_act_dilate, dim3(cdiv(nact, 256)), dim3(256), 0, c->stream, A, actA, actB, c->comm ? c->k0 : 0,
                            c->comm ? c->k1 : c->L.PZ, c->L.PZ);
         uint8_t *t = actA; actA = actB; actB = t;
     }
     const HaloArray lay[6] = {{c->U, 4}, {c->V, 4}, {c->W, 4}, {c->stampU, 1}, {c->stampV, 1}, {c->stampW, 1}};
-    const int z0 = R0.kb / ACT_B, z1 = (R0.ke - 1) / ACT_B;
+    hipLaunchKernelGGL(k_act_compact, dim3(1), dim3(1024), 0, c->stream, A, actA, unk, R0.kb, R0.ke, c->actList);
+    const int ngrid = nact < 4096 ? nact : 4096;
     for (int q = 0; q < layers; q++) {
-        hipLaunchKernelGGL(k_extrap_layer, dim3(cdiv(R0.PX, 64), cdiv(R0.PY, 4), (unsigned)(z1 - z0 + 1)), dim3(64, 4, 1), 0, c->stream,
-                           R0, A, actA, c->U, c->V, c->W, c->stampU, c->stampV, c->stampW, q, z0);
+        hipLaunchKernelGGL(k_extrap_layer, dim3(ngrid), dim3(256), 0, c->stream, R0, A, c->actList, c->U, c->V, c->W, c->stampU, c->stampV,
+                           c->stampW, q);
         rc = fv_halo_copy(c, lay, 6, 1);
         if (rc) return rc;
     }
