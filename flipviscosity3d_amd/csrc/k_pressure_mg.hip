@@ -179,6 +179,45 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
         const MgLevel &B = T.lev[T.n - 1];
         const Lay &L = B.L;
         const int n = d_ncells(L);
+        if (n <= 1024 && (L.I + 2) * (L.J + 2) * (L.ke - L.kb + 2) <= 1000) {
+            // at most one cell per thread: its row of the operator lives in registers, the iterate in LDS (with a zero rim),
+            // so a sweep is an LDS exchange instead of a round trip through L2 (17 sweeps: 25 of the kernel's 33 us before)
+            __shared__ float sx[2][1000];
+            const int q = threadIdx.x;
+            const int W = L.I + 2, H = L.J + 2;
+            for (int e = q; e < 2000; e += blockDim.x) (&sx[0][0])[e] = 0.0f;
+            float dd = 0.0f, ci = 0.0f, cim = 0.0f, cj = 0.0f, cjm = 0.0f, ck = 0.0f, ckm = 0.0f, bb = 0.0f;
+            int li = 0;
+            size_t c = 0;
+            if (q < n) {
+                int i, j, k;
+                d_cell_of(L, q, i, j, k);
+                c = gidx(L, i, j, k);
+                li = (i + 1) + W * ((j + 1) + H * (k - L.kb + 1));
+                dd = B.diag[c]; bb = B.b[c];
+                ci = B.pi[c]; cim = B.pi[c - 1]; cj = B.pj[c]; cjm = B.pj[c - L.sy]; ck = B.pk[c]; ckm = B.pk[c - L.sz];
+            }
+            __syncthreads();
+            if (q < n) sx[0][li] = dd != 0.0f ? MG_OMEGA * bb / dd : 0.0f;
+            __syncthreads();
+            int cur = 0;
+            for (int s = 0; s < MG_COARSEST_SWEEPS + 1; s++) {
+                if (q < n) {
+                    const float *x = sx[cur];
+                    float v = 0.0f;
+                    if (dd != 0.0f) {
+                        const float ax = dd * x[li] + ci * x[li + 1] + cim * x[li - 1] + cj * x[li + W] + cjm * x[li - W] + ck * x[li + W * H] +
+                                         ckm * x[li - W * H];
+                        v = x[li] + MG_OMEGA * (bb - ax) / dd;
+                    }
+                    sx[cur ^ 1][li] = v;
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (q < n) B.t[c] = sx[cur][li];
+            __syncthreads();
+        } else {
         float *cur = B.x, *nxt = B.t;
         for (int q = threadIdx.x; q < n; q += blockDim.x) {
             int i, j, k;
@@ -203,6 +242,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
             }
             __syncthreads();
             float *tmp = cur; cur = nxt; nxt = tmp;
+        }
         }
     }
     for (int l = T.n - 2; l >= 0; l--) {  // up
