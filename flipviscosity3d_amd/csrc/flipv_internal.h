@@ -128,7 +128,7 @@ struct flipv_context {
     double *d_scal_small;  // 64 doubles: communication scratch (counts, CFL max, barrier)
     double *h_scal;   // pinned host mirror
     size_t scalCap;
-    int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits, [4,5] graph iteration counters, [6] interior tile count
+    int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits, [4,5] graph iteration counters, [6] interior tile count, [7] in-domain indices of the listed tiles / 4
     int *h_flags;     // pinned host mirror
     int viscosity_nonzero;  // cached host-side: any viscosity node > 0
 

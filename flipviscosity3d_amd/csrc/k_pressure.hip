@@ -132,10 +132,15 @@ constexpr int ROWL = 64;
 // planes, appended after *prev entries (multi-rank: the SpMV of the interior tiles overlaps the halo exchange)
 __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ flag, int ntiles, int *__restrict__ list,
                                                        int *__restrict__ count, TileGrid tg, int k0, int nk, int mode,
-                                                       const int *__restrict__ prev) {
+                                                       const int *__restrict__ prev, int tw, int th, int wdom, int hdom,
+                                                       int *__restrict__ lanesIn) {
+    // lanesIn: indices of the listed tiles that lie inside the lattices' extent (wdom x hdom), in units of 4 -- the
+    // denominator of the tile fill that picks the geometry (a tile that hangs over the edge of the domain is not "empty")
     __shared__ int wsum[16];
     __shared__ int base;
-    if (threadIdx.x == 0) base = prev ? *prev : 0;
+    __shared__ int inside;
+    int acc = 0;
+    if (threadIdx.x == 0) { base = prev ? *prev : 0; inside = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int start = 0; start < ntiles; start += 1024) {
@@ -154,12 +159,23 @@ __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ f
         for (int q = 0; q < wv; q++) woff += wsum[q];
         int total = 0;
         for (int q = 0; q < 16; q++) total += wsum[q];
-        if (f) list[base + woff + before] = d_virtual_tile(t, tg, k0, nk);
+        if (f) {
+            const int tile = d_virtual_tile(t, tg, k0, nk);
+            list[base + woff + before] = tile;
+            const int tx = tile % tg.ntx, ty = (tile / tg.ntx) % tg.nty;
+            const int w = min(tw, wdom - tx * tw), h = min(th, hdom - ty * th);
+            if (w > 0 && h > 0) acc += (w * h + 3) >> 2;
+        }
         __syncthreads();
         if (threadIdx.x == 0) base += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *count = base;
+    if (acc) atomicAdd(&inside, acc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *count = base;
+        *lanesIn = (mode == 2 ? *lanesIn : 0) + inside;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,7 +211,8 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
     GEO_RUN(tg.rowl, hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, mask, c->tileFlag, c->k0, nk));
     if (!c->comm) {
         hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 0,
-                           (const int *)nullptr);
+                           (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
+        HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         *nActive = *nInterior = c->h_flags[1];
@@ -203,9 +220,10 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
     }
     // list = [tiles of the interior planes | tiles of the slab's first and last plane]
     hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 6, tg, c->k0, nk, 1,
-                       (const int *)nullptr);
+                       (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
     hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 2,
-                       (const int *)(c->d_flags + 6));
+                       (const int *)(c->d_flags + 6), tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
+    HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 6, c->d_flags + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -238,9 +256,9 @@ int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *
     int rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior);
     if (rc) return rc;
     if (!c->forceRowl && *nActive > 0) {
-        // how full the tiles are: indices with unknowns / indices of the listed tiles (256 vw each, either geometry)
-        const double fill = ((double)*hostCount / perIndex) / ((double)*nActive * 256.0 * vw);
-        const int want = (rowl == 64 && fill < 0.45) ? 16 : ((rowl == 16 && fill > 0.80) ? 64 : rowl);
+        // how full the tiles are: indices with unknowns / indices of the listed tiles inside the lattices' extent
+        const double fill = c->h_flags[7] > 0 ? ((double)*hostCount / perIndex) / (4.0 * (double)c->h_flags[7]) : 1.0;
+        const int want = (rowl == 64 && fill < 0.45) ? 16 : ((rowl == 16 && fill > 0.65) ? 64 : rowl);
         if (want != rowl) {
             *tg = make_tile_grid(c->L, want, vw);
             if ((rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior))) return rc;

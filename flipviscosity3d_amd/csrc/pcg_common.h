@@ -259,7 +259,8 @@ static inline int pcg_grid(const flipv_context *c, int ntiles) {
     return nb < 8 ? 8 : (nb < cap ? nb : cap);
 }
 // Builds the tile list and picks the geometry: starts from *tg's (the previous solve's), and switches when the tiles come out
-// less than 45 % full with 64-lane rows / more than 80 % full with 16-lane rows.  `hostCount` (read after the internal
+// less than 45 % full with 64-lane rows / more than 65 % full with 16-lane rows (full = share of the listed tiles' indices
+// inside the lattices' extent that carry unknowns).  `hostCount` (read after the internal
 // synchronisation) = unknowns of this rank, `perIndex` unknowns per index (1 pressure, 3 viscosity).
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap);
