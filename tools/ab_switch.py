@@ -8,7 +8,7 @@ sys.path.insert(0, os.getcwd())
 from bench import build_scene
 from flipviscosity3d_amd.capi import Context
 
-N = 256
+N = int(os.environ.get("AB_N", "256"))
 idx = int(sys.argv[1])
 dx, solid, P = build_scene(N, 5.0)
 for val in [int(a) for a in sys.argv[2:]]:
