@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1 only: attach a one-rank RCCL communicator, so that the multi-rank code path (split SpMV launches, "
                          "halo stream, per-iteration all-reduce) is what gets timed: a lower bound of its overhead")
+    ap.add_argument("--viscosity-cap", type=int, default=700,
+                    help="iteration cap of the viscosity PCG: 700 = the reference's (equal-work timing, SURVEY 8d mode A); "
+                         "a large value runs the solve to its 1e-6 tolerance (equal-accuracy, mode B)")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
     args = ap.parse_args()
 
@@ -188,7 +191,7 @@ def main():
         del solid_g, parts
     c.set_viscosity(args.viscosity)
     c.set_gravity(0.0, -9.81, 0.0)
-    c.set_params(precision=args.precision, kernel_timing=1)
+    c.set_params(precision=args.precision, kernel_timing=1, viscosity_max_iterations=args.viscosity_cap)
     c.particles = particles
     dev_name = c.device_name()
 
@@ -263,7 +266,7 @@ def main():
                 "workload": "%d^3 bunny drop: stanford_bunny.ply liquid in inverted sphere_large.ply, viscosity %g, "
                             "full variational viscosity + pressure substep (BASELINE.json configs[2])" % (N, args.viscosity),
                 "grid": [N, N, N * world], "particles_per_rank": int(len(particles)), "dt": 0.01,
-                "viscosity_cap": 700, "parallelism": ("single GPU" + (", one-rank RCCL communicator attached" if args.force_comm else "")) if world == 1 else
+                "viscosity_cap": args.viscosity_cap, "parallelism": ("single GPU" + (", one-rank RCCL communicator attached" if args.force_comm else "")) if world == 1 else
                 "%d slabs along k of a %dx%dx%d domain (%d stacked copies of the scene), RCCL halo exchange + PCG scalar "
                 "all-reduce + particle migration" % (world, N, N, N * world, world),
             },
