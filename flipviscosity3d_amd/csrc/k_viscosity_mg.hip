@@ -80,6 +80,7 @@ struct FineOp {          // the matrix-free level 0 (k_viscosity.hip's arrays)
     const uint8_t *mask;
 };
 
+__device__ unsigned g_dropped[2];
 static Lay coarse_lay(const Lay &F) {
     Lay C;
     C.I = (F.I + 1) / 2; C.J = (F.J + 1) / 2; C.K = (F.K + 1) / 2;
@@ -111,9 +112,10 @@ __device__ __forceinline__ int d_parents(int c, const int p[3], int P[2][3], flo
 // add value to the coarse entry (row (c, I), column (c2, J)); the offset J - I is always one of the 23 slots
 __device__ __forceinline__ void d_coarse_add(const VLevelDev &C, int c, const int I[3], int c2, const int J[3], float v) {
     const int dx = J[0] - I[0], dy = J[1] - I[1], dz = J[2] - I[2];
-    if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) return;  // cannot happen: the pattern is closed under this coarsening
+    if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) { if (v != 0.0f) atomicAdd(&g_dropped[0], 1u); return; }  // cannot happen: the pattern is closed under this coarsening
     const int s = ST.lut[c][c2][(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)];
     if (s >= 0) atomicAdd(C.coef[c][s] + gidx(C.L, I[0], I[1], I[2]), v);
+    else if (v != 0.0f) atomicAdd(&g_dropped[1], 1u);
 }
 // scatter one entry A(a, b) = v of a finer level into the coarse operator
 __device__ __forceinline__ void d_rap_entry(const VLevelDev &C, int c, const int p[3], int c2, const int q[3], float v) {
@@ -279,7 +281,8 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         Lay F = c->L;
         while (true) {
             const int mx = F.I > F.J ? (F.I > F.K ? F.I : F.K) : (F.J > F.K ? F.J : F.K);
-            if (mx <= 4 || s->lev.size() >= 8) break;
+            static const int minDim = getenv("FLIPV_VMG_MINDIM") ? atoi(getenv("FLIPV_VMG_MINDIM")) : 4;
+            if (mx <= minDim || s->lev.size() >= 8) break;
             VLevel l;
             l.L = coarse_lay(F);
             const size_t per = l.L.n + 2 * l.L.guard;
@@ -310,6 +313,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         for (size_t l = 0; l + 1 < s->lev.size(); l++)
             hipLaunchKernelGGL(k_vmg_rap, LGRID(s->lev[l].L), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
     }
+    if (getenv("FLIPV_VMG_DEBUG")) { unsigned h[2]; (void)hipStreamSynchronize(c->stream); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dropped), sizeof(h)); fprintf(stderr, "vmg dropped entries: out of range %u, no slot %u\n", h[0], h[1]); }
     HIPCHK(c, hipGetLastError());
     *out = s;
     return FLIPV_OK;
@@ -322,7 +326,8 @@ static void vmg_coarse(flipv_context *c, VmgState *s, size_t l) {
     const bool last = l + 1 == s->lev.size();
     hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.x), v3(A.b), v3(A.x), 0);      // x = omega b/d
     if (last) {
-        for (int q = 0; q < VMG_COARSEST_SWEEPS; q += 2) {
+        static const int sweeps = getenv("FLIPV_VMG_SWEEPS") ? atoi(getenv("FLIPV_VMG_SWEEPS")) : VMG_COARSEST_SWEEPS;
+        for (int q = 0; q < sweeps; q += 2) {
             hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.x), v3(A.b), v3(A.y), 1);
             hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.y), v3(A.b), v3(A.x), 1);
         }
