@@ -114,3 +114,46 @@ def test_tile_geometry_follows_the_liquid():
     assert rel_maxnorm3(va, vb) <= 1e-4   # two runs differ by the order of the fp32 scatter atomics, amplified by the solves (measured 4e-5)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("dims", [(37, 19, 23), (70, 33, 9)])
+@pytest.mark.parametrize("rowl", [16, 64])
+def test_odd_sized_domains_match_oracle(oracle, dims, rowl, monkeypatch):
+    """extents that are not multiples of anything the kernels like (lanes of 4, patches of 8 x 4, tiles of 64 x 16 or
+    256 x 4, 8^3 bins): the padded index space, partial tiles and the swizzled plane layout against the oracle, in both
+    tile geometries"""
+    from flipviscosity3d_amd import capi, hostapi as H
+    monkeypatch.setenv("FLIPV_ROWL", str(rowl))
+    I, J, K = dims
+    dx = float(np.float32(1.0 / max(dims)))
+    s = H.FluidSimulation()
+    s.initialize(I, J, K, dx)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 5)
+    s.addLiquid(box_mesh((2.3 * dx, 2.2 * dx, 2.4 * dx), ((I - 2.6) * dx, (J - 5.3) * dx, (K - 2.2) * dx)))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    x = P[:, 0] / (I * dx)
+    P[:, 3] = 0.3 * np.sin(5 * np.pi * x)
+    P[:, 4] = 0.1 * np.cos(3 * np.pi * x)
+    P[:, 5] = 0.05 * np.sin(2 * np.pi * x)
+    nu, dt = 3.0, 0.004
+    c = capi.Context(I, J, K, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(nu)
+    c.set_params(viscosity_max_iterations=20000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+    o = oracle.OracleSim(I, J, K, dx)
+    o.set_solid(solid)
+    o.set_viscosity(nu)
+    o.set_solver_limits(vmaxiter=20000)
+    o.particles = P
+    for t in range(2):
+        c.particles = o.particles
+        st = c.substep(dt)
+        sec, vi, pi = o.substep(dt)
+        assert st["viscosity"]["status"] == 0 and vi["status"] == 0 and st["viscosity"]["rows"] == vi["rows"]
+        got, ref = [c.grid(n) for n in "UVW"], [o.grid(n) for n in "UVW"]
+        assert rel_maxnorm3(got, ref) <= 1e-4, (t, rel_maxnorm3(got, ref))
+        assert np.array_equal(c.grid("LIQUID_PHI"), o.grid("LIQUID_PHI"))
+        assert np.abs(c.particles[:, :3] - o.particles[:, :3]).max() <= 2e-7
+    c.close()
+    o.close()
