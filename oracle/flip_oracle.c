@@ -899,14 +899,22 @@ static int rowW(const vsys *s, int i, int j, int k) { return s->table[s->woff + 
         if ((STATE) == FS_SOLID) rval -= (coef) * (VEL);     \
     } while (0)
 
-static const char *g_visc_dump = NULL;
+static char *g_visc_dump = NULL; /* owned copy of the path (the caller's buffer may be a ctypes temporary) */
 /* research hook: externally supplied control volumes (center,U,V,W,edgeU,edgeV,edgeW) and face states (U,V,W) replace
  * the ones oracle_viscosity_solve derives from phi / the solid SDF; NULL restores the normal path */
 static const float *const *g_vol_override = NULL;
 static const uint8_t *const *g_state_override = NULL;
 void oracle_viscosity_override(const float *const *vols7, const uint8_t *const *states3) { g_vol_override = vols7; g_state_override = states3; }
 /* when set (non-NULL path), the next oracle_viscosity_solve calls also write their assembled system to that file */
-void oracle_viscosity_dump_to(const char *path) { g_visc_dump = path; }
+void oracle_viscosity_dump_to(const char *path) {
+    free(g_visc_dump);
+    g_visc_dump = NULL;
+    if (path && path[0]) {
+        size_t n = strlen(path) + 1;
+        g_visc_dump = (char *)malloc(n);
+        if (g_visc_dump) memcpy(g_visc_dump, path, n);
+    }
+}
 
 void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U, float *V, float *W,
                             const float *phi, const float *solid, const float *visc, double tol, int maxiter,
