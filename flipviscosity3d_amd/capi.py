@@ -47,7 +47,13 @@ class Params(C.Structure):
                 ("pressure_rel_tolerance", C.c_double), ("pressure_max_iterations", C.c_int),
                 ("viscosity_tolerance", C.c_double), ("viscosity_max_iterations", C.c_int),
                 ("viscosity_accept_tolerance", C.c_double), ("precision", C.c_int),
-                ("kernel_timing", C.c_int), ("check_every", C.c_int), ("reserved", C.c_int * 8)]
+                ("kernel_timing", C.c_int), ("check_every", C.c_int),
+                ("pressure_preconditioner", C.c_int), ("viscosity_preconditioner", C.c_int),
+                ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
+                ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int),
+                ("viscosity_update_grid_cap", C.c_int), ("reserved", C.c_int * 4)]
+
+PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID = 0, 1, 2
 
 
 class SolveInfo(C.Structure):

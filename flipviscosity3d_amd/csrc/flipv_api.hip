@@ -291,6 +291,13 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         c->err = "flipv_set_params: invalid parameter";
         return FLIPV_ERR_INVALID;
     }
+    if (c->comm && c->comm->nranks > 1 && c->k1 - c->k0 < fv_min_slab_planes(p->cfl_number)) {
+        c->err = "flipv_set_params: cfl_number needs a halo of " + std::to_string(fv_min_slab_planes(p->cfl_number)) + " planes, this rank's slab has " +
+                 std::to_string(c->k1 - c->k0);
+        return FLIPV_ERR_INVALID;
+    }
+    for (int r = 0; r < 4; r++)
+        if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
     c->prm = *p;
     return FLIPV_OK;
 }

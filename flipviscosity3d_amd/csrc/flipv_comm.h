@@ -43,3 +43,5 @@ int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi,
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n);
 int fv_migrate_particles(flipv_context *c);
 int fv_allreduce_max_f32(flipv_context *c, float *value);  // host value in/out (synchronises)
+// thinnest slab a multi-rank run accepts: the widest exchange moves ceil(cfl) + 3 of a rank's own planes
+static inline int fv_min_slab_planes(float cfl_number) { return (int)ceilf(cfl_number) + 3; }

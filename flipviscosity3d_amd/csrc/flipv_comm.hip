@@ -393,9 +393,30 @@ extern "C" int flipv_comm_get_unique_id(void *id_out) {
     return FLIPV_OK;
 }
 
+// Limits a communicator must respect (checked here, where the rank count becomes known):
+//  * nranks <= NSLOT (32): every rank accumulates its PCG partial sums into its own slots of the NSLOT-wide slot block
+//    (pcg_common.h), and fv_allreduce_max_f32 / the RCCL barrier use one double per rank of the 64-entry scratch;
+//  * a slab must be at least ceil(cfl_number) + 3 planes thick: the widest exchange (the velocity halo of particle
+//    advection) sends that many of its OWN planes to a neighbour that posts a receive of exactly that size, and
+//    migration / halo reductions only ever talk to the two adjacent ranks.
+static int comm_check(flipv_context *c, int nranks) {
+    if (nranks > NSLOT) {
+        c->err = "flipv_comm_init: at most " + std::to_string(NSLOT) + " ranks per communicator (got " + std::to_string(nranks) + ")";
+        return FLIPV_ERR_INVALID;
+    }
+    const int need = fv_min_slab_planes(c->prm.cfl_number);
+    if (nranks > 1 && c->k1 - c->k0 < need) {
+        c->err = "flipv_comm_init: slab [" + std::to_string(c->k0) + ", " + std::to_string(c->k1) + ") is thinner than the widest halo (" +
+                 std::to_string(need) + " planes = ceil(cfl_number) + 3)";
+        return FLIPV_ERR_INVALID;
+    }
+    return FLIPV_OK;
+}
+
 extern "C" int flipv_comm_init_rccl(flipv_context *c, const void *unique_id, int rank, int nranks) {
     if (!c || !unique_id || rank < 0 || rank >= nranks) return FLIPV_ERR_INVALID;
     if (c->comm) { c->err = "flipv_comm_init: communicator already set"; return FLIPV_ERR_INVALID; }
+    { const int rc = comm_check(c, nranks); if (rc) return rc; }
     if (!rccl_load(&c->err)) return FLIPV_ERR_COMM;
     HIPCHK(c, hipSetDevice(c->device));
     RcclComm *cm = new RcclComm();
@@ -411,6 +432,7 @@ extern "C" int flipv_comm_init_rccl(flipv_context *c, const void *unique_id, int
 extern "C" int flipv_comm_init_local(flipv_context **ctxs, int n) {
     if (!ctxs || n < 1) return FLIPV_ERR_INVALID;
     for (int r = 0; r < n; r++) if (!ctxs[r] || ctxs[r]->comm) return FLIPV_ERR_INVALID;
+    for (int r = 0; r < n; r++) { const int rc = comm_check(ctxs[r], n); if (rc) return rc; }
     LocalGroup *g = new LocalGroup();
     g->n = n; g->refs = n;
     g->ops.resize((size_t)n);

@@ -76,6 +76,9 @@ static inline TileGrid make_tile_grid(const Lay &L, int rowl, int vw) {
 }
 
 struct Comm;
+// partial-sum slots per reduced PCG scalar (pcg_common.h); ranks of a communicator own disjoint slot ranges, so this is
+// also the largest rank count a communicator accepts
+constexpr int NSLOT = 32;
 
 struct flipv_context {
     Lay L;           // kb/ke = the whole index space; per-launch ranges come from fv_range()

@@ -595,7 +595,7 @@ int fv_particle_sdf(flipv_context *c) {
     if (c->np) {
         // _particleRadius (fluidsimulation.cpp:36)
         const float radius = (float)(c->dx * 1.01 * sqrt(3.0) / 2.0);
-        if (c->prm.reserved[1]) {  // un-binned scatter (kept for A/B measurements)
+        if (c->prm.unbinned_scatter) {  // un-binned scatter (kept for A/B measurements)
             hipLaunchKernelGGL(k_sdf_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
                                c->phi, c->dx, radius);
         } else {
@@ -621,7 +621,7 @@ int fv_p2g(flipv_context *c) {
     float *acc[6] = {c->accU, c->accV, c->accW, c->wgtU, c->wgtV, c->wgtW};
     for (int q = 0; q < 6; q++) HIPCHK(c, hipMemsetAsync(acc[q] + off, 0, bytes, c->stream));
     if (c->np) {
-        if (c->prm.reserved[1]) {  // un-binned scatter (kept for A/B measurements)
+        if (c->prm.unbinned_scatter) {  // un-binned scatter (kept for A/B measurements)
             hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,
                                c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, c->dx);
         } else {

@@ -335,8 +335,8 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
 
     int conv = -1;
     // preconditioner: aggregation multigrid with fp32 vectors (k_pressure_mg.hip; rank-local in a slab-decomposed run), the
-    // diagonal otherwise (fp64 vectors, tiny grids, or flipv_params.reserved[4] = 1)
-    const bool useMg = f32 && c->prm.reserved[4] != 1 && (L.I > 16 || L.J > 16 || L.K > 16);  // at least two levels below the tile-list level
+    // diagonal otherwise (fp64 vectors, tiny grids, or flipv_params.pressure_preconditioner = DIAGONAL)
+    const bool useMg = f32 && c->prm.pressure_preconditioner != FLIPV_PRECOND_DIAGONAL && (L.I > 16 || L.J > 16 || L.K > 16);  // at least two levels below the tile-list level
     li.preconditioner = useMg ? 1 : 0;
     if (useMg) {
         if ((rc = fv_pressure_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s, int it) { launch_pressure_spmv<float>(cc, s, it, 0, cc->nActiveP); },

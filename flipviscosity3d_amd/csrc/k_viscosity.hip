@@ -409,9 +409,9 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spm
 template <typename T, int NV>
 static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count, const PcgSys<T, 3> *sys = nullptr) {
     // one resident round: the 4-wide kernel holds 189 VGPRs = 2 waves per SIMD = 2 blocks per CU = 512 blocks (measured over
-    // 512..1024 at 256^3: 37.2 ms per solve at 512, 38.1 at 1024, 40.8-43.6 in between); reserved[5] overrides
+    // 512..1024 at 256^3: 37.2 ms per solve at 512, 38.1 at 1024, 40.8-43.6 in between); flipv_params.viscosity_spmv_grid_cap overrides
     int nb = pcg_grid(c, count);
-    const int cap = c->prm.reserved[5] > 0 ? c->prm.reserved[5] : (NV == 4 ? 512 : 1024);
+    const int cap = c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : (NV == 4 ? 512 : 1024);
     if (nb > cap) nb = cap;
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 1, (double)count * (256 * NV));
@@ -493,7 +493,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // plain, and so does everything under the opt-in multigrid.  The geometry is only known once the tiles are built,
     // so the setup kernel runs in the layout of the previous solve's geometry and is repeated on the rare solve where
     // the geometry changes.
-    const bool swzOk = c->allowSwz && c->prm.reserved[7] != 1;
+    const bool swzOk = c->allowSwz && c->prm.viscosity_preconditioner != FLIPV_PRECOND_MULTIGRID;
     const int precNow = std::is_same<T, float>::value ? 0 : 1;
     auto run_setup = [&](int swz) -> int {
         // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers
@@ -518,7 +518,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     HIPCHK(c, hipStreamSynchronize(c->stream));  // h_flags[2] = row count
     const double fill = (double)c->h_flags[2] / (3.0 * (double)(c->k1 - c->k0) * (double)L.PX * (double)L.PY);
     c->vwV = 4;
-    if (c->prm.reserved[3] == 2 || c->prm.reserved[3] == 4) c->vwV = c->prm.reserved[3];  // measurement switch: forced lane width
+    if (c->prm.viscosity_lane_width == 2 || c->prm.viscosity_lane_width == 4) c->vwV = c->prm.viscosity_lane_width;  // measurement switch: forced lane width
     c->vPred = fill <= 0.35;
     rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3, &c->mlistV, &c->mlistCapV);
     if (rc) return rc;
@@ -550,10 +550,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     } else {
         sc.tol = c->prm.viscosity_tolerance * bnorm;
         int nb = pcg_grid(c, c->nActiveV);
-        if (c->prm.reserved[6] > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.reserved[6]) nb = c->prm.reserved[6]; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
+        if (c->prm.viscosity_update_grid_cap > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.viscosity_update_grid_cap) nb = c->prm.viscosity_update_grid_cap; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
         const dim3 blk(64, 4, 1);
         const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
-        const bool useMg = std::is_same<T, float>::value && !c->comm && c->prm.reserved[7] == 1 && c->vwV == 4;
+        const bool useMg = std::is_same<T, float>::value && !c->comm && c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID && c->vwV == 4;
         li.preconditioner = useMg ? 1 : 0;
         if (useMg) {
             if ((rc = fv_viscosity_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); },

@@ -80,7 +80,7 @@ template <> __device__ __forceinline__ double d_recip<double>(float d) { return 
 // Every reduced scalar of iteration `it` is spread over NSLOT partial sums (slot = blockIdx & (NSLOT-1)) so that the
 // one-atomic-per-block accumulation does not serialise on a single L2 address (thousands of blocks per launch);
 // the consuming kernel folds the NSLOT partials with one wave.
-constexpr int NSLOT = 32;
+// (NSLOT itself lives in flipv_internal.h: it also bounds the number of ranks of a communicator)
 // Layout of ctx->d_scal: block `it` = [sig | a | b | c | rmax] x NSLOT doubles.  rmax[it-1], sig[it] (both left by
 // update it-1) and a,b,c[it] (left by SpMV it) are contiguous: ONE all-reduce per iteration, between SpMV and update.
 // In a multi-rank run rank r accumulates only into slots [slot0, slot0 + nslot): the slots are disjoint between
@@ -253,7 +253,7 @@ static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<
 int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT+16 doubles
 // never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
 static inline int pcg_grid(const flipv_context *c, int ntiles) {
-    int cap = c->prm.reserved[2] > 0 ? ((c->prm.reserved[2] + 7) / 8) * 8 : MAX_PCG_BLOCKS;  // test hook: small grids make every block walk many tiles
+    int cap = c->prm.grid_cap > 0 ? ((c->prm.grid_cap + 7) / 8) * 8 : MAX_PCG_BLOCKS;  // test hook: small grids make every block walk many tiles
     if (cap > MAX_PCG_BLOCKS) cap = MAX_PCG_BLOCKS;
     const int nb = ((ntiles + 7) / 8) * 8;
     return nb < 8 ? 8 : (nb < cap ? nb : cap);
@@ -298,7 +298,7 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         update(it);
         return FLIPV_OK;
     };
-    const bool graph = !c->comm && !c->prm.kernel_timing && !c->prm.reserved[0];
+    const bool graph = !c->comm && !c->prm.kernel_timing && !c->prm.no_graph_replay;
     if (graph) {
         HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
         hipGraph_t g = nullptr;

@@ -77,6 +77,7 @@ void FluidSimulation::initialize(int i, int j, int k, float dx) {  // reference 
     _viscosityUniform = 1.0f;
     _viscosityGrid.clear();
     _gravity = vmath::vec3(0.0f, -9.81f, 0.0f);
+    for (int m = 0; m < 3; m++) std::vector<float>().swap(_restoreVel[m]);
     _solidDirty = _viscosityDirty = _gravityDirty = true;
     _initializeBoundary();
 }
@@ -92,6 +93,12 @@ void FluidSimulation::_ensureContext() {
             std::abort();
         }
         _solidDirty = _viscosityDirty = _gravityDirty = true;
+        if (!_restoreVel[0].empty()) {  // resumed from a checkpoint: the MAC field the last substep left (read by _cfl)
+            for (int m = 0; m < 3; m++) {
+                FLIPV_CALL(flipv_write_grid(_ctx, FLIPV_GRID_U + m, _restoreVel[m].data()));
+                std::vector<float>().swap(_restoreVel[m]);
+            }
+        }
     }
     if (_solidDirty) FLIPV_CALL(flipv_set_solid_sdf(_ctx, _solidSDF.getRawArray()));
     if (_viscosityDirty) {
@@ -211,60 +218,108 @@ void FluidSimulation::addLiquid(TriangleMesh &mesh) {  // reference fluidsimulat
             }
 }
 
-// ---- checkpoint file: "FLIPVCK1", int32 I,J,K, float dx, float gravity[3], int32 viscosity kind (0 uniform, 1 grid),
-// float uniform viscosity, uint64 particle count, then solid SDF nodes, [viscosity nodes], particles (6 floats each)
+// ---- checkpoint file "FLIPVCK2": int32 I,J,K, float dx, float gravity[3], int32 viscosity kind (0 uniform, 1 grid),
+// float uniform viscosity, uint64 particle count, int32 hasVelocity, then solid SDF nodes, [viscosity nodes], particles
+// (6 floats each), [U (I+1,J,K), V (I,J+1,K), W (I,J,K+1)].  The MAC field is state: _cfl() of the next advance() reads
+// the velocities the previous substep left (reference fluidsimulation.cpp:139, 241-269), so a resumed run only takes the
+// same substeps as the uninterrupted one if the field comes back with the particles.
 bool FluidSimulation::saveState(const std::string &path) {
-    FILE *f = std::fopen(path.c_str(), "wb");
-    if (!f) return false;
     const MeshLevelSet &sdf = solidSDF();
     const size_t nodes = (size_t)(_isize + 1) * (_jsize + 1) * (_ksize + 1);
+    const size_t nf[3] = {(size_t)(_isize + 1) * _jsize * _ksize, (size_t)_isize * (_jsize + 1) * _ksize, (size_t)_isize * _jsize * (_ksize + 1)};
+    std::vector<float> vel[3];
+    int hasVel = 0;
+    if (_ctx) {  // a context exists once a frame has run (or device setup was used): fetch its field
+        hasVel = 1;
+        for (int m = 0; m < 3; m++) {
+            vel[m].resize(nf[m]);
+            if (flipv_read_grid(_ctx, FLIPV_GRID_U + m, vel[m].data()) < 0) return false;
+        }
+    } else if (!_restoreVel[0].empty()) {  // loaded but not advanced yet: pass the loaded field on
+        hasVel = 1;
+        for (int m = 0; m < 3; m++) vel[m] = _restoreVel[m];
+    }
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
     const int dims[3] = {_isize, _jsize, _ksize};
     const float g[3] = {_gravity.x, _gravity.y, _gravity.z};
     const int kind = _viscosityGrid.empty() ? 0 : 1;
     const unsigned long long np = particles.size();
-    bool ok = std::fwrite("FLIPVCK1", 1, 8, f) == 8 && std::fwrite(dims, sizeof(int), 3, f) == 3 && std::fwrite(&_dx, sizeof(float), 1, f) == 1 &&
+    bool ok = std::fwrite("FLIPVCK2", 1, 8, f) == 8 && std::fwrite(dims, sizeof(int), 3, f) == 3 && std::fwrite(&_dx, sizeof(float), 1, f) == 1 &&
               std::fwrite(g, sizeof(float), 3, f) == 3 && std::fwrite(&kind, sizeof(int), 1, f) == 1 &&
-              std::fwrite(&_viscosityUniform, sizeof(float), 1, f) == 1 && std::fwrite(&np, sizeof(np), 1, f) == 1;
+              std::fwrite(&_viscosityUniform, sizeof(float), 1, f) == 1 && std::fwrite(&np, sizeof(np), 1, f) == 1 &&
+              std::fwrite(&hasVel, sizeof(int), 1, f) == 1;
     ok = ok && std::fwrite(sdf.getRawArray(), sizeof(float), nodes, f) == nodes;
     if (kind) ok = ok && std::fwrite(_viscosityGrid.data(), sizeof(float), nodes, f) == nodes;
     if (np) ok = ok && std::fwrite(&particles[0].position.x, sizeof(FluidParticle), (size_t)np, f) == (size_t)np;
+    if (hasVel)
+        for (int m = 0; m < 3; m++) ok = ok && std::fwrite(vel[m].data(), sizeof(float), nf[m], f) == nf[m];
     return std::fclose(f) == 0 && ok;
 }
 
+// The header is not trusted: dimensions are capped, the payload the header promises is checked against the file length
+// before anything is allocated, and no exception leaves this function (it sits behind an extern "C" wrapper).
 bool FluidSimulation::loadState(const std::string &path) {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
-    char magic[8];
-    int dims[3], kind = 0;
-    float dx = 0, g[3], nu = 0;
-    unsigned long long np = 0;
-    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "FLIPVCK1", 8) == 0 && std::fread(dims, sizeof(int), 3, f) == 3 &&
-              std::fread(&dx, sizeof(float), 1, f) == 1 && std::fread(g, sizeof(float), 3, f) == 3 && std::fread(&kind, sizeof(int), 1, f) == 1 &&
-              std::fread(&nu, sizeof(float), 1, f) == 1 && std::fread(&np, sizeof(np), 1, f) == 1;
-    ok = ok && dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dx > 0 && (kind == 0 || kind == 1) && nu >= 0;
-    if (!ok) { std::fclose(f); return false; }
-    const size_t nodes = (size_t)(dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1);
-    std::vector<float> solid(nodes), visc(kind ? nodes : 0);
-    std::vector<FluidParticle> parts((size_t)np);
-    ok = std::fread(solid.data(), sizeof(float), nodes, f) == nodes;
-    if (kind) ok = ok && std::fread(visc.data(), sizeof(float), nodes, f) == nodes;
-    if (np) ok = ok && std::fread(&parts[0].position.x, sizeof(FluidParticle), (size_t)np, f) == (size_t)np;
-    std::fclose(f);
-    if (!ok) return false;
-    const bool dev = _setupOnDevice;
-    _setupOnDevice = false;  // the solid SDF comes from the file, no boundary to build
-    _destroy();
-    _isize = dims[0]; _jsize = dims[1]; _ksize = dims[2]; _dx = dx;
-    _solidSDF = MeshLevelSet(_isize, _jsize, _ksize, _dx);
-    std::memcpy(_solidSDF.getRawArray(), solid.data(), nodes * sizeof(float));
-    _solidHostStale = false;
-    _viscosityUniform = nu;
-    _viscosityGrid.swap(visc);
-    _gravity = vmath::vec3(g[0], g[1], g[2]);
-    particles.swap(parts);
-    _solidDirty = _viscosityDirty = _gravityDirty = true;
-    _setupOnDevice = dev;
-    return true;
+    try {
+        char magic[8];
+        int dims[3], kind = 0, hasVel = 0;
+        float dx = 0, g[3], nu = 0;
+        unsigned long long np = 0;
+        bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "FLIPVCK2", 8) == 0 && std::fread(dims, sizeof(int), 3, f) == 3 &&
+                  std::fread(&dx, sizeof(float), 1, f) == 1 && std::fread(g, sizeof(float), 3, f) == 3 && std::fread(&kind, sizeof(int), 1, f) == 1 &&
+                  std::fread(&nu, sizeof(float), 1, f) == 1 && std::fread(&np, sizeof(np), 1, f) == 1 && std::fread(&hasVel, sizeof(int), 1, f) == 1;
+        const int maxDim = 1 << 14;  // (2^14+1)^3 nodes still fit a size_t product by a wide margin
+        ok = ok && dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[0] <= maxDim && dims[1] <= maxDim && dims[2] <= maxDim &&
+             dx > 0 && (kind == 0 || kind == 1) && nu >= 0 && (hasVel == 0 || hasVel == 1);
+        if (!ok) { std::fclose(f); return false; }
+        const size_t I = (size_t)dims[0], J = (size_t)dims[1], K = (size_t)dims[2];
+        const size_t nodes = (I + 1) * (J + 1) * (K + 1);
+        const size_t nf[3] = {(I + 1) * J * K, I * (J + 1) * K, I * J * (K + 1)};
+        const long here = std::ftell(f);
+        ok = here >= 0 && std::fseek(f, 0, SEEK_END) == 0;
+        const long end = ok ? std::ftell(f) : -1;
+        ok = ok && end >= here && std::fseek(f, here, SEEK_SET) == 0;
+        if (ok) {
+            const unsigned long long remaining = (unsigned long long)(end - here);
+            const unsigned long long gridBytes = 4ull * (nodes * (unsigned long long)(1 + kind) + (hasVel ? nf[0] + nf[1] + nf[2] : 0));
+            ok = gridBytes <= remaining && np <= (remaining - gridBytes) / sizeof(FluidParticle) &&
+                 gridBytes + np * sizeof(FluidParticle) == remaining;
+        }
+        if (!ok) { std::fclose(f); return false; }
+        std::vector<float> solid(nodes), visc(kind ? nodes : 0), vel[3];
+        std::vector<FluidParticle> parts((size_t)np);
+        ok = std::fread(solid.data(), sizeof(float), nodes, f) == nodes;
+        if (kind) ok = ok && std::fread(visc.data(), sizeof(float), nodes, f) == nodes;
+        if (np) ok = ok && std::fread(&parts[0].position.x, sizeof(FluidParticle), (size_t)np, f) == (size_t)np;
+        if (hasVel)
+            for (int m = 0; m < 3; m++) {
+                vel[m].resize(nf[m]);
+                ok = ok && std::fread(vel[m].data(), sizeof(float), nf[m], f) == nf[m];
+            }
+        std::fclose(f);
+        f = nullptr;
+        if (!ok) return false;
+        const bool dev = _setupOnDevice;
+        _setupOnDevice = false;  // the solid SDF comes from the file, no boundary to build
+        _destroy();
+        _isize = dims[0]; _jsize = dims[1]; _ksize = dims[2]; _dx = dx;
+        _solidSDF = MeshLevelSet(_isize, _jsize, _ksize, _dx);
+        std::memcpy(_solidSDF.getRawArray(), solid.data(), nodes * sizeof(float));
+        _solidHostStale = false;
+        _viscosityUniform = nu;
+        _viscosityGrid.swap(visc);
+        _gravity = vmath::vec3(g[0], g[1], g[2]);
+        particles.swap(parts);
+        for (int m = 0; m < 3; m++) _restoreVel[m].swap(vel[m]);   // written into the context when it is created
+        _solidDirty = _viscosityDirty = _gravityDirty = true;
+        _setupOnDevice = dev;
+        return true;
+    } catch (...) {  // bad_alloc / length_error from a header that passed the checks but cannot be served
+        if (f) std::fclose(f);
+        return false;
+    }
 }
 
 void FluidSimulation::setViscosity(float value) {  // reference fluidsimulation.cpp:99-108

@@ -60,9 +60,10 @@ public:
     // path, far-field distances of the solid SDF are the relaxed ones (include/flipv.h).
     void setSetupOnDevice(bool on) { _setupOnDevice = on; }
     // Checkpoint (the reference cannot stop and resume a run): grid size, cell width, gravity, viscosity,
-    // solid SDF and the particles (positions + velocities) in one little-endian binary file.  loadState() re-initialises
-    // the simulation from the file; a run resumed from a checkpoint continues exactly like the uninterrupted one
-    // (the substep has no other state).  Both return false on I/O or format errors.
+    // solid SDF, the particles (positions + velocities) and the MAC velocity field of the last substep -- _cfl() of the
+    // next frame reads it (reference fluidsimulation.cpp:139, 241-269) -- in one little-endian binary file.  loadState()
+    // re-initialises the simulation from the file; a run resumed from a checkpoint takes the same substeps as the
+    // uninterrupted one.  Both return false on I/O or format errors (a header that does not match the file length included).
     bool saveState(const std::string &path);
     bool loadState(const std::string &path);
     void setQuiet(bool q) { _quiet = q; }                  // the reference prints phase banners on stdout
@@ -92,5 +93,6 @@ private:
     bool _solidDirty = true, _viscosityDirty = true, _gravityDirty = true;
     float _viscosityUniform = 1.0f;          // reference fluidsimulation.cpp:39
     std::vector<float> _viscosityGrid;       // non-empty after setViscosity(Array3d<float>&)
+    std::vector<float> _restoreVel[3];       // U, V, W of a loaded checkpoint until the context exists
     vmath::vec3 _gravity = vmath::vec3(0.0f, -9.81f, 0.0f);  // reference fluidsimulation.cpp:40
 };

@@ -3,10 +3,18 @@ stacked weak-scaling scenes.  Pure index arithmetic, no computation of the simul
 import numpy as np
 
 
-def slab_ranges(K, nranks):
-    """Split K cell planes into nranks contiguous slabs [k_begin, k_end), as evenly as possible."""
+MIN_SLAB_PLANES = 8   # ceil(cfl_number = 5) + 3: the widest halo a slab must be able to send from its own planes
+
+
+def slab_ranges(K, nranks, min_planes=MIN_SLAB_PLANES):
+    """Split K cell planes into nranks contiguous slabs [k_begin, k_end), as evenly as possible.  With more than
+    one rank every slab must hold at least `min_planes` planes (the library rejects thinner ones, include/flipv.h)."""
     if nranks < 1 or nranks > K:
         raise ValueError("need 1 <= nranks <= K")
+    if nranks > 32:
+        raise ValueError("at most 32 ranks per communicator")
+    if nranks > 1 and K // nranks < min_planes:
+        raise ValueError("slabs of %d planes are thinner than the widest halo (%d planes)" % (K // nranks, min_planes))
     base, rem = divmod(K, nranks)
     out, k = [], 0
     for r in range(nranks):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FLIPV_VERSION 1
+#define FLIPV_VERSION 2   /* 2: the measurement switches of flipv_params are named fields; block contexts */
 
 typedef struct flipv_context flipv_context;
 
@@ -60,6 +60,8 @@ enum flipv_grid {
     FLIPV_GRID_COUNT = 16
 };
 
+enum flipv_preconditioner { FLIPV_PRECOND_AUTO = 0, FLIPV_PRECOND_DIAGONAL = 1, FLIPV_PRECOND_MULTIGRID = 2 };
+
 enum flipv_precision {
     FLIPV_PRECISION_FP32 = 0, /* solver vectors fp32, every reduction and scalar fp64 (default) */
     FLIPV_PRECISION_FP64 = 1  /* solver vectors fp64 like the reference's VectorXd / std::vector<double> */
@@ -83,14 +85,17 @@ typedef struct flipv_params {
     int precision;               /* enum flipv_precision */
     int kernel_timing;           /* 1 => bracket every SpMV launch with HIP events (flipv_kernel_stats) */
     int check_every;             /* convergence poll interval in iterations; 0 (default) = 32 on one GPU, 8 with a communicator */
-    int reserved[8];             /* measurement switches, all 0 by default: [0]=1 no hipGraph replay of the PCG loop;
-                                    [1]=1 un-binned particle scatters (global atomics instead of LDS tiles);
-                                    [2]=n>0 caps the PCG kernels' grids at n blocks (tests: every block walks many tiles);
-                                    [3]=2|4 forces the lane width of the viscosity solver kernels;
-                                    [4]=1 diagonal preconditioner for the pressure PCG also where multigrid would be used;
-                                    [5]=n>0 grid cap of the viscosity SpMV kernel alone; [6]=n>0 of its init/update kernels;
-                                    [7]=1 Galerkin multigrid preconditioner for the viscosity PCG (fp32, one rank; experimental:
-                                    fewer iterations but slower than the diagonal) */
+    /* solver choice (enum flipv_preconditioner) */
+    int pressure_preconditioner; /* AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
+    int viscosity_preconditioner;/* AUTO = the diagonal; MULTIGRID = Galerkin multigrid (fp32 vectors, one rank) */
+    /* measurement / test switches, all 0 by default; results do not depend on them beyond solver tolerance */
+    int no_graph_replay;         /* 1: the PCG loop is launched kernel by kernel instead of replayed as a hipGraph */
+    int unbinned_scatter;        /* 1: particle scatters with global atomics instead of LDS tiles (A/B) */
+    int grid_cap;                /* n>0: cap of the PCG kernels' grids in blocks (tests: every block walks many tiles) */
+    int viscosity_lane_width;    /* 2|4: forced lane width of the viscosity solver kernels */
+    int viscosity_spmv_grid_cap; /* n>0: grid cap of the viscosity SpMV kernel alone */
+    int viscosity_update_grid_cap; /* n>0: grid cap of the viscosity init/update kernels */
+    int reserved[4];             /* must be 0 */
 } flipv_params;
 
 typedef struct flipv_solve_info {
@@ -170,8 +175,12 @@ int flipv_compute_weights(flipv_context *ctx);                    /* _computeWei
 int flipv_pressure_solve(flipv_context *ctx, float dt, flipv_solve_info *info);  /* PressureSolver::solve  pressuresolver.cpp:166-194 */
 int flipv_apply_pressure(flipv_context *ctx, float dt);           /* _applyPressure            fluidsimulation.cpp:598-688 */
 int flipv_constrain(flipv_context *ctx);                          /* _constrainVelocityField   fluidsimulation.cpp:696-729 */
-int flipv_update_particle_velocities(flipv_context *ctx);         /* _updateFluidParticleVelocities fluidsimulation.cpp:341-352 */
-int flipv_advect_particles(flipv_context *ctx, float dt);         /* _advectFluidParticles     fluidsimulation.cpp:315-339 */
+/* NOTE: flipv_advect_particles is the fused particle kernel of the substep -- it performs the PIC/FLIP velocity update
+ * (fluidsimulation.cpp:341-352) AND the RK2 advection (:315-339) in one pass over the particles, the order advance()
+ * calls them in.  flipv_update_particle_velocities exists for parity tests of the velocity update alone; calling both
+ * in sequence applies the velocity update twice. */
+int flipv_update_particle_velocities(flipv_context *ctx);         /* _updateFluidParticleVelocities fluidsimulation.cpp:341-352 (alone) */
+int flipv_advect_particles(flipv_context *ctx, float dt);         /* _updateFluidParticleVelocities + _advectFluidParticles  fluidsimulation.cpp:341-352, 315-339 */
 
 /* ---- scene setup on the device (single-domain contexts) ----------------------------
  * Meshes are passed as in TriangleMesh (trianglemesh.h:36-37): `vertices` = nvertices x {x,y,z} floats, `triangles` =
@@ -225,7 +234,10 @@ int flipv_bench_stream(flipv_context *ctx, size_t bytes, int reps, int mode, dou
  * (torch.distributed / MPI / a file), every rank calls flipv_comm_init_rccl.  Halo planes travel with grouped
  * ncclSend/ncclRecv, the PCG scalars with ncclAllReduce, all on the context's own stream.
  * Local backend: all ranks are contexts of ONE process on one device, each driven by its own host thread; it exists to
- * verify the decomposition against the single-domain result on a one-GPU machine. */
+ * verify the decomposition against the single-domain result on a one-GPU machine.
+ * Limits, checked by both init calls (FLIPV_ERR_INVALID): at most 32 ranks per communicator; with more than one rank every
+ * slab must be at least ceil(cfl_number) + 3 cell planes thick (the widest halo; flipv_set_params re-checks it when
+ * cfl_number changes). */
 int flipv_comm_unique_id_bytes(void);
 int flipv_comm_get_unique_id(void *id_out);
 int flipv_comm_init_rccl(flipv_context *ctx, const void *unique_id, int rank, int nranks);

@@ -71,10 +71,14 @@ def test_two_rank_host_logic():
 
 
 def test_slab_ranges_and_ownership():
-    assert partition.slab_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert partition.slab_ranges(10, 3, min_planes=1) == [(0, 4), (4, 7), (7, 10)]
     assert partition.slab_ranges(256, 8)[7] == (224, 256)
     with pytest.raises(ValueError):
         partition.slab_ranges(4, 5)
+    with pytest.raises(ValueError):      # thinner than the widest halo (ceil(cfl) + 3 planes): the library would reject it too
+        partition.slab_ranges(20, 3)
+    with pytest.raises(ValueError):      # a communicator holds at most 32 ranks
+        partition.slab_ranges(1024, 33)
     dx = 0.25
     p = np.zeros((5, 6), np.float32)
     p[:, 2] = [0.01, 0.26, 0.74, 0.99, -0.1]
@@ -86,7 +90,7 @@ def test_slab_ranges_and_ownership():
 
 def test_gather_owned():
     K = 6
-    ranges = partition.slab_ranges(K, 2)
+    ranges = partition.slab_ranges(K, 2, min_planes=1)
     a = np.zeros((K + 1, 2, 2)); b = np.ones((K + 1, 2, 2))
     g = partition.gather_owned([a, b], ranges, K)
     assert g[:3].sum() == 0 and (g[3:] == 1).all()          # the last rank also owns the closing plane

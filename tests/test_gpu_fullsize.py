@@ -40,9 +40,7 @@ def test_fullsize_scatters(scene):
     out = []
     for unbinned in (0, 1):
         c = ctx(scene)
-        p = c.get_params()
-        p.reserved[1] = unbinned
-        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.set_params(unbinned_scatter=unbinned)
         c.particles = Q
         c.particle_sdf()
         phi = c.grid("LIQUID_PHI")

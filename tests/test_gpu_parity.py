@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from helpers import SCENES, Golden, fluid_face_masks, rel_maxnorm, rel_maxnorm3
+from flipviscosity3d_amd.capi import PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID
 
 pytestmark = pytest.mark.gpu
 
@@ -65,14 +66,12 @@ def test_p2g_and_extrapolation(name):
 @pytest.mark.parametrize("precision", [0, 1])
 def test_solvers_with_many_tiles_per_block(name, precision):
     """The PCG kernels walk their tile lists with a grid stride; at the fixture sizes a block normally sees one tile.
-    flipv_params.reserved[2] caps the grid at 8 blocks so that every block loops over many tiles, as at 256^3."""
+    flipv_params.grid_cap caps the grid at 8 blocks so that every block loops over many tiles, as at 256^3."""
     import ctypes as C
     g = Golden(name)
     c = make_ctx(g, precision=precision, viscosity_max_iterations=5000, viscosity_tolerance=1e-7,
                  pressure_rel_tolerance=1e-7 if precision == 0 else 0.0)
-    p = c.get_params()
-    p.reserved[2] = 8
-    c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+    c.set_params(grid_cap=8)
     c.particles = g["particles0"]
     for t in range(g.nsub):
         st = c.substep(g.dt)
@@ -84,7 +83,7 @@ def test_solvers_with_many_tiles_per_block(name, precision):
 @pytest.mark.parametrize("name", SCENES)
 def test_pressure_preconditioners_agree(name):
     """fp32 pressure solve on one GPU: aggregation multigrid (default) against the diagonal preconditioner
-    (flipv_params.reserved[4] = 1) -- same pressure to the solver tolerance, far fewer iterations"""
+    (flipv_params.pressure_preconditioner = DIAGONAL) -- same pressure to the solver tolerance, far fewer iterations"""
     import ctypes as C
     g = Golden(name)
     t = g.nsub - 1
@@ -93,9 +92,7 @@ def test_pressure_preconditioners_agree(name):
     out = []
     for diagonal in (0, 1):
         c = make_ctx(g, pressure_rel_tolerance=1e-7)
-        p = c.get_params()
-        p.reserved[4] = diagonal
-        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.set_params(pressure_preconditioner=PRECOND_DIAGONAL if diagonal else PRECOND_AUTO)
         c.set_grid("LIQUID_PHI", g["s%d_phi" % t])
         load_uvw(c, g.uvw(t, "visc"))
         c.compute_weights()
@@ -116,15 +113,13 @@ def test_pressure_preconditioners_agree(name):
 @pytest.mark.parametrize("name", SCENES)
 def test_binned_scatters_match_global_atomic_scatters(name):
     """The LDS-tile scatters (default) against the one-thread-per-particle global-atomic kernels
-    (flipv_params.reserved[1] = 1): the SDF is a min (bit-exact), P2G differs in summation order only."""
+    (flipv_params.unbinned_scatter = 1): the SDF is a min (bit-exact), P2G differs in summation order only."""
     import ctypes as C
     g = Golden(name)
     out = []
     for unbinned in (0, 1):
         c = make_ctx(g)
-        p = c.get_params()
-        p.reserved[1] = unbinned
-        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.set_params(unbinned_scatter=unbinned)
         c.particles = g.particles_before(g.nsub - 1)
         c.particle_sdf()
         phi = c.grid("LIQUID_PHI")
@@ -249,16 +244,14 @@ def test_viscosity_solve(name, precision, oracle):
 
 @pytest.mark.parametrize("name", ["bunny32_viscous", "twobody20_varvisc"])
 def test_viscosity_multigrid_preconditioner_agrees(name):
-    """the opt-in Galerkin multigrid preconditioner of the viscosity PCG (flipv_params.reserved[7] = 1, k_viscosity_mg.hip):
+    """the opt-in Galerkin multigrid preconditioner of the viscosity PCG (flipv_params.viscosity_preconditioner = MULTIGRID, k_viscosity_mg.hip):
     same velocities as the golden reference output, several times fewer iterations than the diagonal"""
     import ctypes as C
     g = Golden(name)
     its = []
     for mg in (0, 1):
         c = make_ctx(g, viscosity_max_iterations=5000, viscosity_tolerance=1e-7)
-        p = c.get_params()
-        p.reserved[7] = mg
-        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID if mg else PRECOND_AUTO)
         n = 0
         for t in range(g.nsub):
             phi = g["s%d_phi" % t]

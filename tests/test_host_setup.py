@@ -147,8 +147,24 @@ def test_checkpoint_round_trip(tmp_path):
     assert np.array_equal(r.solid_sdf(), solid) and np.array_equal(r.particles, P)
     with pytest.raises(IOError):
         r.loadState(str(tmp_path / "missing.flipv"))
-    with open(path, "r+b") as f:
-        f.write(b"XXXXXXXX")
-    with pytest.raises(IOError):
-        r.loadState(path)
+    raw = open(path, "rb").read()
+    # a truncated file, a header that promises more than the file holds (huge dims / particle count), a wrong magic:
+    # all rejected with an error return, nothing allocated from the header's word alone, nothing thrown
+    import struct
+    bad = {"truncated": raw[:len(raw) // 2],
+           "huge_dims": raw[:8] + struct.pack("<3i", 16000, 16000, 16000) + raw[20:],
+           "overflow_dims": raw[:8] + struct.pack("<3i", 2**31 - 1, 2**31 - 1, 2**31 - 1) + raw[20:],
+           "huge_np": raw[:44] + struct.pack("<Q", 2**62) + raw[52:],
+           "trailing": raw + b"\0" * 24,
+           "magic": b"XXXXXXXX" + raw[8:]}
+    for name, blob in bad.items():
+        q = str(tmp_path / (name + ".flipv"))
+        open(q, "wb").write(blob)
+        with pytest.raises(IOError):
+            r.loadState(q)
+    # the simulation is untouched by the failed loads, and a checkpoint written before any frame re-saves identically
+    assert (r.I, r.J, r.K) == (N, N, N) and np.array_equal(r.particles, P)
+    again = str(tmp_path / "again.flipv")
+    r.saveState(again)
+    assert open(again, "rb").read() == raw
     r.close()

@@ -1,4 +1,4 @@
-"""A/B: LDS-binned particle scatters (default) against the un-binned global-atomic kernels (flipv_params.reserved[1]=1)
+"""A/B: LDS-binned particle scatters (default) against the un-binned global-atomic kernels (flipv_params.unbinned_scatter=1)
 on the 256^3 bench scene; prints the sdf / p2g phase times of the third substep."""
 import ctypes as C
 import os
@@ -14,9 +14,7 @@ for unbinned in (1, 0, 1, 0):
     c.set_solid_sdf(solid)
     c.set_viscosity(0.0)   # viscosity off: only the particle phases matter here
     c.particles = P
-    p = c.get_params()
-    p.reserved[1] = unbinned
-    c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "set")
+    c.set_params(unbinned_scatter=unbinned)
     for t in range(3):
         st = c.substep(min(c.cfl(), 0.01))
     print("global atomics" if unbinned else "LDS bins      ", {k: round(v, 3) for k, v in st["phase_ms"].items()}, "total %.2f" % st["total_ms"])

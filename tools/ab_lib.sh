@@ -20,6 +20,6 @@ if [ "$mode" = build ]; then
 else
   for name in "$@"; do
     echo "== $name"
-    FLIPV_LIB=$PWD/$cs/build/variants/$name.so timeout 300 python3 tools/ab_switch.py 0 0 2>&1 | grep reserved
+    FLIPV_LIB=$PWD/$cs/build/variants/$name.so timeout 300 python3 tools/ab_switch.py no_graph_replay 0 2>&1 | grep no_graph_replay
   done
 fi

@@ -28,10 +28,7 @@ def run(N, precision, reps, viscosity=5.0, gridcap=0):
     c.set_viscosity(viscosity)
     c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4)
     if gridcap:
-        import ctypes as C
-        p = c.get_params()
-        p.reserved[2] = gridcap
-        c._chk(c.L.flipv_set_params(c.h, C.byref(p)), "flipv_set_params")
+        c.set_params(grid_cap=gridcap)
     rng = np.random.default_rng(0)
     c.set_grid("LIQUID_PHI", np.full((N, N, N), -0.5 * dx, np.float32))
     for n in "UVW":
@@ -57,7 +54,7 @@ if __name__ == "__main__":
     ap.add_argument("--sizes", type=int, nargs="+", default=[256, 384])
     ap.add_argument("--precision", type=int, default=0)
     ap.add_argument("--reps", type=int, default=50)
-    ap.add_argument("--gridcap", type=int, default=0, help="cap of the PCG kernels' grids (flipv_params.reserved[2]); 0 = library default")
+    ap.add_argument("--gridcap", type=int, default=0, help="cap of the PCG kernels' grids (flipv_params.grid_cap); 0 = library default")
     a = ap.parse_args()
     for N in a.sizes:
         print(json.dumps(run(N, a.precision, a.reps, gridcap=a.gridcap)), flush=True)
