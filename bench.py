@@ -20,9 +20,13 @@ Extra objects on the JSON line:
   roofline_dense -- the same two SpMV kernels on a completely filled 256^3 box (SURVEY.md 8d "pure kernel roofline
                   runs"), where a launch streams 0.4-0.9 GB and the HBM bound is the relevant one; measured live.
   cpu_baseline -- the reference itself (oracle/_ref, kind "reference") or our C restatement (kind "port"),
-                  one thread, timed here on a bounded sample of the same scene.
-  cpu_baseline -- the reference itself (oracle/_ref, kind "reference") or our C restatement (kind "port"),
-                  one thread, timed here on a bounded sample of the same scene.
+                  one thread, timed here on a bounded sample of the same scene (--cpu-size 256 runs the headline size
+                  itself: ~6 minutes; its committed output is profiles/r2/cpu_baseline_256.json).
+
+The timed region runs the product configuration: no per-launch event timing, the PCG loops replayed as hipGraphs.
+The SpMV launch durations for `roofline` come from a SECOND, untimed pass over the same number of substeps with
+flipv_params.kernel_timing = 1 (HIP events on the library's stream around every 8th launch; that mode launches kernel by
+kernel), plus a back-to-back launch figure of the same kernel on the last system (flipv_bench_spmv).
 """
 import argparse
 import json
@@ -135,7 +139,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--viscosity", type=float, default=5.0)
-    ap.add_argument("--cpu-size", type=int, default=128, help="grid size of the bounded CPU-baseline sample (128: ~15-20 s of CPU work)")
+    ap.add_argument("--cpu-size", type=int, default=128, help="grid size of the bounded CPU-baseline sample (128: ~15-20 s of CPU work; "
+                    "256 = the headline size itself, ~6 minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense", action="store_true", help="skip the filled-box SpMV roofline measurement")
     ap.add_argument("--gpu-setup", action="store_true", help="build the scene with the device setup kernels (for sizes where the host path takes minutes)")
@@ -191,7 +196,7 @@ def main():
         del solid_g, parts
     c.set_viscosity(args.viscosity)
     c.set_gravity(0.0, -9.81, 0.0)
-    c.set_params(precision=args.precision, kernel_timing=1, viscosity_max_iterations=args.viscosity_cap)
+    c.set_params(precision=args.precision, kernel_timing=0, viscosity_max_iterations=args.viscosity_cap)
     c.particles = particles
     dev_name = c.device_name()
 
@@ -207,7 +212,6 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    c.kernel_stats_reset()
     barrier()
     t0 = time.perf_counter()
     stats = []
@@ -219,7 +223,26 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- second pass, NOT timed: the same number of substeps with HIP events around every 8th SpMV launch
+    c.set_params(kernel_timing=1)
+    c.kernel_stats_reset()
+    for _ in range(max(1, min(args.steps, 5))):
+        step()
+    c.synchronize()
     ks = c.kernel_stats()
+    c.set_params(kernel_timing=0)
+    b2b = {}
+    if world == 1:
+        for which, name in ((1, "viscosity"), (0, "pressure")):
+            try:
+                ms, swept = c.bench_spmv(which, 200)
+                b2b[name] = ms
+            except Exception:   # no such system (viscosity off)
+                pass
+
+    def its(key):
+        v = [st[key]["iterations"] for st in stats]
+        return {"mean": float(np.mean(v)), "min": int(min(v)), "max": int(max(v)), "per_step": v if len(v) <= 32 else None}
 
     ms_per_step = elapsed * 1e3 / args.steps
     cells_total = float(N) ** 3 * world  # N x N x (N*world) cells, one N^3 slab per rank
@@ -238,6 +261,8 @@ def main():
         roof = {"kernel": "k_visc_spmv<float>" if args.precision == 0 else "k_visc_spmv<double>", "bound": "hbm",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": avg_ms * 1e3, "launches": v_n, "units_per_launch": units, "bytes_per_unit": VISC_SPMV_BYTES_PER_INDEX,
+                "timing": "HIP events on the library's stream around every 8th launch, untimed second pass",
+                "back_to_back_launch_us": b2b.get("viscosity", 0.0) * 1e3 or None,
                 "unit_definition": "one cell's worth of unknowns = 3 rows of the viscosity system",
                 "swept_indices_per_launch": v_cells / v_n}
     elif p_n > 0:
@@ -271,7 +296,9 @@ def main():
                 "all-reduce + particle migration" % (world, N, N, N * world, world),
             },
             "device": dev_name,
-            "phase_ms": last["phase_ms"],
+            "phase_ms": {k: float(np.mean([st["phase_ms"][k] for st in stats])) for k in last["phase_ms"]},
+            "phase_ms_note": "mean over the timed substeps (GPU time per phase, HIP events)",
+            "viscosity_iterations": its("viscosity"), "pressure_iterations": its("pressure"),
             "viscosity": {k: last["viscosity"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "roofline": roof,

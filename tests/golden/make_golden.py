@@ -85,6 +85,61 @@ def scene(name, N, boundary, liquid, nu, nsub, dt=0.01, gravity=(0.0, -9.81, 0.0
     s.close()
 
 
+def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inputs=True, nprobe=0):
+    """End-of-substep dumps only, for scenes at BASELINE sizes whose phase-by-phase dump would be tens of MB:
+    inputs (unless the test regenerates them bit for bit with the host library: then a particle count and
+    checksums), and per substep the final velocities (whole grids, or `nprobe` seeded probe faces per
+    component), the pressure, the particles (or their checksum) and the solver iteration counts.
+    vcap > 0 lifts the viscosity iteration cap (ViscositySolver::_maxSolverIterations, viscositysolver.h:202)
+    so that the reference's answer is the converged one."""
+    I = J = K = N
+    dx = float(np.float32(1.0 / N))
+    s = R.RefSim(I, J, K, dx)
+    if boundary is not None:
+        bv, bt = load_ply(os.path.join(MESH, boundary[0]))
+        s.add_boundary(bv, bt, boundary[1])
+    R.lib().ref_srand(1)
+    for m in liquid:
+        lv, lt = load_ply(os.path.join(MESH, m))
+        s.add_liquid(lv, lt)
+    s.set_viscosity(nu)
+    if vcap:
+        s.set_viscosity_solver(maxiter=vcap)
+    P0 = s.particles
+    d = dict(I=I, J=J, K=K, dx=np.float32(dx), dt=np.float32(dt), gravity=np.array((0.0, -9.81, 0.0), np.float32),
+             nsub=nsub, nu=np.float32(nu), vcap=vcap, nparticles=len(P0),
+             particles0_sum=P0.astype(np.float64).sum(axis=0), solid_sum=np.float64(s.grid("SOLID_PHI").astype(np.float64).sum()))
+    if store_inputs:
+        d["solid"] = s.grid("SOLID_PHI")
+        d["particles0"] = P0
+    rng = np.random.default_rng(2024)
+    for t in range(nsub):
+        p = "s%d_" % t
+        s.substep(dt)
+        st = s.solver_stats()
+        d[p + "visc_iters"] = st["visc_iters"]; d[p + "visc_err"] = st["visc_err"]
+        d[p + "pres_iters"] = st["pres_iters"]; d[p + "pres_err"] = st["pres_err"]
+        for c in "UVW":
+            a = s.grid(c)
+            d[p + "maxabs_" + c] = np.float32(np.abs(a).max())
+            if nprobe:
+                nz = np.flatnonzero(a)                      # probes on faces that carry a velocity
+                idx = np.sort(rng.choice(nz, size=min(nprobe, len(nz)), replace=False))
+                d[p + "probe_idx_" + c] = idx.astype(np.int64)
+                d[p + "probe_val_" + c] = a.reshape(-1)[idx]
+            else:
+                d[p + "final_" + c] = a
+        Pn = s.particles
+        d[p + "particles_sum"] = Pn.astype(np.float64).sum(axis=0)
+        if store_inputs:
+            d[p + "particles"] = Pn
+        print("  substep %d: viscosity %d its (%.3e), pressure %d its" % (t, st["visc_iters"], st["visc_err"], st["pres_iters"]), flush=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("%-28s %8d particles  %6.0f KiB" % (name, len(P0), os.path.getsize(path) / 1024))
+    s.close()
+
+
 def layered_viscosity(I, J, K):
     # node-sampled, varies with height and x: exercises setViscosity(Array3d<float>&) (fluidsimulation.cpp:110-124)
     k, j, i = np.meshgrid(np.arange(K + 1), np.arange(J + 1), np.arange(I + 1), indexing="ij")
@@ -93,6 +148,11 @@ def layered_viscosity(I, J, K):
 
 if __name__ == "__main__":
     assert R.available(), "build oracle/_ref first: make -C oracle ref"
+    only = sys.argv[1:]   # optional: names of the fixtures to (re)build
+    if only:
+        _scene, _compact = scene, compact_scene
+        scene = lambda name, *a, **k: _scene(name, *a, **k) if name in only else None          # noqa: E731
+        compact_scene = lambda name, *a, **k: _compact(name, *a, **k) if name in only else None  # noqa: E731
     # A: BASELINE config #2 in miniature -- box boundary only, cube liquid, viscosity off
     scene("cube24_inviscid", 24, None, ["cube.ply"], 0.0, 3)
     # B: BASELINE config #1/#3 in miniature -- bunny in inverted sphere, viscosity 5
@@ -100,3 +160,13 @@ if __name__ == "__main__":
     # C: variable viscosity, two liquid bodies (particles append), tilted gravity
     scene("twobody20_varvisc", 20, None, ["sphere_small.ply", "cone.ply"], None, 2, gravity=(1.5, -9.81, 0.7),
           visc_grid=layered_viscosity)
+    # D: BASELINE config #4 in miniature -- honey buckling: rod.ply + sheet.ply through two addLiquid calls (particles
+    #    append, fluidsimulation.cpp:89), nu = 50, default box boundary, 64^3.  The stock cap of 700 is hit even at 64^3
+    #    for nu = 50, so the cap is lifted: the golden is the reference's CONVERGED answer.
+    compact_scene("honey64_nu50", 64, None, ["rod.ply", "sheet.ply"], 50.0, 2, vcap=20000)
+    # E: the largest size at which the reference converges on BASELINE config #3's scene (128^3 bunny drop, nu = 5: 708
+    #    iterations with the cap lifted).  Inputs are regenerated by the test with the host library (bit-exact
+    #    against the reference, tests/test_host_setup.py); the fixture pins counts, checksums and 20 000 probe faces per
+    #    component and substep.
+    compact_scene("bunny128_nu5_converged", 128, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 2, vcap=5000,
+                  store_inputs=False, nprobe=20000)

@@ -1,0 +1,194 @@
+"""GPU parity with the library's DEFAULT solver parameters and at BASELINE.json's sizes (-m gpu).
+
+Everything here runs `flipv_params` exactly as flipv_default_params() returns them unless a test says otherwise in its
+docstring -- the parameters bench.py and a user of the C-ABI run -- against
+ (a) the committed reference dumps (chained substeps: each substep starts from the state the GPU left),
+ (b) the live oracle with ITS defaults (= the reference's caps and tolerances) at config 1's real 64^3 and config 2's
+     real 128^3,
+ (c) the reference's converged answers at sizes / viscosities where the stock cap of 700 truncates the reference itself
+     (config 4 miniature: rod + sheet, nu = 50, 64^3; config 3's scene at 128^3): there both sides run with the cap
+     lifted, which is stated per test.
+Bar: end-of-substep velocities <= 1e-4 relative max-norm (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+from helpers import Golden, rel_maxnorm3
+from test_oracle_compact_golden import build_host_scene
+
+pytestmark = pytest.mark.gpu
+
+VEL_TOL = 1e-4
+
+
+def vel_err(c, ref_uvw):
+    return rel_maxnorm3([c.grid(n) for n in "UVW"], ref_uvw)
+
+
+@pytest.mark.parametrize("name", ["cube24_inviscid", "bunny32_viscous", "twobody20_varvisc"])
+def test_default_params_chained_substeps_match_reference_dumps(name):
+    """no parameter is overridden; the substeps are chained (particles and grids stay on the device)"""
+    from flipviscosity3d_amd.capi import Context
+    g = Golden(name)
+    c = Context(g.I, g.J, g.K, g.dx)
+    c.set_solid_sdf(g["solid"])
+    c.set_viscosity(g["viscosity"])
+    c.set_gravity(*g.gravity)
+    c.particles = g["particles0"]
+    for t in range(g.nsub):
+        st = c.substep(g.dt)
+        assert st["viscosity"]["status"] in (0, 3) and st["pressure"]["status"] in (0, 3), st
+        assert vel_err(c, g.uvw(t, "final")) <= VEL_TOL
+        assert np.abs(c.particles[:, :3] - g["s%d_particles" % t][:, :3]).max() <= 1e-5
+    c.close()
+
+
+def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap=0, vel0=None):
+    """GPU (default parameters unless lift_cap) and oracle (its defaults = the reference's, unless lift_cap) side by side;
+    returns per substep (error, gpu stats, oracle viscosity info, oracle pressure info)"""
+    from flipviscosity3d_amd.capi import Context
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(nu)
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid)
+    o.set_viscosity(nu)
+    if lift_cap:
+        c.set_params(viscosity_max_iterations=lift_cap)
+        o.set_solver_limits(vmaxiter=lift_cap)
+    c.particles = P
+    o.particles = P
+    out = []
+    for t in range(nsub):
+        st = c.substep(dt)
+        sec, vi, pi = o.substep(dt)
+        out.append((vel_err(c, [o.grid(n) for n in "UVW"]), st, vi, pi))
+    perr = np.abs(c.particles[:, :3] - o.particles[:, :3]).max()
+    c.close()
+    o.close()
+    return out, perr
+
+
+def test_config1_default_scene_64_default_params(oracle):
+    """BASELINE configs[0]: bunny in sphere_large, 64^3, nu = 5 (reference main.cpp), 3 chained substeps, default
+    parameters on both sides.  The reference needs 368/427/313 viscosity iterations here: inside its cap."""
+    dx, solid, P = build_host_scene(64, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    assert len(P) == 73176
+    out, perr = run_against_live_oracle(oracle, 64, dx, solid, P, 5.0, 3)
+    for t, (err, st, vi, pi) in enumerate(out):
+        assert vi["status"] == 0 and vi["iterations"] == (368, 427, 313)[t]
+        assert st["viscosity"]["status"] == 0, st["viscosity"]    # converged inside the default cap of 700
+        assert err <= VEL_TOL, (t, err)
+    assert perr <= 1e-5
+
+
+def test_config2_cube128_pressure_only_default_params(oracle):
+    """BASELINE configs[1]: 128^3, cube.ply in the default box, viscosity off; 3 chained substeps, default parameters.
+    Substep 0 has a zero right-hand side (free fall), then 12 / 15 reference iterations."""
+    dx, solid, P = build_host_scene(128, None, ["cube.ply"])
+    assert len(P) == 2097152
+    out, perr = run_against_live_oracle(oracle, 128, dx, solid, P, 0.0, 3)
+    assert [pi["iterations"] for _, _, _, pi in out][1:] == [12, 15]
+    for t, (err, st, vi, pi) in enumerate(out):
+        assert st["viscosity"]["status"] == 3 and st["pressure"]["status"] in (0, 3)
+        assert err <= VEL_TOL, (t, err)
+    assert perr <= 1e-5
+
+
+def test_config2_variant_resting_cube_64_default_params(oracle):
+    """SURVEY.md 8d-2's hydrostatic variant (the cube rests on the floor, so the solver works from substep 0): 64^3,
+    249 690 particles, 31 reference iterations per substep"""
+    from test_gpu_wide import box_mesh
+    from flipviscosity3d_amd import hostapi as H
+    import ctypes
+    N = 64
+    dx = float(np.float32(1.0 / N))
+    s = H.FluidSimulation()
+    s.initialize(N, N, N, dx)
+    ctypes.CDLL(None).srand(1)
+    s.addLiquid(box_mesh((0.25, 1.5 * dx, 0.25), (0.75, 0.5, 0.75)))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    out, perr = run_against_live_oracle(oracle, N, dx, solid, P, 0.0, 3)
+    for t, (err, st, vi, pi) in enumerate(out):
+        assert pi["status"] == 0 and st["pressure"]["status"] == 0
+        assert err <= VEL_TOL, (t, err)
+    assert perr <= 1e-5
+
+
+def test_config4_miniature_honey_rod_on_sheet_nu50():
+    """BASELINE configs[3] in miniature against the committed reference dump honey64_nu50: rod.ply + sheet.ply added with
+    two add-liquid calls, nu = 50, 64^3.  The reference's own MIC(0) solve needs 1184 / 1954 iterations here -- beyond
+    its stock cap of 700 -- so the dump was made with the cap lifted and this test lifts the GPU cap likewise (every
+    other parameter is the default): the comparison is between converged answers."""
+    from flipviscosity3d_amd.capi import Context
+    g = Golden("honey64_nu50")
+    c = Context(g.I, g.J, g.K, g.dx)
+    c.set_solid_sdf(g["solid"])
+    c.set_viscosity(float(g["nu"]))
+    c.set_params(viscosity_max_iterations=int(g["vcap"]))
+    c.particles = g["particles0"]
+    for t in range(g.nsub):
+        st = c.substep(g.dt)
+        assert st["viscosity"]["status"] == 0, st["viscosity"]
+        assert vel_err(c, g.uvw(t, "final")) <= VEL_TOL
+        assert np.abs(c.particles[:, :3] - g["s%d_particles" % t][:, :3]).max() <= 1e-5
+    c.close()
+
+
+def test_config4_miniature_with_the_stock_cap_follows_the_acceptance_rule():
+    """the same scene with the DEFAULT cap: neither the reference nor the GPU solve converges in 700 iterations; both
+    accept the iterate (infinity-norm residual < 10, viscositysolver.cpp:676-689) and carry on.  What can be asserted is
+    the rule, not the velocities (two different preconditioners stopped early)."""
+    from flipviscosity3d_amd.capi import Context
+    g = Golden("honey64_nu50")
+    c = Context(g.I, g.J, g.K, g.dx)
+    c.set_solid_sdf(g["solid"])
+    c.set_viscosity(float(g["nu"]))
+    c.particles = g["particles0"]
+    st = c.substep(g.dt)
+    v = st["viscosity"]
+    assert v["iterations"] <= 700
+    assert v["status"] in (0, 1) and (v["status"] == 0 or v["residual"] < 10.0)
+    assert st["rc"] == (0 if v["status"] == 0 else 1)
+    c.close()
+
+
+def test_config3_scene_128_converged_reference_probes():
+    """BASELINE configs[2]'s scene at 128^3, the largest size at which the reference converges (708 iterations with its
+    cap lifted -- 8 beyond the stock cap -- SURVEY.md 7), against 20 000 probe faces per component of the reference's
+    converged output, two chained substeps.  The GPU cap is lifted like the reference's was; everything else is default."""
+    from flipviscosity3d_amd.capi import Context
+    g = Golden("bunny128_nu5_converged")
+    dx, solid, P = build_host_scene(128, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    assert len(P) == int(g["nparticles"]) and np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])
+    c = Context(128, 128, 128, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(float(g["nu"]))
+    c.set_params(viscosity_max_iterations=int(g["vcap"]))
+    c.particles = P
+    for t in range(g.nsub):
+        st = c.substep(g.dt)
+        assert st["viscosity"]["status"] == 0, st["viscosity"]
+        num = den = 0.0
+        for n in "UVW":
+            a = c.grid(n).reshape(-1)
+            idx, val = g["s%d_probe_idx_%s" % (t, n)], g["s%d_probe_val_%s" % (t, n)]
+            num = max(num, float(np.abs(a[idx].astype(np.float64) - val).max()))
+            den = max(den, float(g["s%d_maxabs_%s" % (t, n)]))
+        assert num / den <= VEL_TOL, (t, num / den)
+        assert np.abs(c.particles.astype(np.float64).sum(axis=0) - g["s%d_particles_sum" % t]).max() <= 1e-3 * len(P) ** 0.5
+    c.close()
+
+
+def test_config3_scene_128_default_cap_against_oracle_default_cap(oracle):
+    """the same scene with the stock cap of 700 on BOTH sides, one substep: where the cap binds, the reference (MIC(0))
+    and the GPU solve (see DESIGN.md for its preconditioner) stop at different iterates, so this is the measurement of
+    how far the shipped defaults are from the reference's own truncated output -- asserted at the level the two truncated
+    solves agree to, reported in DESIGN.md; the converged comparison is the test above."""
+    dx, solid, P = build_host_scene(128, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    out, perr = run_against_live_oracle(oracle, 128, dx, solid, P, 5.0, 1)
+    err, st, vi, pi = out[0]
+    print("128^3 default caps: velocity error %.3e, GPU viscosity %s, oracle viscosity %s" % (err, st["viscosity"], vi))
+    assert st["viscosity"]["status"] in (0, 1) and vi["status"] in (0, 1)
+    assert err <= 1e-3

@@ -181,6 +181,46 @@ def test_resumed_run_continues_like_the_uninterrupted_one(tmp_path):
     assert np.abs(pa[:, 3:] - pr[:, 3:]).max() <= 1e-4 * np.abs(pa[:, 3:]).max()
 
 
+def test_resumed_run_takes_the_same_cfl_substeps(tmp_path):
+    """The checkpoint carries the MAC field: _cfl() of the first frame after a resume reads the velocities the last
+    substep left (reference fluidsimulation.cpp:139, 241-269).  Fast-moving liquid and a frame several CFL steps long: the
+    resumed run must split its frame like the uninterrupted one (without the field the CFL step is +inf and the whole
+    frame becomes one substep)."""
+    from flipviscosity3d_amd import hostapi as H
+    N = 24
+    dx = float(np.float32(1.0 / N))
+    def start():
+        s = H.FluidSimulation()
+        s.initialize(N, N, N, dx)
+        s.addBoundary(H.load_ply(os.path.join(MESH, "sphere_large.ply")), True)
+        s.setSeeding(H.FluidSimulation.SEED_COUNTER, 3)
+        s.addLiquid(H.load_ply(os.path.join(MESH, "stanford_bunny.ply")))
+        s.setViscosity(0.5)
+        P = s.particles
+        P[:, 4] = -6.0                      # 5 dx / 6 = 0.035: a frame of 0.1 needs three substeps
+        s.particles = P
+        return s
+    a = start()
+    a.advance(0.1)
+    na = a.advance(0.1)["substeps"]
+    pa = a.particles
+    a.close()
+    b = start()
+    b.advance(0.1)
+    path = str(tmp_path / "ck.flipv")
+    b.saveState(path)
+    b.close()
+    r = H.FluidSimulation()
+    r.initialize(4, 4, 4, 0.25)
+    r.loadState(path)
+    nr = r.advance(0.1)["substeps"]
+    pr = r.particles
+    r.close()
+    assert na >= 2, na                       # the frame really is CFL-bound
+    assert nr == na
+    assert np.abs(pa[:, :3] - pr[:, :3]).max() <= 1e-5
+
+
 def test_setup_rejects_bad_input():
     from flipviscosity3d_amd import capi
     c = capi.Context(16, 16, 16, 1.0 / 16)

@@ -1,0 +1,81 @@
+"""CPU: the C restatement against the two compact reference dumps at BASELINE sizes (tests/golden/make_golden.py D, E).
+
+ * honey64_nu50 -- config #4 in miniature (rod.ply + sheet.ply through two addLiquid calls, nu = 50, 64^3) with the
+   viscosity cap lifted in the reference harness: the oracle must land on the reference's converged answer bit for bit,
+   iteration for iteration.
+ * bunny128_nu5_converged -- config #3's scene at the largest size where the reference converges (128^3): the scene the
+   host library builds must BE the reference's (count and checksums); the oracle's first substep is compared at the
+   fixture's probe faces (one substep: ~30 s of the CPU suite's budget).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, Golden
+
+MESH = os.path.join(GOLDEN, "meshes")
+
+
+def build_host_scene(N, boundary, liquids):
+    """the reference's scene through the host library with the reference's libc rand() stream (bit-exact:
+    tests/test_host_setup.py)"""
+    from flipviscosity3d_amd import hostapi as H
+    dx = float(np.float32(1.0 / N))
+    s = H.FluidSimulation()
+    s.initialize(N, N, N, dx)
+    if boundary:
+        s.addBoundary(H.load_ply(os.path.join(MESH, boundary[0])), boundary[1])
+    ctypes.CDLL(None).srand(1)
+    for m in liquids:
+        s.addLiquid(H.load_ply(os.path.join(MESH, m)))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    return dx, solid, P
+
+
+def test_honey_scene_setup_matches_reference():
+    g = Golden("honey64_nu50")
+    dx, solid, P = build_host_scene(64, None, ["rod.ply", "sheet.ply"])
+    assert np.array_equal(solid, g["solid"])
+    assert np.array_equal(P, g["particles0"])          # the second addLiquid appends (fluidsimulation.cpp:89)
+
+
+def test_oracle_honey64_converged(oracle):
+    g = Golden("honey64_nu50")
+    I, J, K = g.dims()
+    s = oracle.OracleSim(I, J, K, g.dx)
+    s.set_solid(g["solid"])
+    s.set_viscosity(float(g["nu"]))
+    s.set_solver_limits(vmaxiter=int(g["vcap"]))
+    s.particles = g["particles0"]
+    for t in range(g.nsub):
+        sec, vi, pi = s.substep(g.dt)
+        assert vi["iterations"] == int(g["s%d_visc_iters" % t]) and vi["iterations"] > 700   # beyond the stock cap
+        assert pi["iterations"] == int(g["s%d_pres_iters" % t])
+        for c in "UVW":
+            assert np.array_equal(s.grid(c), g["s%d_final_%s" % (t, c)])
+        assert np.array_equal(s.particles, g["s%d_particles" % t])
+    s.close()
+
+
+def test_oracle_bunny128_first_substep_at_probes(oracle):
+    g = Golden("bunny128_nu5_converged")
+    dx, solid, P = build_host_scene(128, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    assert len(P) == int(g["nparticles"])
+    assert np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])
+    assert np.float64(solid.astype(np.float64).sum()) == g["solid_sum"]
+    s = oracle.OracleSim(128, 128, 128, dx)
+    s.set_solid(solid)
+    s.set_viscosity(float(g["nu"]))
+    s.set_solver_limits(vmaxiter=int(g["vcap"]))
+    s.particles = P
+    sec, vi, pi = s.substep(g.dt)
+    assert vi["iterations"] == int(g["s0_visc_iters"]) and pi["iterations"] == int(g["s0_pres_iters"])
+    for c in "UVW":
+        a = s.grid(c).reshape(-1)
+        assert np.array_equal(a[g["s0_probe_idx_" + c]], g["s0_probe_val_" + c])
+        assert np.float32(np.abs(a).max()) == g["s0_maxabs_" + c]
+    assert np.array_equal(s.particles.astype(np.float64).sum(axis=0), g["s0_particles_sum"])
+    s.close()
