@@ -296,7 +296,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
                  std::to_string(c->k1 - c->k0);
         return FLIPV_ERR_INVALID;
     }
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < 3; r++)
         if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
     c->prm = *p;
     return FLIPV_OK;

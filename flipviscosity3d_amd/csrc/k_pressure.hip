@@ -199,6 +199,7 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     sc->nslot = NSLOT / nr > 0 ? NSLOT / nr : 1;   // disjoint slot ranges per rank (nranks <= NSLOT)
     sc->slot0 = rk * sc->nslot;
     sc->cap = cap;
+    sc->noB = c->prm.beta_from_residual ? 0 : 1;
     sc->itA = c->d_flags + 4;
     sc->itB = c->d_flags + 5;
     *extra = c->d_scal + 5 * n;
@@ -267,13 +268,16 @@ int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *
     return gather_masks(c, *tg, vw, mask, list, *nActive, mlist, mlistCap);
 }
 
+// dots: 0 = only a = s.q (multigrid-preconditioned loop, benchmark launches), 1 = a and c, 2 = a, b and c (reads r)
 template <typename T>
-static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count) {
+static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count, int dots) {
     const int nb = pcg_grid(c, count);
     const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;  // HIP events around every 8th launch
     if (timed) fv_ev_begin(c, 0, (double)count * (256 * VW_P));
-    GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_pressure_spmv<T>, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, c->mlistP ? c->mlistP + (size_t)first * 256 : (const unsigned *)nullptr, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it));
+#define PSPMV(D) GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pressure_spmv<T, D>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L, \
+                       c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, c->mlistP ? c->mlistP + (size_t)first * 256 : (const unsigned *)nullptr, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it))
+    if (dots == 2) PSPMV(2); else if (dots == 1) PSPMV(1); else PSPMV(0);
+#undef PSPMV
     if (timed) fv_ev_end(c);
 }
 
@@ -339,7 +343,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const bool useMg = f32 && c->prm.pressure_preconditioner != FLIPV_PRECOND_DIAGONAL && (L.I > 16 || L.J > 16 || L.K > 16);  // at least two levels below the tile-list level
     li.preconditioner = useMg ? 1 : 0;
     if (useMg) {
-        if ((rc = fv_pressure_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s, int it) { launch_pressure_spmv<float>(cc, s, it, 0, cc->nActiveP); },
+        if ((rc = fv_pressure_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s, int it) { launch_pressure_spmv<float>(cc, s, it, 0, cc->nActiveP, 0); },
                                      &conv)))
             return rc;
     } else {
@@ -353,7 +357,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
         const HaloArray sh[1] = {{c->pS, sizeof(T)}};
         GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pcg_init<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc));
         if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
-        auto spmv = [&](int first, int count, int it) { launch_pressure_spmv<T>(c, sc, it, first, count); };
+        auto spmv = [&](int first, int count, int it) { launch_pressure_spmv<T>(c, sc, it, first, count, sc.noB ? 1 : 2); };
         auto update = [&](int it) {
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it));
         };
@@ -390,12 +394,15 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
     c->prm.kernel_timing = 0;
     PcgScal sc;
     memset(&sc, 0, sizeof(sc));  // no scalars, no stop flag: pure kernel launches
+    // the variant the solve runs: the multigrid-preconditioned loop needs s.q only, the diagonal one also (q/d).q [and (r/d).q]
+    const bool mgLoop = !c->pressurePrec && c->prm.pressure_preconditioner != FLIPV_PRECOND_DIAGONAL && (c->L.I > 16 || c->L.J > 16 || c->L.K > 16);
+    const int bdots = mgLoop ? 0 : (c->prm.beta_from_residual ? 2 : 1);
     for (int w = 0; w < 3; w++) {
-        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0, 0, c->nActiveP); else launch_pressure_spmv<float>(c, sc, 0, 0, c->nActiveP);
+        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0, 0, c->nActiveP, bdots); else launch_pressure_spmv<float>(c, sc, 0, 0, c->nActiveP, bdots);
     }
     HIPCHK(c, hipEventRecord(a, c->stream));
     for (int r = 0; r < reps; r++) {
-        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0, 0, c->nActiveP); else launch_pressure_spmv<float>(c, sc, 0, 0, c->nActiveP);
+        if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0, 0, c->nActiveP, bdots); else launch_pressure_spmv<float>(c, sc, 0, 0, c->nActiveP, bdots);
     }
     HIPCHK(c, hipEventRecord(b, c->stream));
     HIPCHK(c, hipEventSynchronize(b));

@@ -417,12 +417,12 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     if (timed) fv_ev_begin(c, 1, (double)count * (256 * NV));
     PcgSys<T, 3> vv = sys ? *sys : visc_sys<T>(c);
     if (vv.mlist) vv.mlist += (size_t)first * 256;   // the mask words are in list order
-    if (NV == 4 && c->vPred)
-        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, 4, true>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it));
-    else
-        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, NV, NV == 2>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L,
-                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it));
+#define VSPMV(N_, P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, N_, P_, R_>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L, \
+                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
+    const bool rdot = sc.conv ? !sc.noB : c->prm.beta_from_residual != 0;   // benchmark launches (no scalars): the variant the solve would run
+    if (NV == 4 && c->vPred) { if (rdot) VSPMV(4, true, true); else VSPMV(4, true, false); }
+    else { if (rdot) VSPMV(NV, NV == 2, true); else VSPMV(NV, NV == 2, false); }
+#undef VSPMV
     if (timed) fv_ev_end(c);
 }
 

@@ -92,6 +92,7 @@ struct PcgScal {
     int tol_inclusive;  // 1: res <= tol (pcgsolver.h:270), 0: res < tol (pressuresolver.cpp:548)
     int slot0, nslot;
     int cap;        // iteration cap
+    int noB;        // 1: the SpMV did not form b = (r/d).q; the update uses b = a (conjugacy of successive directions)
     // device-side iteration counters for hipGraph replay (kernels launched with it_arg = -1): the SpMV reads itA and
     // publishes it in itB, the update reads itB and stores itB+1 in itA -- a kernel never reads a counter that is
     // written inside the same launch, so late-starting blocks cannot see a half-advanced iteration.

@@ -95,7 +95,12 @@ typedef struct flipv_params {
     int viscosity_lane_width;    /* 2|4: forced lane width of the viscosity solver kernels */
     int viscosity_spmv_grid_cap; /* n>0: grid cap of the viscosity SpMV kernel alone */
     int viscosity_update_grid_cap; /* n>0: grid cap of the viscosity init/update kernels */
-    int reserved[4];             /* must be 0 */
+    int beta_from_residual;      /* 0 (default): the PCG's beta is formed as (alpha^2 (q,q/d) - sigma)/sigma, which uses the
+                                    A-conjugacy of successive search directions ((r/d,q) = (s,q)) and lets the SpMV skip the
+                                    residual; 1: (sigma - 2 alpha (r/d,q) + alpha^2 (q,q/d))/sigma with the residual read by
+                                    the SpMV (+12 B per index, +4 B per pressure cell).  sigma itself is recomputed from
+                                    the stored vectors every iteration either way. */
+    int reserved[3];             /* must be 0 */
 } flipv_params;
 
 typedef struct flipv_solve_info {

@@ -177,7 +177,9 @@ def test_config3_scene_128_converged_reference_probes():
             num = max(num, float(np.abs(a[idx].astype(np.float64) - val).max()))
             den = max(den, float(g["s%d_maxabs_%s" % (t, n)]))
         assert num / den <= VEL_TOL, (t, num / den)
-        assert np.abs(c.particles.astype(np.float64).sum(axis=0) - g["s%d_particles_sum" % t]).max() <= 1e-3 * len(P) ** 0.5
+        # particle checksums (sums over 587 819 particles): mean position within 1e-6, mean velocity within 1e-5
+        d = np.abs(c.particles.astype(np.float64).sum(axis=0) - g["s%d_particles_sum" % t]) / len(P)
+        assert d[:3].max() <= 1e-6 and d[3:].max() <= 1e-5, d
     c.close()
 
 
