@@ -258,6 +258,11 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->surfList) (void)hipFree(c->surfList);
     if (c->mlistP) (void)hipFree(c->mlistP);
     if (c->mlistV) (void)hipFree(c->mlistV);
+    if (c->runsP) (void)hipFree(c->runsP);
+    if (c->runsV) (void)hipFree(c->runsV);
+    if (c->runCand) (void)hipFree(c->runCand);
+    if (c->rmaskP) (void)hipFree(c->rmaskP);
+    if (c->rmaskV) (void)hipFree(c->rmaskV);
     fv_mg_free(c);
     fv_vmg_free(c);
     if (c->binCnt) (void)hipFree(c->binCnt);
@@ -296,7 +301,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
                  std::to_string(c->k1 - c->k0);
         return FLIPV_ERR_INVALID;
     }
-    for (int r = 0; r < 3; r++)
+    for (int r = 0; r < 2; r++)
         if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
     c->prm = *p;
     return FLIPV_OK;

@@ -152,6 +152,12 @@ struct flipv_context {
     uint8_t *pMask;  // 1 where the cell is a pressure cell
     unsigned *mlistP = nullptr, *mlistV = nullptr;   // mask words of the listed tiles in list order (256 per tile), grown on demand
     size_t mlistCapP = 0, mlistCapV = 0;             // capacity in tiles
+    // k-marching work units of the two SpMV kernels (pcg_geo.inc): runs, their lane masks, the candidates' scratch
+    struct Run *runsP = nullptr, *runsV = nullptr, *runCand = nullptr;
+    unsigned *rmaskP = nullptr, *rmaskV = nullptr;
+    size_t runCapP = 0, runCapV = 0, runCandCap = 0, rmaskCapP = 0, rmaskCapV = 0;
+    int nRunsP = 0, nRunsV = 0;          // 0: the tile-at-a-time kernels run
+    int runLenP = 0, runLenV = 0;
     void *pX, *pR, *pZ, *pS;  // vectors (float or double per precision)
     // viscosity system
     float *scp;                                                 // solid phi at cell centres

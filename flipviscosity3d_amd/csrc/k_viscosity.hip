@@ -420,6 +420,17 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
 #define VSPMV(N_, P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, N_, P_, R_>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L, \
                            c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
     const bool rdot = sc.conv ? !sc.noB : c->prm.beta_from_residual != 0;   // benchmark launches (no scalars): the variant the solve would run
+    if (NV == 4 && c->nRunsV > 0 && first == 0 && count == c->nActiveV) {   // k-marching over the run list (the whole system)
+        int nbm = pcg_grid(c, c->nRunsV);
+        if (nbm > cap) nbm = cap;
+#define VMARCH(P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv_march<T, P_, R_>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsV, c->nRunsV, \
+                           (const unsigned *)(c->vPred ? c->rmaskV : nullptr), c->tgV, c->L, c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
+        if (c->vPred) { if (rdot) VMARCH(true, true); else VMARCH(true, false); }
+        else { if (rdot) VMARCH(false, true); else VMARCH(false, false); }
+#undef VMARCH
+        if (timed) fv_ev_end(c);
+        return;
+    }
     if (NV == 4 && c->vPred) { if (rdot) VSPMV(4, true, true); else VSPMV(4, true, false); }
     else { if (rdot) VSPMV(NV, NV == 2, true); else VSPMV(NV, NV == 2, false); }
 #undef VSPMV
@@ -522,6 +533,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     c->vPred = fill <= 0.35;
     rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3, &c->mlistV, &c->mlistCapV);
     if (rc) return rc;
+    if ((rc = fv_build_runs(c, c->tgV, c->vwV, c->nActiveV, !c->vPred, c->vRowMask, &c->runsV, &c->runCapV, &c->nRunsV, &c->runLenV, &c->rmaskV, &c->rmaskCapV))) return rc;
     if (c->vSwz != (swzOk && c->tgV.rowl == 16 ? 1 : 0)) {  // the geometry changed: the vectors go into the other layout
         if ((rc = run_setup(1 - c->vSwz))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -210,6 +210,10 @@ __device__ __forceinline__ TileBatch d_fetch_tiles(int base, int nvb, const int 
 __device__ __forceinline__ int d_pick(const int v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ unsigned d_pick(const unsigned v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 
+// k-marching work unit of the SpMV kernels (pcg_geo.inc): `len` tiles of one column, consecutive in k, starting at `tile`
+constexpr int RUNLEN_MAX = 64;
+struct Run { int tile, len; };
+
 __device__ __forceinline__ bool d_pass(const PcgScal &sc, double res) { return sc.tol_inclusive ? (res <= sc.tol) : (res < sc.tol); }
 
 // K1 prologue shared by both SpMV kernels: returns true if the launch must do nothing
@@ -266,6 +270,12 @@ static inline int pcg_grid(const flipv_context *c, int ntiles) {
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
+// Runs of the tile list fv_build_tiles just built (call right after it: uses its tile flags).  *nruns = 0 when the k-marching
+// kernels are not to be used (multi-rank runs, lane width 2, flipv_params.spmv_run_length = -1).
+// `dense`: the liquid fills the listed tiles (what flipv_params.spmv_run_length = 0 decides by: k-marching pays where the
+// launch is bound by bytes, not where it is bound by the number of blocks that have work).
+int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, bool dense, const uint8_t *mask, Run **runs, size_t *runCap, int *nruns,
+                  int *runLen, unsigned **rmask, size_t *rmaskCap);
 
 // The iteration loop shared by both solves.
 //   spmv(first, count, it)  enqueues K1 over list entries [first, first+count) on c->stream

@@ -100,7 +100,9 @@ typedef struct flipv_params {
                                     residual; 1: (sigma - 2 alpha (r/d,q) + alpha^2 (q,q/d))/sigma with the residual read by
                                     the SpMV (+12 B per index, +4 B per pressure cell).  sigma itself is recomputed from
                                     the stored vectors every iteration either way. */
-    int reserved[3];             /* must be 0 */
+    int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 (default) =
+                                    chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
+    int reserved[2];             /* must be 0 */
 } flipv_params;
 
 typedef struct flipv_solve_info {

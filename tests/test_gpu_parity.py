@@ -360,3 +360,61 @@ def test_empty_and_degenerate_inputs():
     with pytest.raises(FlipvError):
         Context(0, 4, 4, 0.1)
     c.close()
+
+
+@pytest.mark.parametrize("name", ["bunny32_viscous", "twobody20_varvisc", "cube24_inviscid"])
+@pytest.mark.parametrize("runlen", [2, 5, 32])
+def test_k_marching_spmv_matches_tile_kernels(name, runlen):
+    """The k-marching SpMV kernels (runs of `runlen` tiles along k, planes k-1 / k carried in registers) against the
+    tile-at-a-time kernels (flipv_params.spmv_run_length = -1): same operator, so the solves agree to rounding -- checked on
+    the velocities after a full substep, on the iteration counts, and against the reference dump."""
+    g = Golden(name)
+    out = []
+    for rl in (-1, runlen):
+        c = make_ctx(g, spmv_run_length=rl, pressure_preconditioner=PRECOND_DIAGONAL)   # the diagonal loop runs many SpMVs
+        c.particles = g["particles0"]
+        st = c.substep(g.dt)
+        out.append((st, [c.grid(n) for n in "UVW"]))
+        c.close()
+    (st_t, v_t), (st_m, v_m) = out
+    assert rel_maxnorm3(v_m, v_t) <= 2e-5
+    assert rel_maxnorm3(v_m, g.uvw(0, "final")) <= VEL_TOL
+    for key in ("viscosity", "pressure"):
+        assert abs(st_m[key]["iterations"] - st_t[key]["iterations"]) <= max(2, st_t[key]["iterations"] // 50), (key, st_m[key], st_t[key])
+
+
+@pytest.mark.parametrize("rowl", ["16", "64"])
+def test_k_marching_single_spmv_is_the_same_operator(rowl, monkeypatch):
+    """one application of each operator through flipv_bench_spmv's code path is not observable from outside, so compare
+    two one-iteration solves instead: with a cap of 1 the result is x = alpha s with alpha = sigma / (s, A s) -- any
+    difference in A shows up in alpha.  Odd sizes: partial tiles, padding, columns that end inside a run."""
+    from flipviscosity3d_amd import capi, hostapi as H
+    from test_gpu_wide import box_mesh
+    monkeypatch.setenv("FLIPV_ROWL", rowl)
+    I, J, K = 70, 33, 29
+    dx = float(np.float32(1.0 / I))
+    s = H.FluidSimulation()
+    s.initialize(I, J, K, dx)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 4)
+    s.addLiquid(box_mesh((0.1, 3.5 * dx, 4.2 * dx), (0.9, 22.3 * dx, 24.6 * dx)))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    P[:, 3] = 0.3 * np.sin(9 * P[:, 1]); P[:, 4] = -0.2 * np.cos(7 * P[:, 0]); P[:, 5] = 0.1 * np.sin(5 * P[:, 2] + P[:, 0])
+    res = []
+    for rl in (-1, 3, 32):
+        c = capi.Context(I, J, K, dx)
+        c.set_solid_sdf(solid)
+        c.set_viscosity(3.0)
+        c.set_params(spmv_run_length=rl, viscosity_max_iterations=1, pressure_max_iterations=1, pressure_preconditioner=PRECOND_DIAGONAL)
+        c.particles = P
+        c.particle_sdf(); c.advect_velocity_field(); c.body_force(0.01)
+        vi = c.viscosity_solve(0.01)
+        uvw = [c.grid(n) for n in "UVW"]
+        c.compute_weights()
+        pi = c.pressure_solve(0.01)
+        res.append((vi, uvw, pi, c.grid("PRESSURE")))
+        c.close()
+    for vi, uvw, pi, pr in res[1:]:
+        assert vi["rows"] == res[0][0]["rows"] and pi["rows"] == res[0][2]["rows"]
+        assert rel_maxnorm3(uvw, res[0][1]) <= 1e-5
+        assert rel_maxnorm(pr, res[0][3]) <= 1e-5
