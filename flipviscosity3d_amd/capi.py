@@ -20,11 +20,12 @@ VOLUME_IDS = dict(center=0, U=1, V=2, W=3, edgeU=4, edgeV=5, edgeW=6)
 
 # every symbol include/flipv.h declares (tests/test_abi.py checks the header against this and the .so)
 SYMBOLS = [
-    "flipv_create", "flipv_create_on_device", "flipv_create_slab", "flipv_slab_range", "flipv_destroy", "flipv_last_error", "flipv_device_name",
+    "flipv_create", "flipv_create_on_device", "flipv_create_slab", "flipv_slab_range", "flipv_create_block", "flipv_block_range",
+    "flipv_destroy", "flipv_last_error", "flipv_device_name",
     "flipv_default_params", "flipv_set_params", "flipv_get_params", "flipv_set_gravity",
     "flipv_set_solid_sdf", "flipv_set_viscosity_uniform", "flipv_set_viscosity",
     "flipv_upload_particles", "flipv_download_particles", "flipv_num_particles",
-    "flipv_grid_elements", "flipv_read_grid", "flipv_write_grid",
+    "flipv_grid_elements", "flipv_read_grid", "flipv_write_grid", "flipv_grid_box", "flipv_read_grid_box", "flipv_write_grid_box",
     "flipv_cfl", "flipv_particle_sdf", "flipv_p2g", "flipv_extrapolate", "flipv_save_velocity",
     "flipv_advect_velocity_field", "flipv_body_force", "flipv_viscosity_solve", "flipv_compute_weights",
     "flipv_pressure_solve", "flipv_apply_pressure", "flipv_constrain", "flipv_update_particle_velocities",
@@ -33,7 +34,7 @@ SYMBOLS = [
     "flipv_bench_copy", "flipv_bench_stream",
     "flipv_mesh_level_set", "flipv_add_boundary_mesh", "flipv_reset_boundary", "flipv_add_liquid_mesh",
     "flipv_comm_unique_id_bytes", "flipv_comm_get_unique_id", "flipv_comm_init_rccl", "flipv_comm_init_local",
-    "flipv_comm_finalize",
+    "flipv_comm_init_rccl_grid", "flipv_comm_init_local_grid", "flipv_comm_finalize",
 ]
 
 
@@ -101,6 +102,14 @@ def load():
     L.flipv_create_on_device.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(ctx)]
     L.flipv_create_slab.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(ctx)]
     L.flipv_slab_range.argtypes = [ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    i3 = C.POINTER(C.c_int)
+    L.flipv_create_block.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, i3, i3, C.POINTER(ctx)]
+    L.flipv_block_range.argtypes = [ctx, i3, i3]
+    L.flipv_grid_box.argtypes = [ctx, C.c_int, C.c_int, i3, i3]
+    L.flipv_read_grid_box.argtypes = [ctx, C.c_int, fp]
+    L.flipv_write_grid_box.argtypes = [ctx, C.c_int, fp]
+    L.flipv_comm_init_rccl_grid.argtypes = [ctx, C.c_void_p, C.c_int, i3]
+    L.flipv_comm_init_local_grid.argtypes = [C.POINTER(ctx), i3]
     L.flipv_comm_get_unique_id.argtypes = [C.c_void_p]
     L.flipv_comm_init_rccl.argtypes = [ctx, C.c_void_p, C.c_int, C.c_int]
     L.flipv_comm_init_local.argtypes = [C.POINTER(ctx), C.c_int]
@@ -174,14 +183,20 @@ def _F(a):
 class Context:
     """Owns one flipv_context (device state of one simulation / one rank)."""
 
-    def __init__(self, I, J, K, dx, device=None, slab=None):
-        """slab = (k_begin, k_end): one rank of a slab decomposition along k (global grid I x J x K)."""
+    def __init__(self, I, J, K, dx, device=None, slab=None, block=None):
+        """slab = (k_begin, k_end): one rank of a slab decomposition along k (global grid I x J x K);
+        block = ((i0, j0, k0), (i1, j1, k1)): one rank of a block decomposition, cells [lo, hi)."""
         self.L = load()
         self.I, self.J, self.K = int(I), int(J), int(K)
         self.dx = float(np.float32(dx))
         self.slab = slab
+        self.block = block
         h = C.c_void_p()
-        if slab is not None:
+        if block is not None:
+            lo = (C.c_int * 3)(*[int(v) for v in block[0]])
+            hi = (C.c_int * 3)(*[int(v) for v in block[1]])
+            rc = self.L.flipv_create_block(self.I, self.J, self.K, C.c_float(dx), int(device or 0), lo, hi, C.byref(h))
+        elif slab is not None:
             rc = self.L.flipv_create_slab(self.I, self.J, self.K, C.c_float(dx), int(device or 0), int(slab[0]), int(slab[1]),
                                           C.byref(h))
         elif device is None:
@@ -239,9 +254,19 @@ class Context:
         return added.value
 
     # ---- multi-GPU
-    def comm_init_rccl(self, unique_id, rank, nranks):
+    def comm_init_rccl(self, unique_id, rank, nranks, dims=None):
+        """dims = (ranks along i, j, k) of a block decomposition (rank = x + dims[0] * (y + dims[1] * z)); None: slabs along k"""
         buf = C.create_string_buffer(bytes(unique_id), 128)
-        self._chk(self.L.flipv_comm_init_rccl(self.h, buf, rank, nranks), "flipv_comm_init_rccl")
+        if dims is None:
+            self._chk(self.L.flipv_comm_init_rccl(self.h, buf, rank, nranks), "flipv_comm_init_rccl")
+        else:
+            assert int(np.prod(dims)) == nranks
+            self._chk(self.L.flipv_comm_init_rccl_grid(self.h, buf, rank, (C.c_int * 3)(*[int(d) for d in dims])), "flipv_comm_init_rccl_grid")
+
+    def block_range(self):
+        lo, hi = (C.c_int * 3)(), (C.c_int * 3)()
+        self._chk(self.L.flipv_block_range(self.h, lo, hi), "flipv_block_range")
+        return tuple(lo), tuple(hi)
 
     def comm_finalize(self):
         self._chk(self.L.flipv_comm_finalize(self.h), "flipv_comm_finalize")
@@ -300,10 +325,37 @@ class Context:
         return self.L.flipv_num_particles(self.h)
 
     # ---- grids
-    def grid(self, name):
-        a = np.empty(grid_shape(name, self.I, self.J, self.K), np.float32)
+    def grid(self, name, out=None):
+        """Full-size grid.  On a block context only the entries the rank owns are written: pass the same `out` to every
+        rank in turn to assemble the global grid (a fresh array is zero-filled first)."""
+        shp = grid_shape(name, self.I, self.J, self.K)
+        if out is None:
+            a = np.zeros(shp, np.float32) if self.block is not None or self.slab is not None else np.empty(shp, np.float32)
+        else:
+            a = out
+            assert a.shape == shp and a.dtype == np.float32 and a.flags.c_contiguous
         self._chk(self.L.flipv_read_grid(self.h, GRID_IDS[name], _F(a)), "flipv_read_grid")
         return a
+
+    def grid_box(self, name, kind=0):
+        """(lo, hi) of the part of grid `name` this rank owns (kind 0) / allocates (kind 1), global indices (i, j, k)"""
+        lo, hi = (C.c_int * 3)(), (C.c_int * 3)()
+        self._chk(self.L.flipv_grid_box(self.h, GRID_IDS[name], kind, lo, hi), "flipv_grid_box")
+        return tuple(lo), tuple(hi)
+
+    def read_box(self, name):
+        """the owned part of the grid, box-shaped (numpy (depth, height, width) of the box)"""
+        lo, hi = self.grid_box(name, 0)
+        a = np.empty((hi[2] - lo[2], hi[1] - lo[1], hi[0] - lo[0]), np.float32)
+        self._chk(self.L.flipv_read_grid_box(self.h, GRID_IDS[name], _F(a)), "flipv_read_grid_box")
+        return a
+
+    def write_box(self, name, a):
+        """the allocated part (owned + halo) of the grid, box-shaped"""
+        lo, hi = self.grid_box(name, 1)
+        a = np.ascontiguousarray(a, np.float32)
+        assert a.shape == (hi[2] - lo[2], hi[1] - lo[1], hi[0] - lo[0]), (a.shape, lo, hi)
+        self._chk(self.L.flipv_write_grid_box(self.h, GRID_IDS[name], _F(a)), "flipv_write_grid_box")
 
     def set_grid(self, name, a):
         a = np.ascontiguousarray(a, np.float32)
@@ -422,10 +474,16 @@ def comm_unique_id():
     return buf.raw
 
 
-def comm_init_local(contexts):
-    """Attach the in-process verification communicator to N slab contexts of this process."""
+def comm_init_local(contexts, dims=None):
+    """Attach the in-process verification communicator to the N contexts of this process: slabs along k, or with
+    dims = (ranks along i, j, k) a block decomposition (contexts in rank order, x fastest)."""
     L = load()
     arr = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
-    rc = L.flipv_comm_init_local(arr, len(contexts))
+    if dims is None:
+        rc = L.flipv_comm_init_local(arr, len(contexts))
+    else:
+        assert int(np.prod(dims)) == len(contexts)
+        rc = L.flipv_comm_init_local_grid(arr, (C.c_int * 3)(*[int(d) for d in dims]))
     if rc != 0:
-        raise FlipvError("flipv_comm_init_local failed (%d)" % rc)
+        msg = "; ".join(L.flipv_last_error(c.h).decode() for c in contexts if L.flipv_last_error(c.h))
+        raise FlipvError("flipv_comm_init_local failed (%d): %s" % (rc, msg))

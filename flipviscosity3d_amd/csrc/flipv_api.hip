@@ -59,20 +59,35 @@ extern "C" int flipv_default_params(flipv_params *p) {
     p->precision = FLIPV_PRECISION_FP32;
     p->kernel_timing = 0;
     p->check_every = 0;
+    p->beta_from_residual = 1;
     return FLIPV_OK;
 }
 
 extern "C" const char *flipv_last_error(flipv_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbegin, int kend, flipv_context **out) {
+    const int lo[3] = {0, 0, kbegin}, hi[3] = {I, J, kend};
+    return flipv_create_block(I, J, K, dx, dev, lo, hi, out);
+}
+
+extern "C" int flipv_create_block(int I, int J, int K, float dx, int dev, const int *cell_lo, const int *cell_hi, flipv_context **out) {
     if (!out) return FLIPV_ERR_INVALID;
     *out = nullptr;
     if (I < 1 || J < 1 || K < 1 || !(dx > 0.0f)) {
         g_create_error = "flipv_create: grid dimensions must be >= 1 and dx > 0";
         return FLIPV_ERR_INVALID;
     }
-    if (kbegin < 0 || kend > K || kbegin >= kend) {
-        g_create_error = "flipv_create_slab: need 0 <= k_begin < k_end <= K";
+    const int N[3] = {I, J, K};
+    if (!cell_lo || !cell_hi) { g_create_error = "flipv_create_block: null box"; return FLIPV_ERR_INVALID; }
+    for (int a = 0; a < 3; a++)
+        if (cell_lo[a] < 0 || cell_hi[a] > N[a] || cell_lo[a] >= cell_hi[a]) {
+            g_create_error = "flipv_create_block: need 0 <= lo < hi <= size on every axis";
+            return FLIPV_ERR_INVALID;
+        }
+    if (cell_lo[0] % 8 != 0 || (cell_hi[0] != I && cell_hi[0] % 8 != 0)) {
+        // a lane of the solver kernels owns 4 consecutive i and the swizzled layout interleaves patches of 8: a cut along i
+        // must not split either
+        g_create_error = "flipv_create_block: block boundaries along i must be multiples of 8";
         return FLIPV_ERR_INVALID;
     }
     int ndev = 0;
@@ -88,13 +103,34 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     if (!c) return FLIPV_ERR_OOM;
     Lay &L = c->L;
     L.I = I; L.J = J; L.K = K;
-    L.PX = ((I + 1 + 7) / 8) * 8; L.PY = ((J + 1 + 3) / 4) * 4; L.PZ = K + 1;   // 8 | PX and 4 | PY: the swizzled plane layout (sidx) needs whole 8 x 4 patches
+    {
+        // the global index space: 8 | PXg and 4 | PYg (the swizzled plane layout needs whole 8 x 4 patches)
+        const int Pg[3] = {((I + 1 + 7) / 8) * 8, ((J + 1 + 3) / 4) * 4, K + 1};
+        const int align[3] = {8, 4, 1};
+        int o[3], e[3];
+        c->isBlock = 0;
+        for (int a = 0; a < 3; a++) {
+            c->cell0[a] = cell_lo[a]; c->cell1[a] = cell_hi[a];
+            L.olo[a] = cell_lo[a];
+            L.ohi[a] = cell_hi[a] == N[a] ? Pg[a] : cell_hi[a];   // the last block of an axis also owns the closing plane (and the padding)
+            o[a] = cell_lo[a] == 0 ? 0 : cell_lo[a] - FV_HALO;
+            if (o[a] < 0) o[a] = 0;
+            o[a] -= o[a] % align[a];
+            e[a] = cell_hi[a] == N[a] ? Pg[a] : cell_hi[a] + FV_HALO;
+            e[a] = (e[a] + align[a] - 1) / align[a] * align[a];
+            if (e[a] > Pg[a]) e[a] = Pg[a];
+            if (cell_lo[a] != 0 || cell_hi[a] != N[a]) c->isBlock = 1;
+            c->pgrid[a] = 1; c->pcoord[a] = 0;
+        }
+        L.ox = o[0]; L.oy = o[1]; L.oz = o[2];
+        L.PX = e[0] - o[0]; L.PY = e[1] - o[1]; L.PZ = e[2] - o[2];
+    }
     L.sy = L.PX; L.sz = (long)L.PX * L.PY;
     L.n = (size_t)L.sz * L.PZ;
     L.guard = (((size_t)L.sz + (size_t)L.sy + 8) + 63) / 64 * 64;
-    L.kb = 0; L.ke = L.PZ;
-    c->k0 = kbegin;
-    c->k1 = kend == K ? L.PZ : kend;  // the last slab also owns the closing plane of W faces / nodes
+    L.ib = L.ox; L.ie = L.ox + L.PX; L.jb = L.oy; L.je = L.oy + L.PY; L.kb = L.oz; L.ke = L.oz + L.PZ;
+    c->k0 = L.olo[2];
+    c->k1 = L.ohi[2];
     c->comm = nullptr;
     c->pScratch = nullptr; c->pScratchCap = 0;
     c->binIdx = nullptr; c->binIdxCap = 0;
@@ -201,9 +237,9 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     GALLOC(c->pMask);
     GALLOC(c->validCells); GALLOC(c->validTmp);
     for (int q = 0; q < 3; q++) { VALLOC(c->vX[q]); VALLOC(c->vR[q]); VALLOC(c->vZ[q]); VALLOC(c->vS[q]); }
-    // staging buffer for layout conversion: one node-lattice worth of floats
+    // staging buffer for layout conversion: one allocated box worth of floats
     {
-        const size_t cap = (size_t)(I + 1) * (J + 1) * (K + 1);
+        const size_t cap = L.n;
         int rc_ = plain_alloc(c, &c->stage, cap);
         if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
         c->stageCap = cap;
@@ -215,12 +251,7 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     // defaults of initialize(): viscosity 1.0 at every node (fluidsimulation.cpp:39), liquid phi = 3 dx
     int rc = flipv_set_viscosity_uniform(c, 1.0f);
     if (rc == FLIPV_OK) {
-        Lay all = c->L;
-        (void)all;
-        const int k0s = c->k0, k1s = c->k1;
-        c->k0 = 0; c->k1 = c->L.PZ;            // the initial liquid SDF is "far" everywhere
-        rc = fv_fill_cells(c, c->phi, 3.0f * dx, 0);
-        c->k0 = k0s; c->k1 = k1s;
+        rc = fv_fill_cells(c, c->phi, 3.0f * dx, 1 << 20);   // the initial liquid SDF is "far" everywhere (the whole allocated box)
         if (hipStreamSynchronize(c->stream) != hipSuccess) rc = FLIPV_ERR_HIP;
     }
     if (rc != FLIPV_OK) { g_create_error = c->err; flipv_destroy(c); return rc; }
@@ -240,8 +271,13 @@ extern "C" int flipv_create(int I, int J, int K, float dx, flipv_context **out) 
 
 extern "C" int flipv_slab_range(flipv_context *c, int *kbegin, int *kend) {
     if (!c || !kbegin || !kend) return FLIPV_ERR_INVALID;
-    *kbegin = c->k0;
-    *kend = c->k1 >= c->L.PZ ? c->L.K : c->k1;
+    *kbegin = c->cell0[2];
+    *kend = c->cell1[2];
+    return FLIPV_OK;
+}
+extern "C" int flipv_block_range(flipv_context *c, int *cell_lo, int *cell_hi) {
+    if (!c || !cell_lo || !cell_hi) return FLIPV_ERR_INVALID;
+    for (int a = 0; a < 3; a++) { cell_lo[a] = c->cell0[a]; cell_hi[a] = c->cell1[a]; }
     return FLIPV_OK;
 }
 
@@ -296,10 +332,14 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         c->err = "flipv_set_params: invalid parameter";
         return FLIPV_ERR_INVALID;
     }
-    if (c->comm && c->comm->nranks > 1 && c->k1 - c->k0 < fv_min_slab_planes(p->cfl_number)) {
-        c->err = "flipv_set_params: cfl_number needs a halo of " + std::to_string(fv_min_slab_planes(p->cfl_number)) + " planes, this rank's slab has " +
-                 std::to_string(c->k1 - c->k0);
+    if (c->isBlock && fv_min_slab_planes(p->cfl_number) > FV_HALO) {
+        c->err = "flipv_set_params: cfl_number needs a halo of " + std::to_string(fv_min_slab_planes(p->cfl_number)) + " entries, a block context allocates " +
+                 std::to_string(FV_HALO);
         return FLIPV_ERR_INVALID;
+    }
+    if (c->comm && c->comm->nranks > 1) {
+        const int rcT = fv_check_block_thickness(c, p->cfl_number, "flipv_set_params");
+        if (rcT) return rcT;
     }
     for (int r = 0; r < 2; r++)
         if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
@@ -353,21 +393,73 @@ extern "C" size_t flipv_grid_elements(flipv_context *c, int which) {
     return lat_count(c->L, g.lat);
 }
 
-static int read_lattice(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, float *out) {
-    const size_t n = lat_count(c->L, lat);
-    int rc = fv_pack(c, lat, srcf, srcb, c->stage);
+// The part of lattice `lat` inside a box of the index space: kind 0 = the indices this rank owns, 1 = the indices it allocates
+// (owned + halo).  Returns false if the intersection is empty.
+static bool lat_box(const flipv_context *c, int lat, int kind, int lo[3], int hi[3]) {
+    const Lay &L = c->L;
+    int dims[3];
+    lat_dims(L, lat, dims[0], dims[1], dims[2]);
+    const int o[3] = {L.ox, L.oy, L.oz}, P[3] = {L.PX, L.PY, L.PZ};
+    bool any = true;
+    for (int a = 0; a < 3; a++) {
+        lo[a] = kind == 0 ? L.olo[a] : o[a];
+        hi[a] = kind == 0 ? L.ohi[a] : o[a] + P[a];
+        if (hi[a] > dims[a]) hi[a] = dims[a];
+        if (hi[a] <= lo[a]) any = false;
+    }
+    return any;
+}
+static size_t box_count(const int lo[3], const int hi[3]) { return (size_t)(hi[0] - lo[0]) * (size_t)(hi[1] - lo[1]) * (size_t)(hi[2] - lo[2]); }
+
+// device -> host: the OWNED part of the lattice, box-shaped (x fastest) into `out`
+static int read_lattice_box(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, float *out) {
+    int lo[3], hi[3];
+    if (!lat_box(c, lat, 0, lo, hi)) return FLIPV_OK;
+    int rc = fv_pack(c, lat, srcf, srcb, c->stage, lo, hi);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out, c->stage, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(out, c->stage, box_count(lo, hi) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FLIPV_OK;
 }
-static int write_lattice(flipv_context *c, int lat, const float *in, float *dstf, uint8_t *dstb) {
-    const size_t n = lat_count(c->L, lat);
-    HIPCHK(c, hipMemcpyAsync(c->stage, in, n * 4, hipMemcpyHostToDevice, c->stream));
-    int rc = fv_unpack(c, lat, c->stage, dstf, dstb);
+// host -> device: the ALLOCATED part of the lattice, box-shaped in `in`; entries of the allocated box outside the lattice are zeroed
+static int write_lattice_box(flipv_context *c, int lat, const float *in, float *dstf, uint8_t *dstb) {
+    int lo[3], hi[3];
+    if (!lat_box(c, lat, 1, lo, hi)) return FLIPV_OK;
+    HIPCHK(c, hipMemcpyAsync(c->stage, in, box_count(lo, hi) * 4, hipMemcpyHostToDevice, c->stream));
+    int rc = fv_unpack(c, lat, c->stage, dstf, dstb, lo, hi);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return FLIPV_OK;
+}
+// Full-size Array3d at the ABI.  A single-domain context's box IS the lattice; a block context moves its box only: a read
+// fills the entries this rank owns and leaves the rest of `out` untouched, a write takes the entries it allocates.
+static int read_lattice(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, float *out) {
+    if (!c->isBlock) return read_lattice_box(c, lat, srcf, srcb, out);
+    int lo[3], hi[3];
+    if (!lat_box(c, lat, 0, lo, hi)) return FLIPV_OK;
+    std::vector<float> tmp(box_count(lo, hi));
+    int rc = read_lattice_box(c, lat, srcf, srcb, tmp.data());
+    if (rc) return rc;
+    int w, h, d;
+    lat_dims(c->L, lat, w, h, d);
+    const size_t bw = (size_t)(hi[0] - lo[0]), bh = (size_t)(hi[1] - lo[1]);
+    for (int k = lo[2]; k < hi[2]; k++)
+        for (int j = lo[1]; j < hi[1]; j++)
+            memcpy(out + (size_t)lo[0] + (size_t)w * ((size_t)j + (size_t)h * (size_t)k), tmp.data() + bw * ((size_t)(j - lo[1]) + bh * (size_t)(k - lo[2])), bw * 4);
+    return FLIPV_OK;
+}
+static int write_lattice(flipv_context *c, int lat, const float *in, float *dstf, uint8_t *dstb) {
+    if (!c->isBlock) return write_lattice_box(c, lat, in, dstf, dstb);
+    int lo[3], hi[3];
+    if (!lat_box(c, lat, 1, lo, hi)) return FLIPV_OK;
+    std::vector<float> tmp(box_count(lo, hi));
+    int w, h, d;
+    lat_dims(c->L, lat, w, h, d);
+    const size_t bw = (size_t)(hi[0] - lo[0]), bh = (size_t)(hi[1] - lo[1]);
+    for (int k = lo[2]; k < hi[2]; k++)
+        for (int j = lo[1]; j < hi[1]; j++)
+            memcpy(tmp.data() + bw * ((size_t)(j - lo[1]) + bh * (size_t)(k - lo[2])), in + (size_t)lo[0] + (size_t)w * ((size_t)j + (size_t)h * (size_t)k), bw * 4);
+    return write_lattice_box(c, lat, tmp.data(), dstf, dstb);
 }
 
 #define ENTER(c) do { if (!(c)) return FLIPV_ERR_INVALID; hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) { (c)->err = hipGetErrorString(e_); return FLIPV_ERR_HIP; } } while (0)
@@ -395,6 +487,33 @@ extern "C" int flipv_write_grid(flipv_context *c, int which, const float *in) {
     return write_lattice(c, g.lat, in, g.f, g.m);
 }
 
+extern "C" int flipv_grid_box(flipv_context *c, int which, int kind, int *lo, int *hi) {
+    GridRef g;
+    if (!c || !lo || !hi || (kind != 0 && kind != 1) || !grid_ref(c, which, &g)) return FLIPV_ERR_INVALID;
+    if (!lat_box(c, g.lat, kind, lo, hi)) { for (int a = 0; a < 3; a++) hi[a] = lo[a]; }
+    return FLIPV_OK;
+}
+extern "C" int flipv_read_grid_box(flipv_context *c, int which, float *out) {
+    ENTER(c);
+    GridRef g;
+    if (!out || !grid_ref(c, which, &g)) { c->err = "flipv_read_grid_box: bad grid id"; return FLIPV_ERR_INVALID; }
+    return read_lattice_box(c, g.lat, g.f, g.m, out);
+}
+extern "C" int flipv_write_grid_box(flipv_context *c, int which, const float *in) {
+    ENTER(c);
+    GridRef g;
+    if (!in || !grid_ref(c, which, &g)) { c->err = "flipv_write_grid_box: bad grid id"; return FLIPV_ERR_INVALID; }
+    if (which == FLIPV_GRID_SOLID_PHI) c->solidVersion++;
+    if (which == FLIPV_GRID_WEIGHT_U || which == FLIPV_GRID_WEIGHT_V || which == FLIPV_GRID_WEIGHT_W) c->weightsVersion = -1;
+    if (which == FLIPV_GRID_VISCOSITY) {
+        int lo[3], hi[3];
+        int nz = 0;
+        if (lat_box(c, g.lat, 1, lo, hi)) { const size_t n = box_count(lo, hi); for (size_t t = 0; t < n; t++) if (in[t] > 0.0f) { nz = 1; break; } }
+        c->viscosity_nonzero = nz;   // (a block context assumes the other ranks agree: the solve is skipped only if viscosity is zero everywhere)
+    }
+    return write_lattice_box(c, g.lat, in, g.f, g.m);
+}
+
 extern "C" int flipv_set_solid_sdf(flipv_context *c, const float *nodes) { return flipv_write_grid(c, FLIPV_GRID_SOLID_PHI, nodes); }
 extern "C" int flipv_set_viscosity(flipv_context *c, const float *nodes) {
     if (!c || !nodes) return FLIPV_ERR_INVALID;
@@ -406,8 +525,12 @@ extern "C" int flipv_set_viscosity(flipv_context *c, const float *nodes) {
 extern "C" int flipv_set_viscosity_uniform(flipv_context *c, float value) {
     if (!c) return FLIPV_ERR_INVALID;
     if (!(value >= 0.0f)) { c->err = "flipv_set_viscosity_uniform: negative viscosity"; return FLIPV_ERR_INVALID; }  // fluidsimulation.cpp:100
-    std::vector<float> v(lat_count(c->L, LAT_NODE), value);
-    return flipv_write_grid(c, FLIPV_GRID_VISCOSITY, v.data());
+    int lo[3], hi[3];
+    if (!lat_box(c, LAT_NODE, 1, lo, hi)) return FLIPV_OK;
+    std::vector<float> v(box_count(lo, hi), value);
+    const int rc = flipv_write_grid_box(c, FLIPV_GRID_VISCOSITY, v.data());
+    c->viscosity_nonzero = value > 0.0f;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ scene setup (k_meshsdf.hip)
@@ -434,7 +557,7 @@ struct TempGrid {
     ~TempGrid() { if (base) (void)hipFree(base); }
 };
 int mesh_inside_domain(flipv_context *c, const float *v, size_t nverts, const char *who) {  // fluidsimulation.cpp:46-49, 65-68
-    if (c->comm) { c->err = std::string(who) + ": scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
+    if (c->comm || c->isBlock) { c->err = std::string(who) + ": scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
     if (!v || nverts == 0) { c->err = std::string(who) + ": empty mesh"; return FLIPV_ERR_INVALID; }
     float lo[3] = {v[0], v[1], v[2]}, hi[3] = {v[0], v[1], v[2]};
     for (size_t t = 0; t < nverts; t++)
@@ -450,7 +573,7 @@ extern "C" int flipv_mesh_level_set(flipv_context *c, const float *vertices, siz
                                     int bandwidth, float *phi_out, int *closest_out) {
     ENTER(c);
     if (!phi_out) return FLIPV_ERR_INVALID;
-    if (c->comm) { c->err = "flipv_mesh_level_set: scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
+    if (c->comm || c->isBlock) { c->err = "flipv_mesh_level_set: scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
     TempGrid phi, clo;
     int rc = phi.alloc(c);
     if (rc) return rc;
@@ -479,7 +602,7 @@ extern "C" int flipv_add_boundary_mesh(flipv_context *c, const float *vertices, 
 
 extern "C" int flipv_reset_boundary(flipv_context *c) {  // _initializeBoundary (fluidsimulation.cpp:198-239)
     ENTER(c);
-    if (c->comm) { c->err = "flipv_reset_boundary: scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
+    if (c->comm || c->isBlock) { c->err = "flipv_reset_boundary: scene setup runs on a single-domain context"; return FLIPV_ERR_INVALID; }
     const double dx = (double)c->dx, eps = 1e-6;
     // AABB(0,0,0, I dx, J dx, K dx).expand(-3 dx - eps): the constructor and expand() work in double, the corners are
     // stored as float (aabb.cpp:118-124)
@@ -549,7 +672,7 @@ extern "C" int flipv_extrapolate(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_ex
 
 static int save_velocity(flipv_context *c) {
     const Lay R = fv_range(c, 1);
-    const size_t off = (size_t)R.kb * c->L.sz, bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
+    const size_t off = plane_off(c->L, R.kb), bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;   // whole allocated planes
     HIPCHK(c, hipMemcpyAsync(c->sU + off, c->U + off, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->sV + off, c->V + off, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->sW + off, c->W + off, bytes, hipMemcpyDeviceToDevice, c->stream));

@@ -45,3 +45,5 @@ int fv_migrate_particles(flipv_context *c);
 int fv_allreduce_max_f32(flipv_context *c, float *value);  // host value in/out (synchronises)
 // thinnest slab a multi-rank run accepts: the widest exchange moves ceil(cfl) + 3 of a rank's own planes
 static inline int fv_min_slab_planes(float cfl_number) { return (int)ceilf(cfl_number) + 3; }
+// FLIPV_ERR_INVALID (with c->err set) if the block is thinner than that along an axis on which it has neighbours
+int fv_check_block_thickness(flipv_context *c, float cfl_number, const char *who);

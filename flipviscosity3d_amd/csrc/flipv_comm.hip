@@ -17,13 +17,42 @@ __global__ void k_halo_combine(float *__restrict__ dst, const float *__restrict_
     }
 }
 
-// particle -> destination rank by the k index of its cell: 0 stay, 1 previous rank, 2 next rank.
+// A box of the index space <-> a contiguous staging buffer, for up to HALO_MAXARR arrays at once (array a's part of the staging
+// buffer starts at byte offset a * boxcount * 8, whatever its element size: keeps every part 8-byte aligned).
+// mode 0: pack (array -> staging), 1: unpack (staging -> array), 2: combine min, 3: combine add (fp32 arrays only).
+constexpr int HALO_MAXARR = 6;
+struct HaloSet { void *p[HALO_MAXARR]; int elem[HALO_MAXARR]; int n; };
+struct HBox { int lo[3], hi[3]; };
+__global__ void k_halo_box(HaloSet hs, Lay L, HBox b, char *__restrict__ staging, int mode) {
+    const int w = b.hi[0] - b.lo[0], h = b.hi[1] - b.lo[1], d = b.hi[2] - b.lo[2];
+    const size_t cnt = (size_t)w * h * d;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += stride) {
+        const int i = b.lo[0] + (int)(t % (size_t)w), j = b.lo[1] + (int)((t / (size_t)w) % (size_t)h), k = b.lo[2] + (int)(t / ((size_t)w * h));
+        const size_t c = gidx(L, i, j, k);
+        for (int a = 0; a < hs.n; a++) {
+            char *st = staging + (size_t)a * cnt * 8;
+            if (hs.elem[a] == 4) {
+                float *g = (float *)hs.p[a] + c, *q = (float *)st + t;
+                if (mode == 0) *q = *g; else if (mode == 1) *g = *q; else if (mode == 2) *g = fminf(*g, *q); else *g += *q;
+            } else if (hs.elem[a] == 8) {
+                double *g = (double *)hs.p[a] + c, *q = (double *)st + t;
+                if (mode == 0) *q = *g; else *g = *q;
+            } else {
+                uint8_t *g = (uint8_t *)hs.p[a] + c, *q = (uint8_t *)st + t;
+                if (mode == 0) *q = *g; else *g = *q;
+            }
+        }
+    }
+}
+
+// particle -> destination along one axis by the index of its cell on that axis: 0 stay, 1 previous rank, 2 next rank.
 // Output slots come from ONE global atomic per block and destination (nearly every particle stays: one atomic per
 // particle on the same address serialised 4.7 M operations into 58 ms).  Order inside a destination follows the order in which the blocks arrive: it is
 // arbitrary, as it is after any migration.
 __global__ __launch_bounds__(256) void k_migrate_classify(const float *__restrict__ aos6, size_t n, float *__restrict__ stay,
                                                           float *__restrict__ toPrev, float *__restrict__ toNext,
-                                                          unsigned long long *__restrict__ counts, float dx, int kc0, int kc1) {
+                                                          unsigned long long *__restrict__ counts, float dx, int axis, int kc0, int kc1) {
     __shared__ unsigned wcount[4][3];            // per wave, per destination
     __shared__ unsigned long long bbase[3];      // this block's first slot per destination
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,7 +62,8 @@ __global__ __launch_bounds__(256) void k_migrate_classify(const float *__restric
     if (p < n) {
 #pragma unroll
         for (int e = 0; e < 6; e++) q[e] = aos6[6 * p + e];
-        const int k = (int)floor((double)q[2] * (1.0 / (double)dx));
+        const float pos = axis == 0 ? q[0] : (axis == 1 ? q[1] : q[2]);
+        const int k = (int)floor((double)pos * (1.0 / (double)dx));
         dest = k < kc0 ? 1 : (k >= kc1 ? 2 : 0);
     }
     unsigned rank = 0;
@@ -64,29 +94,105 @@ static unsigned grid1d(size_t n) {
     return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
 }
 
+// ================================================================================================ process grid
+static inline int nbr_rank(const flipv_context *c, int axis, int dir) {   // dir -1 / +1; -1 if there is no such neighbour
+    int co[3] = {c->pcoord[0], c->pcoord[1], c->pcoord[2]};
+    co[axis] += dir;
+    if (co[axis] < 0 || co[axis] >= c->pgrid[axis]) return -1;
+    return co[0] + c->pgrid[0] * (co[1] + c->pgrid[1] * co[2]);
+}
+
+int fv_check_block_thickness(flipv_context *c, float cfl_number, const char *who) {
+    const int need = fv_min_slab_planes(cfl_number);
+    for (int a = 0; a < 3; a++)
+        if (c->pgrid[a] > 1 && c->cell1[a] - c->cell0[a] < need) {
+            c->err = std::string(who) + ": the block is " + std::to_string(c->cell1[a] - c->cell0[a]) + " cells thick along axis " + std::to_string(a) +
+                     ", thinner than the widest halo (" + std::to_string(need) + " = ceil(cfl_number) + 3)";
+            return FLIPV_ERR_INVALID;
+        }
+    return FLIPV_OK;
+}
+
+// staging for the packed faces: [send to lower | send to upper | receive from lower | receive from upper], each `bytes` long
+static int xbuf_reserve(flipv_context *c, size_t bytes) {
+    const size_t need = 4 * bytes + 64;
+    if (need <= c->xbufCap) return FLIPV_OK;
+    if (c->xbuf) { HIPCHK(c, hipStreamSynchronize(c->xs)); HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->xbuf); c->xbuf = nullptr; c->xbufCap = 0; }
+    const size_t cap = need + need / 4;
+    HIPCHK(c, hipMalloc((void **)&c->xbuf, cap));
+    c->xbufCap = cap;
+    return FLIPV_OK;
+}
+
+// the box a phase of an exchange moves along `axis`: [lo, hi) on that axis as given; on the other axes the owned range, widened
+// by W (clipped to the allocated box) where the halo has to travel along:
+//   copy (runs x, y, z): the axes already exchanged -- their freshly received halos are forwarded, which fills edges and corners;
+//   reduction (runs z, y, x): the axes still to come -- what was scattered into an edge or corner region rides along until the
+//   phase of its last axis delivers it to the owner.
+static HBox phase_box(const flipv_context *c, int axis, int lo, int hi, int W, bool copyOrder) {
+    const Lay &L = c->L;
+    const int o[3] = {L.ox, L.oy, L.oz}, P[3] = {L.PX, L.PY, L.PZ};
+    HBox b;
+    for (int a = 0; a < 3; a++) {
+        if (a == axis) { b.lo[a] = lo; b.hi[a] = hi; continue; }
+        const bool wide = a < axis;   // copy: already exchanged; reduction (z first): still to come
+        (void)copyOrder;
+        b.lo[a] = L.olo[a]; b.hi[a] = L.ohi[a];
+        if (wide && c->pgrid[a] > 1) {
+            b.lo[a] = L.olo[a] - W < o[a] ? o[a] : L.olo[a] - W;
+            b.hi[a] = L.ohi[a] + W > o[a] + P[a] ? o[a] + P[a] : L.ohi[a] + W;
+        }
+    }
+    return b;
+}
+static size_t hbox_count(const HBox &b) { return (size_t)(b.hi[0] - b.lo[0]) * (size_t)(b.hi[1] - b.lo[1]) * (size_t)(b.hi[2] - b.lo[2]); }
+
 // ================================================================================================ halo helpers
+// owner -> neighbour copies of the H boundary entries of every array, axis by axis (x, then y including the x halos just
+// received, then z including both): after the three phases the edge and corner regions are filled as well, which the
+// coupled viscosity stencil (cross terms like V(i-1, j+1)) and the trilinear particle samples need.
 int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
     Comm *cm = c->comm;
     if (!cm || H <= 0) return FLIPV_OK;
+    if (n > HALO_MAXARR) { c->err = "fv_halo_copy: too many arrays"; return FLIPV_ERR_INVALID; }
     const Lay &L = c->L;
-    const size_t plane = (size_t)L.sz;
-    int rc = cm->begin(c);
-    if (rc) return rc;
-    for (int a = 0; a < n; a++) {
-        char *base = (char *)arr[a].p;
-        const size_t pb = plane * arr[a].elem;
-        if (cm->rank > 0) {  // exchange with the previous rank: send my first H planes, receive its last H planes
-            const int hs = c->k0 + H <= c->k1 ? H : c->k1 - c->k0, hr = c->k0 - H >= 0 ? H : c->k0;
-            rc = cm->sendrecv(c, cm->rank - 1, base + (size_t)c->k0 * pb, (size_t)hs * pb, base + (size_t)(c->k0 - hr) * pb, (size_t)hr * pb);
-            if (rc) return rc;
+    HaloSet hs;
+    hs.n = n;
+    for (int a = 0; a < n; a++) { hs.p[a] = arr[a].p; hs.elem[a] = (int)arr[a].elem; }
+    int rc;
+    for (int axis = 0; axis < 3; axis++) {
+        if (c->pgrid[axis] <= 1) continue;
+        const int lower = nbr_rank(c, axis, -1), upper = nbr_rank(c, axis, +1);
+        const int own0 = L.olo[axis], own1 = L.ohi[axis];
+        if (axis == 2 && c->pgrid[0] == 1 && c->pgrid[1] == 1) {
+            // slabs along k: whole contiguous planes travel straight from / into the arrays
+            const size_t plane = (size_t)L.sz;
+            if ((rc = cm->begin(c))) return rc;
+            for (int a = 0; a < n; a++) {
+                char *base = (char *)arr[a].p;
+                const size_t pb = plane * arr[a].elem;
+                if (lower >= 0 && (rc = cm->sendrecv(c, lower, base + plane_off(L, own0) * arr[a].elem, (size_t)H * pb, base + plane_off(L, own0 - H) * arr[a].elem, (size_t)H * pb))) return rc;
+                if (upper >= 0 && (rc = cm->sendrecv(c, upper, base + plane_off(L, own1 - H) * arr[a].elem, (size_t)H * pb, base + plane_off(L, own1) * arr[a].elem, (size_t)H * pb))) return rc;
+            }
+            if ((rc = cm->end(c))) return rc;
+            continue;
         }
-        if (cm->rank < cm->nranks - 1) {
-            const int hs = c->k1 - H >= c->k0 ? H : c->k1 - c->k0, hr = c->k1 + H <= L.PZ ? H : L.PZ - c->k1;
-            rc = cm->sendrecv(c, cm->rank + 1, base + (size_t)(c->k1 - hs) * pb, (size_t)hs * pb, base + (size_t)c->k1 * pb, (size_t)hr * pb);
-            if (rc) return rc;
-        }
+        const HBox sLo = phase_box(c, axis, own0, own0 + H, H, true), rLo = phase_box(c, axis, own0 - H, own0, H, true);
+        const HBox sHi = phase_box(c, axis, own1 - H, own1, H, true), rHi = phase_box(c, axis, own1, own1 + H, H, true);
+        const size_t cnt = hbox_count(sLo), bytes = cnt * 8 * (size_t)n;
+        if ((rc = xbuf_reserve(c, bytes))) return rc;
+        char *sendLo = c->xbuf, *sendHi = sendLo + bytes, *recvLo = sendHi + bytes, *recvHi = recvLo + bytes;
+        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, sLo, sendLo, 0);
+        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, sHi, sendHi, 0);
+        if ((rc = cm->begin(c))) return rc;
+        if (lower >= 0 && (rc = cm->sendrecv(c, lower, sendLo, bytes, recvLo, bytes))) return rc;
+        if (upper >= 0 && (rc = cm->sendrecv(c, upper, sendHi, bytes, recvHi, bytes))) return rc;
+        if ((rc = cm->end(c))) return rc;
+        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, rLo, recvLo, 1);
+        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, rHi, recvHi, 1);
     }
-    return cm->end(c);
+    HIPCHK(c, hipGetLastError());
+    return FLIPV_OK;
 }
 
 // The same exchange on the communication stream: it starts once everything enqueued on c->stream so far has finished and
@@ -109,45 +215,41 @@ int fv_halo_wait(flipv_context *c) {
     return FLIPV_OK;
 }
 
+// neighbour -> owner: contributions a rank scattered into entries it does not own (Hlo below its box, Hhi above) are combined
+// (min or +) into the owner's entries.  Axis by axis in the order z, y, x, each phase including the halo regions of the axes
+// still to come, so that what was scattered into an edge or corner region reaches its owner in two or three hops.
 int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op) {
     Comm *cm = c->comm;
     if (!cm) return FLIPV_OK;
+    if (n > HALO_MAXARR) { c->err = "fv_halo_reduce: too many arrays"; return FLIPV_ERR_INVALID; }
     const Lay &L = c->L;
-    const size_t plane = (size_t)L.sz;
-    // staging: per array [Hhi planes from prev | Hlo planes from next]
-    const size_t need = (size_t)n * (size_t)(Hlo + Hhi) * plane;
-    if (need > c->haloCap) {
-        if (c->haloBuf) (void)hipFree(c->haloBuf);
-        c->haloBuf = nullptr; c->haloCap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->haloBuf, need * sizeof(float)));
-        c->haloCap = need;
-    }
-    int rc = cm->begin(c);
-    if (rc) return rc;
-    for (int a = 0; a < n; a++) {
-        float *base = arr[a];
-        float *stPrev = c->haloBuf + (size_t)a * (Hlo + Hhi) * plane, *stNext = stPrev + (size_t)Hhi * plane;
-        if (cm->rank > 0) {
-            // I scattered into planes [k0-Hlo, k0) owned by prev; prev scattered into my planes [k0, k0+Hhi)
-            rc = cm->sendrecv(c, cm->rank - 1, base + (size_t)(c->k0 - Hlo) * plane, (size_t)Hlo * plane * 4, stPrev, (size_t)Hhi * plane * 4);
-            if (rc) return rc;
-        }
-        if (cm->rank < cm->nranks - 1) {
-            rc = cm->sendrecv(c, cm->rank + 1, base + (size_t)c->k1 * plane, (size_t)Hhi * plane * 4, stNext, (size_t)Hlo * plane * 4);
-            if (rc) return rc;
-        }
-    }
-    rc = cm->end(c);
-    if (rc) return rc;
-    for (int a = 0; a < n; a++) {
-        float *base = arr[a];
-        float *stPrev = c->haloBuf + (size_t)a * (Hlo + Hhi) * plane, *stNext = stPrev + (size_t)Hhi * plane;
-        if (cm->rank > 0)
-            hipLaunchKernelGGL(k_halo_combine, dim3(grid1d((size_t)Hhi * plane)), dim3(256), 0, c->stream, base + (size_t)c->k0 * plane,
-                               stPrev, (size_t)Hhi * plane, op);
-        if (cm->rank < cm->nranks - 1)
-            hipLaunchKernelGGL(k_halo_combine, dim3(grid1d((size_t)Hlo * plane)), dim3(256), 0, c->stream,
-                               base + (size_t)(c->k1 - Hlo) * plane, stNext, (size_t)Hlo * plane, op);
+    HaloSet hs;
+    hs.n = n;
+    for (int a = 0; a < n; a++) { hs.p[a] = arr[a]; hs.elem[a] = 4; }
+    const int W = Hlo > Hhi ? Hlo : Hhi;
+    int rc;
+    for (int axis = 2; axis >= 0; axis--) {
+        if (c->pgrid[axis] <= 1) continue;
+        const int lower = nbr_rank(c, axis, -1), upper = nbr_rank(c, axis, +1);
+        const int own0 = L.olo[axis], own1 = L.ohi[axis];
+        // to the lower neighbour: what I scattered into [own0-Hlo, own0); from it: what it scattered into my [own0, own0+Hhi)
+        const HBox sLo = phase_box(c, axis, own0 - Hlo, own0, W, false), rLo = phase_box(c, axis, own0, own0 + Hhi, W, false);
+        const HBox sHi = phase_box(c, axis, own1, own1 + Hhi, W, false), rHi = phase_box(c, axis, own1 - Hlo, own1, W, false);
+        const size_t cLo = hbox_count(sLo), cHi = hbox_count(sHi);   // (the lower side's send is Hlo thick and its receive Hhi, and vice versa)
+        const size_t cMax = cLo > cHi ? cLo : cHi;
+        const size_t bytes = cMax * 8 * (size_t)n;
+        if ((rc = xbuf_reserve(c, bytes))) return rc;
+        char *sendLo = c->xbuf, *sendHi = sendLo + bytes, *recvLo = sendHi + bytes, *recvHi = recvLo + bytes;
+        const size_t bLo = cLo * 8 * (size_t)n, bHi = cHi * 8 * (size_t)n;
+        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cLo)), dim3(256), 0, c->xs, hs, L, sLo, sendLo, 0);
+        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cHi)), dim3(256), 0, c->xs, hs, L, sHi, sendHi, 0);
+        if ((rc = cm->begin(c))) return rc;
+        if (lower >= 0 && (rc = cm->sendrecv(c, lower, sendLo, bLo, recvLo, bHi))) return rc;   // I receive Hhi-thick data packed like the neighbour's sHi
+        if (upper >= 0 && (rc = cm->sendrecv(c, upper, sendHi, bHi, recvHi, bLo))) return rc;
+        if ((rc = cm->end(c))) return rc;
+        const int mode = op == HALO_MIN_F32 ? 2 : 3;
+        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cHi)), dim3(256), 0, c->xs, hs, L, rLo, recvLo, mode);
+        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cLo)), dim3(256), 0, c->xs, hs, L, rHi, recvHi, mode);
     }
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
@@ -177,12 +279,13 @@ int fv_allreduce_max_f32(flipv_context *c, float *value) {
     return FLIPV_OK;
 }
 
-// particles whose cell left the slab move to the neighbour that owns it (a particle moves at most CFL = 5 cells per
-// substep, slabs are much thicker, so only the two neighbours can be destinations)
-int fv_migrate_particles(flipv_context *c) {
+// Particles whose cell left the block move to the rank that owns it: axis by axis (x, y, z), each phase to the two
+// neighbours along that axis -- a particle that crossed an edge or a corner arrives in two or three hops.  (A particle moves
+// at most CFL = 5 cells per substep and blocks are at least ceil(CFL) + 3 cells thick, so only adjacent ranks are ever
+// destinations.)
+static int migrate_axis(flipv_context *c, int axis) {
     Comm *cm = c->comm;
-    if (!cm) return FLIPV_OK;
-    const Lay &L = c->L;
+    const int lower = nbr_rank(c, axis, -1), upper = nbr_rank(c, axis, +1);
     const size_t np = c->np;
     const size_t need = 3 * (np + 1024) * 6;
     if (need > c->pScratchCap) {
@@ -194,15 +297,15 @@ int fv_migrate_particles(flipv_context *c) {
     float *stay = c->pScratch, *toPrev = stay + (np + 1024) * 6, *toNext = toPrev + (np + 1024) * 6;
     unsigned long long *cnt = (unsigned long long *)c->d_scal_small;  // [0..2] out counts, [4] from prev, [5] from next
     HIPCHK(c, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), c->stream));
-    const int kc0 = c->k0, kc1 = cm->rank == cm->nranks - 1 ? L.K + 1000000 : c->k1;
-    const int kc0e = cm->rank == 0 ? -1000000 : kc0;
+    // the end ranks keep whatever lies beyond the domain on their side
+    const int kc0 = lower < 0 ? -1000000 : c->cell0[axis], kc1 = upper < 0 ? 1000000000 : c->cell1[axis];
     if (np)
         hipLaunchKernelGGL(k_migrate_classify, dim3(cdiv(np, 256)), dim3(256), 0, c->stream, c->particles, np, stay, toPrev, toNext,
-                           cnt, c->dx, kc0e, kc1);
+                           cnt, c->dx, axis, kc0, kc1);
     int rc = cm->begin(c);
     if (rc) return rc;
-    if (cm->rank > 0) { rc = cm->sendrecv(c, cm->rank - 1, cnt + 1, 8, cnt + 4, 8); if (rc) return rc; }
-    if (cm->rank < cm->nranks - 1) { rc = cm->sendrecv(c, cm->rank + 1, cnt + 2, 8, cnt + 5, 8); if (rc) return rc; }
+    if (lower >= 0) { rc = cm->sendrecv(c, lower, cnt + 1, 8, cnt + 4, 8); if (rc) return rc; }
+    if (upper >= 0) { rc = cm->sendrecv(c, upper, cnt + 2, 8, cnt + 5, 8); if (rc) return rc; }
     rc = cm->end(c);
     if (rc) return rc;
     unsigned long long h[8];
@@ -220,15 +323,25 @@ int fv_migrate_particles(flipv_context *c) {
     if (nStay) HIPCHK(c, hipMemcpyAsync(c->particles, stay, nStay * 24, hipMemcpyDeviceToDevice, c->stream));
     rc = cm->begin(c);
     if (rc) return rc;
-    if (cm->rank > 0) { rc = cm->sendrecv(c, cm->rank - 1, toPrev, nToPrev * 24, c->particles + nStay * 6, nFromPrev * 24); if (rc) return rc; }
-    if (cm->rank < cm->nranks - 1) {
-        rc = cm->sendrecv(c, cm->rank + 1, toNext, nToNext * 24, c->particles + (nStay + nFromPrev) * 6, nFromNext * 24);
+    if (lower >= 0) { rc = cm->sendrecv(c, lower, toPrev, nToPrev * 24, c->particles + nStay * 6, nFromPrev * 24); if (rc) return rc; }
+    if (upper >= 0) {
+        rc = cm->sendrecv(c, upper, toNext, nToNext * 24, c->particles + (nStay + nFromPrev) * 6, nFromNext * 24);
         if (rc) return rc;
     }
     rc = cm->end(c);
     if (rc) return rc;
     c->np = nNew;
     c->binsValid = 0;
+    return FLIPV_OK;
+}
+
+int fv_migrate_particles(flipv_context *c) {
+    if (!c->comm) return FLIPV_OK;
+    for (int axis = 0; axis < 3; axis++) {
+        if (c->pgrid[axis] <= 1) continue;
+        const int rc = migrate_axis(c, axis);
+        if (rc) return rc;
+    }
     return FLIPV_OK;
 }
 
@@ -404,19 +517,40 @@ static int comm_check(flipv_context *c, int nranks) {
         c->err = "flipv_comm_init: at most " + std::to_string(NSLOT) + " ranks per communicator (got " + std::to_string(nranks) + ")";
         return FLIPV_ERR_INVALID;
     }
-    const int need = fv_min_slab_planes(c->prm.cfl_number);
-    if (nranks > 1 && c->k1 - c->k0 < need) {
-        c->err = "flipv_comm_init: slab [" + std::to_string(c->k0) + ", " + std::to_string(c->k1) + ") is thinner than the widest halo (" +
-                 std::to_string(need) + " planes = ceil(cfl_number) + 3)";
-        return FLIPV_ERR_INVALID;
+    return FLIPV_OK;
+}
+// place the context in the process grid `dims` (rank = x + dims[0] * (y + dims[1] * z)) and check that its box fits that place
+static int comm_place(flipv_context *c, int rank, const int *dims) {
+    const int nranks = dims[0] * dims[1] * dims[2];
+    if (dims[0] < 1 || dims[1] < 1 || dims[2] < 1 || rank < 0 || rank >= nranks) { c->err = "flipv_comm_init: bad process grid"; return FLIPV_ERR_INVALID; }
+    int rc = comm_check(c, nranks);
+    if (rc) return rc;
+    const int N[3] = {c->L.I, c->L.J, c->L.K};
+    const int co[3] = {rank % dims[0], (rank / dims[0]) % dims[1], rank / (dims[0] * dims[1])};
+    for (int a = 0; a < 3; a++) {
+        if ((co[a] == 0) != (c->cell0[a] == 0) || (co[a] == dims[a] - 1) != (c->cell1[a] == N[a])) {
+            c->err = "flipv_comm_init: the context's block does not match its place in the process grid (axis " + std::to_string(a) + ")";
+            return FLIPV_ERR_INVALID;
+        }
+        c->pgrid[a] = dims[a]; c->pcoord[a] = co[a];
+    }
+    if (nranks > 1 && (rc = fv_check_block_thickness(c, c->prm.cfl_number, "flipv_comm_init"))) {
+        for (int a = 0; a < 3; a++) { c->pgrid[a] = 1; c->pcoord[a] = 0; }
+        return rc;
     }
     return FLIPV_OK;
 }
 
 extern "C" int flipv_comm_init_rccl(flipv_context *c, const void *unique_id, int rank, int nranks) {
-    if (!c || !unique_id || rank < 0 || rank >= nranks) return FLIPV_ERR_INVALID;
+    const int dims[3] = {1, 1, nranks};   // slabs along k
+    return flipv_comm_init_rccl_grid(c, unique_id, rank, dims);
+}
+
+extern "C" int flipv_comm_init_rccl_grid(flipv_context *c, const void *unique_id, int rank, const int *dims) {
+    if (!c || !unique_id || !dims) return FLIPV_ERR_INVALID;
     if (c->comm) { c->err = "flipv_comm_init: communicator already set"; return FLIPV_ERR_INVALID; }
-    { const int rc = comm_check(c, nranks); if (rc) return rc; }
+    { const int rc = comm_place(c, rank, dims); if (rc) return rc; }
+    const int nranks = dims[0] * dims[1] * dims[2];
     if (!rccl_load(&c->err)) return FLIPV_ERR_COMM;
     HIPCHK(c, hipSetDevice(c->device));
     RcclComm *cm = new RcclComm();
@@ -430,9 +564,16 @@ extern "C" int flipv_comm_init_rccl(flipv_context *c, const void *unique_id, int
 }
 
 extern "C" int flipv_comm_init_local(flipv_context **ctxs, int n) {
-    if (!ctxs || n < 1) return FLIPV_ERR_INVALID;
+    const int dims[3] = {1, 1, n};   // slabs along k
+    return flipv_comm_init_local_grid(ctxs, dims);
+}
+
+extern "C" int flipv_comm_init_local_grid(flipv_context **ctxs, const int *dims) {
+    if (!ctxs || !dims) return FLIPV_ERR_INVALID;
+    const int n = dims[0] * dims[1] * dims[2];
+    if (n < 1) return FLIPV_ERR_INVALID;
     for (int r = 0; r < n; r++) if (!ctxs[r] || ctxs[r]->comm) return FLIPV_ERR_INVALID;
-    for (int r = 0; r < n; r++) { const int rc = comm_check(ctxs[r], n); if (rc) return rc; }
+    for (int r = 0; r < n; r++) { const int rc = comm_place(ctxs[r], r, dims); if (rc) return rc; }
     LocalGroup *g = new LocalGroup();
     g->n = n; g->refs = n;
     g->ops.resize((size_t)n);
@@ -448,5 +589,6 @@ extern "C" int flipv_comm_init_local(flipv_context **ctxs, int n) {
 extern "C" int flipv_comm_finalize(flipv_context *c) {
     if (!c) return FLIPV_ERR_INVALID;
     if (c->comm) { delete c->comm; c->comm = nullptr; }
+    for (int a = 0; a < 3; a++) { c->pgrid[a] = 1; c->pcoord[a] = 0; }
     return FLIPV_OK;
 }

@@ -17,8 +17,12 @@
 //
 // At the ABI every grid is the reference's Array3d (x fastest, its own width/height).  On the device all
 // lattices of one simulation -- cells (I,J,K), U/V/W faces, nodes (I+1,J+1,K+1) and the three edge
-// families -- live in ONE index space of PX x PY x PZ entries, PX = roundup8(I+1), PY = roundup4(J+1), PZ = K+1:
-//     g(i,j,k) = i + PX*(j + PY*k)      for every array.
+// families -- live in ONE index space of roundup8(I+1) x roundup4(J+1) x (K+1) entries, of which a context ALLOCATES a box:
+// the whole space on a single GPU; the block of indices a rank owns plus FV_HALO entries on every side that has a
+// neighbour (rounded out to multiples of 8 in i and 4 in j) in a block-decomposed run.  With (ox,oy,oz) the first
+// allocated index and PX x PY x PZ the allocated extents
+//     g(i,j,k) = (i-ox) + PX*((j-oy) + PY*(k-oz))      for every array,  i, j, k always GLOBAL indices,
+// so that every kernel states the domain's boundary conditions (i == 0, i == I, ...) the same way on every rank.
 // Consequences: a single index and a single set of neighbour offsets (1, PX, PX*PY) address every
 // field; rows start 16-byte aligned so a lane can move 4 consecutive i with one dwordx4 access (a wave:
 // 1 KiB per instruction); a k-plane is one contiguous PX*PY block (the halo unit of a slab decomposition).
@@ -27,24 +31,33 @@
 // addresses.  Conversion to/from Array3d happens in flipv_read_grid / flipv_write_grid (k_pack/k_unpack).
 // ---------------------------------------------------------------------------------------------
 struct Lay {
-    int I, J, K;     // cells (GLOBAL grid: every rank of a slab decomposition indexes the whole domain)
-    int PX, PY, PZ;  // padded index space
+    int I, J, K;     // cells of the GLOBAL grid
+    int PX, PY, PZ;  // extents of the allocated box (8 | PX, 4 | PY)
     long sy, sz;     // strides of j and k
     size_t n;        // PX*PY*PZ
     size_t guard;    // floats of guard zone in front of / behind every array
-    int kb, ke;      // k-planes [kb, ke) a pointwise launch covers (GRID3 / IJK_OR_RETURN)
+    int ox, oy, oz;  // global index of the first allocated entry (8 | ox, 4 | oy; 0 on a single GPU)
+    int ib, ie, jb, je, kb, ke;   // box of indices a pointwise launch covers (GRID3 / IJK_OR_RETURN), half-open
+    int olo[3], ohi[3];           // box of indices this rank OWNS, half-open (the whole allocated box on a single GPU; on the last
+                                  // rank of an axis it runs to the padded end, i.e. includes the closing face / node plane)
 };
 
 __host__ __device__ __forceinline__ size_t gidx(const Lay &L, int i, int j, int k) {
-    return (size_t)i + (size_t)L.PX * ((size_t)j + (size_t)L.PY * (size_t)k);
+    return (size_t)(i - L.ox) + (size_t)L.PX * ((size_t)(j - L.oy) + (size_t)L.PY * (size_t)(k - L.oz));
 }
+__host__ __device__ __forceinline__ bool d_owned(const Lay &L, int i, int j, int k) {
+    return i >= L.olo[0] && i < L.ohi[0] && j >= L.olo[1] && j < L.ohi[1] && k >= L.olo[2] && k < L.ohi[2];
+}
+// first entry of allocated plane k (whole planes are contiguous: copies, fills and reductions over plane ranges)
+__host__ __device__ __forceinline__ size_t plane_off(const Lay &L, int k) { return (size_t)(k - L.oz) * (size_t)L.sz; }
 // Swizzled plane layout (x, r, q and the diagonal of the viscosity PCG, 16-lane tile geometry): the four rows of an aligned row
 // group are interleaved in pieces of 8 indices, so that a 128-byte line holds an 8 x 4 patch of a k-plane instead of a
 // 32 x 1 stick.  On a compact liquid body the sticks are 1.50x over-fetched (both ends of every i-run), the patches 1.20x
 // (counted on the 256^3 bunny); a wave of 16 x 4 lanes still moves one contiguous 1 KB per access.  PX % 8 == 0 and
 // PY % 4 == 0 make it a bijection of each plane; j = -1 aliases the last row of the previous plane as gidx does.
 __host__ __device__ __forceinline__ size_t sidx(const Lay &L, int i, int j, int k) {
-    return (size_t)((long)k * L.sz + (long)(j >> 2) * (4 * L.PX) + (long)(i >> 3) * 32 + (long)(((j & 3) << 3) + (i & 7)));
+    i -= L.ox; j -= L.oy;   // 8 | ox and 4 | oy: patches of the box are patches of the global index space
+    return (size_t)((long)(k - L.oz) * L.sz + (long)(j >> 2) * (4 * L.PX) + (long)(i >> 3) * 32 + (long)(((j & 3) << 3) + (i & 7)));
 }
 
 // lattice ids: logical extents inside the shared index space
@@ -64,14 +77,17 @@ static inline int geo_ty(int rowl) { return 4 * (64 / rowl); }
 struct TileGrid {
     int ntx, nty, ntz;
     int rowl;   // 16 or 64: which geometry the grid (and the tile list built on it) belongs to
+    int ox, oy, oz;   // global index of tile (0,0,0)'s first entry = the first index the rank owns
     __host__ __device__ int count() const { return ntx * nty * ntz; }
 };
+// tiles cover the indices the rank owns (the whole index space on a single GPU)
 static inline TileGrid make_tile_grid(const Lay &L, int rowl, int vw) {
     TileGrid tg;
     tg.rowl = rowl;
-    tg.ntx = (L.PX + rowl * vw - 1) / (rowl * vw);
-    tg.nty = (L.PY + geo_ty(rowl) - 1) / geo_ty(rowl);
-    tg.ntz = L.PZ;
+    tg.ox = L.olo[0]; tg.oy = L.olo[1]; tg.oz = L.olo[2];
+    tg.ntx = (L.ohi[0] - L.olo[0] + rowl * vw - 1) / (rowl * vw);
+    tg.nty = (L.ohi[1] - L.olo[1] + geo_ty(rowl) - 1) / geo_ty(rowl);
+    tg.ntz = L.ohi[2] - L.olo[2];
     return tg;
 }
 
@@ -80,10 +96,20 @@ struct Comm;
 // also the largest rank count a communicator accepts
 constexpr int NSLOT = 32;
 
+// widest halo any exchange uses: the velocity halo of particle advection, ceil(cfl_number) + 3 planes at the default CFL
+// number of 5.  A block context allocates this many entries around its owned box; flipv_set_params rejects a larger CFL
+// number on such a context.
+constexpr int FV_HALO = 8;
+
 struct flipv_context {
-    Lay L;           // kb/ke = the whole index space; per-launch ranges come from fv_range()
-    // slab decomposition along k: this rank owns index planes [k0, k1) (k1 = PZ on the last rank).  Single GPU: [0, PZ).
+    Lay L;           // launch box = the whole allocated box; per-launch ranges come from fv_range()
+    // Block decomposition: this rank owns cells [cell0, cell1) per axis, i.e. indices [L.olo, L.ohi) (the closing face / node
+    // plane belongs to the last rank of the axis).  Single GPU: everything.  k0/k1 = L.olo[2]/L.ohi[2], kept under their
+    // old names where only the k-range matters.
+    int cell0[3], cell1[3];
     int k0, k1;
+    int isBlock;     // created by flipv_create_block with a box smaller than the domain: scene setup entry points refuse it
+    int pgrid[3], pcoord[3];   // process grid and this rank's place in it (set by flipv_comm_init_*; {1,1,1} / {0,0,0} without)
     Comm *comm;      // nullptr on a single GPU
     // communication stream state: point-to-point operations are enqueued on `xs` (normally = stream; = commStream
     // while a halo exchange overlaps interior work, see pcg_common.h), the scalar all-reduces always on `stream`
@@ -107,8 +133,10 @@ struct flipv_context {
     size_t np, pcap;
     float *pScratch;   // migration staging (same capacity)
     size_t pScratchCap;
-    float *haloBuf;    // receive staging for halo reductions
+    float *haloBuf;    // (unused since the box exchanges; kept for layout stability of older tools)
     size_t haloCap;
+    char *xbuf = nullptr;   // staging of the packed halo boxes: send lower | send upper | receive lower | receive upper
+    size_t xbufCap = 0;
     // particle bins (k_particles.hip): particle indices grouped by tile of BIN_T^3 cells, rebuilt by fv_bin_particles
     unsigned *binIdx;      // np particle indices, tile by tile
     size_t binIdxCap;
@@ -201,19 +229,26 @@ struct flipv_context {
 
 static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
-// launch range: the owned planes widened by `halo` planes on each side, clipped to the index space
+// launch range: the owned box widened by `halo` entries on each side, clipped to the allocated box
 static inline Lay fv_range(const flipv_context *c, int halo) {
     Lay L = c->L;
-    L.kb = c->k0 - halo < 0 ? 0 : c->k0 - halo;
-    L.ke = c->k1 + halo > L.PZ ? L.PZ : c->k1 + halo;
+    const int o[3] = {L.ox, L.oy, L.oz}, P[3] = {L.PX, L.PY, L.PZ};
+    int lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {
+        lo[a] = L.olo[a] - halo < o[a] ? o[a] : L.olo[a] - halo;
+        hi[a] = L.ohi[a] + halo > o[a] + P[a] ? o[a] + P[a] : L.ohi[a] + halo;
+    }
+    L.ib = lo[0]; L.ie = hi[0]; L.jb = lo[1]; L.je = hi[1]; L.kb = lo[2]; L.ke = hi[2];
     return L;
 }
 
-// pointwise kernels: one thread per index of the padded space; a wave = 64 consecutive i of one row
-#define GRID3(L) dim3(cdiv((L).PX, 64), cdiv((L).PY, 4), (unsigned)((L).ke - (L).kb)), dim3(64, 4, 1)
+// pointwise kernels: one thread per index of the launch box; a wave = 64 consecutive i of one row
+#define GRID3(L) dim3(cdiv((L).ie - (L).ib, 64), cdiv((L).je - (L).jb, 4), (unsigned)((L).ke - (L).kb)), dim3(64, 4, 1)
+#define IJK_OF_THREAD(L) \
+    const int i = (L).ib + blockIdx.x * 64 + threadIdx.x, j = (L).jb + blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + (L).kb
 #define IJK_OR_RETURN(L)                                                                              \
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + (L).kb;   \
-    if (i >= (L).PX || j >= (L).PY) return;                                                            \
+    IJK_OF_THREAD(L);                                                                                  \
+    if (i >= (L).ie || j >= (L).je) return;                                                            \
     const size_t c = gidx((L), i, j, k);                                                                \
     (void)c
 
@@ -352,8 +387,10 @@ int fv_update_particle_velocities(flipv_context *c);
 int fv_advect_particles(flipv_context *c, float dt);
 int fv_pressure_solve(flipv_context *c, float dt, flipv_solve_info *info);
 int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info);
-int fv_pack(flipv_context *c, int lat, const float *src_f32, const uint8_t *src_u8, float *linear);   // device -> Array3d order
-int fv_unpack(flipv_context *c, int lat, const float *linear, float *dst_f32, uint8_t *dst_u8);       // Array3d order -> device
+// device layout <-> a box [lo, hi) of lattice `lat` in Array3d order (x fastest, box-shaped); unpack zeroes the allocated
+// entries outside the lattice
+int fv_pack(flipv_context *c, int lat, const float *src_f32, const uint8_t *src_u8, float *linear, const int lo[3], const int hi[3]);
+int fv_unpack(flipv_context *c, int lat, const float *linear, float *dst_f32, uint8_t *dst_u8, const int lo[3], const int hi[3]);
 int fv_fill(flipv_context *c, float *p, size_t n, float v);
 int fv_fill_cells(flipv_context *c, float *p, float v, int halo);
 

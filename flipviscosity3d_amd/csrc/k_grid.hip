@@ -9,23 +9,26 @@
 
 // ------------------------------------------------------------------ Array3d <-> device layout
 // linear = the reference's Array3d order for lattice `lat` (flat = i + w*(j + h*k), array3d.h:397-400)
-__global__ void k_unpack(Lay L, int lat, const float *__restrict__ linear, float *__restrict__ dstf,
+// `linear` holds the box [b0, b1) of the lattice, box-shaped
+struct IBox { int lo[3], hi[3]; };
+__device__ __forceinline__ bool d_in_box(const IBox &b, int i, int j, int k) {
+    return i >= b.lo[0] && i < b.hi[0] && j >= b.lo[1] && j < b.hi[1] && k >= b.lo[2] && k < b.hi[2];
+}
+__device__ __forceinline__ size_t d_box_index(const IBox &b, int i, int j, int k) {
+    return (size_t)(i - b.lo[0]) + (size_t)(b.hi[0] - b.lo[0]) * ((size_t)(j - b.lo[1]) + (size_t)(b.hi[1] - b.lo[1]) * (size_t)(k - b.lo[2]));
+}
+__global__ void k_unpack(Lay L, IBox b, const float *__restrict__ linear, float *__restrict__ dstf,
                          uint8_t *__restrict__ dstb) {
     IJK_OR_RETURN(L);
-    int w, h, d;
-    lat_dims(L, lat, w, h, d);
     float v = 0.0f;
-    if (i < w && j < h && k < d) v = linear[(size_t)i + (size_t)w * ((size_t)j + (size_t)h * (size_t)k)];
+    if (d_in_box(b, i, j, k)) v = linear[d_box_index(b, i, j, k)];
     if (dstf) dstf[c] = v;
     else dstb[c] = v != 0.0f;
 }
-__global__ void k_pack(Lay L, int lat, const float *__restrict__ srcf, const uint8_t *__restrict__ srcb,
+__global__ void k_pack(Lay L, IBox b, const float *__restrict__ srcf, const uint8_t *__restrict__ srcb,
                        float *__restrict__ linear) {
     IJK_OR_RETURN(L);
-    int w, h, d;
-    lat_dims(L, lat, w, h, d);
-    if (i < w && j < h && k < d)
-        linear[(size_t)i + (size_t)w * ((size_t)j + (size_t)h * (size_t)k)] = srcf ? srcf[c] : (srcb[c] ? 1.0f : 0.0f);
+    if (d_in_box(b, i, j, k)) linear[d_box_index(b, i, j, k)] = srcf ? srcf[c] : (srcb[c] ? 1.0f : 0.0f);
 }
 
 // ------------------------------------------------------------------ K2: liquid SDF into solids
@@ -92,9 +95,9 @@ __global__ void k_p2g_finalize(Lay L, const float *__restrict__ accU, const floa
 // cell of it can be reached by `layers` <= ACT_B extrapolation layers.  The layer kernel skips every other block
 // (the liquid fills a few percent of the box; the full sweep was 14 x 216 us per substep at 256^3).
 constexpr int ACT_B = 8;
-struct ActGrid { int nx, ny, nz; };
+struct ActGrid { int nx, ny, nz, ox, oy, oz; };   // blocks of the allocated box; (ox,oy,oz) = its first index
 __device__ __forceinline__ int d_act_index(const ActGrid &A, int i, int j, int k) {
-    return (i / ACT_B) + A.nx * ((j / ACT_B) + A.ny * (k / ACT_B));
+    return ((i - A.ox) / ACT_B) + A.nx * (((j - A.oy) / ACT_B) + A.ny * ((k - A.oz) / ACT_B));
 }
 
 __global__ void k_extrap_init(Lay L, ActGrid A, const uint8_t *__restrict__ vU, const uint8_t *__restrict__ vV,
@@ -119,9 +122,10 @@ __global__ void k_extrap_init(Lay L, ActGrid A, const uint8_t *__restrict__ vU, 
     if (fillable) unk[d_act_index(A, i, j, k)] = 1;   // blocks without a single unknown face (the liquid's interior) have nothing to fill
 }
 
-// 3x3x3 dilation; in a multi-rank run every block within ACT_B planes of an interior slab boundary is active as well
-// (the neighbour's valid faces can reach across the cut; its masks are only known one plane deep)
-__global__ void k_act_dilate(ActGrid A, const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int k0, int k1, int PZ) {
+// 3x3x3 dilation; in a multi-rank run every block within ACT_B entries of a face of the owned box that has a neighbour is
+// active as well (the neighbour's valid faces can reach across the cut; its masks are only known one entry deep)
+struct CutFaces { int lo[3], hi[3], has_lo[3], has_hi[3]; };   // owned box and which of its faces are interior cuts
+__global__ void k_act_dilate(ActGrid A, const uint8_t *__restrict__ in, uint8_t *__restrict__ out, CutFaces F) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= A.nx * A.ny * A.nz) return;
     const int bx = t % A.nx, by = (t / A.nx) % A.ny, bz = t / (A.nx * A.ny);
@@ -132,14 +136,17 @@ __global__ void k_act_dilate(ActGrid A, const uint8_t *__restrict__ in, uint8_t 
                 const int x = bx + dxx, y = by + dy, z = bz + dz;
                 if (x >= 0 && y >= 0 && z >= 0 && x < A.nx && y < A.ny && z < A.nz) any |= in[x + A.nx * (y + A.ny * z)];
             }
-    const int lo = bz * ACT_B, hi = lo + ACT_B - 1;  // planes of this block
-    if (k0 > 0 && hi >= k0 - ACT_B && lo <= k0 + ACT_B - 1) any = 1;
-    if (k1 < PZ && hi >= k1 - ACT_B && lo <= k1 + ACT_B - 1) any = 1;
+    const int b3[3] = {bx, by, bz}, o3[3] = {A.ox, A.oy, A.oz};
+    for (int a = 0; a < 3; a++) {
+        const int lo = o3[a] + b3[a] * ACT_B, hi = lo + ACT_B - 1;  // entries of this block along the axis
+        if (F.has_lo[a] && hi >= F.lo[a] - ACT_B && lo <= F.lo[a] + ACT_B - 1) any = 1;
+        if (F.has_hi[a] && hi >= F.hi[a] - ACT_B && lo <= F.hi[a] + ACT_B - 1) any = 1;
+    }
     out[t] = (uint8_t)any;
 }
 
-// the active blocks that hold planes of [kb, ke), compacted by one workgroup: list[0] = count, ids from list[1]
-__global__ __launch_bounds__(1024) void k_act_compact(ActGrid A, const uint8_t *__restrict__ act, const uint8_t *__restrict__ unk, int kb, int ke,
+// the active blocks that hold entries of the launch box of R, compacted by one workgroup: list[0] = count, ids from list[1]
+__global__ __launch_bounds__(1024) void k_act_compact(ActGrid A, const uint8_t *__restrict__ act, const uint8_t *__restrict__ unk, Lay R,
                                                       int *__restrict__ list) {
     __shared__ int wsum[16];
     __shared__ int base;
@@ -151,8 +158,9 @@ __global__ __launch_bounds__(1024) void k_act_compact(ActGrid A, const uint8_t *
         const int t = start + (int)threadIdx.x;
         int f = 0;
         if (t < n && act[t] && unk[t]) {
-            const int bz = t / (A.nx * A.ny);
-            f = bz * ACT_B < ke && bz * ACT_B + ACT_B > kb;
+            const int bx = t % A.nx, by = (t / A.nx) % A.ny, bz = t / (A.nx * A.ny);
+            const int x0 = A.ox + bx * ACT_B, y0 = A.oy + by * ACT_B, z0 = A.oz + bz * ACT_B;
+            f = x0 < R.ie && x0 + ACT_B > R.ib && y0 < R.je && y0 + ACT_B > R.jb && z0 < R.ke && z0 + ACT_B > R.kb;
         }
         const unsigned long long m = __ballot(f);
         if (lane == 0) wsum[wv] = __popcll(m);
@@ -180,11 +188,11 @@ __global__ __launch_bounds__(256) void k_extrap_layer(Lay L, ActGrid A, const in
     for (int b = blockIdx.x; b < count; b += gridDim.x) {
         const int id = list[1 + b];
         const int bx = id % A.nx, by = (id / A.nx) % A.ny, bz = id / (A.nx * A.ny);
-        const int i = bx * ACT_B + lx, j = by * ACT_B + ly;
-        if (i >= L.PX || j >= L.PY) continue;
+        const int i = A.ox + bx * ACT_B + lx, j = A.oy + by * ACT_B + ly;
+        if (i < L.ib || i >= L.ie || j < L.jb || j >= L.je) continue;
 #pragma unroll
         for (int p = 0; p < ACT_B; p += 4) {
-            const int k = bz * ACT_B + p + lz;
+            const int k = A.oz + bz * ACT_B + p + lz;
             if (k < L.kb || k >= L.ke) continue;
             const size_t c = gidx(L, i, j, k);
 #pragma unroll
@@ -311,6 +319,21 @@ __global__ void k_absmax3(const float *__restrict__ a, const float *__restrict__
     if (threadIdx.x == 0) atomicMax(out_bits, __float_as_uint((float)r));
 }
 
+// the same over a launch box (block-decomposed runs: only the entries the rank owns; its halo holds copies of the neighbours'
+// values taken at another moment of the substep)
+__global__ void k_absmax3_box(Lay L, const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ c3,
+                              unsigned *__restrict__ out_bits) {
+    __shared__ double lds[4];
+    IJK_OF_THREAD(L);
+    float m = 0.0f;
+    if (i < L.ie && j < L.je) {
+        const size_t c = gidx(L, i, j, k);
+        m = fmaxf(fabsf(a[c]), fmaxf(fabsf(b[c]), fabsf(c3[c])));
+    }
+    const double r = block_max_256((double)m, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && r > 0.0) atomicMax(out_bits, __float_as_uint((float)r));
+}
+
 // =================================================================== host launchers
 // Ranges: fv_range(c, h) = the planes this rank owns widened by h halo planes (the whole index space on one GPU).
 static unsigned grid1d(size_t n) {
@@ -318,13 +341,21 @@ static unsigned grid1d(size_t n) {
     return (unsigned)(b > 2048 ? 2048 : (b ? b : 1));
 }
 
-int fv_unpack(flipv_context *c, int lat, const float *linear, float *dstf, uint8_t *dstb) {
-    hipLaunchKernelGGL(k_unpack, GRID3(c->L), 0, c->stream, c->L, lat, linear, dstf, dstb);
+int fv_unpack(flipv_context *c, int lat, const float *linear, float *dstf, uint8_t *dstb, const int lo[3], const int hi[3]) {
+    IBox b;
+    for (int a = 0; a < 3; a++) { b.lo[a] = lo[a]; b.hi[a] = hi[a]; }
+    (void)lat;
+    hipLaunchKernelGGL(k_unpack, GRID3(c->L), 0, c->stream, c->L, b, linear, dstf, dstb);   // the whole allocated box: zero outside [lo, hi)
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
-int fv_pack(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, float *linear) {
-    hipLaunchKernelGGL(k_pack, GRID3(c->L), 0, c->stream, c->L, lat, srcf, srcb, linear);
+int fv_pack(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, float *linear, const int lo[3], const int hi[3]) {
+    IBox b;
+    for (int a = 0; a < 3; a++) { b.lo[a] = lo[a]; b.hi[a] = hi[a]; }
+    (void)lat;
+    Lay R = c->L;
+    R.ib = lo[0]; R.ie = hi[0]; R.jb = lo[1]; R.je = hi[1]; R.kb = lo[2]; R.ke = hi[2];
+    hipLaunchKernelGGL(k_pack, GRID3(R), 0, c->stream, R, b, srcf, srcb, linear);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
@@ -361,18 +392,24 @@ int fv_extrapolate(flipv_context *c) {
     // activity blocks: flagged by the init sweep, dilated once per ACT_B layers
     ActGrid A;
     A.nx = (c->L.PX + ACT_B - 1) / ACT_B; A.ny = (c->L.PY + ACT_B - 1) / ACT_B; A.nz = (c->L.PZ + ACT_B - 1) / ACT_B;
+    A.ox = c->L.ox; A.oy = c->L.oy; A.oz = c->L.oz;
+    CutFaces F;
+    for (int a = 0; a < 3; a++) {
+        F.lo[a] = c->L.olo[a]; F.hi[a] = c->L.ohi[a];
+        F.has_lo[a] = c->comm && c->pcoord[a] > 0;
+        F.has_hi[a] = c->comm && c->pcoord[a] < c->pgrid[a] - 1;
+    }
     const int nact = A.nx * A.ny * A.nz;
     uint8_t *actA = c->actFlags, *actB = c->actFlags + nact, *unk = c->actFlags + 2 * (size_t)nact;
     HIPCHK(c, hipMemsetAsync(actA, 0, (size_t)nact, c->stream));
     HIPCHK(c, hipMemsetAsync(unk, 0, (size_t)nact, c->stream));
     hipLaunchKernelGGL(k_extrap_init, GRID3(R1), 0, c->stream, R1, A, c->vU, c->vV, c->vW, c->stampU, c->stampV, c->stampW, actA, unk);
     for (int q = 0; q < (layers + ACT_B - 1) / ACT_B; q++) {
-        hipLaunchKernelGGL(k_act_dilate, dim3(cdiv(nact, 256)), dim3(256), 0, c->stream, A, actA, actB, c->comm ? c->k0 : 0,
-                           c->comm ? c->k1 : c->L.PZ, c->L.PZ);
+        hipLaunchKernelGGL(k_act_dilate, dim3(cdiv(nact, 256)), dim3(256), 0, c->stream, A, actA, actB, F);
         uint8_t *t = actA; actA = actB; actB = t;
     }
     const HaloArray lay[6] = {{c->U, 4}, {c->V, 4}, {c->W, 4}, {c->stampU, 1}, {c->stampV, 1}, {c->stampW, 1}};
-    hipLaunchKernelGGL(k_act_compact, dim3(1), dim3(1024), 0, c->stream, A, actA, unk, R0.kb, R0.ke, c->actList);
+    hipLaunchKernelGGL(k_act_compact, dim3(1), dim3(1024), 0, c->stream, A, actA, unk, R0, c->actList);
     const int ngrid = nact < 4096 ? nact : 4096;
     for (int q = 0; q < layers; q++) {
         hipLaunchKernelGGL(k_extrap_layer, dim3(ngrid), dim3(256), 0, c->stream, R0, A, c->actList, c->U, c->V, c->W, c->stampU, c->stampV,
@@ -409,7 +446,7 @@ int fv_apply_pressure(flipv_context *c, float dt) {
 
 int fv_constrain(flipv_context *c) {
     const Lay R = fv_range(c, 1);
-    const size_t off = (size_t)R.kb * c->L.sz, n = (size_t)(R.ke - R.kb) * c->L.sz;
+    const size_t off = plane_off(c->L, R.kb), n = (size_t)(R.ke - R.kb) * c->L.sz;   // whole allocated planes (pointwise; harmless in the halo)
     hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wU + off, c->U + off, c->sU + off, n);
     hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wV + off, c->V + off, c->sV + off, n);
     hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wW + off, c->W + off, c->sW + off, n);
@@ -420,9 +457,10 @@ int fv_constrain(flipv_context *c) {
 int fv_cfl(flipv_context *c, float *dt_out) {
     unsigned *bits = (unsigned *)(c->d_flags + 3);
     const Lay R = fv_range(c, 0);
-    const size_t off = (size_t)R.kb * c->L.sz, n = (size_t)(R.ke - R.kb) * c->L.sz;
+    const size_t off = plane_off(c->L, R.kb), n = (size_t)(R.ke - R.kb) * c->L.sz;
     HIPCHK(c, hipMemsetAsync(bits, 0, sizeof(unsigned), c->stream));
-    hipLaunchKernelGGL(k_absmax3, dim3(grid1d(n)), dim3(256), 0, c->stream, c->U + off, c->V + off, c->W + off, n, bits);
+    if (c->comm) hipLaunchKernelGGL(k_absmax3_box, GRID3(R), 0, c->stream, R, c->U, c->V, c->W, bits);
+    else hipLaunchKernelGGL(k_absmax3, dim3(grid1d(n)), dim3(256), 0, c->stream, c->U + off, c->V + off, c->W + off, n, bits);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 3, bits, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     unsigned b = *(unsigned *)(c->h_flags + 3);

@@ -96,12 +96,12 @@ __global__ void k_p2g_scatter(Lay L, const float *__restrict__ aos6, size_t n, f
 // below then give one workgroup a tile, accumulate its particles in LDS (ds_add_f32 / ds_min) and touch global memory
 // once per tile node instead of up to 162 times per particle.
 constexpr int BIN_T = 8;
-struct BinGrid { int nbx, nby, nbz, kc0, kc1; };  // kc0/kc1: cell-plane range of the slab the tiles cover
+struct BinGrid { int nbx, nby, nbz, c0[3], c1[3]; };  // c0/c1: the box of cells the rank owns, which the tiles cover
 
 __device__ __forceinline__ int d_bin_of(const BinGrid &B, const Lay &L, float px, float py, float pz, double invdx) {
     int gi = d_pos_index(px, invdx), gj = d_pos_index(py, invdx), gk = d_pos_index(pz, invdx);
-    gi = min(max(gi, 0), L.I - 1); gj = min(max(gj, 0), L.J - 1); gk = min(max(gk, B.kc0), B.kc1 - 1);
-    return gi / BIN_T + B.nbx * (gj / BIN_T + B.nby * ((gk - B.kc0) / BIN_T));
+    gi = min(max(gi, B.c0[0]), B.c1[0] - 1); gj = min(max(gj, B.c0[1]), B.c1[1] - 1); gk = min(max(gk, B.c0[2]), B.c1[2] - 1);
+    return (gi - B.c0[0]) / BIN_T + B.nbx * ((gj - B.c0[1]) / BIN_T + B.nby * ((gk - B.c0[2]) / BIN_T));
 }
 
 // Particles that are neighbours in the caller's order are mostly neighbours in space: the lanes of a wave that hit the
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_sdf_tiles(BinGrid B, Lay L, const float
     for (int tt = blockIdx.x; tt < nl; tt += gridDim.x) {
         const int tile = list[tt];
         const int tx = tile % B.nbx, ty = (tile / B.nbx) % B.nby, tz = tile / (B.nbx * B.nby);
-        const int bi = tx * BIN_T - 1, bj = ty * BIN_T - 1, bk = B.kc0 + tz * BIN_T - 1;
+        const int bi = B.c0[0] + tx * BIN_T - 1, bj = B.c0[1] + ty * BIN_T - 1, bk = B.c0[2] + tz * BIN_T - 1;
         for (int e = threadIdx.x; e < SDF_R * SDF_R * SDF_R; e += 256) sh[e] = maxd;
         __syncthreads();
         const int start = off[tile], n = cnt[tile];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float
     for (int tt = blockIdx.x; tt < nl; tt += gridDim.x) {
         const int tile = list[tt];
         const int tx = tile % B.nbx, ty = (tile / B.nbx) % B.nby, tz = tile / (B.nbx * B.nby);
-        const int bi = tx * BIN_T - 2, bj = ty * BIN_T - 2, bk = B.kc0 + tz * BIN_T - 2;
+        const int bi = B.c0[0] + tx * BIN_T - 2, bj = B.c0[1] + ty * BIN_T - 2, bk = B.c0[2] + tz * BIN_T - 2;
         for (int e = threadIdx.x; e < 6 * P2G_RN; e += 256) sh[e] = 0.0f;
         __syncthreads();
         const int start = off[tile], n = cnt[tile];
@@ -545,12 +545,10 @@ int fv_p2g_finalize(flipv_context *c);
 
 static BinGrid bin_grid(const flipv_context *c) {
     BinGrid B;
-    B.kc0 = c->k0;
-    B.kc1 = c->k1 < c->L.K ? c->k1 : c->L.K;
-    if (B.kc1 <= B.kc0) B.kc1 = B.kc0 + 1;
-    B.nbx = (c->L.I + BIN_T - 1) / BIN_T;
-    B.nby = (c->L.J + BIN_T - 1) / BIN_T;
-    B.nbz = (B.kc1 - B.kc0 + BIN_T - 1) / BIN_T;
+    for (int a = 0; a < 3; a++) { B.c0[a] = c->cell0[a]; B.c1[a] = c->cell1[a]; }
+    B.nbx = (B.c1[0] - B.c0[0] + BIN_T - 1) / BIN_T;
+    B.nby = (B.c1[1] - B.c0[1] + BIN_T - 1) / BIN_T;
+    B.nbz = (B.c1[2] - B.c0[2] + BIN_T - 1) / BIN_T;
     return B;
 }
 
@@ -616,8 +614,8 @@ int fv_particle_sdf(flipv_context *c) {
 }
 
 int fv_p2g(flipv_context *c) {
-    const Lay R = fv_range(c, 2);  // planes this rank's particles can reach
-    const size_t off = (size_t)R.kb * c->L.sz, bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
+    const Lay R = fv_range(c, 2);  // planes this rank's particles can reach (whole allocated planes are cleared)
+    const size_t off = plane_off(c->L, R.kb), bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
     float *acc[6] = {c->accU, c->accV, c->accW, c->wgtU, c->wgtV, c->wgtW};
     for (int q = 0; q < 6; q++) HIPCHK(c, hipMemsetAsync(acc[q] + off, 0, bytes, c->stream));
     if (c->np) {

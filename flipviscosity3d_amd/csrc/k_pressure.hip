@@ -26,12 +26,12 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
                                  const float *__restrict__ wW, float *__restrict__ diag, float *__restrict__ pi,
                                  float *__restrict__ pj, float *__restrict__ pk, RT<T> *__restrict__ r, T *__restrict__ x,
                                  T *__restrict__ s, uint8_t *__restrict__ cellmask, double *__restrict__ bmax,
-                                 int *__restrict__ ncells, int k0own, int k1own, float dxf, float dtf, float minfrac) {
+                                 int *__restrict__ ncells, float dxf, float dtf, float minfrac) {
     __shared__ double lds[4];
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    IJK_OF_THREAD(L);
     double babs = 0.0;
     int cells = 0;
-    if (i < L.PX && j < L.PY) {
+    if (i < L.ie && j < L.je) {
         const size_t c = gidx(L, i, j, k);
         float dg = 0.0f, ci = 0.0f, cj = 0.0f, ck = 0.0f;
         double b = 0.0;
@@ -74,11 +74,11 @@ __global__ void k_pressure_setup(Lay L, const float *__restrict__ phi, const flo
         }
         diag[c] = dg; pi[c] = ci; pj[c] = cj; pk[c] = ck;
         cellmask[c] = (uint8_t)(dg != 0.0f);
-        cells = dg != 0.0f && k >= k0own && k < k1own;
+        cells = dg != 0.0f && d_owned(L, i, j, k);
         r[c] = (RT<T>)b;
         x[c] = (T)0;
         s[c] = (T)0;
-        babs = fabs(b);
+        babs = d_owned(L, i, j, k) ? fabs(b) : 0.0;
     }
     const double bm = block_max_256(babs, lds);
     const double nc = block_sum_256((double)cells, lds);
@@ -112,7 +112,7 @@ __device__ __forceinline__ int d_virtual_tile(int v, const TileGrid &tg, int k0,
     const int kk = r % nk, chunk = r / nk;
     const int ty = chunk * JCH + tyi;
     if (ty >= tg.nty) return -1;
-    return tx + tg.ntx * (ty + tg.nty * (k0 + kk));
+    return tx + tg.ntx * (ty + tg.nty * (k0 + kk));   // k0 = 0: tile planes count from the first owned plane (TileGrid::oz)
 }
 
 // ---- the kernels that depend on the tile geometry, once per geometry (pcg_geo.inc)
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ f
             const int tile = d_virtual_tile(t, tg, k0, nk);
             list[base + woff + before] = tile;
             const int tx = tile % tg.ntx, ty = (tile / tg.ntx) % tg.nty;
-            const int w = min(tw, wdom - tx * tw), h = min(th, hdom - ty * th);
+            const int w = min(tw, wdom - (tg.ox + tx * tw)), h = min(th, hdom - (tg.oy + ty * th));
             if (w > 0 && h > 0) acc += (w * h + 3) >> 2;
         }
         __syncthreads();
@@ -261,22 +261,26 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
 
 static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                             const uint8_t *mask, int *list, int *nActive, int *nInterior) {
-    const int nk = c->k1 - c->k0, nchunks = (tg.nty + JCH - 1) / JCH;
+    const int nk = tg.ntz, nchunks = (tg.nty + JCH - 1) / JCH;
     const int nt = tg.ntx * JCH * nk * nchunks;  // virtual tiles of the owned planes (column-major enumeration)
-    GEO_RUN(tg.rowl, hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, mask, c->tileFlag, c->k0, nk));
-    if (!c->comm) {
-        hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 0,
+    GEO_RUN(tg.rowl, hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, mask, c->tileFlag, 0, nk));
+    // The interior / boundary split of the list (the SpMV over the interior tiles hides the halo exchange) is made for slabs
+    // along k only: with cuts along i or j most tiles of a 64 x 16 or 256 x 4 tiling touch a cut face.
+    const bool split = c->comm && c->pgrid[0] == 1 && c->pgrid[1] == 1;
+    if (!split) {
+        hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 0,
                            (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        *nActive = *nInterior = c->h_flags[1];
+        *nActive = c->h_flags[1];
+        *nInterior = c->comm ? 0 : c->h_flags[1];   // block cuts along i / j: every tile waits for the exchange
         return FLIPV_OK;
     }
     // list = [tiles of the interior planes | tiles of the slab's first and last plane]
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 6, tg, c->k0, nk, 1,
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 6, tg, 0, nk, 1,
                        (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, c->k0, nk, 2,
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 2,
                        (const int *)(c->d_flags + 6), tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -335,7 +339,7 @@ int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, boo
     if (runlen == 0) { if (!dense) return FLIPV_OK; runlen = RUNLEN_MAX; }
     if (runlen < 2) runlen = 2;
     if (runlen > RUNLEN_MAX) runlen = RUNLEN_MAX;
-    const int nk = c->k1 - c->k0;
+    const int nk = tg.ntz;
     const int nchunk = (nk + runlen - 1) / runlen;
     const size_t ncand = (size_t)tg.ntx * tg.nty * nchunk;
     auto grow = [&](void **p, size_t *cap, size_t want, size_t elem) -> int {
@@ -350,7 +354,7 @@ int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, boo
     int rc;
     if ((rc = grow((void **)&c->runCand, &c->runCandCap, ncand, sizeof(Run)))) return rc;
     if ((rc = grow((void **)runs, runCap, ncand, sizeof(Run)))) return rc;
-    hipLaunchKernelGGL(k_run_flags, dim3(cdiv(ncand, 256)), dim3(256), 0, c->stream, tg, (const int *)c->tileFlag, c->k0, nk, JCH, runlen, nchunk, c->runCand);
+    hipLaunchKernelGGL(k_run_flags, dim3(cdiv(ncand, 256)), dim3(256), 0, c->stream, tg, (const int *)c->tileFlag, 0, nk, JCH, runlen, nchunk, c->runCand);
     hipLaunchKernelGGL(k_run_compact, dim3(1), dim3(1024), 0, c->stream, (const Run *)c->runCand, (int)ncand, *runs, c->d_flags + 12);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 12, c->d_flags + 12, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -409,7 +413,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     T *x = f32 ? (T *)c->pressure : (T *)c->pX;
     const Lay R1 = fv_range(c, 1);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
-                       c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->k0, c->k1, c->dx, dt, c->prm.min_frac);
+                       c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->pMask, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1, &c->mlistP, &c->mlistCapP);  // synchronises: h_scal[0] = max|b|

@@ -14,10 +14,13 @@
 //               random right-hand side, 13 against 96 (128^3) for a smooth one.
 // Everything is matrix-free on the levels' own dense index spaces (same layout rules as the fine grid); level 0 walks the
 // solver's tile list.  Coarse levels are launch-bound (a few microseconds per kernel).
-// Slab-decomposed runs: the V-cycle is RANK-LOCAL (block-Jacobi multigrid): every rank builds the hierarchy of its own
-// planes, with the couplings across the slab faces dropped, and cycles it without any exchange; the CG around it uses
-// the true operator (halo exchange of p, two scalar all-reduces per iteration).  A block-diagonal SPD preconditioner:
+// Block-decomposed runs: the V-cycle is RANK-LOCAL (block-Jacobi multigrid): every rank builds the hierarchy of its own
+// box of cells, with the couplings across the box's cut faces dropped, and cycles it without any exchange; the CG around it
+// uses the true operator (halo exchange of p, two scalar all-reduces per iteration).  A block-diagonal SPD preconditioner:
 // same fixed point, a few more iterations than the global cycle, no halo traffic per level and sweep.
+// A level's Lay: I, J, K = the GLOBAL extent of the level (cells), olo/ohi = the box of cells of the rank on that level, and
+// the arrays of a coarse level are allocated for just that box (ox, oy, oz = olo; one spare column / row / plane at the end,
+// so that the +-1 neighbours of a box cell are zero entries of the same array, as on the fine grid).
 #include "flipv_comm.h"
 #include "pcg_common.h"
 
@@ -38,13 +41,20 @@ struct MgLevel {
 static Lay coarse_lay(const Lay &F) {
     Lay C;
     C.I = (F.I + 1) / 2; C.J = (F.J + 1) / 2; C.K = (F.K + 1) / 2;
-    C.PX = ((C.I + 1 + 3) / 4) * 4; C.PY = C.J + 1; C.PZ = C.K + 1;
+    for (int a = 0; a < 3; a++) {      // the aggregates that hold the rank's cells
+        C.olo[a] = F.olo[a] >> 1;
+        C.ohi[a] = ((F.ohi[a] - 1) >> 1) + 1;
+    }
+    C.ox = C.olo[0]; C.oy = C.olo[1]; C.oz = C.olo[2];
+    C.PX = ((C.ohi[0] - C.olo[0] + 1 + 3) / 4) * 4; C.PY = C.ohi[1] - C.olo[1] + 1; C.PZ = C.ohi[2] - C.olo[2] + 1;
     C.sy = C.PX; C.sz = (long)C.PX * C.PY;
     C.n = (size_t)C.sz * C.PZ;
     C.guard = (((size_t)C.sz + (size_t)C.sy + 8) + 63) / 64 * 64;
-    C.kb = F.kb >> 1;                 // cell planes [kb, ke) of this level that hold the rank's cells
-    C.ke = ((F.ke - 1) >> 1) + 1;
+    C.ib = C.olo[0]; C.ie = C.ohi[0]; C.jb = C.olo[1]; C.je = C.ohi[1]; C.kb = C.olo[2]; C.ke = C.ohi[2];
     return C;
+}
+__host__ __device__ __forceinline__ bool d_in_cells(const Lay &L, int i, int j, int k) {   // a cell of the rank on this level
+    return i >= L.olo[0] && i < L.ohi[0] && j >= L.olo[1] && j < L.ohi[1] && k >= L.olo[2] && k < L.ohi[2];
 }
 
 // ---- one cell of the pre-smoothing + residual: x = omega b/d from a zero guess, t = b - A x
@@ -70,7 +80,7 @@ __device__ __forceinline__ void d_mg_pre_cell(const Lay &L, size_t c, const floa
 // ---- one cell of the coarse correction + post-smoothing: y = x + over * xc[parent], out = y + omega (b - A y)/d
 __device__ __forceinline__ float d_mg_y(const Lay &L, const Lay &C, const float *__restrict__ x, const float *__restrict__ xc, int i,
                                         int j, int k) {
-    if (i < 0 || j < 0 || k < 0 || i >= L.I || j >= L.J || k >= L.K) return 0.0f;
+    if (!d_in_cells(L, i, j, k)) return 0.0f;
     return x[gidx(L, i, j, k)] + MG_OVER * xc[gidx(C, i >> 1, j >> 1, k >> 1)];
 }
 __device__ __forceinline__ float d_mg_up_cell(const Lay &L, const Lay &C, int i, int j, int k, const float *__restrict__ d,
@@ -97,23 +107,21 @@ __device__ __forceinline__ float d_mg_up_cell(const Lay &L, const Lay &C, int i,
 __global__ void k_mg_coarsen(Lay F, Lay C, const float *__restrict__ df, const float *__restrict__ pif, const float *__restrict__ pjf,
                              const float *__restrict__ pkf, float *__restrict__ dc, float *__restrict__ pic, float *__restrict__ pjc,
                              float *__restrict__ pkc) {
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y, K = blockIdx.z + C.kb;
-    if (I >= C.PX || J >= C.PY) return;
+    const int I = C.ib + blockIdx.x * 64 + threadIdx.x, J = C.jb + blockIdx.y * 4 + threadIdx.y, K = blockIdx.z + C.kb;
+    if (I >= C.ie || J >= C.je) return;
     const size_t cc = gidx(C, I, J, K);
     float ds = 0.0f, si = 0.0f, sj = 0.0f, sk = 0.0f;
-    if (I < C.I && J < C.J && K < C.ke) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int a = q & 1, b = (q >> 1) & 1, e = q >> 2;
-            const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + e;
-            if (i >= F.I || j >= F.J || k < F.kb || k >= F.ke) continue;   // only the rank's own planes
-            const size_t c = gidx(F, i, j, k);
-            ds += df[c];
-            if (a == 0) ds += 2.0f * pif[c]; else si += pif[c];   // coupling to i+1: inside the aggregate / across its face
-            if (b == 0) ds += 2.0f * pjf[c]; else sj += pjf[c];
-            if (k + 1 < F.ke) { if (e == 0) ds += 2.0f * pkf[c]; else sk += pkf[c]; }   // the coupling across the slab face is dropped
-        }
-        // an odd fine extent leaves the last aggregate one cell thick: its a == 0 coupling points outside the grid and is 0
+    for (int q = 0; q < 8; q++) {
+        const int a = q & 1, b = (q >> 1) & 1, e = q >> 2;
+        const int i = 2 * I + a, j = 2 * J + b, k = 2 * K + e;
+        if (!d_in_cells(F, i, j, k)) continue;   // only the rank's own cells
+        const size_t c = gidx(F, i, j, k);
+        ds += df[c];
+        // coupling to the +1 neighbour: inside the aggregate / across its face; dropped where the neighbour is not the rank's
+        if (i + 1 < F.ohi[0]) { if (a == 0) ds += 2.0f * pif[c]; else si += pif[c]; }
+        if (j + 1 < F.ohi[1]) { if (b == 0) ds += 2.0f * pjf[c]; else sj += pjf[c]; }
+        if (k + 1 < F.ohi[2]) { if (e == 0) ds += 2.0f * pkf[c]; else sk += pkf[c]; }
     }
     dc[cc] = ds; pic[cc] = si; pjc[cc] = sj; pkc[cc] = sk;
 }
@@ -121,26 +129,26 @@ __global__ void k_mg_coarsen(Lay F, Lay C, const float *__restrict__ df, const f
 // ---- coarse levels: dense sweeps over the level's index space
 __global__ void k_mg_pre(Lay L, const float *__restrict__ d, const float *__restrict__ pi, const float *__restrict__ pj,
                          const float *__restrict__ pk, const float *__restrict__ b, float *__restrict__ x, float *__restrict__ t) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
-    if (i >= L.I || j >= L.J || k >= L.ke) return;
+    const int i = L.ib + blockIdx.x * 64 + threadIdx.x, j = L.jb + blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    if (i >= L.ie || j >= L.je) return;
     d_mg_pre_cell(L, gidx(L, i, j, k), d, pi, pj, pk, b, x, t);
 }
 __global__ void k_mg_restrict(Lay F, Lay C, const float *__restrict__ tf, float *__restrict__ bc) {
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y, K = blockIdx.z + C.kb;
-    if (I >= C.I || J >= C.J || K >= C.ke) return;
+    const int I = C.ib + blockIdx.x * 64 + threadIdx.x, J = C.jb + blockIdx.y * 4 + threadIdx.y, K = blockIdx.z + C.kb;
+    if (I >= C.ie || J >= C.je) return;
     float s = 0.0f;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int i = 2 * I + (q & 1), j = 2 * J + ((q >> 1) & 1), k = 2 * K + (q >> 2);
-        if (i < F.I && j < F.J && k >= F.kb && k < F.ke) s += tf[gidx(F, i, j, k)];
+        if (d_in_cells(F, i, j, k)) s += tf[gidx(F, i, j, k)];
     }
     bc[gidx(C, I, J, K)] = s;
 }
 __global__ void k_mg_up(Lay L, Lay C, const float *__restrict__ d, const float *__restrict__ pi, const float *__restrict__ pj,
                         const float *__restrict__ pk, const float *__restrict__ b, const float *__restrict__ x,
                         const float *__restrict__ xc, float *__restrict__ out) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
-    if (i >= L.I || j >= L.J || k >= L.ke) return;
+    const int i = L.ib + blockIdx.x * 64 + threadIdx.x, j = L.jb + blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    if (i >= L.ie || j >= L.je) return;
     out[gidx(L, i, j, k)] = d_mg_up_cell(L, C, i, j, k, d, pi, pj, pk, b, x, xc);
 }
 // The tail of the hierarchy (every level of at most MG_TAIL_CELLS cells, i.e. 16^3 and coarser; measured: with 32^3 included the single workgroup is slower than the launches it saves) in ONE
@@ -149,8 +157,11 @@ __global__ void k_mg_up(Lay L, Lay C, const float *__restrict__ d, const float *
 constexpr int MG_MAX_TAIL = 6;
 constexpr long MG_TAIL_CELLS = 18 * 18 * 18;
 struct MgTail { int n; MgLevel lev[MG_MAX_TAIL]; };
-__device__ __forceinline__ void d_cell_of(const Lay &L, int q, int &i, int &j, int &k) { i = q % L.I; j = (q / L.I) % L.J; k = L.kb + q / (L.I * L.J); }
-__device__ __forceinline__ int d_ncells(const Lay &L) { return L.I * L.J * (L.ke - L.kb); }
+__device__ __forceinline__ void d_cell_of(const Lay &L, int q, int &i, int &j, int &k) {
+    const int w = L.ohi[0] - L.olo[0], h = L.ohi[1] - L.olo[1];
+    i = L.olo[0] + q % w; j = L.olo[1] + (q / w) % h; k = L.olo[2] + q / (w * h);
+}
+__device__ __forceinline__ int d_ncells(const Lay &L) { return (L.ohi[0] - L.olo[0]) * (L.ohi[1] - L.olo[1]) * (L.ohi[2] - L.olo[2]); }
 __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
     for (int l = 0; l + 1 < T.n; l++) {  // down
         const MgLevel &F = T.lev[l];
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int i = 2 * I + (e & 1), j = 2 * J + ((e >> 1) & 1), k = 2 * K + (e >> 2);
-                if (i < F.L.I && j < F.L.J && k >= F.L.kb && k < F.L.ke) s += F.t[gidx(F.L, i, j, k)];
+                if (d_in_cells(F.L, i, j, k)) s += F.t[gidx(F.L, i, j, k)];
             }
             C.b[gidx(C.L, I, J, K)] = s;
         }
@@ -179,12 +190,12 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
         const MgLevel &B = T.lev[T.n - 1];
         const Lay &L = B.L;
         const int n = d_ncells(L);
-        if (n <= 1024 && (L.I + 2) * (L.J + 2) * (L.ke - L.kb + 2) <= 1000) {
+        if (n <= 1024 && (L.ohi[0] - L.olo[0] + 2) * (L.ohi[1] - L.olo[1] + 2) * (L.ohi[2] - L.olo[2] + 2) <= 1000) {
             // at most one cell per thread: its row of the operator lives in registers, the iterate in LDS (with a zero rim),
             // so a sweep is an LDS exchange instead of a round trip through L2 (17 sweeps: 25 of the kernel's 33 us before)
             __shared__ float sx[2][1000];
             const int q = threadIdx.x;
-            const int W = L.I + 2, H = L.J + 2;
+            const int W = L.ohi[0] - L.olo[0] + 2, H = L.ohi[1] - L.olo[1] + 2;
             for (int e = q; e < 2000; e += blockDim.x) (&sx[0][0])[e] = 0.0f;
             float dd = 0.0f, ci = 0.0f, cim = 0.0f, cj = 0.0f, cjm = 0.0f, ck = 0.0f, ckm = 0.0f, bb = 0.0f;
             int li = 0;
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
                 int i, j, k;
                 d_cell_of(L, q, i, j, k);
                 c = gidx(L, i, j, k);
-                li = (i + 1) + W * ((j + 1) + H * (k - L.kb + 1));
+                li = (i - L.olo[0] + 1) + W * ((j - L.olo[1] + 1) + H * (k - L.olo[2] + 1));
                 dd = B.diag[c]; bb = B.b[c];
                 ci = B.pi[c]; cim = B.pi[c - 1]; cj = B.pj[c]; cjm = B.pj[c - L.sy]; ck = B.pk[c]; ckm = B.pk[c - L.sz];
             }
@@ -289,7 +300,7 @@ static int mg_alloc(flipv_context *c, MgState *s, const Lay &L, float **p) {
     return FLIPV_OK;
 }
 
-#define MGGRID(Lv) dim3(cdiv((Lv).PX, 64), cdiv((Lv).PY, 4), (unsigned)((Lv).ke - (Lv).kb)), dim3(64, 4, 1)
+#define MGGRID(Lv) dim3(cdiv((Lv).ie - (Lv).ib, 64), cdiv((Lv).je - (Lv).jb, 4), (unsigned)((Lv).ke - (Lv).kb)), dim3(64, 4, 1)
 
 }  // namespace
 
@@ -308,8 +319,8 @@ static int mg_setup(flipv_context *c, MgState **out) {
         c->mgState = s;
         MgLevel l0;
         l0.L = c->L;
-        l0.L.kb = c->k0;                                   // the rank's cell planes (all of them on a single GPU)
-        l0.L.ke = c->k1 < c->L.K ? c->k1 : c->L.K;
+        for (int a = 0; a < 3; a++) { l0.L.olo[a] = c->cell0[a]; l0.L.ohi[a] = c->cell1[a]; }   // the rank's CELLS (all of them on a single GPU)
+        l0.L.ib = l0.L.olo[0]; l0.L.ie = l0.L.ohi[0]; l0.L.jb = l0.L.olo[1]; l0.L.je = l0.L.ohi[1]; l0.L.kb = l0.L.olo[2]; l0.L.ke = l0.L.ohi[2];
         l0.diag = c->pDiag; l0.pi = c->pPi; l0.pj = c->pPj; l0.pk = c->pPk;
         l0.b = (float *)c->pR;
         int rc;
@@ -317,7 +328,8 @@ static int mg_setup(flipv_context *c, MgState **out) {
         s->lev.push_back(l0);
         while (true) {
             const Lay &F = s->lev.back().L;
-            const int m = F.I > F.J ? (F.I > F.K ? F.I : F.K) : (F.J > F.K ? F.J : F.K);
+            const int e3[3] = {F.ohi[0] - F.olo[0], F.ohi[1] - F.olo[1], F.ohi[2] - F.olo[2]};   // the rank's box decides the depth of ITS hierarchy
+            const int m = e3[0] > e3[1] ? (e3[0] > e3[2] ? e3[0] : e3[2]) : (e3[1] > e3[2] ? e3[1] : e3[2]);
             if (m <= 8 || s->lev.size() >= 8) break;
             MgLevel l;
             l.L = coarse_lay(F);
@@ -329,7 +341,8 @@ static int mg_setup(flipv_context *c, MgState **out) {
         // level 0 always runs on the tile list
         s->tailFirst = (int)s->lev.size() - 1;
         while (s->tailFirst > 1 && (int)s->lev.size() - (s->tailFirst - 1) <= MG_MAX_TAIL &&
-               (long)s->lev[s->tailFirst - 1].L.I * s->lev[s->tailFirst - 1].L.J * (s->lev[s->tailFirst - 1].L.ke - s->lev[s->tailFirst - 1].L.kb) <= MG_TAIL_CELLS)
+               (long)(s->lev[s->tailFirst - 1].L.ohi[0] - s->lev[s->tailFirst - 1].L.olo[0]) * (s->lev[s->tailFirst - 1].L.ohi[1] - s->lev[s->tailFirst - 1].L.olo[1]) *
+                       (s->lev[s->tailFirst - 1].L.ohi[2] - s->lev[s->tailFirst - 1].L.olo[2]) <= MG_TAIL_CELLS)
             s->tailFirst--;
         if (s->lev.size() == 1) s->tailFirst = 0;
     }
@@ -352,7 +365,7 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0) {  // x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
-            (void)hipMemsetAsync(C.b + (size_t)C.L.kb * C.L.sz, 0, (size_t)(C.L.ke - C.L.kb) * C.L.sz * sizeof(float), c->stream);
+            (void)hipMemsetAsync(C.b, 0, C.L.n * sizeof(float), c->stream);
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
                                F.pj, F.pk, c->pMask, F.x, F.b, C.b));
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)

@@ -122,8 +122,8 @@ struct VolLattices { float *vol[7]; int lat[7]; float cs[7][3]; };
 __global__ void k_volume_classify(Lay L, VolLattices Q, const float *__restrict__ phi, const uint8_t *__restrict__ valid,
                                   const uint8_t *__restrict__ prevband, int full, unsigned *__restrict__ list,
                                   unsigned *__restrict__ nlist) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
-    const bool inside = i < L.PX && j < L.PY;
+    IJK_OF_THREAD(L);
+    const bool inside = i < L.ie && j < L.je;
     const size_t c = inside ? gidx(L, i, j, k) : 0;
     float out = 0.0f;
     bool sample = false;
@@ -157,7 +157,7 @@ __global__ void k_volume_classify(Lay L, VolLattices Q, const float *__restrict_
         unsigned base = 0;
         if (lane == lead) base = atomicAdd(nlist, (unsigned)__popcll(m));
         base = __shfl(base, lead, 64);
-        if (sample) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)(i + L.PX * (j + L.PY * k));
+        if (sample) list[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)c;   // position inside the allocated box
     }
 }
 
@@ -171,7 +171,7 @@ __global__ void k_volume_sample(Lay L, VolLattices Q, const float *__restrict__ 
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)n * 7; t += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(t / n);  // lattice-major: a wave works on one lattice
         const unsigned id = list[t - (size_t)m * n];
-        const int i = (int)(id % (unsigned)L.PX), j = (int)((id / (unsigned)L.PX) % (unsigned)L.PY), k = (int)(id / ((unsigned)L.PX * (unsigned)L.PY));
+        const int i = L.ox + (int)(id % (unsigned)L.PX), j = L.oy + (int)((id / (unsigned)L.PX) % (unsigned)L.PY), k = L.oz + (int)(id / ((unsigned)L.PX * (unsigned)L.PY));
         int w, h, d;
         lat_dims(L, Q.lat[m], w, h, d);
         if (i >= w || j >= h || k >= d) continue;
@@ -252,10 +252,10 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                              float *__restrict__ vmW, uint8_t *__restrict__ rowmask, const uint8_t *__restrict__ band,
                              int full, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {   // v.swz: layout of diag, vm, r, x
     __shared__ double lds[4];
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    IJK_OF_THREAD(L);
     double babs = 0.0;
     int rows = 0;
-    if (i < L.PX && j < L.PY) {
+    if (i < L.ie && j < L.je) {
         const size_t c = gidx(L, i, j, k);
         const long sy = L.sy, sz = L.sz;
         float dg[3] = {0.0f, 0.0f, 0.0f}, rv[3] = {0.0f, 0.0f, 0.0f}, vm[3] = {-1.0f, -1.0f, -1.0f};
@@ -385,11 +385,18 @@ static __global__ void k_vec_to_f32(const T *__restrict__ a, float *__restrict__
     for (; t < n; t += stride) o[t] = (float)a[t];
 }
 
+// x -> velocity grid over a launch box (plain layout)
+template <typename T>
+static __global__ void k_box_to_f32(Lay L, const T *__restrict__ a, float *__restrict__ o) {
+    IJK_OR_RETURN(L);
+    o[c] = (float)a[c];
+}
+
 // x in the swizzled plane layout -> velocity grid
 template <typename T>
 static __global__ void k_unswizzle_to_f32(Lay L, const T *__restrict__ a, float *__restrict__ o) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
-    if (i < L.PX && j < L.PY) o[gidx(L, i, j, k)] = (float)a[sidx(L, i, j, k)];
+    IJK_OF_THREAD(L);
+    if (i < L.ie && j < L.je) o[gidx(L, i, j, k)] = (float)a[sidx(L, i, j, k)];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -495,7 +502,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     hipLaunchKernelGGL(k_visc_factors, GRID3(R1), 0, c->stream, R1, c->visc, c->volC, c->volEU, c->volEV, c->volEW, c->fC,
                        c->fEU, c->fEV, c->fEW, factor, c->validCells, c->bandPrev, fullVol);
     {
-        const size_t off = (size_t)R1.kb * L.sz, cnt = (size_t)(R1.ke - R1.kb) * L.sz;
+        const size_t off = plane_off(L, R1.kb), cnt = (size_t)(R1.ke - R1.kb) * L.sz;
         HIPCHK(c, hipMemcpyAsync(c->bandPrev + off, c->validCells + off, cnt, hipMemcpyDeviceToDevice, c->stream));
         c->bandPrevValid = 1;
     }
@@ -527,7 +534,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // narrow variant (2 per lane, twice the waves) no longer wins on sparse liquids (256^3 bunny: 40.7 vs 42.7 ms per
     // solve); it stays selectable for measurements.  Sparse liquids (row fill <= 0.35) use the predicated SpMV.
     HIPCHK(c, hipStreamSynchronize(c->stream));  // h_flags[2] = row count
-    const double fill = (double)c->h_flags[2] / (3.0 * (double)(c->k1 - c->k0) * (double)L.PX * (double)L.PY);
+    const double fill = (double)c->h_flags[2] / (3.0 * (double)(L.ohi[0] - L.olo[0]) * (double)(L.ohi[1] - L.olo[1]) * (double)(L.ohi[2] - L.olo[2]));
     c->vwV = 4;
     if (c->prm.viscosity_lane_width == 2 || c->prm.viscosity_lane_width == 4) c->vwV = c->prm.viscosity_lane_width;  // measurement switch: forced lane width
     c->vPred = fill <= 0.35;
@@ -602,10 +609,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool accepted = success || (iters == cap && res < c->prm.viscosity_accept_tolerance);
     li.status = success ? (iters == 0 ? 3 : 0) : (accepted ? 1 : 2);
     if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
-        const size_t off = (size_t)R0.kb * L.sz, cnt = (size_t)(R0.ke - R0.kb) * L.sz;
+        const size_t off = plane_off(L, R0.kb), cnt = (size_t)(R0.ke - R0.kb) * L.sz;
         float *uvw[3] = {c->U, c->V, c->W};
         for (int m = 0; m < 3; m++) {
             if (c->vSwz) hipLaunchKernelGGL(k_unswizzle_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);
+            else if (c->pgrid[0] > 1 || c->pgrid[1] > 1) hipLaunchKernelGGL(k_box_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);   // only what the rank owns: its i / j halo holds the neighbours' velocities
             else hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[m] + off, uvw[m] + off, cnt);
         }
         const HaloArray uv[3] = {{c->U, 4}, {c->V, 4}, {c->W, 4}};

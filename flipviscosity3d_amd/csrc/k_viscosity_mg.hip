@@ -88,7 +88,9 @@ static Lay coarse_lay(const Lay &F) {
     C.sy = C.PX; C.sz = (long)C.PX * C.PY;
     C.n = (size_t)C.sz * C.PZ;
     C.guard = (((size_t)C.sz + (size_t)C.sy + 8) + 63) / 64 * 64;
-    C.kb = 0; C.ke = C.PZ;
+    C.ox = C.oy = C.oz = 0;   // single-domain hierarchy: every level's box is the level's whole index space
+    C.ib = 0; C.ie = C.PX; C.jb = 0; C.je = C.PY; C.kb = 0; C.ke = C.PZ;
+    C.olo[0] = C.olo[1] = C.olo[2] = 0; C.ohi[0] = C.PX; C.ohi[1] = C.PY; C.ohi[2] = C.PZ;
     return C;
 }
 

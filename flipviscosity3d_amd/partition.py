@@ -24,6 +24,50 @@ def slab_ranges(K, nranks, min_planes=MIN_SLAB_PLANES):
     return out
 
 
+def axis_cuts(n, parts, align=1, min_cells=MIN_SLAB_PLANES):
+    """Cut n cells into `parts` contiguous ranges as evenly as the alignment allows (cuts along i must be multiples of 8:
+    include/flipv.h); every range must hold at least min_cells cells when there is more than one."""
+    if parts < 1:
+        raise ValueError("need at least one part")
+    cuts = [0]
+    for p in range(1, parts):
+        c = int(round(n * p / parts / align)) * align
+        cuts.append(c)
+    cuts.append(n)
+    out = [(cuts[q], cuts[q + 1]) for q in range(parts)]
+    for lo, hi in out:
+        if hi <= lo or (parts > 1 and hi - lo < min_cells):
+            raise ValueError("cannot cut %d cells into %d parts of at least %d cells (alignment %d)" % (n, parts, min_cells, align))
+    return out
+
+
+def block_boxes(I, J, K, dims, min_cells=MIN_SLAB_PLANES):
+    """The boxes (lo, hi) of a dims[0] x dims[1] x dims[2] block decomposition in rank order (x fastest,
+    rank = x + dims[0] * (y + dims[1] * z)): a tensor product of axis cuts, cuts along i multiples of 8."""
+    if dims[0] * dims[1] * dims[2] > 32:
+        raise ValueError("at most 32 ranks per communicator")
+    cx, cy, cz = axis_cuts(I, dims[0], 8, min_cells), axis_cuts(J, dims[1], 1, min_cells), axis_cuts(K, dims[2], 1, min_cells)
+    return [((x[0], y[0], z[0]), (x[1], y[1], z[1])) for z in cz for y in cy for x in cx]
+
+
+def box_owner(particles, dx, boxes, dims):
+    """rank owning each particle: the block that holds its cell (floor(p / dx) in fp64, reference grid3d.h:60-65);
+    particles outside the domain go to the end blocks of that axis."""
+    p = np.asarray(particles)[:, :3].astype(np.float64) * (1.0 / float(np.float32(dx)))
+    cell = np.floor(p).astype(np.int64)
+    co = []
+    for a in range(3):
+        stride = 1 if a == 0 else (dims[0] if a == 1 else dims[0] * dims[1])
+        starts = np.array(sorted({b[0][a] for b in boxes})[1:], np.int64)
+        co.append(np.searchsorted(starts, cell[:, a], side="right") * stride)
+    return co[0] + co[1] + co[2]
+
+
+def split_particles_boxes(particles, dx, boxes, dims):
+    owner = box_owner(particles, dx, boxes, dims)
+    return [np.ascontiguousarray(np.asarray(particles)[owner == r]) for r in range(len(boxes))]
+
+
 def particle_owner(particles, dx, ranges):
     """rank owning each particle = slab containing the k index of its cell, floor(z / dx) in fp64 like
     Grid3d::positionToGridIndex (reference grid3d.h:60-65); out-of-domain particles go to the end ranks."""

@@ -95,11 +95,13 @@ typedef struct flipv_params {
     int viscosity_lane_width;    /* 2|4: forced lane width of the viscosity solver kernels */
     int viscosity_spmv_grid_cap; /* n>0: grid cap of the viscosity SpMV kernel alone */
     int viscosity_update_grid_cap; /* n>0: grid cap of the viscosity init/update kernels */
-    int beta_from_residual;      /* 0 (default): the PCG's beta is formed as (alpha^2 (q,q/d) - sigma)/sigma, which uses the
-                                    A-conjugacy of successive search directions ((r/d,q) = (s,q)) and lets the SpMV skip the
-                                    residual; 1: (sigma - 2 alpha (r/d,q) + alpha^2 (q,q/d))/sigma with the residual read by
-                                    the SpMV (+12 B per index, +4 B per pressure cell).  sigma itself is recomputed from
-                                    the stored vectors every iteration either way. */
+    int beta_from_residual;      /* 1 (default): the PCG's beta = (sigma - 2 alpha (r/d,q) + alpha^2 (q,q/d))/sigma, with the residual
+                                    read by the SpMV for (r/d,q) (+12 B per index, +4 B per pressure cell).  0: (r/d,q) is
+                                    replaced by (s,q), which is equal in exact arithmetic (successive search directions are
+                                    A-conjugate) and lets the SpMV skip the residual: 5-7 % faster per iteration, but on
+                                    ill-conditioned systems (nu dt/dx^2 ~ 2e3: the rod + sheet scene at nu = 50) the fp32
+                                    solve stagnates, so it is an opt-in.  sigma itself is recomputed from the stored vectors
+                                    every iteration either way. */
     int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 (default) =
                                     chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
     int reserved[2];             /* must be 0 */
@@ -138,10 +140,21 @@ typedef struct flipv_kernel_stats {
 /* ---- lifetime: FluidSimulation::initialize (fluidsimulation.cpp:26-43), without the boundary mesh ---- */
 int flipv_create(int isize, int jsize, int ksize, float dx, flipv_context **out);
 int flipv_create_on_device(int isize, int jsize, int ksize, float dx, int hip_device, flipv_context **out);
-/* One rank of a slab decomposition along k (no reference counterpart: the reference is single-process).
- * The context indexes the GLOBAL I x J x K grid -- every grid passed to or read from it is full size -- but owns and
- * computes only cell planes [k_begin, k_end); particles uploaded to it must lie in those planes.  A communicator
- * must be attached (flipv_comm_init_*) before the first substep when there is more than one rank. */
+/* One rank of a block decomposition (no reference counterpart: the reference is single-process).
+ * The context owns and computes the cells [cell_lo, cell_hi) of the GLOBAL I x J x K grid and ALLOCATES only that box plus a
+ * halo of 8 entries on every side that has a neighbour: memory per rank scales with the block, not with the domain.
+ * Blocks must form a tensor-product decomposition (the cuts along each axis are the same for every rank) and cuts along i
+ * must be multiples of 8.  Particles uploaded to the context must lie in its cells.  A communicator must be attached
+ * (flipv_comm_init_*) before the first substep when there is more than one rank.
+ * Grids: flipv_read_grid / flipv_write_grid keep their full-size Array3d signature on such a context -- a read fills the
+ * entries the rank owns and leaves the rest of the caller's array untouched, a write takes the entries the rank allocates
+ * (owned + halo; the solid SDF and the viscosity have no exchange of their own, so their halo comes from the caller) -- and
+ * flipv_read_grid_box / flipv_write_grid_box move the same data box-shaped, so that no full-size array has to exist on
+ * the host either (flipv_grid_box gives the box: kind 0 = owned, what a read returns; kind 1 = allocated, what a write
+ * takes; both clipped to the lattice of that grid, x fastest).
+ * flipv_create_slab = a block that spans i and j: slabs along k. */
+int flipv_create_block(int isize, int jsize, int ksize, float dx, int hip_device, const int *cell_lo, const int *cell_hi, flipv_context **out);
+int flipv_block_range(flipv_context *ctx, int *cell_lo, int *cell_hi);
 int flipv_create_slab(int isize, int jsize, int ksize, float dx, int hip_device, int k_begin, int k_end, flipv_context **out);
 int flipv_slab_range(flipv_context *ctx, int *k_begin, int *k_end);
 int flipv_destroy(flipv_context *ctx);
@@ -168,6 +181,9 @@ size_t flipv_num_particles(flipv_context *ctx);
 size_t flipv_grid_elements(flipv_context *ctx, int which);
 int flipv_read_grid(flipv_context *ctx, int which, float *out);
 int flipv_write_grid(flipv_context *ctx, int which, const float *in);
+int flipv_grid_box(flipv_context *ctx, int which, int kind, int *lo, int *hi);   /* kind 0 owned, 1 allocated; lo/hi: 3 ints each */
+int flipv_read_grid_box(flipv_context *ctx, int which, float *out);              /* the owned box */
+int flipv_write_grid_box(flipv_context *ctx, int which, const float *in);        /* the allocated box */
 
 /* ---- per-operator entry points, one per seam of advance() (fluidsimulation.cpp:138-167) ---- */
 int flipv_cfl(flipv_context *ctx, float *dt_out);                 /* _cfl                      fluidsimulation.cpp:241-269 */
@@ -242,13 +258,18 @@ int flipv_bench_stream(flipv_context *ctx, size_t bytes, int reps, int mode, dou
  * ncclSend/ncclRecv, the PCG scalars with ncclAllReduce, all on the context's own stream.
  * Local backend: all ranks are contexts of ONE process on one device, each driven by its own host thread; it exists to
  * verify the decomposition against the single-domain result on a one-GPU machine.
- * Limits, checked by both init calls (FLIPV_ERR_INVALID): at most 32 ranks per communicator; with more than one rank every
- * slab must be at least ceil(cfl_number) + 3 cell planes thick (the widest halo; flipv_set_params re-checks it when
- * cfl_number changes). */
+ * Limits, checked by the init calls (FLIPV_ERR_INVALID): at most 32 ranks per communicator; along every axis on which a
+ * block has neighbours it must be at least ceil(cfl_number) + 3 cells thick (the widest halo; flipv_set_params re-checks it
+ * when cfl_number changes, and rejects a cfl_number whose halo exceeds the 8 entries a block context allocates). */
 int flipv_comm_unique_id_bytes(void);
 int flipv_comm_get_unique_id(void *id_out);
-int flipv_comm_init_rccl(flipv_context *ctx, const void *unique_id, int rank, int nranks);
+int flipv_comm_init_rccl(flipv_context *ctx, const void *unique_id, int rank, int nranks);   /* slabs along k: grid {1, 1, nranks} */
 int flipv_comm_init_local(flipv_context **ctxs, int nranks);
+/* process grid dims[3] (ranks along i, j, k), rank = x + dims[0] * (y + dims[1] * z); the context's block must sit at that place
+ * of the grid.  Halo copies run axis by axis (x, y, z) so that edge and corner regions are filled; halo reductions the other
+ * way round; particles migrate axis by axis to the adjacent ranks. */
+int flipv_comm_init_rccl_grid(flipv_context *ctx, const void *unique_id, int rank, const int *dims);
+int flipv_comm_init_local_grid(flipv_context **ctxs, const int *dims);
 int flipv_comm_finalize(flipv_context *ctx);
 
 #ifdef __cplusplus
