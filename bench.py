@@ -45,30 +45,63 @@ VISC_SPMV_BYTES_PER_INDEX = 52   # 3 diag + 4 factor + 3 x reads, 3 y writes, fp
 PRES_SPMV_BYTES_PER_CELL = 24    # 4 coefficient + 1 s reads, 1 z write, fp32
 
 
-def build_scene(N, viscosity, on_device=False):
-    """Scene setup (not timed): mesh level sets + seeding by the host C++ path (bit-identical to the reference's level
-    sets) or, with on_device, by the library's HIP setup kernels (same band values, signs and particles; seconds instead
-    of minutes at 512^3)."""
+def box_mesh(lo, hi):
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    v = np.array([[x0, y0, z0], [x1, y0, z0], [x1, y0, z1], [x0, y0, z1], [x0, y1, z0], [x1, y1, z0], [x1, y1, z1], [x0, y1, z1]], np.float32)
+    t = np.array([[0, 1, 2], [0, 2, 3], [4, 7, 6], [4, 6, 5], [0, 3, 7], [0, 7, 4], [1, 5, 6], [1, 6, 2], [0, 4, 5], [0, 5, 1], [3, 2, 6], [3, 6, 7]], np.int32)
+    return v, t
+
+
+WORKLOADS = {
+    # name: (grid as multiples of --size, boundary mesh (None = the default box), liquid meshes, description)
+    "bunny": ((1, 1, 1), ("sphere_large.ply", True), ["stanford_bunny.ply"],
+              "%d^3 bunny drop: stanford_bunny.ply liquid in inverted sphere_large.ply, viscosity %g, full variational viscosity + "
+              "pressure substep (BASELINE.json configs[2])"),
+    "honey": ((1, 1, 1), None, ["rod.ply", "sheet.ply"],
+              "%d^3 honey buckling: rod.ply + sheet.ply liquid (two addLiquid calls) in the default box, viscosity %g (BASELINE.json configs[3])"),
+    "sheet": ((1, 0.5, 0.5), None, [("box", (0.05, 0.30, 0.05), (0.95, 0.3323, 0.45))],
+              "%dx%dx%d thin sheet: liquid box x 0.05..0.95, y 0.30..0.3323, z 0.05..0.45 in a 1 x 0.5 x 0.5 domain, viscosity %g "
+              "(BASELINE.json configs[4]; SURVEY.md 8d-5)"),
+}
+
+
+def build_workload(name, N, on_device):
+    """Scene setup (not timed) -> (I, J, K, dx, solid SDF nodes, particles).  Host C++ path (bit-identical level sets) or, with
+    on_device, the library's HIP setup kernels on a single-domain context (seconds instead of minutes at 512^3)."""
     from flipviscosity3d_amd import hostapi as H
+    mult, boundary, liquids, _ = WORKLOADS[name]
+    I, J, K = [max(8, int(round(N * m))) for m in mult]
+    dx = float(np.float32(1.0 / N))
+
+    def mesh(m):
+        return box_mesh(m[1], m[2]) if isinstance(m, tuple) else H.load_ply(os.path.join(MESH, m))
     if on_device:
         from flipviscosity3d_amd.capi import Context
-        dx = float(np.float32(1.0 / N))
-        c = Context(N, N, N, dx)
+        c = Context(I, J, K, dx)
         c.reset_boundary()
-        c.add_boundary_mesh(H.load_ply(os.path.join(MESH, "sphere_large.ply")), inverted=True)
-        c.add_liquid_mesh(H.load_ply(os.path.join(MESH, "stanford_bunny.ply")), seed=0)
+        if boundary:
+            c.add_boundary_mesh(H.load_ply(os.path.join(MESH, boundary[0])), inverted=boundary[1])
+        for m in liquids:
+            c.add_liquid_mesh(mesh(m), seed=0)
         solid, particles = c.grid("SOLID_PHI"), c.particles
         c.close()
-        return dx, solid, particles
-    dx = float(np.float32(1.0 / N))
+        return I, J, K, dx, solid, particles
     sim = H.FluidSimulation()
-    sim.initialize(N, N, N, dx)
-    sim.addBoundary(H.load_ply(os.path.join(MESH, "sphere_large.ply")), True)
+    sim.initialize(I, J, K, dx)
+    if boundary:
+        sim.addBoundary(H.load_ply(os.path.join(MESH, boundary[0])), boundary[1])
     sim.setSeeding(H.FluidSimulation.SEED_COUNTER, 0)
-    sim.addLiquid(H.load_ply(os.path.join(MESH, "stanford_bunny.ply")))
-    solid = sim.solid_sdf()
-    particles = sim.particles
+    for m in liquids:
+        sim.addLiquid(mesh(m))
+    solid, particles = sim.solid_sdf(), sim.particles
     sim.close()
+    return I, J, K, dx, solid, particles
+
+
+def build_scene(N, viscosity, on_device=False):
+    """the headline scene (workload "bunny") -> (dx, solid, particles); kept for the tools that import it"""
+    I, J, K, dx, solid, particles = build_workload("bunny", N, on_device)
     return dx, solid, particles
 
 
@@ -151,6 +184,13 @@ def main():
                     help="iteration cap of the viscosity PCG: 700 = the reference's (equal-work timing, SURVEY 8d mode A); "
                          "a large value runs the solve to its 1e-6 tolerance (equal-accuracy, mode B)")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bunny",
+                    help="bunny = BASELINE configs[2] (the metric's scene); honey = configs[3] (rod + sheet, use --viscosity 50); "
+                         "sheet = configs[4] (--size is the long axis: 1024 -> 1024x512x512)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong = ONE scene of --size split over the ranks (slabs along k for 2 and 4 ranks, 2x2x2 blocks for 8; "
+                         "slabs along i for the sheet); weak = N copies of the scene stacked along k, one slab per rank")
+    ap.add_argument("--dims", type=str, default="", help="process grid 'px,py,pz' of the strong-scaling decomposition (default: see --scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,20 +214,44 @@ def main():
     from flipviscosity3d_amd.capi import Context
 
     N = args.size
-    dx, solid, particles = build_scene(N, args.viscosity, on_device=args.gpu_setup)
+    GI, GJ, GK, dx, solid, particles = build_workload(args.workload, N, on_device=args.gpu_setup)
+    decomposition = "single GPU"
     if world == 1:
-        c = Context(N, N, N, dx, device=local_rank, slab=(0, N) if args.force_comm else None)
+        c = Context(GI, GJ, GK, dx, device=local_rank, slab=(0, GK) if args.force_comm else None)
         if args.force_comm:
             c.comm_init_rccl(capi.comm_unique_id(), 0, 1)
+            decomposition += ", one-rank RCCL communicator attached"
         c.set_solid_sdf(solid)
+    elif args.scaling == "strong":
+        # strong scaling: ONE scene, decomposed into blocks; every rank builds the (deterministic) scene and keeps its box
+        if args.dims:
+            dims = tuple(int(v) for v in args.dims.split(","))
+        elif args.workload == "sheet":
+            dims = (world, 1, 1)                                   # slabs along the long axis
+        else:
+            dims = {2: (1, 1, 2), 4: (1, 1, 4), 8: (2, 2, 2)}.get(world, (1, 1, world))
+        assert dims[0] * dims[1] * dims[2] == world, "process grid does not match the number of ranks"
+        boxes = partition.block_boxes(GI, GJ, GK, dims)
+        c = Context(GI, GJ, GK, dx, device=local_rank, block=boxes[rank])
+        uid = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        c.comm_init_rccl(uid[0], rank, world, dims)
+        c.set_solid_sdf(solid)                                     # the library takes the entries of its box (owned + halo)
+        particles = partition.split_particles_boxes(particles, dx, boxes, dims)[rank]
+        decomposition = "%dx%dx%d blocks of one %dx%dx%d scene (rank-local allocation), RCCL 6-face halo exchange + PCG scalar all-reduce + " \
+                        "particle migration" % (dims[0], dims[1], dims[2], GI, GJ, GK)
     else:
         # weak scaling: `world` copies of the closed 256^3 scene stacked along k form ONE domain of N x N x (N*world)
         # cells, decomposed into one slab per rank.  The copies do not interact physically, but they are solved as one
         # system: every PCG iteration exchanges the halo planes of the search direction and all-reduces its scalars,
         # every extrapolation layer / P2G / SDF exchanges halos, particles migrate between slabs.
+        assert args.workload == "bunny", "the stacked weak-scaling scene is the closed bunny container"
         solid_g, parts = partition.stack_scene(solid, particles, world, N, dx)
         ranges = partition.slab_ranges(N * world, world)
+        GK = N * world
         c = Context(N, N, N * world, dx, device=local_rank, slab=ranges[rank])
+        decomposition = "%d slabs along k of a %dx%dx%d domain (%d stacked copies of the scene), RCCL halo exchange + PCG scalar " \
+                        "all-reduce + particle migration" % (world, N, N, N * world, world)
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         c.comm_init_rccl(uid[0], rank, world)
@@ -245,7 +309,7 @@ def main():
         return {"mean": float(np.mean(v)), "min": int(min(v)), "max": int(max(v)), "per_step": v if len(v) <= 32 else None}
 
     ms_per_step = elapsed * 1e3 / args.steps
-    cells_total = float(N) ** 3 * world  # N x N x (N*world) cells, one N^3 slab per rank
+    cells_total = float(GI) * GJ * GK   # the whole domain (weak mode: the stacked one)
     value = cells_total / 1e6 / (elapsed / args.steps)
 
     # ---- roofline of the dominant kernel.  Units processed per launch: unknowns of the system in cells' worth
@@ -256,7 +320,7 @@ def main():
     roof = None
     if v_n > 0 and v_ms >= p_ms:
         avg_ms = v_ms / v_n
-        units = last["viscosity"]["rows"] / 3.0
+        units = last["viscosity"]["rows"] / 3.0   # this rank's rows (rank 0)
         gbs = VISC_SPMV_BYTES_PER_INDEX * units / (avg_ms * 1e-3) / 1e9
         roof = {"kernel": "k_visc_spmv<float>" if args.precision == 0 else "k_visc_spmv<double>", "bound": "hbm",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
@@ -283,17 +347,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "MCells/s per substep (P2G+PCG+viscosity), %d^3 grid" % N,
+            "metric": "MCells/s per substep (P2G+PCG+viscosity), %s grid" % ("%d^3" % N if GI == GJ == GK or args.scaling == "weak" else "%dx%dx%d" % (GI, GJ, GK)),
             "value": value, "unit": "MCells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == 0 else "f64", "data": "synthetic",
             "config": {
-                "workload": "%d^3 bunny drop: stanford_bunny.ply liquid in inverted sphere_large.ply, viscosity %g, "
-                            "full variational viscosity + pressure substep (BASELINE.json configs[2])" % (N, args.viscosity),
-                "grid": [N, N, N * world], "particles_per_rank": int(len(particles)), "dt": 0.01,
-                "viscosity_cap": args.viscosity_cap, "parallelism": ("single GPU" + (", one-rank RCCL communicator attached" if args.force_comm else "")) if world == 1 else
-                "%d slabs along k of a %dx%dx%d domain (%d stacked copies of the scene), RCCL halo exchange + PCG scalar "
-                "all-reduce + particle migration" % (world, N, N, N * world, world),
+                "workload": WORKLOADS[args.workload][3] % ((N, args.viscosity) if args.workload != "sheet" else (GI, GJ, GK, args.viscosity)),
+                "grid": [GI, GJ, GK], "particles_rank0": int(len(particles)), "dt": 0.01,
+                "viscosity_cap": args.viscosity_cap, "parallelism": decomposition,
             },
             "device": dev_name,
             "phase_ms": {k: float(np.mean([st["phase_ms"][k] for st in stats])) for k in last["phase_ms"]},
@@ -307,8 +368,8 @@ def main():
         if world == 1 and not args.no_dense:
             c.close()
             c = None
-            out["roofline_dense"] = dense_roofline(N, args.precision)
-        if world == 1 and not args.no_cpu_baseline:
+            out["roofline_dense"] = dense_roofline(min(N, 256), args.precision)
+        if world == 1 and not args.no_cpu_baseline and args.workload == "bunny":
             out["cpu_baseline"] = cpu_baseline(args.viscosity, args.cpu_size)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())

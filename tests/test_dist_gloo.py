@@ -94,3 +94,123 @@ def test_gather_owned():
     a = np.zeros((K + 1, 2, 2)); b = np.ones((K + 1, 2, 2))
     g = partition.gather_owned([a, b], ranges, K)
     assert g[:3].sum() == 0 and (g[3:] == 1).all()          # the last rank also owns the closing plane
+
+
+def test_block_boxes_and_ownership():
+    """tensor-product block decomposition (BASELINE configs[3]: 2 x 2 x 2; configs[4]: 8 slabs along i)"""
+    b = partition.block_boxes(512, 512, 512, (2, 2, 2))
+    assert len(b) == 8 and b[0] == ((0, 0, 0), (256, 256, 256)) and b[7] == ((256, 256, 256), (512, 512, 512))
+    assert b[1] == ((256, 0, 0), (512, 256, 256))                      # x is the fastest rank coordinate
+    s = partition.block_boxes(1024, 512, 512, (8, 1, 1))
+    assert [x[0][0] for x in s] == [128 * r for r in range(8)] and all(x[1][1:] == (512, 512) for x in s)
+    # cuts along i are multiples of 8 whatever the size
+    for I in (70, 100, 250):
+        for lo, hi in partition.axis_cuts(I, 3, 8, 8):
+            assert lo % 8 == 0 and (hi % 8 == 0 or hi == I)
+    with pytest.raises(ValueError):
+        partition.block_boxes(24, 24, 24, (4, 1, 1))                    # 6-cell blocks: thinner than the widest halo
+    with pytest.raises(ValueError):
+        partition.block_boxes(512, 512, 512, (4, 4, 4))                 # 64 ranks: more than a communicator takes
+    # every particle has exactly one owner, and it is the block that holds its cell
+    dx = 1.0 / 32
+    rng = np.random.default_rng(3)
+    p = rng.uniform(-0.05, 1.05, (20000, 6)).astype(np.float32)        # some outside the domain: they go to the end blocks
+    dims = (2, 2, 2)
+    boxes = partition.block_boxes(32, 32, 32, dims)
+    own = partition.box_owner(p, dx, boxes, dims)
+    cell = np.floor(p[:, :3].astype(np.float64) / float(np.float32(dx))).astype(int)
+    for r, (lo, hi) in enumerate(boxes):
+        m = own == r
+        for a in range(3):
+            inside_lo = (cell[m, a] >= lo[a]) | (lo[a] == 0)
+            inside_hi = (cell[m, a] < hi[a]) | (hi[a] == 32)
+            assert inside_lo.all() and inside_hi.all()
+    parts = partition.split_particles_boxes(p, dx, boxes, dims)
+    assert sum(len(x) for x in parts) == len(p)
+
+
+def _block_worker(rank, world, port, q):
+    """each process owns one block context of a 2-block decomposition and drives it through the library's RCCL backend --
+    only where a GPU is visible; on a CPU-only host the workers check the host-side plumbing and report 'no device'"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flipviscosity3d_amd import capi
+        N, dx = 32, 1.0 / 32
+        dims = (1, 1, world)
+        boxes = partition.block_boxes(N, N, N, dims)
+        ndev = torch.cuda.device_count()                  # (counting devices does not initialise the GPU)
+        have_gpu = ndev >= world                          # RCCL refuses two ranks on one device
+        out = {"rank": rank, "box": boxes[rank], "gpu": have_gpu, "ndev": ndev}
+        if ndev == 1:
+            # one device for two processes: no communicator, but each process can still own its block on that device --
+            # rank-local allocation, box I/O and the communication-free operators
+            c = capi.Context(N, N, N, dx, device=0, block=boxes[rank])
+            assert c.block_range() == boxes[rank]
+            rng = np.random.default_rng(0)
+            p = np.zeros((4000, 6), np.float32)
+            p[:, :3] = rng.uniform(0.3, 0.7, (4000, 3))
+            c.particles = partition.split_particles_boxes(p, dx, boxes, dims)[rank]
+            c.particle_sdf()
+            phi = c.read_box("LIQUID_PHI")
+            lo, hi = c.grid_box("LIQUID_PHI", 0)
+            out.update(shape=phi.shape, want=(hi[2] - lo[2], hi[1] - lo[1], hi[0] - lo[0]), liquid=int((phi < 0).sum()))
+            c.close()
+        elif have_gpu:
+            c = capi.Context(N, N, N, dx, device=rank, block=boxes[rank])
+            uid = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            c.comm_init_rccl(uid[0], rank, world, dims)
+            rng = np.random.default_rng(0)
+            p = np.zeros((4000, 6), np.float32)
+            p[:, :3] = rng.uniform(0.3, 0.7, (4000, 3))
+            p[:, 5] = 0.5 if rank == 0 else -0.5
+            mine = partition.split_particles_boxes(p, dx, boxes, dims)[rank]
+            c.set_viscosity(0.5)
+            c.particles = mine
+            for _ in range(2):
+                st = c.substep(0.01)
+            n = torch.tensor([c.num_particles], dtype=torch.int64)
+            dist.all_reduce(n)
+            own = partition.box_owner(c.particles, dx, boxes, dims)
+            out.update(total=int(n.item()), owned_ok=bool((own == rank).all()), visc=st["viscosity"]["iterations"], pres=st["pressure"]["iterations"])
+            c.comm_finalize()
+            c.close()
+        else:
+            try:
+                capi.Context(N, N, N, dx, device=0, block=boxes[rank])
+                out["error"] = "a context was created without a device"
+            except (capi.FlipvError, OSError) as e:      # no CPU path: the library refuses loudly
+                out["refused"] = str(e)
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_each_own_a_block():
+    """world_size 2: two PROCESSES, one block context each.  With a GPU (the -m gpu box) the blocks exchange halos, all-reduce
+    the PCG scalars and migrate particles through the library's RCCL backend -- two ranks on one device; without one the
+    library must refuse to create a context (it has no CPU path) and only the host-side decomposition is checked."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_block_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0]["box"] == ((0, 0, 0), (32, 32, 16)) and res[1]["box"] == ((0, 0, 16), (32, 32, 32))
+    if res[0]["gpu"]:
+        for r in res:
+            assert r["total"] == 4000 and r["owned_ok"]
+        assert res[0]["visc"] == res[1]["visc"] and res[0]["pres"] == res[1]["pres"]   # every rank takes the same solver decisions
+    elif res[0]["ndev"] == 1:
+        for r in res:
+            assert r["shape"] == r["want"] == (16, 32, 32) and r["liquid"] > 0
+    else:
+        for r in res:
+            assert "refused" in r and "error" not in r

@@ -194,3 +194,86 @@ def test_config3_scene_128_default_cap_against_oracle_default_cap(oracle):
     print("128^3 default caps: velocity error %.3e, GPU viscosity %s, oracle viscosity %s" % (err, st["viscosity"], vi))
     assert st["viscosity"]["status"] in (0, 1) and vi["status"] in (0, 1)
     assert err <= 1e-3
+
+
+def sheet_scene(N):
+    """BASELINE configs[4] at long-axis size N: domain N x N/2 x N/2 cells (1 x 0.5 x 0.5), default box boundary, liquid box
+    x 0.05..0.95, y 0.30..0.3323, z 0.05..0.45, seeded by the host library (counter mode)"""
+    from bench import box_mesh
+    from flipviscosity3d_amd import hostapi as H
+    I, J, K = N, N // 2, N // 2
+    dx = float(np.float32(1.0 / N))
+    s = H.FluidSimulation()
+    s.initialize(I, J, K, dx)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 0)
+    s.addLiquid(box_mesh((0.05, 0.30, 0.05), (0.95, 0.3323, 0.45)))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    return I, J, K, dx, solid, P
+
+
+def test_config5_miniature_thin_sheet_against_oracle(oracle):
+    """BASELINE configs[4] in miniature (256 x 128 x 128 instead of 1024 x 512 x 512: a non-cubic domain, dx = 1/256), free
+    surface only (viscosity off), two chained substeps with default parameters on both sides against the live oracle"""
+    from flipviscosity3d_amd.capi import Context
+    I, J, K, dx, solid, P = sheet_scene(256)
+    assert (I, J, K) == (256, 128, 128) and len(P) > 1_000_000
+    c = Context(I, J, K, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(0.0)
+    o = oracle.OracleSim(I, J, K, dx)
+    o.set_solid(solid)
+    o.set_viscosity(0.0)
+    c.particles = P
+    o.particles = P
+    for t in range(2):
+        st = c.substep(0.01)
+        sec, vi, pi = o.substep(0.01)
+        assert st["viscosity"]["status"] == 3 and st["pressure"]["status"] in (0, 3)
+        assert vel_err(c, [o.grid(n) for n in "UVW"]) <= VEL_TOL, t
+        assert np.array_equal(c.grid("LIQUID_PHI"), o.grid("LIQUID_PHI")) or t > 0
+    assert np.abs(c.particles[:, :3] - o.particles[:, :3]).max() <= 1e-5
+    c.close()
+    o.close()
+
+
+def test_config5_miniature_eight_slabs_along_the_long_axis():
+    """the decomposition of BASELINE configs[4]: 8 slabs along i (the long axis, the FASTEST memory axis: every rank keeps its own
+    box-local arrays) with particle migration, here 8 in-process ranks on one GPU against the single-domain run; viscosity 5,
+    the particles drift along i so that they cross the cuts"""
+    import threading
+    from flipviscosity3d_amd import capi, partition
+    I, J, K, dx, solid, P = sheet_scene(256)
+    P[:, 3] = 1.2                                        # 3 cells per substep along i
+    dims = (8, 1, 1)
+    boxes = partition.block_boxes(I, J, K, dims)
+    assert [b[0][0] for b in boxes] == [32 * r for r in range(8)]
+    params = dict(viscosity_max_iterations=4000)
+    ref = capi.Context(I, J, K, dx)
+    ref.set_solid_sdf(solid); ref.set_viscosity(5.0); ref.set_params(**params); ref.particles = P
+    ctxs = [capi.Context(I, J, K, dx, device=0, block=b) for b in boxes]
+    capi.comm_init_local(ctxs, dims)
+    for c, p in zip(ctxs, partition.split_particles_boxes(P, dx, boxes, dims)):
+        c.set_solid_sdf(solid); c.set_viscosity(5.0); c.set_params(**params); c.particles = p
+    before = [c.num_particles for c in ctxs]
+    for t in range(2):
+        ref.substep(0.005)
+        th = [threading.Thread(target=lambda c=c: c.substep(0.005)) for c in ctxs]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        got = []
+        for n in "UVW":
+            out = None
+            for c in ctxs:
+                out = c.grid(n, out)
+            got.append(out)
+        assert rel_maxnorm3(got, [ref.grid(n) for n in "UVW"]) <= 5e-5, t
+    after = [c.num_particles for c in ctxs]
+    assert sum(after) == len(P) and after != before      # particles crossed the cuts
+    allp = np.concatenate([c.particles for c in ctxs])
+    assert np.array_equal(partition.box_owner(allp, dx, boxes, dims), np.repeat(np.arange(8), after))
+    for c in ctxs:
+        c.close()
+    ref.close()
