@@ -66,7 +66,7 @@ WORKLOADS = {
 }
 
 
-def build_workload(name, N, on_device):
+def build_workload(name, N, on_device, device=None):
     """Scene setup (not timed) -> (I, J, K, dx, solid SDF nodes, particles).  Host C++ path (bit-identical level sets) or, with
     on_device, the library's HIP setup kernels on a single-domain context (seconds instead of minutes at 512^3)."""
     from flipviscosity3d_amd import hostapi as H
@@ -78,7 +78,7 @@ def build_workload(name, N, on_device):
         return box_mesh(m[1], m[2]) if isinstance(m, tuple) else H.load_ply(os.path.join(MESH, m))
     if on_device:
         from flipviscosity3d_amd.capi import Context
-        c = Context(I, J, K, dx)
+        c = Context(I, J, K, dx, device=device, setup_only=True)    # 3 grids + the setup kernels' temporaries, not a full context
         c.reset_boundary()
         if boundary:
             c.add_boundary_mesh(H.load_ply(os.path.join(MESH, boundary[0])), inverted=boundary[1])
@@ -214,7 +214,7 @@ def main():
     from flipviscosity3d_amd.capi import Context
 
     N = args.size
-    GI, GJ, GK, dx, solid, particles = build_workload(args.workload, N, on_device=args.gpu_setup)
+    GI, GJ, GK, dx, solid, particles = build_workload(args.workload, N, on_device=args.gpu_setup, device=local_rank)
     decomposition = "single GPU"
     if world == 1:
         c = Context(GI, GJ, GK, dx, device=local_rank, slab=(0, GK) if args.force_comm else None)

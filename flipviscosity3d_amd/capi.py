@@ -20,7 +20,7 @@ VOLUME_IDS = dict(center=0, U=1, V=2, W=3, edgeU=4, edgeV=5, edgeW=6)
 
 # every symbol include/flipv.h declares (tests/test_abi.py checks the header against this and the .so)
 SYMBOLS = [
-    "flipv_create", "flipv_create_on_device", "flipv_create_slab", "flipv_slab_range", "flipv_create_block", "flipv_block_range",
+    "flipv_create", "flipv_create_on_device", "flipv_create_slab", "flipv_slab_range", "flipv_create_block", "flipv_block_range", "flipv_create_setup",
     "flipv_destroy", "flipv_last_error", "flipv_device_name",
     "flipv_default_params", "flipv_set_params", "flipv_get_params", "flipv_set_gravity",
     "flipv_set_solid_sdf", "flipv_set_viscosity_uniform", "flipv_set_viscosity",
@@ -105,6 +105,7 @@ def load():
     i3 = C.POINTER(C.c_int)
     L.flipv_create_block.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, i3, i3, C.POINTER(ctx)]
     L.flipv_block_range.argtypes = [ctx, i3, i3]
+    L.flipv_create_setup.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(ctx)]
     L.flipv_grid_box.argtypes = [ctx, C.c_int, C.c_int, i3, i3]
     L.flipv_read_grid_box.argtypes = [ctx, C.c_int, fp]
     L.flipv_write_grid_box.argtypes = [ctx, C.c_int, fp]
@@ -183,16 +184,19 @@ def _F(a):
 class Context:
     """Owns one flipv_context (device state of one simulation / one rank)."""
 
-    def __init__(self, I, J, K, dx, device=None, slab=None, block=None):
+    def __init__(self, I, J, K, dx, device=None, slab=None, block=None, setup_only=False):
         """slab = (k_begin, k_end): one rank of a slab decomposition along k (global grid I x J x K);
-        block = ((i0, j0, k0), (i1, j1, k1)): one rank of a block decomposition, cells [lo, hi)."""
+        block = ((i0, j0, k0), (i1, j1, k1)): one rank of a block decomposition, cells [lo, hi);
+        setup_only: a light single-domain context for the scene-setup entry points (flipv_create_setup)."""
         self.L = load()
         self.I, self.J, self.K = int(I), int(J), int(K)
         self.dx = float(np.float32(dx))
         self.slab = slab
         self.block = block
         h = C.c_void_p()
-        if block is not None:
+        if setup_only:
+            rc = self.L.flipv_create_setup(self.I, self.J, self.K, C.c_float(dx), int(device or 0), C.byref(h))
+        elif block is not None:
             lo = (C.c_int * 3)(*[int(v) for v in block[0]])
             hi = (C.c_int * 3)(*[int(v) for v in block[1]])
             rc = self.L.flipv_create_block(self.I, self.J, self.K, C.c_float(dx), int(device or 0), lo, hi, C.byref(h))

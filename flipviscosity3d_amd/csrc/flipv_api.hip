@@ -70,7 +70,17 @@ extern "C" int flipv_create_slab(int I, int J, int K, float dx, int dev, int kbe
     return flipv_create_block(I, J, K, dx, dev, lo, hi, out);
 }
 
+static int create_context(int I, int J, int K, float dx, int dev, const int *cell_lo, const int *cell_hi, int setupOnly, flipv_context **out);
+
 extern "C" int flipv_create_block(int I, int J, int K, float dx, int dev, const int *cell_lo, const int *cell_hi, flipv_context **out) {
+    return create_context(I, J, K, dx, dev, cell_lo, cell_hi, 0, out);
+}
+extern "C" int flipv_create_setup(int I, int J, int K, float dx, int dev, flipv_context **out) {
+    const int lo[3] = {0, 0, 0}, hi[3] = {I, J, K};
+    return create_context(I, J, K, dx, dev, lo, hi, 1, out);
+}
+
+static int create_context(int I, int J, int K, float dx, int dev, const int *cell_lo, const int *cell_hi, int setupOnly, flipv_context **out) {
     if (!out) return FLIPV_ERR_INVALID;
     *out = nullptr;
     if (I < 1 || J < 1 || K < 1 || !(dx > 0.0f)) {
@@ -180,19 +190,23 @@ extern "C" int flipv_create_block(int I, int J, int K, float dx, int dev, const 
     CHK(hipEventCreateWithFlags(&c->evPoll[1], hipEventDisableTiming));
     c->xs = c->stream;
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) CHK(hipEventCreate(&c->phaseEv[q]));
+    c->setupOnly = setupOnly;
+    GALLOC(c->phi); GALLOC(c->solid); GALLOC(c->visc);
+    if (!setupOnly) {
     GALLOC(c->U); GALLOC(c->V); GALLOC(c->W);
     GALLOC(c->sU); GALLOC(c->sV); GALLOC(c->sW);
     GALLOC(c->wU); GALLOC(c->wV); GALLOC(c->wW);
     GALLOC(c->vU); GALLOC(c->vV); GALLOC(c->vW);
-    GALLOC(c->phi); GALLOC(c->pressure); GALLOC(c->solid); GALLOC(c->visc);
+    GALLOC(c->pressure);
     GALLOC(c->accU); GALLOC(c->accV); GALLOC(c->accW);
     GALLOC(c->wgtU); GALLOC(c->wgtV); GALLOC(c->wgtW);
     GALLOC(c->stampU); GALLOC(c->stampV); GALLOC(c->stampW);
+    }
     {
         int rc_ = plain_alloc(c, &c->d_flags, 16);
         if (!rc_) rc_ = plain_alloc(c, &c->d_scal_small, 64);
-        if (!rc_) rc_ = plain_alloc(c, &c->actFlags, (size_t)3 * ((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8));
-        if (!rc_) rc_ = plain_alloc(c, &c->actList, (size_t)((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8) + 16);
+        if (!rc_ && !setupOnly) rc_ = plain_alloc(c, &c->actFlags, (size_t)3 * ((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8));
+        if (!rc_ && !setupOnly) rc_ = plain_alloc(c, &c->actList, (size_t)((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8) + 16);
         if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
     }
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
@@ -208,7 +222,7 @@ extern "C" int flipv_create_block(int I, int J, int K, float dx, int dev, const 
     }
     c->tgP = make_tile_grid(L, c->forceRowl ? c->forceRowl : 64, VW_P);
     c->tgV = make_tile_grid(L, c->forceRowl ? c->forceRowl : 64, VW_V);
-    {
+    if (!setupOnly) {
         size_t ntmax = 0;   // the largest tile grid of any geometry and lane width; the virtual enumeration pads nty to a multiple of 4
         for (int rl = 16; rl <= 64; rl *= 4)
             for (int vw = 2; vw <= 4; vw *= 2) {
@@ -221,6 +235,7 @@ extern "C" int flipv_create_block(int I, int J, int K, float dx, int dev, const 
         if (!rc_) rc_ = plain_alloc(c, &c->tileFlag, ntmax);
         if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
     }
+    if (!setupOnly) {
     // pressure system
     GALLOC(c->pDiag); GALLOC(c->pPi); GALLOC(c->pPj); GALLOC(c->pPk);
     VALLOC(c->pX); VALLOC(c->pR); VALLOC(c->pZ); VALLOC(c->pS);
@@ -237,6 +252,7 @@ extern "C" int flipv_create_block(int I, int J, int K, float dx, int dev, const 
     GALLOC(c->pMask);
     GALLOC(c->validCells); GALLOC(c->validTmp);
     for (int q = 0; q < 3; q++) { VALLOC(c->vX[q]); VALLOC(c->vR[q]); VALLOC(c->vZ[q]); VALLOC(c->vS[q]); }
+    }
     // staging buffer for layout conversion: one allocated box worth of floats
     {
         const size_t cap = L.n;
@@ -462,6 +478,7 @@ static int write_lattice(flipv_context *c, int lat, const float *in, float *dstf
     return write_lattice_box(c, lat, tmp.data(), dstf, dstb);
 }
 
+#define NOT_SETUP_ONLY(c) do { if ((c)->setupOnly) { (c)->err = "this context was created by flipv_create_setup: it only serves the scene-setup entry points"; return FLIPV_ERR_INVALID; } } while (0)
 #define ENTER(c) do { if (!(c)) return FLIPV_ERR_INVALID; hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) { (c)->err = hipGetErrorString(e_); return FLIPV_ERR_HIP; } } while (0)
 #define SYNC_RET(c, rc) do { int rc__ = (rc); hipError_t e_ = hipStreamSynchronize((c)->stream); if (e_ != hipSuccess) { (c)->err = std::string("stream sync: ") + hipGetErrorString(e_); return FLIPV_ERR_HIP; } return rc__; } while (0)
 
@@ -665,10 +682,10 @@ extern "C" int flipv_download_particles(flipv_context *c, float *aos6, size_t ca
 extern "C" size_t flipv_num_particles(flipv_context *c) { return c ? c->np : 0; }
 
 // ------------------------------------------------------------------------------------------------ operators
-extern "C" int flipv_cfl(flipv_context *c, float *dt_out) { ENTER(c); if (!dt_out) return FLIPV_ERR_INVALID; return fv_cfl(c, dt_out); }
-extern "C" int flipv_particle_sdf(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_particle_sdf(c)); }
-extern "C" int flipv_p2g(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_p2g(c)); }
-extern "C" int flipv_extrapolate(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_extrapolate(c)); }
+extern "C" int flipv_cfl(flipv_context *c, float *dt_out) { ENTER(c); NOT_SETUP_ONLY(c); if (!dt_out) return FLIPV_ERR_INVALID; return fv_cfl(c, dt_out); }
+extern "C" int flipv_particle_sdf(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_particle_sdf(c)); }
+extern "C" int flipv_p2g(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_p2g(c)); }
+extern "C" int flipv_extrapolate(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_extrapolate(c)); }
 
 static int save_velocity(flipv_context *c) {
     const Lay R = fv_range(c, 1);
@@ -678,7 +695,7 @@ static int save_velocity(flipv_context *c) {
     HIPCHK(c, hipMemcpyAsync(c->sW + off, c->W + off, bytes, hipMemcpyDeviceToDevice, c->stream));
     return FLIPV_OK;
 }
-extern "C" int flipv_save_velocity(flipv_context *c) { ENTER(c); SYNC_RET(c, save_velocity(c)); }
+extern "C" int flipv_save_velocity(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, save_velocity(c)); }
 
 static int advect_velocity_field(flipv_context *c) {  // fluidsimulation.cpp:500-519
     int rc = fv_p2g(c);
@@ -687,18 +704,19 @@ static int advect_velocity_field(flipv_context *c) {  // fluidsimulation.cpp:500
     if (rc) return rc;
     return save_velocity(c);
 }
-extern "C" int flipv_advect_velocity_field(flipv_context *c) { ENTER(c); SYNC_RET(c, advect_velocity_field(c)); }
-extern "C" int flipv_body_force(flipv_context *c, float dt) { ENTER(c); SYNC_RET(c, fv_body_force(c, dt)); }
-extern "C" int flipv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) { ENTER(c); SYNC_RET(c, fv_viscosity_solve(c, dt, info)); }
-extern "C" int flipv_compute_weights(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_compute_weights(c)); }
-extern "C" int flipv_pressure_solve(flipv_context *c, float dt, flipv_solve_info *info) { ENTER(c); SYNC_RET(c, fv_pressure_solve(c, dt, info)); }
-extern "C" int flipv_apply_pressure(flipv_context *c, float dt) { ENTER(c); SYNC_RET(c, fv_apply_pressure(c, dt)); }
-extern "C" int flipv_constrain(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_constrain(c)); }
-extern "C" int flipv_update_particle_velocities(flipv_context *c) { ENTER(c); SYNC_RET(c, fv_update_particle_velocities(c)); }
-extern "C" int flipv_advect_particles(flipv_context *c, float dt) { ENTER(c); SYNC_RET(c, fv_advect_particles(c, dt)); }
+extern "C" int flipv_advect_velocity_field(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, advect_velocity_field(c)); }
+extern "C" int flipv_body_force(flipv_context *c, float dt) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_body_force(c, dt)); }
+extern "C" int flipv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_viscosity_solve(c, dt, info)); }
+extern "C" int flipv_compute_weights(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_compute_weights(c)); }
+extern "C" int flipv_pressure_solve(flipv_context *c, float dt, flipv_solve_info *info) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_pressure_solve(c, dt, info)); }
+extern "C" int flipv_apply_pressure(flipv_context *c, float dt) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_apply_pressure(c, dt)); }
+extern "C" int flipv_constrain(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_constrain(c)); }
+extern "C" int flipv_update_particle_velocities(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_update_particle_velocities(c)); }
+extern "C" int flipv_advect_particles(flipv_context *c, float dt) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_advect_particles(c, dt)); }
 
 extern "C" int flipv_read_viscosity_volume(flipv_context *c, int which, float *out) {
     ENTER(c);
+    NOT_SETUP_ONLY(c);
     if (!out || which < 0 || which > 6) return FLIPV_ERR_INVALID;
     const float *src[7] = {c->volC, c->volU, c->volV, c->volW, c->volEU, c->volEV, c->volEW};
     const int lat[7] = {LAT_CELL, LAT_U, LAT_V, LAT_W, LAT_EU, LAT_EV, LAT_EW};
@@ -759,12 +777,14 @@ static int substep(flipv_context *c, float dt, flipv_stats *st) {
 
 extern "C" int flipv_substep(flipv_context *c, float dt, flipv_stats *st) {
     ENTER(c);
+    NOT_SETUP_ONLY(c);
     if (!(dt > 0.0f)) { c->err = "flipv_substep: dt must be > 0"; return FLIPV_ERR_INVALID; }
     return substep(c, dt, st);
 }
 
 extern "C" int flipv_advance(flipv_context *c, float dt, flipv_stats *st) {
     ENTER(c);
+    NOT_SETUP_ONLY(c);
     if (!(dt > 0.0f)) { c->err = "flipv_advance: dt must be > 0"; return FLIPV_ERR_INVALID; }
     // fluidsimulation.cpp:135-168
     float t = 0;
@@ -846,6 +866,7 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
 int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cells);
 extern "C" int flipv_bench_spmv(flipv_context *c, int which, int reps, double *ms_out, double *cells_out) {
     ENTER(c);
+    NOT_SETUP_ONLY(c);
     if (!ms_out || !cells_out || reps < 1) return FLIPV_ERR_INVALID;
     return which == 0 ? fv_bench_pressure_spmv(c, reps, ms_out, cells_out) : fv_bench_viscosity_spmv(c, reps, ms_out, cells_out);
 }

@@ -17,35 +17,11 @@ __global__ void k_halo_combine(float *__restrict__ dst, const float *__restrict_
     }
 }
 
-// A box of the index space <-> a contiguous staging buffer, for up to HALO_MAXARR arrays at once (array a's part of the staging
-// buffer starts at byte offset a * boxcount * 8, whatever its element size: keeps every part 8-byte aligned).
-// mode 0: pack (array -> staging), 1: unpack (staging -> array), 2: combine min, 3: combine add (fp32 arrays only).
+// Boxes of the index space <-> a contiguous staging buffer, for up to HALO_MAXARR arrays at once (array a's part of a box's
+// staging starts at byte offset a * boxcount * 8, whatever its element size: keeps every part 8-byte aligned): k_halo_dirs.
 constexpr int HALO_MAXARR = 6;
 struct HaloSet { void *p[HALO_MAXARR]; int elem[HALO_MAXARR]; int n; };
 struct HBox { int lo[3], hi[3]; };
-__global__ void k_halo_box(HaloSet hs, Lay L, HBox b, char *__restrict__ staging, int mode) {
-    const int w = b.hi[0] - b.lo[0], h = b.hi[1] - b.lo[1], d = b.hi[2] - b.lo[2];
-    const size_t cnt = (size_t)w * h * d;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += stride) {
-        const int i = b.lo[0] + (int)(t % (size_t)w), j = b.lo[1] + (int)((t / (size_t)w) % (size_t)h), k = b.lo[2] + (int)(t / ((size_t)w * h));
-        const size_t c = gidx(L, i, j, k);
-        for (int a = 0; a < hs.n; a++) {
-            char *st = staging + (size_t)a * cnt * 8;
-            if (hs.elem[a] == 4) {
-                float *g = (float *)hs.p[a] + c, *q = (float *)st + t;
-                if (mode == 0) *q = *g; else if (mode == 1) *g = *q; else if (mode == 2) *g = fminf(*g, *q); else *g += *q;
-            } else if (hs.elem[a] == 8) {
-                double *g = (double *)hs.p[a] + c, *q = (double *)st + t;
-                if (mode == 0) *q = *g; else *g = *q;
-            } else {
-                uint8_t *g = (uint8_t *)hs.p[a] + c, *q = (uint8_t *)st + t;
-                if (mode == 0) *q = *g; else *g = *q;
-            }
-        }
-    }
-}
-
 // particle -> destination along one axis by the index of its cell on that axis: 0 stay, 1 previous rank, 2 next rank.
 // Output slots come from ONE global atomic per block and destination (nearly every particle stays: one atomic per
 // particle on the same address serialised 4.7 M operations into 58 ms).  Order inside a destination follows the order in which the blocks arrive: it is
@@ -124,75 +100,144 @@ static int xbuf_reserve(flipv_context *c, size_t bytes) {
     return FLIPV_OK;
 }
 
-// the box a phase of an exchange moves along `axis`: [lo, hi) on that axis as given; on the other axes the owned range, widened
-// by W (clipped to the allocated box) where the halo has to travel along:
-//   copy (runs x, y, z): the axes already exchanged -- their freshly received halos are forwarded, which fills edges and corners;
-//   reduction (runs z, y, x): the axes still to come -- what was scattered into an edge or corner region rides along until the
-//   phase of its last axis delivers it to the owner.
-static HBox phase_box(const flipv_context *c, int axis, int lo, int hi, int W, bool copyOrder) {
-    const Lay &L = c->L;
-    const int o[3] = {L.ox, L.oy, L.oz}, P[3] = {L.PX, L.PY, L.PZ};
-    HBox b;
-    for (int a = 0; a < 3; a++) {
-        if (a == axis) { b.lo[a] = lo; b.hi[a] = hi; continue; }
-        const bool wide = a < axis;   // copy: already exchanged; reduction (z first): still to come
-        (void)copyOrder;
-        b.lo[a] = L.olo[a]; b.hi[a] = L.ohi[a];
-        if (wide && c->pgrid[a] > 1) {
-            b.lo[a] = L.olo[a] - W < o[a] ? o[a] : L.olo[a] - W;
-            b.hi[a] = L.ohi[a] + W > o[a] + P[a] ? o[a] + P[a] : L.ohi[a] + W;
-        }
-    }
-    return b;
-}
 static size_t hbox_count(const HBox &b) { return (size_t)(b.hi[0] - b.lo[0]) * (size_t)(b.hi[1] - b.lo[1]) * (size_t)(b.hi[2] - b.lo[2]); }
 
+// ---- direct exchange with the (up to 26) neighbouring blocks: ONE pack kernel, ONE group of sends / receives, ONE unpack
+// kernel per exchange, whatever the decomposition -- faces, edges and corners each go straight to the rank that needs them.
+// (An axis-by-axis exchange forwards edges and corners in two or three hops and costs three groups and up to twelve small
+// kernels; the PCG exchanges its search direction every iteration, so the count of dependent steps is what matters.)
+constexpr int HALO_MAXDIR = 26;
+struct DirSet {
+    int n;
+    int peer[HALO_MAXDIR];
+    HBox sbox[HALO_MAXDIR], rbox[HALO_MAXDIR];
+    unsigned long long soff[HALO_MAXDIR], roff[HALO_MAXDIR];   // byte offsets of the direction's part of the send / receive staging
+    unsigned long long scnt[HALO_MAXDIR], rcnt[HALO_MAXDIR];   // entries of the boxes
+};
+// blockIdx.y = direction; recv = 0: sbox -> staging + soff (pack); recv = 1: staging + roff -> rbox with `mode` (1 copy, 2 min, 3 add)
+__global__ void k_halo_dirs(HaloSet hs, Lay L, DirSet D, char *__restrict__ staging, int recv, int mode) {
+    const int q = blockIdx.y;
+    const HBox b = recv ? D.rbox[q] : D.sbox[q];
+    const int w = b.hi[0] - b.lo[0], h = b.hi[1] - b.lo[1], d = b.hi[2] - b.lo[2];
+    const size_t cnt = (size_t)w * h * d;
+    char *base = staging + (recv ? D.roff[q] : D.soff[q]);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += stride) {
+        const int i = b.lo[0] + (int)(t % (size_t)w), j = b.lo[1] + (int)((t / (size_t)w) % (size_t)h), k = b.lo[2] + (int)(t / ((size_t)w * h));
+        const size_t c = gidx(L, i, j, k);
+        for (int a = 0; a < hs.n; a++) {
+            char *st = base + (size_t)a * cnt * 8;
+            if (hs.elem[a] == 4) {
+                float *g = (float *)hs.p[a] + c, *p = (float *)st + t;
+                // a reduction's receive boxes overlap where faces meet (an edge cell takes contributions from up to three, a corner
+                // cell from up to seven neighbours, each handled by another blockIdx.y): combine atomically
+                if (!recv) *p = *g;
+                else if (mode == 1) *g = *p;
+                else if (mode == 2) { const float v = *p; if (v >= 0.0f) atomicMin((int *)g, __float_as_int(v)); else atomicMax((unsigned *)g, __float_as_uint(v)); }
+                else atomicAdd(g, *p);
+            } else if (hs.elem[a] == 8) {
+                double *g = (double *)hs.p[a] + c, *p = (double *)st + t;
+                if (!recv) *p = *g; else *g = *p;
+            } else {
+                uint8_t *g = (uint8_t *)hs.p[a] + c, *p = (uint8_t *)st + t;
+                if (!recv) *p = *g; else *g = *p;
+            }
+        }
+    }
+}
+
+// The directions of an exchange.  Along an axis with offset -1 / +1 the send range is s0 / s1 and the receive range r0 / r1 (given
+// per axis as [lo, hi) pairs by the caller: a copy sends owned entries and receives halo entries, a reduction the other way
+// round); with offset 0 both are the owned range.
+struct AxisRanges { int sLo[2], sHi[2], rLo[2], rHi[2]; };   // [lo, hi) towards the lower / upper neighbour
+static void build_dirs(const flipv_context *c, const AxisRanges R[3], int narr, DirSet *D, size_t *sendBytes, size_t *recvBytes) {
+    const Lay &L = c->L;
+    D->n = 0;
+    size_t so = 0, ro = 0;
+    for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int dd[3] = {dx, dy, dz};
+                if (!dx && !dy && !dz) continue;
+                int co[3];
+                bool ok = true;
+                for (int a = 0; a < 3; a++) {
+                    co[a] = c->pcoord[a] + dd[a];
+                    if (co[a] < 0 || co[a] >= c->pgrid[a]) ok = false;
+                }
+                if (!ok) continue;
+                const int q = D->n++;
+                D->peer[q] = co[0] + c->pgrid[0] * (co[1] + c->pgrid[1] * co[2]);
+                for (int a = 0; a < 3; a++) {
+                    if (dd[a] < 0) { D->sbox[q].lo[a] = R[a].sLo[0]; D->sbox[q].hi[a] = R[a].sLo[1]; D->rbox[q].lo[a] = R[a].rLo[0]; D->rbox[q].hi[a] = R[a].rLo[1]; }
+                    else if (dd[a] > 0) { D->sbox[q].lo[a] = R[a].sHi[0]; D->sbox[q].hi[a] = R[a].sHi[1]; D->rbox[q].lo[a] = R[a].rHi[0]; D->rbox[q].hi[a] = R[a].rHi[1]; }
+                    else { D->sbox[q].lo[a] = D->rbox[q].lo[a] = L.olo[a]; D->sbox[q].hi[a] = D->rbox[q].hi[a] = L.ohi[a]; }
+                }
+                D->scnt[q] = hbox_count(D->sbox[q]); D->rcnt[q] = hbox_count(D->rbox[q]);
+                D->soff[q] = so; D->roff[q] = ro;
+                so += D->scnt[q] * 8 * (size_t)narr;
+                ro += D->rcnt[q] * 8 * (size_t)narr;
+            }
+    *sendBytes = so; *recvBytes = ro;
+    for (int q = 0; q < D->n; q++) D->roff[q] += so;   // the receive staging follows the send staging
+}
+static int exchange_dirs(flipv_context *c, const HaloSet &hs, DirSet &D, size_t sendBytes, size_t recvBytes, int mode) {
+    Comm *cm = c->comm;
+    int rc;
+    if (D.n == 0) return FLIPV_OK;
+    if ((rc = xbuf_reserve(c, (sendBytes + recvBytes + 3) / 4))) return rc;   // (xbuf_reserve sizes four parts)
+    size_t maxs = 1, maxr = 1;
+    for (int q = 0; q < D.n; q++) { if (D.scnt[q] > maxs) maxs = D.scnt[q]; if (D.rcnt[q] > maxr) maxr = D.rcnt[q]; }
+    unsigned gs = grid1d(maxs), gr = grid1d(maxr);
+    if (gs > 512) gs = 512;
+    if (gr > 512) gr = 512;
+    hipLaunchKernelGGL(k_halo_dirs, dim3(gs, D.n), dim3(256), 0, c->xs, hs, c->L, D, c->xbuf, 0, 0);
+    if ((rc = cm->begin(c))) return rc;
+    for (int q = 0; q < D.n; q++)
+        if ((rc = cm->sendrecv(c, D.peer[q], c->xbuf + D.soff[q], D.scnt[q] * 8 * (size_t)hs.n, c->xbuf + D.roff[q], D.rcnt[q] * 8 * (size_t)hs.n))) return rc;
+    if ((rc = cm->end(c))) return rc;
+    hipLaunchKernelGGL(k_halo_dirs, dim3(gr, D.n), dim3(256), 0, c->xs, hs, c->L, D, c->xbuf, 1, mode);
+    HIPCHK(c, hipGetLastError());
+    return FLIPV_OK;
+}
+
 // ================================================================================================ halo helpers
-// owner -> neighbour copies of the H boundary entries of every array, axis by axis (x, then y including the x halos just
-// received, then z including both): after the three phases the edge and corner regions are filled as well, which the
-// coupled viscosity stencil (cross terms like V(i-1, j+1)) and the trilinear particle samples need.
+// owner -> neighbour copies of the H boundary entries of every array, edges and corners included (the coupled viscosity
+// stencil has cross terms like V(i-1, j+1); particles sample the fields trilinearly).
 int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
     Comm *cm = c->comm;
     if (!cm || H <= 0) return FLIPV_OK;
     if (n > HALO_MAXARR) { c->err = "fv_halo_copy: too many arrays"; return FLIPV_ERR_INVALID; }
     const Lay &L = c->L;
+    int rc;
+    if (c->pgrid[0] == 1 && c->pgrid[1] == 1) {
+        // slabs along k: whole contiguous planes travel straight from / into the arrays
+        if (c->pgrid[2] <= 1) return FLIPV_OK;
+        const int lower = nbr_rank(c, 2, -1), upper = nbr_rank(c, 2, +1);
+        const int own0 = L.olo[2], own1 = L.ohi[2];
+        const size_t plane = (size_t)L.sz;
+        if ((rc = cm->begin(c))) return rc;
+        for (int a = 0; a < n; a++) {
+            char *base = (char *)arr[a].p;
+            const size_t pb = plane * arr[a].elem;
+            if (lower >= 0 && (rc = cm->sendrecv(c, lower, base + plane_off(L, own0) * arr[a].elem, (size_t)H * pb, base + plane_off(L, own0 - H) * arr[a].elem, (size_t)H * pb))) return rc;
+            if (upper >= 0 && (rc = cm->sendrecv(c, upper, base + plane_off(L, own1 - H) * arr[a].elem, (size_t)H * pb, base + plane_off(L, own1) * arr[a].elem, (size_t)H * pb))) return rc;
+        }
+        return cm->end(c);
+    }
     HaloSet hs;
     hs.n = n;
     for (int a = 0; a < n; a++) { hs.p[a] = arr[a].p; hs.elem[a] = (int)arr[a].elem; }
-    int rc;
-    for (int axis = 0; axis < 3; axis++) {
-        if (c->pgrid[axis] <= 1) continue;
-        const int lower = nbr_rank(c, axis, -1), upper = nbr_rank(c, axis, +1);
-        const int own0 = L.olo[axis], own1 = L.ohi[axis];
-        if (axis == 2 && c->pgrid[0] == 1 && c->pgrid[1] == 1) {
-            // slabs along k: whole contiguous planes travel straight from / into the arrays
-            const size_t plane = (size_t)L.sz;
-            if ((rc = cm->begin(c))) return rc;
-            for (int a = 0; a < n; a++) {
-                char *base = (char *)arr[a].p;
-                const size_t pb = plane * arr[a].elem;
-                if (lower >= 0 && (rc = cm->sendrecv(c, lower, base + plane_off(L, own0) * arr[a].elem, (size_t)H * pb, base + plane_off(L, own0 - H) * arr[a].elem, (size_t)H * pb))) return rc;
-                if (upper >= 0 && (rc = cm->sendrecv(c, upper, base + plane_off(L, own1 - H) * arr[a].elem, (size_t)H * pb, base + plane_off(L, own1) * arr[a].elem, (size_t)H * pb))) return rc;
-            }
-            if ((rc = cm->end(c))) return rc;
-            continue;
-        }
-        const HBox sLo = phase_box(c, axis, own0, own0 + H, H, true), rLo = phase_box(c, axis, own0 - H, own0, H, true);
-        const HBox sHi = phase_box(c, axis, own1 - H, own1, H, true), rHi = phase_box(c, axis, own1, own1 + H, H, true);
-        const size_t cnt = hbox_count(sLo), bytes = cnt * 8 * (size_t)n;
-        if ((rc = xbuf_reserve(c, bytes))) return rc;
-        char *sendLo = c->xbuf, *sendHi = sendLo + bytes, *recvLo = sendHi + bytes, *recvHi = recvLo + bytes;
-        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, sLo, sendLo, 0);
-        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, sHi, sendHi, 0);
-        if ((rc = cm->begin(c))) return rc;
-        if (lower >= 0 && (rc = cm->sendrecv(c, lower, sendLo, bytes, recvLo, bytes))) return rc;
-        if (upper >= 0 && (rc = cm->sendrecv(c, upper, sendHi, bytes, recvHi, bytes))) return rc;
-        if ((rc = cm->end(c))) return rc;
-        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, rLo, recvLo, 1);
-        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cnt)), dim3(256), 0, c->xs, hs, L, rHi, recvHi, 1);
+    AxisRanges R[3];
+    for (int a = 0; a < 3; a++) {
+        const int o0 = L.olo[a], o1 = L.ohi[a];
+        R[a].sLo[0] = o0; R[a].sLo[1] = o0 + H; R[a].rLo[0] = o0 - H; R[a].rLo[1] = o0;
+        R[a].sHi[0] = o1 - H; R[a].sHi[1] = o1; R[a].rHi[0] = o1; R[a].rHi[1] = o1 + H;
     }
-    HIPCHK(c, hipGetLastError());
-    return FLIPV_OK;
+    DirSet D;
+    size_t sb, rb;
+    build_dirs(c, R, n, &D, &sb, &rb);
+    return exchange_dirs(c, hs, D, sb, rb, 1);
 }
 
 // The same exchange on the communication stream: it starts once everything enqueued on c->stream so far has finished and
@@ -216,8 +261,8 @@ int fv_halo_wait(flipv_context *c) {
 }
 
 // neighbour -> owner: contributions a rank scattered into entries it does not own (Hlo below its box, Hhi above) are combined
-// (min or +) into the owner's entries.  Axis by axis in the order z, y, x, each phase including the halo regions of the axes
-// still to come, so that what was scattered into an edge or corner region reaches its owner in two or three hops.
+// (min or +) into the owner's entries.  Every region outside the owned box -- face, edge or corner -- belongs to exactly one
+// neighbour and goes straight to it.
 int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op) {
     Comm *cm = c->comm;
     if (!cm) return FLIPV_OK;
@@ -226,33 +271,17 @@ int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi,
     HaloSet hs;
     hs.n = n;
     for (int a = 0; a < n; a++) { hs.p[a] = arr[a]; hs.elem[a] = 4; }
-    const int W = Hlo > Hhi ? Hlo : Hhi;
-    int rc;
-    for (int axis = 2; axis >= 0; axis--) {
-        if (c->pgrid[axis] <= 1) continue;
-        const int lower = nbr_rank(c, axis, -1), upper = nbr_rank(c, axis, +1);
-        const int own0 = L.olo[axis], own1 = L.ohi[axis];
-        // to the lower neighbour: what I scattered into [own0-Hlo, own0); from it: what it scattered into my [own0, own0+Hhi)
-        const HBox sLo = phase_box(c, axis, own0 - Hlo, own0, W, false), rLo = phase_box(c, axis, own0, own0 + Hhi, W, false);
-        const HBox sHi = phase_box(c, axis, own1, own1 + Hhi, W, false), rHi = phase_box(c, axis, own1 - Hlo, own1, W, false);
-        const size_t cLo = hbox_count(sLo), cHi = hbox_count(sHi);   // (the lower side's send is Hlo thick and its receive Hhi, and vice versa)
-        const size_t cMax = cLo > cHi ? cLo : cHi;
-        const size_t bytes = cMax * 8 * (size_t)n;
-        if ((rc = xbuf_reserve(c, bytes))) return rc;
-        char *sendLo = c->xbuf, *sendHi = sendLo + bytes, *recvLo = sendHi + bytes, *recvHi = recvLo + bytes;
-        const size_t bLo = cLo * 8 * (size_t)n, bHi = cHi * 8 * (size_t)n;
-        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cLo)), dim3(256), 0, c->xs, hs, L, sLo, sendLo, 0);
-        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cHi)), dim3(256), 0, c->xs, hs, L, sHi, sendHi, 0);
-        if ((rc = cm->begin(c))) return rc;
-        if (lower >= 0 && (rc = cm->sendrecv(c, lower, sendLo, bLo, recvLo, bHi))) return rc;   // I receive Hhi-thick data packed like the neighbour's sHi
-        if (upper >= 0 && (rc = cm->sendrecv(c, upper, sendHi, bHi, recvHi, bLo))) return rc;
-        if ((rc = cm->end(c))) return rc;
-        const int mode = op == HALO_MIN_F32 ? 2 : 3;
-        if (lower >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cHi)), dim3(256), 0, c->xs, hs, L, rLo, recvLo, mode);
-        if (upper >= 0) hipLaunchKernelGGL(k_halo_box, dim3(grid1d(cLo)), dim3(256), 0, c->xs, hs, L, rHi, recvHi, mode);
+    AxisRanges R[3];
+    for (int a = 0; a < 3; a++) {
+        const int o0 = L.olo[a], o1 = L.ohi[a];
+        // to the lower neighbour: what I scattered into [o0-Hlo, o0); from it: what it scattered into my [o0, o0+Hhi)
+        R[a].sLo[0] = o0 - Hlo; R[a].sLo[1] = o0; R[a].rLo[0] = o0; R[a].rLo[1] = o0 + Hhi;
+        R[a].sHi[0] = o1; R[a].sHi[1] = o1 + Hhi; R[a].rHi[0] = o1 - Hlo; R[a].rHi[1] = o1;
     }
-    HIPCHK(c, hipGetLastError());
-    return FLIPV_OK;
+    DirSet D;
+    size_t sb, rb;
+    build_dirs(c, R, n, &D, &sb, &rb);
+    return exchange_dirs(c, hs, D, sb, rb, op == HALO_MIN_F32 ? 2 : 3);
 }
 
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n) {

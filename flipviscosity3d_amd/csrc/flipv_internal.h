@@ -108,6 +108,8 @@ struct flipv_context {
     // old names where only the k-range matters.
     int cell0[3], cell1[3];
     int k0, k1;
+    int setupOnly;   // created by flipv_create_setup: only the arrays the scene-setup entry points touch exist (solid SDF, viscosity, liquid phi,
+                     // particles, staging); every substep entry point refuses it
     int isBlock;     // created by flipv_create_block with a box smaller than the domain: scene setup entry points refuse it
     int pgrid[3], pcoord[3];   // process grid and this rank's place in it (set by flipv_comm_init_*; {1,1,1} / {0,0,0} without)
     Comm *comm;      // nullptr on a single GPU

@@ -357,7 +357,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
 }
 
 // z = M^-1 r into level 0's t, (r, z) accumulated into sig(it_next)
-static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_next) {
+static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_next) {   // it_next = IT_DEVICE: device-side counter + 1
     const int nl = (int)s->lev.size();
     const int nb = pcg_grid(c, c->nActiveP);
     const int t0 = s->tailFirst;  // levels [t0, nl) run inside k_mg_tail
@@ -406,6 +406,42 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
     // an iteration after the stop is a full V-cycle (plus, multi-rank, three exchanges): poll often
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 4;
     int conv = -1, it = 0;
+    // One GPU: `every` iterations (16 kernels each: most of them a few microseconds of work on a coarse level) + the read-back
+    // of the stop flag are captured once into a hipGraph and replayed -- the loop was bound by launch overhead.
+    const bool graph = !c->comm && !c->prm.kernel_timing && !c->prm.no_graph_replay;
+    if (graph) {
+        HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int e = 0; e < every; e++) {
+            spmv(c, sc, -1);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, IT_DEVICE));
+            mg_vcycle(c, s, sc, IT_DEVICE);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, IT_DEVICE));
+        }
+        hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+        if (e1 != hipSuccess || e2 != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); c->err = "multigrid PCG: stream capture failed"; return FLIPV_ERR_HIP; }
+        hipError_t e3 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (e3 != hipSuccess) { (void)hipGraphDestroy(g); c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3); return FLIPV_ERR_HIP; }
+        for (; it < cap && conv < 0; it += every) {
+            hipError_t el = hipGraphLaunch(ge, c->stream);
+            hipError_t es = hipStreamSynchronize(c->stream);
+            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+            conv = c->h_flags[0];
+        }
+        (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(g);
+        if (conv < 0) {   // cap reached: the stop test of the last iteration ran inside k_mgp_p already; nothing left to check
+            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            conv = c->h_flags[0];
+        }
+        HIPCHK(c, hipGetLastError());
+        *conv_out = conv;
+        return FLIPV_OK;
+    }
     while (it < cap && conv < 0) {
         const int stop = it + every < cap ? it + every : cap;
         for (; it < stop; it++) {

@@ -210,6 +210,10 @@ __device__ __forceinline__ TileBatch d_fetch_tiles(int base, int nvb, const int 
 __device__ __forceinline__ int d_pick(const int v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 __device__ __forceinline__ unsigned d_pick(const unsigned v[TBATCH], int t) { return t == 0 ? v[0] : (t == 1 ? v[1] : (t == 2 ? v[2] : v[3])); }
 
+// iteration argument of the multigrid-PCG vector kernels meaning "read the device-side counter" (hipGraph replay); the
+// SpMV / update kernels use -1 for the same purpose, where -1 already means "before the first iteration" to the former
+constexpr int IT_DEVICE = -2;
+
 // k-marching work unit of the SpMV kernels (pcg_geo.inc): `len` tiles of one column, consecutive in k, starting at `tile`
 constexpr int RUNLEN_MAX = 64;
 struct Run { int tile, len; };

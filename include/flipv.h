@@ -157,6 +157,13 @@ int flipv_create_block(int isize, int jsize, int ksize, float dx, int hip_device
 int flipv_block_range(flipv_context *ctx, int *cell_lo, int *cell_hi);
 int flipv_create_slab(int isize, int jsize, int ksize, float dx, int hip_device, int k_begin, int k_end, flipv_context **out);
 int flipv_slab_range(flipv_context *ctx, int *k_begin, int *k_end);
+/* A single-domain context that serves ONLY the scene-setup entry points below (flipv_reset_boundary, flipv_add_boundary_mesh,
+ * flipv_add_liquid_mesh, flipv_mesh_level_set) and the grid / particle transfers: 3 grids instead of ~70, i.e. ~4 % of the
+ * memory of a full context.  This is how a rank of a block decomposition builds its scene on its own device: set the whole
+ * scene up here (deterministic: every rank gets the same solid SDF and particles), hand the solid SDF to the block context
+ * (flipv_write_grid takes the entries of its box) together with the particles that lie in its cells, destroy this one.
+ * Every substep entry point returns FLIPV_ERR_INVALID on such a context. */
+int flipv_create_setup(int isize, int jsize, int ksize, float dx, int hip_device, flipv_context **out);
 int flipv_destroy(flipv_context *ctx);
 const char *flipv_last_error(flipv_context *ctx); /* ctx may be NULL for create-time errors */
 int flipv_device_name(flipv_context *ctx, char *buf, size_t len);

@@ -132,9 +132,10 @@ def test_block_boxes_and_ownership():
 def _block_worker(rank, world, port, q):
     """each process owns one block context of a 2-block decomposition and drives it through the library's RCCL backend --
     only where a GPU is visible; on a CPU-only host the workers check the host-side plumbing and report 'no device'"""
+    import datetime
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
     try:
         from flipviscosity3d_amd import capi
         N, dx = 32, 1.0 / 32
@@ -189,20 +190,29 @@ def _block_worker(rank, world, port, q):
 
 
 def test_two_processes_each_own_a_block():
-    """world_size 2: two PROCESSES, one block context each.  With a GPU (the -m gpu box) the blocks exchange halos, all-reduce
-    the PCG scalars and migrate particles through the library's RCCL backend -- two ranks on one device; without one the
-    library must refuse to create a context (it has no CPU path) and only the host-side decomposition is checked."""
+    """world_size 2: two PROCESSES, one block context each.  With two GPUs the blocks exchange halos, all-reduce the PCG scalars
+    and migrate particles through the library's RCCL backend; with one, each process owns its block on the shared device (RCCL
+    refuses two ranks on one device); without any the library must refuse to create a context (it has no CPU path) and only
+    the host-side decomposition is checked.  NOT part of the -m gpu suite: the workers are started with the `spawn` method
+    (fork + exec), which must not happen from a process that has already initialised the GPU -- run this file on its own
+    (python -m pytest tests/test_dist_gloo.py) on a GPU machine."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_block_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_block_worker, args=(r, world, port, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda d: d["rank"])
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = sorted((q.get(timeout=150) for _ in range(world)), key=lambda d: d["rank"])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:      # never leave a worker behind (a stuck rendezvous would otherwise outlive the test run)
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
     assert res[0]["box"] == ((0, 0, 0), (32, 32, 16)) and res[1]["box"] == ((0, 0, 16), (32, 32, 32))
     if res[0]["gpu"]:
         for r in res:

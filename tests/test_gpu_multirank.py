@@ -208,10 +208,3 @@ def test_block_context_allocates_its_box_only():
     with pytest.raises(capi.FlipvError):
         c.set_params(cfl_number=9.0)                            # would need a halo of 12 entries
     c.close()
-
-
-def test_two_processes_each_own_a_block_on_the_gpu_box():
-    """tests/test_dist_gloo.py's two-process test on a machine with a GPU: with two devices the two block contexts talk through
-    the library's RCCL backend; with one (this pool's test box) each process owns its block on the shared device"""
-    from test_dist_gloo import test_two_processes_each_own_a_block
-    test_two_processes_each_own_a_block()

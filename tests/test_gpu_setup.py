@@ -222,6 +222,34 @@ def test_resumed_run_takes_the_same_cfl_substeps(tmp_path):
     assert np.abs(pa[:, :3] - pr[:, :3]).max() <= 1e-3
 
 
+def test_setup_only_context_builds_the_same_scene():
+    """flipv_create_setup: the light context a rank of a block decomposition builds its scene with -- same solid SDF and
+    particles as a full context, none of the substep state, every substep entry point refused"""
+    from flipviscosity3d_amd import capi, hostapi as H
+    N = 40
+    dx = float(np.float32(1.0 / N))
+    sphere, bunny = H.load_ply(os.path.join(MESH, "sphere_large.ply")), H.load_ply(os.path.join(MESH, "stanford_bunny.ply"))
+    out = []
+    for setup_only in (False, True):
+        c = capi.Context(N, N, N, dx, setup_only=setup_only)
+        c.reset_boundary()
+        c.add_boundary_mesh(sphere, inverted=True)
+        n = c.add_liquid_mesh(bunny, seed=7)
+        out.append((c.grid("SOLID_PHI"), c.particles, n))
+        if setup_only:
+            with pytest.raises(capi.FlipvError):
+                c.substep(0.01)
+            with pytest.raises(capi.FlipvError):
+                c.particle_sdf()
+        c.close()
+    assert out[0][2] == out[1][2] > 1000
+    sa, sb = out[0][0], out[1][0]
+    near = np.abs(sa) <= 2.5 * dx                   # exact band + signs: bit-identical; the far field is a relaxation's fixed point
+    assert np.array_equal(sa[near], sb[near]) and np.array_equal(np.signbit(sa), np.signbit(sb))
+    assert np.abs(sa - sb).max() <= 0.02 * np.abs(sa).max()
+    assert np.array_equal(out[0][1], out[1][1])
+
+
 def test_setup_rejects_bad_input():
     from flipviscosity3d_amd import capi
     c = capi.Context(16, 16, 16, 1.0 / 16)
