@@ -182,10 +182,12 @@ __global__ __launch_bounds__(1024) void k_run_compact(const Run *__restrict__ ca
 
 
 // ordered compaction of the flagged tiles by one block (tile counts are 1e4..1e5)
-// mode 0: every flagged tile; 1: only tiles of the interior planes (k0 < k < k0+nk-1); 2: only tiles of the two boundary
-// planes, appended after *prev entries (multi-rank: the SpMV of the interior tiles overlaps the halo exchange)
+// mode 0: every flagged tile; 1: only INTERIOR tiles -- tiles none of whose indices sits next to a cut face of the rank's box
+// (cut[2 a] / cut[2 a + 1]: the lower / upper face of axis a has a neighbouring rank) --; 2: only the tiles at cut faces, appended
+// after *prev entries (multi-rank: the SpMV of the interior tiles overlaps the halo exchange)
+struct CutMask { int cut[6]; };
 __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ flag, int ntiles, int *__restrict__ list,
-                                                       int *__restrict__ count, TileGrid tg, int k0, int nk, int mode,
+                                                       int *__restrict__ count, TileGrid tg, int k0, int nk, int mode, CutMask cm,
                                                        const int *__restrict__ prev, int tw, int th, int wdom, int hdom,
                                                        int *__restrict__ lanesIn) {
     // lanesIn: indices of the listed tiles that lie inside the lattices' extent (wdom x hdom), in units of 4 -- the
@@ -201,8 +203,10 @@ __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ f
         const int t = start + threadIdx.x;
         int f = (t < ntiles) ? (flag[t] != 0) : 0;
         if (f && mode) {
-            const int kk = (t / (tg.ntx * JCH)) % nk;  // plane of virtual tile t (d_virtual_tile)
-            const bool boundary = kk == 0 || kk == nk - 1;
+            const int tile = d_virtual_tile(t, tg, k0, nk);
+            const int tx = tile % tg.ntx, ty = (tile / tg.ntx) % tg.nty, kk = tile / (tg.ntx * tg.nty);
+            const bool boundary = (cm.cut[0] && tx == 0) || (cm.cut[1] && tx == tg.ntx - 1) || (cm.cut[2] && ty == 0) || (cm.cut[3] && ty == tg.nty - 1) ||
+                                  (cm.cut[4] && kk == 0) || (cm.cut[5] && kk == nk - 1);
             f = (mode == 2) == boundary;
         }
         const unsigned long long m = __ballot(f);
@@ -264,23 +268,24 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
     const int nk = tg.ntz, nchunks = (tg.nty + JCH - 1) / JCH;
     const int nt = tg.ntx * JCH * nk * nchunks;  // virtual tiles of the owned planes (column-major enumeration)
     GEO_RUN(tg.rowl, hipLaunchKernelGGL(k_tile_flags, dim3(nt), dim3(64, 4, 1), 0, c->stream, tg, c->L, vw, nc, d0, d1, d2, mask, c->tileFlag, 0, nk));
-    // The interior / boundary split of the list (the SpMV over the interior tiles hides the halo exchange) is made for slabs
-    // along k only: with cuts along i or j most tiles of a 64 x 16 or 256 x 4 tiling touch a cut face.
-    const bool split = c->comm && c->pgrid[0] == 1 && c->pgrid[1] == 1;
+    // The interior / boundary split of the list: the SpMV over the tiles that touch no cut face of the rank's box runs while the
+    // halo of the search direction is exchanged.  (With cuts along i a 64- or 256-wide tile column is a large share of the box.)
+    const bool split = c->comm != nullptr && c->comm->nranks > 1;
+    CutMask cm;
+    for (int a = 0; a < 3; a++) { cm.cut[2 * a] = c->comm && c->pcoord[a] > 0; cm.cut[2 * a + 1] = c->comm && c->pcoord[a] < c->pgrid[a] - 1; }
     if (!split) {
-        hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 0,
+        hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 0, cm,
                            (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        *nActive = c->h_flags[1];
-        *nInterior = c->comm ? 0 : c->h_flags[1];   // block cuts along i / j: every tile waits for the exchange
+        *nActive = *nInterior = c->h_flags[1];
         return FLIPV_OK;
     }
-    // list = [tiles of the interior planes | tiles of the slab's first and last plane]
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 6, tg, 0, nk, 1,
+    // list = [interior tiles | tiles at the cut faces]
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 6, tg, 0, nk, 1, cm,
                        (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
-    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 2,
+    hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 2, cm,
                        (const int *)(c->d_flags + 6), tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
