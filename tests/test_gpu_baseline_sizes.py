@@ -257,6 +257,12 @@ def test_config5_miniature_eight_slabs_along_the_long_axis():
         c.set_solid_sdf(solid); c.set_viscosity(5.0); c.set_params(**params); c.particles = p
     before = [c.num_particles for c in ctxs]
     for t in range(2):
+        if t > 0:
+            # every substep starts from the single-domain run's particles: a 1e-6 difference in a position can flip a discrete
+            # decision (a cell entering the liquid) and the two runs then differ locally by 1e-3 one substep later -- sensitivity
+            # of the method, not of the decomposition (tests/test_gpu_wide.py)
+            for c, p in zip(ctxs, partition.split_particles_boxes(ref.particles, dx, boxes, dims)):
+                c.particles = p
         ref.substep(0.005)
         th = [threading.Thread(target=lambda c=c: c.substep(0.005)) for c in ctxs]
         for x in th:
@@ -270,10 +276,12 @@ def test_config5_miniature_eight_slabs_along_the_long_axis():
                 out = c.grid(n, out)
             got.append(out)
         assert rel_maxnorm3(got, [ref.grid(n) for n in "UVW"]) <= 5e-5, t
-    after = [c.num_particles for c in ctxs]
-    assert sum(after) == len(P) and after != before      # particles crossed the cuts
-    allp = np.concatenate([c.particles for c in ctxs])
-    assert np.array_equal(partition.box_owner(allp, dx, boxes, dims), np.repeat(np.arange(8), after))
+        after = [c.num_particles for c in ctxs]
+        assert sum(after) == len(P)
+        if t == 0:
+            assert after != before                       # particles crossed the cuts
+        allp = np.concatenate([c.particles for c in ctxs])
+        assert np.array_equal(partition.box_owner(allp, dx, boxes, dims), np.repeat(np.arange(8), after))
     for c in ctxs:
         c.close()
     ref.close()
