@@ -422,7 +422,7 @@ def committed_profile(kernel, N, args, world):
     """HBM traffic per launch of `kernel` from the committed PMC summary of this very workload (FETCH_SIZE x2 + WRITE_SIZE,
     separate rocprofv3 --pmc passes, tools/profile_round.sh), and rocprofv3's kernel-only average duration next to the
     HIP-event figure measured in this run.  Counters cannot be collected from inside the process, so the numbers
-    are the newest profiles/r*/bench<N>_v*_ files; null when this run is a different workload."""
+    are the newest profiles/r*/bench<N>_* files; null when this run is a different workload."""
     import csv
     import glob
     import re
@@ -431,7 +431,7 @@ def committed_profile(kernel, N, args, world):
         return out
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     key = lambda p: [int(x) for x in re.findall(r"\d+", os.path.relpath(p, root))]
-    pmc = sorted(glob.glob(os.path.join(root, "r*", "bench%d_v*_pmc_traffic.json" % N)), key=key)
+    pmc = sorted(glob.glob(os.path.join(root, "r*", "bench%d_*_pmc_traffic.json" % N)), key=key)
     if pmc:
         d = json.load(open(pmc[-1]))
         for name, v in d.items():
@@ -441,7 +441,7 @@ def committed_profile(kernel, N, args, world):
                 out["traffic_unit"] = "bytes per launch (HBM read + write, PMC)"
                 out["traffic_source"] = os.path.relpath(pmc[-1], os.path.dirname(root))
                 break
-    st = sorted(glob.glob(os.path.join(root, "r*", "bench%d_v*_kernel_stats.csv" % N)), key=key)
+    st = sorted(glob.glob(os.path.join(root, "r*", "bench%d_*_kernel_stats.csv" % N)), key=key)
     if st:
         for r in csv.DictReader(open(st[-1])):
             nm = re.sub(r"^(void )?(g\d+::)?", "", r["Name"])

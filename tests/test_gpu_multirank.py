@@ -208,3 +208,31 @@ def test_block_context_allocates_its_box_only():
     with pytest.raises(capi.FlipvError):
         c.set_params(cfl_number=9.0)                            # would need a halo of 12 entries
     c.close()
+
+
+def test_config4_miniature_on_2x2x2_blocks():
+    """BASELINE configs[3] as it is meant to run -- honey buckling (rod + sheet, nu = 50) on a 2 x 2 x 2 block decomposition --
+    in miniature: the 64^3 scene of the reference dump honey64_nu50 (cut with the reference's cap lifted: 1184 iterations) on
+    eight 32^3 blocks of this process, cap lifted likewise.  The sheet lies in the z = 0.5 plane and the rod along x = z = 0.5:
+    the liquid sits ON the cuts, every block exchanges faces, edges and corners."""
+    from flipviscosity3d_amd import capi, partition
+    g = Golden("honey64_nu50")
+    I, J, K = g.dims()
+    dims = (2, 2, 2)
+    boxes = partition.block_boxes(I, J, K, dims)
+    ctxs = [capi.Context(I, J, K, g.dx, device=0, block=b) for b in boxes]
+    capi.comm_init_local(ctxs, dims)
+    for c, p in zip(ctxs, partition.split_particles_boxes(g["particles0"], g.dx, boxes, dims)):
+        c.set_solid_sdf(g["solid"]); c.set_viscosity(float(g["nu"])); c.set_params(viscosity_max_iterations=int(g["vcap"]))
+        c.particles = p
+    assert min(c.num_particles for c in ctxs) > 0
+    sts = run_ranks(ctxs, lambda r, c: c.substep(g.dt))
+    assert all(s["viscosity"]["status"] == 0 for s in sts), sts[0]["viscosity"]
+    got = [assemble(ctxs, n) for n in "UVW"]
+    assert rel_maxnorm3(got, g.uvw(0, "final")) <= 1e-4
+    allp = np.concatenate([c.particles for c in ctxs])
+    a = allp[np.lexsort(allp[:, :3].T)]
+    b = g["s0_particles"][np.lexsort(g["s0_particles"][:, :3].T)]
+    assert len(a) == len(b) and np.abs(a[:, :3] - b[:, :3]).max() <= 1e-5
+    for c in ctxs:
+        c.close()
