@@ -491,6 +491,7 @@ extern "C" int flipv_read_grid(flipv_context *c, int which, float *out) {
 
 extern "C" int flipv_write_grid(flipv_context *c, int which, const float *in) {
     ENTER(c);
+    c->liqValid = c->liqPrevValid = 0;   // grids edited from outside: the next substep sweeps everything
     GridRef g;
     if (!in || !grid_ref(c, which, &g)) { c->err = "flipv_write_grid: bad grid id"; return FLIPV_ERR_INVALID; }
     if (which == FLIPV_GRID_SOLID_PHI) c->solidVersion++;
@@ -518,6 +519,7 @@ extern "C" int flipv_read_grid_box(flipv_context *c, int which, float *out) {
 }
 extern "C" int flipv_write_grid_box(flipv_context *c, int which, const float *in) {
     ENTER(c);
+    c->liqValid = c->liqPrevValid = 0;
     GridRef g;
     if (!in || !grid_ref(c, which, &g)) { c->err = "flipv_write_grid_box: bad grid id"; return FLIPV_ERR_INVALID; }
     if (which == FLIPV_GRID_SOLID_PHI) c->solidVersion++;
@@ -688,7 +690,7 @@ extern "C" int flipv_p2g(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_R
 extern "C" int flipv_extrapolate(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_extrapolate(c)); }
 
 static int save_velocity(flipv_context *c) {
-    const Lay R = fv_range(c, 1);
+    const Lay R = fv_range_liquid(c, 1);   // (whole planes of its k-range)
     const size_t off = plane_off(c->L, R.kb), bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;   // whole allocated planes
     HIPCHK(c, hipMemcpyAsync(c->sU + off, c->U + off, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->sV + off, c->V + off, bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -724,7 +726,14 @@ extern "C" int flipv_read_viscosity_volume(flipv_context *c, int which, float *o
 }
 
 // ------------------------------------------------------------------------------------------------ substep
+static int substep_inner(flipv_context *c, float dt, flipv_stats *st);
 static int substep(flipv_context *c, float dt, flipv_stats *st) {
+    c->inSubstep = 1;   // the sweeps may restrict themselves to where the liquid is (flipv_context::liqValid)
+    const int rc = substep_inner(c, dt, st);
+    c->inSubstep = 0;
+    return rc;
+}
+static int substep_inner(flipv_context *c, float dt, flipv_stats *st) {
     // phase order of the while-loop body, fluidsimulation.cpp:145-164
     int rc, warn = FLIPV_OK;
     flipv_solve_info vi, pi;
@@ -949,7 +958,7 @@ extern "C" int fvdbg_pcg_scalars(flipv_context *c, int cap, int n, double *out) 
         for (int it = 0; it < n; it++) {
             double v = 0;
             for (int s = 0; s < NSLOT; s++) {
-                const double x = h[q * per + (size_t)it * NSLOT + s];
+                const double x = h[(size_t)it * 5 * NSLOT + (size_t)q * NSLOT + s];   // block `it` = [sig | a | b | c | rmax] x NSLOT (PcgScal)
                 v = q == 4 ? (x > v ? x : v) : v + x;
             }
             out[(size_t)q * n + it] = v;

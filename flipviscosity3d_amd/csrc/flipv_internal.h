@@ -110,6 +110,15 @@ struct flipv_context {
     int k0, k1;
     int setupOnly;   // created by flipv_create_setup: only the arrays the scene-setup entry points touch exist (solid SDF, viscosity, liquid phi,
                      // particles, staging); every substep entry point refuses it
+    // Where the liquid is.  Inside flipv_substep / flipv_advance the sweeps whose result is trivial away from the liquid (liquid SDF
+    // reset, P2G finalisation, extrapolation set-up, body force, the set-up kernels of both solves, the pressure gradient, the
+    // velocity copies) cover only the box of the particle bins that hold particles, widened by LIQ_MARGIN cells, united with the
+    // previous substep's box: what lay outside both was written with its trivial value (phi = 3 dx, velocity 0, valid 0,
+    // coefficients 0, band 0) when it was last covered and has not been touched since.  Any grid written through the ABI, or an
+    // operator called on its own, resets this to "everywhere".
+    int inSubstep;
+    int liqValid, liqPrevValid;
+    int liqLo[3], liqHi[3], liqPrevLo[3], liqPrevHi[3];   // index boxes, half-open
     int isBlock;     // created by flipv_create_block with a box smaller than the domain: scene setup entry points refuse it
     int pgrid[3], pcoord[3];   // process grid and this rank's place in it (set by flipv_comm_init_*; {1,1,1} / {0,0,0} without)
     Comm *comm;      // nullptr on a single GPU
@@ -241,6 +250,24 @@ static inline Lay fv_range(const flipv_context *c, int halo) {
         hi[a] = L.ohi[a] + halo > o[a] + P[a] ? o[a] + P[a] : L.ohi[a] + halo;
     }
     L.ib = lo[0]; L.ie = hi[0]; L.jb = lo[1]; L.je = hi[1]; L.kb = lo[2]; L.ke = hi[2];
+    return L;
+}
+
+// 7 extrapolation layers + the particles' reach (2) + the viscosity band's two dilations and the 4^3 neighbourhood of the volume
+// classification (3): nothing further from a particle than this is ever non-trivial
+constexpr int LIQ_MARGIN = 12;
+// fv_range clipped to where the liquid is or was one substep ago (see flipv_context::liqValid)
+static inline Lay fv_range_liquid(const flipv_context *c, int halo) {
+    Lay L = fv_range(c, halo);
+    if (!c->inSubstep || !c->liqValid || !c->liqPrevValid) return L;
+    int *lo[3] = {&L.ib, &L.jb, &L.kb}, *hi[3] = {&L.ie, &L.je, &L.ke};
+    for (int a = 0; a < 3; a++) {
+        const int l = c->liqLo[a] < c->liqPrevLo[a] ? c->liqLo[a] : c->liqPrevLo[a];
+        const int h = c->liqHi[a] > c->liqPrevHi[a] ? c->liqHi[a] : c->liqPrevHi[a];
+        if (l > *lo[a]) *lo[a] = l;
+        if (h < *hi[a]) *hi[a] = h;
+        if (*hi[a] <= *lo[a]) *hi[a] = *lo[a] + 1;   // (never empty: a launch needs a block)
+    }
     return L;
 }
 
@@ -395,6 +422,7 @@ int fv_pack(flipv_context *c, int lat, const float *src_f32, const uint8_t *src_
 int fv_unpack(flipv_context *c, int lat, const float *linear, float *dst_f32, uint8_t *dst_u8, const int lo[3], const int hi[3]);
 int fv_fill(flipv_context *c, float *p, size_t n, float v);
 int fv_fill_cells(flipv_context *c, float *p, float v, int halo);
+int fv_fill_cells_liquid(flipv_context *c, float *p, float v, int halo);   // the same over fv_range_liquid
 
 // event-pool helpers for kernel timing
 void fv_ev_begin(flipv_context *c, int which, double cells);

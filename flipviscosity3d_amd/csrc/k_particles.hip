@@ -133,6 +133,15 @@ __global__ void k_bin_count(BinGrid B, Lay L, const float *__restrict__ aos6, si
     if (valid && rank == 0) atomicAdd(&cnt[t], size);
 }
 
+// bounding box of the non-empty tiles: bb = {min x, y, z, max x, y, z} in tile coordinates
+__global__ void k_bin_bbox(BinGrid B, const int *__restrict__ cnt, int *__restrict__ bb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B.nbx * B.nby * B.nbz || cnt[t] <= 0) return;
+    const int x = t % B.nbx, y = (t / B.nbx) % B.nby, z = t / (B.nbx * B.nby);
+    atomicMin(bb + 0, x); atomicMin(bb + 1, y); atomicMin(bb + 2, z);
+    atomicMax(bb + 3, x); atomicMax(bb + 4, y); atomicMax(bb + 5, z);
+}
+
 // exclusive scan of the tile counts + ordered list of the non-empty tiles, one block of 1024 threads
 __global__ __launch_bounds__(1024) void k_bin_scan(const int *__restrict__ cnt, int ntiles, int *__restrict__ off,
                                                    int *__restrict__ cur, int *__restrict__ list, int *__restrict__ nlist) {
@@ -589,7 +598,33 @@ static unsigned bin_blocks(const flipv_context *c) {
 
 int fv_particle_sdf(flipv_context *c) {
     const float maxd = 3.0f * (float)(double)c->dx;
-    fv_fill_cells(c, c->phi, maxd, 1);  // _getMaxDistance (particlelevelset.cpp:94-96)
+    // where the liquid is (flipv_context::liqValid): the box of the non-empty particle bins + LIQ_MARGIN, known before anything
+    // of this substep is swept
+    c->liqPrevValid = c->liqValid;
+    for (int a = 0; a < 3; a++) { c->liqPrevLo[a] = c->liqLo[a]; c->liqPrevHi[a] = c->liqHi[a]; }
+    c->liqValid = 0;
+    // (not in a multi-rank run: a neighbour's particles scatter into this rank's boundary cells, which its own bins know nothing of)
+    if (c->inSubstep && c->np && !c->prm.unbinned_scatter && !(c->comm && c->comm->nranks > 1)) {
+        int rcb = fv_bin_particles(c);
+        if (rcb) return rcb;
+        const BinGrid B = bin_grid(c);
+        int *bb = c->d_flags + 8;   // 6 ints: min x, y, z, max x, y, z of the non-empty bins (d_flags[8..13]; [12], [13] are rewritten by the run builder later)
+        const int init[6] = {1 << 30, 1 << 30, 1 << 30, -1, -1, -1};
+        HIPCHK(c, hipMemcpyAsync(bb, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        const int nt = B.nbx * B.nby * B.nbz;
+        hipLaunchKernelGGL(k_bin_bbox, dim3(cdiv(nt, 256)), dim3(256), 0, c->stream, B, c->binCnt, bb);
+        int h[6];
+        HIPCHK(c, hipMemcpyAsync(h, bb, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (h[3] >= 0) {
+            for (int a = 0; a < 3; a++) {
+                c->liqLo[a] = B.c0[a] + h[a] * BIN_T - LIQ_MARGIN;
+                c->liqHi[a] = B.c0[a] + (h[3 + a] + 1) * BIN_T + LIQ_MARGIN;
+            }
+            c->liqValid = 1;
+        }
+    }
+    fv_fill_cells_liquid(c, c->phi, maxd, 1);  // _getMaxDistance (particlelevelset.cpp:94-96)
     if (c->np) {
         // _particleRadius (fluidsimulation.cpp:36)
         const float radius = (float)(c->dx * 1.01 * sqrt(3.0) / 2.0);
@@ -614,7 +649,7 @@ int fv_particle_sdf(flipv_context *c) {
 }
 
 int fv_p2g(flipv_context *c) {
-    const Lay R = fv_range(c, 2);  // planes this rank's particles can reach (whole allocated planes are cleared)
+    const Lay R = fv_range_liquid(c, 2);  // planes this rank's particles can reach (whole allocated planes are cleared)
     const size_t off = plane_off(c->L, R.kb), bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
     float *acc[6] = {c->accU, c->accV, c->accW, c->wgtU, c->wgtV, c->wgtW};
     for (int q = 0; q < 6; q++) HIPCHK(c, hipMemsetAsync(acc[q] + off, 0, bytes, c->stream));

@@ -260,6 +260,13 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     sc->noB = c->prm.beta_from_residual ? 0 : 1;
     sc->itA = c->d_flags + 4;
     sc->itB = c->d_flags + 5;
+    sc->best = c->d_scal_small + 49;
+    sc->stalled = c->d_flags + 11;
+    {   // reset the stall guard (enqueued before any kernel of the solve)
+        const double inf = 1e300;
+        (void)hipMemcpyAsync(sc->best, &inf, sizeof(double), hipMemcpyHostToDevice, c->stream);
+        (void)hipMemsetAsync(sc->stalled, 0, sizeof(int), c->stream);
+    }
     *extra = c->d_scal + 5 * n;
 }
 
@@ -416,7 +423,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     // with fp32 vectors x IS the pressure grid
     constexpr bool f32 = std::is_same<T, float>::value;
     T *x = f32 ? (T *)c->pressure : (T *)c->pX;
-    const Lay R1 = fv_range(c, 1);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
+    const Lay R1 = fv_range_liquid(c, 1);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -484,6 +491,11 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     li.iterations = conv >= 0 ? conv + 1 : cap;
     li.residual = c->h_scal[0];
     li.status = conv >= 0 ? 0 : 1;
+    if (conv >= 0 && !useMg) {   // the diagonal loop's stall guard stops through the same flag: that is not convergence
+        int st = 0;
+        HIPCHK(c, hipMemcpy(&st, sc.stalled, sizeof(int), hipMemcpyDeviceToHost));
+        if (st) { li.status = 1; conv = -1; }
+    }
     if (c->prm.kernel_timing) fv_ev_collect(c);
     if (info) *info = li;
     {

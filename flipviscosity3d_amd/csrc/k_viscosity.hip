@@ -469,13 +469,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
 
     // Everything up to the factors is evaluated redundantly on the halo planes a neighbour-owned row would need
     // (inputs: phi with a 4-plane halo, the replicated solid SDF), so the setup needs no exchange of its own.
-    const Lay R0 = fv_range(c, 0), R1 = fv_range(c, 1), R2 = fv_range(c, 2), R3 = fv_range(c, 3);
     // face states
-    if (c->faceStateVersion != c->solidVersion) {  // functions of the solid SDF only
-        hipLaunchKernelGGL(k_solid_center, GRID3(R2), 0, c->stream, R2, c->solid, c->scp);
-        hipLaunchKernelGGL(k_face_states, GRID3(R1), 0, c->stream, R1, c->scp, c->stU, c->stV, c->stW);
+    if (c->faceStateVersion != c->solidVersion) {  // functions of the solid SDF only: everywhere
+        const Lay F1 = fv_range(c, 1), F2 = fv_range(c, 2);
+        hipLaunchKernelGGL(k_solid_center, GRID3(F2), 0, c->stream, F2, c->solid, c->scp);
+        hipLaunchKernelGGL(k_face_states, GRID3(F1), 0, c->stream, F1, c->scp, c->stU, c->stV, c->stW);
         c->faceStateVersion = c->solidVersion;
     }
+    const Lay R0 = fv_range_liquid(c, 0), R1 = fv_range_liquid(c, 1), R2 = fv_range_liquid(c, 2), R3 = fv_range_liquid(c, 3);
     // band mask + the seven volume lattices (viscositysolver.cpp:135-178)
     hipLaunchKernelGGL(k_valid_init, GRID3(R3), 0, c->stream, R3, c->phi, c->validCells);
     hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validCells, c->validTmp);
@@ -521,8 +522,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         PcgSys<T, 3> vs = visc_sys<T>(c);
         HIPCHK(c, hipMemsetAsync(bmax, 0, sizeof(double), c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));
-        // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane)
-        hipLaunchKernelGGL(k_visc_setup<T>, GRID3(R0), 0, c->stream, R0, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
+        // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane); a change
+        // of layout or precision rewrites every entry, not only those near the liquid
+        const Lay RS = full ? fv_range(c, 0) : R0;
+        hipLaunchKernelGGL(k_visc_setup<T>, GRID3(RS), 0, c->stream, RS, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                            c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2);
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -561,7 +564,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
 
     int conv = -1, iters = 0;
     double res = bnorm;
-    bool success = false;
+    bool success = false, stalled = false;
     int anyActive = c->nActiveV;
     if (c->comm) { float f = (float)anyActive; if ((rc = fv_allreduce_max_f32(c, &f))) return rc; anyActive = (int)f; }
     if (bnorm == 0.0 || anyActive == 0) {  // pcgsolver.h:254-258: zero rhs -> zero solution, success
@@ -602,11 +605,17 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         res = c->h_scal[0];
         iters = conv >= 0 ? conv + 1 : cap;
         success = conv >= 0;
+        if (success && !useMg) {   // the stall guard (PcgScal) stops the loop through the same flag: that is not convergence
+            int st = 0;
+            HIPCHK(c, hipMemcpy(&st, sc.stalled, sizeof(int), hipMemcpyDeviceToHost));
+            if (st) { success = false; stalled = true; }
+        }
     }
     li.iterations = iters;
     li.residual = res;
     // acceptance rule of viscositysolver.cpp:676-689
-    const bool accepted = success || (iters == cap && res < c->prm.viscosity_accept_tolerance);
+    // (a stalled solve is treated like one that ran into the cap: its iterate is used if the residual passes the acceptance bound)
+    const bool accepted = success || ((iters == cap || stalled) && res < c->prm.viscosity_accept_tolerance);
     li.status = success ? (iters == 0 ? 3 : 0) : (accepted ? 1 : 2);
     if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
         const size_t off = plane_off(L, R0.kb), cnt = (size_t)(R0.ke - R0.kb) * L.sz;

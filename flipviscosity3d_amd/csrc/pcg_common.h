@@ -93,6 +93,13 @@ struct PcgScal {
     int slot0, nslot;
     int cap;        // iteration cap
     int noB;        // 1: the SpMV did not form b = (r/d).q; the update uses b = a (conjugacy of successive directions)
+    // Stall guard.  An fp32 solve whose attainable residual sits right at the tolerance can miss it by a hair, stagnate and --
+    // thousands of iterations later, the recurrence residual having drifted from the true one -- blow up (seen on a thin-sheet
+    // scene with the cap lifted: relative residual 1.4e-6 against a tolerance of 1e-6 around iteration 1 100, 1e+2 at 3 000).
+    // *best = smallest max|r| so far; once that is within 100 x the tolerance and the current residual exceeds 16 x *best the
+    // update kernel stops the solve (sets *stalled and the stop flag): the iterate of that moment is returned as "not converged".
+    double *best;   // nullptr: no guard
+    int *stalled;
     // device-side iteration counters for hipGraph replay (kernels launched with it_arg = -1): the SpMV reads itA and
     // publishes it in itB, the update reads itB and stores itB+1 in itA -- a kernel never reads a counter that is
     // written inside the same launch, so late-starting blocks cannot see a half-advanced iteration.

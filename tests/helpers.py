@@ -65,3 +65,21 @@ def fluid_face_masks(phi):
     mw[:-1, :, :] |= f
     mw[1:, :, :] |= f
     return mu, mv, mw
+
+
+def assert_same_particle_set(a, b, tol=1e-5):
+    """two particle arrays hold the same particles up to `tol` in position, in any order: every particle of `a` has a partner in
+    `b` within tol, and the pairing is one to one (sorting both and comparing row by row mispairs particles whose leading
+    coordinate differs in the last bit)"""
+    from scipy.spatial import cKDTree
+    a = np.asarray(a)[:, :3].astype(np.float64)
+    b = np.asarray(b)[:, :3].astype(np.float64)
+    assert len(a) == len(b), (len(a), len(b))
+    if len(a) == 0:
+        return
+    dist, idx = cKDTree(b).query(a, k=1)
+    assert dist.max() <= tol, dist.max()
+    # one to one, unless two particles of b coincide within tol (then any of them is a valid partner)
+    if len(np.unique(idx)) != len(idx):
+        dist2, _ = cKDTree(a).query(b, k=1)
+        assert dist2.max() <= tol, dist2.max()

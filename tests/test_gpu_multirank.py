@@ -6,7 +6,7 @@ import threading
 import numpy as np
 import pytest
 
-from helpers import Golden, rel_maxnorm3
+from helpers import Golden, assert_same_particle_set, rel_maxnorm3
 
 pytestmark = pytest.mark.gpu
 
@@ -62,10 +62,7 @@ def test_slab_decomposition_matches_single_domain(name, nranks):
         assert np.array_equal(phi, ref.grid("LIQUID_PHI"))
         # particles: same set (order differs after migration)
         allp = np.concatenate([c.particles for c in ctxs])
-        assert len(allp) == len(ref.particles)
-        a = allp[np.lexsort(allp[:, :3].T)]
-        b = ref.particles[np.lexsort(ref.particles[:, :3].T)]
-        assert np.abs(a[:, :3] - b[:, :3]).max() <= 1e-5
+        assert_same_particle_set(allp, ref.particles, 1e-5)
         # ownership invariant after migration
         for c, (k0, k1) in zip(ctxs, ranges):
             kk = np.floor(c.particles[:, 2].astype(np.float64) / g.dx)
@@ -172,10 +169,7 @@ def test_block_decomposition_matches_single_domain(name, dims):
         assert rel_maxnorm3(got, g.uvw(t, "final")) <= 1e-4
         assert np.array_equal(assemble(ctxs, "LIQUID_PHI"), ref.grid("LIQUID_PHI"))      # order-free: identical bits
         allp = np.concatenate([c.particles for c in ctxs])
-        assert len(allp) == len(ref.particles)
-        a = allp[np.lexsort(allp[:, :3].T)]
-        b = ref.particles[np.lexsort(ref.particles[:, :3].T)]
-        assert np.abs(a[:, :3] - b[:, :3]).max() <= 1e-5
+        assert_same_particle_set(allp, ref.particles, 1e-5)
         own = partition.box_owner(allp, g.dx, boxes, dims)                               # ownership after migration
         assert np.array_equal(own, np.repeat(np.arange(len(ctxs)), [c.num_particles for c in ctxs]))
     cfl = run_ranks(ctxs, lambda r, c: c.cfl())
@@ -230,9 +224,6 @@ def test_config4_miniature_on_2x2x2_blocks():
     assert all(s["viscosity"]["status"] == 0 for s in sts), sts[0]["viscosity"]
     got = [assemble(ctxs, n) for n in "UVW"]
     assert rel_maxnorm3(got, g.uvw(0, "final")) <= 1e-4
-    allp = np.concatenate([c.particles for c in ctxs])
-    a = allp[np.lexsort(allp[:, :3].T)]
-    b = g["s0_particles"][np.lexsort(g["s0_particles"][:, :3].T)]
-    assert len(a) == len(b) and np.abs(a[:, :3] - b[:, :3]).max() <= 1e-5
+    assert_same_particle_set(np.concatenate([c.particles for c in ctxs]), g["s0_particles"], 1e-5)
     for c in ctxs:
         c.close()
