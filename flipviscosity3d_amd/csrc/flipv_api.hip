@@ -216,6 +216,10 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     {
         const char *e = getenv("FLIPV_ROWL");
         c->forceRowl = e ? atoi(e) : 0;
+        const char *lb = getenv("FLIPV_LIQBOX");
+        c->liqBoxOff = lb && atoi(lb) == 0;
+        const char *lm = getenv("FLIPV_LIQMASK");
+        c->liqMask = lm ? (unsigned)strtoul(lm, nullptr, 0) : 0xffffffffu;
         const char *z = getenv("FLIPV_SWZ");
         c->allowSwz = !(z && atoi(z) == 0);
         if (c->forceRowl != 16 && c->forceRowl != 64) c->forceRowl = 0;
@@ -690,7 +694,7 @@ extern "C" int flipv_p2g(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_R
 extern "C" int flipv_extrapolate(flipv_context *c) { ENTER(c); NOT_SETUP_ONLY(c); SYNC_RET(c, fv_extrapolate(c)); }
 
 static int save_velocity(flipv_context *c) {
-    const Lay R = fv_range_liquid(c, 1);   // (whole planes of its k-range)
+    const Lay R = fv_range_liquid(c, 1, 8);   // (whole planes of its k-range)
     const size_t off = plane_off(c->L, R.kb), bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;   // whole allocated planes
     HIPCHK(c, hipMemcpyAsync(c->sU + off, c->U + off, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->sV + off, c->V + off, bytes, hipMemcpyDeviceToDevice, c->stream));

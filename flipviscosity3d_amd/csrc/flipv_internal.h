@@ -117,6 +117,8 @@ struct flipv_context {
     // coefficients 0, band 0) when it was last covered and has not been touched since.  Any grid written through the ABI, or an
     // operator called on its own, resets this to "everywhere".
     int inSubstep;
+    int liqBoxOff;   // FLIPV_LIQBOX=0: never restrict (A/B and the test that compares the two)
+    unsigned liqMask; // FLIPV_LIQMASK: bit per call site (debugging aid), default all ones
     int liqValid, liqPrevValid;
     int liqLo[3], liqHi[3], liqPrevLo[3], liqPrevHi[3];   // index boxes, half-open
     int isBlock;     // created by flipv_create_block with a box smaller than the domain: scene setup entry points refuse it
@@ -257,9 +259,9 @@ static inline Lay fv_range(const flipv_context *c, int halo) {
 // classification (3): nothing further from a particle than this is ever non-trivial
 constexpr int LIQ_MARGIN = 12;
 // fv_range clipped to where the liquid is or was one substep ago (see flipv_context::liqValid)
-static inline Lay fv_range_liquid(const flipv_context *c, int halo) {
+static inline Lay fv_range_liquid(const flipv_context *c, int halo, int site = 31) {
     Lay L = fv_range(c, halo);
-    if (!c->inSubstep || !c->liqValid || !c->liqPrevValid) return L;
+    if (!c->inSubstep || c->liqBoxOff || !c->liqValid || !c->liqPrevValid || !((c->liqMask >> site) & 1u)) return L;
     int *lo[3] = {&L.ib, &L.jb, &L.kb}, *hi[3] = {&L.ie, &L.je, &L.ke};
     for (int a = 0; a < 3; a++) {
         const int l = c->liqLo[a] < c->liqPrevLo[a] ? c->liqLo[a] : c->liqPrevLo[a];
@@ -422,7 +424,7 @@ int fv_pack(flipv_context *c, int lat, const float *src_f32, const uint8_t *src_
 int fv_unpack(flipv_context *c, int lat, const float *linear, float *dst_f32, uint8_t *dst_u8, const int lo[3], const int hi[3]);
 int fv_fill(flipv_context *c, float *p, size_t n, float v);
 int fv_fill_cells(flipv_context *c, float *p, float v, int halo);
-int fv_fill_cells_liquid(flipv_context *c, float *p, float v, int halo);   // the same over fv_range_liquid
+int fv_fill_cells_liquid(flipv_context *c, float *p, float v, int halo, int site);   // the same over fv_range_liquid
 
 // event-pool helpers for kernel timing
 void fv_ev_begin(flipv_context *c, int which, double cells);

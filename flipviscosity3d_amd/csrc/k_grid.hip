@@ -361,7 +361,7 @@ int fv_pack(flipv_context *c, int lat, const float *srcf, const uint8_t *srcb, f
 }
 
 int fv_sdf_finish(flipv_context *c) {
-    const Lay R = fv_range_liquid(c, 0);
+    const Lay R = fv_range_liquid(c, 0, 0);
     hipLaunchKernelGGL(k_sdf_into_solids, GRID3(R), 0, c->stream, R, c->phi, c->solid, c->dx);
     return FLIPV_OK;
 }
@@ -376,14 +376,14 @@ int fv_fill_cells(flipv_context *c, float *p, float v, int halo) {
     return FLIPV_OK;
 }
 
-int fv_fill_cells_liquid(flipv_context *c, float *p, float v, int halo) {
-    const Lay R = fv_range_liquid(c, halo);
+int fv_fill_cells_liquid(flipv_context *c, float *p, float v, int halo, int site) {
+    const Lay R = fv_range_liquid(c, halo, site);
     hipLaunchKernelGGL(k_fill_cells, GRID3(R), 0, c->stream, R, p, v);
     return FLIPV_OK;
 }
 
 int fv_p2g_finalize(flipv_context *c) {
-    const Lay R = fv_range_liquid(c, 0);
+    const Lay R = fv_range_liquid(c, 0, 1);
     hipLaunchKernelGGL(k_p2g_finalize, GRID3(R), 0, c->stream, R, c->accU, c->wgtU, c->accV, c->wgtV, c->accW, c->wgtW, c->phi,
                        c->U, c->V, c->W, c->vU, c->vV, c->vW);
     return FLIPV_OK;
@@ -394,7 +394,7 @@ int fv_extrapolate(flipv_context *c) {
     const HaloArray in[6] = {{c->U, 4}, {c->V, 4}, {c->W, 4}, {c->vU, 1}, {c->vV, 1}, {c->vW, 1}};
     int rc = fv_halo_copy(c, in, 6, 1);
     if (rc) return rc;
-    const Lay R1 = fv_range_liquid(c, 1), R0 = fv_range_liquid(c, 0);
+    const Lay R1 = fv_range_liquid(c, 1, 2), R0 = fv_range_liquid(c, 0, 2);
     // activity blocks: flagged by the init sweep, dilated once per ACT_B layers
     ActGrid A;
     A.nx = (c->L.PX + ACT_B - 1) / ACT_B; A.ny = (c->L.PY + ACT_B - 1) / ACT_B; A.nz = (c->L.PZ + ACT_B - 1) / ACT_B;
@@ -428,7 +428,7 @@ int fv_extrapolate(flipv_context *c) {
 }
 
 int fv_body_force(flipv_context *c, float dt) {
-    const Lay R = fv_range_liquid(c, 1);
+    const Lay R = fv_range_liquid(c, 1, 3);
     hipLaunchKernelGGL(k_body_force, GRID3(R), 0, c->stream, R, c->U, c->V, c->W, c->phi, c->gravity[0] * dt, c->gravity[1] * dt,
                        c->gravity[2] * dt);
     HIPCHK(c, hipGetLastError());
@@ -443,7 +443,7 @@ int fv_compute_weights(flipv_context *c) {
 }
 
 int fv_apply_pressure(flipv_context *c, float dt) {
-    const Lay R = fv_range_liquid(c, 0);
+    const Lay R = fv_range_liquid(c, 0, 6);
     hipLaunchKernelGGL(k_apply_pressure, GRID3(R), 0, c->stream, R, c->U, c->V, c->W, c->vU, c->vV, c->vW, c->wU, c->wV, c->wW,
                        c->pressure, c->phi, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipGetLastError());
@@ -451,7 +451,7 @@ int fv_apply_pressure(flipv_context *c, float dt) {
 }
 
 int fv_constrain(flipv_context *c) {
-    const Lay R = fv_range_liquid(c, 1);   // (whole planes of its k-range)
+    const Lay R = fv_range_liquid(c, 1, 7);   // (whole planes of its k-range)
     const size_t off = plane_off(c->L, R.kb), n = (size_t)(R.ke - R.kb) * c->L.sz;   // whole allocated planes (pointwise; harmless in the halo)
     hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wU + off, c->U + off, c->sU + off, n);
     hipLaunchKernelGGL(k_constrain, dim3(grid1d(n)), dim3(256), 0, c->stream, c->wV + off, c->V + off, c->sV + off, n);

@@ -285,6 +285,10 @@ __device__ __noinline__ void d_p2g_global(Lay L, int dir, float px, float py, fl
     }
 }
 
+#ifndef FLIPV_P2G_STRIDE
+#define FLIPV_P2G_STRIDE 8
+#endif
+constexpr int P2G_STRIDE = FLIPV_P2G_STRIDE;   // 8 particles per cell at seeding time
 constexpr int P2G_R = BIN_T + 3;
 constexpr int P2G_RN = P2G_R * P2G_R * P2G_R;
 __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float *__restrict__ aos6,
@@ -310,7 +314,13 @@ __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float
         for (int e = threadIdx.x; e < 6 * P2G_RN; e += 256) sh[e] = 0.0f;
         __syncthreads();
         const int start = off[tile], n = cnt[tile];
-        for (int q = threadIdx.x; q < n; q += 256) {
+        // Lane -> particle: consecutive entries of a bin are mostly particles of the same cell (the caller's order is cell order at
+        // seeding time and stays close to it), i.e. the lanes of a wave would add to the same few LDS words and the adds
+        // serialise.  With P2G_STRIDE > 1 consecutive lanes take entries P2G_STRIDE apart (entry = (q mod rows) * stride + q div rows).
+        const int rows = (n + P2G_STRIDE - 1) / P2G_STRIDE;
+        for (int q0 = threadIdx.x; q0 < rows * P2G_STRIDE; q0 += 256) {
+            const int q = (q0 % rows) * P2G_STRIDE + q0 / rows;
+            if (q >= n) continue;
             const size_t p = idx[start + q];
             const float P[3] = {aos6[6 * p], aos6[6 * p + 1], aos6[6 * p + 2]};
             const float Vv[3] = {aos6[6 * p + 3], aos6[6 * p + 4], aos6[6 * p + 5]};
@@ -624,7 +634,7 @@ int fv_particle_sdf(flipv_context *c) {
             c->liqValid = 1;
         }
     }
-    fv_fill_cells_liquid(c, c->phi, maxd, 1);  // _getMaxDistance (particlelevelset.cpp:94-96)
+    fv_fill_cells_liquid(c, c->phi, maxd, 1, 0);  // _getMaxDistance (particlelevelset.cpp:94-96)
     if (c->np) {
         // _particleRadius (fluidsimulation.cpp:36)
         const float radius = (float)(c->dx * 1.01 * sqrt(3.0) / 2.0);
@@ -649,7 +659,7 @@ int fv_particle_sdf(flipv_context *c) {
 }
 
 int fv_p2g(flipv_context *c) {
-    const Lay R = fv_range_liquid(c, 2);  // planes this rank's particles can reach (whole allocated planes are cleared)
+    const Lay R = fv_range_liquid(c, 2, 1);  // planes this rank's particles can reach (whole allocated planes are cleared)
     const size_t off = plane_off(c->L, R.kb), bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
     float *acc[6] = {c->accU, c->accV, c->accW, c->wgtU, c->wgtV, c->wgtW};
     for (int q = 0; q < 6; q++) HIPCHK(c, hipMemsetAsync(acc[q] + off, 0, bytes, c->stream));

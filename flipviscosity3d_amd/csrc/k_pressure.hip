@@ -423,7 +423,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     // with fp32 vectors x IS the pressure grid
     constexpr bool f32 = std::is_same<T, float>::value;
     T *x = f32 ? (T *)c->pressure : (T *)c->pX;
-    const Lay R1 = fv_range_liquid(c, 1);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
+    const Lay R1 = fv_range_liquid(c, 1, 5);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -476,7 +476,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         hipLaunchKernelGGL(k_face_states, GRID3(F1), 0, c->stream, F1, c->scp, c->stU, c->stV, c->stW);
         c->faceStateVersion = c->solidVersion;
     }
-    const Lay R0 = fv_range_liquid(c, 0), R1 = fv_range_liquid(c, 1), R2 = fv_range_liquid(c, 2), R3 = fv_range_liquid(c, 3);
+    const Lay R0 = fv_range_liquid(c, 0, 4), R1 = fv_range_liquid(c, 1, 4), R2 = fv_range_liquid(c, 2, 4), R3 = fv_range_liquid(c, 3, 4);
     // band mask + the seven volume lattices (viscositysolver.cpp:135-178)
     hipLaunchKernelGGL(k_valid_init, GRID3(R3), 0, c->stream, R3, c->phi, c->validCells);
     hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validCells, c->validTmp);

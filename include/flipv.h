@@ -20,7 +20,8 @@
  *  - There is NO CPU fallback: without a HIP device flipv_create() fails with FLIPV_ERR_NO_DEVICE.
  *  - Environment (read by flipv_create, measurement / test switches only; results do not depend on them beyond
  *    solver tolerance):  FLIPV_ROWL=16|64 pins the solver tile geometry (default: chosen per solve from the tile
- *    fill);  FLIPV_SWZ=0 keeps every solver array in the plain plane layout.
+ *    fill);  FLIPV_SWZ=0 keeps every solver array in the plain plane layout;  FLIPV_LIQBOX=0 makes every sweep of a substep cover
+ *    the whole box instead of the neighbourhood of the liquid.
  */
 #ifndef FLIPV_H
 #define FLIPV_H
