@@ -227,3 +227,42 @@ def test_config4_miniature_on_2x2x2_blocks():
     assert_same_particle_set(np.concatenate([c.particles for c in ctxs]), g["s0_particles"], 1e-5)
     for c in ctxs:
         c.close()
+
+
+def test_blocks_with_fp64_vectors_and_odd_sizes():
+    """two things the cubic fp32 block tests do not touch: (i) fp64 solver vectors (8-byte entries through the packed halo
+    exchange, the diagonal-preconditioned pressure loop under a communicator) and (ii) a domain whose sizes are multiples of
+    nothing (70 x 33 x 29: partial tiles and padding at the cut faces, a cut along i at 32, blocks of unequal size)"""
+    from flipviscosity3d_amd import capi, partition, hostapi as H
+    from test_gpu_wide import box_mesh
+    I, J, K = 70, 33, 29
+    dx = float(np.float32(1.0 / I))
+    s = H.FluidSimulation()
+    s.initialize(I, J, K, dx)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 9)
+    s.addLiquid(box_mesh((0.12, 3.5 * dx, 4.2 * dx), (0.88, 24.3 * dx, 23.6 * dx)))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    P[:, 3] = 0.3 * np.sin(9 * P[:, 1]); P[:, 4] = -0.2 * np.cos(7 * P[:, 0]); P[:, 5] = 0.1 * np.sin(5 * P[:, 2] + P[:, 0])
+    for precision, dims in ((1, (2, 2, 1)), (0, (2, 1, 2)), (1, (1, 2, 2))):
+        params = dict(precision=precision, viscosity_max_iterations=6000, viscosity_tolerance=1e-7,
+                      pressure_rel_tolerance=0.0 if precision else 1e-7)
+        ref = capi.Context(I, J, K, dx)
+        ref.set_solid_sdf(solid); ref.set_viscosity(2.0); ref.set_params(**params); ref.particles = P
+        boxes = partition.block_boxes(I, J, K, dims)
+        ctxs = [capi.Context(I, J, K, dx, device=0, block=b) for b in boxes]
+        capi.comm_init_local(ctxs, dims)
+        for c, p in zip(ctxs, partition.split_particles_boxes(P, dx, boxes, dims)):
+            c.set_solid_sdf(solid); c.set_viscosity(2.0); c.set_params(**params); c.particles = p
+        st_ref = ref.substep(0.005)
+        sts = run_ranks(ctxs, lambda r, c: c.substep(0.005))
+        assert sum(s["viscosity"]["rows"] for s in sts) == st_ref["viscosity"]["rows"]
+        assert sum(s["pressure"]["rows"] for s in sts) == st_ref["pressure"]["rows"]
+        assert all(s["viscosity"]["status"] == 0 and s["pressure"]["status"] == 0 for s in sts), (precision, dims, sts[0])
+        got = [assemble(ctxs, n) for n in "UVW"]
+        assert rel_maxnorm3(got, [ref.grid(n) for n in "UVW"]) <= 2e-5, (precision, dims)
+        assert np.array_equal(assemble(ctxs, "LIQUID_PHI"), ref.grid("LIQUID_PHI"))
+        assert_same_particle_set(np.concatenate([c.particles for c in ctxs]), ref.particles, 1e-5)
+        for c in ctxs:
+            c.close()
+        ref.close()
