@@ -323,6 +323,7 @@ extern "C" int flipv_destroy(flipv_context *c) {
     fv_vmg_free(c);
     if (c->binCnt) (void)hipFree(c->binCnt);
     if (c->haloBuf) (void)hipFree(c->haloBuf);
+    if (c->xbuf) (void)hipFree(c->xbuf);
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->h_flags) (void)hipHostFree(c->h_flags);

@@ -619,8 +619,8 @@ int fv_particle_sdf(flipv_context *c) {
         if (rcb) return rcb;
         const BinGrid B = bin_grid(c);
         int *bb = c->d_flags + 8;   // 6 ints: min x, y, z, max x, y, z of the non-empty bins (d_flags[8..13]; [12], [13] are rewritten by the run builder later)
-        const int init[6] = {1 << 30, 1 << 30, 1 << 30, -1, -1, -1};
-        HIPCHK(c, hipMemcpyAsync(bb, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(bb, 0x7f, 3 * sizeof(int), c->stream));       // minima start at 0x7f7f7f7f
+        HIPCHK(c, hipMemsetAsync(bb + 3, 0xff, 3 * sizeof(int), c->stream));   // maxima at -1
         const int nt = B.nbx * B.nby * B.nbz;
         hipLaunchKernelGGL(k_bin_bbox, dim3(cdiv(nt, 256)), dim3(256), 0, c->stream, B, c->binCnt, bb);
         int h[6];

@@ -262,11 +262,9 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     sc->itB = c->d_flags + 5;
     sc->best = c->d_scal_small + 49;
     sc->stalled = c->d_flags + 11;
-    {   // reset the stall guard (enqueued before any kernel of the solve)
-        const double inf = 1e300;
-        (void)hipMemcpyAsync(sc->best, &inf, sizeof(double), hipMemcpyHostToDevice, c->stream);
-        (void)hipMemsetAsync(sc->stalled, 0, sizeof(int), c->stream);
-    }
+    // reset the stall guard (enqueued before any kernel of the solve): best = 0x7f7f... = 1.4e306, "nothing seen yet"
+    (void)hipMemsetAsync(sc->best, 0x7f, sizeof(double), c->stream);
+    (void)hipMemsetAsync(sc->stalled, 0, sizeof(int), c->stream);
     *extra = c->d_scal + 5 * n;
 }
 
