@@ -634,16 +634,20 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     return success ? FLIPV_OK : (accepted ? FLIPV_WARN_NOT_CONVERGED : FLIPV_WARN_SOLVE_FAILED);
 }
 
-// out = A in for arbitrary fp32 vectors (zero off the rows), with the solver's SpMV kernel and no dot products
-void fv_visc_apply_f32(flipv_context *c, float *const in[3], float *const out[3]) {
+// One fine-level sweep of the multigrid preconditioner (k_viscosity_mg.hip) with the solver's tile SpMV kernel: out = in + omega
+// (r - A in)/d (epi 1; epi 3 also adds (r, out) into sig(it + sig_shift)) or out = r - A in (epi 2).  fp32 vectors in the plain
+// layout, zero off the rows; `out` must not alias `in`.  it_arg < 0: the device-side iteration counter (hipGraph replay).
+void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift) {
     PcgSys<float, 3> v = visc_sys<float>(c);
     for (int m = 0; m < 3; m++) { v.s[m] = in[m]; v.q[m] = out[m]; }
-    PcgScal none;
-    memset(&none, 0, sizeof(none));
-    const int saved = c->prm.kernel_timing;
-    c->prm.kernel_timing = 0;
-    launch_visc_spmv<float, 4>(c, none, 0, 0, c->nActiveV, &v);
-    c->prm.kernel_timing = saved;
+    int nb = pcg_grid(c, c->nActiveV);
+    const int cap = c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : 512;
+    if (nb > cap) nb = cap;
+#define VSWEEP(P_, E_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<float, 4, P_, true, E_>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, \
+                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, v, sc, it_arg, omega, sig_shift))
+    if (c->vPred) { if (epi == 1) VSWEEP(true, EPI_JACOBI); else if (epi == 2) VSWEEP(true, EPI_RESIDUAL); else VSWEEP(true, EPI_JACOBI_DOT); }
+    else { if (epi == 1) VSWEEP(false, EPI_JACOBI); else if (epi == 2) VSWEEP(false, EPI_RESIDUAL); else VSWEEP(false, EPI_JACOBI_DOT); }
+#undef VSWEEP
 }
 
 int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) {

@@ -10,22 +10,33 @@
 //                same-component neighbours (normal offset -1/0/+1 times {centre, +-1 along either transverse axis}) and 4
 //                + 4 cross-component neighbours -- the fine 15-point pattern plus the normal-times-transverse diagonals.
 //                Storage: one coefficient grid per (component, slot) on the level's dense index space ("dense slots").
-//   level 0      matrix-free: the SpMV kernel of k_viscosity.hip applies A, pointwise kernels do the Jacobi updates
+//   level 0      matrix-free: the tile SpMV kernel of k_viscosity.hip with the Jacobi update / the residual as its epilogue
+//                (k_visc_spmv<.., EPI>): a sweep is ONE launch that reads the iterate with its halo and writes the next one
 //   assembly     level 1 is scattered from the matrix-free fine rows with atomics (each fine row knows its <= 15 entries
 //                and each end of an entry its <= 2 parents), level l+1 from level l the same way
-//   cycle        V(2,2), damped Jacobi (omega 0.6: lambda_max(D^-1 A) ~ 3), zero initial guess
+//   cycle        V(2,2), damped Jacobi (omega 0.6: lambda_max(D^-1 A) ~ 3), zero initial guess; the hierarchy stops at 16^3
+//                (16 sweeps there: deeper levels bought nothing in the prototype, tools/vmg_proto.py)
+//   where        every coarse sweep covers only the box of the level's index space that the listed tiles reach (the liquid's
+//                bounding box halved level by level); levels whose box holds <= VMG_TAIL_POS positions run inside ONE
+//                single-workgroup launch (k_vmg_tail), the larger ones as 6 launches per level
+//   loop         PCG around it; `check_every` iterations are captured into a hipGraph once per solve and replayed
+//                (device-side iteration counters, as in pcg_common.h)
 #include "flipv_internal.h"
 #include "pcg_common.h"
 
 #include <vector>
 
-void fv_visc_apply_f32(flipv_context *c, float *const in[3], float *const out[3]);  // k_viscosity.hip: out = A in (fp32, no dots)
+void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);  // k_viscosity.hip
 
 namespace {
 
 constexpr int VS = 23;             // slots per row
 constexpr float VMG_OMEGA = 0.6f;
-constexpr int VMG_COARSEST_SWEEPS = 8;
+constexpr int VMG_COARSEST_SWEEPS = 16;   // even: the sweeps ping-pong between x and y and must end in x
+constexpr int VMG_MIN_DIM = 16;           // no level below this many cells along the longest axis
+constexpr int VMG_TAIL_POS = 640;         // levels with at most this many index positions in their box go into the single-workgroup tail
+constexpr int VMG_TAIL_MAX = 3;           // ... at most this many levels
+constexpr int VMG_MAX_LEVELS = 15;
 
 // slot tables: neighbour component and offset of slot s of a row of component c; inverse look-up by (c, c', offset)
 struct SlotTables {
@@ -65,14 +76,37 @@ static void build_slot_tables(SlotTables *T) {
     }
 }
 
+// The same tables as compile-time functions: inside fully unrolled loops the neighbour component and offset of a slot fold to
+// constants, so a row's 23 neighbour addresses are immediate offsets and no pointer array is indexed at run time (which would
+// push the kernel arguments into scratch memory).
+constexpr int slot_comp(int c, int s) { return s < 15 ? c : (s < 19 ? (c + 1) % 3 : (c + 2) % 3); }
+constexpr int slot_off(int c, int s, int a) {   // offset of slot s of a row of component c along axis a
+    const int n = c, t1 = (c + 1) % 3, t2 = (c + 2) % 3;
+    if (s < 15) {
+        const int dn = s / 5 - 1, q = s % 5;
+        const int tr0 = q == 1 ? -1 : (q == 2 ? 1 : 0), tr1 = q == 3 ? -1 : (q == 4 ? 1 : 0);
+        return a == n ? dn : (a == t1 ? tr0 : tr1);
+    }
+    const int x = s < 19 ? t1 : t2, idx = s < 19 ? s - 15 : s - 19;
+    const int dn = idx / 2 - 1, da = idx % 2;
+    (void)t2;
+    return a == n ? dn : (a == x ? da : 0);
+}
+constexpr int slot_diag(int c) { (void)c; return 5; }   // (c, 0, 0, 0): dn = 0, q = 0
+
+struct Box3 { int lo[3], hi[3]; };   // index box of a level, half-open
+struct Vec3p { float *p[3]; };
 struct VLevel {          // a coarse level (>= 1)
     Lay L;
     float *coef[3][VS];
     float *x[3], *y[3], *b[3], *t[3];
+    Box3 box;
 };
 struct VLevelDev {       // what kernels need of a coarse level
     Lay L;
     float *coef[3][VS];
+    Vec3p x, y, b, t;
+    Box3 box;
 };
 struct FineOp {          // the matrix-free level 0 (k_viscosity.hip's arrays)
     const float *vm[3];
@@ -128,10 +162,15 @@ __device__ __forceinline__ void d_rap_entry(const VLevelDev &C, int c, const int
         for (int b = 0; b < nj; b++) d_coarse_add(C, c, PI[a], c2, PJ[b], wi[a] * v * wj[b]);
 }
 
-// ---- level l -> level l+1 (l >= 1): every stored entry of the dense-slot operator
+// thread -> index of a level's box (64 x 4 x 1 threads per block)
+#define BOX_IJK_OR_RETURN(B)                                                                                   \
+    const int i = (B).lo[0] + blockIdx.x * 64 + threadIdx.x, j = (B).lo[1] + blockIdx.y * 4 + threadIdx.y,     \
+              k = (B).lo[2] + blockIdx.z;                                                                      \
+    if (i >= (B).hi[0] || j >= (B).hi[1]) return
+
+// ---- level l -> level l+1 (l >= 1): every stored entry of the dense-slot operator inside the level's box
 __global__ void k_vmg_rap(VLevelDev F, VLevelDev C) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= F.L.PX || j >= F.L.PY) return;
+    BOX_IJK_OR_RETURN(F.box);
     const size_t ci = gidx(F.L, i, j, k);
     const int p[3] = {i, j, k};
     for (int c = 0; c < 3; c++) {
@@ -145,78 +184,224 @@ __global__ void k_vmg_rap(VLevelDev F, VLevelDev C) {
     }
 }
 
-// ---- coarse levels: y = A x for one dof
-__device__ __forceinline__ float d_apply(const VLevelDev &A, float *const x[3], int c, size_t ci) {
+// ---- coarse levels: y = A x for one dof of component C
+template <int C>
+__device__ __forceinline__ float d_apply(const VLevelDev &A, const Vec3p &x, size_t ci) {
     const long sy = A.L.sy, sz = A.L.sz;
     // all coefficients, then all neighbour values, then the sum: 46 independent loads instead of 23 dependent
     // load-test-load chains (empty slots hold 0 and the guard zones make every neighbour address valid)
     float v[VS], xv[VS];
 #pragma unroll
-    for (int q = 0; q < VS; q++) v[q] = A.coef[c][q][ci];
+    for (int q = 0; q < VS; q++) v[q] = A.coef[C][q][ci];
 #pragma unroll
-    for (int q = 0; q < VS; q++) xv[q] = x[ST.comp[c][q]][(long)ci + ST.off[c][q][0] + ST.off[c][q][1] * sy + ST.off[c][q][2] * sz];
+    for (int q = 0; q < VS; q++) xv[q] = x.p[slot_comp(C, q)][(long)ci + slot_off(C, q, 0) + slot_off(C, q, 1) * sy + slot_off(C, q, 2) * sz];
     float s = 0.0f;
 #pragma unroll
     for (int q = 0; q < VS; q++) s += v[q] * xv[q];
     return s;
 }
-struct Vec3p { float *p[3]; };
-// mode 0: out = omega b/d (sweep from a zero guess)   1: out = x + omega (b - A x)/d   2: out = b - A x
-__global__ void k_vmg_op(VLevelDev A, Vec3p x, Vec3p b, Vec3p out, int mode) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= A.L.PX || j >= A.L.PY) return;
-    const size_t ci = gidx(A.L, i, j, k);
+
+// The six steps of a coarse level's share of the V-cycle, for the three dofs of index (i, j, k).  Vectors of a level are zero
+// wherever there is no row (diagonal slot 0) and outside the level's box.
+enum VmgOp { OP_RESTRICT = 0,   // b = P^T (finer level's t) ; x = omega b/d          (first pre-sweep from a zero guess)
+       OP_PRE2 = 1,       // y = x + omega (b - A x)/d
+       OP_RESID = 2,      // t = b - A y
+       OP_PROLONG = 3,    // y += P (coarser level's x)
+       OP_POST1 = 4,      // t = y + omega (b - A y)/d
+       OP_POST2 = 5,      // x = t + omega (b - A t)/d
+       OP_SWEEP_XY = 6,   // y = x + omega (b - A x)/d     (coarsest level)
+       OP_SWEEP_YX = 7 }; // x = y + omega (b - A y)/d
+// (P^T t)(C, P): the <= 12 fine children of coarse dof P of component C
+template <int C>
+__device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const int P[3]) {
+    constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
+    float s = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float d = A.coef[c][ST.diag[c]][ci];
-        if (d == 0.0f) { if (mode != 2) out.p[c][ci] = 0.0f; else out.p[c][ci] = 0.0f; continue; }
-        const float bb = b.p[c][ci];
-        if (mode == 0) { out.p[c][ci] = VMG_OMEGA * bb / d; continue; }
-        const float ax = d_apply(A, x.p, c, ci);
-        out.p[c][ci] = mode == 1 ? x.p[c][ci] + VMG_OMEGA * (bb - ax) / d : bb - ax;
+    for (int dn = -1; dn <= 1; dn++)
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) {
+                int q[3];
+                q[C] = 2 * P[C] + dn; q[t1] = 2 * P[t1] + a; q[t2] = 2 * P[t2] + b;
+                if (d_in_lattice(F, C, q)) s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][gidx(F, q[0], q[1], q[2])];
+            }
+    return s;
+}
+template <int OP, int C>
+__device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
+    const size_t ci = gidx(A.L, i, j, k);
+    const int P[3] = {i, j, k};
+    const float d = A.coef[C][slot_diag(C)][ci];
+    if (OP == OP_RESTRICT) {
+        const float s = d != 0.0f ? d_restrict<C>(F, ft, P) : 0.0f;   // (a coarse dof with a fine child that is a row has a diagonal)
+        A.b.p[C][ci] = s;
+        A.x.p[C][ci] = d != 0.0f ? VMG_OMEGA * s / d : 0.0f;
+        return;
+    }
+    if (d == 0.0f) return;   // no row: every vector stays 0 here
+    if (OP == OP_PROLONG) {
+        int Q[2][3];
+        float w[2];
+        const int n = d_parents(C, P, Q, w);
+        float s = w[0] * cx.p[C][gidx(Cn, Q[0][0], Q[0][1], Q[0][2])];
+        if (n == 2) s += w[1] * cx.p[C][gidx(Cn, Q[1][0], Q[1][1], Q[1][2])];
+        A.y.p[C][ci] += s;
+        return;
+    }
+    const Vec3p &in = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.x : (OP == OP_POST2 ? A.t : A.y);
+    const Vec3p &out = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.y : ((OP == OP_RESID || OP == OP_POST1) ? A.t : A.x);
+    const float ax = d_apply<C>(A, in, ci);
+    const float bb = A.b.p[C][ci];
+    out.p[C][ci] = OP == OP_RESID ? bb - ax : in.p[C][ci] + VMG_OMEGA * (bb - ax) / d;
+}
+template <int OP>
+__device__ __forceinline__ void d_vmg_step_c(int c, const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
+    if (c == 0) d_vmg_step<OP, 0>(A, F, ft, Cn, cx, i, j, k);
+    else if (c == 1) d_vmg_step<OP, 1>(A, F, ft, Cn, cx, i, j, k);
+    else d_vmg_step<OP, 2>(A, F, ft, Cn, cx, i, j, k);
+}
+// One step of one level as a launch over the level's box: blockIdx.z = 3 * plane + component.  The level descriptors live in
+// device memory (VmgState::d_lev, uploaded per solve): lev[l] is this level, lev[l - 1] the finer one (l = 0: the fine level's
+// lattice and residual come as arguments), lev[l + 1] the coarser one.  conv: nothing to do once the solve has stopped.
+template <int OP>
+__global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv) {
+    if (*conv >= 0) return;
+    const VLevelDev &A = lev[l];
+    const int c = (int)blockIdx.z % 3;
+    const int i = A.box.lo[0] + blockIdx.x * 64 + threadIdx.x, j = A.box.lo[1] + blockIdx.y * 4 + threadIdx.y, k = A.box.lo[2] + (int)blockIdx.z / 3;
+    if (i >= A.box.hi[0] || j >= A.box.hi[1]) return;
+    if (OP == OP_RESTRICT) {
+        if (l == 0) d_vmg_step_c<OP>(c, A, F0, ft0, A.L, ft0, i, j, k);
+        else d_vmg_step_c<OP>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
+    } else if (OP == OP_PROLONG) d_vmg_step_c<OP>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
+    else d_vmg_step_c<OP>(c, A, A.L, ft0, A.L, ft0, i, j, k);
+}
+
+// the coarsest levels in one workgroup: levels lev[first..n), lev[first] restricts from lev[first - 1] (first = 0: from (F0, ft0))
+template <int OP>
+__device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx) {
+    const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
+    const int n = w * h * dz;
+    for (int q = threadIdx.x; q < 3 * n; q += blockDim.x) {
+        const int c = q / n, r = q - c * n;
+        const int i = A.box.lo[0] + r % w, j = A.box.lo[1] + (r / w) % h, k = A.box.lo[2] + r / (w * h);
+        d_vmg_step_c<OP>(c, A, F, ft, Cn, cx, i, j, k);
+    }
+    __syncthreads();
+}
+// The coarsest level with the iterate in LDS and the operator rows in registers: a thread owns at most one row per component
+// (the rows of each component are compacted into a list first), the three components' iterates sit in LDS boxes with a rim of
+// zeros, so a sweep is 23 LDS reads per row and one barrier instead of a round trip through L2 per row (16 sweeps at 16^3: 200 us
+// of the cycle's 520 before).  Falls back to the global-memory sweeps when the box or a component's row count does not fit.
+constexpr int VMG_LDS_POS = 4096;     // positions of the box including its rim
+struct CoarseRow { float cf[VS]; float invd, b; int li; size_t ci; bool has; };
+template <int C>
+__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP) {
+    R.has = (int)threadIdx.x < nrows;
+    if (!R.has) return;
+    const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1];
+    const int r = rowlist[threadIdx.x];
+    const int di = r % w, dj = (r / w) % h, dk = r / (w * h);
+    const int P[3] = {A.box.lo[0] + di, A.box.lo[1] + dj, A.box.lo[2] + dk};
+    R.ci = gidx(A.L, P[0], P[1], P[2]);
+    R.li = (di + 1) + W * ((dj + 1) + H * (dk + 1));
+#pragma unroll
+    for (int q = 0; q < VS; q++) R.cf[q] = A.coef[C][q][R.ci];
+    R.invd = 1.0f / R.cf[slot_diag(C)];
+    R.b = d_restrict<C>(F, ft, P);
+    xs0[C * NP + R.li] = VMG_OMEGA * R.b * R.invd;
+}
+template <int C>
+__device__ __forceinline__ void d_coarsest_sweep(const CoarseRow &R, const float *cur, float *nxt, int NP, int W, int WH) {
+    if (!R.has) return;
+    float ax = 0.0f;
+#pragma unroll
+    for (int q = 0; q < VS; q++) ax += R.cf[q] * cur[slot_comp(C, q) * NP + R.li + slot_off(C, q, 0) + slot_off(C, q, 1) * W + slot_off(C, q, 2) * WH];
+    nxt[C * NP + R.li] = cur[C * NP + R.li] + VMG_OMEGA * (R.b - ax) * R.invd;
+}
+
+__global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, Lay F0, Vec3p ft0, const int *__restrict__ conv) {
+    if (*conv >= 0) return;
+    // can the coarsest level live in LDS?  (decided before anything else: every thread takes the same path)
+    __shared__ float xs[2 * 3 * VMG_LDS_POS];
+    __shared__ int rowlist[3][1024];
+    __shared__ int cnt[3];
+    int W = 0, H = 0, NP = 0;
+    bool coarsest_in_lds = false;
+    {
+        const VLevelDev &A = lev[n - 1];
+        const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
+        W = w + 2; H = h + 2; NP = W * H * (dz + 2);
+        if (NP <= VMG_LDS_POS) {
+            for (int e = threadIdx.x; e < 2 * 3 * VMG_LDS_POS; e += blockDim.x) xs[e] = 0.0f;
+            if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+            __syncthreads();
+            const int npos = w * h * dz;
+            for (int q = threadIdx.x; q < 3 * npos; q += blockDim.x) {
+                const int c = q / npos, r = q - c * npos;
+                const size_t ci = gidx(A.L, A.box.lo[0] + r % w, A.box.lo[1] + (r / w) % h, A.box.lo[2] + r / (w * h));
+                if (A.coef[c][slot_diag(c)][ci] != 0.0f) {
+                    const int idx = atomicAdd(&cnt[c], 1);
+                    if (idx < 1024) rowlist[c][idx] = r;
+                }
+            }
+            __syncthreads();
+            coarsest_in_lds = cnt[0] <= 1024 && cnt[1] <= 1024 && cnt[2] <= 1024;
+        }
+    }
+    for (int l = first; l < n; l++) {   // down
+        const VLevelDev &A = lev[l];
+        if (l == n - 1 && coarsest_in_lds) break;   // restricted straight into registers below
+        if (l == 0) d_tail_step<OP_RESTRICT>(A, F0, ft0, A.L, ft0);
+        else d_tail_step<OP_RESTRICT>(A, lev[l - 1].L, lev[l - 1].t, A.L, ft0);
+        if (l + 1 < n) {
+            d_tail_step<OP_PRE2>(A, A.L, ft0, A.L, ft0);
+            d_tail_step<OP_RESID>(A, A.L, ft0, A.L, ft0);
+        }
+    }
+    if (!coarsest_in_lds) {   // coarsest level through global memory (its restriction was done by the loop above)
+        const VLevelDev &A = lev[n - 1];
+        for (int s = 0; s < sweeps; s += 2) {
+            d_tail_step<OP_SWEEP_XY>(A, A.L, ft0, A.L, ft0);
+            d_tail_step<OP_SWEEP_YX>(A, A.L, ft0, A.L, ft0);
+        }
+    } else {
+        const VLevelDev &A = lev[n - 1];
+        const Lay &F = n - 1 == 0 ? F0 : lev[n - 2].L;
+        const Vec3p &ft = n - 1 == 0 ? ft0 : lev[n - 2].t;
+        CoarseRow RU, RV, RW;
+        d_coarsest_load<0>(A, F, ft, rowlist[0], cnt[0], W, H, RU, xs, NP);
+        d_coarsest_load<1>(A, F, ft, rowlist[1], cnt[1], W, H, RV, xs, NP);
+        d_coarsest_load<2>(A, F, ft, rowlist[2], cnt[2], W, H, RW, xs, NP);
+        __syncthreads();
+        float *cur = xs, *nxt = xs + 3 * VMG_LDS_POS;
+        for (int s = 0; s < sweeps; s++) {
+            d_coarsest_sweep<0>(RU, cur, nxt, NP, W, W * H);
+            d_coarsest_sweep<1>(RV, cur, nxt, NP, W, W * H);
+            d_coarsest_sweep<2>(RW, cur, nxt, NP, W, W * H);
+            __syncthreads();
+            float *t = cur; cur = nxt; nxt = t;
+        }
+        if (RU.has) A.x.p[0][RU.ci] = cur[0 * NP + RU.li];
+        if (RV.has) A.x.p[1][RV.ci] = cur[1 * NP + RV.li];
+        if (RW.has) A.x.p[2][RW.ci] = cur[2 * NP + RW.li];
+        __syncthreads();
+    }
+    for (int l = n - 2; l >= first; l--) {   // up
+        const VLevelDev &A = lev[l];
+        d_tail_step<OP_PROLONG>(A, A.L, ft0, lev[l + 1].L, lev[l + 1].x);
+        d_tail_step<OP_POST1>(A, A.L, ft0, A.L, ft0);
+        d_tail_step<OP_POST2>(A, A.L, ft0, A.L, ft0);
     }
 }
 
-// ---- transfers (the fine side is any level's dense index space, level 0 included)
-// restriction: coarse b = P^T t
-__global__ void k_vmg_restrict(Lay F, Lay C, Vec3p tf, Vec3p bc) {
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y, K = blockIdx.z;
-    if (I >= C.PX || J >= C.PY) return;
-    const int P[3] = {I, J, K};
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float s = 0.0f;
-        if (d_in_lattice(C, c, P)) {
-            const int t1 = (c + 1) % 3, t2 = (c + 2) % 3;
-            for (int dn = -1; dn <= 1; dn++)
-                for (int a = 0; a < 2; a++)
-                    for (int b = 0; b < 2; b++) {
-                        int q[3];
-                        q[c] = 2 * P[c] + dn; q[t1] = 2 * P[t1] + a; q[t2] = 2 * P[t2] + b;
-                        if (d_in_lattice(F, c, q)) s += (dn == 0 ? 1.0f : 0.5f) * tf.p[c][gidx(F, q[0], q[1], q[2])];
-                    }
-        }
-        bc.p[c][gidx(C, I, J, K)] = s;
-    }
-}
-// prolongation: fine x += P xc, on dofs flagged by `fmask` (level 0: the row mask) or everywhere (coarse levels: nullptr)
-__global__ void k_vmg_prolong(Lay F, Lay C, Vec3p xf, Vec3p xc, const uint8_t *__restrict__ fmask) {
-    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y, k = blockIdx.z;
-    if (i >= F.PX || j >= F.PY) return;
-    const size_t ci = gidx(F, i, j, k);
-    const unsigned m = fmask ? fmask[ci] : 7u;
-    if (!m) return;
-    const int p[3] = {i, j, k};
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        if (!((m >> c) & 1u) || !d_in_lattice(F, c, p)) continue;
-        int P[2][3];
-        float w[2];
-        const int n = d_parents(c, p, P, w);
-        float s = w[0] * xc.p[c][gidx(C, P[0][0], P[0][1], P[0][2])];
-        if (n == 2) s += w[1] * xc.p[c][gidx(C, P[1][0], P[1][1], P[1][2])];
-        xf.p[c][ci] += s;
-    }
+// zero a set of arrays inside a box (+ one ring): the coarse operators of this solve, before the Galerkin scatter
+struct ZeroSet { float *p[3 * VS]; int n; };
+__global__ __launch_bounds__(256) void k_vmg_zero_box(ZeroSet Z, Lay L, Box3 B) {
+    BOX_IJK_OR_RETURN(B);
+    const size_t ci = gidx(L, i, j, k);
+    for (int a = 0; a < Z.n; a++) Z.p[a][ci] = 0.0f;
 }
 
 // ---- the kernels that walk the solver's tile list: once per tile geometry (pcg_geo.inc)
@@ -233,10 +418,15 @@ constexpr int ROWL = 64;
 
 struct VmgState {
     std::vector<VLevel> lev;     // coarse levels 1..
-    float *z[3] = {nullptr, nullptr, nullptr}, *q2[3] = {nullptr, nullptr, nullptr};   // level 0: z = M^-1 r, q2 = A z / residual
+    float *za[3] = {nullptr, nullptr, nullptr}, *zb[3] = {nullptr, nullptr, nullptr}, *t0[3] = {nullptr, nullptr, nullptr};   // level 0: the sweeps' two iterates, the residual
     std::vector<void *> allocs;
-    std::vector<std::pair<void *, size_t>> coefBlocks;   // (base, bytes) of every level's coefficient storage, zeroed per solve
-    ~VmgState() { for (void *p : allocs) (void)hipFree(p); }
+    std::vector<std::pair<void *, size_t>> vecBlocks;    // (base, bytes) of every level's vector storage, zeroed per solve
+    Box3 prevBox[16];            // per coarse level: the box whose coefficients the previous solve wrote (hi <= lo: none yet)
+    int *d_box = nullptr;
+    VLevelDev *d_lev = nullptr;  // the level descriptors in device memory (this solve's boxes), h_lev their pinned staging copy
+    VLevelDev *h_lev = nullptr;
+    int tailFirst = 0;           // index into lev of the first level the tail kernel handles (this solve)
+    ~VmgState() { for (void *p : allocs) (void)hipFree(p); if (h_lev) (void)hipHostFree(h_lev); }
 };
 
 static int vmg_alloc(flipv_context *c, VmgState *s, const Lay &L, size_t count, float **base) {
@@ -250,15 +440,18 @@ static int vmg_alloc(flipv_context *c, VmgState *s, const Lay &L, size_t count, 
     return FLIPV_OK;
 }
 
+static Vec3p v3(float *const p[3]) { Vec3p v; v.p[0] = p[0]; v.p[1] = p[1]; v.p[2] = p[2]; return v; }
 static VLevelDev dev_of(const VLevel &l) {
     VLevelDev d;
     d.L = l.L;
     for (int c = 0; c < 3; c++) for (int s = 0; s < VS; s++) d.coef[c][s] = l.coef[c][s];
+    d.x = v3(l.x); d.y = v3(l.y); d.b = v3(l.b); d.t = v3(l.t);
+    d.box = l.box;
     return d;
 }
-static Vec3p v3(float *const p[3]) { Vec3p v; v.p[0] = p[0]; v.p[1] = p[1]; v.p[2] = p[2]; return v; }
+static long box_positions(const Box3 &b) { return (long)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); }
 
-#define LGRID(Lv) dim3(cdiv((Lv).PX, 64), cdiv((Lv).PY, 4), (unsigned)(Lv).PZ), dim3(64, 4, 1)
+#define BGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
 
 }  // namespace
 
@@ -276,21 +469,32 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(ST), &T, sizeof(T)));
         s = new VmgState();
         c->vmgState = s;
+        for (auto &b : s->prevBox) { b.lo[0] = b.lo[1] = b.lo[2] = 0; b.hi[0] = b.hi[1] = b.hi[2] = 0; }
+        HIPCHK(c, hipMalloc((void **)&s->d_box, 8 * sizeof(int)));
+        s->allocs.push_back(s->d_box);
+        HIPCHK(c, hipMalloc((void **)&s->d_lev, VMG_MAX_LEVELS * sizeof(VLevelDev)));
+        s->allocs.push_back(s->d_lev);
+        HIPCHK(c, hipHostMalloc((void **)&s->h_lev, VMG_MAX_LEVELS * sizeof(VLevelDev)));
         float *base;
-        if ((rc = vmg_alloc(c, s, c->L, 6, &base))) return rc;
+        if ((rc = vmg_alloc(c, s, c->L, 9, &base))) return rc;
         const size_t per0 = c->L.n + 2 * c->L.guard;
-        for (int m = 0; m < 3; m++) { s->z[m] = base + (size_t)m * per0 + c->L.guard; s->q2[m] = base + (size_t)(3 + m) * per0 + c->L.guard; }
+        s->vecBlocks.push_back({base, 9 * per0 * sizeof(float)});
+        for (int m = 0; m < 3; m++) {
+            s->za[m] = base + (size_t)m * per0 + c->L.guard;
+            s->zb[m] = base + (size_t)(3 + m) * per0 + c->L.guard;
+            s->t0[m] = base + (size_t)(6 + m) * per0 + c->L.guard;
+        }
         Lay F = c->L;
         while (true) {
             const int mx = F.I > F.J ? (F.I > F.K ? F.I : F.K) : (F.J > F.K ? F.J : F.K);
-            static const int minDim = getenv("FLIPV_VMG_MINDIM") ? atoi(getenv("FLIPV_VMG_MINDIM")) : 4;
-            if (mx <= minDim || s->lev.size() >= 8) break;
+            static const int minDim = getenv("FLIPV_VMG_MINDIM") ? atoi(getenv("FLIPV_VMG_MINDIM")) : VMG_MIN_DIM;
+            if (mx <= minDim || (int)s->lev.size() >= VMG_MAX_LEVELS) break;
             VLevel l;
             l.L = coarse_lay(F);
             const size_t per = l.L.n + 2 * l.L.guard;
             float *cb, *vb;
             if ((rc = vmg_alloc(c, s, l.L, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, l.L, 12, &vb))) return rc;
-            s->coefBlocks.push_back({cb, per * 3 * VS * sizeof(float)});
+            s->vecBlocks.push_back({vb, per * 12 * sizeof(float)});
             for (int m = 0; m < 3; m++) {
                 for (int q = 0; q < VS; q++) l.coef[m][q] = cb + (size_t)(m * VS + q) * per + l.L.guard;
                 l.x[m] = vb + (size_t)m * per + l.L.guard;
@@ -302,9 +506,49 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             F = l.L;
         }
     }
-    // this solve's coarse operators; z and q2 must be zero wherever there is no row (the SpMV reads neighbours unmasked)
-    HIPCHK(c, hipMemsetAsync(s->z[0] - c->L.guard, 0, 6 * (c->L.n + 2 * c->L.guard) * sizeof(float), c->stream));
-    for (auto &b : s->coefBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));
+    // ---- this solve: the box of the rows, level by level
+    {
+        HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)s->d_box, 0x7fffffff, 3, c->stream));
+        HIPCHK(c, hipMemsetAsync(s->d_box + 3, 0, 3 * sizeof(int), c->stream));
+        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_tile_bbox, dim3(64), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, s->d_box));
+        int hb[6];
+        HIPCHK(c, hipMemcpyAsync(hb, s->d_box, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        Box3 fb;
+        const int ext0[3] = {c->L.I + 1, c->L.J + 1, c->L.K + 1};
+        for (int a = 0; a < 3; a++) { fb.lo[a] = hb[a] < 0 ? 0 : hb[a]; fb.hi[a] = hb[3 + a] > ext0[a] ? ext0[a] : hb[3 + a]; if (fb.hi[a] <= fb.lo[a]) { fb.lo[a] = 0; fb.hi[a] = 1; } }
+        for (size_t l = 0; l < s->lev.size(); l++) {
+            VLevel &A = s->lev[l];
+            const int ext[3] = {A.L.I + 1, A.L.J + 1, A.L.K + 1};
+            for (int a = 0; a < 3; a++) {   // parents of fine index p: p >> 1 and (p + 1) >> 1
+                A.box.lo[a] = fb.lo[a] >> 1;
+                A.box.hi[a] = (fb.hi[a] >> 1) + 1;
+                if (A.box.hi[a] > ext[a]) A.box.hi[a] = ext[a];
+                if (A.box.hi[a] <= A.box.lo[a]) A.box.hi[a] = A.box.lo[a] + 1;
+            }
+            fb = A.box;
+        }
+        // the tail: the coarsest levels whose boxes are small enough for one workgroup (the last level always)
+        s->tailFirst = (int)s->lev.size() - 1;
+        while (s->tailFirst > 0 && (int)s->lev.size() - (s->tailFirst - 1) <= VMG_TAIL_MAX && box_positions(s->lev[s->tailFirst - 1].box) <= VMG_TAIL_POS) s->tailFirst--;
+    }
+    for (size_t l = 0; l < s->lev.size(); l++) s->h_lev[l] = dev_of(s->lev[l]);
+    if (!s->lev.empty()) HIPCHK(c, hipMemcpyAsync(s->d_lev, s->h_lev, s->lev.size() * sizeof(VLevelDev), hipMemcpyHostToDevice, c->stream));
+    // the sweeps' vectors must be zero wherever there is no row (the SpMV and the restriction read neighbours unmasked)
+    for (auto &b : s->vecBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));
+    // this solve's coarse operators: zero them over the box they are about to be scattered into, united with the box the previous
+    // solve wrote (the sweeps never look outside the current box, but the next solve's box may)
+    for (size_t l = 0; l < s->lev.size(); l++) {
+        VLevel &A = s->lev[l];
+        Box3 z = A.box;
+        const Box3 &pb = s->prevBox[l];
+        if (pb.hi[0] > pb.lo[0]) for (int a = 0; a < 3; a++) { if (pb.lo[a] < z.lo[a]) z.lo[a] = pb.lo[a]; if (pb.hi[a] > z.hi[a]) z.hi[a] = pb.hi[a]; }
+        ZeroSet Z;
+        Z.n = 3 * VS;
+        for (int m = 0; m < 3; m++) for (int q = 0; q < VS; q++) Z.p[m * VS + q] = A.coef[m][q];
+        hipLaunchKernelGGL(k_vmg_zero_box, BGRID(z), 0, c->stream, Z, A.L, z);
+        s->prevBox[l] = A.box;
+    }
     if (!s->lev.empty()) {
         FineOp A;
         A.vm[0] = c->vmU; A.vm[1] = c->vmV; A.vm[2] = c->vmW;
@@ -313,87 +557,121 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_rap_fine, dim3(pcg_grid(c, c->nActiveV)), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A,
                            dev_of(s->lev[0])));
         for (size_t l = 0; l + 1 < s->lev.size(); l++)
-            hipLaunchKernelGGL(k_vmg_rap, LGRID(s->lev[l].L), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
+            hipLaunchKernelGGL(k_vmg_rap, BGRID(s->lev[l].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
     }
-    if (getenv("FLIPV_VMG_DEBUG")) { unsigned h[2]; (void)hipStreamSynchronize(c->stream); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dropped), sizeof(h)); fprintf(stderr, "vmg dropped entries: out of range %u, no slot %u\n", h[0], h[1]); }
+    if (getenv("FLIPV_VMG_DEBUG")) {
+        unsigned h[2];
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dropped), sizeof(h));
+        fprintf(stderr, "vmg dropped entries: out of range %u, no slot %u; levels %zu, tail from %d\n", h[0], h[1], s->lev.size(), s->tailFirst);
+        for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d)\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]); }
+    }
     HIPCHK(c, hipGetLastError());
     *out = s;
     return FLIPV_OK;
 }
 
-// coarse level l (index into s->lev): x <- V-cycle(b), result in lev[l].x
-static void vmg_coarse(flipv_context *c, VmgState *s, size_t l) {
-    VLevel &A = s->lev[l];
-    const VLevelDev Ad = dev_of(A);
-    const bool last = l + 1 == s->lev.size();
-    hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.x), v3(A.b), v3(A.x), 0);      // x = omega b/d
-    if (last) {
-        static const int sweeps = getenv("FLIPV_VMG_SWEEPS") ? atoi(getenv("FLIPV_VMG_SWEEPS")) : VMG_COARSEST_SWEEPS;
-        for (int q = 0; q < sweeps; q += 2) {
-            hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.x), v3(A.b), v3(A.y), 1);
-            hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.y), v3(A.b), v3(A.x), 1);
-        }
-        return;
-    }
-    hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.x), v3(A.b), v3(A.y), 1);      // second pre-sweep -> y
-    hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.y), v3(A.b), v3(A.t), 2);      // t = b - A y
-    VLevel &C = s->lev[l + 1];
-    hipLaunchKernelGGL(k_vmg_restrict, LGRID(C.L), 0, c->stream, A.L, C.L, v3(A.t), v3(C.b));
-    vmg_coarse(c, s, l + 1);
-    hipLaunchKernelGGL(k_vmg_prolong, LGRID(A.L), 0, c->stream, A.L, C.L, v3(A.y), v3(C.x), (const uint8_t *)nullptr);
-    hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.y), v3(A.b), v3(A.t), 1);      // post-sweeps: y -> t -> x
-    hipLaunchKernelGGL(k_vmg_op, LGRID(A.L), 0, c->stream, Ad, v3(A.t), v3(A.b), v3(A.x), 1);
-}
-
-// z = M^-1 r (level 0), (r, z) into sig(it_next)
-static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_next) {
+// z = M^-1 r (level 0) into zb, (r, z) into sig(it + sig_shift).  On entry za = omega r/d (k_vpcg_xr left it).
+// it_arg = IT_DEVICE: the device-side iteration counter (inside the replayed graph)
+static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_arg, int sig_shift) {
     const int nb = pcg_grid(c, c->nActiveV);
     const dim3 blk(64, 4, 1);
+    const int it_spmv = it_arg == IT_DEVICE ? -1 : it_arg;   // the SpMV kernel's spelling of "device-side counter"
     float *dg[3] = {c->vDiagU, c->vDiagV, c->vDiagW};
-    float *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
-    PcgScal none;
-    memset(&none, 0, sizeof(none));
-#define FINE(mode, scal, itn) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(dg), v3(r), v3(s->z), v3(s->q2), mode, scal, itn))
-    FINE(0, none, 0);                                  // z = omega r/d
-    fv_visc_apply_f32(c, s->z, s->q2); FINE(1, none, 0);   // second pre-sweep
+    const int *conv = sc.conv;
+    fv_visc_sweep_f32(c, s->za, s->zb, 1, sc, it_spmv, VMG_OMEGA, 0);                       // second pre-sweep: za -> zb
     if (!s->lev.empty()) {
-        fv_visc_apply_f32(c, s->z, s->q2); FINE(2, none, 0);   // q2 = r - A z
-        VLevel &C = s->lev[0];
-        hipLaunchKernelGGL(k_vmg_restrict, LGRID(C.L), 0, c->stream, c->L, C.L, v3(s->q2), v3(C.b));
-        vmg_coarse(c, s, 0);
-        hipLaunchKernelGGL(k_vmg_prolong, LGRID(c->L), 0, c->stream, c->L, C.L, v3(s->z), v3(C.x), (const uint8_t *)c->vRowMask);
+        fv_visc_sweep_f32(c, s->zb, s->t0, 2, sc, it_spmv, VMG_OMEGA, 0);                   // t0 = r - A zb
+        const int nl = (int)s->lev.size(), t0 = s->tailFirst;
+        const Lay &F0 = c->L;
+        const Vec3p ft0 = v3(s->t0);
+#define SGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), 3u * (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
+#define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), SGRID(s->lev[l_].box), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv)
+        for (int l = 0; l < t0; l++) {   // down
+            STEP(OP_RESTRICT, l);
+            STEP(OP_PRE2, l);
+            STEP(OP_RESID, l);
+        }
+        {
+            static const int sweeps = getenv("FLIPV_VMG_SWEEPS") ? (atoi(getenv("FLIPV_VMG_SWEEPS")) + 1) / 2 * 2 : VMG_COARSEST_SWEEPS;
+            hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, sweeps, F0, ft0, conv);
+        }
+        for (int l = t0 - 1; l >= 0; l--) {   // up
+            STEP(OP_PROLONG, l);
+            STEP(OP_POST1, l);
+            STEP(OP_POST2, l);
+        }
+#undef STEP
+#undef SGRID
+        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
+                           v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
     }
-    fv_visc_apply_f32(c, s->z, s->q2); FINE(1, none, 0);   // post-sweeps
-    fv_visc_apply_f32(c, s->z, s->q2); FINE(3, sc, it_next);
-#undef FINE
+    fv_visc_sweep_f32(c, s->zb, s->za, 1, sc, it_spmv, VMG_OMEGA, 0);                       // post-sweeps: zb -> za -> zb
+    fv_visc_sweep_f32(c, s->za, s->zb, 3, sc, it_spmv, VMG_OMEGA, sig_shift);
 }
 
 // PCG with the V-cycle as preconditioner.  On entry k_visc_setup has left r = rhs, x = 0, s (= p) = 0 and the tile list;
-// the scalars' slot blocks are zero.  spmv(it) computes q = A p with a(it) = p.q.
-int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv)(flipv_context *, const PcgScal &, int), int *conv_out) {
+// the scalars' slot blocks are zero.  spmv(it) computes q = A p with a(it) = p.q (it = -1: the device-side counter).
+int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*spmv)(flipv_context *, const PcgScal &, int), int *conv_out) {
     VmgState *s = nullptr;
     int rc = vmg_setup(c, &s);
     if (rc) return rc;
+    PcgScal sc = sc_in;
+    sc.noB = 1;   // this loop needs p.q only: the SpMV variant that does not read the residual
     const int nb = pcg_grid(c, c->nActiveV);
     const dim3 blk(64, 4, 1);
+    float *dg[3] = {c->vDiagU, c->vDiagV, c->vDiagW};
     float *x[3] = {(float *)c->vX[0], (float *)c->vX[1], (float *)c->vX[2]}, *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
     float *p[3] = {(float *)c->vS[0], (float *)c->vS[1], (float *)c->vS[2]}, *q[3] = {(float *)c->vZ[0], (float *)c->vZ[1], (float *)c->vZ[2]};
-    vmg_vcycle(c, s, sc, 0);
-    GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(s->z), v3(p), sc, -1));
-    const int every = c->prm.check_every > 0 ? c->prm.check_every : 4;
-    int conv = -1, it = 0;
-    while (it < cap && conv < 0) {
-        const int stop = it + every < cap ? it + every : cap;
-        for (; it < stop; it++) {
-            spmv(c, sc, it);
-            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(x), v3(r), v3(p), v3(q), sc, it));
-            vmg_vcycle(c, s, sc, it + 1);
-            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, v3(s->z), v3(p), sc, it));
+#define XR(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), VMG_OMEGA, sc, it_))
+#define PP(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, v3(s->zb), v3(p), sc, it_))
+    HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
+    XR(-1);                       // za = omega r/d
+    vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)
+    PP(-1);                       // p = z
+    const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
+    int conv = -1;
+    auto iteration = [&](int it) {   // it = IT_DEVICE inside the graph
+        spmv(c, sc, it == IT_DEVICE ? -1 : it);
+        XR(it);
+        vmg_vcycle(c, s, sc, it, 1);
+        PP(it);
+    };
+    const bool graph = !c->prm.kernel_timing && !c->prm.no_graph_replay;
+    if (graph) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        for (int e = 0; e < every; e++) iteration(IT_DEVICE);
+        hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+        if (e1 != hipSuccess || e2 != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            c->err = "viscosity multigrid: stream capture failed";
+            return FLIPV_ERR_HIP;
         }
-        HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        conv = c->h_flags[0];
+        hipError_t e3 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (e3 != hipSuccess) { (void)hipGraphDestroy(g); c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3); return FLIPV_ERR_HIP; }
+        for (int done = 0; done < cap && conv < 0; done += every) {
+            hipError_t el = hipGraphLaunch(ge, c->stream);
+            hipError_t es = hipStreamSynchronize(c->stream);
+            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+            conv = c->h_flags[0];
+        }
+        (void)hipGraphExecDestroy(ge);
+        (void)hipGraphDestroy(g);
+    } else {
+        int it = 0;
+        while (it < cap && conv < 0) {
+            const int stop = it + every < cap ? it + every : cap;
+            for (; it < stop; it++) iteration(it);
+            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            conv = c->h_flags[0];
+        }
     }
+#undef XR
+#undef PP
     HIPCHK(c, hipGetLastError());
     *conv_out = conv;
     return FLIPV_OK;
