@@ -183,6 +183,10 @@ def main():
     ap.add_argument("--viscosity-cap", type=int, default=700,
                     help="iteration cap of the viscosity PCG: 700 = the reference's (equal-work timing, SURVEY 8d mode A); "
                          "a large value runs the solve to its 1e-6 tolerance (equal-accuracy, mode B)")
+    ap.add_argument("--viscosity-preconditioner", choices=["diagonal", "multigrid"], default="diagonal",
+                    help="diagonal = the library default (what the headline is timed with); multigrid = the Galerkin multigrid V-cycle "
+                         "(flipv_params.viscosity_preconditioner, one GPU, fp32): converges where the diagonal runs into the cap "
+                         "(256^3: ~120-140 iterations / 47 ms against 2 000-2 400 / 84-102 ms; use with --viscosity-cap 20000 for mode B)")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bunny",
                     help="bunny = BASELINE configs[2] (the metric's scene); honey = configs[3] (rod + sheet, use --viscosity 50); "
@@ -261,6 +265,8 @@ def main():
     c.set_viscosity(args.viscosity)
     c.set_gravity(0.0, -9.81, 0.0)
     c.set_params(precision=args.precision, kernel_timing=0, viscosity_max_iterations=args.viscosity_cap)
+    if args.viscosity_preconditioner == "multigrid":
+        c.set_params(viscosity_preconditioner=capi.PRECOND_MULTIGRID)
     c.particles = particles
     dev_name = c.device_name()
 
@@ -354,7 +360,7 @@ def main():
             "config": {
                 "workload": WORKLOADS[args.workload][3] % ((N, args.viscosity) if args.workload != "sheet" else (GI, GJ, GK, args.viscosity)),
                 "grid": [GI, GJ, GK], "particles_rank0": int(len(particles)), "dt": 0.01,
-                "viscosity_cap": args.viscosity_cap, "parallelism": decomposition,
+                "viscosity_cap": args.viscosity_cap, "viscosity_preconditioner": args.viscosity_preconditioner, "parallelism": decomposition,
             },
             "device": dev_name,
             "phase_ms": {k: float(np.mean([st["phase_ms"][k] for st in stats])) for k in last["phase_ms"]},

@@ -43,7 +43,7 @@ def test_default_params_chained_substeps_match_reference_dumps(name):
     c.close()
 
 
-def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap=0, vel0=None):
+def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap=0, vel0=None, multigrid=False):
     """GPU (default parameters unless lift_cap) and oracle (its defaults = the reference's, unless lift_cap) side by side;
     returns per substep (error, gpu stats, oracle viscosity info, oracle pressure info)"""
     from flipviscosity3d_amd.capi import Context
@@ -56,6 +56,9 @@ def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap
     if lift_cap:
         c.set_params(viscosity_max_iterations=lift_cap)
         o.set_solver_limits(vmaxiter=lift_cap)
+    if multigrid:
+        from flipviscosity3d_amd.capi import PRECOND_MULTIGRID
+        c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
     c.particles = P
     o.particles = P
     out = []
@@ -69,15 +72,19 @@ def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap
     return out, perr
 
 
-def test_config1_default_scene_64_default_params(oracle):
+@pytest.mark.parametrize("precond", ["default", "multigrid"])
+def test_config1_default_scene_64_default_params(oracle, precond):
     """BASELINE configs[0]: bunny in sphere_large, 64^3, nu = 5 (reference main.cpp), 3 chained substeps, default
-    parameters on both sides.  The reference needs 368/427/313 viscosity iterations here: inside its cap."""
+    parameters on both sides.  The reference needs 368/427/313 viscosity iterations here: inside its cap.
+    Variant multigrid: flipv_params.viscosity_preconditioner = MULTIGRID, every other parameter the default."""
     dx, solid, P = build_host_scene(64, ("sphere_large.ply", True), ["stanford_bunny.ply"])
     assert len(P) == 73176                                        # SURVEY.md 8c
-    out, perr = run_against_live_oracle(oracle, 64, dx, solid, P, 5.0, 3)
+    out, perr = run_against_live_oracle(oracle, 64, dx, solid, P, 5.0, 3, multigrid=precond == "multigrid")
     for t, (err, st, vi, pi) in enumerate(out):
         assert vi["status"] == 0 and vi["iterations"] == (368, 427, 313)[t]
         assert st["viscosity"]["status"] == 0, st["viscosity"]    # converged inside the default cap of 700
+        if precond == "multigrid":
+            assert st["viscosity"]["preconditioner"] == 1 and st["viscosity"]["iterations"] < 100, st["viscosity"]
         assert err <= VEL_TOL, (t, err)
     assert perr <= 1e-5
 
@@ -116,21 +123,29 @@ def test_config2_variant_resting_cube_64_default_params(oracle):
     assert perr <= 1e-5
 
 
-def test_config4_miniature_honey_rod_on_sheet_nu50():
+@pytest.mark.parametrize("precond", ["diagonal", "multigrid", "multigrid_stock_cap"])
+def test_config4_miniature_honey_rod_on_sheet_nu50(precond):
     """BASELINE configs[3] in miniature against the committed reference dump honey64_nu50: rod.ply + sheet.ply added with
     two add-liquid calls, nu = 50, 64^3.  The reference's own MIC(0) solve needs 1184 / 1954 iterations here -- beyond
     its stock cap of 700 -- so the dump was made with the cap lifted and this test lifts the GPU cap likewise (every
-    other parameter is the default): the comparison is between converged answers."""
-    from flipviscosity3d_amd.capi import Context
+    other parameter is the default): the comparison is between converged answers.  With the multigrid preconditioner
+    (flipv_params.viscosity_preconditioner) the solve converges well inside the STOCK cap, so that variant leaves the cap alone too."""
+    from flipviscosity3d_amd.capi import Context, PRECOND_MULTIGRID
     g = Golden("honey64_nu50")
     c = Context(g.I, g.J, g.K, g.dx)
     c.set_solid_sdf(g["solid"])
     c.set_viscosity(float(g["nu"]))
-    c.set_params(viscosity_max_iterations=int(g["vcap"]))
+    if precond != "multigrid_stock_cap":
+        c.set_params(viscosity_max_iterations=int(g["vcap"]))
+    if precond != "diagonal":
+        c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
     c.particles = g["particles0"]
     for t in range(g.nsub):
         st = c.substep(g.dt)
         assert st["viscosity"]["status"] == 0, st["viscosity"]
+        assert st["viscosity"]["preconditioner"] == (0 if precond == "diagonal" else 1)
+        if precond != "diagonal":
+            assert st["viscosity"]["iterations"] < 200, st["viscosity"]
         assert vel_err(c, g.uvw(t, "final")) <= VEL_TOL
         assert np.abs(c.particles[:, :3] - g["s%d_particles" % t][:, :3]).max() <= 1e-5
     c.close()
@@ -154,22 +169,29 @@ def test_config4_miniature_with_the_stock_cap_follows_the_acceptance_rule():
     c.close()
 
 
-def test_config3_scene_128_converged_reference_probes():
+@pytest.mark.parametrize("precond", ["diagonal", "multigrid_stock_cap"])
+def test_config3_scene_128_converged_reference_probes(precond):
     """BASELINE configs[2]'s scene at 128^3, the largest size at which the reference converges (708 iterations with its
     cap lifted -- 8 beyond the stock cap -- SURVEY.md 7), against 20 000 probe faces per component of the reference's
-    converged output, two chained substeps.  The GPU cap is lifted like the reference's was; everything else is default."""
-    from flipviscosity3d_amd.capi import Context
+    converged output, two chained substeps.  The GPU cap is lifted like the reference's was; everything else is default.
+    Variant multigrid_stock_cap: the multigrid-preconditioned solve with the STOCK cap of 700 (it converges in ~100 iterations):
+    every parameter but the preconditioner is the default, and the answer is the reference's converged one."""
+    from flipviscosity3d_amd.capi import Context, PRECOND_MULTIGRID
     g = Golden("bunny128_nu5_converged")
     dx, solid, P = build_host_scene(128, ("sphere_large.ply", True), ["stanford_bunny.ply"])
     assert len(P) == int(g["nparticles"]) and np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])
     c = Context(128, 128, 128, dx)
     c.set_solid_sdf(solid)
     c.set_viscosity(float(g["nu"]))
-    c.set_params(viscosity_max_iterations=int(g["vcap"]))
+    if precond == "diagonal":
+        c.set_params(viscosity_max_iterations=int(g["vcap"]))
+    else:
+        c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
     c.particles = P
     for t in range(g.nsub):
         st = c.substep(g.dt)
         assert st["viscosity"]["status"] == 0, st["viscosity"]
+        assert st["viscosity"]["preconditioner"] == (0 if precond == "diagonal" else 1)
         num = den = 0.0
         for n in "UVW":
             a = c.grid(n).reshape(-1)
