@@ -101,12 +101,22 @@ struct VLevel {          // a coarse level (>= 1)
     float *coef[3][VS];
     float *x[3], *y[3], *b[3], *t[3];
     Box3 box;
+    int *strips = nullptr, *stripFlag = nullptr;   // capacity: the strips of the level's whole index space
+    int nstrips = 0;
 };
 struct VLevelDev {       // what kernels need of a coarse level
     Lay L;
     float *coef[3][VS];
     Vec3p x, y, b, t;
     Box3 box;
+    // strips: runs of 64 consecutive i of one (j, k) row of the box that hold at least one row of the operator, in box order
+    // (i fastest); the sweeps of a level visit only these (the liquid fills 10-20 % of its bounding box on the coarse levels too)
+    const int *strips;
+    int nstrips;
+    // the coarsest level: per component the rows (as box positions), at most 1024 each, for the LDS-resident sweeps; rowcnt[3] = 1
+    // when box and rows fit
+    const int *rowlist;   // [3][1024]
+    const int *rowcnt;    // [4]
 };
 struct FineOp {          // the matrix-free level 0 (k_viscosity.hip's arrays)
     const float *vm[3];
@@ -268,14 +278,81 @@ template <int OP>
 __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv) {
     if (*conv >= 0) return;
     const VLevelDev &A = lev[l];
-    const int c = (int)blockIdx.z % 3;
-    const int i = A.box.lo[0] + blockIdx.x * 64 + threadIdx.x, j = A.box.lo[1] + blockIdx.y * 4 + threadIdx.y, k = A.box.lo[2] + (int)blockIdx.z / 3;
-    if (i >= A.box.hi[0] || j >= A.box.hi[1]) return;
+    const int sidx = (int)blockIdx.x * 4 + (int)threadIdx.y;   // a wave per strip and component
+    if (sidx >= A.nstrips) return;
+    const int c = (int)blockIdx.y;
+    const int code = A.strips[sidx];
+    const int nsx = (A.box.hi[0] - A.box.lo[0] + 63) >> 6, h = A.box.hi[1] - A.box.lo[1];
+    const int sx = code % nsx, r = code / nsx;
+    const int i = A.box.lo[0] + sx * 64 + (int)threadIdx.x, j = A.box.lo[1] + r % h, k = A.box.lo[2] + r / h;
+    if (i >= A.box.hi[0]) return;
     if (OP == OP_RESTRICT) {
         if (l == 0) d_vmg_step_c<OP>(c, A, F0, ft0, A.L, ft0, i, j, k);
         else d_vmg_step_c<OP>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
     } else if (OP == OP_PROLONG) d_vmg_step_c<OP>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
     else d_vmg_step_c<OP>(c, A, A.L, ft0, A.L, ft0, i, j, k);
+}
+// strips of a level's box that hold rows: flags (one wave per strip), then an ordered compaction by one workgroup
+__global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__restrict__ flag) {
+    const int nsx = (A.box.hi[0] - A.box.lo[0] + 63) >> 6, h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
+    const int sidx = (int)blockIdx.x * 4 + (int)threadIdx.y;
+    if (sidx >= nsx * h * dz) return;
+    const int sx = sidx % nsx, r = sidx / nsx;
+    const int i = A.box.lo[0] + sx * 64 + (int)threadIdx.x, j = A.box.lo[1] + r % h, k = A.box.lo[2] + r / h;
+    bool any = false;
+    if (i < A.box.hi[0]) {
+        const size_t ci = gidx(A.L, i, j, k);
+        any = A.coef[0][slot_diag(0)][ci] != 0.0f || A.coef[1][slot_diag(1)][ci] != 0.0f || A.coef[2][slot_diag(2)][ci] != 0.0f;
+    }
+    const unsigned long long m = __ballot(any);
+    if (threadIdx.x == 0) flag[sidx] = m != 0ull;
+}
+__global__ __launch_bounds__(1024) void k_vmg_strip_compact(const int *__restrict__ flag, int n, int *__restrict__ list, int *__restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int start = 0; start < n; start += 1024) {
+        const int t = start + (int)threadIdx.x;
+        const int f = t < n ? flag[t] != 0 : 0;
+        const unsigned long long m = __ballot(f);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int q = 0; q < 16; q++) { if (q < wv) woff += wsum[q]; total += wsum[q]; }
+        if (f) list[base + woff + before] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+// the coarsest level's rows per component (box positions), for the LDS-resident sweeps of k_vmg_tail: out = [3][1024], cnt[0..2]
+// the row counts, cnt[3] = 1 if the box (with its rim) and every component's rows fit
+constexpr int VMG_LDS_POS = 4096;     // positions of the box including its rim
+__global__ __launch_bounds__(1024) void k_vmg_coarsest_rows(VLevelDev A, int *__restrict__ out, int *__restrict__ cnt) {
+    __shared__ int n[3];
+    if (threadIdx.x < 3) n[threadIdx.x] = 0;
+    __syncthreads();
+    const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
+    const int npos = w * h * dz;
+    const bool fits = (w + 2) * (h + 2) * (dz + 2) <= VMG_LDS_POS;
+    if (fits)
+        for (int base = 0; base < 3 * npos; base += 1024) {   // in order within a component (a wave's rows stay neighbours)
+            const int q = base + (int)threadIdx.x;
+            int c = 0, r = 0;
+            bool row = false;
+            if (q < 3 * npos) {
+                c = q / npos; r = q - c * npos;
+                row = A.coef[c][slot_diag(c)][gidx(A.L, A.box.lo[0] + r % w, A.box.lo[1] + (r / w) % h, A.box.lo[2] + r / (w * h))] != 0.0f;
+            }
+            if (row) { const int idx = atomicAdd(&n[c], 1); if (idx < 1024) out[c * 1024 + idx] = r; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 3) cnt[threadIdx.x] = n[threadIdx.x];
+    if (threadIdx.x == 0) cnt[3] = fits && n[0] <= 1024 && n[1] <= 1024 && n[2] <= 1024;
 }
 
 // the coarsest levels in one workgroup: levels lev[first..n), lev[first] restricts from lev[first - 1] (first = 0: from (F0, ft0))
@@ -294,7 +371,6 @@ __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, co
 // (the rows of each component are compacted into a list first), the three components' iterates sit in LDS boxes with a rim of
 // zeros, so a sweep is 23 LDS reads per row and one barrier instead of a round trip through L2 per row (16 sweeps at 16^3: 200 us
 // of the cycle's 520 before).  Falls back to the global-memory sweeps when the box or a component's row count does not fit.
-constexpr int VMG_LDS_POS = 4096;     // positions of the box including its rim
 struct CoarseRow { float cf[VS]; float invd, b; int li; size_t ci; bool has; };
 template <int C>
 __device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP) {
@@ -323,32 +399,18 @@ __device__ __forceinline__ void d_coarsest_sweep(const CoarseRow &R, const float
 
 __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, Lay F0, Vec3p ft0, const int *__restrict__ conv) {
     if (*conv >= 0) return;
-    // can the coarsest level live in LDS?  (decided before anything else: every thread takes the same path)
+    // the coarsest level lives in LDS when its box and rows fit (k_vmg_coarsest_rows decided that for this solve)
     __shared__ float xs[2 * 3 * VMG_LDS_POS];
-    __shared__ int rowlist[3][1024];
-    __shared__ int cnt[3];
     int W = 0, H = 0, NP = 0;
-    bool coarsest_in_lds = false;
-    {
+    const int *rowlist[3] = {lev[n - 1].rowlist, lev[n - 1].rowlist + 1024, lev[n - 1].rowlist + 2048};
+    int cnt[3] = {0, 0, 0};
+    const bool coarsest_in_lds = lev[n - 1].rowcnt[3] != 0;
+    if (coarsest_in_lds) {
         const VLevelDev &A = lev[n - 1];
-        const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
-        W = w + 2; H = h + 2; NP = W * H * (dz + 2);
-        if (NP <= VMG_LDS_POS) {
-            for (int e = threadIdx.x; e < 2 * 3 * VMG_LDS_POS; e += blockDim.x) xs[e] = 0.0f;
-            if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
-            __syncthreads();
-            const int npos = w * h * dz;
-            for (int q = threadIdx.x; q < 3 * npos; q += blockDim.x) {
-                const int c = q / npos, r = q - c * npos;
-                const size_t ci = gidx(A.L, A.box.lo[0] + r % w, A.box.lo[1] + (r / w) % h, A.box.lo[2] + r / (w * h));
-                if (A.coef[c][slot_diag(c)][ci] != 0.0f) {
-                    const int idx = atomicAdd(&cnt[c], 1);
-                    if (idx < 1024) rowlist[c][idx] = r;
-                }
-            }
-            __syncthreads();
-            coarsest_in_lds = cnt[0] <= 1024 && cnt[1] <= 1024 && cnt[2] <= 1024;
-        }
+        W = A.box.hi[0] - A.box.lo[0] + 2; H = A.box.hi[1] - A.box.lo[1] + 2; NP = W * H * (A.box.hi[2] - A.box.lo[2] + 2);
+        cnt[0] = A.rowcnt[0]; cnt[1] = A.rowcnt[1]; cnt[2] = A.rowcnt[2];
+        for (int e = threadIdx.x; e < 3 * NP; e += blockDim.x) { xs[e] = 0.0f; xs[3 * VMG_LDS_POS + e] = 0.0f; }
+        __syncthreads();
     }
     for (int l = first; l < n; l++) {   // down
         const VLevelDev &A = lev[l];
@@ -423,6 +485,7 @@ struct VmgState {
     std::vector<std::pair<void *, size_t>> vecBlocks;    // (base, bytes) of every level's vector storage, zeroed per solve
     Box3 prevBox[16];            // per coarse level: the box whose coefficients the previous solve wrote (hi <= lo: none yet)
     int *d_box = nullptr;
+    int *d_rowlist = nullptr, *d_rowcnt = nullptr, *d_stripCount = nullptr;   // coarsest level's rows; per level the number of listed strips
     VLevelDev *d_lev = nullptr;  // the level descriptors in device memory (this solve's boxes), h_lev their pinned staging copy
     VLevelDev *h_lev = nullptr;
     int tailFirst = 0;           // index into lev of the first level the tail kernel handles (this solve)
@@ -447,6 +510,8 @@ static VLevelDev dev_of(const VLevel &l) {
     for (int c = 0; c < 3; c++) for (int s = 0; s < VS; s++) d.coef[c][s] = l.coef[c][s];
     d.x = v3(l.x); d.y = v3(l.y); d.b = v3(l.b); d.t = v3(l.t);
     d.box = l.box;
+    d.strips = l.strips; d.nstrips = l.nstrips;
+    d.rowlist = nullptr; d.rowcnt = nullptr;
     return d;
 }
 static long box_positions(const Box3 &b) { return (long)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); }
@@ -472,6 +537,10 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         for (auto &b : s->prevBox) { b.lo[0] = b.lo[1] = b.lo[2] = 0; b.hi[0] = b.hi[1] = b.hi[2] = 0; }
         HIPCHK(c, hipMalloc((void **)&s->d_box, 8 * sizeof(int)));
         s->allocs.push_back(s->d_box);
+        HIPCHK(c, hipMalloc((void **)&s->d_rowlist, (3 * 1024 + 4 + VMG_MAX_LEVELS) * sizeof(int)));
+        s->allocs.push_back(s->d_rowlist);
+        s->d_rowcnt = s->d_rowlist + 3 * 1024;
+        s->d_stripCount = s->d_rowcnt + 4;
         HIPCHK(c, hipMalloc((void **)&s->d_lev, VMG_MAX_LEVELS * sizeof(VLevelDev)));
         s->allocs.push_back(s->d_lev);
         HIPCHK(c, hipHostMalloc((void **)&s->h_lev, VMG_MAX_LEVELS * sizeof(VLevelDev)));
@@ -495,6 +564,12 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             float *cb, *vb;
             if ((rc = vmg_alloc(c, s, l.L, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, l.L, 12, &vb))) return rc;
             s->vecBlocks.push_back({vb, per * 12 * sizeof(float)});
+            {
+                const size_t nstr = (size_t)cdiv(l.L.PX, 64) * l.L.PY * l.L.PZ;
+                HIPCHK(c, hipMalloc((void **)&l.strips, 2 * nstr * sizeof(int)));
+                s->allocs.push_back(l.strips);
+                l.stripFlag = l.strips + nstr;
+            }
             for (int m = 0; m < 3; m++) {
                 for (int q = 0; q < VS; q++) l.coef[m][q] = cb + (size_t)(m * VS + q) * per + l.L.guard;
                 l.x[m] = vb + (size_t)m * per + l.L.guard;
@@ -532,8 +607,6 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         s->tailFirst = (int)s->lev.size() - 1;
         while (s->tailFirst > 0 && (int)s->lev.size() - (s->tailFirst - 1) <= VMG_TAIL_MAX && box_positions(s->lev[s->tailFirst - 1].box) <= VMG_TAIL_POS) s->tailFirst--;
     }
-    for (size_t l = 0; l < s->lev.size(); l++) s->h_lev[l] = dev_of(s->lev[l]);
-    if (!s->lev.empty()) HIPCHK(c, hipMemcpyAsync(s->d_lev, s->h_lev, s->lev.size() * sizeof(VLevelDev), hipMemcpyHostToDevice, c->stream));
     // the sweeps' vectors must be zero wherever there is no row (the SpMV and the restriction read neighbours unmasked)
     for (auto &b : s->vecBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));
     // this solve's coarse operators: zero them over the box they are about to be scattered into, united with the box the previous
@@ -559,12 +632,34 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         for (size_t l = 0; l + 1 < s->lev.size(); l++)
             hipLaunchKernelGGL(k_vmg_rap, BGRID(s->lev[l].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
     }
+    // where the rows are on the levels that run as launches (strip lists) and on the coarsest one (row lists); then the level
+    // descriptors go to the device
+    if (!s->lev.empty()) {
+        for (int l = 0; l < s->tailFirst; l++) {
+            VLevel &A = s->lev[l];
+            const int nstr = (int)cdiv(A.box.hi[0] - A.box.lo[0], 64) * (A.box.hi[1] - A.box.lo[1]) * (A.box.hi[2] - A.box.lo[2]);
+            hipLaunchKernelGGL(k_vmg_strip_flags, dim3(cdiv(nstr, 4)), dim3(64, 4, 1), 0, c->stream, dev_of(A), A.stripFlag);
+            hipLaunchKernelGGL(k_vmg_strip_compact, dim3(1), dim3(1024), 0, c->stream, (const int *)A.stripFlag, nstr, A.strips, s->d_stripCount + l);
+        }
+        hipLaunchKernelGGL(k_vmg_coarsest_rows, dim3(1), dim3(1024), 0, c->stream, dev_of(s->lev.back()), s->d_rowlist, s->d_rowcnt);
+        int counts[VMG_MAX_LEVELS];
+        if (s->tailFirst > 0) {
+            HIPCHK(c, hipMemcpyAsync(counts, s->d_stripCount, s->tailFirst * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        for (size_t l = 0; l < s->lev.size(); l++) {
+            s->lev[l].nstrips = (int)l < s->tailFirst ? counts[l] : 0;
+            s->h_lev[l] = dev_of(s->lev[l]);
+            s->h_lev[l].rowlist = s->d_rowlist; s->h_lev[l].rowcnt = s->d_rowcnt;
+        }
+        HIPCHK(c, hipMemcpyAsync(s->d_lev, s->h_lev, s->lev.size() * sizeof(VLevelDev), hipMemcpyHostToDevice, c->stream));
+    }
     if (getenv("FLIPV_VMG_DEBUG")) {
         unsigned h[2];
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dropped), sizeof(h));
         fprintf(stderr, "vmg dropped entries: out of range %u, no slot %u; levels %zu, tail from %d\n", h[0], h[1], s->lev.size(), s->tailFirst);
-        for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d)\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2]); }
+        for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d), %d strips\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2], s->lev[l].nstrips); }
     }
     HIPCHK(c, hipGetLastError());
     *out = s;
@@ -585,8 +680,7 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
         const int nl = (int)s->lev.size(), t0 = s->tailFirst;
         const Lay &F0 = c->L;
         const Vec3p ft0 = v3(s->t0);
-#define SGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), 3u * (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
-#define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), SGRID(s->lev[l_].box), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv)
+#define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), dim3(cdiv(s->lev[l_].nstrips > 0 ? s->lev[l_].nstrips : 1, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv)
         for (int l = 0; l < t0; l++) {   // down
             STEP(OP_RESTRICT, l);
             STEP(OP_PRE2, l);
@@ -602,7 +696,6 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
             STEP(OP_POST2, l);
         }
 #undef STEP
-#undef SGRID
         GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
                            v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
     }
