@@ -321,6 +321,7 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->rmaskV) (void)hipFree(c->rmaskV);
     fv_mg_free(c);
     fv_vmg_free(c);
+    for (auto &ge : c->geCache) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
     if (c->binCnt) (void)hipFree(c->binCnt);
     if (c->haloBuf) (void)hipFree(c->haloBuf);
     if (c->xbuf) (void)hipFree(c->xbuf);

@@ -479,7 +479,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
         auto update = [&](int it) {
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pcg_update<T, 1, VW_P>), dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, L, v, sc, it));
         };
-        if ((rc = pcg_run(c, sc, cap, sh, 1, c->nIntP, c->nActiveP, spmv, update, &conv))) return rc;
+        if ((rc = pcg_run(c, sc, cap, sh, 1, c->nIntP, c->nActiveP, spmv, update, &conv, FV_GE_PRESSURE))) return rc;
     }
     const int last = conv >= 0 ? conv : cap - 1;
     hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);

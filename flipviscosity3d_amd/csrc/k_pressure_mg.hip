@@ -423,15 +423,13 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
         hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
         if (e1 != hipSuccess || e2 != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); c->err = "multigrid PCG: stream capture failed"; return FLIPV_ERR_HIP; }
-        hipError_t e3 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-        if (e3 != hipSuccess) { (void)hipGraphDestroy(g); c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3); return FLIPV_ERR_HIP; }
+        if ((rc = fv_graph_exec(c, FV_GE_PRESSURE_MG, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
         for (; it < cap && conv < 0; it += every) {
             hipError_t el = hipGraphLaunch(ge, c->stream);
             hipError_t es = hipStreamSynchronize(c->stream);
-            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
             conv = c->h_flags[0];
         }
-        (void)hipGraphExecDestroy(ge);
         (void)hipGraphDestroy(g);
         if (conv < 0) {   // cap reached: the stop test of the last iteration ran inside k_mgp_p already; nothing left to check
             HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -596,7 +596,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             else
                 GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_pcg_update<T, 3, 2>), dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, L, v, sc, it));
         };
-        if ((rc = pcg_run(c, sc, cap, sh, 3, c->nIntV, c->nActiveV, spmv, update, &conv))) return rc;
+        if ((rc = pcg_run(c, sc, cap, sh, 3, c->nIntV, c->nActiveV, spmv, update, &conv, FV_GE_VISCOSITY))) return rc;
         }
         const int last = conv >= 0 ? conv : cap - 1;
         hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
@@ -605,7 +605,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         res = c->h_scal[0];
         iters = conv >= 0 ? conv + 1 : cap;
         success = conv >= 0;
-        if (success && !useMg) {   // the stall guard (PcgScal) stops the loop through the same flag: that is not convergence
+        if (success) {   // the stall guard (PcgScal) stops the loop through the same flag: that is not convergence
             int st = 0;
             HIPCHK(c, hipMemcpy(&st, sc.stalled, sizeof(int), hipMemcpyDeviceToHost));
             if (st) { success = false; stalled = true; }

@@ -743,15 +743,13 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
             c->err = "viscosity multigrid: stream capture failed";
             return FLIPV_ERR_HIP;
         }
-        hipError_t e3 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-        if (e3 != hipSuccess) { (void)hipGraphDestroy(g); c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3); return FLIPV_ERR_HIP; }
+        if ((rc = fv_graph_exec(c, FV_GE_VISCOSITY_MG, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
         for (int done = 0; done < cap && conv < 0; done += every) {
             hipError_t el = hipGraphLaunch(ge, c->stream);
             hipError_t es = hipStreamSynchronize(c->stream);
-            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
             conv = c->h_flags[0];
         }
-        (void)hipGraphExecDestroy(ge);
         (void)hipGraphDestroy(g);
     } else {
         int it = 0;

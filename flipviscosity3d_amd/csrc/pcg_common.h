@@ -288,6 +288,24 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
 int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, bool dense, const uint8_t *mask, Run **runs, size_t *runCap, int *nruns,
                   int *runLen, unsigned **rmask, size_t *rmaskCap);
 
+// An executable for the freshly captured graph g: the slot's cached executable updated in place when the topology still matches,
+// a newly instantiated one otherwise (which then takes the slot).  The caller launches *ge and destroys g, never *ge.
+static int fv_graph_exec(flipv_context *c, int slot, hipGraph_t g, hipGraphExec_t *ge) {
+    static const bool reuse = !(getenv("FLIPV_GRAPH_REUSE") && atoi(getenv("FLIPV_GRAPH_REUSE")) == 0);
+    hipGraphExec_t &cached = c->geCache[slot];
+    if (cached && reuse) {
+        hipGraphNode_t bad = nullptr;
+        hipGraphExecUpdateResult res;
+        if (hipGraphExecUpdate(cached, g, &bad, &res) == hipSuccess) { *ge = cached; return FLIPV_OK; }
+        (void)hipGetLastError();
+    }
+    if (cached) { (void)hipGraphExecDestroy(cached); cached = nullptr; }
+    hipError_t e = hipGraphInstantiate(&cached, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { cached = nullptr; c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e); return FLIPV_ERR_HIP; }
+    *ge = cached;
+    return FLIPV_OK;
+}
+
 // The iteration loop shared by both solves.
 //   spmv(first, count, it)  enqueues K1 over list entries [first, first+count) on c->stream
 //   update(it)              enqueues K2 over the whole list
@@ -303,7 +321,7 @@ int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, boo
 // so the exchange hides behind the interior SpMV and the only exposed communication is one 1.3 KB all-reduce.
 template <class Spmv, class Update>
 static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray *sh, int nsh, int nInt, int nAct, Spmv spmv,
-                   Update update, int *conv_out) {
+                   Update update, int *conv_out, int geSlot) {
     // poll interval: an iteration after the stop costs two empty launches (~6 us) on one GPU but a halo exchange and an
     // all-reduce in a multi-rank run; a poll costs a read-back and a host wake-up (~14 us)
     const int every = c->prm.check_every > 0 ? c->prm.check_every : (c->comm ? 8 : 32);
@@ -335,15 +353,13 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
             c->err = "pcg_run: stream capture failed";
             return rc != FLIPV_OK ? rc : FLIPV_ERR_HIP;
         }
-        hipError_t e3 = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-        if (e3 != hipSuccess) { (void)hipGraphDestroy(g); c->err = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3); return FLIPV_ERR_HIP; }
+        if ((rc = fv_graph_exec(c, geSlot, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
         for (int done = 0; done < cap && conv < 0; done += every) {
             hipError_t el = hipGraphLaunch(ge, c->stream);
             hipError_t es = hipStreamSynchronize(c->stream);
-            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
             conv = c->h_flags[0];
         }
-        (void)hipGraphExecDestroy(ge);
         (void)hipGraphDestroy(g);
     } else {
         // Chunks of `every` iterations, each followed by a read-back of the stop flag into its own pinned slot.  The next

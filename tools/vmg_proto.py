@@ -142,11 +142,12 @@ def transfer(comp, ijk, dims, mode="lin"):
 
 class MG:
     def __init__(self, A, comp, ijk, dims, nu1=2, nu2=2, omega=0.6, min_dim=4, smoother="jacobi", cheb_deg=2, f32=False, mode="lin", coarse_sweeps=8,
-                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0):
+                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0, gamma_at=-1, omega_coarse=0.0):
         self.lev = []
         self.nu1, self.nu2, self.omega, self.smoother, self.cheb_deg, self.coarse_sweeps, self.cheb_lo = nu1, nu2, omega, smoother, cheb_deg, coarse_sweeps, cheb_lo
         self.alpha, self.gamma, self.nu_fine, self.nu_coarse = alpha, gamma, nu_fine, nu_coarse
         self.additive = additive
+        self.gamma_at, self.omega_coarse = gamma_at, omega_coarse   # gamma_at = l: only level l visits its coarser level gamma times
         while True:
             d = A.diagonal()
             if l1:   # l1-Jacobi: the smoother's diagonal is the row's absolute sum (times l1)
@@ -185,6 +186,8 @@ class MG:
         A, d = L["A"], L["d"]
         if self.smoother == "jacobi":
             om = self.omega if self.omega > 0 else -self.omega / (L["lam"] / 1.1)   # omega < 0: |omega| / lambda_max of the level
+            if l > 0 and self.omega_coarse:
+                om = self.omega_coarse
             for _ in range(n):
                 x = x + om * (b - A @ x) / d if x is not None else om * b / d
             return x
@@ -228,7 +231,7 @@ class MG:
         r = b - L["A"] @ x
         bc = L["P"].T @ r
         xc = self.cycle(l + 1, bc)
-        for _ in range(self.gamma - 1):   # W-cycle: second visit, as a correction on the coarse level
+        for _ in range((self.gamma if self.gamma_at in (-1, l) else 1) - 1):   # W-cycle: second visit, as a correction on the coarse level
             Ac = self.lev[l + 1]["A"]
             xc = xc + self.cycle(l + 1, bc - Ac @ xc)
         x = x + self.alpha * (L["P"] @ xc)
