@@ -88,7 +88,10 @@ typedef struct flipv_params {
     int check_every;             /* convergence poll interval in iterations; 0 (default) = 32 on one GPU, 8 with a communicator */
     /* solver choice (enum flipv_preconditioner) */
     int pressure_preconditioner; /* AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
-    int viscosity_preconditioner;/* AUTO = the diagonal; MULTIGRID = Galerkin multigrid (fp32 vectors, one rank) */
+    int viscosity_preconditioner;/* AUTO = the diagonal; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors, one rank; other solves fall
+                                    back to the diagonal and say so in flipv_solve_info.preconditioner).  Converges in 15-250 iterations
+                                    where the diagonal needs 200-4 000: the choice when the solve is to CONVERGE (256^3: 43-47 ms against
+                                    76-102 ms); 700 capped diagonal iterations, the reference's own budget, cost 29 ms */
     /* measurement / test switches, all 0 by default; results do not depend on them beyond solver tolerance */
     int no_graph_replay;         /* 1: the PCG loop is launched kernel by kernel instead of replayed as a hipGraph */
     int unbinned_scatter;        /* 1: particle scatters with global atomics instead of LDS tiles (A/B) */
@@ -116,7 +119,8 @@ typedef struct flipv_solve_info {
     int rows;            /* unknowns */
     int active_tiles;    /* tiles swept per launch */
     int total_tiles;
-    int preconditioner;  /* 0 diagonal, 1 aggregation multigrid (pressure with fp32 vectors; rank-local V-cycle under slabs) */
+    int preconditioner;  /* 0 diagonal, 1 multigrid (pressure: aggregation V-cycle with fp32 vectors, rank-local under blocks; viscosity:
+                            the opt-in Galerkin V-cycle) */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */

@@ -142,12 +142,13 @@ def transfer(comp, ijk, dims, mode="lin"):
 
 class MG:
     def __init__(self, A, comp, ijk, dims, nu1=2, nu2=2, omega=0.6, min_dim=4, smoother="jacobi", cheb_deg=2, f32=False, mode="lin", coarse_sweeps=8,
-                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0, gamma_at=-1, omega_coarse=0.0):
+                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0, gamma_at=-1, omega_coarse=0.0, nu_deep=0, deep_from=2):
         self.lev = []
         self.nu1, self.nu2, self.omega, self.smoother, self.cheb_deg, self.coarse_sweeps, self.cheb_lo = nu1, nu2, omega, smoother, cheb_deg, coarse_sweeps, cheb_lo
         self.alpha, self.gamma, self.nu_fine, self.nu_coarse = alpha, gamma, nu_fine, nu_coarse
         self.additive = additive
-        self.gamma_at, self.omega_coarse = gamma_at, omega_coarse   # gamma_at = l: only level l visits its coarser level gamma times
+        self.gamma_at, self.omega_coarse = gamma_at, omega_coarse
+        self.nu_deep, self.deep_from = nu_deep, deep_from   # levels >= deep_from smooth nu_deep times (0: like the others)   # gamma_at = l: only level l visits its coarser level gamma times
         while True:
             d = A.diagonal()
             if l1:   # l1-Jacobi: the smoother's diagonal is the row's absolute sum (times l1)
@@ -227,6 +228,8 @@ class MG:
         nu1, nu2 = (self.nu_fine, self.nu_fine) if (l == 0 and self.nu_fine) else (self.nu1, self.nu2)
         if l > 0 and self.nu_coarse:
             nu1 = nu2 = self.nu_coarse
+        if self.nu_deep and l >= self.deep_from:
+            nu1 = nu2 = self.nu_deep
         x = self.smooth(l, None, b, nu1)
         r = b - L["A"] @ x
         bc = L["P"].T @ r
