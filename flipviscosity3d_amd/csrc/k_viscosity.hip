@@ -575,7 +575,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (c->prm.viscosity_update_grid_cap > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.viscosity_update_grid_cap) nb = c->prm.viscosity_update_grid_cap; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
         const dim3 blk(64, 4, 1);
         const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
-        const bool useMg = std::is_same<T, float>::value && !c->comm && c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID && c->vwV == 4;
+        const bool useMg = std::is_same<T, float>::value && !c->comm && !c->isBlock && c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID && c->vwV == 4;   // (the hierarchy is built over a whole, single-rank index space)
         li.preconditioner = useMg ? 1 : 0;
         if (useMg) {
             if ((rc = fv_viscosity_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); },
