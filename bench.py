@@ -10,6 +10,8 @@ viscosity PCG (reference cap 700 iterations, rel. tol 1e-6: "equal-work" mode A 
 pressure PCG + extrapolation + constrain + G2P/RK2 advection.  A "step" is one substep of
 min(CFL step, 0.01 s) exactly as FluidSimulation::advance takes them (fluidsimulation.cpp:138-167).
 Inputs are resident in HBM before the timed region; value = grid cells / wall seconds per substep.
+(The face weights and face states, functions of the solid SDF alone, are cached across substeps -- the reference recomputes
+them every substep, fluidsimulation.cpp:585; ~0.2 ms of a 31-37 ms substep)
 
 Extra objects on the JSON line:
   roofline     -- the dominant kernel of the substep, the matrix-free viscosity SpMV.  Unit = one MAC cell's worth of
