@@ -6,7 +6,9 @@
 Workload (N=1): BASELINE.json configs[2] -- 256^3 grid, stanford_bunny.ply dropped inside the inverted
 sphere_large.ply container, viscosity 5 at every node, gravity (0,-9.81,0), 8 jittered particles per cell
 (counter-based RNG, seed 0), full substep: particle SDF + P2G + extrapolation + body force + variational
-viscosity PCG (reference cap 700 iterations, rel. tol 1e-6: "equal-work" mode A of SURVEY.md 8d) +
+viscosity PCG (reference cap 700 iterations, rel. tol 1e-6: "equal-work" mode A of SURVEY.md 8d; the library's default
+picks the preconditioner per solve -- the diagonal, which runs into that cap during the stiff first dozen substeps exactly as the
+reference's MIC(0) solve does, or the multigrid V-cycle, which converges in 15-60 iterations once the liquid moves) +
 pressure PCG + extrapolation + constrain + G2P/RK2 advection.  A "step" is one substep of
 min(CFL step, 0.01 s) exactly as FluidSimulation::advance takes them (fluidsimulation.cpp:138-167).
 Inputs are resident in HBM before the timed region; value = grid cells / wall seconds per substep.
@@ -185,10 +187,10 @@ def main():
     ap.add_argument("--viscosity-cap", type=int, default=700,
                     help="iteration cap of the viscosity PCG: 700 = the reference's (equal-work timing, SURVEY 8d mode A); "
                          "a large value runs the solve to its 1e-6 tolerance (equal-accuracy, mode B)")
-    ap.add_argument("--viscosity-preconditioner", choices=["diagonal", "multigrid"], default="diagonal",
-                    help="diagonal = the library default (what the headline is timed with); multigrid = the Galerkin multigrid V-cycle "
-                         "(flipv_params.viscosity_preconditioner, one GPU, fp32): converges where the diagonal runs into the cap "
-                         "(256^3: ~120-140 iterations / 47 ms against 2 000-2 400 / 84-102 ms; use with --viscosity-cap 20000 for mode B)")
+    ap.add_argument("--viscosity-preconditioner", choices=["auto", "diagonal", "multigrid"], default="auto",
+                    help="auto = the library default (flipv_params.viscosity_preconditioner = AUTO: per solve the diagonal or the Galerkin "
+                         "multigrid V-cycle, whichever the previous solve's iteration count predicts to be cheaper; what the headline is "
+                         "timed with); diagonal / multigrid pin one (multigrid: one GPU, fp32)")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bunny",
                     help="bunny = BASELINE configs[2] (the metric's scene); honey = configs[3] (rod + sheet, use --viscosity 50); "
@@ -267,8 +269,8 @@ def main():
     c.set_viscosity(args.viscosity)
     c.set_gravity(0.0, -9.81, 0.0)
     c.set_params(precision=args.precision, kernel_timing=0, viscosity_max_iterations=args.viscosity_cap)
-    if args.viscosity_preconditioner == "multigrid":
-        c.set_params(viscosity_preconditioner=capi.PRECOND_MULTIGRID)
+    if args.viscosity_preconditioner != "auto":
+        c.set_params(viscosity_preconditioner=capi.PRECOND_MULTIGRID if args.viscosity_preconditioner == "multigrid" else capi.PRECOND_DIAGONAL)
     c.particles = particles
     dev_name = c.device_name()
 
@@ -368,6 +370,7 @@ def main():
             "phase_ms": {k: float(np.mean([st["phase_ms"][k] for st in stats])) for k in last["phase_ms"]},
             "phase_ms_note": "mean over the timed substeps (GPU time per phase, HIP events)",
             "viscosity_iterations": its("viscosity"), "pressure_iterations": its("pressure"),
+            "viscosity_preconditioner_per_step": [st["viscosity"]["preconditioner"] for st in stats],   # 0 diagonal, 1 multigrid (AUTO picks per solve)
             "viscosity": {k: last["viscosity"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "roofline": roof,

@@ -231,6 +231,10 @@ struct flipv_context {
     int pressureReady, viscosityReady;
     int solidVersion, weightsVersion, faceStateVersion;  // products of the solid SDF (weights; solid phi at cell centres + face states) are reused while it is unchanged
     int viscStateValid, viscStatePrec;  // k_visc_setup's off-row values are in place for this vector precision
+    // what the previous viscosity solve did (flipv_params.viscosity_preconditioner = AUTO picks the next one's preconditioner from it,
+    // fv_visc_auto_pick): 0 nothing yet, 1 diagonal, 2 multigrid
+    int vLastPrec, vLastIts, vLastConverged;
+    double vLastRelRes;
     int pressurePrec, viscosityPrec;
 };
 

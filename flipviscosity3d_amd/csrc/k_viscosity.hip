@@ -412,6 +412,7 @@ static PcgSys<T, 3> visc_sys(flipv_context *c) {
 }
 
 int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv)(flipv_context *, const PcgScal &, int), int *conv_out);
+int fv_vmg_prepare(flipv_context *c);
 
 template <typename T, int NV>
 static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count, const PcgSys<T, 3> *sys = nullptr) {
@@ -442,6 +443,39 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     else { if (rdot) VSPMV(NV, NV == 2, true); else VSPMV(NV, NV == 2, false); }
 #undef VSPMV
     if (timed) fv_ev_end(c);
+}
+
+// flipv_params.viscosity_preconditioner = AUTO: the diagonal or the multigrid V-cycle, whichever the previous solve says will be
+// cheaper.  Costs in units of one diagonal-preconditioned iteration (SpMV + update, 41 us at 256^3): a multigrid iteration ~9 (5
+// fine SpMV-class launches + the coarse levels, 340-380 us), its set-up ~70 (3 ms); one multigrid iteration does the work of ~15
+// diagonal ones (10-30 measured on the bench scene).  The diagonal solve stops at the cap whether converged or not
+// (the reference's budget); the multigrid is only worth starting when it is predicted to CONVERGE for less than that:
+//   after a diagonal solve that converged in n iterations        -> multigrid next if 70 + 9 n/15 < n           (n > 175)
+//   after a diagonal solve stopped at the cap with residual rho  -> n is extrapolated, n = cap ln(tol)/ln(rho); multigrid if 70 + 9 n/15 < cap
+//   after a multigrid solve of m iterations                      -> stay while 70 + 9 m < min(15 m, cap)        (12 <= m <= 69 at the stock cap)
+// with 10 % hysteresis.  Decisions depend on iteration counts only, never on wall-clock times, so a run is reproducible.
+// On the bench scene the first dozen substeps (the bunny at rest, nu dt/dx^2 = 3 300: 120-250 multigrid iterations) stay with the
+// capped diagonal solve like the reference; once the liquid moves (dt shrinks, 15-60 iterations) the multigrid takes over and
+// every solve converges: 25-30 ms per substep against 31-36.  FLIPV_VISC_AUTO=0: AUTO = always the diagonal.
+static bool fv_visc_auto_pick(const flipv_context *c) {
+    static const bool off = getenv("FLIPV_VISC_AUTO") && atoi(getenv("FLIPV_VISC_AUTO")) == 0;
+    if (off || c->vLastPrec == 0) return false;
+    const double cap = (double)c->prm.viscosity_max_iterations, tol = c->prm.viscosity_tolerance > 0 ? c->prm.viscosity_tolerance : 1e-6;
+    const double MG_ITER = 9.0, MG_SETUP = 70.0, RATIO = 15.0;
+    if (c->vLastPrec == 1) {
+        double n = (double)c->vLastIts;
+        if (!c->vLastConverged) {
+            const double rho = c->vLastRelRes;
+            if (!(rho > 0.0) || rho >= 1.0) return false;
+            n = n * log(tol) / log(rho);
+        }
+        const double costD = n < cap ? n : cap, costM = MG_SETUP + MG_ITER * n / RATIO;
+        return costM < 0.9 * costD;
+    }
+    if (!c->vLastConverged) return false;   // a multigrid solve that stalled or ran into the cap: back to the diagonal
+    const double m = (double)c->vLastIts;
+    const double costM = MG_SETUP + MG_ITER * m, costD = RATIO * m < cap ? RATIO * m : cap;
+    return costM < 1.1 * costD;
 }
 
 template <typename T>
@@ -512,7 +546,15 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // plain, and so does everything under the opt-in multigrid.  The geometry is only known once the tiles are built,
     // so the setup kernel runs in the layout of the previous solve's geometry and is repeated on the rare solve where
     // the geometry changes.
-    const bool swzOk = c->allowSwz && c->prm.viscosity_preconditioner != FLIPV_PRECOND_MULTIGRID;
+    // the preconditioner of this solve (the multigrid needs fp32 vectors in the plain layout over a whole, single-rank index space)
+    const bool mgPossible = std::is_same<T, float>::value && !c->comm && !c->isBlock && c->prm.viscosity_lane_width != 2;
+    const bool mgPlanned = mgPossible && (c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID ||
+                                          (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && fv_visc_auto_pick(c)));
+    const bool swzOk = c->allowSwz && !mgPlanned;
+    if (mgPossible && c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && !c->vmgState && !(getenv("FLIPV_VISC_AUTO") && atoi(getenv("FLIPV_VISC_AUTO")) == 0)) {
+        const int prc = fv_vmg_prepare(c);   // AUTO may pick the multigrid later in the run: allocate its hierarchy now, not in that substep
+        if (prc) return prc;
+    }
     const int precNow = std::is_same<T, float>::value ? 0 : 1;
     auto run_setup = [&](int swz) -> int {
         // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers
@@ -575,7 +617,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (c->prm.viscosity_update_grid_cap > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.viscosity_update_grid_cap) nb = c->prm.viscosity_update_grid_cap; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
         const dim3 blk(64, 4, 1);
         const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
-        const bool useMg = std::is_same<T, float>::value && !c->comm && !c->isBlock && c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID && c->vwV == 4;   // (the hierarchy is built over a whole, single-rank index space)
+        const bool useMg = mgPlanned && c->vwV == 4;
         li.preconditioner = useMg ? 1 : 0;
         if (useMg) {
             if ((rc = fv_viscosity_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); },
@@ -613,6 +655,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     }
     li.iterations = iters;
     li.residual = res;
+    c->vLastPrec = (bnorm == 0.0 || anyActive == 0) ? c->vLastPrec : (li.preconditioner ? 2 : 1);   // (a trivial solve says nothing)
+    if (!(bnorm == 0.0 || anyActive == 0)) { c->vLastIts = iters; c->vLastConverged = success ? 1 : 0; c->vLastRelRes = bnorm > 0.0 ? res / bnorm : 0.0; }
     // acceptance rule of viscositysolver.cpp:676-689
     // (a stalled solve is treated like one that ran into the cap: its iterate is used if the residual passes the acceptance bound)
     const bool accepted = success || ((iters == cap || stalled) && res < c->prm.viscosity_accept_tolerance);

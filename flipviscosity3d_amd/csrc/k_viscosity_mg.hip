@@ -525,7 +525,8 @@ void fv_vmg_free(flipv_context *c) {
     c->vmgState = nullptr;
 }
 
-static int vmg_setup(flipv_context *c, VmgState **out) {
+// the level structure and its storage (once per context)
+static int vmg_alloc_state(flipv_context *c) {
     VmgState *s = (VmgState *)c->vmgState;
     int rc;
     if (!s) {
@@ -581,6 +582,16 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             F = l.L;
         }
     }
+    return FLIPV_OK;
+}
+// Allocate the hierarchy ahead of its first use (flipv_params.viscosity_preconditioner = AUTO: the first multigrid solve comes some
+// substeps into a run; the allocation -- 1.3 GB at 256^3 -- and its memsets then do not land in that substep)
+int fv_vmg_prepare(flipv_context *c) { return vmg_alloc_state(c); }
+
+static int vmg_setup(flipv_context *c, VmgState **out) {
+    int rc = vmg_alloc_state(c);
+    if (rc) return rc;
+    VmgState *s = (VmgState *)c->vmgState;
     // ---- this solve: the box of the rows, level by level
     {
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)s->d_box, 0x7fffffff, 3, c->stream));

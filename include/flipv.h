@@ -88,10 +88,14 @@ typedef struct flipv_params {
     int check_every;             /* convergence poll interval in iterations; 0 (default) = 32 on one GPU, 8 with a communicator */
     /* solver choice (enum flipv_preconditioner) */
     int pressure_preconditioner; /* AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
-    int viscosity_preconditioner;/* AUTO = the diagonal; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors, one rank; other solves fall
-                                    back to the diagonal and say so in flipv_solve_info.preconditioner).  Converges in 15-250 iterations
-                                    where the diagonal needs 200-4 000: the choice when the solve is to CONVERGE (256^3: 43-47 ms against
-                                    76-102 ms); 700 capped diagonal iterations, the reference's own budget, cost 29 ms */
+    int viscosity_preconditioner;/* DIAGONAL; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors, one rank, whole-domain context; other
+                                    solves fall back to the diagonal and say so in flipv_solve_info.preconditioner): 15-250 iterations
+                                    where the diagonal needs 200-4 000.  AUTO (default) = per solve whichever of the two the PREVIOUS
+                                    solve's iteration count predicts to be cheaper (k_viscosity.hip: fv_visc_auto_pick): the diagonal,
+                                    stopped at the cap like the reference's solve, while the system is so stiff that the multigrid
+                                    would need more than ~70 iterations; the multigrid, converging, otherwise (256^3 bunny drop, 150
+                                    substeps: 25.0 ms per substep against 32.6 with the diagonal alone).  Decisions use iteration
+                                    counts only, never timings */
     /* measurement / test switches, all 0 by default; results do not depend on them beyond solver tolerance */
     int no_graph_replay;         /* 1: the PCG loop is launched kernel by kernel instead of replayed as a hipGraph */
     int unbinned_scatter;        /* 1: particle scatters with global atomics instead of LDS tiles (A/B) */

@@ -85,6 +85,10 @@ def test_config1_default_scene_64_default_params(oracle, precond):
         assert st["viscosity"]["status"] == 0, st["viscosity"]    # converged inside the default cap of 700
         if precond == "multigrid":
             assert st["viscosity"]["preconditioner"] == 1 and st["viscosity"]["iterations"] < 100, st["viscosity"]
+        else:
+            # AUTO (the default): the first solve takes the diagonal; it converges in ~400 iterations, from which the multigrid is
+            # predicted to be cheaper (k_viscosity.hip: fv_visc_auto_pick) and takes over
+            assert st["viscosity"]["preconditioner"] == (0 if t == 0 else 1), (t, st["viscosity"])
         assert err <= VEL_TOL, (t, err)
     assert perr <= 1e-5
 
@@ -130,15 +134,14 @@ def test_config4_miniature_honey_rod_on_sheet_nu50(precond):
     its stock cap of 700 -- so the dump was made with the cap lifted and this test lifts the GPU cap likewise (every
     other parameter is the default): the comparison is between converged answers.  With the multigrid preconditioner
     (flipv_params.viscosity_preconditioner) the solve converges well inside the STOCK cap, so that variant leaves the cap alone too."""
-    from flipviscosity3d_amd.capi import Context, PRECOND_MULTIGRID
+    from flipviscosity3d_amd.capi import Context, PRECOND_DIAGONAL, PRECOND_MULTIGRID
     g = Golden("honey64_nu50")
     c = Context(g.I, g.J, g.K, g.dx)
     c.set_solid_sdf(g["solid"])
     c.set_viscosity(float(g["nu"]))
     if precond != "multigrid_stock_cap":
         c.set_params(viscosity_max_iterations=int(g["vcap"]))
-    if precond != "diagonal":
-        c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
+    c.set_params(viscosity_preconditioner=PRECOND_DIAGONAL if precond == "diagonal" else PRECOND_MULTIGRID)
     c.particles = g["particles0"]
     for t in range(g.nsub):
         st = c.substep(g.dt)
@@ -173,7 +176,7 @@ def converged_probe_run(name, N, precond):
     """GPU run against a compact reference dump (probe faces + particle checksums, tests/golden/make_golden.py compact_scene):
     precond "diagonal" lifts the viscosity cap like the reference's was lifted, "multigrid_stock_cap" only switches the
     preconditioner (the solve then converges inside the stock cap)"""
-    from flipviscosity3d_amd.capi import Context, PRECOND_MULTIGRID
+    from flipviscosity3d_amd.capi import Context, PRECOND_DIAGONAL, PRECOND_MULTIGRID
     g = Golden(name)
     dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
     assert len(P) == int(g["nparticles"]) and np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])
@@ -181,7 +184,7 @@ def converged_probe_run(name, N, precond):
     c.set_solid_sdf(solid)
     c.set_viscosity(float(g["nu"]))
     if precond == "diagonal":
-        c.set_params(viscosity_max_iterations=int(g["vcap"]))
+        c.set_params(viscosity_max_iterations=int(g["vcap"]), viscosity_preconditioner=PRECOND_DIAGONAL)
     else:
         c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
     c.particles = P
@@ -295,7 +298,8 @@ def test_config5_miniature_eight_slabs_along_the_long_axis():
     assert [b[0][0] for b in boxes] == [32 * r for r in range(8)]
     # (tolerance 1e-5: at the default 1e-6 this scene's fp32 solve sits at its attainable residual -- 1.4e-6 -- and converges or
     # stalls depending on the summation order of the atomics; the decomposition is what is under test here)
-    params = dict(viscosity_max_iterations=4000, viscosity_tolerance=1e-5)
+    from flipviscosity3d_amd.capi import PRECOND_DIAGONAL
+    params = dict(viscosity_max_iterations=4000, viscosity_tolerance=1e-5, viscosity_preconditioner=PRECOND_DIAGONAL)
     ref = capi.Context(I, J, K, dx)
     ref.set_solid_sdf(solid); ref.set_viscosity(5.0); ref.set_params(**params); ref.particles = P
     ctxs = [capi.Context(I, J, K, dx, device=0, block=b) for b in boxes]

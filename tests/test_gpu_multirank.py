@@ -35,7 +35,8 @@ def test_slab_decomposition_matches_single_domain(name, nranks):
     from flipviscosity3d_amd import capi, partition
     g = Golden(name)
     I, J, K = g.dims()
-    params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+    params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,
+                  viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # (the single-domain context would otherwise be free to pick the multigrid, which block contexts do not have)
     ref = capi.Context(I, J, K, g.dx)
     ref.set_solid_sdf(g["solid"]); ref.set_viscosity(g["viscosity"]); ref.set_gravity(*g.gravity); ref.set_params(**params)
     ref.particles = g["particles0"]
@@ -109,6 +110,7 @@ def test_stacked_weak_scaling_scene_two_slabs():
     ranges = partition.slab_ranges(K * copies, copies)
     ref = capi.Context(I, J, K * copies, g.dx)
     ref.set_solid_sdf(solid_g); ref.set_viscosity(5.0); ref.particles = np.concatenate(parts)
+    ref.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # what the slab contexts run
     ctxs = [capi.Context(I, J, K * copies, g.dx, device=0, slab=r) for r in ranges]
     capi.comm_init_local(ctxs)
     for c, p in zip(ctxs, parts):
@@ -145,7 +147,8 @@ def test_block_decomposition_matches_single_domain(name, dims):
     from flipviscosity3d_amd import capi, partition
     g = Golden(name)
     I, J, K = g.dims()
-    params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+    params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,
+                  viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # (the single-domain context would otherwise be free to pick the multigrid, which block contexts do not have)
     ref = capi.Context(I, J, K, g.dx)
     ref.set_solid_sdf(g["solid"]); ref.set_viscosity(g["viscosity"]); ref.set_gravity(*g.gravity); ref.set_params(**params)
     ref.particles = g["particles0"]
@@ -245,7 +248,7 @@ def test_blocks_with_fp64_vectors_and_odd_sizes():
     s.close()
     P[:, 3] = 0.3 * np.sin(9 * P[:, 1]); P[:, 4] = -0.2 * np.cos(7 * P[:, 0]); P[:, 5] = 0.1 * np.sin(5 * P[:, 2] + P[:, 0])
     for precision, dims in ((1, (2, 2, 1)), (0, (2, 1, 2)), (1, (1, 2, 2))):
-        params = dict(precision=precision, viscosity_max_iterations=6000, viscosity_tolerance=1e-7,
+        params = dict(precision=precision, viscosity_max_iterations=6000, viscosity_tolerance=1e-7, viscosity_preconditioner=capi.PRECOND_DIAGONAL,
                       pressure_rel_tolerance=0.0 if precision else 1e-7)
         ref = capi.Context(I, J, K, dx)
         ref.set_solid_sdf(solid); ref.set_viscosity(2.0); ref.set_params(**params); ref.particles = P

@@ -1,5 +1,5 @@
 """Soak run: the bench scene at N^3 for many substeps (bunny drop, splash, settling) -- watches for NaNs, lost particles,
-solver failures and tile-geometry switches.   python tools/soak.py [N=128] [substeps=200]"""
+solver failures and tile-geometry switches.   python tools/soak.py [N=128] [substeps=200] [mg]      (mg: multigrid-preconditioned viscosity solve)"""
 import os
 import sys
 import numpy as np
@@ -13,10 +13,15 @@ dx, solid, P = build_scene(N, 5.0)
 c = Context(N, N, N, dx)
 c.set_solid_sdf(solid)
 c.set_viscosity(5.0)
+if len(sys.argv) > 3 and sys.argv[3] == "mg":
+    from flipviscosity3d_amd.capi import PRECOND_MULTIGRID
+    c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
 c.particles = P
 n0 = c.num_particles
 last = None
 worst = 0.0
+total = 0.0
+precs = []
 for t in range(steps):
     dt = min(c.cfl(), 0.01)
     st = c.substep(dt)
@@ -27,6 +32,8 @@ for t in range(steps):
             geo, st["pressure"]["active_tiles"], st["viscosity"]["active_tiles"], st["total_ms"]), flush=True)
         last = geo
     worst = max(worst, st["total_ms"])
+    total += st["total_ms"]
+    precs.append(st["viscosity"]["preconditioner"])
     assert st["rc"] >= 0, st
     if t % 25 == 24 or t == steps - 1:
         Q = c.particles
@@ -35,5 +42,5 @@ for t in range(steps):
         lo, hi = Q[:, :3].min(), Q[:, :3].max()
         assert lo >= 0.0 and hi <= N * dx, (lo, hi)
         print("   particles ok: y range %.3f..%.3f, max speed %.3f" % (Q[:, 1].min(), Q[:, 1].max(), np.abs(Q[:, 3:]).max()), flush=True)
-print("done: %d substeps, worst %.2f ms" % (steps, worst))
+print("done: %d substeps, %.1f ms in all (%.2f ms per substep), worst %.2f ms; multigrid-preconditioned viscosity solves: %d" % (steps, total, total / steps, worst, sum(precs)))
 c.close()
