@@ -233,6 +233,8 @@ struct flipv_context {
     int viscStateValid, viscStatePrec;  // k_visc_setup's off-row values are in place for this vector precision
     // what the previous viscosity solve did (flipv_params.viscosity_preconditioner = AUTO picks the next one's preconditioner from it,
     // fv_visc_auto_pick): 0 nothing yet, 1 diagonal, 2 multigrid
+    long viscSolves;     // viscosity solves so far (the multigrid hierarchy is dated with it)
+    int vNoMultigridOnce; // set while a failed multigrid solve is being repeated with the diagonal
     int vLastPrec, vLastIts, vLastConverged;
     double vLastRelRes;
     int pressurePrec, viscosityPrec;

@@ -37,6 +37,7 @@ constexpr int VMG_MIN_DIM = 16;           // no level below this many cells alon
 constexpr int VMG_TAIL_POS = 640;         // levels with at most this many index positions in their box go into the single-workgroup tail
 constexpr int VMG_TAIL_MAX = 3;           // ... at most this many levels
 constexpr int VMG_MAX_LEVELS = 15;
+constexpr int VMG_KEEP = 1;               // consecutive viscosity solves one assembled hierarchy serves
 
 // slot tables: neighbour component and offset of slot s of a row of component c; inverse look-up by (c, c', offset)
 struct SlotTables {
@@ -489,6 +490,9 @@ struct VmgState {
     VLevelDev *d_lev = nullptr;  // the level descriptors in device memory (this solve's boxes), h_lev their pinned staging copy
     VLevelDev *h_lev = nullptr;
     int tailFirst = 0;           // index into lev of the first level the tail kernel handles (this solve)
+    long builtAt = -1;           // flipv_context::viscSolves when the coarse operators were last assembled (-1: never)
+    void *fineVecs = nullptr;    // the fine level's three sweep vectors (zeroed every solve; the coarse levels' only with a new hierarchy)
+    size_t fineVecBytes = 0;
     ~VmgState() { for (void *p : allocs) (void)hipFree(p); if (h_lev) (void)hipHostFree(h_lev); }
 };
 
@@ -548,7 +552,7 @@ static int vmg_alloc_state(flipv_context *c) {
         float *base;
         if ((rc = vmg_alloc(c, s, c->L, 9, &base))) return rc;
         const size_t per0 = c->L.n + 2 * c->L.guard;
-        s->vecBlocks.push_back({base, 9 * per0 * sizeof(float)});
+        s->fineVecs = base; s->fineVecBytes = 9 * per0 * sizeof(float);
         for (int m = 0; m < 3; m++) {
             s->za[m] = base + (size_t)m * per0 + c->L.guard;
             s->zb[m] = base + (size_t)(3 + m) * per0 + c->L.guard;
@@ -592,7 +596,16 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     int rc = vmg_alloc_state(c);
     if (rc) return rc;
     VmgState *s = (VmgState *)c->vmgState;
-    // ---- this solve: the box of the rows, level by level
+    // the fine level's sweep vectors must be zero wherever there is no row (the SpMV and the restriction read neighbours unmasked)
+    HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
+    // The coarse operators may serve several consecutive solves (FLIPV_VMG_KEEP, default VMG_KEEP): between substeps the liquid moves by
+    // a fraction of a coarse cell, a preconditioner only has to be symmetric positive definite and the same throughout one solve,
+    // and the fine level -- matrix-free -- is always this solve's operator.  A kept hierarchy costs nothing per solve (its vectors
+    // are rewritten by every cycle wherever its rows are and stay zero elsewhere); assembling one costs ~2.5 ms at 256^3.
+    static const int keep = getenv("FLIPV_VMG_KEEP") ? atoi(getenv("FLIPV_VMG_KEEP")) : VMG_KEEP;
+    if (s->builtAt >= 0 && c->viscSolves - s->builtAt < (long)keep) { *out = s; return FLIPV_OK; }
+    s->builtAt = c->viscSolves;
+    // ---- a new hierarchy: the box of the rows, level by level
     {
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)s->d_box, 0x7fffffff, 3, c->stream));
         HIPCHK(c, hipMemsetAsync(s->d_box + 3, 0, 3 * sizeof(int), c->stream));
@@ -618,8 +631,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         s->tailFirst = (int)s->lev.size() - 1;
         while (s->tailFirst > 0 && (int)s->lev.size() - (s->tailFirst - 1) <= VMG_TAIL_MAX && box_positions(s->lev[s->tailFirst - 1].box) <= VMG_TAIL_POS) s->tailFirst--;
     }
-    // the sweeps' vectors must be zero wherever there is no row (the SpMV and the restriction read neighbours unmasked)
-    for (auto &b : s->vecBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));
+    for (auto &b : s->vecBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));   // the coarse levels' vectors: zero off their rows
     // this solve's coarse operators: zero them over the box they are about to be scattered into, united with the box the previous
     // solve wrote (the sweeps never look outside the current box, but the next solve's box may)
     for (size_t l = 0; l < s->lev.size(); l++) {
