@@ -156,11 +156,28 @@ __device__ __forceinline__ int d_parents(int c, const int p[3], int P[2][3], flo
     w[0] = 1.0f; w[1] = 0.0f;
     return 1;
 }
+// slot of column (c2, I + (dx, dy, dz)) in a row of component c, or -1: the inverse of slot_comp / slot_off in arithmetic (a table in
+// __constant__ memory indexed with computed offsets is a dependent load per scattered contribution: 60 per fine row)
+__device__ __forceinline__ int d_slot_of(int c, int c2, int dx, int dy, int dz) {
+    const int t1 = c == 2 ? 0 : c + 1, t2 = c == 0 ? 2 : c - 1;           // (c + 1) % 3, (c + 2) % 3
+    const int dn = c == 0 ? dx : (c == 1 ? dy : dz);
+    const int e1 = t1 == 0 ? dx : (t1 == 1 ? dy : dz), e2 = t2 == 0 ? dx : (t2 == 1 ? dy : dz);
+    if (dn < -1 || dn > 1) return -1;
+    if (c2 == c) {
+        if (e1 != 0 && e2 != 0) return -1;
+        const int q = e2 == 0 ? (e1 == 0 ? 0 : (e1 == -1 ? 1 : (e1 == 1 ? 2 : -1))) : (e2 == -1 ? 3 : (e2 == 1 ? 4 : -1));
+        return q < 0 ? -1 : (dn + 1) * 5 + q;
+    }
+    const bool first = c2 == t1;
+    const int da = first ? e1 : e2, other = first ? e2 : e1;
+    if (other != 0 || dn > 0 || da < 0 || da > 1) return -1;
+    return 15 + (first ? 0 : 4) + (dn + 1) * 2 + da;
+}
 // add value to the coarse entry (row (c, I), column (c2, J)); the offset J - I is always one of the 23 slots
 __device__ __forceinline__ void d_coarse_add(const VLevelDev &C, int c, const int I[3], int c2, const int J[3], float v) {
     const int dx = J[0] - I[0], dy = J[1] - I[1], dz = J[2] - I[2];
     if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) { if (v != 0.0f) atomicAdd(&g_dropped[0], 1u); return; }  // cannot happen: the pattern is closed under this coarsening
-    const int s = ST.lut[c][c2][(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)];
+    const int s = d_slot_of(c, c2, dx, dy, dz);
     if (s >= 0) atomicAdd(C.coef[c][s] + gidx(C.L, I[0], I[1], I[2]), v);
     else if (v != 0.0f) atomicAdd(&g_dropped[1], 1u);
 }
@@ -650,7 +667,9 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         A.vm[0] = c->vmU; A.vm[1] = c->vmV; A.vm[2] = c->vmW;
         A.fC = c->fC; A.fE[0] = c->fEU; A.fE[1] = c->fEV; A.fE[2] = c->fEW;
         A.mask = c->vRowMask;
-        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_rap_fine, dim3(pcg_grid(c, c->nActiveV)), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A,
+        static const int rapGrid = getenv("FLIPV_VMG_RAPGRID") ? atoi(getenv("FLIPV_VMG_RAPGRID")) : 0;
+        const int nbRap = rapGrid > 0 ? ((c->nActiveV + 7) / 8 * 8 < rapGrid ? (c->nActiveV + 7) / 8 * 8 : rapGrid) : pcg_grid(c, c->nActiveV);
+        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_rap_fine, dim3(nbRap), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A,
                            dev_of(s->lev[0])));
         for (size_t l = 0; l + 1 < s->lev.size(); l++)
             hipLaunchKernelGGL(k_vmg_rap, BGRID(s->lev[l].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
