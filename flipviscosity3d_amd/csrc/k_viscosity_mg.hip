@@ -2,8 +2,9 @@
 //
 // The viscosity system (viscositysolver.cpp:276-664) couples the three face-velocity components through the shear
 // stresses; its rigid modes make piecewise-constant coarse spaces useless and only Galerkin coarse operators survive the
-// near-empty control volumes at the free surface.  What works (scipy prototype on the oracle's matrices:
-// 64 PCG iterations at 64^3, 68 at 128^3 with V(2,2), against 440 / 1490 with the diagonal):
+// near-empty control volumes at the free surface.  What works (scipy prototype on the oracle's matrices,
+// tools/vmg_proto.py: 65 PCG iterations at 64^3, 78 at 128^3, 139-151 at 256^3 with V(2,2), against 440 / 1490 / 2071 with the
+// diagonal; what limits it is in DESIGN.md 8.1):
 //   transfer P   per component, on the MAC lattices: linear along the face normal (a fine face on a coarse face plane
 //                takes that coarse face, one between two planes the mean of both), piecewise constant across
 //   coarse A     P^T A P.  With this P the coarse operator of every level has the SAME 23-entry pattern per row: 15
@@ -12,13 +13,16 @@
 //                Storage: one coefficient grid per (component, slot) on the level's dense index space ("dense slots").
 //   level 0      matrix-free: the tile SpMV kernel of k_viscosity.hip with the Jacobi update / the residual as its epilogue
 //                (k_visc_spmv<.., EPI>): a sweep is ONE launch that reads the iterate with its halo and writes the next one
-//   assembly     level 1 is scattered from the matrix-free fine rows with atomics (each fine row knows its <= 15 entries
-//                and each end of an entry its <= 2 parents), level l+1 from level l the same way
+//   assembly     level 1 is scattered from the matrix-free fine rows (each fine row knows its <= 15 entries and each end of an
+//                entry its <= 2 parents; a tile's contributions are summed in LDS and flushed with one atomic per coarse entry),
+//                level l+1 from level l with atomics
 //   cycle        V(2,2), damped Jacobi (omega 0.6: lambda_max(D^-1 A) ~ 3), zero initial guess; the hierarchy stops at 16^3
 //                (16 sweeps there: deeper levels bought nothing in the prototype, tools/vmg_proto.py)
-//   where        every coarse sweep covers only the box of the level's index space that the listed tiles reach (the liquid's
-//                bounding box halved level by level); levels whose box holds <= VMG_TAIL_POS positions run inside ONE
-//                single-workgroup launch (k_vmg_tail), the larger ones as 6 launches per level
+//   where        every coarse sweep covers only the strips (64 consecutive i of a (j, k) row) that hold rows, inside the box of the
+//                level's index space that the listed tiles reach; levels whose box holds <= VMG_TAIL_POS positions run inside
+//                ONE single-workgroup launch (k_vmg_tail: the coarsest level in LDS), the larger ones as 6 launches per level
+//   who          flipv_params.viscosity_preconditioner: MULTIGRID always, AUTO (default) when the previous solve's iteration count
+//                predicts it to be cheaper than the diagonal (k_viscosity.hip: fv_visc_auto_pick)
 //   loop         PCG around it; `check_every` iterations are captured into a hipGraph once per solve and replayed
 //                (device-side iteration counters, as in pcg_common.h)
 #include "flipv_internal.h"
