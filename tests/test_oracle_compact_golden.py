@@ -79,3 +79,18 @@ def test_oracle_bunny128_first_substep_at_probes(oracle):
         assert np.float32(np.abs(a).max()) == g["s0_maxabs_" + c]
     assert np.array_equal(s.particles.astype(np.float64).sum(axis=0), g["s0_particles_sum"])
     s.close()
+
+
+def test_bunny256_scene_setup_matches_reference():
+    """bunny256_nu5_converged (the reference's converged answer at the HEADLINE size, cap lifted: ~25 minutes per substep, so neither the
+    reference nor the oracle is re-run here): the scene the GPU test builds with the host library must be the reference's -- particle
+    count, particle checksum, solid-SDF checksum -- and the fixture must say what it is"""
+    if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged.npz")):
+        pytest.skip("fixture not built")
+    g = Golden("bunny256_nu5_converged")
+    assert g.dims() == (256, 256, 256) and int(g["vcap"]) >= 20000 and float(g["nu"]) == 5.0
+    assert int(g["s0_visc_iters"]) > 700                     # far beyond the stock cap: the dump is the converged answer
+    dx, solid, P = build_host_scene(256, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    assert len(P) == int(g["nparticles"])
+    assert np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])
+    assert np.float64(solid.astype(np.float64).sum()) == g["solid_sum"]
