@@ -172,7 +172,7 @@ def test_config4_miniature_with_the_stock_cap_follows_the_acceptance_rule():
     c.close()
 
 
-def converged_probe_run(name, N, precond):
+def converged_probe_run(name, N, precond, vel_tol=VEL_TOL):
     """GPU run against a compact reference dump (probe faces + particle checksums, tests/golden/make_golden.py compact_scene):
     precond "diagonal" lifts the viscosity cap like the reference's was lifted, "multigrid_stock_cap" only switches the
     preconditioner (the solve then converges inside the stock cap)"""
@@ -199,7 +199,7 @@ def converged_probe_run(name, N, precond):
             num = max(num, float(np.abs(a[idx].astype(np.float64) - val).max()))
             den = max(den, float(g["s%d_maxabs_%s" % (t, n)]))
         print("%s %s substep %d: %d iterations, velocity error %.3e (reference: %d iterations)" % (name, precond, t, st["viscosity"]["iterations"], num / den, int(g["s%d_visc_iters" % t])))
-        assert num / den <= VEL_TOL, (t, num / den)
+        assert num / den <= vel_tol, (t, num / den)
         # particle checksums: mean position within 1e-6, mean velocity within 1e-5
         d = np.abs(c.particles.astype(np.float64).sum(axis=0) - g["s%d_particles_sum" % t]) / len(P)
         assert d[:3].max() <= 1e-6 and d[3:].max() <= 1e-5, d
@@ -218,17 +218,30 @@ def test_config3_scene_128_converged_reference_probes(precond):
 
 @pytest.mark.parametrize("precond", ["diagonal", "multigrid_stock_cap"])
 def test_config3_headline_256_converged_reference_probes(precond):
-    """BASELINE configs[2] ITSELF (the metric's 256^3 bunny drop, nu = 5) against the reference's converged answer: the reference was
-    run with its viscosity cap lifted (tests/golden/make_golden.py bunny256_nu5_converged; its MIC(0) solve needs far more than the
-    stock 700 iterations at this size, about ten minutes per substep on one core), 20 000 probe faces per component and substep,
-    two chained substeps.  "diagonal": GPU cap lifted likewise (2 000-2 400 iterations); "multigrid_stock_cap": every parameter but
-    the preconditioner is the default.  With the STOCK cap and the default preconditioner both sides stop unconverged at different
-    iterates (test_gpu_fullsize.py asserts the acceptance rule there)."""
+    """BASELINE configs[2] ITSELF (the metric's 256^3 bunny drop, nu = 5) against the reference run with its viscosity cap lifted
+    (tests/golden/make_golden.py bunny256_nu5_converged: its MIC(0) solve needs 7 689 and 13 160 iterations here, 25-45 minutes per
+    substep on one core), 20 000 probe faces per component and substep, two chained substeps.  "diagonal": GPU cap lifted likewise
+    (~1 750 iterations); "multigrid_stock_cap": every parameter but the preconditioner is the default (~140 iterations).
+    Tolerance 2.5e-4, not 1e-4: at this size the reference's answer at ITS stopping tolerance (1e-6 of max|rhs|) is itself 1.5e-4 /
+    2e-4 away from the solution of the linear system -- every GPU variant (either preconditioner, fp32 or fp64 vectors, tolerance
+    1e-6 or 1e-7) agrees with every other to 2e-6 and differs from this dump by 1.45e-4 / 1.96e-4.  The next test holds the 1e-4 bar
+    against a reference converged beyond its stock tolerance."""
     import os
     from helpers import GOLDEN
     if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged.npz")):
         pytest.skip("fixture not built")
-    converged_probe_run("bunny256_nu5_converged", 256, precond)
+    converged_probe_run("bunny256_nu5_converged", 256, precond, vel_tol=2.5e-4)
+
+
+@pytest.mark.parametrize("precond", ["diagonal", "multigrid_stock_cap"])
+def test_config3_headline_256_tight_reference_probes(precond):
+    """the same scene, first substep, against the reference with its cap lifted AND its viscosity tolerance tightened to 1e-8
+    (bunny256_nu5_tight): velocities <= 1e-4 with the GPU's default tolerance"""
+    import os
+    from helpers import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_tight.npz")):
+        pytest.skip("fixture not built")
+    converged_probe_run("bunny256_nu5_tight", 256, precond)
 
 
 def test_config3_scene_128_default_cap_against_oracle_default_cap(oracle):
