@@ -511,6 +511,7 @@ struct VmgState {
     VLevelDev *d_lev = nullptr;  // the level descriptors in device memory (this solve's boxes), h_lev their pinned staging copy
     VLevelDev *h_lev = nullptr;
     int tailFirst = 0;           // index into lev of the first level the tail kernel handles (this solve)
+    bool ready = false;          // every allocation of vmg_alloc_state succeeded
     long builtAt = -1;           // flipv_context::viscSolves when the coarse operators were last assembled (-1: never)
     void *fineVecs = nullptr;    // the fine level's three sweep vectors (zeroed every solve; the coarse levels' only with a new hierarchy)
     size_t fineVecBytes = 0;
@@ -554,6 +555,7 @@ void fv_vmg_free(flipv_context *c) {
 static int vmg_alloc_state(flipv_context *c) {
     VmgState *s = (VmgState *)c->vmgState;
     int rc;
+    if (s && !s->ready) { fv_vmg_free(c); s = nullptr; }   // an earlier attempt ran out of memory half way: start over
     if (!s) {
         SlotTables T;
         build_slot_tables(&T);
@@ -606,6 +608,7 @@ static int vmg_alloc_state(flipv_context *c) {
             s->lev.push_back(l);
             F = l.L;
         }
+        s->ready = true;
     }
     return FLIPV_OK;
 }
