@@ -354,10 +354,23 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
             return rc != FLIPV_OK ? rc : FLIPV_ERR_HIP;
         }
         if ((rc = fv_graph_exec(c, geSlot, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
-        for (int done = 0; done < cap && conv < 0; done += every) {
-            hipError_t el = hipGraphLaunch(ge, c->stream);
-            hipError_t es = hipStreamSynchronize(c->stream);
-            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+        // Replays are pipelined: replay k+1 is enqueued before the host waits for replay k's stop flag, so the GPU does not idle
+        // through the host's wake-up and launch between replays (22 of them in a capped solve: ~0.4 ms).  The flag only ever goes
+        // from -1 to an iteration number, so whichever replay's copy the host reads is valid; a solve that stops early leaves one
+        // replay of launches that return at once behind it.
+        {
+            hipEvent_t ev[2] = {c->evPoll[0], c->evPoll[1]};
+            int slot = 0, pending = -1;
+            bool bad = false;
+            for (int done = 0; done < cap && conv < 0; done += every) {
+                bad = bad || hipGraphLaunch(ge, c->stream) != hipSuccess || hipEventRecord(ev[slot], c->stream) != hipSuccess;
+                if (pending >= 0) { bad = bad || hipEventSynchronize(ev[pending]) != hipSuccess; conv = c->h_flags[0]; }
+                if (bad) break;
+                pending = slot;
+                slot ^= 1;
+            }
+            bad = bad || hipStreamSynchronize(c->stream) != hipSuccess;
+            if (bad) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
             conv = c->h_flags[0];
         }
         (void)hipGraphDestroy(g);
