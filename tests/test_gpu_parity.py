@@ -300,6 +300,26 @@ def test_viscosity_multigrid_on_a_filled_box_agrees_with_the_diagonal():
     assert res[1][1] * 3 < res[0][1], (res[0][1], res[1][1])
 
 
+def test_switching_the_viscosity_preconditioner_between_substeps():
+    """multigrid -> diagonal -> multigrid from one substep to the next (what AUTO does when the iteration counts cross its thresholds):
+    the vectors change layout (plain <-> swizzled patches) and the set-up kernel rewrites everything; the run must stay on the
+    trajectory of a run that never switches"""
+    from flipviscosity3d_amd.capi import Context
+    g = Golden("bunny32_viscous")
+    runs = []
+    for seq in ([PRECOND_DIAGONAL] * 5, [PRECOND_MULTIGRID, PRECOND_DIAGONAL, PRECOND_DIAGONAL, PRECOND_MULTIGRID, PRECOND_DIAGONAL]):
+        c = make_ctx(g, viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+        c.particles = g["particles0"]
+        for pc in seq:
+            c.set_params(viscosity_preconditioner=pc)
+            st = c.substep(g.dt)
+            assert st["viscosity"]["status"] == 0 and st["viscosity"]["preconditioner"] == (1 if pc == PRECOND_MULTIGRID else 0), st["viscosity"]
+        runs.append(([c.grid(k) for k in "UVW"], c.particles))
+        c.close()
+    assert rel_maxnorm3(runs[1][0], runs[0][0]) <= 2e-5
+    assert np.abs(runs[1][1][:, :3] - runs[0][1][:, :3]).max() <= 1e-6
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_particle_advection(name):
     g = Golden(name)
