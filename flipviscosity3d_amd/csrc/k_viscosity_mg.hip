@@ -3,7 +3,7 @@
 // The viscosity system (viscositysolver.cpp:276-664) couples the three face-velocity components through the shear
 // stresses; its rigid modes make piecewise-constant coarse spaces useless and only Galerkin coarse operators survive the
 // near-empty control volumes at the free surface.  What works (scipy prototype on the oracle's matrices,
-// tools/vmg_proto.py: 65 PCG iterations at 64^3, 78 at 128^3, 139-151 at 256^3 with V(2,2), against 440 / 1490 / 2071 with the
+// tests/research/vmg_proto.py: 65 PCG iterations at 64^3, 78 at 128^3, 139-151 at 256^3 with V(2,2), against 440 / 1490 / 2071 with the
 // diagonal; what limits it is in DESIGN.md 8.1):
 //   transfer P   per component, on the MAC lattices: linear along the face normal (a fine face on a coarse face plane
 //                takes that coarse face, one between two planes the mean of both), piecewise constant across
@@ -17,7 +17,7 @@
 //                entry its <= 2 parents; a tile's contributions are summed in LDS and flushed with one atomic per coarse entry),
 //                level l+1 from level l with atomics
 //   cycle        V(2,2), damped Jacobi (omega 0.6: lambda_max(D^-1 A) ~ 3), zero initial guess; the hierarchy stops at 16^3
-//                (16 sweeps there: deeper levels bought nothing in the prototype, tools/vmg_proto.py)
+//                (16 sweeps there: deeper levels bought nothing in the prototype, tests/research/vmg_proto.py)
 //   where        every coarse sweep covers only the strips (64 consecutive i of a (j, k) row) that hold rows, inside the box of the
 //                level's index space that the listed tiles reach; levels whose box holds <= VMG_TAIL_POS positions run inside
 //                ONE single-workgroup launch (k_vmg_tail: the coarsest level in LDS), the larger ones as 6 launches per level

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""vmg_proto.py -- scipy prototype of the viscosity multigrid on the oracle's assembled systems (solver research, CPU only).
+"""vmg_proto.py -- scipy prototype of the viscosity multigrid on the oracle's assembled systems (solver research, CPU only; lives under
+tests/ because it drives the oracle, which is test infrastructure; not collected by pytest).
 
-    python tools/vmg_proto.py dump 128            # bench scene at 128^3 -> /tmp/visc_128.vdump (oracle_viscosity_dump_to)
-    python tools/vmg_proto.py run 128 [options]   # PCG iteration counts: diagonal vs Galerkin multigrid variants
+    python tests/research/vmg_proto.py dump 128            # bench scene at 128^3 -> /tmp/visc_128.vdump (oracle_viscosity_dump_to)
+    python tests/research/vmg_proto.py run 128 [options]   # PCG iteration counts: diagonal vs Galerkin multigrid variants
 
 The transfer is the one of k_viscosity_mg.hip: per component, linear along the face normal, piecewise constant across.
 """
@@ -13,7 +14,7 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
