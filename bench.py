@@ -298,13 +298,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # ---- second pass, NOT timed: the same number of substeps with HIP events around every 8th SpMV launch
+    # (with the diagonal preconditioner pinned: the kernel being priced is the SpMV of the 700-iteration solves that dominate the
+    # timed region; left on AUTO this pass, which continues the run, would time the few SpMV launches of multigrid-preconditioned
+    # solves instead -- the same kernel inside a kernel-by-kernel loop of 27 launches per iteration)
     c.set_params(kernel_timing=1)
+    if args.viscosity_preconditioner == "auto":
+        c.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL)
     c.kernel_stats_reset()
     for _ in range(max(1, min(args.steps, 5))):
         step()
     c.synchronize()
     ks = c.kernel_stats()
     c.set_params(kernel_timing=0)
+    if args.viscosity_preconditioner == "auto":
+        c.set_params(viscosity_preconditioner=capi.PRECOND_AUTO)
     b2b = {}
     if world == 1:
         for which, name in ((1, "viscosity"), (0, "pressure")):
