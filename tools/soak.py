@@ -1,21 +1,24 @@
 """Soak run: the bench scene at N^3 for many substeps (bunny drop, splash, settling) -- watches for NaNs, lost particles,
-solver failures and tile-geometry switches.   python tools/soak.py [N=128] [substeps=200] [mg]      (mg: multigrid-preconditioned viscosity solve)"""
+solver failures and tile-geometry switches.   python tools/soak.py [N=128] [substeps=200] [auto|mg|diag] [bunny|honey|sheet] [viscosity=5]
+(auto = the library default; FLIPV_VISC_AUTO=0 makes it the diagonal alone)"""
 import os
 import sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
-from bench import build_scene
-from flipviscosity3d_amd.capi import Context
+from bench import build_workload
+from flipviscosity3d_amd.capi import Context, PRECOND_DIAGONAL, PRECOND_MULTIGRID
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-dx, solid, P = build_scene(N, 5.0)
-c = Context(N, N, N, dx)
+mode = sys.argv[3] if len(sys.argv) > 3 else "auto"
+workload = sys.argv[4] if len(sys.argv) > 4 else "bunny"
+nu = float(sys.argv[5]) if len(sys.argv) > 5 else 5.0
+I, J, K, dx, solid, P = build_workload(workload, N, on_device=True)
+c = Context(I, J, K, dx)
 c.set_solid_sdf(solid)
-c.set_viscosity(5.0)
-if len(sys.argv) > 3 and sys.argv[3] == "mg":
-    from flipviscosity3d_amd.capi import PRECOND_MULTIGRID
-    c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
+c.set_viscosity(nu)
+if mode in ("mg", "diag"):
+    c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID if mode == "mg" else PRECOND_DIAGONAL)
 c.particles = P
 n0 = c.num_particles
 last = None
@@ -40,7 +43,7 @@ for t in range(steps):
         assert np.isfinite(Q).all(), "non-finite particle state at substep %d" % t
         assert len(Q) == n0
         lo, hi = Q[:, :3].min(), Q[:, :3].max()
-        assert lo >= 0.0 and hi <= N * dx, (lo, hi)
+        assert lo >= 0.0 and hi <= max(I, J, K) * dx, (lo, hi)
         print("   particles ok: y range %.3f..%.3f, max speed %.3f" % (Q[:, 1].min(), Q[:, 1].max(), np.abs(Q[:, 3:]).max()), flush=True)
 print("done: %d substeps, %.1f ms in all (%.2f ms per substep), worst %.2f ms; multigrid-preconditioned viscosity solves: %d" % (steps, total, total / steps, worst, sum(precs)))
 c.close()
