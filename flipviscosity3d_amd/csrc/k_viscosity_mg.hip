@@ -162,7 +162,7 @@ __device__ __forceinline__ int d_parents(int c, const int p[3], int P[2][3], flo
 }
 // slot of column (c2, I + (dx, dy, dz)) in a row of component c, or -1: the inverse of slot_comp / slot_off in arithmetic (a table in
 // __constant__ memory indexed with computed offsets is a dependent load per scattered contribution: 60 per fine row)
-__device__ __forceinline__ int d_slot_of(int c, int c2, int dx, int dy, int dz) {
+constexpr __host__ __device__ __forceinline__ int d_slot_of(int c, int c2, int dx, int dy, int dz) {
     const int t1 = c == 2 ? 0 : c + 1, t2 = c == 0 ? 2 : c - 1;           // (c + 1) % 3, (c + 2) % 3
     const int dn = c == 0 ? dx : (c == 1 ? dy : dz);
     const int e1 = t1 == 0 ? dx : (t1 == 1 ? dy : dz), e2 = t2 == 0 ? dx : (t2 == 1 ? dy : dz);
@@ -214,6 +214,167 @@ __global__ void k_vmg_rap(VLevelDev F, VLevelDev C) {
             d_rap_entry(C, c, p, ST.comp[c][s], q, v);
         }
     }
+}
+
+// ---- level l -> level l+1 as a GATHER (no atomics, no divergence): coarse row (C, I) collects, from its <= 12 children p = 2 I + delta
+// (delta along the normal -1/0/+1 with weights 1/2, 1, 1/2; 0/1 across) and each child's 23 stored entries, w_child * A(p, q) * w_parent
+// into the slot of q's parent(s).  Everything but the values is known at compile time once the loops are unrolled -- the parity of q
+// along its own normal decides between one parent and two, the parent's offset from I picks the slot -- so the 23 accumulators are
+// registers.  (k_vmg_rap above, the scatter with atomics, stays as the cross-check under FLIPV_VMG_DEBUG: 0.26-0.36 ms per level
+// against 20-40 us.)
+constexpr int floor_half(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
+template <int C, int DN, int A_, int B_, int T>
+__device__ __forceinline__ void d_rap_gather_term(float v, float (&acc)[VS]) {
+    constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
+    constexpr int c2 = slot_comp(C, T);
+    // q - 2 I per axis
+    constexpr int e0 = (C == 0 ? DN : (t1 == 0 ? A_ : B_)) + slot_off(C, T, 0);
+    constexpr int e1 = (C == 1 ? DN : (t1 == 1 ? A_ : B_)) + slot_off(C, T, 1);
+    constexpr int e2 = (C == 2 ? DN : (t1 == 2 ? A_ : B_)) + slot_off(C, T, 2);
+    (void)t2;
+    constexpr int en = c2 == 0 ? e0 : (c2 == 1 ? e1 : e2);          // along the column's own normal
+    constexpr bool two = (en & 1) != 0;
+    constexpr float wc = DN == 0 ? 1.0f : 0.5f;
+    // first (or only) parent
+    constexpr int p0 = c2 == 0 && two ? floor_half(e0 - 1) : floor_half(e0);
+    constexpr int p1 = c2 == 1 && two ? floor_half(e1 - 1) : floor_half(e1);
+    constexpr int p2 = c2 == 2 && two ? floor_half(e2 - 1) : floor_half(e2);
+    constexpr int s0 = d_slot_of(C, c2, p0, p1, p2);
+    static_assert(s0 >= 0 && s0 < VS, "the 23-slot pattern is closed under this coarsening");
+    acc[s0] += (two ? 0.5f * wc : wc) * v;
+    if constexpr (two) {
+        constexpr int s1 = d_slot_of(C, c2, p0 + (c2 == 0), p1 + (c2 == 1), p2 + (c2 == 2));
+        static_assert(s1 >= 0 && s1 < VS, "the 23-slot pattern is closed under this coarsening");
+        acc[s1] += 0.5f * wc * v;
+    }
+}
+template <int C, int DN, int A_, int B_, int T>
+struct RapGatherSlots {
+    static __device__ __forceinline__ void run(const VLevelDev &F, size_t ci, float (&acc)[VS]) {
+        d_rap_gather_term<C, DN, A_, B_, T>(F.coef[C][T][ci], acc);
+        RapGatherSlots<C, DN, A_, B_, T + 1>::run(F, ci, acc);
+    }
+};
+template <int C, int DN, int A_, int B_>
+struct RapGatherSlots<C, DN, A_, B_, VS> {
+    static __device__ __forceinline__ void run(const VLevelDev &, size_t, float (&)[VS]) {}
+};
+template <int C, int DN, int A_, int B_>
+__device__ __forceinline__ void d_rap_gather_child(const VLevelDev &F, const int I[3], float (&acc)[VS]) {
+    constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
+    int p[3];
+    p[C] = 2 * I[C] + DN; p[t1] = 2 * I[t1] + A_; p[t2] = 2 * I[t2] + B_;
+    if (!d_in_lattice(F.L, C, p)) return;
+    const size_t ci = gidx(F.L, p[0], p[1], p[2]);
+    if (F.coef[C][slot_diag(C)][ci] == 0.0f) return;   // no row: all its slots are 0
+    RapGatherSlots<C, DN, A_, B_, 0>::run(F, ci, acc);
+}
+// ---- level 0 -> level 1 the same way: the child's entries come from the matrix-free operator (viscositysolver.cpp:394-465 and the
+// V / W analogues; k_vmg_rap_fine in k_viscosity_mg_geo.inc is the scatter form of the same rows, kept as the cross-check).  In the
+// 23-slot numbering a fine row of component C has: the diagonal (slot 5); -fP / -fM towards its same-component neighbours along each
+// axis a (fP, fM = the factor on the + / - side: the cell-centre factor along the normal, an edge factor across); and, for each
+// transverse axis a, four entries of component a: -fP at p + e_a, +fP at p + e_a - e_C, +fM at p, -fM at p - e_C.  An entry exists
+// only where the neighbour is a row (mask bit).
+struct FineChild {   // everything a child row needs, loaded up front
+    float vm, fP[3], fM[3];
+    unsigned m, mP[3], mM[3], mPc[3];   // row masks at p, p + e_a, p - e_a, p + e_a - e_C
+};
+template <int C, int T>
+__device__ __forceinline__ float d_fine_entry(const FineChild &f) {
+    constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
+    if constexpr (T < 15) {
+        constexpr int dn = T / 5 - 1, q = T % 5;
+        if constexpr (dn == 0 && q == 0) return f.vm + ((f.fP[0] + f.fM[0]) + (f.fP[1] + f.fM[1]) + (f.fP[2] + f.fM[2]));
+        else if constexpr (dn != 0 && q == 0) return dn > 0 ? (((f.mP[C] >> C) & 1u) ? -f.fP[C] : 0.0f) : (((f.mM[C] >> C) & 1u) ? -f.fM[C] : 0.0f);
+        else if constexpr (dn == 0) {
+            constexpr int a = (q == 1 || q == 2) ? t1 : t2;
+            constexpr bool plus = q == 2 || q == 4;
+            return plus ? (((f.mP[a] >> C) & 1u) ? -f.fP[a] : 0.0f) : (((f.mM[a] >> C) & 1u) ? -f.fM[a] : 0.0f);
+        } else return 0.0f;
+    } else {
+        constexpr int a = T < 19 ? t1 : t2, idx = T < 19 ? T - 15 : T - 19;
+        constexpr int dn = idx / 2 - 1, da = idx % 2;
+        if constexpr (dn == 0 && da == 1) return ((f.mP[a] >> a) & 1u) ? -f.fP[a] : 0.0f;
+        else if constexpr (dn == -1 && da == 1) return ((f.mPc[a] >> a) & 1u) ? f.fP[a] : 0.0f;
+        else if constexpr (dn == 0 && da == 0) return ((f.m >> a) & 1u) ? f.fM[a] : 0.0f;
+        else return ((f.mM[C] >> a) & 1u) ? -f.fM[a] : 0.0f;
+    }
+}
+template <int C, int DN, int A_, int B_, int T>
+struct RapGatherFineSlots {
+    static __device__ __forceinline__ void run(const FineChild &f, float (&acc)[VS]) {
+        constexpr bool structural_zero = T < 15 && (T / 5 - 1) != 0 && (T % 5) != 0;   // a fine row has no normal-times-transverse neighbour
+        if constexpr (!structural_zero) d_rap_gather_term<C, DN, A_, B_, T>(d_fine_entry<C, T>(f), acc);
+        RapGatherFineSlots<C, DN, A_, B_, T + 1>::run(f, acc);
+    }
+};
+template <int C, int DN, int A_, int B_>
+struct RapGatherFineSlots<C, DN, A_, B_, VS> {
+    static __device__ __forceinline__ void run(const FineChild &, float (&)[VS]) {}
+};
+template <int C, int DN, int A_, int B_>
+__device__ __forceinline__ void d_rap_gather_child_fine(const FineOp &A, const Lay &L, const int I[3], float (&acc)[VS]) {
+    constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
+    int p[3];
+    p[C] = 2 * I[C] + DN; p[t1] = 2 * I[t1] + A_; p[t2] = 2 * I[t2] + B_;
+    if (!d_in_lattice(L, C, p)) return;
+    const size_t ci = gidx(L, p[0], p[1], p[2]);
+    FineChild f;
+    f.m = A.mask[ci];
+    if (!((f.m >> C) & 1u)) return;
+    const long st[3] = {1, L.sy, L.sz};
+    f.vm = A.vm[C][ci];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (a == C) { f.fP[a] = A.fC[ci]; f.fM[a] = A.fC[ci - st[C]]; }
+        else { f.fP[a] = A.fE[3 - C - a][ci + st[a]]; f.fM[a] = A.fE[3 - C - a][ci]; }
+        f.mP[a] = A.mask[ci + st[a]]; f.mM[a] = A.mask[ci - st[a]];
+        f.mPc[a] = a == C ? 0u : A.mask[ci + st[a] - st[C]];
+    }
+    RapGatherFineSlots<C, DN, A_, B_, 0>::run(f, acc);
+}
+template <int C>
+__device__ __forceinline__ void d_rap_gather_row_fine(const FineOp &A, const Lay &L, const VLevelDev &Cl, int i, int j, int k) {
+    const int I[3] = {i, j, k};
+    float acc[VS];
+#pragma unroll
+    for (int s = 0; s < VS; s++) acc[s] = 0.0f;
+    d_rap_gather_child_fine<C, -1, 0, 0>(A, L, I, acc); d_rap_gather_child_fine<C, -1, 1, 0>(A, L, I, acc); d_rap_gather_child_fine<C, -1, 0, 1>(A, L, I, acc); d_rap_gather_child_fine<C, -1, 1, 1>(A, L, I, acc);
+    d_rap_gather_child_fine<C, 0, 0, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 0, 1, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 0, 0, 1>(A, L, I, acc); d_rap_gather_child_fine<C, 0, 1, 1>(A, L, I, acc);
+    d_rap_gather_child_fine<C, 1, 0, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 1, 1, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 1, 0, 1>(A, L, I, acc); d_rap_gather_child_fine<C, 1, 1, 1>(A, L, I, acc);
+    const size_t co = gidx(Cl.L, i, j, k);
+#pragma unroll
+    for (int s = 0; s < VS; s++) Cl.coef[C][s][co] = acc[s];
+}
+__global__ __launch_bounds__(256) void k_vmg_rap_gather_fine(FineOp A, Lay L, VLevelDev Cl) {   // grid: level 1's box, blockIdx.z = 3 * plane + component
+    const int c = (int)blockIdx.z % 3;
+    const int i = Cl.box.lo[0] + blockIdx.x * 64 + threadIdx.x, j = Cl.box.lo[1] + blockIdx.y * 4 + threadIdx.y, k = Cl.box.lo[2] + (int)blockIdx.z / 3;
+    if (i >= Cl.box.hi[0] || j >= Cl.box.hi[1]) return;
+    if (c == 0) d_rap_gather_row_fine<0>(A, L, Cl, i, j, k);
+    else if (c == 1) d_rap_gather_row_fine<1>(A, L, Cl, i, j, k);
+    else d_rap_gather_row_fine<2>(A, L, Cl, i, j, k);
+}
+
+template <int C>
+__device__ __forceinline__ void d_rap_gather_row(const VLevelDev &F, const VLevelDev &Cl, int i, int j, int k) {
+    const int I[3] = {i, j, k};
+    float acc[VS];
+#pragma unroll
+    for (int s = 0; s < VS; s++) acc[s] = 0.0f;
+    d_rap_gather_child<C, -1, 0, 0>(F, I, acc); d_rap_gather_child<C, -1, 1, 0>(F, I, acc); d_rap_gather_child<C, -1, 0, 1>(F, I, acc); d_rap_gather_child<C, -1, 1, 1>(F, I, acc);
+    d_rap_gather_child<C, 0, 0, 0>(F, I, acc); d_rap_gather_child<C, 0, 1, 0>(F, I, acc); d_rap_gather_child<C, 0, 0, 1>(F, I, acc); d_rap_gather_child<C, 0, 1, 1>(F, I, acc);
+    d_rap_gather_child<C, 1, 0, 0>(F, I, acc); d_rap_gather_child<C, 1, 1, 0>(F, I, acc); d_rap_gather_child<C, 1, 0, 1>(F, I, acc); d_rap_gather_child<C, 1, 1, 1>(F, I, acc);
+    const size_t co = gidx(Cl.L, i, j, k);
+#pragma unroll
+    for (int s = 0; s < VS; s++) Cl.coef[C][s][co] = acc[s];
+}
+__global__ __launch_bounds__(256) void k_vmg_rap_gather(VLevelDev F, VLevelDev Cl) {   // grid: the COARSE level's box, blockIdx.z = 3 * plane + component
+    const int c = (int)blockIdx.z % 3;
+    const int i = Cl.box.lo[0] + blockIdx.x * 64 + threadIdx.x, j = Cl.box.lo[1] + blockIdx.y * 4 + threadIdx.y, k = Cl.box.lo[2] + (int)blockIdx.z / 3;
+    if (i >= Cl.box.hi[0] || j >= Cl.box.hi[1]) return;
+    if (c == 0) d_rap_gather_row<0>(F, Cl, i, j, k);
+    else if (c == 1) d_rap_gather_row<1>(F, Cl, i, j, k);
+    else d_rap_gather_row<2>(F, Cl, i, j, k);
 }
 
 // ---- coarse levels: y = A x for one dof of component C
@@ -656,30 +817,38 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         while (s->tailFirst > 0 && (int)s->lev.size() - (s->tailFirst - 1) <= VMG_TAIL_MAX && box_positions(s->lev[s->tailFirst - 1].box) <= VMG_TAIL_POS) s->tailFirst--;
     }
     for (auto &b : s->vecBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));   // the coarse levels' vectors: zero off their rows
-    // this solve's coarse operators: zero them over the box they are about to be scattered into, united with the box the previous
-    // solve wrote (the sweeps never look outside the current box, but the next solve's box may)
-    for (size_t l = 0; l < s->lev.size(); l++) {
-        VLevel &A = s->lev[l];
-        Box3 z = A.box;
-        const Box3 &pb = s->prevBox[l];
-        if (pb.hi[0] > pb.lo[0]) for (int a = 0; a < 3; a++) { if (pb.lo[a] < z.lo[a]) z.lo[a] = pb.lo[a]; if (pb.hi[a] > z.hi[a]) z.hi[a] = pb.hi[a]; }
-        ZeroSet Z;
-        Z.n = 3 * VS;
-        for (int m = 0; m < 3; m++) for (int q = 0; q < VS; q++) Z.p[m * VS + q] = A.coef[m][q];
-        hipLaunchKernelGGL(k_vmg_zero_box, BGRID(z), 0, c->stream, Z, A.L, z);
-        s->prevBox[l] = A.box;
-    }
+    // this solve's coarse operators, level by level, as gathers that write every entry of the level's box (rows or not): nothing has to
+    // be zeroed first, and what lies outside the box is never looked at.  FLIPV_VMG_RAP_SCATTER=1: the scatter kernels with atomics
+    // instead (the cross-check: same operators up to the summation order), which need the boxes zeroed.
+    static const bool scatter = getenv("FLIPV_VMG_RAP_SCATTER") && atoi(getenv("FLIPV_VMG_RAP_SCATTER")) != 0;
+    if (scatter)
+        for (size_t l = 0; l < s->lev.size(); l++) {
+            VLevel &A = s->lev[l];
+            Box3 z = A.box;
+            const Box3 &pb = s->prevBox[l];
+            if (pb.hi[0] > pb.lo[0]) for (int a = 0; a < 3; a++) { if (pb.lo[a] < z.lo[a]) z.lo[a] = pb.lo[a]; if (pb.hi[a] > z.hi[a]) z.hi[a] = pb.hi[a]; }
+            ZeroSet Z;
+            Z.n = 3 * VS;
+            for (int m = 0; m < 3; m++) for (int q = 0; q < VS; q++) Z.p[m * VS + q] = A.coef[m][q];
+            hipLaunchKernelGGL(k_vmg_zero_box, BGRID(z), 0, c->stream, Z, A.L, z);
+            s->prevBox[l] = A.box;
+        }
     if (!s->lev.empty()) {
         FineOp A;
         A.vm[0] = c->vmU; A.vm[1] = c->vmV; A.vm[2] = c->vmW;
         A.fC = c->fC; A.fE[0] = c->fEU; A.fE[1] = c->fEV; A.fE[2] = c->fEW;
         A.mask = c->vRowMask;
-        static const int rapGrid = getenv("FLIPV_VMG_RAPGRID") ? atoi(getenv("FLIPV_VMG_RAPGRID")) : 0;
-        const int nbRap = rapGrid > 0 ? ((c->nActiveV + 7) / 8 * 8 < rapGrid ? (c->nActiveV + 7) / 8 * 8 : rapGrid) : pcg_grid(c, c->nActiveV);
-        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_rap_fine, dim3(nbRap), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A,
-                           dev_of(s->lev[0])));
-        for (size_t l = 0; l + 1 < s->lev.size(); l++)
-            hipLaunchKernelGGL(k_vmg_rap, BGRID(s->lev[l].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
+#define CGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), 3u * (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
+        if (scatter) {
+            static const int rapGrid = getenv("FLIPV_VMG_RAPGRID") ? atoi(getenv("FLIPV_VMG_RAPGRID")) : 0;
+            const int nbRap = rapGrid > 0 ? ((c->nActiveV + 7) / 8 * 8 < rapGrid ? (c->nActiveV + 7) / 8 * 8 : rapGrid) : pcg_grid(c, c->nActiveV);
+            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_rap_fine, dim3(nbRap), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A, dev_of(s->lev[0])));
+        } else hipLaunchKernelGGL(k_vmg_rap_gather_fine, CGRID(s->lev[0].box), 0, c->stream, A, c->L, dev_of(s->lev[0]));
+        for (size_t l = 0; l + 1 < s->lev.size(); l++) {
+            if (scatter) hipLaunchKernelGGL(k_vmg_rap, BGRID(s->lev[l].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
+            else hipLaunchKernelGGL(k_vmg_rap_gather, CGRID(s->lev[l + 1].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
+        }
+#undef CGRID
     }
     // where the rows are on the levels that run as launches (strip lists) and on the coarsest one (row lists); then the level
     // descriptors go to the device
