@@ -264,7 +264,10 @@ __device__ __forceinline__ void d_rap_gather_child(const VLevelDev &F, const int
     constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
     int p[3];
     p[C] = 2 * I[C] + DN; p[t1] = 2 * I[t1] + A_; p[t2] = 2 * I[t2] + B_;
-    if (!d_in_lattice(F.L, C, p)) return;
+    // only children inside the finer level's box: what lies outside it was not written by this solve (it may hold another solve's rows)
+#ifndef FLIPV_VMG_TEST_NO_BOXCHECK   // (build switch for checking that tests/test_gpu_parity.py::test_multigrid_hierarchy_carries_nothing_over... has teeth)
+    if (p[0] < F.box.lo[0] || p[0] >= F.box.hi[0] || p[1] < F.box.lo[1] || p[1] >= F.box.hi[1] || p[2] < F.box.lo[2] || p[2] >= F.box.hi[2]) return;
+#endif
     const size_t ci = gidx(F.L, p[0], p[1], p[2]);
     if (F.coef[C][slot_diag(C)][ci] == 0.0f) return;   // no row: all its slots are 0
     RapGatherSlots<C, DN, A_, B_, 0>::run(F, ci, acc);

@@ -109,3 +109,29 @@ def test_fullsize_precisions_agree_on_pressure_only_step(scene):
         c.close()
     scale = max(np.abs(g).max() for g in res[1])
     assert max(np.abs(a - b).max() for a, b in zip(*res)) <= 1e-4 * scale
+
+
+def test_auto_preconditioner_over_the_drop_and_splash(scene):
+    """70 substeps of the bench scene with the default (AUTO) viscosity preconditioner: the stiff start runs the capped diagonal solve,
+    then the multigrid takes over -- with diagonal interludes while the liquid keeps moving, i.e. every multigrid solve assembles its
+    hierarchy next to the leftovers of one assembled several cells away.  Every multigrid solve must converge, and in the number of
+    iterations a clean hierarchy needs (33-64 on this stretch).  (A Galerkin gather that read children outside the finer level's
+    current box -- another solve's rows -- went from 63 to 326 iterations at substep 50 of `tools/soak.py 256 150 auto` and into the
+    diagonal fallback a few substeps later; that failure depends on exactly when AUTO switches and does not reproduce on every
+    trajectory, so this test is the guard for the whole mechanism rather than a reproducer of that one bug.)"""
+    c = ctx(scene)
+    mg = []
+    for t in range(70):
+        st = c.substep(min(c.cfl(), 0.01))
+        v = st["viscosity"]
+        assert st["rc"] in (0, 1), (t, st["rc"], v)
+        if v["preconditioner"] == 1:
+            assert v["status"] == 0, (t, v)
+            mg.append(v["iterations"])
+        elif t > 0:
+            assert v["status"] in (0, 1)                      # the capped diagonal solve: converged or accepted (reference rule)
+    Q = c.particles
+    c.close()
+    assert np.isfinite(Q).all()
+    assert len(mg) >= 40, len(mg)                            # the multigrid did take over
+    assert max(mg) <= 110, mg                                # 326 with the polluted hierarchy

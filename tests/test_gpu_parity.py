@@ -300,6 +300,42 @@ def test_viscosity_multigrid_on_a_filled_box_agrees_with_the_diagonal():
     assert res[1][1] * 3 < res[0][1], (res[0][1], res[1][1])
 
 
+def test_multigrid_hierarchy_carries_nothing_over_from_earlier_solves():
+    """a context that has been solving with the multigrid while the liquid moved (boxes, strip lists and coarse operators of a dozen
+    earlier solves in its buffers) takes the next substep exactly like a fresh context given the same particles: same iteration
+    count, same velocities."""
+    from flipviscosity3d_amd.capi import Context
+    from test_oracle_compact_golden import build_host_scene
+    N = 64                                      # two coarse levels (32^3, 16^3) with the default depth
+    dx, solid, P0 = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+
+    def ctx():
+        c = Context(N, N, N, dx)
+        c.set_solid_sdf(solid); c.set_viscosity(5.0); c.set_gravity(8.0, -9.81, 6.0)   # sideways too: the liquid's box moves along every axis
+        c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+        return c
+    old = ctx()
+    rng = np.random.default_rng(11)
+    for shift in rng.uniform(-0.16, 0.16, (12, 3)):   # the same liquid elsewhere, a dozen times: other boxes, other rows on every level
+        Q = P0.copy()
+        Q[:, :3] += np.array(shift, np.float32)
+        old.particles = Q
+        old.substep(0.01)
+    for t in range(20):                         # and a stretch of the real thing moving
+        old.substep(0.01)
+    P = old.particles
+    new = ctx()
+    old.particles = P
+    new.particles = P
+    a, b = old.substep(0.01), new.substep(0.01)
+    assert a["viscosity"]["status"] == 0 and b["viscosity"]["status"] == 0
+    assert a["viscosity"]["preconditioner"] == 1 and b["viscosity"]["preconditioner"] == 1
+    print("iterations: used context %d, fresh context %d" % (a["viscosity"]["iterations"], b["viscosity"]["iterations"]))
+    assert abs(a["viscosity"]["iterations"] - b["viscosity"]["iterations"]) <= 1, (a["viscosity"], b["viscosity"])
+    assert rel_maxnorm3([old.grid(k) for k in "UVW"], [new.grid(k) for k in "UVW"]) <= 1e-5
+    old.close(); new.close()
+
+
 def test_switching_the_viscosity_preconditioner_between_substeps():
     """multigrid -> diagonal -> multigrid from one substep to the next (what AUTO does when the iteration counts cross its thresholds):
     the vectors change layout (plain <-> swizzled patches) and the set-up kernel rewrites everything; the run must stay on the
