@@ -94,7 +94,7 @@ typedef struct flipv_params {
                                     solve's iteration count predicts to be cheaper (k_viscosity.hip: fv_visc_auto_pick): the diagonal,
                                     stopped at the cap like the reference's solve, while the system is so stiff that the multigrid
                                     would need more than ~70 iterations; the multigrid, converging, otherwise (256^3 bunny drop, 150
-                                    substeps: 25.0 ms per substep against 32.6 with the diagonal alone).  Decisions use iteration
+                                    substeps: 23.2 ms per substep against 32.6 with the diagonal alone).  Decisions use iteration
                                     counts only, never timings */
     /* measurement / test switches, all 0 by default; results do not depend on them beyond solver tolerance */
     int no_graph_replay;         /* 1: the PCG loop is launched kernel by kernel instead of replayed as a hipGraph */
