@@ -89,6 +89,7 @@ def test_rccl_backend_single_rank_smoke():
     b.comm_init_rccl(capi.comm_unique_id(), 0, 1)
     for c in (a, b):
         c.set_solid_sdf(g["solid"]); c.set_viscosity(g["viscosity"]); c.set_gravity(*g.gravity)
+        c.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # (a context with a communicator has no multigrid to pick)
         c.particles = g["particles0"]
     for t in range(g.nsub):
         sa, sb = a.substep(g.dt), b.substep(g.dt)
