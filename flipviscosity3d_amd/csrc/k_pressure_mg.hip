@@ -140,7 +140,8 @@ __global__ void k_mg_restrict(Lay F, Lay C, const float *__restrict__ tf, float 
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const int i = 2 * I + (q & 1), j = 2 * J + ((q >> 1) & 1), k = 2 * K + (q >> 2);
-        if (d_in_cells(F, i, j, k)) s += tf[gidx(F, i, j, k)];
+        // (children outside the box the finer level's sweeps cover hold another solve's residual)
+        if (d_in_cells(F, i, j, k) && i >= F.ib && i < F.ie && j >= F.jb && j < F.je && k >= F.kb && k < F.ke) s += tf[gidx(F, i, j, k)];
     }
     bc[gidx(C, I, J, K)] = s;
 }
@@ -283,6 +284,8 @@ constexpr int ROWL = 64;
 
 struct MgState {
     std::vector<MgLevel> lev;
+    std::vector<Lay> range;   // per level: the level's Lay with the launch box (ib..ke) of this solve's sweeps -- the cells within reach of the
+                              // liquid (fv_range_liquid, halved level by level); the whole level in multi-rank runs and outside a substep
     int tailFirst = 0;  // first level handled by k_mg_tail
     std::vector<void *> allocs;
     int I = 0, J = 0, K = 0;
@@ -349,7 +352,27 @@ static int mg_setup(flipv_context *c, MgState **out) {
     for (size_t l = 0; l + 1 < s->lev.size(); l++) {
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
-        hipLaunchKernelGGL(k_mg_coarsen, MGGRID(C.L), 0, c->stream, F.L, C.L, F.diag, F.pi, F.pj, F.pk, C.diag, C.pi, C.pj, C.pk);
+        hipLaunchKernelGGL(k_mg_coarsen, MGGRID(C.L), 0, c->stream, F.L, C.L, F.diag, F.pi, F.pj, F.pk, C.diag, C.pi, C.pj, C.pk);   // (the WHOLE level: coefficients are fresh everywhere)
+    }
+    // Where this solve's sweeps run: the cells within reach of the liquid, halved level by level (the whole level when the liquid's
+    // box is not known: multi-rank runs, operators called outside a substep).  Outside the box the vectors of a level keep whatever
+    // an earlier solve left there; nothing reads it: a coupling is non-zero only between two pressure cells (both inside the box),
+    // and the restriction skips children outside the finer level's box.
+    {
+        static const bool off = getenv("FLIPV_MG_BOX") && atoi(getenv("FLIPV_MG_BOX")) == 0;
+        const Lay R = off ? fv_range(c, 0) : fv_range_liquid(c, 1, 5);
+        s->range.resize(s->lev.size());
+        int lo[3] = {R.ib, R.jb, R.kb}, hi[3] = {R.ie, R.je, R.ke};
+        for (size_t l = 0; l < s->lev.size(); l++) {
+            Lay Lr = s->lev[l].L;
+            int *b[3] = {&Lr.ib, &Lr.jb, &Lr.kb}, *e[3] = {&Lr.ie, &Lr.je, &Lr.ke};
+            for (int a = 0; a < 3; a++) {
+                if (l > 0) { lo[a] = lo[a] >> 1; hi[a] = ((hi[a] - 1) >> 1) + 1; }
+                const int l0 = lo[a] > Lr.olo[a] ? lo[a] : Lr.olo[a], h0 = hi[a] < Lr.ohi[a] ? hi[a] : Lr.ohi[a];
+                *b[a] = l0; *e[a] = h0 > l0 ? h0 : l0 + 1;
+            }
+            s->range[l] = Lr;
+        }
     }
     HIPCHK(c, hipGetLastError());
     *out = s;
@@ -369,8 +392,10 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
                                F.pj, F.pk, c->pMask, F.x, F.b, C.b));
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
-            hipLaunchKernelGGL(k_mg_pre, MGGRID(F.L), 0, c->stream, F.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, F.t);
-            hipLaunchKernelGGL(k_mg_restrict, MGGRID(C.L), 0, c->stream, F.L, C.L, F.t, C.b);
+            const Lay &Fr = s->range[l];
+            const Lay &Cr = l + 1 < t0 ? s->range[l + 1] : C.L;   // the first level of the tail is swept whole: its right-hand side is written everywhere
+            hipLaunchKernelGGL(k_mg_pre, MGGRID(Fr), 0, c->stream, Fr, F.diag, F.pi, F.pj, F.pk, F.b, F.x, F.t);
+            hipLaunchKernelGGL(k_mg_restrict, MGGRID(Cr), 0, c->stream, Fr, Cr, F.t, C.b);
         }
     }
     MgTail T;
@@ -384,7 +409,7 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
                                F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, sc, it_next));
         else
-            hipLaunchKernelGGL(k_mg_up, MGGRID(F.L), 0, c->stream, F.L, C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
+            hipLaunchKernelGGL(k_mg_up, MGGRID(s->range[l]), 0, c->stream, s->range[l], C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
     }
 }
 
