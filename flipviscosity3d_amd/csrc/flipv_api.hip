@@ -250,6 +250,7 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     GALLOC(c->fC); GALLOC(c->fEU); GALLOC(c->fEV); GALLOC(c->fEW);
     GALLOC(c->vDiagU); GALLOC(c->vDiagV); GALLOC(c->vDiagW);
     GALLOC(c->vmU); GALLOC(c->vmV); GALLOC(c->vmW);
+    GALLOC(c->vrU); GALLOC(c->vrV); GALLOC(c->vrW);
     GALLOC(c->stU); GALLOC(c->stV); GALLOC(c->stW);
     GALLOC(c->vRowMask);
     GALLOC(c->bandPrev);

@@ -205,7 +205,8 @@ struct flipv_context {
     float *volC, *volU, *volV, *volW, *volEU, *volEV, *volEW;  // control volumes (kept for parity reads)
     float *fC, *fEU, *fEV, *fEW;                               // factor lattices
     float *vDiagU, *vDiagV, *vDiagW;
-    float *vmU, *vmV, *vmW;                                    // own volume of a row, -1 elsewhere (SpMV row mask)
+    float *vmU, *vmV, *vmW;                                    // own volume of a row, -1 elsewhere (SpMV row mask): the exact operator (multigrid sweeps and coarse operators)
+    float *vrU, *vrV, *vrW;                                    // the same plus the rounding defect of the reference's float diagonal (k_viscosity.hip: d_ref_volume): the operator the PCG solves with
     uint8_t *vRowMask;                                         // bit m set: component m has a row at this index
     uint8_t *stU, *stV, *stW;
     void *vX[3], *vR[3], *vZ[3], *vS[3];
@@ -235,6 +236,7 @@ struct flipv_context {
     // fv_visc_auto_pick): 0 nothing yet, 1 diagonal, 2 multigrid
     long viscSolves;     // viscosity solves so far (the multigrid hierarchy is dated with it)
     int vNoMultigridOnce; // set while a failed multigrid solve is being repeated with the diagonal
+    int vOperatorExact;   // 1: the viscosity SpMV applies the exact operator (vm*), 0: the reference's float-rounded one (vr*); set per solve
     int vLastPrec, vLastIts, vLastConverged;
     double vLastRelRes;
     int pressurePrec, viscosityPrec;

@@ -238,6 +238,20 @@ __device__ __forceinline__ bool d_row_range(int dir, int i, int j, int k, const 
 // rhs follows viscositysolver.cpp:448-465 (and :546-563, :644-659): own volume * velocity minus the
 // couplings to SOLID-state neighbours, accumulated in fp32 in the reference's order.
 #define RHS(st, vel, coef) do { if ((st) == ST_SOLID) rval -= (coef) * (vel); } while (0)
+// The reference stores its matrix in float and forms a row's diagonal as the float sum vol + fR + fL + fT + fB + fF + fK
+// (viscositysolver.cpp:394-446), so ITS matrix is the exact one plus a rounding defect on the diagonal, up to ~3 ulp of a diagonal
+// that is nu dt/dx^2 ~ 10^3-10^4 times the volume term.  On a rigid motion the stress terms cancel and only the volume term is left
+// of a row, so that defect is a relative change of up to ~1e-3 of what the row does to such a field, and of 1.5e-4 / 2e-4 in the
+// converged velocities of the 256^3 bunny scene (measured against the reference run to 1e-8: every variant of the exact operator --
+// either preconditioner, fp32 or fp64 vectors -- agrees with every other to 2e-6 and differs from the reference by that much).  The
+// difference-form SpMV applies the exact operator vol*u - div(tau); storing vol + defect as the row's "own volume" makes it apply the
+// reference's: the defect is fl(diagonal) minus the exact sum of the same seven floats (exact in fp64).  Values stay >= -0.02; the
+// "no row" marker is -1.  Opt-in (FLIPV_REF_DIAG=1, see viscosity_solve_t): the reference's operator is visibly worse conditioned than
+// the exact one (its own MIC(0) PCG needs 7 689 iterations for 1e-6 and 42 223 for 1e-8 at 256^3).
+__device__ __forceinline__ float d_ref_volume(float vol, float fR, float fL, float fT, float fB, float fF, float fK, float dgf) {
+    const double exact = (double)vol + (double)fR + (double)fL + (double)fT + (double)fB + (double)fF + (double)fK;
+    return (float)((double)vol + ((double)dgf - exact));
+}
 template <typename T>
 __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__restrict__ V,
                              const float *__restrict__ W, const uint8_t *__restrict__ SU,
@@ -249,8 +263,9 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                              const float *__restrict__ fEU, const float *__restrict__ fEV,
                              const float *__restrict__ fEW, float *__restrict__ dgU, float *__restrict__ dgV,
                              float *__restrict__ dgW, float *__restrict__ vmU, float *__restrict__ vmV,
-                             float *__restrict__ vmW, uint8_t *__restrict__ rowmask, const uint8_t *__restrict__ band,
-                             int full, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows) {   // v.swz: layout of diag, vm, r, x
+                             float *__restrict__ vmW, float *__restrict__ vrU, float *__restrict__ vrV, float *__restrict__ vrW,
+                             uint8_t *__restrict__ rowmask, const uint8_t *__restrict__ band,
+                             int full, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows, int refdiag) {   // v.swz: layout of diag, vm, r, x
     __shared__ double lds[4];
     IJK_OF_THREAD(L);
     double babs = 0.0;
@@ -258,7 +273,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
     if (i < L.ie && j < L.je) {
         const size_t c = gidx(L, i, j, k);
         const long sy = L.sy, sz = L.sz;
-        float dg[3] = {0.0f, 0.0f, 0.0f}, rv[3] = {0.0f, 0.0f, 0.0f}, vm[3] = {-1.0f, -1.0f, -1.0f};
+        float dg[3] = {0.0f, 0.0f, 0.0f}, rv[3] = {0.0f, 0.0f, 0.0f}, vm[3] = {-1.0f, -1.0f, -1.0f}, vr[3] = {-1.0f, -1.0f, -1.0f};
         // every control volume is zero off the band mask (k_volume_lattice), and a row needs a non-zero volume at its own
         // index or at an index one step down/up an axis: no band there, no row here
         const bool near = band[c] || band[c - 1] || band[c + 1] || band[c - sy] || band[c + sy] || band[c - sz] || band[c + sz];
@@ -287,7 +302,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 RHS(SW[c - 1], W[c - 1], -fK);
                 dg[0] = vol + fR + fL + fT + fB + fF + fK;
                 rv[0] = dg[0] != 0.0f ? rval : 0.0f;
-                if (dg[0] != 0.0f) vm[0] = vol;
+                if (dg[0] != 0.0f) { vm[0] = vol; vr[0] = refdiag ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[0]) : vol; }
             }
         }
         if (d_row_range(1, i, j, k, L) && SV[c] == ST_FLUID) {  // ---- V face (viscositysolver.cpp:472-568)
@@ -312,7 +327,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 RHS(SW[c - sy], W[c - sy], -fK);
                 dg[1] = vol + fR + fL + fT + fB + fF + fK;
                 rv[1] = dg[1] != 0.0f ? rval : 0.0f;
-                if (dg[1] != 0.0f) vm[1] = vol;
+                if (dg[1] != 0.0f) { vm[1] = vol; vr[1] = refdiag ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[1]) : vol; }
             }
         }
         if (d_row_range(2, i, j, k, L) && SW[c] == ST_FLUID) {  // ---- W face (viscositysolver.cpp:570-664)
@@ -337,7 +352,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 RHS(SV[c - sz], V[c - sz], -fB);
                 dg[2] = vol + fR + fL + fT + fB + fF + fK;
                 rv[2] = dg[2] != 0.0f ? rval : 0.0f;
-                if (dg[2] != 0.0f) vm[2] = vol;
+                if (dg[2] != 0.0f) { vm[2] = vol; vr[2] = refdiag ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[2]) : vol; }
             }
         }
     store:
@@ -347,6 +362,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 const size_t cs = v.swz ? sidx(L, i, j, k) : c;
                 dgU[cs] = dg[0]; dgV[cs] = dg[1]; dgW[cs] = dg[2];
                 vmU[cs] = vm[0]; vmV[cs] = vm[1]; vmW[cs] = vm[2];
+                vrU[cs] = vr[0]; vrV[cs] = vr[1]; vrW[cs] = vr[2];
                 rowmask[c] = now;
 #pragma unroll
                 for (int m = 0; m < 3; m++) {
@@ -425,14 +441,19 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     if (timed) fv_ev_begin(c, 1, (double)count * (256 * NV));
     PcgSys<T, 3> vv = sys ? *sys : visc_sys<T>(c);
     if (vv.mlist) vv.mlist += (size_t)first * 256;   // the mask words are in list order
+    // which operator: the reference's (own volumes + the rounding defect of its float diagonal, d_ref_volume) under the diagonal
+    // preconditioner; the exact one under the multigrid, whose fp32 recursion bottoms out at a relative residual of 2e-5 against the
+    // former in the stiff start of the 256^3 scene (the defect changes near-rigid modes of small liquid clusters by O(1) relative to
+    // what the hierarchy, built from the exact rows, expects)
+    const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
 #define VSPMV(N_, P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, N_, P_, R_>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L, \
-                           c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
+                           vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
     const bool rdot = sc.conv ? !sc.noB : c->prm.beta_from_residual != 0;   // benchmark launches (no scalars): the variant the solve would run
     if (NV == 4 && c->nRunsV > 0 && first == 0 && count == c->nActiveV) {   // k-marching over the run list (the whole system)
         int nbm = pcg_grid(c, c->nRunsV);
         if (nbm > cap) nbm = cap;
 #define VMARCH(P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv_march<T, P_, R_>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsV, c->nRunsV, \
-                           (const unsigned *)(c->vPred ? c->rmaskV : nullptr), c->tgV, c->L, c->vmU, c->vmV, c->vmW, c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
+                           (const unsigned *)(c->vPred ? c->rmaskV : nullptr), c->tgV, c->L, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
         if (c->vPred) { if (rdot) VMARCH(true, true); else VMARCH(true, false); }
         else { if (rdot) VMARCH(false, true); else VMARCH(false, false); }
 #undef VMARCH
@@ -557,6 +578,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (prc) return prc;
     }
     const int precNow = std::is_same<T, float>::value ? 0 : 1;
+    // FLIPV_REF_DIAG=1: the diagonally preconditioned solve applies the reference's operator INCLUDING the rounding of its float
+    // diagonal (d_ref_volume) -- bit-faithful parity at sizes where that rounding shows (256^3: 7e-6 instead of 1.45e-4 against the
+    // reference's converged answer) at the price of the reference's conditioning: fp32 solves then sit closer to their attainable
+    // accuracy (tight tolerances stall more often).  Default: the exact operator.  Read per solve (tests toggle it).
+    const int refDiag = getenv("FLIPV_REF_DIAG") && atoi(getenv("FLIPV_REF_DIAG")) != 0;
     auto run_setup = [&](int swz) -> int {
         // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers
         // are shared), of the layout or of the slab make it store everywhere
@@ -570,7 +596,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const Lay RS = full ? fv_range(c, 0) : R0;
         hipLaunchKernelGGL(k_visc_setup<T>, GRID3(RS), 0, c->stream, RS, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
-                           c->vDiagW, c->vmU, c->vmV, c->vmW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2);
+                           c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, refDiag);
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         return FLIPV_OK;
@@ -621,6 +647,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const bool useMg = mgPlanned && c->vwV == 4;
         li.preconditioner = useMg ? 1 : 0;
         ranMg = useMg;
+        c->vOperatorExact = useMg ? 1 : 0;
         if (useMg) {
             if ((rc = fv_viscosity_pcg_mg(c, sc, cap, [](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); },
                                           &conv)))
@@ -655,10 +682,15 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             if (st) { success = false; stalled = true; }
         }
     }
-    if (ranMg && !success) {
+    // (A multigrid-preconditioned fp32 solve that STALLS two orders of magnitude or more below the right-hand side -- seen in the stiff
+    // start of the 256^3 scene, where the recursion bottoms out at a relative residual of 2e-5 against the reference's float-rounded
+    // operator -- keeps its iterate: it is far closer to the solution than 700 diagonal iterations get, and is reported as "not
+    // converged" like any accepted iterate.)
+    if (ranMg && !success && !(stalled && res < 1e-4 * bnorm)) {
         // The multigrid-preconditioned solve did not reach the tolerance (never seen with a hierarchy assembled for this very system;
         // a stale one -- FLIPV_VMG_KEEP > 1 after a change of dt -- over-corrects and breaks PCG down).  Its iterate is not used:
         // the solve is repeated from scratch with the diagonal, whose capped iterate is what the reference's acceptance rule is about.
+        if (getenv("FLIPV_VMG_DEBUG")) fprintf(stderr, "multigrid-preconditioned solve failed: %d iterations, residual %.3g (rhs %.3g), stalled %d; repeating with the diagonal\n", iters, res, bnorm, (int)stalled);
         c->viscSolves++;
         c->vLastPrec = 2; c->vLastIts = iters; c->vLastConverged = 0; c->vLastRelRes = bnorm > 0.0 ? res / bnorm : 0.0;
         c->vNoMultigridOnce = 1;
