@@ -52,7 +52,8 @@ class Params(C.Structure):
                 ("pressure_preconditioner", C.c_int), ("viscosity_preconditioner", C.c_int),
                 ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
                 ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int),
-                ("viscosity_update_grid_cap", C.c_int), ("beta_from_residual", C.c_int), ("spmv_run_length", C.c_int), ("reserved", C.c_int * 2)]
+                ("viscosity_update_grid_cap", C.c_int), ("beta_from_residual", C.c_int), ("spmv_run_length", C.c_int), ("reference_diagonal", C.c_int),
+                ("reserved", C.c_int * 1)]
 
 PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID = 0, 1, 2
 

@@ -578,11 +578,12 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (prc) return prc;
     }
     const int precNow = std::is_same<T, float>::value ? 0 : 1;
-    // FLIPV_REF_DIAG=1: the diagonally preconditioned solve applies the reference's operator INCLUDING the rounding of its float
+    // flipv_params.reference_diagonal = 1 (or FLIPV_REF_DIAG=1): the diagonally preconditioned solve applies the reference's operator INCLUDING the rounding of its float
     // diagonal (d_ref_volume) -- bit-faithful parity at sizes where that rounding shows (256^3: 7e-6 instead of 1.45e-4 against the
     // reference's converged answer) at the price of the reference's conditioning: fp32 solves then sit closer to their attainable
     // accuracy (tight tolerances stall more often).  Default: the exact operator.  Read per solve (tests toggle it).
-    const int refDiag = getenv("FLIPV_REF_DIAG") && atoi(getenv("FLIPV_REF_DIAG")) != 0;
+    const char *refEnv = getenv("FLIPV_REF_DIAG");
+    const int refDiag = refEnv ? (atoi(refEnv) != 0) : (c->prm.reference_diagonal != 0);   // flipv_params.reference_diagonal; the environment overrides
     auto run_setup = [&](int swz) -> int {
         // the setup kernel only stores where a row is or was; the first solve, a change of vector precision (the buffers
         // are shared), of the layout or of the slab make it store everywhere

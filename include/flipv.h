@@ -112,7 +112,15 @@ typedef struct flipv_params {
                                     every iteration either way. */
     int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 (default) =
                                     chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
-    int reserved[2];             /* must be 0 */
+    int reference_diagonal;      /* 1: the diagonally preconditioned viscosity solve applies the reference's operator INCLUDING the
+                                    rounding of its float diagonal (the reference sums vol + fR + fL + fT + fB + fF + fK in float,
+                                    viscositysolver.cpp:394-446; the defect is folded into the row's own volume, no extra bytes).
+                                    Matters where nu dt/dx^2 is large: at 256^3 (3 300) the reference's converged velocities differ
+                                    from the exact operator's by 1.5e-4 and from this mode's by 7e-6.  0 (default): the exact operator --
+                                    the rounded one is worse conditioned (the reference's own PCG needs 42 000 iterations for 1e-8
+                                    there), fp32 solves stall at tight tolerances.  The multigrid-preconditioned solve always
+                                    applies the exact operator.  Environment FLIPV_REF_DIAG=0|1 overrides.   */
+    int reserved[1];             /* must be 0 */
 } flipv_params;
 
 typedef struct flipv_solve_info {

@@ -43,7 +43,7 @@ def test_default_params_chained_substeps_match_reference_dumps(name):
     c.close()
 
 
-def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap=0, vel0=None, multigrid=False):
+def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap=0, vel0=None, multigrid=False, reference_diagonal=False):
     """GPU (default parameters unless lift_cap) and oracle (its defaults = the reference's, unless lift_cap) side by side;
     returns per substep (error, gpu stats, oracle viscosity info, oracle pressure info)"""
     from flipviscosity3d_amd.capi import Context
@@ -59,6 +59,9 @@ def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap
     if multigrid:
         from flipviscosity3d_amd.capi import PRECOND_MULTIGRID
         c.set_params(viscosity_preconditioner=PRECOND_MULTIGRID)
+    if reference_diagonal:
+        from flipviscosity3d_amd.capi import PRECOND_DIAGONAL
+        c.set_params(reference_diagonal=1, viscosity_preconditioner=PRECOND_DIAGONAL)
     c.particles = P
     o.particles = P
     out = []
@@ -72,20 +75,21 @@ def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap
     return out, perr
 
 
-@pytest.mark.parametrize("precond", ["default", "multigrid"])
+@pytest.mark.parametrize("precond", ["default", "multigrid", "reference_diagonal"])
 def test_config1_default_scene_64_default_params(oracle, precond):
     """BASELINE configs[0]: bunny in sphere_large, 64^3, nu = 5 (reference main.cpp), 3 chained substeps, default
     parameters on both sides.  The reference needs 368/427/313 viscosity iterations here: inside its cap.
-    Variant multigrid: flipv_params.viscosity_preconditioner = MULTIGRID, every other parameter the default."""
+    Variant multigrid: flipv_params.viscosity_preconditioner = MULTIGRID, every other parameter the default; variant
+    reference_diagonal: the reference's float-rounded operator under the diagonal preconditioner (flipv_params.reference_diagonal)."""
     dx, solid, P = build_host_scene(64, ("sphere_large.ply", True), ["stanford_bunny.ply"])
     assert len(P) == 73176                                        # SURVEY.md 8c
-    out, perr = run_against_live_oracle(oracle, 64, dx, solid, P, 5.0, 3, multigrid=precond == "multigrid")
+    out, perr = run_against_live_oracle(oracle, 64, dx, solid, P, 5.0, 3, multigrid=precond == "multigrid", reference_diagonal=precond == "reference_diagonal")
     for t, (err, st, vi, pi) in enumerate(out):
         assert vi["status"] == 0 and vi["iterations"] == (368, 427, 313)[t]
         assert st["viscosity"]["status"] == 0, st["viscosity"]    # converged inside the default cap of 700
         if precond == "multigrid":
             assert st["viscosity"]["preconditioner"] == 1 and st["viscosity"]["iterations"] < 100, st["viscosity"]
-        else:
+        elif precond == "default":
             # AUTO (the default): the first solve takes the diagonal; it converges in ~400 iterations, from which the multigrid is
             # predicted to be cheaper (k_viscosity.hip: fv_visc_auto_pick) and takes over
             assert st["viscosity"]["preconditioner"] == (0 if t == 0 else 1), (t, st["viscosity"])
@@ -172,7 +176,7 @@ def test_config4_miniature_with_the_stock_cap_follows_the_acceptance_rule():
     c.close()
 
 
-def converged_probe_run(name, N, precond, vel_tol=VEL_TOL, allow_stall=False):
+def converged_probe_run(name, N, precond, vel_tol=VEL_TOL, allow_stall=False, reference_diagonal=0):
     """GPU run against a compact reference dump (probe faces + particle checksums, tests/golden/make_golden.py compact_scene):
     precond "diagonal" lifts the viscosity cap like the reference's was lifted, "multigrid_stock_cap" only switches the
     preconditioner (the solve then converges inside the stock cap)"""
@@ -183,6 +187,7 @@ def converged_probe_run(name, N, precond, vel_tol=VEL_TOL, allow_stall=False):
     c = Context(N, N, N, dx)
     c.set_solid_sdf(solid)
     c.set_viscosity(float(g["nu"]))
+    c.set_params(reference_diagonal=reference_diagonal)
     if precond == "diagonal":
         c.set_params(viscosity_max_iterations=int(g["vcap"]), viscosity_preconditioner=PRECOND_DIAGONAL)
     else:
@@ -220,11 +225,11 @@ def test_config3_scene_128_converged_reference_probes(precond):
 
 
 @pytest.mark.parametrize("variant", ["diagonal_reference_operator", "diagonal", "multigrid_stock_cap"])
-def test_config3_headline_256_converged_reference_probes(variant, monkeypatch):
+def test_config3_headline_256_converged_reference_probes(variant):
     """BASELINE configs[2] ITSELF (the metric's 256^3 bunny drop, nu = 5) against the reference run with its viscosity cap lifted
     (tests/golden/make_golden.py bunny256_nu5_converged: its MIC(0) solve needs 7 689 and 13 160 iterations here, 25-45 minutes per
     substep on one core), 20 000 probe faces per component and substep, two chained substeps.
-      diagonal_reference_operator  FLIPV_REF_DIAG=1: the reference's operator including the rounding of its float diagonal
+      diagonal_reference_operator  flipv_params.reference_diagonal = 1: the reference's operator including the rounding of its float diagonal
                                    (k_viscosity.hip: d_ref_volume), GPU cap lifted like the reference's: <= 1e-4 (measured 3.5e-5 / 1.1e-5)
       diagonal                     the default, exact operator, cap lifted: 1.45e-4 / 1.96e-4, asserted <= 2.5e-4
       multigrid_stock_cap          exact operator, every parameter but the preconditioner the default: the same 1.45e-4 / 1.96e-4
@@ -237,12 +242,12 @@ def test_config3_headline_256_converged_reference_probes(variant, monkeypatch):
     if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged.npz")):
         pytest.skip("fixture not built")
     ref_op = variant == "diagonal_reference_operator"
-    monkeypatch.setenv("FLIPV_REF_DIAG", "1" if ref_op else "0")
-    converged_probe_run("bunny256_nu5_converged", 256, "diagonal" if ref_op else variant, vel_tol=VEL_TOL if ref_op else 2.5e-4, allow_stall=True)
+    converged_probe_run("bunny256_nu5_converged", 256, "diagonal" if ref_op else variant, vel_tol=VEL_TOL if ref_op else 2.5e-4, allow_stall=True,
+                        reference_diagonal=1 if ref_op else 0)
 
 
 @pytest.mark.parametrize("variant", ["diagonal_reference_operator", "multigrid_stock_cap"])
-def test_config3_headline_256_tight_reference_probes(variant, monkeypatch):
+def test_config3_headline_256_tight_reference_probes(variant):
     """the same scene, first substep, against the reference with its cap lifted AND its viscosity tolerance tightened to 1e-8
     (bunny256_nu5_tight; 42 223 reference iterations): with the reference's operator 7e-6; with the exact one still 1.45e-4 -- the
     difference is not the reference's truncation error"""
@@ -251,8 +256,8 @@ def test_config3_headline_256_tight_reference_probes(variant, monkeypatch):
     if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_tight.npz")):
         pytest.skip("fixture not built")
     ref_op = variant == "diagonal_reference_operator"
-    monkeypatch.setenv("FLIPV_REF_DIAG", "1" if ref_op else "0")
-    converged_probe_run("bunny256_nu5_tight", 256, "diagonal" if ref_op else variant, vel_tol=VEL_TOL if ref_op else 2.5e-4, allow_stall=True)
+    converged_probe_run("bunny256_nu5_tight", 256, "diagonal" if ref_op else variant, vel_tol=VEL_TOL if ref_op else 2.5e-4, allow_stall=True,
+                        reference_diagonal=1 if ref_op else 0)
 
 
 def test_config3_scene_128_default_cap_against_oracle_default_cap(oracle):
