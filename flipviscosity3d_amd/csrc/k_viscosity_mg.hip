@@ -943,7 +943,8 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     XR(-1);                       // za = omega r/d
     vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)
     PP(-1);                       // p = z
-    const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
+    static const int everyEnv = getenv("FLIPV_VMG_EVERY") ? atoi(getenv("FLIPV_VMG_EVERY")) : 0;
+    const int every = c->prm.check_every > 0 ? c->prm.check_every : (everyEnv > 0 ? everyEnv : 8);
     int conv = -1;
     auto iteration = [&](int it) {   // it = IT_DEVICE inside the graph
         spmv(c, sc, it == IT_DEVICE ? -1 : it);
