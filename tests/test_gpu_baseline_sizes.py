@@ -176,7 +176,7 @@ def test_config4_miniature_with_the_stock_cap_follows_the_acceptance_rule():
     c.close()
 
 
-def converged_probe_run(name, N, precond, vel_tol=VEL_TOL, allow_stall=False, reference_diagonal=0):
+def converged_probe_run(name, N, precond, vel_tol=VEL_TOL, allow_stall=False, reference_diagonal=0, precision=0):
     """GPU run against a compact reference dump (probe faces + particle checksums, tests/golden/make_golden.py compact_scene):
     precond "diagonal" lifts the viscosity cap like the reference's was lifted, "multigrid_stock_cap" only switches the
     preconditioner (the solve then converges inside the stock cap)"""
@@ -187,7 +187,7 @@ def converged_probe_run(name, N, precond, vel_tol=VEL_TOL, allow_stall=False, re
     c = Context(N, N, N, dx)
     c.set_solid_sdf(solid)
     c.set_viscosity(float(g["nu"]))
-    c.set_params(reference_diagonal=reference_diagonal)
+    c.set_params(reference_diagonal=reference_diagonal, precision=precision)
     if precond == "diagonal":
         c.set_params(viscosity_max_iterations=int(g["vcap"]), viscosity_preconditioner=PRECOND_DIAGONAL)
     else:
@@ -246,15 +246,18 @@ def test_config3_headline_256_converged_reference_probes(variant):
                         reference_diagonal=1 if ref_op else 0)
 
 
-@pytest.mark.parametrize("variant", ["diagonal_reference_operator", "multigrid_stock_cap"])
+@pytest.mark.parametrize("variant", ["fp64_reference_operator", "diagonal_reference_operator", "multigrid_stock_cap"])
 def test_config3_headline_256_tight_reference_probes(variant):
     """the same scene, first substep, against the reference with its cap lifted AND its viscosity tolerance tightened to 1e-8
-    (bunny256_nu5_tight; 42 223 reference iterations): with the reference's operator 7e-6; with the exact one still 1.45e-4 -- the
-    difference is not the reference's truncation error"""
+    (bunny256_nu5_tight; 42 223 reference iterations): with the reference's operator 7e-6 in fp32 and 5.6e-7 with fp64 vectors (asserted
+    <= 5e-6: the same solution); with the exact one still 1.45e-4 -- the difference is not the reference's truncation error"""
     import os
     from helpers import GOLDEN
     if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_tight.npz")):
         pytest.skip("fixture not built")
+    if variant == "fp64_reference_operator":
+        converged_probe_run("bunny256_nu5_tight", 256, "diagonal", vel_tol=5e-6, reference_diagonal=1, precision=1)
+        return
     ref_op = variant == "diagonal_reference_operator"
     converged_probe_run("bunny256_nu5_tight", 256, "diagonal" if ref_op else variant, vel_tol=VEL_TOL if ref_op else 2.5e-4, allow_stall=True,
                         reference_diagonal=1 if ref_op else 0)
