@@ -16,7 +16,8 @@ def agg(path, cname):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == cname:
-            d[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")   # (kernels in anonymous namespaces would otherwise all collapse to "")
+            d[name.split("(")[0]].append(float(r["Counter_Value"]))
     return d
 
 
