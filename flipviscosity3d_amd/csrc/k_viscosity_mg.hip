@@ -114,8 +114,8 @@ struct VLevelDev {       // what kernels need of a coarse level
     float *coef[3][VS];
     Vec3p x, y, b, t;
     Box3 box;
-    // strips: runs of 64 consecutive i of one (j, k) row of the box that hold at least one row of the operator, in box order
-    // (i fastest); the sweeps of a level visit only these (the liquid fills 10-20 % of its bounding box on the coarse levels too)
+    // "strips" (the name is from the first version: 64 consecutive i of a row): the BRICKS (8 x 4 x 2 indices, cidx) of the box that hold
+    // at least one row of the operator, numbered inside the box's brick range; the sweeps of a level visit only these
     const int *strips;
     int nstrips;
     // the coarsest level: per component the rows (as box positions), at most 1024 each, for the LDS-resident sweeps; rowcnt[3] = 1
@@ -130,13 +130,24 @@ struct FineOp {          // the matrix-free level 0 (k_viscosity.hip's arrays)
 };
 
 __device__ unsigned g_dropped[2];
+// Coarse levels are stored in BRICKS of 8 x 4 x 2 indices (64 entries = two 128-byte lines): the liquid fills 10-30 % of a level's
+// bounding box, and with plain rows a wave's 64 consecutive i of a (j, k) row carried rows in a third of its lanes while every
+// array was fetched in whole lines (level 1 of the 256^3 bunny: 80 MB per sweep for 25 MB of operator).  A wave now owns one brick
+// -- a compact 8 x 4 x 2 piece of space, far fuller wherever the liquid is at all -- and its own-index accesses are 256 contiguous
+// bytes.  One brick of padding on every side: indices -1 and PX..PX+7 are addressable, nothing needs a guard zone.
+// For a coarse level Lay::sy / Lay::sz hold the BRICK strides (bricks per row, bricks per plane), not index strides.
+__host__ __device__ __forceinline__ size_t cidx(const Lay &L, int i, int j, int k) {
+    const int ip = i + 8, jp = j + 4, kp = k + 2;
+    return ((size_t)((long)(kp >> 1) * L.sz + (long)(jp >> 2) * L.sy + (long)(ip >> 3)) << 6) + (size_t)(((kp & 1) << 5) + ((jp & 3) << 3) + (ip & 7));
+}
 static Lay coarse_lay(const Lay &F) {
     Lay C;
     C.I = (F.I + 1) / 2; C.J = (F.J + 1) / 2; C.K = (F.K + 1) / 2;
-    C.PX = ((C.I + 1 + 3) / 4) * 4; C.PY = C.J + 1; C.PZ = C.K + 1;
-    C.sy = C.PX; C.sz = (long)C.PX * C.PY;
-    C.n = (size_t)C.sz * C.PZ;
-    C.guard = (((size_t)C.sz + (size_t)C.sy + 8) + 63) / 64 * 64;
+    C.PX = C.I + 2; C.PY = C.J + 2; C.PZ = C.K + 2;                         // indices 0..I / J / K, one more for the stencils' reach
+    const long nbx = (C.PX + 8 + 7) / 8 + 1, nby = (C.PY + 4 + 3) / 4 + 1, nbz = (C.PZ + 2 + 1) / 2 + 1;   // with the padding bricks
+    C.sy = nbx; C.sz = nbx * nby;
+    C.n = (size_t)(nbx * nby * nbz) * 64;
+    C.guard = 64;
     C.ox = C.oy = C.oz = 0;   // single-domain hierarchy: every level's box is the level's whole index space
     C.ib = 0; C.ie = C.PX; C.jb = 0; C.je = C.PY; C.kb = 0; C.ke = C.PZ;
     C.olo[0] = C.olo[1] = C.olo[2] = 0; C.ohi[0] = C.PX; C.ohi[1] = C.PY; C.ohi[2] = C.PZ;
@@ -182,7 +193,7 @@ __device__ __forceinline__ void d_coarse_add(const VLevelDev &C, int c, const in
     const int dx = J[0] - I[0], dy = J[1] - I[1], dz = J[2] - I[2];
     if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) { if (v != 0.0f) atomicAdd(&g_dropped[0], 1u); return; }  // cannot happen: the pattern is closed under this coarsening
     const int s = d_slot_of(c, c2, dx, dy, dz);
-    if (s >= 0) atomicAdd(C.coef[c][s] + gidx(C.L, I[0], I[1], I[2]), v);
+    if (s >= 0) atomicAdd(C.coef[c][s] + cidx(C.L, I[0], I[1], I[2]), v);
     else if (v != 0.0f) atomicAdd(&g_dropped[1], 1u);
 }
 // scatter one entry A(a, b) = v of a finer level into the coarse operator
@@ -203,7 +214,7 @@ __device__ __forceinline__ void d_rap_entry(const VLevelDev &C, int c, const int
 // ---- level l -> level l+1 (l >= 1): every stored entry of the dense-slot operator inside the level's box
 __global__ void k_vmg_rap(VLevelDev F, VLevelDev C) {
     BOX_IJK_OR_RETURN(F.box);
-    const size_t ci = gidx(F.L, i, j, k);
+    const size_t ci = cidx(F.L, i, j, k);
     const int p[3] = {i, j, k};
     for (int c = 0; c < 3; c++) {
         if (F.coef[c][ST.diag[c]][ci] == 0.0f) continue;
@@ -268,7 +279,7 @@ __device__ __forceinline__ void d_rap_gather_child(const VLevelDev &F, const int
 #ifndef FLIPV_VMG_TEST_NO_BOXCHECK   // (build switch for checking that tests/test_gpu_parity.py::test_multigrid_hierarchy_carries_nothing_over... has teeth)
     if (p[0] < F.box.lo[0] || p[0] >= F.box.hi[0] || p[1] < F.box.lo[1] || p[1] >= F.box.hi[1] || p[2] < F.box.lo[2] || p[2] >= F.box.hi[2]) return;
 #endif
-    const size_t ci = gidx(F.L, p[0], p[1], p[2]);
+    const size_t ci = cidx(F.L, p[0], p[1], p[2]);
     if (F.coef[C][slot_diag(C)][ci] == 0.0f) return;   // no row: all its slots are 0
     RapGatherSlots<C, DN, A_, B_, 0>::run(F, ci, acc);
 }
@@ -345,7 +356,7 @@ __device__ __forceinline__ void d_rap_gather_row_fine(const FineOp &A, const Lay
     d_rap_gather_child_fine<C, -1, 0, 0>(A, L, I, acc); d_rap_gather_child_fine<C, -1, 1, 0>(A, L, I, acc); d_rap_gather_child_fine<C, -1, 0, 1>(A, L, I, acc); d_rap_gather_child_fine<C, -1, 1, 1>(A, L, I, acc);
     d_rap_gather_child_fine<C, 0, 0, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 0, 1, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 0, 0, 1>(A, L, I, acc); d_rap_gather_child_fine<C, 0, 1, 1>(A, L, I, acc);
     d_rap_gather_child_fine<C, 1, 0, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 1, 1, 0>(A, L, I, acc); d_rap_gather_child_fine<C, 1, 0, 1>(A, L, I, acc); d_rap_gather_child_fine<C, 1, 1, 1>(A, L, I, acc);
-    const size_t co = gidx(Cl.L, i, j, k);
+    const size_t co = cidx(Cl.L, i, j, k);
 #pragma unroll
     for (int s = 0; s < VS; s++) Cl.coef[C][s][co] = acc[s];
 }
@@ -367,7 +378,7 @@ __device__ __forceinline__ void d_rap_gather_row(const VLevelDev &F, const VLeve
     d_rap_gather_child<C, -1, 0, 0>(F, I, acc); d_rap_gather_child<C, -1, 1, 0>(F, I, acc); d_rap_gather_child<C, -1, 0, 1>(F, I, acc); d_rap_gather_child<C, -1, 1, 1>(F, I, acc);
     d_rap_gather_child<C, 0, 0, 0>(F, I, acc); d_rap_gather_child<C, 0, 1, 0>(F, I, acc); d_rap_gather_child<C, 0, 0, 1>(F, I, acc); d_rap_gather_child<C, 0, 1, 1>(F, I, acc);
     d_rap_gather_child<C, 1, 0, 0>(F, I, acc); d_rap_gather_child<C, 1, 1, 0>(F, I, acc); d_rap_gather_child<C, 1, 0, 1>(F, I, acc); d_rap_gather_child<C, 1, 1, 1>(F, I, acc);
-    const size_t co = gidx(Cl.L, i, j, k);
+    const size_t co = cidx(Cl.L, i, j, k);
 #pragma unroll
     for (int s = 0; s < VS; s++) Cl.coef[C][s][co] = acc[s];
 }
@@ -380,17 +391,16 @@ __global__ __launch_bounds__(256) void k_vmg_rap_gather(VLevelDev F, VLevelDev C
     else d_rap_gather_row<2>(F, Cl, i, j, k);
 }
 
-// ---- coarse levels: y = A x for one dof of component C
+// ---- coarse levels: y = A x for one dof of component C at (i, j, k)
 template <int C>
-__device__ __forceinline__ float d_apply(const VLevelDev &A, const Vec3p &x, size_t ci) {
-    const long sy = A.L.sy, sz = A.L.sz;
+__device__ __forceinline__ float d_apply(const VLevelDev &A, const Vec3p &x, size_t ci, int i, int j, int k) {
     // all coefficients, then all neighbour values, then the sum: 46 independent loads instead of 23 dependent
-    // load-test-load chains (empty slots hold 0 and the guard zones make every neighbour address valid)
+    // load-test-load chains (empty slots hold 0 and the padding bricks make every neighbour address valid)
     float v[VS], xv[VS];
 #pragma unroll
     for (int q = 0; q < VS; q++) v[q] = A.coef[C][q][ci];
 #pragma unroll
-    for (int q = 0; q < VS; q++) xv[q] = x.p[slot_comp(C, q)][(long)ci + slot_off(C, q, 0) + slot_off(C, q, 1) * sy + slot_off(C, q, 2) * sz];
+    for (int q = 0; q < VS; q++) xv[q] = x.p[slot_comp(C, q)][cidx(A.L, i + slot_off(C, q, 0), j + slot_off(C, q, 1), k + slot_off(C, q, 2))];
     float s = 0.0f;
 #pragma unroll
     for (int q = 0; q < VS; q++) s += v[q] * xv[q];
@@ -407,8 +417,9 @@ enum VmgOp { OP_RESTRICT = 0,   // b = P^T (finer level's t) ; x = omega b/d    
        OP_POST2 = 5,      // x = t + omega (b - A t)/d
        OP_SWEEP_XY = 6,   // y = x + omega (b - A x)/d     (coarsest level)
        OP_SWEEP_YX = 7 }; // x = y + omega (b - A y)/d
-// (P^T t)(C, P): the <= 12 fine children of coarse dof P of component C
-template <int C>
+// (P^T t)(C, P): the <= 12 fine children of coarse dof P of component C.  FINE0: the finer level is level 0 (plain rows, gidx);
+// otherwise a coarse level (bricks, cidx)
+template <int C, bool FINE0>
 __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const int P[3]) {
     constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
     float s = 0.0f;
@@ -420,17 +431,17 @@ __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const
             for (int b = 0; b < 2; b++) {
                 int q[3];
                 q[C] = 2 * P[C] + dn; q[t1] = 2 * P[t1] + a; q[t2] = 2 * P[t2] + b;
-                if (d_in_lattice(F, C, q)) s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][gidx(F, q[0], q[1], q[2])];
+                if (d_in_lattice(F, C, q)) s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][FINE0 ? gidx(F, q[0], q[1], q[2]) : cidx(F, q[0], q[1], q[2])];
             }
     return s;
 }
-template <int OP, int C>
+template <int OP, int C, bool FINE0>
 __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
-    const size_t ci = gidx(A.L, i, j, k);
+    const size_t ci = cidx(A.L, i, j, k);
     const int P[3] = {i, j, k};
     const float d = A.coef[C][slot_diag(C)][ci];
     if (OP == OP_RESTRICT) {
-        const float s = d != 0.0f ? d_restrict<C>(F, ft, P) : 0.0f;   // (a coarse dof with a fine child that is a row has a diagonal)
+        const float s = d != 0.0f ? d_restrict<C, FINE0>(F, ft, P) : 0.0f;   // (a coarse dof with a fine child that is a row has a diagonal)
         A.b.p[C][ci] = s;
         A.x.p[C][ci] = d != 0.0f ? VMG_OMEGA * s / d : 0.0f;
         return;
@@ -440,54 +451,68 @@ __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, con
         int Q[2][3];
         float w[2];
         const int n = d_parents(C, P, Q, w);
-        float s = w[0] * cx.p[C][gidx(Cn, Q[0][0], Q[0][1], Q[0][2])];
-        if (n == 2) s += w[1] * cx.p[C][gidx(Cn, Q[1][0], Q[1][1], Q[1][2])];
+        float s = w[0] * cx.p[C][cidx(Cn, Q[0][0], Q[0][1], Q[0][2])];
+        if (n == 2) s += w[1] * cx.p[C][cidx(Cn, Q[1][0], Q[1][1], Q[1][2])];
         A.y.p[C][ci] += s;
         return;
     }
     const Vec3p &in = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.x : (OP == OP_POST2 ? A.t : A.y);
     const Vec3p &out = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.y : ((OP == OP_RESID || OP == OP_POST1) ? A.t : A.x);
-    const float ax = d_apply<C>(A, in, ci);
+    const float ax = d_apply<C>(A, in, ci, i, j, k);
     const float bb = A.b.p[C][ci];
     out.p[C][ci] = OP == OP_RESID ? bb - ax : in.p[C][ci] + VMG_OMEGA * (bb - ax) / d;
 }
-template <int OP>
+template <int OP, bool FINE0>
 __device__ __forceinline__ void d_vmg_step_c(int c, const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
-    if (c == 0) d_vmg_step<OP, 0>(A, F, ft, Cn, cx, i, j, k);
-    else if (c == 1) d_vmg_step<OP, 1>(A, F, ft, Cn, cx, i, j, k);
-    else d_vmg_step<OP, 2>(A, F, ft, Cn, cx, i, j, k);
+    if (c == 0) d_vmg_step<OP, 0, FINE0>(A, F, ft, Cn, cx, i, j, k);
+    else if (c == 1) d_vmg_step<OP, 1, FINE0>(A, F, ft, Cn, cx, i, j, k);
+    else d_vmg_step<OP, 2, FINE0>(A, F, ft, Cn, cx, i, j, k);
 }
-// One step of one level as a launch over the level's box: blockIdx.z = 3 * plane + component.  The level descriptors live in
-// device memory (VmgState::d_lev, uploaded per solve): lev[l] is this level, lev[l - 1] the finer one (l = 0: the fine level's
-// lattice and residual come as arguments), lev[l + 1] the coarser one.  conv: nothing to do once the solve has stopped.
+// One step of one level: a wave per listed BRICK (8 x 4 x 2 indices) and component.  The list holds the bricks of the level's box
+// that carry at least one row, numbered inside the box's brick range (bx fastest); positions of an edge brick that lie outside the
+// box are skipped (they hold other solves' entries).  The level descriptors live in device memory (VmgState::d_lev, uploaded per
+// solve): lev[l] is this level, lev[l - 1] the finer one (l = 0: the fine level's lattice and residual come as arguments), lev[l + 1]
+// the coarser one.  conv: nothing to do once the solve has stopped.
+struct BrickRange { int b0[3], nb[3]; };   // first brick and brick counts of a box, per axis (padded brick coordinates)
+__device__ __forceinline__ BrickRange d_brick_range(const Box3 &B) {
+    BrickRange R;
+    R.b0[0] = (B.lo[0] + 8) >> 3; R.nb[0] = ((B.hi[0] - 1 + 8) >> 3) - R.b0[0] + 1;
+    R.b0[1] = (B.lo[1] + 4) >> 2; R.nb[1] = ((B.hi[1] - 1 + 4) >> 2) - R.b0[1] + 1;
+    R.b0[2] = (B.lo[2] + 2) >> 1; R.nb[2] = ((B.hi[2] - 1 + 2) >> 1) - R.b0[2] + 1;
+    return R;
+}
+// this lane's index inside brick `code` of the box's brick range; false if it lies outside the box
+__device__ __forceinline__ bool d_brick_lane(const Box3 &B, int code, int lane, int &i, int &j, int &k) {
+    const BrickRange R = d_brick_range(B);
+    const int bx = code % R.nb[0], r = code / R.nb[0], by = r % R.nb[1], bz = r / R.nb[1];
+    i = ((R.b0[0] + bx) << 3) - 8 + (lane & 7);
+    j = ((R.b0[1] + by) << 2) - 4 + ((lane >> 3) & 3);
+    k = ((R.b0[2] + bz) << 1) - 2 + (lane >> 5);
+    return i >= B.lo[0] && i < B.hi[0] && j >= B.lo[1] && j < B.hi[1] && k >= B.lo[2] && k < B.hi[2];
+}
 template <int OP>
 __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv) {
     if (*conv >= 0) return;
     const VLevelDev &A = lev[l];
-    const int sidx = (int)blockIdx.x * 4 + (int)threadIdx.y;   // a wave per strip and component
+    const int sidx = (int)blockIdx.x * 4 + (int)threadIdx.y;   // a wave per brick and component
     if (sidx >= A.nstrips) return;
     const int c = (int)blockIdx.y;
-    const int code = A.strips[sidx];
-    const int nsx = (A.box.hi[0] - A.box.lo[0] + 63) >> 6, h = A.box.hi[1] - A.box.lo[1];
-    const int sx = code % nsx, r = code / nsx;
-    const int i = A.box.lo[0] + sx * 64 + (int)threadIdx.x, j = A.box.lo[1] + r % h, k = A.box.lo[2] + r / h;
-    if (i >= A.box.hi[0]) return;
+    int i, j, k;
+    if (!d_brick_lane(A.box, A.strips[sidx], (int)threadIdx.x, i, j, k)) return;
     if (OP == OP_RESTRICT) {
-        if (l == 0) d_vmg_step_c<OP>(c, A, F0, ft0, A.L, ft0, i, j, k);
-        else d_vmg_step_c<OP>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
-    } else if (OP == OP_PROLONG) d_vmg_step_c<OP>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
-    else d_vmg_step_c<OP>(c, A, A.L, ft0, A.L, ft0, i, j, k);
+        if (l == 0) d_vmg_step_c<OP, true>(c, A, F0, ft0, A.L, ft0, i, j, k);
+        else d_vmg_step_c<OP, false>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
+    } else if (OP == OP_PROLONG) d_vmg_step_c<OP, false>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
+    else d_vmg_step_c<OP, false>(c, A, A.L, ft0, A.L, ft0, i, j, k);
 }
-// strips of a level's box that hold rows: flags (one wave per strip), then an ordered compaction by one workgroup
-__global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__restrict__ flag) {
-    const int nsx = (A.box.hi[0] - A.box.lo[0] + 63) >> 6, h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
+// bricks of a level's box that hold rows: flags (one wave per brick), then an ordered compaction by one workgroup
+__global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__restrict__ flag, int nbricks) {
     const int sidx = (int)blockIdx.x * 4 + (int)threadIdx.y;
-    if (sidx >= nsx * h * dz) return;
-    const int sx = sidx % nsx, r = sidx / nsx;
-    const int i = A.box.lo[0] + sx * 64 + (int)threadIdx.x, j = A.box.lo[1] + r % h, k = A.box.lo[2] + r / h;
+    if (sidx >= nbricks) return;
+    int i, j, k;
     bool any = false;
-    if (i < A.box.hi[0]) {
-        const size_t ci = gidx(A.L, i, j, k);
+    if (d_brick_lane(A.box, sidx, (int)threadIdx.x, i, j, k)) {
+        const size_t ci = cidx(A.L, i, j, k);
         any = A.coef[0][slot_diag(0)][ci] != 0.0f || A.coef[1][slot_diag(1)][ci] != 0.0f || A.coef[2][slot_diag(2)][ci] != 0.0f;
     }
     const unsigned long long m = __ballot(any);
@@ -532,7 +557,7 @@ __global__ __launch_bounds__(1024) void k_vmg_coarsest_rows(VLevelDev A, int *__
             bool row = false;
             if (q < 3 * npos) {
                 c = q / npos; r = q - c * npos;
-                row = A.coef[c][slot_diag(c)][gidx(A.L, A.box.lo[0] + r % w, A.box.lo[1] + (r / w) % h, A.box.lo[2] + r / (w * h))] != 0.0f;
+                row = A.coef[c][slot_diag(c)][cidx(A.L, A.box.lo[0] + r % w, A.box.lo[1] + (r / w) % h, A.box.lo[2] + r / (w * h))] != 0.0f;
             }
             if (row) { const int idx = atomicAdd(&n[c], 1); if (idx < 1024) out[c * 1024 + idx] = r; }
         }
@@ -542,14 +567,14 @@ __global__ __launch_bounds__(1024) void k_vmg_coarsest_rows(VLevelDev A, int *__
 }
 
 // the coarsest levels in one workgroup: levels lev[first..n), lev[first] restricts from lev[first - 1] (first = 0: from (F0, ft0))
-template <int OP>
+template <int OP, bool FINE0 = false>
 __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx) {
     const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
     const int n = w * h * dz;
     for (int q = threadIdx.x; q < 3 * n; q += blockDim.x) {
         const int c = q / n, r = q - c * n;
         const int i = A.box.lo[0] + r % w, j = A.box.lo[1] + (r / w) % h, k = A.box.lo[2] + r / (w * h);
-        d_vmg_step_c<OP>(c, A, F, ft, Cn, cx, i, j, k);
+        d_vmg_step_c<OP, FINE0>(c, A, F, ft, Cn, cx, i, j, k);
     }
     __syncthreads();
 }
@@ -559,19 +584,19 @@ __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, co
 // of the cycle's 520 before).  Falls back to the global-memory sweeps when the box or a component's row count does not fit.
 struct CoarseRow { float cf[VS]; float invd, b; int li; size_t ci; bool has; };
 template <int C>
-__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP) {
+__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, bool fine0, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP) {
     R.has = (int)threadIdx.x < nrows;
     if (!R.has) return;
     const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1];
     const int r = rowlist[threadIdx.x];
     const int di = r % w, dj = (r / w) % h, dk = r / (w * h);
     const int P[3] = {A.box.lo[0] + di, A.box.lo[1] + dj, A.box.lo[2] + dk};
-    R.ci = gidx(A.L, P[0], P[1], P[2]);
+    R.ci = cidx(A.L, P[0], P[1], P[2]);
     R.li = (di + 1) + W * ((dj + 1) + H * (dk + 1));
 #pragma unroll
     for (int q = 0; q < VS; q++) R.cf[q] = A.coef[C][q][R.ci];
     R.invd = 1.0f / R.cf[slot_diag(C)];
-    R.b = d_restrict<C>(F, ft, P);
+    R.b = fine0 ? d_restrict<C, true>(F, ft, P) : d_restrict<C, false>(F, ft, P);
     xs0[C * NP + R.li] = VMG_OMEGA * R.b * R.invd;
 }
 template <int C>
@@ -601,7 +626,7 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
     for (int l = first; l < n; l++) {   // down
         const VLevelDev &A = lev[l];
         if (l == n - 1 && coarsest_in_lds) break;   // restricted straight into registers below
-        if (l == 0) d_tail_step<OP_RESTRICT>(A, F0, ft0, A.L, ft0);
+        if (l == 0) d_tail_step<OP_RESTRICT, true>(A, F0, ft0, A.L, ft0);
         else d_tail_step<OP_RESTRICT>(A, lev[l - 1].L, lev[l - 1].t, A.L, ft0);
         if (l + 1 < n) {
             d_tail_step<OP_PRE2>(A, A.L, ft0, A.L, ft0);
@@ -619,9 +644,9 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
         const Lay &F = n - 1 == 0 ? F0 : lev[n - 2].L;
         const Vec3p &ft = n - 1 == 0 ? ft0 : lev[n - 2].t;
         CoarseRow RU, RV, RW;
-        d_coarsest_load<0>(A, F, ft, rowlist[0], cnt[0], W, H, RU, xs, NP);
-        d_coarsest_load<1>(A, F, ft, rowlist[1], cnt[1], W, H, RV, xs, NP);
-        d_coarsest_load<2>(A, F, ft, rowlist[2], cnt[2], W, H, RW, xs, NP);
+        d_coarsest_load<0>(A, F, ft, n - 1 == 0, rowlist[0], cnt[0], W, H, RU, xs, NP);
+        d_coarsest_load<1>(A, F, ft, n - 1 == 0, rowlist[1], cnt[1], W, H, RV, xs, NP);
+        d_coarsest_load<2>(A, F, ft, n - 1 == 0, rowlist[2], cnt[2], W, H, RW, xs, NP);
         __syncthreads();
         float *cur = xs, *nxt = xs + 3 * VMG_LDS_POS;
         for (int s = 0; s < sweeps; s++) {
@@ -648,7 +673,7 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
 struct ZeroSet { float *p[3 * VS]; int n; };
 __global__ __launch_bounds__(256) void k_vmg_zero_box(ZeroSet Z, Lay L, Box3 B) {
     BOX_IJK_OR_RETURN(B);
-    const size_t ci = gidx(L, i, j, k);
+    const size_t ci = cidx(L, i, j, k);
     for (int a = 0; a < Z.n; a++) Z.p[a][ci] = 0.0f;
 }
 
@@ -757,7 +782,7 @@ static int vmg_alloc_state(flipv_context *c) {
             if ((rc = vmg_alloc(c, s, l.L, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, l.L, 12, &vb))) return rc;
             s->vecBlocks.push_back({vb, per * 12 * sizeof(float)});
             {
-                const size_t nstr = (size_t)cdiv(l.L.PX, 64) * l.L.PY * l.L.PZ;
+                const size_t nstr = l.L.n / 64;   // bricks of the level
                 HIPCHK(c, hipMalloc((void **)&l.strips, 2 * nstr * sizeof(int)));
                 s->allocs.push_back(l.strips);
                 l.stripFlag = l.strips + nstr;
@@ -858,8 +883,9 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     if (!s->lev.empty()) {
         for (int l = 0; l < s->tailFirst; l++) {
             VLevel &A = s->lev[l];
-            const int nstr = (int)cdiv(A.box.hi[0] - A.box.lo[0], 64) * (A.box.hi[1] - A.box.lo[1]) * (A.box.hi[2] - A.box.lo[2]);
-            hipLaunchKernelGGL(k_vmg_strip_flags, dim3(cdiv(nstr, 4)), dim3(64, 4, 1), 0, c->stream, dev_of(A), A.stripFlag);
+            const int nstr = ((((A.box.hi[0] - 1 + 8) >> 3) - ((A.box.lo[0] + 8) >> 3)) + 1) * ((((A.box.hi[1] - 1 + 4) >> 2) - ((A.box.lo[1] + 4) >> 2)) + 1) *
+                             ((((A.box.hi[2] - 1 + 2) >> 1) - ((A.box.lo[2] + 2) >> 1)) + 1);   // bricks of the box (d_brick_range)
+            hipLaunchKernelGGL(k_vmg_strip_flags, dim3(cdiv(nstr, 4)), dim3(64, 4, 1), 0, c->stream, dev_of(A), A.stripFlag, nstr);
             hipLaunchKernelGGL(k_vmg_strip_compact, dim3(1), dim3(1024), 0, c->stream, (const int *)A.stripFlag, nstr, A.strips, s->d_stripCount + l);
         }
         hipLaunchKernelGGL(k_vmg_coarsest_rows, dim3(1), dim3(1024), 0, c->stream, dev_of(s->lev.back()), s->d_rowlist, s->d_rowcnt);
@@ -880,7 +906,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dropped), sizeof(h));
         fprintf(stderr, "vmg dropped entries: out of range %u, no slot %u; levels %zu, tail from %d\n", h[0], h[1], s->lev.size(), s->tailFirst);
-        for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d), %d strips\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2], s->lev[l].nstrips); }
+        for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d), %d bricks\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2], s->lev[l].nstrips); }
     }
     HIPCHK(c, hipGetLastError());
     *out = s;
