@@ -565,14 +565,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     }
     // Layout of x, r, q and the diagonal -- the arrays that are only ever read at a lane's own indices: swizzled 8 x 4
     // patches (sidx) go with the 16-lane tile geometry; s, which the SpMV reads with its halo (and slabs exchange), stays
-    // plain, and so does everything under the opt-in multigrid.  The geometry is only known once the tiles are built,
+    // plain, and so do the multigrid's sweep vectors (za, zb, t0: each is the next sweep's input).  The geometry is only known once the tiles are built,
     // so the setup kernel runs in the layout of the previous solve's geometry and is repeated on the rare solve where
     // the geometry changes.
-    // the preconditioner of this solve (the multigrid needs fp32 vectors in the plain layout over a whole, single-rank index space)
+    // the preconditioner of this solve (the multigrid needs fp32 vectors over a whole, single-rank index space)
     const bool mgPossible = std::is_same<T, float>::value && !c->comm && !c->isBlock && c->prm.viscosity_lane_width != 2 && !c->vNoMultigridOnce;
     const bool mgPlanned = mgPossible && (c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID ||
                                           (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && fv_visc_auto_pick(c)));
-    const bool swzOk = c->allowSwz && !mgPlanned;
+    const bool swzOk = c->allowSwz;   // (also under the multigrid: its own kernels address diag / x / r / q / own volumes through sidx, its sweep vectors stay plain)
     if (mgPossible && c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && !c->vmgState && !(getenv("FLIPV_VISC_AUTO") && atoi(getenv("FLIPV_VISC_AUTO")) == 0)) {
         const int prc = fv_vmg_prepare(c);   // AUTO may pick the multigrid later in the run: allocate its hierarchy now, not in that substep
         if (prc) return prc;

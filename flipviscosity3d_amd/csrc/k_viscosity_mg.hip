@@ -124,6 +124,7 @@ struct VLevelDev {       // what kernels need of a coarse level
     const int *rowcnt;    // [4]
 };
 struct FineOp {          // the matrix-free level 0 (k_viscosity.hip's arrays)
+    int swz;             // 1: vm is stored in the swizzled plane layout (sidx); the factors and the mask never are
     const float *vm[3];
     const float *fC, *fE[3];
     const uint8_t *mask;
@@ -337,7 +338,7 @@ __device__ __forceinline__ void d_rap_gather_child_fine(const FineOp &A, const L
     f.m = A.mask[ci];
     if (!((f.m >> C) & 1u)) return;
     const long st[3] = {1, L.sy, L.sz};
-    f.vm = A.vm[C][ci];
+    f.vm = A.vm[C][A.swz ? sidx(L, p[0], p[1], p[2]) : ci];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         if (a == C) { f.fP[a] = A.fC[ci]; f.fM[a] = A.fC[ci - st[C]]; }
@@ -863,6 +864,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         }
     if (!s->lev.empty()) {
         FineOp A;
+        A.swz = c->vSwz;
         A.vm[0] = c->vmU; A.vm[1] = c->vmV; A.vm[2] = c->vmW;
         A.fC = c->fC; A.fE[0] = c->fEU; A.fE[1] = c->fEV; A.fE[2] = c->fEW;
         A.mask = c->vRowMask;
@@ -944,7 +946,7 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
         }
 #undef STEP
         GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
-                           v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
+                           c->vSwz, v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
     }
     fv_visc_sweep_f32(c, s->zb, s->za, 1, sc, it_spmv, VMG_OMEGA, 0);                       // post-sweeps: zb -> za -> zb
     fv_visc_sweep_f32(c, s->za, s->zb, 3, sc, it_spmv, VMG_OMEGA, sig_shift);
@@ -963,8 +965,8 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     float *dg[3] = {c->vDiagU, c->vDiagV, c->vDiagW};
     float *x[3] = {(float *)c->vX[0], (float *)c->vX[1], (float *)c->vX[2]}, *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
     float *p[3] = {(float *)c->vS[0], (float *)c->vS[1], (float *)c->vS[2]}, *q[3] = {(float *)c->vZ[0], (float *)c->vZ[1], (float *)c->vZ[2]};
-#define XR(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), VMG_OMEGA, sc, it_))
-#define PP(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, v3(s->zb), v3(p), sc, it_))
+#define XR(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), VMG_OMEGA, sc, it_))
+#define PP(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(s->zb), v3(p), sc, it_))
     HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
     XR(-1);                       // za = omega r/d
     vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)
