@@ -467,14 +467,14 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
 }
 
 // flipv_params.viscosity_preconditioner = AUTO: the diagonal or the multigrid V-cycle, whichever the previous solve says will be
-// cheaper.  Costs in units of one diagonal-preconditioned iteration (SpMV + update, 41 us at 256^3): a multigrid iteration ~9 (5
-// fine SpMV-class launches + the coarse levels, 340-380 us), its set-up ~35 (1.3 ms: Galerkin gathers, lists, graph capture, the
+// cheaper.  Costs in units of one diagonal-preconditioned iteration (SpMV + update, 41 us at 256^3): a multigrid iteration ~7.5 (5
+// fine SpMV-class launches + the coarse levels, 300 us), its set-up ~35 (1.3 ms: Galerkin gathers, lists, graph capture, the
 // cycle before the first iteration); one multigrid iteration does the work of ~15 diagonal ones (10-30 measured on the bench scene,
 // DESIGN.md 3).  The diagonal solve stops at the cap whether converged or not
 // (the reference's budget); the multigrid is only worth starting when it is predicted to CONVERGE for less than that:
-//   after a diagonal solve that converged in n iterations        -> multigrid next if 35 + 9 n/15 < n           (n > ~100)
-//   after a diagonal solve stopped at the cap with residual rho  -> n is extrapolated, n = cap ln(tol)/ln(rho); multigrid if 35 + 9 n/15 < cap
-//   after a multigrid solve of m iterations                      -> stay while 35 + 9 m < min(15 m, cap)        (6 <= m <= 73 at the stock cap)
+//   after a diagonal solve that converged in n iterations        -> multigrid next if 35 + 7.5 n/15 < n         (n > ~80)
+//   after a diagonal solve stopped at the cap with residual rho  -> n is extrapolated, n = cap ln(tol)/ln(rho); multigrid if 35 + 7.5 n/15 < cap
+//   after a multigrid solve of m iterations                      -> stay while 35 + 7.5 m < min(15 m, cap)      (5 <= m <= 88 at the stock cap)
 // with 10 % hysteresis.  Decisions depend on iteration counts only, never on wall-clock times, so a run is reproducible.
 // On the bench scene the first dozen substeps (the bunny at rest, nu dt/dx^2 = 3 300: 120-250 multigrid iterations) stay with the
 // capped diagonal solve like the reference; once the liquid moves (dt shrinks, 15-60 iterations) the multigrid takes over and
@@ -483,7 +483,7 @@ static bool fv_visc_auto_pick(const flipv_context *c) {
     static const bool off = getenv("FLIPV_VISC_AUTO") && atoi(getenv("FLIPV_VISC_AUTO")) == 0;
     if (off || c->vLastPrec == 0) return false;
     const double cap = (double)c->prm.viscosity_max_iterations, tol = c->prm.viscosity_tolerance > 0 ? c->prm.viscosity_tolerance : 1e-6;
-    const double MG_ITER = 9.0, MG_SETUP = 35.0, RATIO = 15.0;
+    const double MG_ITER = 7.5, MG_SETUP = 35.0, RATIO = 15.0;
     if (c->vLastPrec == 1) {
         double n = (double)c->vLastIts;
         if (!c->vLastConverged) {

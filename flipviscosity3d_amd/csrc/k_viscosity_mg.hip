@@ -417,7 +417,15 @@ enum VmgOp { OP_RESTRICT = 0,   // b = P^T (finer level's t) ; x = omega b/d    
        OP_POST1 = 4,      // t = y + omega (b - A y)/d
        OP_POST2 = 5,      // x = t + omega (b - A t)/d
        OP_SWEEP_XY = 6,   // y = x + omega (b - A x)/d     (coarsest level)
-       OP_SWEEP_YX = 7 }; // x = y + omega (b - A y)/d
+       OP_SWEEP_YX = 7,   // x = y + omega (b - A y)/d
+       OP_PROPOST = 8 };  // OP_PROLONG and OP_POST1 in one launch: t = y' + omega (b - A y')/d with y' = y + P (coarser level's x) formed at the 23 stencil positions; y itself is not updated
+// (P x)(M, p) for ANY index p of a level (rows or not): along the component's normal an even index has one parent, an odd one the mean of two --
+// written as the mean of parents (p[M] >> 1) and ((p[M] + 1) >> 1), which coincide for even p[M]; across, the parent is p >> 1
+__device__ __forceinline__ float d_prolong_at(int M, const Lay &Cn, const Vec3p &cx, int p0, int p1, int p2) {   // (M folds to a constant in the unrolled callers)
+    const int q0 = p0 >> 1, q1 = p1 >> 1, q2 = p2 >> 1;
+    const int r0 = M == 0 ? (p0 + 1) >> 1 : q0, r1 = M == 1 ? (p1 + 1) >> 1 : q1, r2 = M == 2 ? (p2 + 1) >> 1 : q2;
+    return 0.5f * (cx.p[M][cidx(Cn, q0, q1, q2)] + cx.p[M][cidx(Cn, r0, r1, r2)]);
+}
 // (P^T t)(C, P): the <= 12 fine children of coarse dof P of component C.  FINE0: the finer level is level 0 (plain rows, gidx);
 // otherwise a coarse level (bricks, cidx)
 template <int C, bool FINE0>
@@ -455,6 +463,23 @@ __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, con
         float s = w[0] * cx.p[C][cidx(Cn, Q[0][0], Q[0][1], Q[0][2])];
         if (n == 2) s += w[1] * cx.p[C][cidx(Cn, Q[1][0], Q[1][1], Q[1][2])];
         A.y.p[C][ci] += s;
+        return;
+    }
+    if (OP == OP_PROPOST) {
+        // Entries towards indices without a row are exactly 0 on every level (an entry exists only where the neighbour is a row), so the
+        // prolongated values formed at such neighbours drop out, as the zeros of y did in the two-launch form.
+        float v[VS], xv[VS];
+#pragma unroll
+        for (int q = 0; q < VS; q++) v[q] = A.coef[C][q][ci];
+#pragma unroll
+        for (int q = 0; q < VS; q++) {
+            const int pi = i + slot_off(C, q, 0), pj = j + slot_off(C, q, 1), pk = k + slot_off(C, q, 2);
+            xv[q] = A.y.p[slot_comp(C, q)][cidx(A.L, pi, pj, pk)] + d_prolong_at(slot_comp(C, q), Cn, cx, pi, pj, pk);
+        }
+        float ax = 0.0f;
+#pragma unroll
+        for (int q = 0; q < VS; q++) ax += v[q] * xv[q];
+        A.t.p[C][ci] = xv[slot_diag(C)] + VMG_OMEGA * (A.b.p[C][ci] - ax) / d;
         return;
     }
     const Vec3p &in = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.x : (OP == OP_POST2 ? A.t : A.y);
@@ -503,7 +528,7 @@ __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ 
     if (OP == OP_RESTRICT) {
         if (l == 0) d_vmg_step_c<OP, true>(c, A, F0, ft0, A.L, ft0, i, j, k);
         else d_vmg_step_c<OP, false>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
-    } else if (OP == OP_PROLONG) d_vmg_step_c<OP, false>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
+    } else if (OP == OP_PROLONG || OP == OP_PROPOST) d_vmg_step_c<OP, false>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
     else d_vmg_step_c<OP, false>(c, A, A.L, ft0, A.L, ft0, i, j, k);
 }
 // bricks of a level's box that hold rows: flags (one wave per brick), then an ordered compaction by one workgroup
@@ -940,8 +965,9 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
             hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, sweeps, F0, ft0, conv);
         }
         for (int l = t0 - 1; l >= 0; l--) {   // up
-            STEP(OP_PROLONG, l);
-            STEP(OP_POST1, l);
+            static const int fuseFrom = getenv("FLIPV_VMG_FUSE_FROM") ? atoi(getenv("FLIPV_VMG_FUSE_FROM")) : 0;   // (A/B switch: levels below this index prolong and sweep in two launches)
+            if (l >= fuseFrom) STEP(OP_PROPOST, l);
+            else { STEP(OP_PROLONG, l); STEP(OP_POST1, l); }
             STEP(OP_POST2, l);
         }
 #undef STEP

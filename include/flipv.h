@@ -93,7 +93,7 @@ typedef struct flipv_params {
                                     where the diagonal needs 200-4 000.  AUTO (default) = per solve whichever of the two the PREVIOUS
                                     solve's iteration count predicts to be cheaper (k_viscosity.hip: fv_visc_auto_pick): the diagonal,
                                     stopped at the cap like the reference's solve, while the system is so stiff that the multigrid
-                                    would need more than ~70 iterations; the multigrid, converging, otherwise (256^3 bunny drop, 150
+                                    would need more than ~80 iterations; the multigrid, converging, otherwise (256^3 bunny drop, 150
                                     substeps: 23.2 ms per substep against 32.6 with the diagonal alone).  Decisions use iteration
                                     counts only, never timings */
     /* measurement / test switches, all 0 by default; results do not depend on them beyond solver tolerance */
