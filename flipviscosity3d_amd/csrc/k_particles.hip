@@ -288,9 +288,52 @@ __device__ __noinline__ void d_p2g_global(Lay L, int dir, float px, float py, fl
 #ifndef FLIPV_P2G_STRIDE
 #define FLIPV_P2G_STRIDE 8
 #endif
+#ifndef FLIPV_P2G_NATIVE_ADD
+#define FLIPV_P2G_NATIVE_ADD 0   // 1: ds_add_f32 (A/B)
+#endif
 constexpr int P2G_STRIDE = FLIPV_P2G_STRIDE;   // 8 particles per cell at seeding time
 constexpr int P2G_R = BIN_T + 3;
 constexpr int P2G_RN = P2G_R * P2G_R * P2G_R;
+// float add on an LDS word through a compare-and-swap loop.  ds_add_f32 retires about one LANE per three cycles on gfx950 whatever the
+// addresses are (tools/micro/lds_atomic_rate.hip: 0.33 lane-atomics per CU-cycle against 13 for ds_add_u32); ds_cmpst_rtn_b32 runs at
+// the integer rate, so the loop wins as long as few lanes of a wave meet on one word (4.3 per cycle without collisions, 3.0 on random
+// addresses, break-even at 8 lanes per word).  Same semantics: a float sum in arbitrary order.
+__device__ __forceinline__ void d_lds_add_f32(float *addr, float v) {
+#if FLIPV_P2G_NATIVE_ADD
+    atomicAdd(addr, v);
+#else
+    unsigned *w = (unsigned *)addr;
+    unsigned old = *w, assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(w, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+    } while (old != assumed);
+#endif
+}
+// the LDS adds of one particle and component over the stencil offsets T0..2 per axis (T0 = 0: the whole 3 x 3 x 3 stencil; 1: the
+// corners of the particle's own cell)
+template <int T0>
+__device__ __forceinline__ void d_p2g_lds(float *sv, float *sw, int lbase, float vel, const float (&ox2)[3], const float (&oy2)[3], const float (&oz2)[3],
+                                          const bool (&vi)[3], const bool (&vj)[3], const bool (&vk)[3], float rsq, float coef1, float coef2, float coef3) {
+#pragma unroll
+    for (int tk = T0; tk < 3; tk++) {
+        if (!vk[tk]) continue;
+#pragma unroll
+        for (int tj = T0; tj < 3; tj++) {
+            if (!vj[tj] || !(oy2[tj] + oz2[tk] < rsq)) continue;
+#pragma unroll
+            for (int ti = T0; ti < 3; ti++) {
+                const float qq = ox2[ti] + oy2[tj] + oz2[tk];
+                if (vi[ti] && qq < rsq) {
+                    const float weight = 1.0f - coef1 * qq * qq * qq + coef2 * qq * qq - coef3 * qq;
+                    const int l = lbase + ti + P2G_R * (tj + P2G_R * tk);
+                    d_lds_add_f32(&sv[l], weight * vel);
+                    d_lds_add_f32(&sw[l], weight);
+                }
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float *__restrict__ aos6,
                                                    const unsigned *__restrict__ idx, const int *__restrict__ off,
                                                    const int *__restrict__ cnt, const int *__restrict__ list,
@@ -359,24 +402,13 @@ __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float
                     vj[t] = gj - 1 + t >= j0 && gj - 1 + t <= j1;
                     vk[t] = gk - 1 + t >= k0 && gk - 1 + t <= k1 && oz2[t] < rsq;
                 }
-#pragma unroll
-                for (int tk = 0; tk < 3; tk++) {
-                    if (!vk[tk]) continue;
-#pragma unroll
-                    for (int tj = 0; tj < 3; tj++) {
-                        if (!vj[tj] || !(oy2[tj] + oz2[tk] < rsq)) continue;
-#pragma unroll
-                        for (int ti = 0; ti < 3; ti++) {
-                            const float qq = ox2[ti] + oy2[tj] + oz2[tk];
-                            if (vi[ti] && qq < rsq) {
-                                const float weight = 1.0f - coef1 * qq * qq * qq + coef2 * qq * qq - coef3 * qq;
-                                const int l = lbase + ti + P2G_R * (tj + P2G_R * tk);
-                                atomicAdd(&sv[l], weight * vel);
-                                atomicAdd(&sw[l], weight);
-                            }
-                        }
-                    }
-                }
+                // Only the 8 corners of the cell that holds the (shifted) particle can lie inside the kernel radius dx: the lower stencil
+                // plane of an axis is a whole cell width away unless rounding put the particle a hair beyond a cell boundary, and
+                // q >= ox^2 (sums of non-negative floats are monotone), so "no lower plane is closer than dx" is an exact test.  The
+                // usual case then issues 16 LDS adds per component instead of 54 -- the kernel is bound by LDS atomic issue
+                // (SQ_WAIT_INST_LDS 76 % of its wave cycles) -- and the rare case walks all 27 nodes as before: same sums either way.
+                if (ox2[0] < rsq || oy2[0] < rsq || oz2[0] < rsq) d_p2g_lds<0>(sv, sw, lbase, vel, ox2, oy2, oz2, vi, vj, vk, rsq, coef1, coef2, coef3);
+                else d_p2g_lds<1>(sv, sw, lbase, vel, ox2, oy2, oz2, vi, vj, vk, rsq, coef1, coef2, coef3);
             }
         }
         __syncthreads();
