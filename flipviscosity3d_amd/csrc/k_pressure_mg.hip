@@ -379,6 +379,10 @@ static int mg_setup(flipv_context *c, MgState **out) {
     return FLIPV_OK;
 }
 
+static bool mg_clear_in_up0() {   // FLIPV_MG_FILL=1: level 1's right-hand side is filled with zeros in every cycle instead (A/B)
+    static const bool fill = getenv("FLIPV_MG_FILL") && atoi(getenv("FLIPV_MG_FILL")) != 0;
+    return !fill;
+}
 // z = M^-1 r into level 0's t, (r, z) accumulated into sig(it_next)
 static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_next) {   // it_next = IT_DEVICE: device-side counter + 1
     const int nl = (int)s->lev.size();
@@ -388,7 +392,7 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0) {  // x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
-            (void)hipMemsetAsync(C.b, 0, C.L.n * sizeof(float), c->stream);
+            if (!mg_clear_in_up0()) (void)hipMemsetAsync(C.b, 0, C.L.n * sizeof(float), c->stream);   // (otherwise: zero on entry to the solve, then k_mg_up0 clears what k_mg_down0 filled)
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
                                F.pj, F.pk, c->pMask, F.x, F.b, C.b));
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
@@ -407,7 +411,7 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &C = s->lev[l + 1];
         if (l == 0)
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, sc, it_next));
+                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, mg_clear_in_up0() ? C.b : (float *)nullptr, sc, it_next));
         else
             hipLaunchKernelGGL(k_mg_up, MGGRID(s->range[l]), 0, c->stream, s->range[l], C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
     }
@@ -424,6 +428,7 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
     float *x = c->pressure, *r = (float *)c->pR, *q = (float *)c->pZ, *p = (float *)c->pS, *z = s->lev[0].t;
     float *x0 = s->lev[0].x;
     const HaloArray ph[1] = {{p, sizeof(float)}};
+    if (mg_clear_in_up0() && s->tailFirst > 0) HIPCHK(c, hipMemsetAsync(s->lev[1].b, 0, s->lev[1].L.n * sizeof(float), c->stream));   // once per solve; every cycle leaves it cleared (k_mg_up0)
     GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, -1));
     mg_vcycle(c, s, sc, 0);
     if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;

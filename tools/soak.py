@@ -3,6 +3,7 @@ solver failures and tile-geometry switches.   python tools/soak.py [N=128] [subs
 (auto = the library default; FLIPV_VISC_AUTO=0 makes it the diagonal alone)"""
 import os
 import sys
+import time
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from bench import build_workload
@@ -25,9 +26,13 @@ last = None
 worst = 0.0
 total = 0.0
 precs = []
+phases = {}
+wall = []
 for t in range(steps):
     dt = min(c.cfl(), 0.01)
+    t0_ = time.perf_counter()
     st = c.substep(dt)
+    wall.append((time.perf_counter() - t0_) * 1e3)
     geo = (st["pressure"]["total_tiles"], st["viscosity"]["total_tiles"])
     if geo != last or t % 25 == 0 or st["rc"] not in (0, 1):
         print("substep %4d dt %.4f rc %d  visc %4d its st %d  pres %3d its st %d  tiles %s active %d/%d  %.2f ms" % (
@@ -37,6 +42,11 @@ for t in range(steps):
     worst = max(worst, st["total_ms"])
     total += st["total_ms"]
     precs.append(st["viscosity"]["preconditioner"])
+    if t >= steps - 50:   # phase times of the last 50 substeps
+        phases["total_ms"] = phases.get("total_ms", 0.0) + st["total_ms"] / min(50, steps)
+        phases["wall_ms"] = phases.get("wall_ms", 0.0) + wall[-1] / min(50, steps)
+        for k_, v_ in st["phase_ms"].items():
+            phases[k_] = phases.get(k_, 0.0) + v_ / min(50, steps)
     assert st["rc"] >= 0, st
     if t % 25 == 24 or t == steps - 1:
         Q = c.particles
@@ -46,4 +56,5 @@ for t in range(steps):
         assert lo >= 0.0 and hi <= max(I, J, K) * dx, (lo, hi)
         print("   particles ok: y range %.3f..%.3f, max speed %.3f" % (Q[:, 1].min(), Q[:, 1].max(), np.abs(Q[:, 3:]).max()), flush=True)
 print("done: %d substeps, %.1f ms in all (%.2f ms per substep), worst %.2f ms; multigrid-preconditioned viscosity solves: %d" % (steps, total, total / steps, worst, sum(precs)))
+print("phase ms over the last %d substeps: %s" % (min(50, steps), ", ".join("%s %.2f" % kv for kv in phases.items())))
 c.close()
