@@ -433,6 +433,18 @@ __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float
 // ------------------------------------------------------------------ K15: grid -> particle
 // MACVelocityField::_interpolateLinearU/V/W (reference macvelocityfield.cpp:455-546): fp64 position,
 // cell origin and weights; out-of-range corners contribute 0; corner order of interpolation.cpp:54-66.
+// The two corners (i, j, k), (i + 1, j, k) of an interpolation cell with ONE 8-byte load where both are inside the array (global loads of
+// two dwords need 4-byte alignment only): the particle kernels are bound by the number of per-lane gather instructions, not by bytes.
+// A corner outside the array contributes 0, as in the reference.
+struct __attribute__((packed, aligned(4))) FloatPair { float a, b; };
+__device__ __forceinline__ void d_corner_pair(const float *__restrict__ g, const Lay &L, int i, int j, int k, int w, int h, int d, float &a, float &b) {
+    a = 0.0f; b = 0.0f;
+    if (j < 0 || j >= h || k < 0 || k >= d) return;
+    const bool r0 = i >= 0 && i < w, r1 = i + 1 >= 0 && i + 1 < w;
+    if (r0 && r1) { const FloatPair v = *reinterpret_cast<const FloatPair *>(g + gidx(L, i, j, k)); a = v.a; b = v.b; }
+    else if (r0) a = g[gidx(L, i, j, k)];
+    else if (r1) b = g[gidx(L, i + 1, j, k)];
+}
 __device__ __forceinline__ double d_mac_lerp(int dir, double x, double y, double z, double dx, const Lay &L,
                                              const float *__restrict__ g) {
     const int w = L.I + (dir == 0), h = L.J + (dir == 1), d = L.K + (dir == 2);
@@ -442,15 +454,12 @@ __device__ __forceinline__ double d_mac_lerp(int dir, double x, double y, double
     const double invdx = 1.0 / dx;
     const int i = (int)floor(x * invdx), j = (int)floor(y * invdx), k = (int)floor(z * invdx);
     const double ix = (x - (double)i * dx) * invdx, iy = (y - (double)j * dx) * invdx, iz = (z - (double)k * dx) * invdx;
-    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0, p7 = 0;
-    if (d_in_range(i, j, k, w, h, d)) p0 = g[gidx(L, i, j, k)];
-    if (d_in_range(i + 1, j, k, w, h, d)) p1 = g[gidx(L, i + 1, j, k)];
-    if (d_in_range(i, j + 1, k, w, h, d)) p2 = g[gidx(L, i, j + 1, k)];
-    if (d_in_range(i, j, k + 1, w, h, d)) p3 = g[gidx(L, i, j, k + 1)];
-    if (d_in_range(i + 1, j, k + 1, w, h, d)) p4 = g[gidx(L, i + 1, j, k + 1)];
-    if (d_in_range(i, j + 1, k + 1, w, h, d)) p5 = g[gidx(L, i, j + 1, k + 1)];
-    if (d_in_range(i + 1, j + 1, k, w, h, d)) p6 = g[gidx(L, i + 1, j + 1, k)];
-    if (d_in_range(i + 1, j + 1, k + 1, w, h, d)) p7 = g[gidx(L, i + 1, j + 1, k + 1)];
+    float f0, f1, f2, f3, f4, f5, f6, f7;
+    d_corner_pair(g, L, i, j, k, w, h, d, f0, f1);
+    d_corner_pair(g, L, i, j + 1, k, w, h, d, f2, f6);
+    d_corner_pair(g, L, i, j, k + 1, w, h, d, f3, f4);
+    d_corner_pair(g, L, i, j + 1, k + 1, w, h, d, f5, f7);
+    const double p0 = f0, p1 = f1, p2 = f2, p3 = f3, p4 = f4, p5 = f5, p6 = f6, p7 = f7;
     return p0 * (1 - ix) * (1 - iy) * (1 - iz) + p1 * ix * (1 - iy) * (1 - iz) + p2 * (1 - ix) * iy * (1 - iz) +
            p3 * (1 - ix) * (1 - iy) * iz + p4 * ix * (1 - iy) * iz + p5 * (1 - ix) * iy * iz + p6 * ix * iy * (1 - iz) +
            p7 * ix * iy * iz;
@@ -508,15 +517,11 @@ __device__ __forceinline__ float d_solid_value_grad(float px, float py, float pz
     const int gi = d_pos_index(px, invdx), gj = d_pos_index(py, invdx), gk = d_pos_index(pz, invdx);
     const float gx = (float)(gi * dx), gy = (float)(gj * dx), gz = (float)(gk * dx);
     const double ix = (px - gx) * invdx, iy = (py - gy) * invdx, iz = (pz - gz) * invdx;
-    float v000 = 0, v100 = 0, v010 = 0, v001 = 0, v101 = 0, v011 = 0, v110 = 0, v111 = 0;
-    if (d_in_range(gi, gj, gk, w, h, d)) v000 = g[gidx(L, gi, gj, gk)];
-    if (d_in_range(gi + 1, gj, gk, w, h, d)) v100 = g[gidx(L, gi + 1, gj, gk)];
-    if (d_in_range(gi, gj + 1, gk, w, h, d)) v010 = g[gidx(L, gi, gj + 1, gk)];
-    if (d_in_range(gi, gj, gk + 1, w, h, d)) v001 = g[gidx(L, gi, gj, gk + 1)];
-    if (d_in_range(gi + 1, gj, gk + 1, w, h, d)) v101 = g[gidx(L, gi + 1, gj, gk + 1)];
-    if (d_in_range(gi, gj + 1, gk + 1, w, h, d)) v011 = g[gidx(L, gi, gj + 1, gk + 1)];
-    if (d_in_range(gi + 1, gj + 1, gk, w, h, d)) v110 = g[gidx(L, gi + 1, gj + 1, gk)];
-    if (d_in_range(gi + 1, gj + 1, gk + 1, w, h, d)) v111 = g[gidx(L, gi + 1, gj + 1, gk + 1)];
+    float v000, v100, v010, v001, v101, v011, v110, v111;
+    d_corner_pair(g, L, gi, gj, gk, w, h, d, v000, v100);
+    d_corner_pair(g, L, gi, gj + 1, gk, w, h, d, v010, v110);
+    d_corner_pair(g, L, gi, gj, gk + 1, w, h, d, v001, v101);
+    d_corner_pair(g, L, gi, gj + 1, gk + 1, w, h, d, v011, v111);
     const double val = (double)v000 * (1 - ix) * (1 - iy) * (1 - iz) + (double)v100 * ix * (1 - iy) * (1 - iz) +
                        (double)v010 * (1 - ix) * iy * (1 - iz) + (double)v001 * (1 - ix) * (1 - iy) * iz +
                        (double)v101 * ix * (1 - iy) * iz + (double)v011 * (1 - ix) * iy * iz +
