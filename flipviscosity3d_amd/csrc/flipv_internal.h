@@ -300,6 +300,19 @@ static inline Lay fv_range_liquid(const flipv_context *c, int halo, int site = 3
 __device__ __forceinline__ bool d_in_range(int i, int j, int k, int w, int h, int d) {
     return i >= 0 && j >= 0 && k >= 0 && i < w && j < h && k < d;
 }
+// The two corners (i, j, k), (i + 1, j, k) of an interpolation cell with ONE 8-byte load where both are inside the array (global loads of
+// two dwords need 4-byte alignment only): the particle kernels are bound by the number of per-lane gather instructions, not by bytes.
+// A corner outside the array contributes 0, as in the reference.
+struct __attribute__((packed, aligned(4))) FloatPair { float a, b; };
+struct __attribute__((packed, aligned(4))) FloatQuad { float a, b, c, d; };
+__device__ __forceinline__ void d_corner_pair(const float *__restrict__ g, const Lay &L, int i, int j, int k, int w, int h, int d, float &a, float &b) {
+    a = 0.0f; b = 0.0f;
+    if (j < 0 || j >= h || k < 0 || k >= d) return;
+    const bool r0 = i >= 0 && i < w, r1 = i + 1 >= 0 && i + 1 < w;
+    if (r0 && r1) { const FloatPair v = *reinterpret_cast<const FloatPair *>(g + gidx(L, i, j, k)); a = v.a; b = v.b; }
+    else if (r0) a = g[gidx(L, i, j, k)];
+    else if (r1) b = g[gidx(L, i + 1, j, k)];
+}
 
 // LevelsetUtils::fractionInside, 2-point (reference levelsetutils.cpp:15-27)
 __device__ __forceinline__ float d_frac2(float l, float r) {

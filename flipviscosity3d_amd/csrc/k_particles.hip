@@ -433,18 +433,6 @@ __global__ __launch_bounds__(256) void k_p2g_tiles(BinGrid B, Lay L, const float
 // ------------------------------------------------------------------ K15: grid -> particle
 // MACVelocityField::_interpolateLinearU/V/W (reference macvelocityfield.cpp:455-546): fp64 position,
 // cell origin and weights; out-of-range corners contribute 0; corner order of interpolation.cpp:54-66.
-// The two corners (i, j, k), (i + 1, j, k) of an interpolation cell with ONE 8-byte load where both are inside the array (global loads of
-// two dwords need 4-byte alignment only): the particle kernels are bound by the number of per-lane gather instructions, not by bytes.
-// A corner outside the array contributes 0, as in the reference.
-struct __attribute__((packed, aligned(4))) FloatPair { float a, b; };
-__device__ __forceinline__ void d_corner_pair(const float *__restrict__ g, const Lay &L, int i, int j, int k, int w, int h, int d, float &a, float &b) {
-    a = 0.0f; b = 0.0f;
-    if (j < 0 || j >= h || k < 0 || k >= d) return;
-    const bool r0 = i >= 0 && i < w, r1 = i + 1 >= 0 && i + 1 < w;
-    if (r0 && r1) { const FloatPair v = *reinterpret_cast<const FloatPair *>(g + gidx(L, i, j, k)); a = v.a; b = v.b; }
-    else if (r0) a = g[gidx(L, i, j, k)];
-    else if (r1) b = g[gidx(L, i + 1, j, k)];
-}
 __device__ __forceinline__ double d_mac_lerp(int dir, double x, double y, double z, double dx, const Lay &L,
                                              const float *__restrict__ g) {
     const int w = L.I + (dir == 0), h = L.J + (dir == 1), d = L.K + (dir == 2);

@@ -73,13 +73,15 @@ __device__ __forceinline__ float d_liquid_phi_at(float px, float py, float pz, d
     const int gi = (int)floor((double)px * invdx), gj = (int)floor((double)py * invdx), gk = (int)floor((double)pz * invdx);
     const float gx = (float)(gi * dx), gy = (float)(gj * dx), gz = (float)(gk * dx);
     const double ix = (px - gx) * invdx, iy = (py - gy) * invdx, iz = (pz - gz) * invdx;
+    // corner order of interpolation.cpp:54-66: 000,100,010,001,101,011,110,111; the two i-neighbours of a (j, k) row in one 8-byte gather
+    float f[8];
+    d_corner_pair(phi, L, gi, gj, gk, L.I, L.J, L.K, f[0], f[1]);
+    d_corner_pair(phi, L, gi, gj + 1, gk, L.I, L.J, L.K, f[2], f[6]);
+    d_corner_pair(phi, L, gi, gj, gk + 1, L.I, L.J, L.K, f[3], f[4]);
+    d_corner_pair(phi, L, gi, gj + 1, gk + 1, L.I, L.J, L.K, f[5], f[7]);
     double p[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {  // corner order of interpolation.cpp:54-66: 000,100,010,001,101,011,110,111
-        const int oi = (q == 1 || q == 4 || q == 6 || q == 7), oj = (q == 2 || q == 5 || q == 6 || q == 7),
-                  ok = (q == 3 || q == 4 || q == 5 || q == 7);
-        p[q] = d_in_range(gi + oi, gj + oj, gk + ok, L.I, L.J, L.K) ? (double)phi[gidx(L, gi + oi, gj + oj, gk + ok)] : 0.0;
-    }
+    for (int q = 0; q < 8; q++) p[q] = (double)f[q];
     return (float)(p[0] * (1 - ix) * (1 - iy) * (1 - iz) + p[1] * ix * (1 - iy) * (1 - iz) + p[2] * (1 - ix) * iy * (1 - iz) +
                    p[3] * (1 - ix) * (1 - iy) * iz + p[4] * ix * (1 - iy) * iz + p[5] * (1 - ix) * iy * iz +
                    p[6] * ix * iy * (1 - iz) + p[7] * ix * iy * iz);
@@ -133,8 +135,8 @@ __global__ void k_volume_classify(Lay L, VolLattices Q, const float *__restrict_
             int nn = 0;
             for (int dk = -1; dk <= 2; dk++)
                 for (int dj = -1; dj <= 2; dj++) {
-                    const float *row = phi + gidx(L, i - 1, j + dj, k + dk);
-                    nn += (row[0] < 0.0f) + (row[1] < 0.0f) + (row[2] < 0.0f) + (row[3] < 0.0f);
+                    const FloatQuad row = *reinterpret_cast<const FloatQuad *>(phi + gidx(L, i - 1, j + dj, k + dk));   // one 16-byte gather (4-byte aligned)
+                    nn += (row.a < 0.0f) + (row.b < 0.0f) + (row.c < 0.0f) + (row.d < 0.0f);
                 }
             if (nn == 64) { out = 1.0f; sample = false; }
             else if (nn == 0) { out = 0.0f; sample = false; }
