@@ -30,7 +30,8 @@ namespace {
 // FLIPV_MG_OVER can override them for parameter scans (read once, at the first solve)
 __constant__ float MG_OMEGA = 0.9f;   // scan at 256^3 (omega, over -> iterations): (0.8,1.0) 38, (0.8,1.5) 25, (0.8,1.8) 24, (0.9,1.5) 22,
 __constant__ float MG_OVER = 1.8f;    // (0.9,1.8) 20, (1.0,1.5) 84
-constexpr int MG_COARSEST_SWEEPS = 16;
+__constant__ int MG_COARSEST_SWEEPS = 8;    // even (the global-memory variant ping-pongs and must end in t); FLIPV_MG_SWEEPS overrides it for scans.
+                                            // The count does not move the iterations (2 ... 128 sweeps: 19.35 on the 256^3 bunny, 15.6-15.8 on the 512x256x256 sheet, 16.15 at 128^3)
 
 struct MgLevel {
     Lay L;
@@ -317,6 +318,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
     MgState *s = (MgState *)c->mgState;
     if (!s) {
         if (const char *e = getenv("FLIPV_MG_OMEGA")) { const float v = (float)atof(e); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OMEGA), &v, sizeof(float))); }
+        if (const char *e = getenv("FLIPV_MG_SWEEPS")) { const int v = (atoi(e) + 1) / 2 * 2; HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_COARSEST_SWEEPS), &v, sizeof(int))); }
         if (const char *e = getenv("FLIPV_MG_OVER")) { const float v = (float)atof(e); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OVER), &v, sizeof(float))); }
         s = new MgState();
         c->mgState = s;
