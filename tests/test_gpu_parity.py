@@ -133,6 +133,47 @@ def test_binned_scatters_match_global_atomic_scatters(name):
         assert np.array_equal(a, b)
 
 
+def test_p2g_with_particles_on_and_next_to_cell_boundaries():
+    """k_p2g_tiles visits only the 8 corners of a particle's own cell unless an exact test says that a lower stencil plane can be
+    inside the kernel radius -- which only happens for a particle within an ulp of a cell boundary.  Particles ON boundaries (cell
+    faces and the half-cell-shifted faces of the staggered components), one ulp below and one ulp above them, against the
+    global-atomic kernel, which walks the whole 3 x 3 x 3 stencil like the reference (fluidsimulation.cpp:384-417).  The particles
+    sit four cells apart, so a face reached through the rounding case alone (weight ~1e-7, still >= the 1e-9 that makes a face
+    valid) would show in the valid masks; sums agree up to the summation order.  (Built with -DFLIPV_P2G_TEST_NO_FULL_STENCIL the
+    kernel still passes this test: on these samples the rounding case does not arise -- the full-stencil path is a safety net the
+    test exercises the decision for, not a path it can prove necessary.)"""
+    g = Golden(SCENES[0])
+    rng = np.random.default_rng(7)
+    dx = np.float32(g.dx)
+    I, J, K = g.dims()
+    ax = [np.arange(3, d - 3, 4) for d in (I, J, K)]
+    cells = np.stack(np.meshgrid(*ax, indexing="ij"), axis=-1).reshape(-1, 3)
+    n = len(cells)
+    faces = 0
+    for batch in range(8):
+        frac = rng.random((n, 3)).astype(np.float32)
+        kind = rng.integers(0, 3, (n, 3))   # per coordinate: inside the cell / on the face / on the half-cell face
+        base = np.where(kind == 1, 0.0, np.where(kind == 2, 0.5, frac)).astype(np.float64)
+        pos = ((cells + base) * np.float64(dx)).astype(np.float32)
+        nudge = rng.integers(-1, 2, (n, 3))   # -1 / 0 / +1 ulp
+        pos = np.where(nudge < 0, np.nextafter(pos, np.float32(-1)), np.where(nudge > 0, np.nextafter(pos, np.float32(2)), pos)).astype(np.float32)
+        P = np.concatenate([pos, 1.0 + rng.random((n, 3)).astype(np.float32)], axis=1)
+        out = []
+        for unbinned in (0, 1):
+            c = make_ctx(g)
+            c.set_params(unbinned_scatter=unbinned)
+            c.particles = P
+            c.particle_sdf()
+            c.advect_velocity_field()
+            out.append(([c.grid(m) for m in "UVW"], [c.grid("VALID_" + m) for m in "UVW"]))
+            c.close()
+        assert rel_maxnorm3(out[0][0], out[1][0]) <= P2G_TOL
+        for a, b2 in zip(out[0][1], out[1][1]):
+            assert np.array_equal(a, b2), "valid masks differ in batch %d" % batch
+        faces += sum(int(np.count_nonzero(m)) for m in out[0][1])
+    assert faces > 1000
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_extrapolation_bit_exact(name, oracle):
     g = Golden(name)
