@@ -162,6 +162,36 @@ def cpu_baseline(viscosity, budget_size):
     }
 
 
+def spawn_ranks(n, result_fd):
+    """Run this script as `n` ranks under torch.distributed.run (children of this process, started before anything here has
+    initialised the GPU), pass rank 0's JSON line -- the only thing the ranks write to their stdout -- through to the saved
+    stdout descriptor, and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in p.stdout:
+        txt = raw.decode(errors="replace")
+        if txt.lstrip().startswith("{") and '"metric"' in txt:
+            line = txt
+        else:
+            sys.stderr.write(txt)
+    rc = p.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        os.write(result_fd, line.encode())
+    return rc
+
+
 def main():
     # Exactly one line may reach stdout: the JSON result.  RCCL prints a version banner on stdout when a communicator
     # is created (the library's own and torch.distributed's), HIP tools may print too: everything written to fd 1 during
@@ -199,15 +229,31 @@ def main():
                     help="N > 1: strong = ONE scene of --size split over the ranks (slabs along k for 2 and 4 ranks, 2x2x2 blocks for 8; "
                          "slabs along i for the sheet); weak = N copies of the scene stacked along k, one slab per rank")
     ap.add_argument("--dims", type=str, default="", help="process grid 'px,py,pz' of the strong-scaling decomposition (default: see --scaling)")
+    ap.add_argument("--spawn-selftest", action="store_true",
+                    help="plumbing check that needs no GPU (tests/test_dist_gloo.py): the ranks only rendezvous over gloo and rank 0 prints a result line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.spawn_selftest and "WORLD_SIZE" in os.environ:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        print("rank %d of %d up" % (rank, world))   # goes to stderr (fd 1 is redirected above): must not reach the relayed line
+        if rank == 0:
+            os.write(result_fd, (json.dumps({"metric": "spawn selftest", "n_gpus": world, "sum": float(t.item())}) + "\n").encode())
+        dist.destroy_process_group()
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, torch.distributed.run on
+        # 127.0.0.1) and relay rank 0's JSON line.  Nothing in this process has touched the GPU yet and nothing will: it only waits.
+        sys.exit(spawn_ranks(args.gpus, result_fd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus), file=sys.stderr)
-            sys.exit(2)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     import torch
     dist = None
     if world > 1:
