@@ -50,18 +50,23 @@ class Params(C.Structure):
                 ("viscosity_accept_tolerance", C.c_double), ("precision", C.c_int),
                 ("kernel_timing", C.c_int), ("check_every", C.c_int),
                 ("pressure_preconditioner", C.c_int), ("viscosity_preconditioner", C.c_int),
+                ("exact_viscosity_operator", C.c_int), ("residual_replacement", C.c_int), ("viscosity_layout", C.c_int), ("tile_rows", C.c_int),
+                ("viscosity_mg_coarsest_sweeps", C.c_int), ("viscosity_mg_min_dim", C.c_int), ("pressure_mg_coarsest_sweeps", C.c_int),
+                ("pressure_mg_omega", C.c_float), ("pressure_mg_overcorrection", C.c_float),
+                ("no_liquid_box", C.c_int), ("no_comm_overlap", C.c_int), ("verbose", C.c_int),
                 ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
                 ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int),
-                ("viscosity_update_grid_cap", C.c_int), ("beta_from_residual", C.c_int), ("spmv_run_length", C.c_int), ("reference_diagonal", C.c_int),
-                ("reserved", C.c_int * 1)]
+                ("viscosity_update_grid_cap", C.c_int), ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int),
+                ("reserved", C.c_int * 4)]
 
+LAYOUT_AUTO, LAYOUT_PLAIN, LAYOUT_SWIZZLED, LAYOUT_BRICK = 0, 1, 2, 3
 PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID = 0, 1, 2
 
 
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("rhs_norm", C.c_double),
                 ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
-                ("preconditioner", C.c_int)]
+                ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,0 +1,131 @@
+// brick.h -- device helpers of the kernels that walk the viscosity system in the brick layout (flipv_internal.h: bidx):
+// k_viscosity_brick.hip (PCG) and k_viscosity_mg.hip (the multigrid preconditioner's fine-level vector kernels).
+// One wave per brick of 8 x 4 x 2 indices, one lane per index; a block of (64, 4, 1) threads takes four consecutive list entries.
+#pragma once
+#include "pcg_common.h"
+
+// the bricks an index box [ib, ie) x [jb, je) x [kb, ke) touches, in padded brick coordinates
+struct BrickBox { int b0[3], nb[3]; };
+static inline BrickBox brick_box(const Lay &box) {
+    BrickBox R;
+    R.b0[0] = (box.ib + 8) >> 3; R.nb[0] = ((box.ie - 1 + 8) >> 3) - R.b0[0] + 1;
+    R.b0[1] = (box.jb + 4) >> 2; R.nb[1] = ((box.je - 1 + 4) >> 2) - R.b0[1] + 1;
+    R.b0[2] = (box.kb + 2) >> 1; R.nb[2] = ((box.ke - 1 + 2) >> 1) - R.b0[2] + 1;
+    return R;
+}
+// linear brick id (x fastest over the whole padded brick grid) of brick `code` of the box's brick range
+__device__ __forceinline__ int d_brick_of_code(const BrickBox &R, const Lay &LB, int code) {
+    const int bx = code % R.nb[0], r = code / R.nb[0], by = r % R.nb[1], bz = r / R.nb[1];
+    return (int)((long)(R.b0[2] + bz) * LB.sz + (long)(R.b0[1] + by) * LB.sy + (long)(R.b0[0] + bx));
+}
+// index (i, j, k) of lane `lane` of brick `brick`
+__device__ __forceinline__ void d_brick_ijk(const Lay &LB, int brick, int lane, int &i, int &j, int &k) {
+    const int bx = brick % (int)LB.sy, r = brick / (int)LB.sy, nby = (int)(LB.sz / LB.sy), by = r % nby, bz = r / nby;
+    i = (bx << 3) - 8 + ((lane >> 5) << 2) + (lane & 3);
+    j = (by << 2) - 4 + ((lane >> 2) & 3);
+    k = (bz << 1) - 2 + ((lane >> 4) & 1);
+}
+// neighbour offsets of this lane (threadIdx.x = position inside the brick): nb_brick() from the lane's bits
+__device__ __forceinline__ NbOff d_lane_off(int sby, int sbz) {
+    const int lane = (int)threadIdx.x, li = lane & 3, lj = (lane >> 2) & 3, lk = (lane >> 4) & 1;
+    NbOff o;
+    o.xp = li < 3 ? 1 : 29;          o.xm = li > 0 ? -1 : -29;
+    o.yp = lj < 3 ? 4 : sby - 12;    o.ym = lj > 0 ? -4 : -(sby - 12);
+    o.zp = lk == 0 ? 16 : sbz - 16;  o.zm = lk == 1 ? -16 : -(sbz - 16);
+    return o;
+}
+
+// the system's arrays, all in the brick layout
+template <typename T>
+struct BrickSys {
+    const float *diag[3];
+    T *x[3], *q[3], *s[3];
+    RT<T> *r[3];
+    const uint8_t *mask;   // bit m: component m has a row at the index
+    int sby, sbz;          // element strides between bricks along j and k
+};
+
+// A wave's walk over the brick list.  Blocks take quads of list entries (wave w of a block the quad's entry w) with a grid stride;
+// d_tile_slot hands each XCD a contiguous eighth of the list (bricks are listed x fastest, so an eighth is a slab of brick planes:
+// the face neighbours of a wave's brick are bricks of the same XCD's L2).  The next brick's id and this lane's mask byte are
+// requested before the current brick is worked on: the id -> mask -> data chain of dependent loads is paid once per wave, not per brick.
+struct BrickWalk {
+    int vb, nquads, nvb;
+    size_t a, an;
+    unsigned m, mn;
+    __device__ __forceinline__ void fetch(int v, const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask, size_t &ao, unsigned &mo) const {
+        ao = 0; mo = 0u;
+        if (v < nvb) {
+            const int slot = d_tile_slot(v, nquads);
+            const int e = slot * 4 + (int)threadIdx.y;
+            if (slot < nquads && e < nb) {
+                ao = ((size_t)bricks[e] << 6) + threadIdx.x;
+                mo = mask[ao];
+            }
+        }
+    }
+    __device__ __forceinline__ void begin(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask) {
+        nquads = (nb + 3) >> 2;
+        nvb = ((nquads + 7) >> 3) << 3;
+        vb = (int)blockIdx.x;
+        fetch(vb, bricks, nb, mask, a, m);
+        fetch(vb + (int)gridDim.x, bricks, nb, mask, an, mn);
+    }
+    __device__ __forceinline__ bool valid() const { return vb < nvb; }
+    __device__ __forceinline__ void next(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask) {
+        a = an; m = mn;
+        vb += (int)gridDim.x;
+        fetch(vb + (int)gridDim.x, bricks, nb, mask, an, mn);
+    }
+};
+
+// Scalar prologue of the update kernel (K2 of pcg_common.h), shared with k_pcg_update's logic (pcg_geo.inc): folds rmax(it-1), sigma(it),
+// a, b, c(it), runs the stop test and the stall guard, forms alpha and beta.  Returns false when the launch must do nothing.
+// lds: 8 doubles.  Every thread of the block must call it.
+__device__ __forceinline__ bool d_update_scalars(const PcgScal &sc, int it_arg, double *lds, int &it, double &alpha_d, double &beta_d) {
+    const int conv_now = *sc.conv, itB_now = it_arg >= 0 ? it_arg : *sc.itB;   // two independent loads
+    if (conv_now >= 0) return false;
+    it = itB_now;
+    if (it >= sc.cap) return false;
+    const int tid = d_tid256();
+    const int grp = tid >> 5;  // 0 rmax(it-1), 1 sig, 2 a, 3 b, 4 c
+    double v = 0.0;
+    if (grp < 5 && (it > 0 || grp > 0)) v = (sc.sig(it) - NSLOT)[tid];
+#pragma unroll
+    for (int off = NSLOT / 2; off > 0; off >>= 1) {
+        const double o = __shfl_down(v, off, NSLOT);
+        v = grp == 0 ? fmax(v, o) : v + o;
+    }
+    if (grp < 5 && (tid & (NSLOT - 1)) == 0) lds[grp] = v;
+    __syncthreads();
+    if (it > 0 && d_pass(sc, lds[0])) {
+        if (blockIdx.x == 0 && tid == 0) *sc.conv = it - 1;
+        return false;
+    }
+    if (it > 0 && sc.best) {   // stall guard (PcgScal)
+        const double bestNow = *sc.best, res = lds[0];
+        if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > 16.0 * bestNow) {
+            if (blockIdx.x == 0 && tid == 0) { *sc.stalled = 1; *sc.conv = it - 1; }
+            return false;
+        }
+        if (blockIdx.x == 0 && tid == 0 && res < bestNow) *sc.best = res;
+    }
+    const double sg = lds[1], a = lds[2];
+    alpha_d = a != 0.0 ? sg / a : 0.0;
+    const double bdot = sc.noB ? a : lds[3];
+    double est = sg - 2.0 * alpha_d * bdot + alpha_d * alpha_d * lds[4];
+    if (!(est > 0.0)) est = 0.0;
+    beta_d = sg != 0.0 ? est / sg : 0.0;
+    return true;
+}
+
+// ---- host entry points of k_viscosity_brick.hip
+int fv_build_bricks(flipv_context *c, const Lay &box);     // c->brickList / c->nBricks from c->vMaskB inside the launch box
+int fv_brick_grid(const flipv_context *c, int nbricks, int cap);
+template <typename T> void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot);
+template <typename T> void fv_brick_init(flipv_context *c, const PcgScal &sc);
+template <typename T> void fv_brick_update(flipv_context *c, const PcgScal &sc, int it);
+void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);
+template <typename T> void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int period, int withSigma, float *const z[3], float omega);
+template <typename T> void fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact);
+template <typename T> void fv_brick_writeback(flipv_context *c, const Lay &R, int m, bool withAcc, float *dst);

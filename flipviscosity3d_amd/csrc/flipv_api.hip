@@ -11,8 +11,10 @@ static thread_local std::string g_create_error;
 // ------------------------------------------------------------------------------------------------
 // every grid array: guard zone | n entries | guard zone, all zero-initialised; returns the pointer to entry 0
 template <typename T>
-static int grid_alloc(flipv_context *c, T **p, size_t elem_bytes = sizeof(T)) {
-    const size_t n = c->L.n, g = c->L.guard;
+static int grid_alloc(flipv_context *c, T **p, size_t elem_bytes = sizeof(T), size_t min_after = 0) {
+    size_t n = c->L.n;
+    const size_t g = c->L.guard;
+    if (min_after > n + g) n = min_after - g;   // (solver arrays: room for the brick layout behind the pointer)
     const size_t bytes = (n + 2 * g) * elem_bytes;
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
@@ -59,7 +61,6 @@ extern "C" int flipv_default_params(flipv_params *p) {
     p->precision = FLIPV_PRECISION_FP32;
     p->kernel_timing = 0;
     p->check_every = 0;
-    p->beta_from_residual = 1;
     return FLIPV_OK;
 }
 
@@ -141,6 +142,9 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     L.ib = L.ox; L.ie = L.ox + L.PX; L.jb = L.oy; L.je = L.oy + L.PY; L.kb = L.oz; L.ke = L.oz + L.PZ;
     c->k0 = L.olo[2];
     c->k1 = L.ohi[2];
+    c->LB = brick_lay(L);
+    c->solverCap = L.n + L.guard;
+    if (!c->isBlock && c->LB.n > c->solverCap) c->solverCap = c->LB.n;
     c->comm = nullptr;
     c->pScratch = nullptr; c->pScratchCap = 0;
     c->binIdx = nullptr; c->binIdxCap = 0;
@@ -171,15 +175,12 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     c->gravity[0] = 0.0f; c->gravity[1] = -9.81f; c->gravity[2] = 0.0f;  // fluidsimulation.cpp:40
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); flipv_destroy(c); return FLIPV_ERR_HIP; } } while (0)
 #define GALLOC(ptr) do { int rc_ = grid_alloc(c, &(ptr)); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } } while (0)
-#define VALLOC(ptr) do { double *t_ = nullptr; int rc_ = grid_alloc(c, &t_); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } (ptr) = t_; } while (0)
+#define VALLOC(ptr) do { double *t_ = nullptr; int rc_ = grid_alloc(c, &t_, sizeof(double), c->solverCap); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } (ptr) = t_; } while (0)
+#define SALLOC(ptr) do { int rc_ = grid_alloc(c, &(ptr), sizeof(*(ptr)), c->solverCap); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } } while (0)
     c->stream = c->xs = c->commStream = nullptr;
     c->evMain = c->evHalo = nullptr;
     c->evPoll[0] = c->evPoll[1] = nullptr;
     c->nIntP = c->nIntV = 0;
-    {
-        const char *e = getenv("FLIPV_COMM_OVERLAP");
-        c->commOverlap = !(e && e[0] == '0');
-    }
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) c->phaseEv[q] = nullptr;
     CHK(hipSetDevice(dev));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -213,19 +214,9 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     memset(c->h_flags, 0, 16 * sizeof(int));
     // solver tiles over the shared index space
     // the geometry is chosen per solve (fv_build_tiles); FLIPV_ROWL = 16 | 64 pins it (tests, A/B measurements)
-    {
-        const char *e = getenv("FLIPV_ROWL");
-        c->forceRowl = e ? atoi(e) : 0;
-        const char *lb = getenv("FLIPV_LIQBOX");
-        c->liqBoxOff = lb && atoi(lb) == 0;
-        const char *lm = getenv("FLIPV_LIQMASK");
-        c->liqMask = lm ? (unsigned)strtoul(lm, nullptr, 0) : 0xffffffffu;
-        const char *z = getenv("FLIPV_SWZ");
-        c->allowSwz = !(z && atoi(z) == 0);
-        if (c->forceRowl != 16 && c->forceRowl != 64) c->forceRowl = 0;
-    }
-    c->tgP = make_tile_grid(L, c->forceRowl ? c->forceRowl : 64, VW_P);
-    c->tgV = make_tile_grid(L, c->forceRowl ? c->forceRowl : 64, VW_V);
+    // the geometry is chosen per solve (fv_build_tiles); flipv_params.tile_rows pins it
+    c->tgP = make_tile_grid(L, 64, VW_P);
+    c->tgV = make_tile_grid(L, 64, VW_V);
     if (!setupOnly) {
         size_t ntmax = 0;   // the largest tile grid of any geometry and lane width; the virtual enumeration pads nty to a multiple of 4
         for (int rl = 16; rl <= 64; rl *= 4)
@@ -247,12 +238,20 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     GALLOC(c->scp);
     GALLOC(c->volC); GALLOC(c->volU); GALLOC(c->volV); GALLOC(c->volW);
     GALLOC(c->volEU); GALLOC(c->volEV); GALLOC(c->volEW);
-    GALLOC(c->fC); GALLOC(c->fEU); GALLOC(c->fEV); GALLOC(c->fEW);
-    GALLOC(c->vDiagU); GALLOC(c->vDiagV); GALLOC(c->vDiagW);
-    GALLOC(c->vmU); GALLOC(c->vmV); GALLOC(c->vmW);
-    GALLOC(c->vrU); GALLOC(c->vrV); GALLOC(c->vrW);
+    SALLOC(c->fC); SALLOC(c->fEU); SALLOC(c->fEV); SALLOC(c->fEW);
+    SALLOC(c->vDiagU); SALLOC(c->vDiagV); SALLOC(c->vDiagW);
+    SALLOC(c->vmU); SALLOC(c->vmV); SALLOC(c->vmW);
+    SALLOC(c->vrU); SALLOC(c->vrV); SALLOC(c->vrW);
     GALLOC(c->stU); GALLOC(c->stV); GALLOC(c->stW);
     GALLOC(c->vRowMask);
+    SALLOC(c->vMaskB);
+    for (int q = 0; q < 3; q++) { SALLOC(c->vB[q]); SALLOC(c->vXacc[q]); }
+    if (!c->isBlock) {
+        c->brickCap = c->LB.n / 64;
+        int rc_ = plain_alloc(c, &c->brickList, c->brickCap + 64);
+        if (!rc_) rc_ = plain_alloc(c, &c->brickFlag, c->brickCap + 64);
+        if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
+    }
     GALLOC(c->bandPrev);
     GALLOC(c->pMask);
     GALLOC(c->validCells); GALLOC(c->validTmp);
@@ -269,6 +268,7 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
 #undef CHK
 #undef GALLOC
 #undef VALLOC
+#undef SALLOC
     // defaults of initialize(): viscosity 1.0 at every node (fluidsimulation.cpp:39), liquid phi = 3 dx
     int rc = flipv_set_viscosity_uniform(c, 1.0f);
     if (rc == FLIPV_OK) {
@@ -364,7 +364,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         const int rcT = fv_check_block_thickness(c, p->cfl_number, "flipv_set_params");
         if (rcT) return rcT;
     }
-    for (int r = 0; r < 1; r++)
+    for (int r = 0; r < 4; r++)
         if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
     c->prm = *p;
     return FLIPV_OK;
@@ -505,9 +505,10 @@ extern "C" int flipv_write_grid(flipv_context *c, int which, const float *in) {
     if (which == FLIPV_GRID_WEIGHT_U || which == FLIPV_GRID_WEIGHT_V || which == FLIPV_GRID_WEIGHT_W) c->weightsVersion = -1;
     if (which == FLIPV_GRID_VISCOSITY) {
         const size_t n = lat_count(c->L, g.lat);
-        int nz = 0;
-        for (size_t t = 0; t < n; t++) if (in[t] > 0.0f) { nz = 1; break; }
-        c->viscosity_nonzero = nz;
+        float vmax = 0.0f;
+        for (size_t t = 0; t < n; t++) if (in[t] > vmax) vmax = in[t];
+        c->viscosity_nonzero = vmax > 0.0f;
+        c->viscosity_max = vmax;
     }
     return write_lattice(c, g.lat, in, g.f, g.m);
 }
@@ -533,9 +534,10 @@ extern "C" int flipv_write_grid_box(flipv_context *c, int which, const float *in
     if (which == FLIPV_GRID_WEIGHT_U || which == FLIPV_GRID_WEIGHT_V || which == FLIPV_GRID_WEIGHT_W) c->weightsVersion = -1;
     if (which == FLIPV_GRID_VISCOSITY) {
         int lo[3], hi[3];
-        int nz = 0;
-        if (lat_box(c, g.lat, 1, lo, hi)) { const size_t n = box_count(lo, hi); for (size_t t = 0; t < n; t++) if (in[t] > 0.0f) { nz = 1; break; } }
-        c->viscosity_nonzero = nz;   // (a block context assumes the other ranks agree: the solve is skipped only if viscosity is zero everywhere)
+        float vmax = 0.0f;
+        if (lat_box(c, g.lat, 1, lo, hi)) { const size_t n = box_count(lo, hi); for (size_t t = 0; t < n; t++) if (in[t] > vmax) vmax = in[t]; }
+        c->viscosity_nonzero = vmax > 0.0f;   // this rank's box; the solve all-reduces it (k_viscosity.hip) so that every rank takes the same path
+        c->viscosity_max = vmax;
     }
     return write_lattice_box(c, g.lat, in, g.f, g.m);
 }
@@ -556,6 +558,7 @@ extern "C" int flipv_set_viscosity_uniform(flipv_context *c, float value) {
     std::vector<float> v(box_count(lo, hi), value);
     const int rc = flipv_write_grid_box(c, FLIPV_GRID_VISCOSITY, v.data());
     c->viscosity_nonzero = value > 0.0f;
+    c->viscosity_max = value;
     return rc;
 }
 

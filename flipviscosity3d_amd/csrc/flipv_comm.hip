@@ -244,7 +244,7 @@ int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
 // runs beside whatever c->stream is given next; fv_halo_wait() makes c->stream wait for it.
 int fv_halo_copy_begin(flipv_context *c, const HaloArray *arr, int n, int H) {
     if (!c->comm || H <= 0) return FLIPV_OK;
-    if (!c->commOverlap) return fv_halo_copy(c, arr, n, H);
+    if (c->prm.no_comm_overlap) return fv_halo_copy(c, arr, n, H);
     HIPCHK(c, hipEventRecord(c->evMain, c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->commStream, c->evMain, 0));
     c->xs = c->commStream;
@@ -255,7 +255,7 @@ int fv_halo_copy_begin(flipv_context *c, const HaloArray *arr, int n, int H) {
     return FLIPV_OK;
 }
 int fv_halo_wait(flipv_context *c) {
-    if (!c->comm || !c->commOverlap) return FLIPV_OK;
+    if (!c->comm || c->prm.no_comm_overlap) return FLIPV_OK;
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evHalo, 0));
     return FLIPV_OK;
 }

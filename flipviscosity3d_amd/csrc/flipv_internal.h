@@ -60,6 +60,45 @@ __host__ __device__ __forceinline__ size_t sidx(const Lay &L, int i, int j, int 
     return (size_t)((long)(k - L.oz) * L.sz + (long)(j >> 2) * (4 * L.PX) + (long)(i >> 3) * 32 + (long)(((j & 3) << 3) + (i & 7)));
 }
 
+// Brick layout of the viscosity solver's arrays on sparse liquids (single-GPU contexts; k_viscosity_brick.hip).  The index space is cut
+// into bricks of 8 x 4 x 2 indices = 64 entries = 256 contiguous bytes, each brick two 128-byte lines of 4 x 4 x 2 indices side by side
+// in i, bricks in x-fastest order with ONE padding brick on every side (indices -8.. and up to the padded end + 7 are addressable:
+// stencil neighbours of any in-range index need no guard zone and no bounds test).  On the reference's scenes the liquid fills a
+// few per cent of the box as a compact body: a 128-byte line that is a 32 x 1 stick of a k-plane (the plain layout) is 1.5x
+// over-fetched at the ends of the liquid's i-runs, a 4 x 4 x 2 block 1.1x (counted on the 256^3 bunny).  A wave owns one brick, a lane
+// one index; the address is SEPARABLE, bidx = f(i) + g(j) + h(k), so the offset to a neighbour along an axis depends on the lane's own
+// position along that axis only (NbOff: six per-lane constants address the whole 15-point coupled stencil, diagonals by addition).
+// For a Lay describing this layout sy / sz hold the BRICK strides in bricks (bricks per row, bricks per plane), as for the multigrid's
+// coarse levels (k_viscosity_mg.hip: cidx); brick_lay() derives it from the context's plain Lay.
+__host__ __device__ __forceinline__ size_t bidx(const Lay &B, int i, int j, int k) {
+    const int ip = i + 8, jp = j + 4, kp = k + 2;
+    return ((size_t)((long)(kp >> 1) * B.sz + (long)(jp >> 2) * B.sy + (long)(ip >> 3)) << 6) +
+           (size_t)((((ip >> 2) & 1) << 5) + ((kp & 1) << 4) + ((jp & 3) << 2) + (ip & 3));
+}
+static inline Lay brick_lay(const Lay &L) {   // single-domain contexts only (ox = oy = oz = 0)
+    Lay B = L;
+    const long nbx = L.PX / 8 + 2, nby = L.PY / 4 + 2, nbz = (L.PZ + 1) / 2 + 2;
+    B.sy = nbx; B.sz = nbx * nby;
+    B.n = (size_t)(nbx * nby * nbz) * 64;
+    return B;
+}
+// element offsets from an index to its six axis neighbours (plain layout: +-1, +-sy, +-sz for every index; brick layout: per index)
+struct NbOff { int xm, xp, ym, yp, zm, zp; };
+__host__ __device__ __forceinline__ NbOff nb_plain(const Lay &L) {
+    NbOff o; o.xm = -1; o.xp = 1; o.ym = -(int)L.sy; o.yp = (int)L.sy; o.zm = -(int)L.sz; o.zp = (int)L.sz;
+    return o;
+}
+__host__ __device__ __forceinline__ NbOff nb_brick(const Lay &B, int i, int j, int k) {
+    const int sby = (int)B.sy * 64, sbz = (int)B.sz * 64;
+    NbOff o;
+    o.xp = (i & 3) < 3 ? 1 : 29;          o.xm = (i & 3) > 0 ? -1 : -29;            // into the other half-brick / the next brick: +32 - 3
+    o.yp = (j & 3) < 3 ? 4 : sby - 12;    o.ym = (j & 3) > 0 ? -4 : -(sby - 12);
+    o.zp = (k & 1) == 0 ? 16 : sbz - 16;  o.zm = (k & 1) == 1 ? -16 : -(sbz - 16);
+    return o;
+}
+// layout of the viscosity solver's arrays for the current solve
+enum { VLAYOUT_PLAIN = 0, VLAYOUT_SWZ = 1, VLAYOUT_BRICK = 2 };
+
 // lattice ids: logical extents inside the shared index space
 enum { LAT_CELL = 0, LAT_U = 1, LAT_V = 2, LAT_W = 3, LAT_NODE = 4, LAT_EU = 5, LAT_EV = 6, LAT_EW = 7 };
 __host__ __device__ __forceinline__ void lat_dims(const Lay &L, int lat, int &w, int &h, int &d) {
@@ -117,8 +156,6 @@ struct flipv_context {
     // coefficients 0, band 0) when it was last covered and has not been touched since.  Any grid written through the ABI, or an
     // operator called on its own, resets this to "everywhere".
     int inSubstep;
-    int liqBoxOff;   // FLIPV_LIQBOX=0: never restrict (A/B and the test that compares the two)
-    unsigned liqMask; // FLIPV_LIQMASK: bit per call site (debugging aid), default all ones
     int liqValid, liqPrevValid;
     int liqLo[3], liqHi[3], liqPrevLo[3], liqPrevHi[3];   // index boxes, half-open
     int isBlock;     // created by flipv_create_block with a box smaller than the domain: scene setup entry points refuse it
@@ -129,7 +166,6 @@ struct flipv_context {
     hipStream_t xs, commStream;
     hipEvent_t evMain, evHalo;
     hipEvent_t evPoll[2];  // stop-flag read-backs of the PCG loop (two in flight)
-    int commOverlap;  // 1: halo exchange of the PCG search direction overlaps the interior SpMV (FLIPV_COMM_OVERLAP=0 disables)
     float dx;
     int device;
     hipStream_t stream;
@@ -174,13 +210,24 @@ struct flipv_context {
     size_t scalCap;
     int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits, [4,5] graph iteration counters, [6] interior tile count, [7] in-domain indices of the listed tiles / 4
     int *h_flags;     // pinned host mirror
-    int viscosity_nonzero;  // cached host-side: any viscosity node > 0
+    int viscosity_nonzero;  // cached host-side: any viscosity node > 0 (in this rank's box)
+    float viscosity_max = 1.0f;     // largest viscosity node value (the a-priori stiffness estimate nu dt/dx^2 of fv_visc_auto_pick)
+    int viscosity_nonzero_any = 1;  // ... on any rank of the communicator (all-reduced at the start of every viscosity solve)
+    int vForceMultigridOnce = 0;    // set while a diagonal solve AUTO picked and that ran into the cap is being repeated with the multigrid
+    int facValid = 0;               // the factor arrays hold the current layout's values wherever the band was
 
     // solver tiles
     TileGrid tgP, tgV;
-    int vSwz = 0;        // the viscosity PCG arrays of the current solve are in the swizzled layout
-    int allowSwz = 1;    // FLIPV_SWZ=0 disables the swizzled layout (A/B measurements)
-    int forceRowl = 0;   // FLIPV_ROWL: 16 or 64 pins the tile geometry, 0 = chosen per solve
+    int vSwz = 0;        // the viscosity PCG arrays of the current solve are in the swizzled layout (vLayout == VLAYOUT_SWZ)
+    int vLayout = 0;     // VLAYOUT_*: layout of the viscosity solver's arrays (factors, own volumes, diagonal, row mask copy, x, r, q, s, b) for the current solve
+    Lay LB;              // the brick layout of this context's index space (brick_lay(L)); valid on single-domain contexts
+    size_t solverCap = 0; // entries every solver array holds behind its pointer: max(plain layout + guard, brick layout)
+    int *brickList = nullptr, *brickFlag = nullptr;   // active bricks of the current solve (linear brick ids, x fastest), flags of the box's bricks
+    size_t brickCap = 0;
+    int nBricks = 0;
+    uint8_t *vMaskB = nullptr;   // the row mask in the brick layout (vRowMask stays plain: the setup's "was a row" memory)
+    float *vB[3] = {nullptr, nullptr, nullptr};      // right-hand side of the current solve (residual replacement recomputes r = b - A x from it)
+    double *vXacc[3] = {nullptr, nullptr, nullptr};  // fp64 accumulator of the solution (group-wise update: x of the PCG loop is flushed into it at every residual replacement)
     int *tileListP, *tileListV;
     int *tileFlag;
     int nActiveP, nActiveV;
@@ -272,7 +319,8 @@ constexpr int LIQ_MARGIN = 12;
 // fv_range clipped to where the liquid is or was one substep ago (see flipv_context::liqValid)
 static inline Lay fv_range_liquid(const flipv_context *c, int halo, int site = 31) {
     Lay L = fv_range(c, halo);
-    if (!c->inSubstep || c->liqBoxOff || !c->liqValid || !c->liqPrevValid || !((c->liqMask >> site) & 1u)) return L;
+    (void)site;
+    if (!c->inSubstep || c->prm.no_liquid_box || !c->liqValid || !c->liqPrevValid) return L;
     int *lo[3] = {&L.ib, &L.jb, &L.kb}, *hi[3] = {&L.ie, &L.je, &L.ke};
     for (int a = 0; a < 3; a++) {
         const int l = c->liqLo[a] < c->liqPrevLo[a] ? c->liqLo[a] : c->liqPrevLo[a];

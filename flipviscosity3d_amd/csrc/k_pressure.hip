@@ -257,10 +257,11 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     sc->nslot = NSLOT / nr > 0 ? NSLOT / nr : 1;   // disjoint slot ranges per rank (nranks <= NSLOT)
     sc->slot0 = rk * sc->nslot;
     sc->cap = cap;
-    sc->noB = c->prm.beta_from_residual ? 0 : 1;
+    sc->noB = c->prm.beta_from_conjugacy ? 1 : 0;
     sc->itA = c->d_flags + 4;
     sc->itB = c->d_flags + 5;
     sc->best = c->d_scal_small + 49;
+    sc->stall_below = 0.0;
     sc->stalled = c->d_flags + 11;
     // reset the stall guard (enqueued before any kernel of the solve): best = 0x7f7f... = 1.4e306, "nothing seen yet"
     (void)hipMemsetAsync(sc->best, 0x7f, sizeof(double), c->stream);
@@ -320,11 +321,12 @@ static int gather_masks(flipv_context *c, const TileGrid &tg, int vw, const uint
 
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap) {
-    int rowl = c->forceRowl ? c->forceRowl : tg->rowl;
+    const int forceRowl = (c->prm.tile_rows == 16 || c->prm.tile_rows == 64) ? c->prm.tile_rows : 0;
+    int rowl = forceRowl ? forceRowl : tg->rowl;
     *tg = make_tile_grid(c->L, rowl, vw);
     int rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior);
     if (rc) return rc;
-    if (!c->forceRowl && *nActive > 0) {
+    if (!forceRowl && *nActive > 0) {
         // how full the tiles are: indices with unknowns / indices of the listed tiles inside the lattices' extent
         const double fill = c->h_flags[7] > 0 ? ((double)*hostCount / perIndex) / (4.0 * (double)c->h_flags[7]) : 1.0;
         const int want = (rowl == 64 && fill < 0.45) ? 16 : ((rowl == 16 && fill > 0.65) ? 64 : rowl);
@@ -519,7 +521,7 @@ int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells
     memset(&sc, 0, sizeof(sc));  // no scalars, no stop flag: pure kernel launches
     // the variant the solve runs: the multigrid-preconditioned loop needs s.q only, the diagonal one also (q/d).q [and (r/d).q]
     const bool mgLoop = !c->pressurePrec && c->prm.pressure_preconditioner != FLIPV_PRECOND_DIAGONAL && (c->L.I > 16 || c->L.J > 16 || c->L.K > 16);
-    const int bdots = mgLoop ? 0 : (c->prm.beta_from_residual ? 2 : 1);
+    const int bdots = mgLoop ? 0 : (c->prm.beta_from_conjugacy ? 1 : 2);
     for (int w = 0; w < 3; w++) {
         if (c->pressurePrec) launch_pressure_spmv<double>(c, sc, 0, 0, c->nActiveP, bdots); else launch_pressure_spmv<float>(c, sc, 0, 0, c->nActiveP, bdots);
     }

@@ -26,11 +26,11 @@
 
 namespace {
 
-// smoothing weight and over-correction of the coarse-grid term; in __constant__ memory so that FLIPV_MG_OMEGA /
-// FLIPV_MG_OVER can override them for parameter scans (read once, at the first solve)
+// smoothing weight and over-correction of the coarse-grid term; in __constant__ memory so that flipv_params.pressure_mg_omega /
+// pressure_mg_overcorrection can override them for parameter scans
 __constant__ float MG_OMEGA = 0.9f;   // scan at 256^3 (omega, over -> iterations): (0.8,1.0) 38, (0.8,1.5) 25, (0.8,1.8) 24, (0.9,1.5) 22,
 __constant__ float MG_OVER = 1.8f;    // (0.9,1.8) 20, (1.0,1.5) 84
-__constant__ int MG_COARSEST_SWEEPS = 8;    // even (the global-memory variant ping-pongs and must end in t); FLIPV_MG_SWEEPS overrides it for scans.
+__constant__ int MG_COARSEST_SWEEPS = 8;    // even (the global-memory variant ping-pongs and must end in t); flipv_params.pressure_mg_coarsest_sweeps overrides it for scans.
                                             // The count does not move the iterations (2 ... 128 sweeps: 19.35 on the 256^3 bunny, 15.6-15.8 on the 512x256x256 sheet, 16.15 at 128^3)
 
 struct MgLevel {
@@ -288,6 +288,7 @@ struct MgState {
     std::vector<Lay> range;   // per level: the level's Lay with the launch box (ib..ke) of this solve's sweeps -- the cells within reach of the
                               // liquid (fv_range_liquid, halved level by level); the whole level in multi-rank runs and outside a substep
     int tailFirst = 0;  // first level handled by k_mg_tail
+    float omega = 0.9f, over = 1.8f; int sweeps = 8;   // what the __constant__ scan parameters currently hold (flipv_params.pressure_mg_*)
     std::vector<void *> allocs;
     int I = 0, J = 0, K = 0;
     ~MgState() { for (void *p : allocs) (void)hipFree(p); }
@@ -317,9 +318,6 @@ void fv_mg_free(flipv_context *c) {
 static int mg_setup(flipv_context *c, MgState **out) {
     MgState *s = (MgState *)c->mgState;
     if (!s) {
-        if (const char *e = getenv("FLIPV_MG_OMEGA")) { const float v = (float)atof(e); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OMEGA), &v, sizeof(float))); }
-        if (const char *e = getenv("FLIPV_MG_SWEEPS")) { const int v = (atoi(e) + 1) / 2 * 2; HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_COARSEST_SWEEPS), &v, sizeof(int))); }
-        if (const char *e = getenv("FLIPV_MG_OVER")) { const float v = (float)atof(e); HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OVER), &v, sizeof(float))); }
         s = new MgState();
         c->mgState = s;
         MgLevel l0;
@@ -351,6 +349,17 @@ static int mg_setup(flipv_context *c, MgState **out) {
             s->tailFirst--;
         if (s->lev.size() == 1) s->tailFirst = 0;
     }
+    {   // flipv_params.pressure_mg_*: scan parameters in __constant__ memory (per device, i.e. shared by the contexts of one device)
+        const float om = c->prm.pressure_mg_omega > 0.0f ? c->prm.pressure_mg_omega : 0.9f, ov = c->prm.pressure_mg_overcorrection > 0.0f ? c->prm.pressure_mg_overcorrection : 1.8f;
+        const int sw = c->prm.pressure_mg_coarsest_sweeps > 0 ? (c->prm.pressure_mg_coarsest_sweeps + 1) / 2 * 2 : 8;
+        if (om != s->omega || ov != s->over || sw != s->sweeps) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OMEGA), &om, sizeof(float)));
+            HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OVER), &ov, sizeof(float)));
+            HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_COARSEST_SWEEPS), &sw, sizeof(int)));
+            s->omega = om; s->over = ov; s->sweeps = sw;
+        }
+    }
     for (size_t l = 0; l + 1 < s->lev.size(); l++) {
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
@@ -361,8 +370,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
     // an earlier solve left there; nothing reads it: a coupling is non-zero only between two pressure cells (both inside the box),
     // and the restriction skips children outside the finer level's box.
     {
-        static const bool off = getenv("FLIPV_MG_BOX") && atoi(getenv("FLIPV_MG_BOX")) == 0;
-        const Lay R = off ? fv_range(c, 0) : fv_range_liquid(c, 1, 5);
+        const Lay R = fv_range_liquid(c, 1, 5);
         s->range.resize(s->lev.size());
         int lo[3] = {R.ib, R.jb, R.kb}, hi[3] = {R.ie, R.je, R.ke};
         for (size_t l = 0; l < s->lev.size(); l++) {
@@ -381,10 +389,6 @@ static int mg_setup(flipv_context *c, MgState **out) {
     return FLIPV_OK;
 }
 
-static bool mg_clear_in_up0() {   // FLIPV_MG_FILL=1: level 1's right-hand side is filled with zeros in every cycle instead (A/B)
-    static const bool fill = getenv("FLIPV_MG_FILL") && atoi(getenv("FLIPV_MG_FILL")) != 0;
-    return !fill;
-}
 // z = M^-1 r into level 0's t, (r, z) accumulated into sig(it_next)
 static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_next) {   // it_next = IT_DEVICE: device-side counter + 1
     const int nl = (int)s->lev.size();
@@ -394,7 +398,7 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0) {  // x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
-            if (!mg_clear_in_up0()) (void)hipMemsetAsync(C.b, 0, C.L.n * sizeof(float), c->stream);   // (otherwise: zero on entry to the solve, then k_mg_up0 clears what k_mg_down0 filled)
+            // (C.b: zero on entry to the solve, then k_mg_up0 clears what k_mg_down0 filled)
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
                                F.pj, F.pk, c->pMask, F.x, F.b, C.b));
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
@@ -413,7 +417,7 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &C = s->lev[l + 1];
         if (l == 0)
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, mg_clear_in_up0() ? C.b : (float *)nullptr, sc, it_next));
+                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, C.b, sc, it_next));
         else
             hipLaunchKernelGGL(k_mg_up, MGGRID(s->range[l]), 0, c->stream, s->range[l], C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
     }
@@ -430,7 +434,7 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
     float *x = c->pressure, *r = (float *)c->pR, *q = (float *)c->pZ, *p = (float *)c->pS, *z = s->lev[0].t;
     float *x0 = s->lev[0].x;
     const HaloArray ph[1] = {{p, sizeof(float)}};
-    if (mg_clear_in_up0() && s->tailFirst > 0) HIPCHK(c, hipMemsetAsync(s->lev[1].b, 0, s->lev[1].L.n * sizeof(float), c->stream));   // once per solve; every cycle leaves it cleared (k_mg_up0)
+    if (s->tailFirst > 0) HIPCHK(c, hipMemsetAsync(s->lev[1].b, 0, s->lev[1].L.n * sizeof(float), c->stream));   // once per solve; every cycle leaves it cleared (k_mg_up0)
     GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, -1));
     mg_vcycle(c, s, sc, 0);
     if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;

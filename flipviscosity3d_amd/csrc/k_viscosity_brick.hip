@@ -1,0 +1,471 @@
+// k_viscosity_brick.hip -- the viscosity PCG on the BRICK layout (flipv_internal.h: bidx): one wave per brick of 8 x 4 x 2 indices, one
+// lane per index.
+//
+// Why a second set of kernels.  On the reference's scenes the liquid is a compact body filling a few per cent of the box (256^3 bunny:
+// 4 %).  The tile kernels (k_viscosity_geo.inc: 64 x 16 x 1 tiles, a lane owns 4 consecutive i of a plain k-plane) move 1.9x the
+// algorithmic bytes there -- 128-byte lines that are 32 x 1 sticks are half used at both ends of every i-run of the liquid -- and a
+// block walks its 3-4 tiles one dependent round trip after the other at 2 waves per SIMD (189 VGPRs): 20 us per SpMV of which the bytes
+// explain 8.  Here every array the solve touches is stored in bricks, so that
+//   * a 128-byte line is a 4 x 4 x 2 block of space (1.1x over-fetch on that scene instead of 1.5x),
+//   * a wave's own-index access is one contiguous 256-byte run whatever the array,
+//   * the 15-point coupled stencil is addressed with six per-lane constants (the layout is separable: NbOff), every neighbour a plain
+//     load that hits the lines the wave's own brick and its six face neighbours occupy,
+//   * a lane holds one index: ~70 VGPRs, 6-7 waves per SIMD -- the latency of a brick's loads is hidden by the other bricks in
+//     flight, not by a deeper pipeline inside one wave.
+// Same arithmetic as the tile kernels: the rows come from d_visc_rows (visc_rows.h) with NV = 1.
+// Used when the liquid is sparse (row fill <= 0.35), on single-domain contexts; filled boxes keep the k-marching tile kernels, which
+// stream whole planes, block contexts (multi-GPU) keep the plain layout their halo exchange packs from.
+#include "flipv_internal.h"
+#include "pcg_common.h"
+#include "visc_rows.h"
+#include "brick.h"
+
+// ------------------------------------------------------------------ active bricks
+// flag per brick of the box's brick range (one wave per brick), and the number of flagged bricks per chunk of 1024
+__global__ __launch_bounds__(256) void k_brick_flags(BrickBox R, Lay LB, const uint8_t *__restrict__ maskB, int *__restrict__ flag, int *__restrict__ chunkCount, int n) {
+    const int code = (int)blockIdx.x * 4 + (int)threadIdx.y;
+    if (code >= n) return;
+    const size_t a = ((size_t)d_brick_of_code(R, LB, code) << 6) + threadIdx.x;
+    const unsigned long long m = __ballot(maskB[a] != 0);
+    if (threadIdx.x == 0) {
+        flag[code] = m != 0ull;
+        if (m) atomicAdd(chunkCount + (code >> 10), 1);
+    }
+}
+// exclusive scan of the chunk counts by one workgroup; total into *count
+__global__ __launch_bounds__(1024) void k_brick_scan(int *__restrict__ chunkCount, int nchunks, int *__restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base;
+    if (threadIdx.x == 0) base = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int start = 0; start < nchunks; start += 1024) {
+        const int t = start + (int)threadIdx.x;
+        const int v = t < nchunks ? chunkCount[t] : 0;
+        int inc = v;   // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int q = 0; q < 16; q++) { if (q < wv) woff += wsum[q]; total += wsum[q]; }
+        if (t < nchunks) chunkCount[t] = base + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base;
+}
+// ordered scatter: chunk `blockIdx.x` writes its flagged bricks behind its offset
+__global__ __launch_bounds__(1024) void k_brick_scatter(BrickBox R, Lay LB, const int *__restrict__ flag, const int *__restrict__ chunkOff, int n, int *__restrict__ list) {
+    __shared__ int wsum[16];
+    const int code = (int)blockIdx.x * 1024 + (int)threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int f = code < n ? flag[code] != 0 : 0;
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wv; q++) woff += wsum[q];
+    if (f) list[chunkOff[blockIdx.x] + woff + __popcll(m & ((1ull << lane) - 1ull))] = d_brick_of_code(R, LB, code);
+}
+
+int fv_build_bricks(flipv_context *c, const Lay &box) {
+    const Lay &LB = c->LB;
+    const BrickBox R = brick_box(box);
+    const int n = R.nb[0] * R.nb[1] * R.nb[2];
+    const int nchunks = (n + 1023) / 1024;
+    int *chunk = c->brickFlag + c->brickCap - nchunks - 1;   // the tail of the flag array: the box's bricks never fill it (padding bricks are never in a box)
+    HIPCHK(c, hipMemsetAsync(chunk, 0, (size_t)nchunks * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_brick_flags, dim3(cdiv(n, 4)), dim3(64, 4, 1), 0, c->stream, R, LB, (const uint8_t *)c->vMaskB, c->brickFlag, chunk, n);
+    hipLaunchKernelGGL(k_brick_scan, dim3(1), dim3(1024), 0, c->stream, chunk, nchunks, c->d_flags + 1);
+    hipLaunchKernelGGL(k_brick_scatter, dim3(nchunks), dim3(1024), 0, c->stream, R, LB, (const int *)c->brickFlag, (const int *)chunk, n, c->brickList);
+    HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->nBricks = c->h_flags[1];
+    return FLIPV_OK;
+}
+
+// ------------------------------------------------------------------ K9 SpMV / multigrid fine-level sweeps
+// q = A s (EPI_SPMV, with the fused dot products) or one of the multigrid preconditioner's fine-level sweeps (EPI_*: v.s = input,
+// v.q = output, v.r = the residual), exactly like k_visc_spmv (k_viscosity_geo.inc).  vm* = the rows' own volumes (exact operator) or
+// own volumes + the reference's diagonal defect (d_ref_volume); a lane has rows where its mask byte says so.
+template <typename T, bool RDOT, int EPI>
+__global__ __launch_bounds__(256) void k_bvisc_spmv(const int *__restrict__ bricks, int nb, const float *__restrict__ vmU, const float *__restrict__ vmV,
+                                                    const float *__restrict__ vmW, const float *__restrict__ fC, const float *__restrict__ fEU,
+                                                    const float *__restrict__ fEV, const float *__restrict__ fEW, BrickSys<T> v, PcgScal sc, int it_arg,
+                                                    float omega, int sig_shift) {
+#pragma clang fp contract(fast)
+    __shared__ double lds[12];
+    BrickWalk w;
+    w.begin(bricks, nb, v.mask);
+    bool stop;
+    const int it = d_iter_spmv(sc, it_arg, stop);
+    if (stop) return;
+    const NbOff o = d_lane_off(v.sby, v.sbz);
+    const T *__restrict__ xu = v.s[0], *__restrict__ xv = v.s[1], *__restrict__ xw = v.s[2];
+    double da = 0.0, db = 0.0, dc = 0.0;
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, v.mask);
+        if (m == 0u) continue;
+        // every load of the lane first (46 independent loads; a lane without rows issues none)
+        const float C0 = fC[a], C0l = fC[a + o.xm], Cjm = fC[a + o.ym], Ckm = fC[a + o.zm];
+        const float EW0 = fEW[a], EW0r = fEW[a + o.xp], EWjp = fEW[a + o.yp];
+        const float EV0 = fEV[a], EV0r = fEV[a + o.xp], EVkp = fEV[a + o.zp];
+        const float EU0 = fEU[a], EUjp = fEU[a + o.yp], EUkp = fEU[a + o.zp];
+        const T U0 = xu[a], U0l = xu[a + o.xm], U0r = xu[a + o.xp], Ujm = xu[a + o.ym], Ujp = xu[a + o.yp], Ukm = xu[a + o.zm], Ukp = xu[a + o.zp];
+        const T Ujmr = xu[a + o.ym + o.xp], Ukmr = xu[a + o.zm + o.xp];
+        const T V0 = xv[a], V0l = xv[a + o.xm], V0r = xv[a + o.xp], Vjm = xv[a + o.ym], Vjp = xv[a + o.yp], Vkm = xv[a + o.zm], Vkp = xv[a + o.zp];
+        const T Vjpl = xv[a + o.yp + o.xm], Vjpkm = xv[a + o.yp + o.zm];
+        const T W0 = xw[a], W0l = xw[a + o.xm], W0r = xw[a + o.xp], Wjm = xw[a + o.ym], Wjp = xw[a + o.yp], Wkm = xw[a + o.zm], Wkp = xw[a + o.zp];
+        const T Wkpl = xw[a + o.zp + o.xm], Wjmkp = xw[a + o.ym + o.zp];
+        const float MU = (m & 1u) ? vmU[a] : -1.0f, MV = (m & 2u) ? vmV[a] : -1.0f, MW = (m & 4u) ? vmW[a] : -1.0f;
+        RT<T> RU = (RT<T>)0, RV = (RT<T>)0, RW = (RT<T>)0;
+        if (RDOT) { RU = v.r[0][a]; RV = v.r[1][a]; RW = v.r[2][a]; }
+        Vec<T, 1> yU, yV, yW;
+        T ta = (T)0, tb = (T)0, tc = (T)0;
+#define V1F(x_) Vec<float, 1>{{x_}}
+#define V1T(x_) Vec<T, 1>{{x_}}
+#define V1R(x_) Vec<RT<T>, 1>{{x_}}
+        d_visc_rows<T, 1, RDOT, EPI>(V1F(MU), V1F(MV), V1F(MW), V1F(C0), V1F(Cjm), V1F(Ckm), V1F(EW0), V1F(EWjp), V1F(EV0), V1F(EVkp), V1F(EU0), V1F(EUjp),
+                                     V1F(EUkp), V1T(U0), V1T(Ujm), V1T(Ujp), V1T(Ukm), V1T(Ukp), V1T(V0), V1T(Vjm), V1T(Vjp), V1T(Vkm), V1T(Vkp), V1T(W0),
+                                     V1T(Wjm), V1T(Wjp), V1T(Wkm), V1T(Wkp), V1T(Vjpkm), V1T(Wjmkp), V1R(RU), V1R(RV), V1R(RW), C0l, EW0r, EV0r, U0l, U0r, V0l,
+                                     V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr, yU, yV, yW, ta, tb, tc, (T)omega);
+#undef V1F
+#undef V1T
+#undef V1R
+        da += (double)ta; dc += (double)tc;
+        db += (double)tb;
+        if (m & 1u) v.q[0][a] = yU.v[0];
+        if (m & 2u) v.q[1][a] = yV.v[0];
+        if (m & 4u) v.q[2][a] = yW.v[0];
+    }
+    if (EPI == EPI_JACOBI || EPI == EPI_RESIDUAL) return;
+    if (EPI == EPI_JACOBI_DOT) {   // (r, z) into sig(it + sig_shift)
+        const double rz = block_sum_256(da, lds);
+        if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
+            const int sl = sc.my_slot();
+            if (rz != 0.0) atomicAdd(sc.sig(it + sig_shift) + sl, rz);
+        }
+        return;
+    }
+    block_sum3_256(da, db, dc, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
+        const int sl = sc.my_slot();
+        if (da != 0.0) atomicAdd(sc.a(it) + sl, da);
+        if (db != 0.0) atomicAdd(sc.b(it) + sl, db);
+        if (dc != 0.0) atomicAdd(sc.c(it) + sl, dc);
+    }
+}
+
+// ------------------------------------------------------------------ z = r/d, s = z, sigma(0) = (r, z)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bpcg_init(const int *__restrict__ bricks, int nb, BrickSys<T> v, PcgScal sc) {
+    __shared__ double lds[4];
+    BrickWalk w;
+    w.begin(bricks, nb, v.mask);
+    double acc = 0.0;
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, v.mask);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (!((m >> c) & 1u)) continue;
+            const float d = v.diag[c][a];
+            const RT<T> r = v.r[c][a];
+            const double zd = d != 0.0f ? (double)r / (double)d : 0.0;
+            v.s[c][a] = (T)zd;
+            acc += zd * (double)r;
+        }
+    }
+    const double tot = block_sum_256(acc, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && tot != 0.0) atomicAdd(sc.sig(0) + sc.my_slot(), tot);
+}
+
+// ------------------------------------------------------------------ K2: x += alpha s ; r -= alpha q ; s = r/d + beta s ; sigma' ; rmax
+// (the scalar prologue, the stop test and the stall guard are k_pcg_update's, pcg_geo.inc)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bricks, int nb, BrickSys<T> v, PcgScal sc, int it_arg) {
+    BrickWalk w;
+    w.begin(bricks, nb, v.mask);
+    __shared__ double lds[8];
+    int it;
+    double alpha_d, beta_d;
+    if (!d_update_scalars(sc, it_arg, lds, it, alpha_d, beta_d)) return;
+    const T alpha = (T)alpha_d;
+    double acc = 0.0;
+    float mxf = 0.0f;
+    double mxd = 0.0;
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, v.mask);
+        // every load of the lane first (one round trip per brick, not one per component: the stores below may alias for all the compiler knows)
+        float d[3];
+        T x[3], s[3], q[3];
+        RT<T> r[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const bool on = (m >> c) & 1u;
+            d[c] = on ? v.diag[c][a] : 0.0f;
+            x[c] = on ? v.x[c][a] : (T)0; s[c] = on ? v.s[c][a] : (T)0; q[c] = on ? v.q[c][a] : (T)0;
+            r[c] = on ? v.r[c][a] : (RT<T>)0;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (d[c] == 0.0f) continue;
+            const RT<T> rn_t = (RT<T>)((double)r[c] - alpha_d * (double)q[c]);
+            const double rn = (double)rn_t;
+            const double zn = sizeof(RT<T>) == 4 ? (double)((float)rn_t / d[c]) : rn / (double)d[c];
+            v.x[c][a] = x[c] + alpha * s[c];
+            v.r[c][a] = rn_t;
+            v.s[c][a] = (T)(zn + beta_d * (double)s[c]);
+            if (sizeof(RT<T>) == 4) mxf = fmaxf(mxf, fabsf((float)rn_t)); else mxd = fmax(mxd, fabs(rn));
+            acc += zn * rn;
+        }
+    }
+    __shared__ double red[8];
+    double tot = wave_sum(acc), bm = wave_max(fmax((double)mxf, mxd));
+    {
+        const int tid = d_tid256();
+        if ((tid & 63) == 0) { red[tid >> 6] = tot; red[4 + (tid >> 6)] = bm; }
+        __syncthreads();
+        if (tid == 0) {
+            tot = red[0] + red[1] + red[2] + red[3];
+            bm = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+        }
+    }
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const int sl = sc.my_slot();
+        if (tot != 0.0) atomicAdd(sc.sig(it + 1) + sl, tot);
+        if (bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sl, bm);
+        if (it_arg < 0 && blockIdx.x == 0) *sc.itA = it + 1;
+    }
+}
+
+// ------------------------------------------------------------------ residual replacement (group-wise update, van der Vorst & Ye)
+// An fp32 PCG recurrence r -= alpha q drifts away from the true residual b - A x once |r| has dropped a few orders below |b| (here:
+// nu dt/dx^2 ~ 3e3, diagonal / own volume ~ 1e3-1e4), and an fp32 x cannot even represent the solution to a true residual of 1e-6 |b|.
+// Every `period` iterations the x accumulated so far is flushed into an fp64 accumulator (xacc += x; x = 0) and r is REPLACED by
+// b - A xacc evaluated in fp64; the search direction is kept, sigma' = (r/d, r) and max|r| are recomputed from the replaced residual.
+// Cost: two launches per `period` iterations.  The solution of the solve is xacc (after a last flush).
+//   k_bflush:     xacc += x, x = 0 ; clears the scalars the residual kernel re-accumulates
+//   k_bresidual:  r = b - A xacc (fp64 arithmetic, fp32 coefficients) ; optional z = omega r/d (the multigrid loop's first pre-sweep) ;
+//                 rmax(it) [and sigma(it + 1) = (r/d, r) when `withSigma`: the diagonal loop]
+// when: the launches act if force, or if iteration (it + 1) is a multiple of period, it = it_arg or the device-side counter *sc.itB
+__device__ __forceinline__ bool d_replace_now(const PcgScal &sc, int it_arg, int period, int force, int &it) {
+    it = it_arg >= 0 ? it_arg : *sc.itB;
+    if (force) return true;
+    if (*sc.conv >= 0 || it >= sc.cap) return false;
+    return period > 0 && ((it + 1) % period) == 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_bflush(const int *__restrict__ bricks, int nb, BrickSys<T> v, double *__restrict__ xaU, double *__restrict__ xaV,
+                                                double *__restrict__ xaW, PcgScal sc, int it_arg, int period, int force, int withSigma) {
+    BrickWalk w;
+    w.begin(bricks, nb, v.mask);
+    int it;
+    if (!d_replace_now(sc, it_arg, period, force, it)) return;
+    if (!force && blockIdx.x == 0 && threadIdx.y == 0 && threadIdx.x < NSLOT) {   // the replaced residual's scalars are accumulated afresh
+        sc.rmax(it)[threadIdx.x] = 0.0;
+        if (withSigma) sc.sig(it + 1)[threadIdx.x] = 0.0;
+
+    }
+    double *xa[3] = {xaU, xaV, xaW};
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, v.mask);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (!((m >> c) & 1u)) continue;
+            xa[c][a] += (double)v.x[c][a];
+            v.x[c][a] = (T)0;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_bresidual(const int *__restrict__ bricks, int nb, const float *__restrict__ vmU, const float *__restrict__ vmV,
+                                                   const float *__restrict__ vmW, const float *__restrict__ fC, const float *__restrict__ fEU,
+                                                   const float *__restrict__ fEV, const float *__restrict__ fEW, BrickSys<T> v,
+                                                   const double *__restrict__ xu, const double *__restrict__ xv, const double *__restrict__ xw,
+                                                   const float *__restrict__ bU, const float *__restrict__ bV, const float *__restrict__ bW,
+                                                   float *__restrict__ zU, float *__restrict__ zV, float *__restrict__ zW, float omega,
+                                                   PcgScal sc, int it_arg, int period, int withSigma, int force) {
+    __shared__ double red[8];
+    BrickWalk w;
+    w.begin(bricks, nb, v.mask);
+    int it;
+    if (!d_replace_now(sc, it_arg, period, force, it)) return;
+    const NbOff o = d_lane_off(v.sby, v.sbz);
+    double acc = 0.0, mx = 0.0, mz = 0.0;
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, v.mask);
+        if (m == 0u) continue;
+        const float C0 = fC[a], C0l = fC[a + o.xm], Cjm = fC[a + o.ym], Ckm = fC[a + o.zm];
+        const float EW0 = fEW[a], EW0r = fEW[a + o.xp], EWjp = fEW[a + o.yp];
+        const float EV0 = fEV[a], EV0r = fEV[a + o.xp], EVkp = fEV[a + o.zp];
+        const float EU0 = fEU[a], EUjp = fEU[a + o.yp], EUkp = fEU[a + o.zp];
+        const double U0 = xu[a], U0l = xu[a + o.xm], U0r = xu[a + o.xp], Ujm = xu[a + o.ym], Ujp = xu[a + o.yp], Ukm = xu[a + o.zm], Ukp = xu[a + o.zp];
+        const double Ujmr = xu[a + o.ym + o.xp], Ukmr = xu[a + o.zm + o.xp];
+        const double V0 = xv[a], V0l = xv[a + o.xm], V0r = xv[a + o.xp], Vjm = xv[a + o.ym], Vjp = xv[a + o.yp], Vkm = xv[a + o.zm], Vkp = xv[a + o.zp];
+        const double Vjpl = xv[a + o.yp + o.xm], Vjpkm = xv[a + o.yp + o.zm];
+        const double W0 = xw[a], W0l = xw[a + o.xm], W0r = xw[a + o.xp], Wjm = xw[a + o.ym], Wjp = xw[a + o.yp], Wkm = xw[a + o.zm], Wkp = xw[a + o.zp];
+        const double Wkpl = xw[a + o.zp + o.xm], Wjmkp = xw[a + o.ym + o.zp];
+        const float MU = (m & 1u) ? vmU[a] : -1.0f, MV = (m & 2u) ? vmV[a] : -1.0f, MW = (m & 4u) ? vmW[a] : -1.0f;
+        const double RU = (m & 1u) ? (double)bU[a] : 0.0, RV = (m & 2u) ? (double)bV[a] : 0.0, RW = (m & 4u) ? (double)bW[a] : 0.0;
+        Vec<double, 1> yU, yV, yW;
+        double ta = 0.0, tb = 0.0, tc = 0.0;
+#define V1F(x_) Vec<float, 1>{{x_}}
+#define V1D(x_) Vec<double, 1>{{x_}}
+        d_visc_rows<double, 1, true, EPI_RESIDUAL>(V1F(MU), V1F(MV), V1F(MW), V1F(C0), V1F(Cjm), V1F(Ckm), V1F(EW0), V1F(EWjp), V1F(EV0), V1F(EVkp), V1F(EU0),
+                                                   V1F(EUjp), V1F(EUkp), V1D(U0), V1D(Ujm), V1D(Ujp), V1D(Ukm), V1D(Ukp), V1D(V0), V1D(Vjm), V1D(Vjp), V1D(Vkm),
+                                                   V1D(Vkp), V1D(W0), V1D(Wjm), V1D(Wjp), V1D(Wkm), V1D(Wkp), V1D(Vjpkm), V1D(Wjmkp), V1D(RU), V1D(RV), V1D(RW),
+                                                   C0l, EW0r, EV0r, U0l, U0r, V0l, V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr, yU, yV, yW, ta, tb, tc, 0.0);
+#undef V1F
+#undef V1D
+        const double rr[3] = {yU.v[0], yV.v[0], yW.v[0]};
+        float *zz[3] = {zU, zV, zW};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (!((m >> c) & 1u)) continue;
+            const RT<T> rt = (RT<T>)rr[c];
+            v.r[c][a] = rt;
+            const float d = v.diag[c][a];
+            const double z = d != 0.0f ? (double)rt / (double)d : 0.0;
+            if (zU) zz[c][a] = omega * (float)z;
+            acc += z * (double)rt;
+            mx = fmax(mx, fabs((double)rt));
+            mz = fmax(mz, fabs(z));
+        }
+    }
+    double tot = wave_sum(acc), bm = wave_max(mx);
+    {
+        const int tid = d_tid256();
+        if ((tid & 63) == 0) { red[tid >> 6] = tot; red[4 + (tid >> 6)] = bm; }
+        __syncthreads();
+        if (tid == 0) {
+            tot = red[0] + red[1] + red[2] + red[3];
+            bm = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+        }
+    }
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const int sl = sc.my_slot();
+        if (withSigma && tot != 0.0) atomicAdd(sc.sig(it + 1) + sl, tot);
+        if (bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sl, bm);
+
+    }
+}
+
+// ------------------------------------------------------------------ solution -> velocity grid (plain layout), over a launch box
+template <typename T>
+__global__ void k_unbrick_to_f32(Lay L, Lay LB, const T *__restrict__ a, const double *__restrict__ acc, float *__restrict__ o) {
+    IJK_OF_THREAD(L);
+    if (i >= L.ie || j >= L.je) return;
+    const size_t b = bidx(LB, i, j, k);
+    o[gidx(L, i, j, k)] = acc ? (float)(acc[b] + (double)a[b]) : (float)a[b];
+}
+
+// ------------------------------------------------------------------ host side
+template <typename T>
+static BrickSys<T> brick_sys(flipv_context *c) {
+    BrickSys<T> v;
+    v.mask = c->vMaskB;
+    v.sby = (int)c->LB.sy * 64; v.sbz = (int)c->LB.sz * 64;
+    v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
+    for (int m = 0; m < 3; m++) { v.x[m] = (T *)c->vX[m]; v.r[m] = (RT<T> *)c->vR[m]; v.q[m] = (T *)c->vZ[m]; v.s[m] = (T *)c->vS[m]; }
+    return v;
+}
+int fv_brick_grid(const flipv_context *c, int nbricks, int cap) {
+    int nb = (((nbricks + 3) / 4 + 7) / 8) * 8;
+    if (c->prm.grid_cap > 0 && cap > ((c->prm.grid_cap + 7) / 8) * 8) cap = ((c->prm.grid_cap + 7) / 8) * 8;   // test hook: every block walks many bricks
+    if (nb > cap) nb = cap;
+    return nb < 8 ? 8 : nb;
+}
+// one resident round: 88-92 VGPRs = 5 waves per SIMD = 5 blocks per CU
+static int spmv_grid(const flipv_context *c) { return fv_brick_grid(c, c->nBricks, c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : 1280); }
+static int update_grid(const flipv_context *c) { return fv_brick_grid(c, c->nBricks, c->prm.viscosity_update_grid_cap > 0 ? c->prm.viscosity_update_grid_cap : 2048); }
+
+template <typename T>
+void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot) {
+    const bool timed = c->prm.kernel_timing && (it & 7) == 0;
+    if (timed) fv_ev_begin(c, 1, (double)c->nBricks * 64);
+    const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
+    const BrickSys<T> v = brick_sys<T>(c);
+    const dim3 g(spmv_grid(c)), b(64, 4, 1);
+    if (rdot) hipLaunchKernelGGL((k_bvisc_spmv<T, true, EPI_SPMV>), g, b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
+    else hipLaunchKernelGGL((k_bvisc_spmv<T, false, EPI_SPMV>), g, b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
+    if (timed) fv_ev_end(c);
+}
+template void fv_brick_spmv<float>(flipv_context *, const PcgScal &, int, bool);
+template void fv_brick_spmv<double>(flipv_context *, const PcgScal &, int, bool);
+
+template <typename T>
+void fv_brick_init(flipv_context *c, const PcgScal &sc) {
+    hipLaunchKernelGGL((k_bpcg_init<T>), dim3(update_grid(c)), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, brick_sys<T>(c), sc);
+}
+template void fv_brick_init<float>(flipv_context *, const PcgScal &);
+template void fv_brick_init<double>(flipv_context *, const PcgScal &);
+
+template <typename T>
+void fv_brick_update(flipv_context *c, const PcgScal &sc, int it) {
+    hipLaunchKernelGGL((k_bpcg_update<T>), dim3(update_grid(c)), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, brick_sys<T>(c), sc, it);
+}
+template void fv_brick_update<float>(flipv_context *, const PcgScal &, int);
+template void fv_brick_update<double>(flipv_context *, const PcgScal &, int);
+
+// the multigrid's fine-level sweeps (fp32): out = in + omega (r - A in)/d (epi 1; 3 also adds (r, out) into sig(it + sig_shift)), out = r - A in (epi 2)
+void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift) {
+    BrickSys<float> v = brick_sys<float>(c);
+    for (int m = 0; m < 3; m++) { v.s[m] = in[m]; v.q[m] = out[m]; }
+    const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
+    const dim3 g(spmv_grid(c)), b(64, 4, 1);
+#define BSWEEP(E_) hipLaunchKernelGGL((k_bvisc_spmv<float, true, E_>), g, b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it_arg, omega, sig_shift)
+    if (epi == 1) BSWEEP(EPI_JACOBI); else if (epi == 2) BSWEEP(EPI_RESIDUAL); else BSWEEP(EPI_JACOBI_DOT);
+#undef BSWEEP
+}
+
+// residual replacement (see above); z (optional): the multigrid loop's first pre-sweep vector, rewritten as omega r/d
+template <typename T>
+void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int period, int withSigma, float *const z[3], float omega) {
+    const BrickSys<T> v = brick_sys<T>(c);
+    const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
+    const dim3 b(64, 4, 1);
+    hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, it_arg, period, 0, withSigma);
+    hipLaunchKernelGGL((k_bresidual<T>), dim3(spmv_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v,
+                       (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1],
+                       (const float *)c->vB[2], z ? z[0] : nullptr, z ? z[1] : nullptr, z ? z[2] : nullptr, omega, sc, it_arg, period, withSigma, 0);
+}
+template void fv_brick_replace<float>(flipv_context *, const PcgScal &, int, int, int, float *const[3], float);
+template void fv_brick_replace<double>(flipv_context *, const PcgScal &, int, int, int, float *const[3], float);
+// Iterative refinement after a stalled fp32 solve: xacc += x, x = 0, r = b - A xacc evaluated in fp64 -- the PCG loop is then run again
+// on the correction equation A dx = r (whatever the stop flag says: the caller resets the solve's scalars afterwards)
+// scalBytes: the solve's scalar block is cleared in between, so that rmax(0) afterwards is max|r| of the recomputed residual
+// outerExact: which operator the recomputed residual belongs to -- the exact one, or the reference's float-rounded one (the operator the
+// SOLVE is for; the PCG loop in between may run on the exact operator, see viscosity_solve_t)
+template <typename T>
+void fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact) {
+    const BrickSys<T> v = brick_sys<T>(c);
+    const float *const vo[3] = {outerExact ? c->vmU : c->vrU, outerExact ? c->vmV : c->vrV, outerExact ? c->vmW : c->vrW};
+    const dim3 b(64, 4, 1);
+    hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0);
+    (void)hipMemsetAsync(sc.base, 0, scalBytes, c->stream);
+    hipLaunchKernelGGL((k_bresidual<T>), dim3(spmv_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v,
+                       (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1],
+                       (const float *)c->vB[2], (float *)nullptr, (float *)nullptr, (float *)nullptr, 0.0f, sc, 0, 0, 0, 1);
+}
+template void fv_brick_refine<float>(flipv_context *, const PcgScal &, size_t, bool);
+template void fv_brick_refine<double>(flipv_context *, const PcgScal &, size_t, bool);
+
+// x (+ xacc) -> velocity grid over the launch box R
+template <typename T>
+void fv_brick_writeback(flipv_context *c, const Lay &R, int m, bool withAcc, float *dst) {
+    hipLaunchKernelGGL((k_unbrick_to_f32<T>), GRID3(R), 0, c->stream, R, c->LB, (const T *)c->vX[m], withAcc ? (const double *)c->vXacc[m] : (const double *)nullptr, dst);
+}
+template void fv_brick_writeback<float>(flipv_context *, const Lay &, int, bool, float *);
+template void fv_brick_writeback<double>(flipv_context *, const Lay &, int, bool, float *);

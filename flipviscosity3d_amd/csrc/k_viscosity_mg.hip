@@ -27,10 +27,11 @@
 //                (device-side iteration counters, as in pcg_common.h)
 #include "flipv_internal.h"
 #include "pcg_common.h"
+#include "brick.h"
 
 #include <vector>
 
-void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);  // k_viscosity.hip
+void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);  // k_viscosity.hip (tile kernels or, in the brick layout, k_viscosity_brick.hip)
 
 namespace {
 
@@ -41,7 +42,6 @@ constexpr int VMG_MIN_DIM = 16;           // no level below this many cells alon
 constexpr int VMG_TAIL_POS = 640;         // levels with at most this many index positions in their box go into the single-workgroup tail
 constexpr int VMG_TAIL_MAX = 3;           // ... at most this many levels
 constexpr int VMG_MAX_LEVELS = 15;
-constexpr int VMG_KEEP = 1;               // consecutive viscosity solves one assembled hierarchy serves
 
 // slot tables: neighbour component and offset of slot s of a row of component c; inverse look-up by (c, c', offset)
 struct SlotTables {
@@ -125,12 +125,13 @@ struct VLevelDev {       // what kernels need of a coarse level
 };
 struct FineOp {          // the matrix-free level 0 (k_viscosity.hip's arrays)
     int swz;             // 1: vm is stored in the swizzled plane layout (sidx); the factors and the mask never are
+    int brick;           // 1: everything (vm, factors, mask) is stored in the brick layout (bidx over LB)
+    Lay LB;
     const float *vm[3];
     const float *fC, *fE[3];
     const uint8_t *mask;
 };
 
-__device__ unsigned g_dropped[2];
 // Coarse levels are stored in BRICKS of 8 x 4 x 2 indices (64 entries = two 128-byte lines): the liquid fills 10-30 % of a level's
 // bounding box, and with plain rows a wave's 64 consecutive i of a (j, k) row carried rows in a third of its lanes while every
 // array was fetched in whole lines (level 1 of the 256^3 bunny: 80 MB per sweep for 25 MB of operator).  A wave now owns one brick
@@ -189,51 +190,17 @@ constexpr __host__ __device__ __forceinline__ int d_slot_of(int c, int c2, int d
     if (other != 0 || dn > 0 || da < 0 || da > 1) return -1;
     return 15 + (first ? 0 : 4) + (dn + 1) * 2 + da;
 }
-// add value to the coarse entry (row (c, I), column (c2, J)); the offset J - I is always one of the 23 slots
-__device__ __forceinline__ void d_coarse_add(const VLevelDev &C, int c, const int I[3], int c2, const int J[3], float v) {
-    const int dx = J[0] - I[0], dy = J[1] - I[1], dz = J[2] - I[2];
-    if (dx < -1 || dx > 1 || dy < -1 || dy > 1 || dz < -1 || dz > 1) { if (v != 0.0f) atomicAdd(&g_dropped[0], 1u); return; }  // cannot happen: the pattern is closed under this coarsening
-    const int s = d_slot_of(c, c2, dx, dy, dz);
-    if (s >= 0) atomicAdd(C.coef[c][s] + cidx(C.L, I[0], I[1], I[2]), v);
-    else if (v != 0.0f) atomicAdd(&g_dropped[1], 1u);
-}
-// scatter one entry A(a, b) = v of a finer level into the coarse operator
-__device__ __forceinline__ void d_rap_entry(const VLevelDev &C, int c, const int p[3], int c2, const int q[3], float v) {
-    int PI[2][3], PJ[2][3];
-    float wi[2], wj[2];
-    const int ni = d_parents(c, p, PI, wi), nj = d_parents(c2, q, PJ, wj);
-    for (int a = 0; a < ni; a++)
-        for (int b = 0; b < nj; b++) d_coarse_add(C, c, PI[a], c2, PJ[b], wi[a] * v * wj[b]);
-}
-
 // thread -> index of a level's box (64 x 4 x 1 threads per block)
 #define BOX_IJK_OR_RETURN(B)                                                                                   \
     const int i = (B).lo[0] + blockIdx.x * 64 + threadIdx.x, j = (B).lo[1] + blockIdx.y * 4 + threadIdx.y,     \
               k = (B).lo[2] + blockIdx.z;                                                                      \
     if (i >= (B).hi[0] || j >= (B).hi[1]) return
 
-// ---- level l -> level l+1 (l >= 1): every stored entry of the dense-slot operator inside the level's box
-__global__ void k_vmg_rap(VLevelDev F, VLevelDev C) {
-    BOX_IJK_OR_RETURN(F.box);
-    const size_t ci = cidx(F.L, i, j, k);
-    const int p[3] = {i, j, k};
-    for (int c = 0; c < 3; c++) {
-        if (F.coef[c][ST.diag[c]][ci] == 0.0f) continue;
-        for (int s = 0; s < VS; s++) {
-            const float v = F.coef[c][s][ci];
-            if (v == 0.0f) continue;
-            const int q[3] = {i + ST.off[c][s][0], j + ST.off[c][s][1], k + ST.off[c][s][2]};
-            d_rap_entry(C, c, p, ST.comp[c][s], q, v);
-        }
-    }
-}
-
 // ---- level l -> level l+1 as a GATHER (no atomics, no divergence): coarse row (C, I) collects, from its <= 12 children p = 2 I + delta
 // (delta along the normal -1/0/+1 with weights 1/2, 1, 1/2; 0/1 across) and each child's 23 stored entries, w_child * A(p, q) * w_parent
 // into the slot of q's parent(s).  Everything but the values is known at compile time once the loops are unrolled -- the parity of q
 // along its own normal decides between one parent and two, the parent's offset from I picks the slot -- so the 23 accumulators are
-// registers.  (k_vmg_rap above, the scatter with atomics, stays as the cross-check under FLIPV_VMG_DEBUG: 0.26-0.36 ms per level
-// against 20-40 us.)
+// registers.  (The scatter with atomics this replaced took 0.26-0.36 ms per level against 20-40 us.)
 constexpr int floor_half(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
 template <int C, int DN, int A_, int B_, int T>
 __device__ __forceinline__ void d_rap_gather_term(float v, float (&acc)[VS]) {
@@ -285,7 +252,7 @@ __device__ __forceinline__ void d_rap_gather_child(const VLevelDev &F, const int
     RapGatherSlots<C, DN, A_, B_, 0>::run(F, ci, acc);
 }
 // ---- level 0 -> level 1 the same way: the child's entries come from the matrix-free operator (viscositysolver.cpp:394-465 and the
-// V / W analogues; k_vmg_rap_fine in k_viscosity_mg_geo.inc is the scatter form of the same rows, kept as the cross-check).  In the
+// V / W analogues).  In the
 // 23-slot numbering a fine row of component C has: the diagonal (slot 5); -fP / -fM towards its same-component neighbours along each
 // axis a (fP, fM = the factor on the + / - side: the cell-centre factor along the normal, an edge factor across); and, for each
 // transverse axis a, four entries of component a: -fP at p + e_a, +fP at p + e_a - e_C, +fM at p, -fM at p - e_C.  An entry exists
@@ -333,18 +300,19 @@ __device__ __forceinline__ void d_rap_gather_child_fine(const FineOp &A, const L
     int p[3];
     p[C] = 2 * I[C] + DN; p[t1] = 2 * I[t1] + A_; p[t2] = 2 * I[t2] + B_;
     if (!d_in_lattice(L, C, p)) return;
-    const size_t ci = gidx(L, p[0], p[1], p[2]);
+    const size_t ci = A.brick ? bidx(A.LB, p[0], p[1], p[2]) : gidx(L, p[0], p[1], p[2]);
     FineChild f;
     f.m = A.mask[ci];
     if (!((f.m >> C) & 1u)) return;
-    const long st[3] = {1, L.sy, L.sz};
+    const NbOff o = A.brick ? nb_brick(A.LB, p[0], p[1], p[2]) : nb_plain(L);
+    const long stp[3] = {o.xp, o.yp, o.zp}, stm[3] = {o.xm, o.ym, o.zm};   // offsets to the +- neighbours along each axis
     f.vm = A.vm[C][A.swz ? sidx(L, p[0], p[1], p[2]) : ci];
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        if (a == C) { f.fP[a] = A.fC[ci]; f.fM[a] = A.fC[ci - st[C]]; }
-        else { f.fP[a] = A.fE[3 - C - a][ci + st[a]]; f.fM[a] = A.fE[3 - C - a][ci]; }
-        f.mP[a] = A.mask[ci + st[a]]; f.mM[a] = A.mask[ci - st[a]];
-        f.mPc[a] = a == C ? 0u : A.mask[ci + st[a] - st[C]];
+        if (a == C) { f.fP[a] = A.fC[ci]; f.fM[a] = A.fC[ci + stm[C]]; }
+        else { f.fP[a] = A.fE[3 - C - a][ci + stp[a]]; f.fM[a] = A.fE[3 - C - a][ci]; }
+        f.mP[a] = A.mask[ci + stp[a]]; f.mM[a] = A.mask[ci + stm[a]];
+        f.mPc[a] = a == C ? 0u : A.mask[ci + stp[a] + stm[C]];
     }
     RapGatherFineSlots<C, DN, A_, B_, 0>::run(f, acc);
 }
@@ -428,7 +396,8 @@ __device__ __forceinline__ float d_prolong_at(int M, const Lay &Cn, const Vec3p 
 }
 // (P^T t)(C, P): the <= 12 fine children of coarse dof P of component C.  FINE0: the finer level is level 0 (plain rows, gidx);
 // otherwise a coarse level (bricks, cidx)
-template <int C, bool FINE0>
+// FINE0: what the finer level is: 0 a coarse level (bricks, cidx), 1 level 0 in plain rows (gidx), 2 level 0 in the brick layout (bidx; F = the brick Lay)
+template <int C, int FINE0>
 __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const int P[3]) {
     constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
     float s = 0.0f;
@@ -440,11 +409,11 @@ __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const
             for (int b = 0; b < 2; b++) {
                 int q[3];
                 q[C] = 2 * P[C] + dn; q[t1] = 2 * P[t1] + a; q[t2] = 2 * P[t2] + b;
-                if (d_in_lattice(F, C, q)) s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][FINE0 ? gidx(F, q[0], q[1], q[2]) : cidx(F, q[0], q[1], q[2])];
+                if (d_in_lattice(F, C, q)) s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][FINE0 == 1 ? gidx(F, q[0], q[1], q[2]) : (FINE0 == 2 ? bidx(F, q[0], q[1], q[2]) : cidx(F, q[0], q[1], q[2]))];
             }
     return s;
 }
-template <int OP, int C, bool FINE0>
+template <int OP, int C, int FINE0>
 __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
     const size_t ci = cidx(A.L, i, j, k);
     const int P[3] = {i, j, k};
@@ -488,7 +457,7 @@ __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, con
     const float bb = A.b.p[C][ci];
     out.p[C][ci] = OP == OP_RESID ? bb - ax : in.p[C][ci] + VMG_OMEGA * (bb - ax) / d;
 }
-template <int OP, bool FINE0>
+template <int OP, int FINE0>
 __device__ __forceinline__ void d_vmg_step_c(int c, const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
     if (c == 0) d_vmg_step<OP, 0, FINE0>(A, F, ft, Cn, cx, i, j, k);
     else if (c == 1) d_vmg_step<OP, 1, FINE0>(A, F, ft, Cn, cx, i, j, k);
@@ -517,7 +486,7 @@ __device__ __forceinline__ bool d_brick_lane(const Box3 &B, int code, int lane, 
     return i >= B.lo[0] && i < B.hi[0] && j >= B.lo[1] && j < B.hi[1] && k >= B.lo[2] && k < B.hi[2];
 }
 template <int OP>
-__global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv) {
+__global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick) {   // fineBrick: level 0 (F0, ft0) is in the brick layout
     if (*conv >= 0) return;
     const VLevelDev &A = lev[l];
     const int sidx = (int)blockIdx.x * 4 + (int)threadIdx.y;   // a wave per brick and component
@@ -526,10 +495,10 @@ __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ 
     int i, j, k;
     if (!d_brick_lane(A.box, A.strips[sidx], (int)threadIdx.x, i, j, k)) return;
     if (OP == OP_RESTRICT) {
-        if (l == 0) d_vmg_step_c<OP, true>(c, A, F0, ft0, A.L, ft0, i, j, k);
-        else d_vmg_step_c<OP, false>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
-    } else if (OP == OP_PROLONG || OP == OP_PROPOST) d_vmg_step_c<OP, false>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
-    else d_vmg_step_c<OP, false>(c, A, A.L, ft0, A.L, ft0, i, j, k);
+        if (l == 0) { if (fineBrick) d_vmg_step_c<OP, 2>(c, A, F0, ft0, A.L, ft0, i, j, k); else d_vmg_step_c<OP, 1>(c, A, F0, ft0, A.L, ft0, i, j, k); }
+        else d_vmg_step_c<OP, 0>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
+    } else if (OP == OP_PROLONG || OP == OP_PROPOST) d_vmg_step_c<OP, 0>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
+    else d_vmg_step_c<OP, 0>(c, A, A.L, ft0, A.L, ft0, i, j, k);
 }
 // bricks of a level's box that hold rows: flags (one wave per brick), then an ordered compaction by one workgroup
 __global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__restrict__ flag, int nbricks) {
@@ -593,7 +562,7 @@ __global__ __launch_bounds__(1024) void k_vmg_coarsest_rows(VLevelDev A, int *__
 }
 
 // the coarsest levels in one workgroup: levels lev[first..n), lev[first] restricts from lev[first - 1] (first = 0: from (F0, ft0))
-template <int OP, bool FINE0 = false>
+template <int OP, int FINE0 = 0>
 __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx) {
     const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dz = A.box.hi[2] - A.box.lo[2];
     const int n = w * h * dz;
@@ -610,7 +579,7 @@ __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, co
 // of the cycle's 520 before).  Falls back to the global-memory sweeps when the box or a component's row count does not fit.
 struct CoarseRow { float cf[VS]; float invd, b; int li; size_t ci; bool has; };
 template <int C>
-__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, bool fine0, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP) {
+__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, int fine0, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP) {   // fine0: d_restrict's FINE0
     R.has = (int)threadIdx.x < nrows;
     if (!R.has) return;
     const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1];
@@ -622,7 +591,7 @@ __device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F
 #pragma unroll
     for (int q = 0; q < VS; q++) R.cf[q] = A.coef[C][q][R.ci];
     R.invd = 1.0f / R.cf[slot_diag(C)];
-    R.b = fine0 ? d_restrict<C, true>(F, ft, P) : d_restrict<C, false>(F, ft, P);
+    R.b = fine0 == 1 ? d_restrict<C, 1>(F, ft, P) : (fine0 == 2 ? d_restrict<C, 2>(F, ft, P) : d_restrict<C, 0>(F, ft, P));
     xs0[C * NP + R.li] = VMG_OMEGA * R.b * R.invd;
 }
 template <int C>
@@ -634,7 +603,7 @@ __device__ __forceinline__ void d_coarsest_sweep(const CoarseRow &R, const float
     nxt[C * NP + R.li] = cur[C * NP + R.li] + VMG_OMEGA * (R.b - ax) * R.invd;
 }
 
-__global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, Lay F0, Vec3p ft0, const int *__restrict__ conv) {
+__global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick) {
     if (*conv >= 0) return;
     // the coarsest level lives in LDS when its box and rows fit (k_vmg_coarsest_rows decided that for this solve)
     __shared__ float xs[2 * 3 * VMG_LDS_POS];
@@ -652,7 +621,7 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
     for (int l = first; l < n; l++) {   // down
         const VLevelDev &A = lev[l];
         if (l == n - 1 && coarsest_in_lds) break;   // restricted straight into registers below
-        if (l == 0) d_tail_step<OP_RESTRICT, true>(A, F0, ft0, A.L, ft0);
+        if (l == 0) { if (fineBrick) d_tail_step<OP_RESTRICT, 2>(A, F0, ft0, A.L, ft0); else d_tail_step<OP_RESTRICT, 1>(A, F0, ft0, A.L, ft0); }
         else d_tail_step<OP_RESTRICT>(A, lev[l - 1].L, lev[l - 1].t, A.L, ft0);
         if (l + 1 < n) {
             d_tail_step<OP_PRE2>(A, A.L, ft0, A.L, ft0);
@@ -670,9 +639,10 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
         const Lay &F = n - 1 == 0 ? F0 : lev[n - 2].L;
         const Vec3p &ft = n - 1 == 0 ? ft0 : lev[n - 2].t;
         CoarseRow RU, RV, RW;
-        d_coarsest_load<0>(A, F, ft, n - 1 == 0, rowlist[0], cnt[0], W, H, RU, xs, NP);
-        d_coarsest_load<1>(A, F, ft, n - 1 == 0, rowlist[1], cnt[1], W, H, RV, xs, NP);
-        d_coarsest_load<2>(A, F, ft, n - 1 == 0, rowlist[2], cnt[2], W, H, RW, xs, NP);
+        const int fine0 = n - 1 == 0 ? (fineBrick ? 2 : 1) : 0;
+        d_coarsest_load<0>(A, F, ft, fine0, rowlist[0], cnt[0], W, H, RU, xs, NP);
+        d_coarsest_load<1>(A, F, ft, fine0, rowlist[1], cnt[1], W, H, RV, xs, NP);
+        d_coarsest_load<2>(A, F, ft, fine0, rowlist[2], cnt[2], W, H, RW, xs, NP);
         __syncthreads();
         float *cur = xs, *nxt = xs + 3 * VMG_LDS_POS;
         for (int s = 0; s < sweeps; s++) {
@@ -695,12 +665,157 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
     }
 }
 
-// zero a set of arrays inside a box (+ one ring): the coarse operators of this solve, before the Galerkin scatter
-struct ZeroSet { float *p[3 * VS]; int n; };
-__global__ __launch_bounds__(256) void k_vmg_zero_box(ZeroSet Z, Lay L, Box3 B) {
-    BOX_IJK_OR_RETURN(B);
-    const size_t ci = cidx(L, i, j, k);
-    for (int a = 0; a < Z.n; a++) Z.p[a][ci] = 0.0f;
+// ---- what the x / r kernels of either layout publish and the p kernels test: max|r| into rmax(it)
+__device__ __forceinline__ void d_vmg_publish_max(const PcgScal &sc, int it, float mx, double *lds) {
+    if (it < 0) return;
+    const double bm = block_max_256((double)mx, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sc.my_slot(), bm);
+}
+// stop test and stall guard of iteration it >= 0; true: the launch returns (every thread of the block calls this)
+__device__ __forceinline__ bool d_vmg_stop_test(const PcgScal &sc, int it, double *lds) {
+    const double res = d_fold_max(sc.rmax(it), lds);
+    const bool first = blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0;
+    if (d_pass(sc, res)) {
+        if (first) *sc.conv = it;
+        return true;
+    }
+    if (sc.best) {   // stall guard, as in k_pcg_update (pcg_common.h: PcgScal::best)
+        const double bestNow = *sc.best;
+        if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > 16.0 * bestNow) {
+            if (first) { *sc.stalled = 1; *sc.conv = it; }
+            return true;
+        }
+        if (first && res < bestNow) *sc.best = res;
+    }
+    return false;
+}
+
+// ---- level 0 in the brick layout (k_viscosity_brick.hip): the vector kernels of the PCG loop, one wave per listed brick, one lane per index
+__device__ __forceinline__ int d_bvmg_iter(const PcgScal &sc, int it_arg) { return it_arg == IT_DEVICE ? *sc.itB : it_arg; }
+// bounding box of the listed bricks' indices
+__global__ __launch_bounds__(256) void k_bvmg_bbox(const int *__restrict__ bricks, int nb, Lay LB, int *__restrict__ box) {
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {0, 0, 0};
+    for (int e = blockIdx.x * 256 + (int)(threadIdx.y * 64 + threadIdx.x); e < nb; e += gridDim.x * 256) {
+        int i, j, k;
+        d_brick_ijk(LB, bricks[e], 0, i, j, k);
+        const int p0[3] = {i, j, k}, p1[3] = {i + 8, j + 4, k + 2};
+#pragma unroll
+        for (int a = 0; a < 3; a++) { lo[a] = min(lo[a], p0[a]); hi[a] = max(hi[a], p1[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        lo[a] = -(int)wave_max((double)(-lo[a])); hi[a] = (int)wave_max((double)hi[a]);
+        if ((threadIdx.x & 63) == 0) { atomicMin(box + a, lo[a]); atomicMax(box + 3 + a, hi[a]); }
+    }
+}
+// x += alpha p ; r -= alpha q ; rmax(it) ; z = omega r/d      (k_vpcg_xr of k_viscosity_mg_geo.inc)
+__global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask, Vec3p d, Vec3p x, Vec3p r, Vec3p p, Vec3p q,
+                                                  Vec3p z, float omega, PcgScal sc, int it_arg) {
+    BrickWalk w;
+    w.begin(bricks, nb, mask);
+    if (*sc.conv >= 0) return;
+    const int it = d_bvmg_iter(sc, it_arg);
+    if (it >= sc.cap) return;
+    __shared__ double lds[8];
+    double alpha_d = 0.0;
+    if (it >= 0) {
+        double f[4];
+        d_fold_sums(sc.sig(it), sc.a(it), nullptr, nullptr, f, lds);
+        alpha_d = f[1] != 0.0 ? f[0] / f[1] : 0.0;
+    }
+    const float alpha = (float)alpha_d;
+    float mx = 0.0f;
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, mask);
+        // every load of the lane first (one round trip per brick, not one per component)
+        float dd[3], rr[3], xx[3], pp[3], qq[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const bool on = (m >> c) & 1u;
+            dd[c] = on ? d.p[c][a] : 0.0f;
+            rr[c] = on ? r.p[c][a] : 0.0f;
+            xx[c] = (on && it >= 0) ? x.p[c][a] : 0.0f;
+            pp[c] = (on && it >= 0) ? p.p[c][a] : 0.0f;
+            qq[c] = (on && it >= 0) ? q.p[c][a] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            if (!((m >> c) & 1u)) continue;
+            if (it >= 0 && dd[c] != 0.0f) {
+                x.p[c][a] = xx[c] + alpha * pp[c];
+                rr[c] = (float)((double)rr[c] - alpha_d * (double)qq[c]);
+                r.p[c][a] = rr[c];
+            }
+            const float zz = dd[c] != 0.0f ? rr[c] / dd[c] : 0.0f;
+            if (it >= 0 && dd[c] != 0.0f) mx = fmaxf(mx, fabsf(rr[c]));
+            z.p[c][a] = omega * zz;
+        }
+    }
+    d_vmg_publish_max(sc, it, mx, lds);
+}
+// z += P xc on the rows (the coarse correction of level 1)
+__global__ __launch_bounds__(256) void k_bvmg_prolong_fine(const int *__restrict__ bricks, int nb, Lay LB, Lay C, const uint8_t *__restrict__ mask, Vec3p z, Vec3p xc,
+                                                           PcgScal sc, int it_arg) {
+    BrickWalk w;
+    w.begin(bricks, nb, mask);
+    if (*sc.conv >= 0 || d_bvmg_iter(sc, it_arg) >= sc.cap) return;
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, mask);
+        if (m == 0u) continue;
+        int p[3];
+        d_brick_ijk(LB, (int)(a >> 6), (int)threadIdx.x, p[0], p[1], p[2]);
+        float add[3], zz[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {   // the loads of all three components first
+            add[c] = 0.0f; zz[c] = 0.0f;
+            if (!((m >> c) & 1u)) continue;
+            int Q[2][3];
+            float wt[2];
+            const int n = d_parents(c, p, Q, wt);
+            zz[c] = z.p[c][a];
+            add[c] = wt[0] * xc.p[c][cidx(C, Q[0][0], Q[0][1], Q[0][2])];
+            if (n == 2) add[c] += wt[1] * xc.p[c][cidx(C, Q[1][0], Q[1][1], Q[1][2])];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            if ((m >> c) & 1u) z.p[c][a] = zz[c] + add[c];
+    }
+}
+// stop test on rmax(it) ; beta = sig(it+1)/sig(it) ; p = z + beta p          (it = -1: p = z)
+__global__ __launch_bounds__(256) void k_bvpcg_p(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask, Vec3p z, Vec3p p, PcgScal sc, int it_arg) {
+    BrickWalk w;
+    w.begin(bricks, nb, mask);
+    if (*sc.conv >= 0) return;
+    const int it = d_bvmg_iter(sc, it_arg);
+    if (it >= sc.cap) return;
+    __shared__ double lds[8];
+    float beta = 0.0f;
+    if (it >= 0) {
+        if (d_vmg_stop_test(sc, it, lds)) return;
+        double f[4];
+        d_fold_sums(sc.sig(it + 1), sc.sig(it), nullptr, nullptr, f, lds);
+        beta = f[1] != 0.0 ? (float)(f[0] / f[1]) : 0.0f;
+    }
+    while (w.valid()) {
+        const size_t a = w.a;
+        const unsigned m = w.m;
+        w.next(bricks, nb, mask);
+        float zz[3], pp[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const bool on = (m >> c) & 1u;
+            zz[c] = on ? z.p[c][a] : 0.0f;
+            pp[c] = (on && it >= 0) ? p.p[c][a] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            if ((m >> c) & 1u) p.p[c][a] = zz[c] + beta * pp[c];
+    }
+    if (it_arg == IT_DEVICE && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.itA = it + 1;
 }
 
 // ---- the kernels that walk the solver's tile list: once per tile geometry (pcg_geo.inc)
@@ -720,21 +835,20 @@ struct VmgState {
     float *za[3] = {nullptr, nullptr, nullptr}, *zb[3] = {nullptr, nullptr, nullptr}, *t0[3] = {nullptr, nullptr, nullptr};   // level 0: the sweeps' two iterates, the residual
     std::vector<void *> allocs;
     std::vector<std::pair<void *, size_t>> vecBlocks;    // (base, bytes) of every level's vector storage, zeroed per solve
-    Box3 prevBox[16];            // per coarse level: the box whose coefficients the previous solve wrote (hi <= lo: none yet)
     int *d_box = nullptr;
     int *d_rowlist = nullptr, *d_rowcnt = nullptr, *d_stripCount = nullptr;   // coarsest level's rows; per level the number of listed strips
     VLevelDev *d_lev = nullptr;  // the level descriptors in device memory (this solve's boxes), h_lev their pinned staging copy
     VLevelDev *h_lev = nullptr;
     int tailFirst = 0;           // index into lev of the first level the tail kernel handles (this solve)
     bool ready = false;          // every allocation of vmg_alloc_state succeeded
-    long builtAt = -1;           // flipv_context::viscSolves when the coarse operators were last assembled (-1: never)
+    int minDim = 0;              // the coarsest level's longest axis the hierarchy was allocated for (flipv_params.viscosity_mg_min_dim)
     void *fineVecs = nullptr;    // the fine level's three sweep vectors (zeroed every solve; the coarse levels' only with a new hierarchy)
     size_t fineVecBytes = 0;
     ~VmgState() { for (void *p : allocs) (void)hipFree(p); if (h_lev) (void)hipHostFree(h_lev); }
 };
 
-static int vmg_alloc(flipv_context *c, VmgState *s, const Lay &L, size_t count, float **base) {
-    const size_t tot = (L.n + 2 * L.guard) * count;
+static int vmg_alloc(flipv_context *c, VmgState *s, size_t per, size_t count, float **base) {
+    const size_t tot = per * count;
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, tot * sizeof(float));
     if (e != hipSuccess) { c->err = std::string("hipMalloc(viscosity multigrid): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
@@ -757,8 +871,6 @@ static VLevelDev dev_of(const VLevel &l) {
 }
 static long box_positions(const Box3 &b) { return (long)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); }
 
-#define BGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
-
 }  // namespace
 
 void fv_vmg_free(flipv_context *c) {
@@ -766,18 +878,24 @@ void fv_vmg_free(flipv_context *c) {
     c->vmgState = nullptr;
 }
 
-// the level structure and its storage (once per context)
+static int vmg_min_dim(const flipv_context *c) { return c->prm.viscosity_mg_min_dim > 0 ? c->prm.viscosity_mg_min_dim : VMG_MIN_DIM; }
+
+// the level structure and its storage (once per context; again if flipv_params.viscosity_mg_min_dim changes)
 static int vmg_alloc_state(flipv_context *c) {
     VmgState *s = (VmgState *)c->vmgState;
     int rc;
-    if (s && !s->ready) { fv_vmg_free(c); s = nullptr; }   // an earlier attempt ran out of memory half way: start over
+    if (s && (!s->ready || s->minDim != vmg_min_dim(c))) {   // an earlier attempt ran out of memory half way, or another depth is asked for: start over
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        fv_vmg_free(c);
+        s = nullptr;
+    }
     if (!s) {
         SlotTables T;
         build_slot_tables(&T);
         HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(ST), &T, sizeof(T)));
         s = new VmgState();
         c->vmgState = s;
-        for (auto &b : s->prevBox) { b.lo[0] = b.lo[1] = b.lo[2] = 0; b.hi[0] = b.hi[1] = b.hi[2] = 0; }
+        s->minDim = vmg_min_dim(c);
         HIPCHK(c, hipMalloc((void **)&s->d_box, 8 * sizeof(int)));
         s->allocs.push_back(s->d_box);
         HIPCHK(c, hipMalloc((void **)&s->d_rowlist, (3 * 1024 + 4 + VMG_MAX_LEVELS) * sizeof(int)));
@@ -788,8 +906,8 @@ static int vmg_alloc_state(flipv_context *c) {
         s->allocs.push_back(s->d_lev);
         HIPCHK(c, hipHostMalloc((void **)&s->h_lev, VMG_MAX_LEVELS * sizeof(VLevelDev)));
         float *base;
-        if ((rc = vmg_alloc(c, s, c->L, 9, &base))) return rc;
-        const size_t per0 = c->L.n + 2 * c->L.guard;
+        const size_t per0 = c->L.guard + c->solverCap + c->L.guard;   // room for either layout of level 0
+        if ((rc = vmg_alloc(c, s, per0, 9, &base))) return rc;
         s->fineVecs = base; s->fineVecBytes = 9 * per0 * sizeof(float);
         for (int m = 0; m < 3; m++) {
             s->za[m] = base + (size_t)m * per0 + c->L.guard;
@@ -799,13 +917,12 @@ static int vmg_alloc_state(flipv_context *c) {
         Lay F = c->L;
         while (true) {
             const int mx = F.I > F.J ? (F.I > F.K ? F.I : F.K) : (F.J > F.K ? F.J : F.K);
-            static const int minDim = getenv("FLIPV_VMG_MINDIM") ? atoi(getenv("FLIPV_VMG_MINDIM")) : VMG_MIN_DIM;
-            if (mx <= minDim || (int)s->lev.size() >= VMG_MAX_LEVELS) break;
+            if (mx <= s->minDim || (int)s->lev.size() >= VMG_MAX_LEVELS) break;
             VLevel l;
             l.L = coarse_lay(F);
             const size_t per = l.L.n + 2 * l.L.guard;
             float *cb, *vb;
-            if ((rc = vmg_alloc(c, s, l.L, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, l.L, 12, &vb))) return rc;
+            if ((rc = vmg_alloc(c, s, per, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, per, 12, &vb))) return rc;
             s->vecBlocks.push_back({vb, per * 12 * sizeof(float)});
             {
                 const size_t nstr = l.L.n / 64;   // bricks of the level
@@ -827,28 +944,24 @@ static int vmg_alloc_state(flipv_context *c) {
     }
     return FLIPV_OK;
 }
-// Allocate the hierarchy ahead of its first use (flipv_params.viscosity_preconditioner = AUTO: the first multigrid solve comes some
-// substeps into a run; the allocation -- 1.3 GB at 256^3 -- and its memsets then do not land in that substep)
+// Allocate the hierarchy ahead of its first use (the allocation -- 1.3 GB at 256^3 -- and its memsets then do not land in a timed substep)
 int fv_vmg_prepare(flipv_context *c) { return vmg_alloc_state(c); }
+
+static bool vmg_brick(const flipv_context *c) { return c->vLayout == VLAYOUT_BRICK; }
 
 static int vmg_setup(flipv_context *c, VmgState **out) {
     int rc = vmg_alloc_state(c);
     if (rc) return rc;
     VmgState *s = (VmgState *)c->vmgState;
+    const bool brick = vmg_brick(c);
     // the fine level's sweep vectors must be zero wherever there is no row (the SpMV and the restriction read neighbours unmasked)
     HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
-    // The coarse operators may serve several consecutive solves (FLIPV_VMG_KEEP, default VMG_KEEP): between substeps the liquid moves by
-    // a fraction of a coarse cell, a preconditioner only has to be symmetric positive definite and the same throughout one solve,
-    // and the fine level -- matrix-free -- is always this solve's operator.  A kept hierarchy costs nothing per solve (its vectors
-    // are rewritten by every cycle wherever its rows are and stay zero elsewhere); assembling one costs ~2.5 ms at 256^3.
-    static const int keep = getenv("FLIPV_VMG_KEEP") ? atoi(getenv("FLIPV_VMG_KEEP")) : VMG_KEEP;
-    if (s->builtAt >= 0 && c->viscSolves - s->builtAt < (long)keep) { *out = s; return FLIPV_OK; }
-    s->builtAt = c->viscSolves;
-    // ---- a new hierarchy: the box of the rows, level by level
+    // ---- a new hierarchy for every solve (a kept one over-corrects after a change of dt): the box of the rows, level by level
     {
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)s->d_box, 0x7fffffff, 3, c->stream));
         HIPCHK(c, hipMemsetAsync(s->d_box + 3, 0, 3 * sizeof(int), c->stream));
-        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_tile_bbox, dim3(64), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, s->d_box));
+        if (brick) hipLaunchKernelGGL(k_bvmg_bbox, dim3(64), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->LB, s->d_box);
+        else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_tile_bbox, dim3(64), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, s->d_box));
         int hb[6];
         HIPCHK(c, hipMemcpyAsync(hb, s->d_box, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -872,37 +985,21 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     }
     for (auto &b : s->vecBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));   // the coarse levels' vectors: zero off their rows
     // this solve's coarse operators, level by level, as gathers that write every entry of the level's box (rows or not): nothing has to
-    // be zeroed first, and what lies outside the box is never looked at.  FLIPV_VMG_RAP_SCATTER=1: the scatter kernels with atomics
-    // instead (the cross-check: same operators up to the summation order), which need the boxes zeroed.
-    static const bool scatter = getenv("FLIPV_VMG_RAP_SCATTER") && atoi(getenv("FLIPV_VMG_RAP_SCATTER")) != 0;
-    if (scatter)
-        for (size_t l = 0; l < s->lev.size(); l++) {
-            VLevel &A = s->lev[l];
-            Box3 z = A.box;
-            const Box3 &pb = s->prevBox[l];
-            if (pb.hi[0] > pb.lo[0]) for (int a = 0; a < 3; a++) { if (pb.lo[a] < z.lo[a]) z.lo[a] = pb.lo[a]; if (pb.hi[a] > z.hi[a]) z.hi[a] = pb.hi[a]; }
-            ZeroSet Z;
-            Z.n = 3 * VS;
-            for (int m = 0; m < 3; m++) for (int q = 0; q < VS; q++) Z.p[m * VS + q] = A.coef[m][q];
-            hipLaunchKernelGGL(k_vmg_zero_box, BGRID(z), 0, c->stream, Z, A.L, z);
-            s->prevBox[l] = A.box;
-        }
+    // be zeroed first, and what lies outside the box is never looked at.  The rows' own volumes are those of the operator the solve
+    // applies: the exact one, or the reference's float-rounded one (vr*, k_viscosity.hip: d_ref_volume) -- the defect is a diagonal term
+    // and goes through the Galerkin product like the volume itself.
     if (!s->lev.empty()) {
         FineOp A;
         A.swz = c->vSwz;
-        A.vm[0] = c->vmU; A.vm[1] = c->vmV; A.vm[2] = c->vmW;
+        A.brick = brick ? 1 : 0;
+        A.LB = c->LB;
+        A.vm[0] = c->vOperatorExact ? c->vmU : c->vrU; A.vm[1] = c->vOperatorExact ? c->vmV : c->vrV; A.vm[2] = c->vOperatorExact ? c->vmW : c->vrW;
         A.fC = c->fC; A.fE[0] = c->fEU; A.fE[1] = c->fEV; A.fE[2] = c->fEW;
-        A.mask = c->vRowMask;
+        A.mask = brick ? c->vMaskB : c->vRowMask;
 #define CGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), 3u * (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
-        if (scatter) {
-            static const int rapGrid = getenv("FLIPV_VMG_RAPGRID") ? atoi(getenv("FLIPV_VMG_RAPGRID")) : 0;
-            const int nbRap = rapGrid > 0 ? ((c->nActiveV + 7) / 8 * 8 < rapGrid ? (c->nActiveV + 7) / 8 * 8 : rapGrid) : pcg_grid(c, c->nActiveV);
-            GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_rap_fine, dim3(nbRap), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, A, dev_of(s->lev[0])));
-        } else hipLaunchKernelGGL(k_vmg_rap_gather_fine, CGRID(s->lev[0].box), 0, c->stream, A, c->L, dev_of(s->lev[0]));
-        for (size_t l = 0; l + 1 < s->lev.size(); l++) {
-            if (scatter) hipLaunchKernelGGL(k_vmg_rap, BGRID(s->lev[l].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
-            else hipLaunchKernelGGL(k_vmg_rap_gather, CGRID(s->lev[l + 1].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
-        }
+        hipLaunchKernelGGL(k_vmg_rap_gather_fine, CGRID(s->lev[0].box), 0, c->stream, A, c->L, dev_of(s->lev[0]));
+        for (size_t l = 0; l + 1 < s->lev.size(); l++)
+            hipLaunchKernelGGL(k_vmg_rap_gather, CGRID(s->lev[l + 1].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
 #undef CGRID
     }
     // where the rows are on the levels that run as launches (strip lists) and on the coarsest one (row lists); then the level
@@ -928,11 +1025,9 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         }
         HIPCHK(c, hipMemcpyAsync(s->d_lev, s->h_lev, s->lev.size() * sizeof(VLevelDev), hipMemcpyHostToDevice, c->stream));
     }
-    if (getenv("FLIPV_VMG_DEBUG")) {
-        unsigned h[2];
+    if (c->prm.verbose) {
         (void)hipStreamSynchronize(c->stream);
-        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dropped), sizeof(h));
-        fprintf(stderr, "vmg dropped entries: out of range %u, no slot %u; levels %zu, tail from %d\n", h[0], h[1], s->lev.size(), s->tailFirst);
+        fprintf(stderr, "viscosity multigrid: %zu coarse levels, tail from %d, level 0 in the %s layout\n", s->lev.size(), s->tailFirst, brick ? "brick" : "plain");
         for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d), %d bricks\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2], s->lev[l].nstrips); }
     }
     HIPCHK(c, hipGetLastError());
@@ -943,7 +1038,8 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
 // z = M^-1 r (level 0) into zb, (r, z) into sig(it + sig_shift).  On entry za = omega r/d (k_vpcg_xr left it).
 // it_arg = IT_DEVICE: the device-side iteration counter (inside the replayed graph)
 static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_arg, int sig_shift) {
-    const int nb = pcg_grid(c, c->nActiveV);
+    const bool brick = vmg_brick(c);
+    const int nb = brick ? fv_brick_grid(c, c->nBricks, 2048) : pcg_grid(c, c->nActiveV);
     const dim3 blk(64, 4, 1);
     const int it_spmv = it_arg == IT_DEVICE ? -1 : it_arg;   // the SpMV kernel's spelling of "device-side counter"
     float *dg[3] = {c->vDiagU, c->vDiagV, c->vDiagW};
@@ -952,66 +1048,81 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
     if (!s->lev.empty()) {
         fv_visc_sweep_f32(c, s->zb, s->t0, 2, sc, it_spmv, VMG_OMEGA, 0);                   // t0 = r - A zb
         const int nl = (int)s->lev.size(), t0 = s->tailFirst;
-        const Lay &F0 = c->L;
+        const Lay F0 = brick ? c->LB : c->L;
+        const int fb = brick ? 1 : 0;
         const Vec3p ft0 = v3(s->t0);
-#define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), dim3(cdiv(s->lev[l_].nstrips > 0 ? s->lev[l_].nstrips : 1, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv)
+#define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), dim3(cdiv(s->lev[l_].nstrips > 0 ? s->lev[l_].nstrips : 1, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv, fb)
         for (int l = 0; l < t0; l++) {   // down
             STEP(OP_RESTRICT, l);
             STEP(OP_PRE2, l);
             STEP(OP_RESID, l);
         }
         {
-            static const int sweeps = getenv("FLIPV_VMG_SWEEPS") ? (atoi(getenv("FLIPV_VMG_SWEEPS")) + 1) / 2 * 2 : VMG_COARSEST_SWEEPS;
-            hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, sweeps, F0, ft0, conv);
+            const int sweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2 : VMG_COARSEST_SWEEPS;
+            hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, sweeps, F0, ft0, conv, fb);
         }
         for (int l = t0 - 1; l >= 0; l--) {   // up
-            static const int fuseFrom = getenv("FLIPV_VMG_FUSE_FROM") ? atoi(getenv("FLIPV_VMG_FUSE_FROM")) : 0;   // (A/B switch: levels below this index prolong and sweep in two launches)
-            if (l >= fuseFrom) STEP(OP_PROPOST, l);
-            else { STEP(OP_PROLONG, l); STEP(OP_POST1, l); }
+            STEP(OP_PROPOST, l);
             STEP(OP_POST2, l);
         }
 #undef STEP
-        GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
+        if (brick) hipLaunchKernelGGL(k_bvmg_prolong_fine, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, c->LB, s->lev[0].L, (const uint8_t *)c->vMaskB, v3(s->zb), v3(s->lev[0].x), sc, it_arg);
+        else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
                            c->vSwz, v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
     }
     fv_visc_sweep_f32(c, s->zb, s->za, 1, sc, it_spmv, VMG_OMEGA, 0);                       // post-sweeps: zb -> za -> zb
     fv_visc_sweep_f32(c, s->za, s->zb, 3, sc, it_spmv, VMG_OMEGA, sig_shift);
 }
 
-// PCG with the V-cycle as preconditioner.  On entry k_visc_setup has left r = rhs, x = 0, s (= p) = 0 and the tile list;
+// PCG with the V-cycle as preconditioner.  On entry k_visc_setup has left r = rhs, x = 0, s (= p) = 0 and the tile / brick list;
 // the scalars' slot blocks are zero.  spmv(it) computes q = A p with a(it) = p.q (it = -1: the device-side counter).
-int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*spmv)(flipv_context *, const PcgScal &, int), int *conv_out) {
-    VmgState *s = nullptr;
-    int rc = vmg_setup(c, &s);
+// replace_period > 0 (brick layout only): residual replacement every that many iterations (k_viscosity_brick.hip), right after the
+// x / r update and before the V-cycle that turns the (replaced) residual into z.
+// restart: the hierarchy of this solve exists already (iterative refinement after a stall: the same system, a new right-hand side in r)
+int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*spmv)(flipv_context *, const PcgScal &, int), int replace_period, int restart, int *conv_out) {
+    VmgState *s = (VmgState *)c->vmgState;
+    int rc = FLIPV_OK;
+    if (!restart || !s) rc = vmg_setup(c, &s);
+    else HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
     if (rc) return rc;
     PcgScal sc = sc_in;
     sc.noB = 1;   // this loop needs p.q only: the SpMV variant that does not read the residual
-    const int nb = pcg_grid(c, c->nActiveV);
+    const bool brick = vmg_brick(c);
+    const int nb = brick ? fv_brick_grid(c, c->nBricks, 2048) : pcg_grid(c, c->nActiveV);
     const dim3 blk(64, 4, 1);
     float *dg[3] = {c->vDiagU, c->vDiagV, c->vDiagW};
     float *x[3] = {(float *)c->vX[0], (float *)c->vX[1], (float *)c->vX[2]}, *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
     float *p[3] = {(float *)c->vS[0], (float *)c->vS[1], (float *)c->vS[2]}, *q[3] = {(float *)c->vZ[0], (float *)c->vZ[1], (float *)c->vZ[2]};
-#define XR(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), VMG_OMEGA, sc, it_))
-#define PP(it_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(s->zb), v3(p), sc, it_))
+    auto XR = [&](int it_) {
+        if (brick) hipLaunchKernelGGL(k_bvpcg_xr, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, (const uint8_t *)c->vMaskB, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), VMG_OMEGA, sc, it_);
+        else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), VMG_OMEGA, sc, it_));
+    };
+    auto PP = [&](int it_) {
+        if (brick) hipLaunchKernelGGL(k_bvpcg_p, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, (const uint8_t *)c->vMaskB, v3(s->zb), v3(p), sc, it_);
+        else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(s->zb), v3(p), sc, it_));
+    };
+    if (!brick) replace_period = 0;
     HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
     XR(-1);                       // za = omega r/d
     vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)
     PP(-1);                       // p = z
-    static const int everyEnv = getenv("FLIPV_VMG_EVERY") ? atoi(getenv("FLIPV_VMG_EVERY")) : 0;
-    const int every = c->prm.check_every > 0 ? c->prm.check_every : (everyEnv > 0 ? everyEnv : 8);
+    const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
     int conv = -1;
-    auto iteration = [&](int it) {   // it = IT_DEVICE inside the graph
+    auto iteration = [&](int it, bool replace) {   // it = IT_DEVICE inside the graph
         spmv(c, sc, it == IT_DEVICE ? -1 : it);
         XR(it);
+        if (replace) fv_brick_replace<float>(c, sc, it == IT_DEVICE ? -1 : it, replace_period, 0, s->za, VMG_OMEGA);
         vmg_vcycle(c, s, sc, it, 1);
         PP(it);
     };
+    // where in a chunk of `every` iterations a replacement can fall due (the kernels decide exactly, from the iteration number)
+    auto may_replace = [&](int e) { return replace_period > 0 && ((e + 1) % (replace_period < every ? replace_period : every)) == 0; };
     const bool graph = !c->prm.kernel_timing && !c->prm.no_graph_replay;
     if (graph) {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int e = 0; e < every; e++) iteration(IT_DEVICE);
+        for (int e = 0; e < every; e++) iteration(IT_DEVICE, may_replace(e));
         hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
         if (e1 != hipSuccess || e2 != hipSuccess || !g) {
@@ -1031,14 +1142,12 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         int it = 0;
         while (it < cap && conv < 0) {
             const int stop = it + every < cap ? it + every : cap;
-            for (; it < stop; it++) iteration(it);
+            for (; it < stop; it++) iteration(it, may_replace(it % every));
             HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             conv = c->h_flags[0];
         }
     }
-#undef XR
-#undef PP
     HIPCHK(c, hipGetLastError());
     *conv_out = conv;
     return FLIPV_OK;

@@ -100,6 +100,8 @@ struct PcgScal {
     // update kernel stops the solve (sets *stalled and the stop flag): the iterate of that moment is returned as "not converged".
     double *best;   // nullptr: no guard
     int *stalled;
+    double stall_below;   // the guard arms once *best <= this; 0 = 100 x tol.  (A loop restarted close to its tolerance -- iterative refinement --
+                          // sets it to a fraction of the restart's residual: the first iterations of CG overshoot it in the max norm.)
     // device-side iteration counters for hipGraph replay (kernels launched with it_arg = -1): the SpMV reads itA and
     // publishes it in itB, the update reads itB and stores itB+1 in itA -- a kernel never reads a counter that is
     // written inside the same launch, so late-starting blocks cannot see a half-advanced iteration.
@@ -291,9 +293,8 @@ int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, boo
 // An executable for the freshly captured graph g: the slot's cached executable updated in place when the topology still matches,
 // a newly instantiated one otherwise (which then takes the slot).  The caller launches *ge and destroys g, never *ge.
 static int fv_graph_exec(flipv_context *c, int slot, hipGraph_t g, hipGraphExec_t *ge) {
-    static const bool reuse = !(getenv("FLIPV_GRAPH_REUSE") && atoi(getenv("FLIPV_GRAPH_REUSE")) == 0);
     hipGraphExec_t &cached = c->geCache[slot];
-    if (cached && reuse) {
+    if (cached) {
         hipGraphNode_t bad = nullptr;
         hipGraphExecUpdateResult res;
         if (hipGraphExecUpdate(cached, g, &bad, &res) == hipSuccess) { *ge = cached; return FLIPV_OK; }
@@ -319,16 +320,21 @@ static int fv_graph_exec(flipv_context *c, int slot, hipGraph_t g, hipGraphExec_
 //   c->stream:             K1 over the tiles of the interior planes  |  wait for the halo  |  K1 over the tiles of the
 //                          two boundary planes  |  ONE all-reduce [rmax(it-1) sig(it) a b c(it)]  |  K2
 // so the exchange hides behind the interior SpMV and the only exposed communication is one 1.3 KB all-reduce.
-template <class Spmv, class Update>
+//   post(it)                (optional, period `postPeriod` > 0) enqueues work after the update of every iteration whose number + 1 is a
+//                           multiple of postPeriod -- residual replacement (k_viscosity_brick.hip).  The kernels re-test that condition
+//                           themselves from the iteration number; the host only has to launch them wherever it can hold.
+struct PcgNoPost { void operator()(int) const {} };
+template <class Spmv, class Update, class Post = PcgNoPost>
 static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray *sh, int nsh, int nInt, int nAct, Spmv spmv,
-                   Update update, int *conv_out, int geSlot) {
+                   Update update, int *conv_out, int geSlot, Post post = Post(), int postPeriod = 0) {
     // poll interval: an iteration after the stop costs two empty launches (~6 us) on one GPU but a halo exchange and an
     // all-reduce in a multi-rank run; a poll costs a read-back and a host wake-up (~14 us)
     const int every = c->prm.check_every > 0 ? c->prm.check_every : (c->comm ? 8 : 32);
     int conv = -1, rc;
-    auto launch_iter = [&](int it) -> int {
+    auto post_due = [&](int e) { return postPeriod > 0 && ((e + 1) % (postPeriod < every ? postPeriod : every)) == 0; };   // e: position inside a chunk of `every`
+    auto launch_iter = [&](int it, int e) -> int {
         int r;
-        if (!c->comm) { spmv(0, nAct, it); update(it); return FLIPV_OK; }
+        if (!c->comm) { spmv(0, nAct, it); update(it); if (post_due(e)) post(it); return FLIPV_OK; }
         if ((r = fv_halo_copy_begin(c, sh, nsh, 1))) return r;
         if (nInt > 0) spmv(0, nInt, it);
         if ((r = fv_halo_wait(c))) return r;
@@ -345,7 +351,7 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         hipGraphExec_t ge = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         rc = FLIPV_OK;
-        for (int e = 0; e < every && rc == FLIPV_OK; e++) rc = launch_iter(-1);
+        for (int e = 0; e < every && rc == FLIPV_OK; e++) rc = launch_iter(-1, e);
         hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
         if (rc != FLIPV_OK || e1 != hipSuccess || e2 != hipSuccess || !g) {
@@ -388,7 +394,7 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
             while (it < cap && conv < 0) {
                 const int stop = (it + every < cap) ? it + every : cap;
                 for (; it < stop; it++)
-                    if ((rc = launch_iter(it))) return rc;
+                    if ((rc = launch_iter(it, it % every))) return rc;
                 // (the stop is recorded by the update kernel of the NEXT iteration -- in a multi-rank run after the all-reduce
                 // that merges the partial maxima -- so a solve that converges on a chunk's last iteration is seen one poll later)
                 HIPCHK(c, hipMemcpyAsync(c->h_flags + 8 + slot, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -1,0 +1,103 @@
+// visc_rows.h -- the U, V and W rows of the variational viscosity operator at one lane's NV consecutive indices, in DIFFERENCE form
+// (viscositysolver.cpp:394-446 and the V / W analogues; signs: SURVEY.md A.6b).  Shared by the tile kernels (k_viscosity_geo.inc:
+// NV = 2 or 4, i-neighbours by lane shift) and the brick kernels (k_viscosity_brick.hip: NV = 1, every neighbour a load).
+#pragma once
+#include "pcg_common.h"
+
+#define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
+#define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
+// The U, V and W rows of a lane's NV indices (difference form, see above) and this lane's share of the three dot products.
+// Inputs: own volumes M*, the factor vectors at the index and its j/k neighbours, x at the index and its j/k neighbours,
+// the residual (RDOT), and the i-neighbour scalars across the lane boundary (suffix l / r).
+// EPI (the multigrid preconditioner's fine-level sweeps, k_viscosity_mg.hip; x = the sweep's input vector, R = the residual r):
+//   0  y = A x and the three dot products (the PCG SpMV)
+//   1  y = x + omega (r - A x)/d            one damped-Jacobi sweep
+//   2  y = r - A x                          the residual that is restricted to the first coarse level
+//   3  as 1, and ta = this lane's share of (r, y)
+constexpr int EPI_SPMV = 0, EPI_JACOBI = 1, EPI_RESIDUAL = 2, EPI_JACOBI_DOT = 3;
+template <typename T, int NV, bool RDOT, int EPI = EPI_SPMV>
+__device__ __forceinline__ void d_visc_rows(
+    const Vec<float, NV> &MU, const Vec<float, NV> &MV, const Vec<float, NV> &MW, const Vec<float, NV> &C0, const Vec<float, NV> &Cjm,
+    const Vec<float, NV> &Ckm, const Vec<float, NV> &EW0, const Vec<float, NV> &EWjp, const Vec<float, NV> &EV0, const Vec<float, NV> &EVkp,
+    const Vec<float, NV> &EU0, const Vec<float, NV> &EUjp, const Vec<float, NV> &EUkp, const Vec<T, NV> &U0, const Vec<T, NV> &Ujm,
+    const Vec<T, NV> &Ujp, const Vec<T, NV> &Ukm, const Vec<T, NV> &Ukp, const Vec<T, NV> &V0, const Vec<T, NV> &Vjm, const Vec<T, NV> &Vjp,
+    const Vec<T, NV> &Vkm, const Vec<T, NV> &Vkp, const Vec<T, NV> &W0, const Vec<T, NV> &Wjm, const Vec<T, NV> &Wjp, const Vec<T, NV> &Wkm,
+    const Vec<T, NV> &Wkp, const Vec<T, NV> &Vjpkm, const Vec<T, NV> &Wjmkp, const Vec<RT<T>, NV> &RU, const Vec<RT<T>, NV> &RV,
+    const Vec<RT<T>, NV> &RW, float C0l, float EW0r, float EV0r, T U0l, T U0r, T V0l, T V0r, T W0l, T W0r, T Vjpl, T Wkpl, T Ujmr, T Ukmr,
+    Vec<T, NV> &yU, Vec<T, NV> &yV, Vec<T, NV> &yW, T &ta, T &tb, T &tc, T omega = (T)0) {
+#pragma clang fp contract(fast)
+    // the three dot products: this lane's <= 3 NV rows are summed in the vector precision, then folded into the fp64
+    // accumulators once per tile (12 fp32 FMAs instead of ~100 fp64 operations per tile and lane; every sum across
+    // lanes, tiles and blocks stays fp64)
+#pragma unroll
+    for (int e = 0; e < NV; e++) {
+        const T uc = U0.v[e], vc = V0.v[e], wc = W0.v[e];
+        const T ur = RSH(U0, U0r, e), ul = LSH(U0, U0l, e);
+        const T vr = RSH(V0, V0r, e), vl = LSH(V0, V0l, e);
+        const T wr = RSH(W0, W0r, e), wl = LSH(W0, W0l, e);
+        {   // U row
+            const float fR = C0.v[e], fL = LSH(C0, C0l, e), fT = EWjp.v[e], fB = EW0.v[e], fF = EVkp.v[e], fK = EV0.v[e];
+            T y = (T)0;
+            if (MU.v[e] > -0.5f) {
+                const T txx = (T)fR * (ur - uc) - (T)fL * (uc - ul);
+                const T txy = (T)fT * ((Ujp.v[e] - uc) + (Vjp.v[e] - LSH(Vjp, Vjpl, e))) - (T)fB * ((uc - Ujm.v[e]) + (vc - vl));
+                const T txz = (T)fF * ((Ukp.v[e] - uc) + (Wkp.v[e] - LSH(Wkp, Wkpl, e))) - (T)fK * ((uc - Ukm.v[e]) + (wc - wl));
+                y = (T)MU.v[e] * uc - txx - txy - txz;
+                const float dg = MU.v[e] + fR + fL + fT + fB + fF + fK;  // same order as k_visc_setup
+                if (EPI == EPI_SPMV) {
+                    const T yi = y * d_recip<T>(dg);
+                    ta += uc * y; if (RDOT) tb += (T)RU.v[e] * yi; tc += y * yi;
+                } else if (EPI == EPI_RESIDUAL) {
+                    y = (T)RU.v[e] - y;
+                } else {
+                    y = uc + omega * ((T)RU.v[e] - y) * d_recip<T>(dg);
+                    if (EPI == EPI_JACOBI_DOT) ta += (T)RU.v[e] * y;
+                }
+            }
+            yU.v[e] = y;
+        }
+        {   // V row
+            const float fR = RSH(EW0, EW0r, e), fL = EW0.v[e], fT = C0.v[e], fB = Cjm.v[e], fF = EUkp.v[e], fK = EU0.v[e];
+            T y = (T)0;
+            if (MV.v[e] > -0.5f) {
+                const T tyy = (T)fT * (Vjp.v[e] - vc) - (T)fB * (vc - Vjm.v[e]);
+                const T txy = (T)fR * ((vr - vc) + (ur - RSH(Ujm, Ujmr, e))) - (T)fL * ((vc - vl) + (uc - Ujm.v[e]));
+                const T tyz = (T)fF * ((Vkp.v[e] - vc) + (Wkp.v[e] - Wjmkp.v[e])) - (T)fK * ((vc - Vkm.v[e]) + (wc - Wjm.v[e]));
+                y = (T)MV.v[e] * vc - tyy - txy - tyz;
+                const float dg = MV.v[e] + fR + fL + fT + fB + fF + fK;
+                if (EPI == EPI_SPMV) {
+                    const T yi = y * d_recip<T>(dg);
+                    ta += vc * y; if (RDOT) tb += (T)RV.v[e] * yi; tc += y * yi;
+                } else if (EPI == EPI_RESIDUAL) {
+                    y = (T)RV.v[e] - y;
+                } else {
+                    y = vc + omega * ((T)RV.v[e] - y) * d_recip<T>(dg);
+                    if (EPI == EPI_JACOBI_DOT) ta += (T)RV.v[e] * y;
+                }
+            }
+            yV.v[e] = y;
+        }
+        {   // W row
+            const float fR = RSH(EV0, EV0r, e), fL = EV0.v[e], fT = EUjp.v[e], fB = EU0.v[e], fF = C0.v[e], fK = Ckm.v[e];
+            T y = (T)0;
+            if (MW.v[e] > -0.5f) {
+                const T tzz = (T)fF * (Wkp.v[e] - wc) - (T)fK * (wc - Wkm.v[e]);
+                const T txz = (T)fR * ((wr - wc) + (ur - RSH(Ukm, Ukmr, e))) - (T)fL * ((wc - wl) + (uc - Ukm.v[e]));
+                const T tyz = (T)fT * ((Wjp.v[e] - wc) + (Vjp.v[e] - Vjpkm.v[e])) - (T)fB * ((wc - Wjm.v[e]) + (vc - Vkm.v[e]));
+                y = (T)MW.v[e] * wc - tzz - txz - tyz;
+                const float dg = MW.v[e] + fR + fL + fT + fB + fF + fK;
+                if (EPI == EPI_SPMV) {
+                    const T yi = y * d_recip<T>(dg);
+                    ta += wc * y; if (RDOT) tb += (T)RW.v[e] * yi; tc += y * yi;
+                } else if (EPI == EPI_RESIDUAL) {
+                    y = (T)RW.v[e] - y;
+                } else {
+                    y = wc + omega * ((T)RW.v[e] - y) * d_recip<T>(dg);
+                    if (EPI == EPI_JACOBI_DOT) ta += (T)RW.v[e] * y;
+                }
+            }
+            yW.v[e] = y;
+        }
+    }
+}
+

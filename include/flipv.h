@@ -18,10 +18,7 @@
  *    Nothing throws or aborts across this ABI.
  *  - One context per host thread; contexts are independent (one HIP stream each).
  *  - There is NO CPU fallback: without a HIP device flipv_create() fails with FLIPV_ERR_NO_DEVICE.
- *  - Environment (read by flipv_create, measurement / test switches only; results do not depend on them beyond
- *    solver tolerance):  FLIPV_ROWL=16|64 pins the solver tile geometry (default: chosen per solve from the tile
- *    fill);  FLIPV_SWZ=0 keeps every solver array in the plain plane layout;  FLIPV_LIQBOX=0 makes every sweep of a substep cover
- *    the whole box instead of the neighbourhood of the liquid.
+ *  - The library reads NO environment variables: every switch that changes what a solve does is a field of flipv_params.
  */
 #ifndef FLIPV_H
 #define FLIPV_H
@@ -33,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLIPV_VERSION 2   /* 2: the measurement switches of flipv_params are named fields; block contexts */
+#define FLIPV_VERSION 3   /* 3: every behavioural switch is a flipv_params field (no environment variables); brick layout; residual replacement */
 
 typedef struct flipv_context flipv_context;
 
@@ -90,37 +87,58 @@ typedef struct flipv_params {
     int pressure_preconditioner; /* AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
     int viscosity_preconditioner;/* DIAGONAL; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors, one rank, whole-domain context; other
                                     solves fall back to the diagonal and say so in flipv_solve_info.preconditioner): 15-250 iterations
-                                    where the diagonal needs 200-4 000.  AUTO (default) = per solve whichever of the two the PREVIOUS
-                                    solve's iteration count predicts to be cheaper (k_viscosity.hip: fv_visc_auto_pick): the diagonal,
-                                    stopped at the cap like the reference's solve, while the system is so stiff that the multigrid
-                                    would need more than ~80 iterations; the multigrid, converging, otherwise (256^3 bunny drop, 150
-                                    substeps: 23.2 ms per substep against 32.6 with the diagonal alone).  Decisions use iteration
-                                    counts only, never timings */
-    /* measurement / test switches, all 0 by default; results do not depend on them beyond solver tolerance */
+                                    where the diagonal needs 200-4 000.  AUTO (default) = the multigrid unless the previous solve shows
+                                    that the diagonal CONVERGES for less (k_viscosity.hip: fv_visc_auto_pick); a diagonal solve AUTO
+                                    picked that runs into the cap is repeated with the multigrid, so a default run never returns an
+                                    iterate stopped at the cap where a converged one is affordable.  Decisions use iteration counts only,
+                                    never timings; every path converges to the same tolerance, so the history of a context changes the
+                                    cost of a solve, not its answer beyond solver tolerance.  Contexts on which the multigrid is not
+                                    available (block contexts / communicators, fp64 vectors) run the diagonal, stopped at the cap like the
+                                    reference's solve */
+    /* ---- every field below: 0 = the default behaviour (a zero-initialised tail is a valid default configuration) ---- */
+    int exact_viscosity_operator;/* 0 (default): the viscosity solve applies the REFERENCE's operator, including the rounding of its float
+                                    diagonal (the reference sums vol + fR + fL + fT + fB + fF + fK in float, viscositysolver.cpp:394-446;
+                                    the defect is folded into the row's own volume, no extra bytes).  Matters where nu dt/dx^2 is large: at
+                                    256^3 (3 300) the reference's converged velocities are 7e-6 from this operator's and 1.5e-4 from the
+                                    exact one's.  1: the exact operator vol u - div(tau) (better conditioned; what rounds differently is the
+                                    reference).   */
+    int residual_replacement;    /* n > 0 (fp32 vectors in the brick layout): every n iterations the solution accumulated so far is flushed into an
+                                    fp64 accumulator and the recurrence residual is REPLACED by b - A x evaluated in fp64 (group-wise update, van
+                                    der Vorst & Ye; two extra launches per n iterations), so that the stop test sees the true residual.  0
+                                    (default) = off: measured here, an fp32 x drifts from its recurrence residual by ~3e-5 max|b| within 15
+                                    iterations (rounding of x += alpha s times a diagonal of nu dt/dx^2 ~ 1e3), far above the 1e-6 the recurrence
+                                    reaches, so a periodic replacement restarts CG with a stale direction again and again (38 -> 421 iterations
+                                    on the 20^3 fixture); the drift sits in rough modes and changes the velocities by 1e-8.  Kept for studies */
+    int viscosity_layout;        /* layout of the viscosity solver's arrays: 0 = chosen per solve (bricks of 8 x 4 x 2 indices on sparse
+                                    liquids of a single-domain context, plain planes otherwise), 1 = plain planes, 2 = plain planes with the
+                                    own-index arrays in 8 x 4 patches under the 16-lane tile geometry (the pre-brick default), 3 = bricks
+                                    wherever they are available */
+    int tile_rows;               /* 16 | 64: pins the tile geometry of the plane-layout kernels (lanes of a wave along i); 0 = chosen per
+                                    solve from how full the tiles are */
+    int viscosity_mg_coarsest_sweeps; /* Jacobi sweeps on the LDS-resident coarsest level of the viscosity multigrid; 0 = 16 */
+    int viscosity_mg_min_dim;    /* the viscosity hierarchy stops at the level whose longest axis is <= this many cells; 0 = 16 */
+    int pressure_mg_coarsest_sweeps; /* 0 = 8 */
+    float pressure_mg_omega;     /* damping of the pressure multigrid's Jacobi sweeps; 0 = 0.9 */
+    float pressure_mg_overcorrection; /* scaling of its coarse-grid correction; 0 = 1.8 */
+    int no_liquid_box;           /* 1: every sweep of a substep covers the whole box instead of the neighbourhood of the liquid (A/B, tests) */
+    int no_comm_overlap;         /* 1: the halo exchange of the PCG search direction does not overlap the interior SpMV */
+    int verbose;                 /* 1: one line per viscosity solve and the multigrid's level table on stderr */
+    /* measurement / test switches; results do not depend on them beyond solver tolerance */
     int no_graph_replay;         /* 1: the PCG loop is launched kernel by kernel instead of replayed as a hipGraph */
     int unbinned_scatter;        /* 1: particle scatters with global atomics instead of LDS tiles (A/B) */
     int grid_cap;                /* n>0: cap of the PCG kernels' grids in blocks (tests: every block walks many tiles) */
-    int viscosity_lane_width;    /* 2|4: forced lane width of the viscosity solver kernels */
+    int viscosity_lane_width;    /* 2|4: forced lane width of the viscosity tile kernels (2 excludes the brick layout and the multigrid) */
     int viscosity_spmv_grid_cap; /* n>0: grid cap of the viscosity SpMV kernel alone */
     int viscosity_update_grid_cap; /* n>0: grid cap of the viscosity init/update kernels */
-    int beta_from_residual;      /* 1 (default): the PCG's beta = (sigma - 2 alpha (r/d,q) + alpha^2 (q,q/d))/sigma, with the residual
-                                    read by the SpMV for (r/d,q) (+12 B per index, +4 B per pressure cell).  0: (r/d,q) is
+    int beta_from_conjugacy;     /* 0 (default): the PCG's beta = (sigma - 2 alpha (r/d,q) + alpha^2 (q,q/d))/sigma, with the residual
+                                    read by the SpMV for (r/d,q) (+12 B per index, +4 B per pressure cell).  1: (r/d,q) is
                                     replaced by (s,q), which is equal in exact arithmetic (successive search directions are
                                     A-conjugate) and lets the SpMV skip the residual: 5-7 % faster per iteration, but on
                                     ill-conditioned systems (nu dt/dx^2 ~ 2e3: the rod + sheet scene at nu = 50) the fp32
-                                    solve stagnates, so it is an opt-in.  sigma itself is recomputed from the stored vectors
-                                    every iteration either way. */
+                                    solve stagnates.  sigma itself is recomputed from the stored vectors every iteration either way. */
     int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 (default) =
                                     chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
-    int reference_diagonal;      /* 1: the diagonally preconditioned viscosity solve applies the reference's operator INCLUDING the
-                                    rounding of its float diagonal (the reference sums vol + fR + fL + fT + fB + fF + fK in float,
-                                    viscositysolver.cpp:394-446; the defect is folded into the row's own volume, no extra bytes).
-                                    Matters where nu dt/dx^2 is large: at 256^3 (3 300) the reference's converged velocities differ
-                                    from the exact operator's by 1.5e-4 and from this mode's by 7e-6.  0 (default): the exact operator --
-                                    the rounded one is worse conditioned (the reference's own PCG needs 42 000 iterations for 1e-8
-                                    there), fp32 solves stall at tight tolerances.  The multigrid-preconditioned solve always
-                                    applies the exact operator.  Environment FLIPV_REF_DIAG=0|1 overrides.   */
-    int reserved[1];             /* must be 0 */
+    int reserved[4];             /* must be 0 */
 } flipv_params;
 
 typedef struct flipv_solve_info {
@@ -132,7 +150,11 @@ typedef struct flipv_solve_info {
     int active_tiles;    /* tiles swept per launch */
     int total_tiles;
     int preconditioner;  /* 0 diagonal, 1 multigrid (pressure: aggregation V-cycle with fp32 vectors, rank-local under blocks; viscosity:
-                            the opt-in Galerkin V-cycle) */
+                            the Galerkin V-cycle) */
+    int layout;          /* viscosity: layout of the solver's arrays in this solve, 0 plain planes, 1 plain + swizzled own-index arrays, 2 bricks
+                            (active_tiles / total_tiles then count bricks of 8 x 4 x 2 indices) */
+    int refinements;     /* viscosity, fp32 vectors in the brick layout: how often the solve was continued on the correction equation after a stall
+                            (x flushed into an fp64 accumulator, r = b - A x evaluated in fp64, PCG restarted); `iterations` counts all rounds */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */
@@ -290,8 +312,8 @@ int flipv_comm_get_unique_id(void *id_out);
 int flipv_comm_init_rccl(flipv_context *ctx, const void *unique_id, int rank, int nranks);   /* slabs along k: grid {1, 1, nranks} */
 int flipv_comm_init_local(flipv_context **ctxs, int nranks);
 /* process grid dims[3] (ranks along i, j, k), rank = x + dims[0] * (y + dims[1] * z); the context's block must sit at that place
- * of the grid.  Halo copies run axis by axis (x, y, z) so that edge and corner regions are filled; halo reductions the other
- * way round; particles migrate axis by axis to the adjacent ranks. */
+ * of the grid.  Halo copies and reductions are exchanged DIRECTLY with the <= 26 neighbouring blocks (faces, edges and corners: one pack
+ * kernel, one group of sends / receives, one unpack kernel per exchange); particles migrate axis by axis (x, y, z) to the adjacent ranks. */
 int flipv_comm_init_rccl_grid(flipv_context *ctx, const void *unique_id, int rank, const int *dims);
 int flipv_comm_init_local_grid(flipv_context **ctxs, const int *dims);
 int flipv_comm_finalize(flipv_context *ctx);

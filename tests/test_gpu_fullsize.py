@@ -66,8 +66,13 @@ def test_fullsize_projection_is_divergence_free(scene, precision):
     c = ctx(scene, precision=precision, pressure_rel_tolerance=1e-6 if precision == 0 else 0.0)
     st = c.substep(0.01)
     assert st["pressure"]["status"] == 0
-    # the reference accepts the capped, unconverged viscosity solve when the residual is below 10 (viscositysolver.cpp:676-689)
-    assert st["viscosity"]["iterations"] == 700 and st["viscosity"]["status"] == 1 and st["viscosity"]["residual"] < 10.0
+    # the default viscosity solve converges inside the reference's cap (fp32: the multigrid-preconditioned loop; fp64 vectors run the
+    # diagonal, which stops at the cap and is accepted because the residual is below 10, viscositysolver.cpp:676-689)
+    v = st["viscosity"]
+    if precision == 0:
+        assert v["status"] == 0 and v["preconditioner"] == 1 and v["iterations"] < 700, v
+    else:
+        assert v["iterations"] == 700 and v["status"] == 1 and v["residual"] < 10.0, v
     U, V, W = (c.grid(n).astype(np.float64) for n in "UVW")
     wU, wV, wW = (c.grid("WEIGHT_" + n).astype(np.float64) for n in "UVW")
     phi = c.grid("LIQUID_PHI")
@@ -112,10 +117,10 @@ def test_fullsize_precisions_agree_on_pressure_only_step(scene):
 
 
 def test_auto_preconditioner_over_the_drop_and_splash(scene):
-    """70 substeps of the bench scene with the default (AUTO) viscosity preconditioner: the stiff start runs the capped diagonal solve,
-    then the multigrid takes over -- with diagonal interludes while the liquid keeps moving, i.e. every multigrid solve assembles its
-    hierarchy next to the leftovers of one assembled several cells away.  Every multigrid solve must converge, and in the number of
-    iterations a clean hierarchy needs (33-64 on this stretch).  (A Galerkin gather that read children outside the finer level's
+    """70 substeps of the bench scene with the default (AUTO) viscosity preconditioner: the multigrid from the first solve on, the
+    liquid moving all the while, i.e. every solve assembles its hierarchy next to the leftovers of one assembled several cells away.
+    EVERY solve of a default run must converge (status 0), and in the number of iterations a clean hierarchy needs (<= 200 in the stiff
+    start, 33-64 once the liquid moves).  (A Galerkin gather that read children outside the finer level's
     current box -- another solve's rows -- went from 63 to 326 iterations at substep 50 of `tools/soak.py 256 150 auto` and into the
     diagonal fallback a few substeps later; that failure depends on exactly when AUTO switches and does not reproduce on every
     trajectory, so this test is the guard for the whole mechanism rather than a reproducer of that one bug.)"""
@@ -125,13 +130,11 @@ def test_auto_preconditioner_over_the_drop_and_splash(scene):
         st = c.substep(min(c.cfl(), 0.01))
         v = st["viscosity"]
         assert st["rc"] in (0, 1), (t, st["rc"], v)
+        assert v["status"] == 0, (t, v)                        # a default run never returns an iterate stopped at the cap
         if v["preconditioner"] == 1:
-            assert v["status"] == 0, (t, v)
             mg.append(v["iterations"])
-        elif t > 0:
-            assert v["status"] in (0, 1)                      # the capped diagonal solve: converged or accepted (reference rule)
     Q = c.particles
     c.close()
     assert np.isfinite(Q).all()
-    assert len(mg) >= 40, len(mg)                            # the multigrid did take over
-    assert max(mg) <= 110, mg                                # 326 with the polluted hierarchy
+    assert len(mg) >= 60, len(mg)                            # the multigrid runs (nearly) every solve
+    assert max(mg) <= 260 and max(mg[30:]) <= 110, mg        # 326 with the polluted hierarchy (substep 50)

@@ -437,13 +437,13 @@ def test_full_substeps_velocity_parity(name, precision):
 
 @pytest.mark.parametrize("name", SCENES)
 @pytest.mark.parametrize("rowl", [16, 64])
-def test_full_substeps_with_either_tile_geometry(name, rowl, monkeypatch):
-    """the solver kernels exist for two tile geometries (16-lane rows: 64 x 16 tiles, 64-lane rows: 256 x 4 tiles;
-    csrc/pcg_geo.inc), chosen per solve from how full the tiles are; FLIPV_ROWL pins one.  Both must give the reference's
-    velocities, and the tile grids must really differ."""
+def test_full_substeps_with_either_tile_geometry(name, rowl):
+    """the plane-layout solver kernels exist for two tile geometries (16-lane rows: 64 x 16 tiles, 64-lane rows: 256 x 4 tiles;
+    csrc/pcg_geo.inc), chosen per solve from how full the tiles are; flipv_params.tile_rows pins one (and viscosity_layout = 2 keeps the
+    viscosity solve on them: the default on these sparse scenes is the brick layout).  Both must give the reference's velocities, and
+    the tile grids must really differ."""
     g = Golden(name)
-    monkeypatch.setenv("FLIPV_ROWL", str(rowl))
-    c = make_ctx(g, viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+    c = make_ctx(g, viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7, tile_rows=rowl, viscosity_layout=2)
     c.particles = g["particles0"]
     for t in range(g.nsub):
         st = c.substep(g.dt)
@@ -511,14 +511,13 @@ def test_k_marching_spmv_matches_tile_kernels(name, runlen):
         assert abs(st_m[key]["iterations"] - st_t[key]["iterations"]) <= max(2, st_t[key]["iterations"] // 50), (key, st_m[key], st_t[key])
 
 
-@pytest.mark.parametrize("rowl", ["16", "64"])
-def test_k_marching_single_spmv_is_the_same_operator(rowl, monkeypatch):
+@pytest.mark.parametrize("rowl", [16, 64])
+def test_k_marching_single_spmv_is_the_same_operator(rowl):
     """one application of each operator through flipv_bench_spmv's code path is not observable from outside, so compare
     two one-iteration solves instead: with a cap of 1 the result is x = alpha s with alpha = sigma / (s, A s) -- any
     difference in A shows up in alpha.  Odd sizes: partial tiles, padding, columns that end inside a run."""
     from flipviscosity3d_amd import capi, hostapi as H
     from test_gpu_wide import box_mesh
-    monkeypatch.setenv("FLIPV_ROWL", rowl)
     I, J, K = 70, 33, 29
     dx = float(np.float32(1.0 / I))
     s = H.FluidSimulation()
@@ -533,7 +532,8 @@ def test_k_marching_single_spmv_is_the_same_operator(rowl, monkeypatch):
         c = capi.Context(I, J, K, dx)
         c.set_solid_sdf(solid)
         c.set_viscosity(3.0)
-        c.set_params(spmv_run_length=rl, viscosity_max_iterations=1, pressure_max_iterations=1, pressure_preconditioner=PRECOND_DIAGONAL)
+        c.set_params(spmv_run_length=rl, viscosity_max_iterations=1, pressure_max_iterations=1, pressure_preconditioner=PRECOND_DIAGONAL,
+                     viscosity_preconditioner=PRECOND_DIAGONAL, tile_rows=rowl, viscosity_layout=2)
         c.particles = P
         c.particle_sdf(); c.advect_velocity_field(); c.body_force(0.01)
         vi = c.viscosity_solve(0.01)

@@ -95,7 +95,7 @@ def test_tile_geometry_follows_the_liquid():
         c = capi.Context(I, J, K, dx)
         c.set_solid_sdf(solid)
         c.set_viscosity(2.0)
-        c.set_params(viscosity_max_iterations=20000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+        c.set_params(viscosity_max_iterations=20000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (the plane layouts: this test is about their tile geometry)
         return c
 
     a = ctx()
@@ -117,13 +117,12 @@ def test_tile_geometry_follows_the_liquid():
 
 
 @pytest.mark.parametrize("dims", [(37, 19, 23), (70, 33, 9)])
-@pytest.mark.parametrize("rowl", [16, 64])
-def test_odd_sized_domains_match_oracle(oracle, dims, rowl, monkeypatch):
+@pytest.mark.parametrize("rowl", [16, 64, 0])
+def test_odd_sized_domains_match_oracle(oracle, dims, rowl):
     """extents that are not multiples of anything the kernels like (lanes of 4, patches of 8 x 4, tiles of 64 x 16 or
-    256 x 4, 8^3 bins): the padded index space, partial tiles and the swizzled plane layout against the oracle, in both
-    tile geometries"""
+    256 x 4, bricks of 8 x 4 x 2, 8^3 bins): the padded index space, partial tiles and the swizzled plane layout against the oracle, in
+    both tile geometries (rowl 16 / 64: flipv_params.tile_rows, viscosity on the plane layouts) and in the brick layout (rowl 0: bricks forced)"""
     from flipviscosity3d_amd import capi, hostapi as H
-    monkeypatch.setenv("FLIPV_ROWL", str(rowl))
     I, J, K = dims
     dx = float(np.float32(1.0 / max(dims)))
     s = H.FluidSimulation()
@@ -140,7 +139,8 @@ def test_odd_sized_domains_match_oracle(oracle, dims, rowl, monkeypatch):
     c = capi.Context(I, J, K, dx)
     c.set_solid_sdf(solid)
     c.set_viscosity(nu)
-    c.set_params(viscosity_max_iterations=20000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7)
+    c.set_params(viscosity_max_iterations=20000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7, tile_rows=rowl,
+                 viscosity_layout=capi.LAYOUT_SWIZZLED if rowl else capi.LAYOUT_BRICK)
     o = oracle.OracleSim(I, J, K, dx)
     o.set_solid(solid)
     o.set_viscosity(nu)
@@ -159,10 +159,10 @@ def test_odd_sized_domains_match_oracle(oracle, dims, rowl, monkeypatch):
     o.close()
 
 
-def test_liquid_box_restriction_over_a_long_run(monkeypatch):
+def test_liquid_box_restriction_over_a_long_run():
     """Inside a substep the sweeps whose result is trivial away from the liquid cover only the liquid's neighbourhood (this
     substep's and the previous one's).  Stale data would only show once the liquid has MOVED: 40 substeps of the bunny falling
-    and splashing (64^3), every substep compared with a context that sweeps everything (FLIPV_LIQBOX=0) started from the same
+    and splashing (64^3), every substep compared with a context that sweeps everything (flipv_params.no_liquid_box) started from the same
     particles: liquid SDF bit for bit, velocities to summation-order noise."""
     import os
     from flipviscosity3d_amd import capi, hostapi as H
@@ -178,9 +178,8 @@ def test_liquid_box_restriction_over_a_long_run(monkeypatch):
     s.close()
     P[:, 3:] = np.array([0.9, -2.5, 0.6], np.float32)          # moving fast: the box changes every substep
     a = capi.Context(N, N, N, dx)
-    monkeypatch.setenv("FLIPV_LIQBOX", "0")
     b = capi.Context(N, N, N, dx)
-    monkeypatch.delenv("FLIPV_LIQBOX")
+    b.set_params(no_liquid_box=1)
     for c in (a, b):   # (tight solver tolerances: the comparison is about which entries were swept, not about where an iteration stopped)
         c.set_solid_sdf(solid); c.set_viscosity(0.5)
         c.set_params(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,

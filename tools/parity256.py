@@ -19,7 +19,7 @@ for name in ("bunny256_nu5_tight", "bunny256_nu5_converged"):
     print("== %s: reference viscosity iterations %s" % (name, [int(g["s%d_visc_iters" % t]) for t in range(g.nsub)]), flush=True)
     for prec, fp64, tol, ref in variants:
         c = Context(256, 256, 256, dx); c.set_solid_sdf(solid); c.set_viscosity(5.0)
-        c.set_params(viscosity_preconditioner=prec, viscosity_tolerance=tol, viscosity_max_iterations=60000, precision=fp64, reference_diagonal=ref)
+        c.set_params(viscosity_preconditioner=prec, viscosity_tolerance=tol, viscosity_max_iterations=60000, precision=fp64, exact_viscosity_operator=0 if ref else 1)
         c.particles = P
         for t in range(g.nsub):
             st = c.substep(g.dt)
