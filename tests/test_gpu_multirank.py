@@ -36,7 +36,7 @@ def test_slab_decomposition_matches_single_domain(name, nranks):
     g = Golden(name)
     I, J, K = g.dims()
     params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,
-                  viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # (the single-domain context would otherwise be free to pick the multigrid, which block contexts do not have)
+                  viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (the single-domain context would otherwise pick the multigrid and the brick layout, which block contexts do not have: the comparison is about the decomposition, bit for bit where it can be)
     ref = capi.Context(I, J, K, g.dx)
     ref.set_solid_sdf(g["solid"]); ref.set_viscosity(g["viscosity"]); ref.set_gravity(*g.gravity); ref.set_params(**params)
     ref.particles = g["particles0"]
@@ -89,7 +89,7 @@ def test_rccl_backend_single_rank_smoke():
     b.comm_init_rccl(capi.comm_unique_id(), 0, 1)
     for c in (a, b):
         c.set_solid_sdf(g["solid"]); c.set_viscosity(g["viscosity"]); c.set_gravity(*g.gravity)
-        c.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # (a context with a communicator has no multigrid to pick)
+        c.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (a context with a communicator has neither the multigrid nor the brick layout to pick)
         c.particles = g["particles0"]
     for t in range(g.nsub):
         sa, sb = a.substep(g.dt), b.substep(g.dt)
@@ -111,7 +111,7 @@ def test_stacked_weak_scaling_scene_two_slabs():
     ranges = partition.slab_ranges(K * copies, copies)
     ref = capi.Context(I, J, K * copies, g.dx)
     ref.set_solid_sdf(solid_g); ref.set_viscosity(5.0); ref.particles = np.concatenate(parts)
-    ref.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # what the slab contexts run
+    ref.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # what the slab contexts run
     ctxs = [capi.Context(I, J, K * copies, g.dx, device=0, slab=r) for r in ranges]
     capi.comm_init_local(ctxs)
     for c, p in zip(ctxs, parts):
@@ -149,7 +149,7 @@ def test_block_decomposition_matches_single_domain(name, dims):
     g = Golden(name)
     I, J, K = g.dims()
     params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,
-                  viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # (the single-domain context would otherwise be free to pick the multigrid, which block contexts do not have)
+                  viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (the single-domain context would otherwise pick the multigrid and the brick layout, which block contexts do not have: the comparison is about the decomposition, bit for bit where it can be)
     ref = capi.Context(I, J, K, g.dx)
     ref.set_solid_sdf(g["solid"]); ref.set_viscosity(g["viscosity"]); ref.set_gravity(*g.gravity); ref.set_params(**params)
     ref.particles = g["particles0"]
@@ -249,7 +249,7 @@ def test_blocks_with_fp64_vectors_and_odd_sizes():
     s.close()
     P[:, 3] = 0.3 * np.sin(9 * P[:, 1]); P[:, 4] = -0.2 * np.cos(7 * P[:, 0]); P[:, 5] = 0.1 * np.sin(5 * P[:, 2] + P[:, 0])
     for precision, dims in ((1, (2, 2, 1)), (0, (2, 1, 2)), (1, (1, 2, 2))):
-        params = dict(precision=precision, viscosity_max_iterations=6000, viscosity_tolerance=1e-7, viscosity_preconditioner=capi.PRECOND_DIAGONAL,
+        params = dict(precision=precision, viscosity_max_iterations=6000, viscosity_tolerance=1e-7, viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED,
                       pressure_rel_tolerance=0.0 if precision else 1e-7)
         ref = capi.Context(I, J, K, dx)
         ref.set_solid_sdf(solid); ref.set_viscosity(2.0); ref.set_params(**params); ref.particles = P

@@ -183,7 +183,9 @@ def test_liquid_box_restriction_over_a_long_run():
     for c in (a, b):   # (tight solver tolerances: the comparison is about which entries were swept, not about where an iteration stopped)
         c.set_solid_sdf(solid); c.set_viscosity(0.5)
         c.set_params(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,
-                     viscosity_preconditioner=capi.PRECOND_DIAGONAL)   # (AUTO decides from iteration counts, which may differ by one between two runs)
+                     viscosity_preconditioner=capi.PRECOND_DIAGONAL,   # (AUTO decides from iteration counts, which may differ by one between two runs)
+                     exact_viscosity_operator=1)   # (the reference's float-rounded diagonal leaves the near-rigid modes of tiny liquid clusters ill-determined:
+                                                   #  two runs of ONE configuration then differ by 4e-2 on the substep where the body touches the wall)
     a.particles = P
     worst = 0.0
     for t in range(40):
