@@ -214,6 +214,7 @@ struct flipv_context {
     float viscosity_max = 1.0f;     // largest viscosity node value (the a-priori stiffness estimate nu dt/dx^2 of fv_visc_auto_pick)
     int viscosity_nonzero_any = 1;  // ... on any rank of the communicator (all-reduced at the start of every viscosity solve)
     int vForceMultigridOnce = 0;    // set while a diagonal solve AUTO picked and that ran into the cap is being repeated with the multigrid
+    int vmgSweeps = 16;             // Jacobi sweeps on the multigrid's LDS-resident coarsest level for the current solve (viscosity_solve_t picks)
     int facValid = 0;               // the factor arrays hold the current layout's values wherever the band was
 
     // solver tiles

@@ -191,6 +191,22 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bricks, int nb, BrickSys<T> v, PcgScal sc, int it_arg) {
     BrickWalk w;
     w.begin(bricks, nb, v.mask);
+    // A brick's 15 values are requested as soon as its mask byte is known -- the first brick's BEFORE the scalar prologue (stop flag,
+    // iteration counter, the 160 partial sums and a barrier, none of which the data depends on), the next brick's before the current
+    // one's stores (which may alias for all the compiler knows): the kernel is a chain of dependent round trips, not a stream.
+    struct Data { float d[3]; T x[3], s[3], q[3]; RT<T> r[3]; };
+    auto fetch = [&](size_t a, unsigned m) {
+        Data D;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const bool on = (m >> c) & 1u;
+            D.d[c] = on ? v.diag[c][a] : 0.0f;
+            D.x[c] = on ? v.x[c][a] : (T)0; D.s[c] = on ? v.s[c][a] : (T)0; D.q[c] = on ? v.q[c][a] : (T)0;
+            D.r[c] = on ? v.r[c][a] : (RT<T>)0;
+        }
+        return D;
+    };
+    Data cur = fetch(w.a, w.m);
     __shared__ double lds[8];
     int it;
     double alpha_d, beta_d;
@@ -201,19 +217,14 @@ __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bri
     double mxd = 0.0;
     while (w.valid()) {
         const size_t a = w.a;
-        const unsigned m = w.m;
         w.next(bricks, nb, v.mask);
-        // every load of the lane first (one round trip per brick, not one per component: the stores below may alias for all the compiler knows)
+        const Data nxt = fetch(w.a, w.m);
         float d[3];
         T x[3], s[3], q[3];
         RT<T> r[3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const bool on = (m >> c) & 1u;
-            d[c] = on ? v.diag[c][a] : 0.0f;
-            x[c] = on ? v.x[c][a] : (T)0; s[c] = on ? v.s[c][a] : (T)0; q[c] = on ? v.q[c][a] : (T)0;
-            r[c] = on ? v.r[c][a] : (RT<T>)0;
-        }
+        for (int c = 0; c < 3; c++) { d[c] = cur.d[c]; x[c] = cur.x[c]; s[c] = cur.s[c]; q[c] = cur.q[c]; r[c] = cur.r[c]; }
+        cur = nxt;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             if (d[c] == 0.0f) continue;

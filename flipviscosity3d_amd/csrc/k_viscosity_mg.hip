@@ -1058,7 +1058,7 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
             STEP(OP_RESID, l);
         }
         {
-            const int sweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2 : VMG_COARSEST_SWEEPS;
+            const int sweeps = c->vmgSweeps > 0 ? c->vmgSweeps : VMG_COARSEST_SWEEPS;
             hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, sweeps, F0, ft0, conv, fb);
         }
         for (int l = t0 - 1; l >= 0; l--) {   // up
