@@ -6,9 +6,9 @@
 Workload (N=1): BASELINE.json configs[2] -- 256^3 grid, stanford_bunny.ply dropped inside the inverted
 sphere_large.ply container, viscosity 5 at every node, gravity (0,-9.81,0), 8 jittered particles per cell
 (counter-based RNG, seed 0), full substep: particle SDF + P2G + extrapolation + body force + variational
-viscosity PCG (reference cap 700 iterations, rel. tol 1e-6: "equal-work" mode A of SURVEY.md 8d; the library's default
-picks the preconditioner per solve -- the diagonal, which runs into that cap during the stiff first dozen substeps exactly as the
-reference's MIC(0) solve does, or the multigrid V-cycle, which converges in 15-60 iterations once the liquid moves) +
+viscosity PCG (reference tolerance 1e-6 and cap 700; the library's default never returns an iterate stopped at the cap where a converged
+one is affordable: multigrid-preconditioned, 100-190 iterations in the stiff start, 15-60 once the liquid moves, so the timed substeps are
+"equal-accuracy" ones -- mode B of SURVEY.md 8d -- and `mode_b` on the result line says whether every timed solve converged) +
 pressure PCG + extrapolation + constrain + G2P/RK2 advection.  A "step" is one substep of
 min(CFL step, 0.01 s) exactly as FluidSimulation::advance takes them (fluidsimulation.cpp:138-167).
 Inputs are resident in HBM before the timed region; value = grid cells / wall seconds per substep.
@@ -16,11 +16,11 @@ Inputs are resident in HBM before the timed region; value = grid cells / wall se
 them every substep, fluidsimulation.cpp:585; ~0.2 ms of a 31-37 ms substep)
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel of the substep, the matrix-free viscosity SpMV.  Unit = one MAC cell's worth of
-                  unknowns (3 rows), 52 algorithmic bytes per unit (DESIGN.md 3); units per launch = rows of the system / 3;
-                  duration measured with HIP events on the library's own stream around every 8th launch inside the
-                  timed region.  On this scene the liquid fills 4 % of the box and a launch moves ~40 MB: the kernel is
-                  latency-bound, not HBM-bound, and the fraction says so.
+  roofline     -- the dominant kernel of the substep, the matrix-free viscosity SpMV (on this sparse scene the brick-layout kernel
+                  k_bvisc_spmv: the PCG's q = A p and, with other epilogues, the multigrid's four fine-level sweeps).  Unit = one MAC
+                  cell's worth of unknowns (3 rows), 52 algorithmic bytes per unit; units per launch = rows of the
+                  system / 3; duration measured with HIP events on the library's own stream around every 8th launch of the PCG's
+                  own SpMV in an untimed second pass.
   roofline_dense -- the same two SpMV kernels on a completely filled 256^3 box (SURVEY.md 8d "pure kernel roofline
                   runs"), where a launch streams 0.4-0.9 GB and the HBM bound is the relevant one; measured live.
   cpu_baseline -- the reference itself (oracle/_ref, kind "reference") or our C restatement (kind "port"),
@@ -121,7 +121,7 @@ def cpu_baseline(viscosity, budget_size):
     sim.addLiquid(H.load_ply(os.path.join(MESH, "stanford_bunny.ply")))
     solid, particles = sim.solid_sdf(), sim.particles
     sim.close()
-    nsub = 2
+    nsub = 2 if N < 256 else 1   # (256^3: ~3 minutes per substep on one core)
     try:
         from oracle import refbind as R
         use_ref = R.available()
@@ -192,6 +192,29 @@ def spawn_ranks(n, result_fd):
     return rc
 
 
+def cpu_baseline_all_cores(viscosity, budget_size, threads):
+    """The all-cores figure SURVEY.md 8d asks for: the C restatement of the reference's algorithm built with OpenMP (oracle/omp_baseline.py,
+    kind "port"), run as a child process with OMP_NUM_THREADS = `threads` on the same bounded sample.  What the reference's algorithm
+    makes sequential (MIC(0)'s triangular solves) stays sequential, so this is Amdahl-bound by construction."""
+    import subprocess
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = str(threads)
+    env["OMP_PROC_BIND"] = "close"
+    try:
+        p = subprocess.run([sys.executable, "-m", "oracle.omp_baseline", str(budget_size), "2" if budget_size < 256 else "1", repr(viscosity)], cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+        line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": p.stderr.decode()[-400:]}
+        out = json.loads(line[-1])
+        out["sample"] = "same scene at %d^3, mean of %d substeps of 0.01 s from rest, OpenMP build of the C restatement on %d threads, %.2f s per substep" % (
+            out["size"], out["substeps"], out["cores"], out["seconds_per_substep"])
+        out["host_cpus"] = os.cpu_count()
+        return out
+    except Exception as e:   # (the baseline must never take the bench line down)
+        return {"error": repr(e)}
+
+
 def main():
     # Exactly one line may reach stdout: the JSON result.  RCCL prints a version banner on stdout when a communicator
     # is created (the library's own and torch.distributed's), HIP tools may print too: everything written to fd 1 during
@@ -207,8 +230,10 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--viscosity", type=float, default=5.0)
     ap.add_argument("--cpu-size", type=int, default=128, help="grid size of the bounded CPU-baseline sample (128: ~15-20 s of CPU work; "
-                    "256 = the headline size itself, ~6 minutes)")
+                    "256 = the headline size itself, ONE substep: ~3 minutes of one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU baseline (OpenMP build of the C restatement): 0 = min(host cpus, 32), "
+                    "1 = skip it")
     ap.add_argument("--no-dense", action="store_true", help="skip the filled-box SpMV roofline measurement")
     ap.add_argument("--gpu-setup", action="store_true", help="build the scene with the device setup kernels (for sizes where the host path takes minutes)")
     ap.add_argument("--force-comm", action="store_true",
@@ -222,6 +247,9 @@ def main():
                          "multigrid V-cycle, whichever the previous solve's iteration count predicts to be cheaper; what the headline is "
                          "timed with); diagonal / multigrid pin one (multigrid: one GPU, fp32)")
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
+    ap.add_argument("--exact-operator", action="store_true", help="flipv_params.exact_viscosity_operator = 1: the exact viscosity operator instead of the "
+                    "reference's float-rounded one (no defect-correction stage; 1.5e-4 from the reference's converged velocities at 256^3)")
+    ap.add_argument("--dense-size", type=int, default=384, help="second size of the filled-box SpMV roofline (the first is min(--size, 256)); 0 = skip")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bunny",
                     help="bunny = BASELINE configs[2] (the metric's scene); honey = configs[3] (rod + sheet, use --viscosity 50); "
                          "sheet = configs[4] (--size is the long axis: 1024 -> 1024x512x512)")
@@ -314,7 +342,7 @@ def main():
         del solid_g, parts
     c.set_viscosity(args.viscosity)
     c.set_gravity(0.0, -9.81, 0.0)
-    c.set_params(precision=args.precision, kernel_timing=0, viscosity_max_iterations=args.viscosity_cap)
+    c.set_params(precision=args.precision, kernel_timing=0, viscosity_max_iterations=args.viscosity_cap, exact_viscosity_operator=1 if args.exact_operator else 0)
     if args.viscosity_preconditioner != "auto":
         c.set_params(viscosity_preconditioner=capi.PRECOND_MULTIGRID if args.viscosity_preconditioner == "multigrid" else capi.PRECOND_DIAGONAL)
     c.particles = particles
@@ -343,21 +371,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # ---- second pass, NOT timed: the same number of substeps with HIP events around every 8th SpMV launch
-    # (with the diagonal preconditioner pinned: the kernel being priced is the SpMV of the 700-iteration solves that dominate the
-    # timed region; left on AUTO this pass, which continues the run, would time the few SpMV launches of multigrid-preconditioned
-    # solves instead -- the same kernel inside a kernel-by-kernel loop of 27 launches per iteration)
+    # ---- second pass, NOT timed: a few more substeps with HIP events around every 8th launch of the PCG's own SpMV (kernel_timing
+    # launches the loop kernel by kernel, so it reads a little above rocprofv3's kernel-only average)
     c.set_params(kernel_timing=1)
-    if args.viscosity_preconditioner == "auto":
-        c.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL)
     c.kernel_stats_reset()
     for _ in range(max(1, min(args.steps, 5))):
         step()
     c.synchronize()
     ks = c.kernel_stats()
     c.set_params(kernel_timing=0)
-    if args.viscosity_preconditioner == "auto":
-        c.set_params(viscosity_preconditioner=capi.PRECOND_AUTO)
     b2b = {}
     if world == 1:
         for which, name in ((1, "viscosity"), (0, "pressure")):
@@ -385,10 +407,12 @@ def main():
         avg_ms = v_ms / v_n
         units = last["viscosity"]["rows"] / 3.0   # this rank's rows (rank 0)
         gbs = VISC_SPMV_BYTES_PER_INDEX * units / (avg_ms * 1e-3) / 1e9
-        roof = {"kernel": "k_visc_spmv<float>" if args.precision == 0 else "k_visc_spmv<double>", "bound": "hbm",
+        kname = ("k_bvisc_spmv" if last["viscosity"]["layout"] == 2 else "k_visc_spmv") + ("<float>" if args.precision == 0 else "<double>")
+        roof = {"kernel": kname, "bound": "hbm",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": avg_ms * 1e3, "launches": v_n, "units_per_launch": units, "bytes_per_unit": VISC_SPMV_BYTES_PER_INDEX,
-                "timing": "HIP events on the library's stream around every 8th launch, untimed second pass",
+                "timing": "HIP events on the library's stream around every 8th launch of the PCG's own SpMV, untimed second pass",
+                "layout": {0: "plain planes", 1: "plain planes, swizzled own-index arrays", 2: "bricks of 8 x 4 x 2 indices"}[last["viscosity"]["layout"]],
                 "back_to_back_launch_us": b2b.get("viscosity", 0.0) * 1e3 or None,
                 "unit_definition": "one cell's worth of unknowns = 3 rows of the viscosity system",
                 "swept_indices_per_launch": v_cells / v_n}
@@ -424,6 +448,16 @@ def main():
             "phase_ms_note": "mean over the timed substeps (GPU time per phase, HIP events)",
             "viscosity_iterations": its("viscosity"), "pressure_iterations": its("pressure"),
             "viscosity_preconditioner_per_step": [st["viscosity"]["preconditioner"] for st in stats],   # 0 diagonal, 1 multigrid (AUTO picks per solve)
+            "viscosity_status_per_step": [st["viscosity"]["status"] for st in stats],                   # 0 converged, 1 cap reached / stalled (iterate accepted), 3 trivial
+            "viscosity_operator": "exact (vol u - div tau)" if args.exact_operator else
+                                  "the reference's (float-rounded diagonal, viscositysolver.cpp:394-446): exact-operator multigrid-PCG + one defect-correction stage",
+            # mode B of SURVEY.md 8d (equal accuracy): every viscosity solve run to the reference's 1e-6 tolerance.  A default run IS that
+            # when every timed solve converged; otherwise this object says how many did not
+            "mode_b": {"value": value if all(st["viscosity"]["status"] in (0, 3) for st in stats) else None,
+                       "unit": "MCells/s", "all_timed_solves_converged": all(st["viscosity"]["status"] in (0, 3) for st in stats),
+                       "unconverged_solves": int(sum(st["viscosity"]["status"] not in (0, 3) for st in stats)),
+                       "mean_viscosity_iterations": float(np.mean([st["viscosity"]["iterations"] for st in stats])),
+                       "note": "same run as `value`: the default parameters converge every solve inside the reference's cap of 700"},
             "viscosity": {k: last["viscosity"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "roofline": roof,
@@ -433,8 +467,14 @@ def main():
             c.close()
             c = None
             out["roofline_dense"] = dense_roofline(min(N, 256), args.precision)
+            if args.dense_size > 0 and args.dense_size != min(N, 256):
+                # (at 256^3 an fp32 array is 64 MiB against a 256 MiB Infinity Cache; 384^3 arrays are 216 MiB each)
+                out["roofline_dense_%d" % args.dense_size] = dense_roofline(args.dense_size, args.precision, reps=20)
         if world == 1 and not args.no_cpu_baseline and args.workload == "bunny":
             out["cpu_baseline"] = cpu_baseline(args.viscosity, args.cpu_size)
+            if args.cpu_threads != 1:
+                nthr = args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 32)
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.viscosity, args.cpu_size, nthr)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:

@@ -66,7 +66,7 @@ PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID = 0, 1, 2
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("rhs_norm", C.c_double),
                 ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
-                ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int)]
+                ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int), ("defect_residual", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -712,6 +712,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     int conv = -1, iters = 0, refinements = 0;
     double res = bnorm;
     bool success = false, stalled = false, ranMg = false;
+    const bool defectLimited = false;
+    double defectRes = 0.0, mainRes = 0.0;   // max|b - A_ref x| after the defect-correction stage; the exact-operator loop's own final residual
     int anyActive = c->nActiveV;
     // residual replacement (k_viscosity_brick.hip): fp32 vectors in the brick layout
     int replacePeriod = 0;
@@ -754,6 +756,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (useAcc) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
         int itersDone = 0, corrections = 0;
         bool correctionDue = false;
+        double resBeforeStage = 0.0;
         const bool innerDiffers = staged && useMg;   // the Krylov loop runs on the exact operator, the solve is for the reference's
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
@@ -839,6 +842,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             fprintf(stderr, "\n");
         }
         itersDone += itersNow;
+        if (!correction) resBeforeStage = res;                   // the main loop's own (recurrence) residual
         if (correction) { success = true; stalled = false; }   // a correction stage is accepted as it comes
         if (success && !innerDiffers) break;
         if (!canRefine) break;
@@ -850,23 +854,31 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if ((rc = recompute_residual())) return rc;
         stalled = false;
         success = false;
-        if (res <= (innerDiffers ? 2.0 : 1.0) * tolFinal) { success = true; break; }
-        if (innerDiffers && wasConverged) {   // the defect E x the exact-operator loop left behind: ONE bounded correction stage, accepted as it comes
-            if (corrections >= 1 || itersDone >= cap) { success = true; break; }
+        if (res <= tolFinal) { success = true; break; }
+        if (innerDiffers && wasConverged) {
+            // The defect E x the exact-operator loop left behind: ONE bounded correction stage, accepted as it comes -- a first-order
+            // correction.  |A^-1 E| is ~1e-3 at 256^3 / nu = 5: what is left is 2 % of the first order plus the second, and the velocities
+            // land 4e-5 from the reference's converged ones (1.5e-4 without).  Where nu dt/dx^2 is extreme the reference's float diagonal is
+            // simply wrong -- 512^3 / nu = 50, nu dt/dx^2 = 131 072: max|E x| = 1.2 max|b|, further stages contract by 2-50x each and stop
+            // contracting around 1e-5 -- and chasing it costs more than the solve (measured: 6 stages, +70 % iterations, no convergence).
+            // The solve's status and residual are the exact-operator loop's; `defect_residual` reports max|b - A_ref x| at the end.
+            if (corrections >= 1 || itersDone >= cap) { success = true; defectRes = res; res = mainRes; break; }
             corrections++;
             correctionDue = true;
+            mainRes = resBeforeStage;
         } else correctionDue = false;
         if (itersDone >= cap) break;
         }
         iters = itersDone;
     }
     li.refinements = refinements;
+    li.defect_residual = defectRes;
     if (c->prm.verbose && nontrivial)
         fprintf(stderr, "viscosity solve %ld: %s, %s layout, %d iterations, residual %.3g (rhs %.3g), %s\n", c->viscSolves, ranMg ? "multigrid" : "diagonal",
                 brick ? "brick" : (c->vSwz ? "swizzled" : "plain"), iters, res, bnorm, success ? "converged" : (stalled ? "stalled" : "cap"));
     // (A multigrid-preconditioned fp32 solve that STALLS two orders of magnitude or more below the right-hand side keeps its iterate: it
     // is far closer to the solution than a capped diagonal solve gets, and is reported as "not converged" like any accepted iterate.)
-    if (ranMg && !success && !(stalled && res < 1e-4 * bnorm)) {
+    if (ranMg && !success && !defectLimited && !(stalled && res < 1e-4 * bnorm)) {
         // The multigrid-preconditioned solve did not reach the tolerance.  Its iterate is not used: the solve is repeated from scratch
         // with the diagonal, whose capped iterate is what the reference's acceptance rule is about.
         c->viscSolves++;
@@ -891,10 +903,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     li.residual = res;
     c->viscSolves++;
     c->vLastPrec = !nontrivial ? c->vLastPrec : (li.preconditioner ? 2 : 1);   // (a trivial solve says nothing)
-    if (nontrivial) { c->vLastIts = iters; c->vLastConverged = success ? 1 : 0; c->vLastRelRes = bnorm > 0.0 ? res / bnorm : 0.0; }
+    if (nontrivial) { c->vLastIts = iters; c->vLastConverged = (success || defectLimited) ? 1 : 0; c->vLastRelRes = bnorm > 0.0 ? res / bnorm : 0.0; }
     // acceptance rule of viscositysolver.cpp:676-689
     // (a stalled solve is treated like one that ran into the cap: its iterate is used if the residual passes the acceptance bound)
-    const bool accepted = success || ((iters == cap || stalled) && res < c->prm.viscosity_accept_tolerance);
+    const bool accepted = success || defectLimited || ((iters == cap || stalled) && res < c->prm.viscosity_accept_tolerance);
     li.status = success ? (iters == 0 ? 3 : 0) : (accepted ? 1 : 2);
     if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
         const size_t off = plane_off(L, R0.kb), cnt = (size_t)(R0.ke - R0.kb) * L.sz;

@@ -155,6 +155,9 @@ typedef struct flipv_solve_info {
                             (active_tiles / total_tiles then count bricks of 8 x 4 x 2 indices) */
     int refinements;     /* viscosity, fp32 vectors in the brick layout: how often the solve was continued on the correction equation after a stall
                             (x flushed into an fp64 accumulator, r = b - A x evaluated in fp64, PCG restarted); `iterations` counts all rounds */
+    double defect_residual; /* viscosity, default operator under the multigrid: max|b - A_ref x| (fp64) after the defect-correction stage, A_ref the
+                            reference's float-rounded operator; `status` / `residual` are those of the exact-operator PCG loop.  0 when there was
+                            no such stage */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */

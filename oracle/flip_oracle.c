@@ -17,6 +17,25 @@
 
 #define IDX(i, j, k, w, h) ((size_t)(i) + (size_t)(w) * ((size_t)(j) + (size_t)(h) * (size_t)(k)))
 
+/* Optional all-cores build (make -C oracle oracle_omp -> libfliporacle_omp.so, -fopenmp): the loops of the reference's algorithm that
+ * are data-parallel as written (SpMV, dot products, axpys, max norms, volume fractions, particle kernels) run across the host's cores;
+ * what the reference's algorithm makes sequential stays sequential (the two triangular solves of MIC(0), the incomplete
+ * factorisation, the scatters in particle order, the layered extrapolation).  Dot products then sum in a different order, so this
+ * build is NOT the bit-pinned oracle (tests/ use the plain one); it exists for bench.py's all-cores CPU baseline. */
+#ifdef _OPENMP
+#include <omp.h>
+#define OMP_FOR _Pragma("omp parallel for schedule(static)")
+#define OMP_FOR_SUM(v) _Pragma(STRINGIFY_(omp parallel for schedule(static) reduction(+ : v)))
+#define OMP_FOR_MAX(v) _Pragma(STRINGIFY_(omp parallel for schedule(static) reduction(max : v)))
+#define STRINGIFY_(x) #x
+int oracle_omp_threads(void) { return omp_get_max_threads(); }
+#else
+#define OMP_FOR
+#define OMP_FOR_SUM(v)
+#define OMP_FOR_MAX(v)
+int oracle_omp_threads(void) { return 1; }
+#endif
+
 static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -477,6 +496,7 @@ static void p_apply_precon(const psys *s, const double *r, double *z, double *q)
 }
 
 static void p_apply_matrix(const psys *s, const double *x, double *y) { /* pressuresolver.cpp:464-499 */
+    OMP_FOR
     for (int idx = 0; idx < s->n; idx++) {
         int i = s->ci[idx], j = s->cj[idx], k = s->ck[idx];
         double val = 0.0;
@@ -494,11 +514,13 @@ static void p_apply_matrix(const psys *s, const double *x, double *y) { /* press
 
 static double vdot(const double *a, const double *b, int n) {
     double s = 0.0;
+    OMP_FOR_SUM(s)
     for (int i = 0; i < n; i++) s += a[i] * b[i];
     return s;
 }
 static double vabsmax_neginf(const double *a, int n) { /* pressuresolver.cpp:75-84 */
     double m = -INFINITY;
+    OMP_FOR_MAX(m)
     for (int i = 0; i < n; i++) if (fabs(a[i]) > m) m = fabs(a[i]);
     return m;
 }
@@ -628,13 +650,16 @@ void oracle_pressure_solve(int I, int J, int K, float dxf, float dtf, const floa
         while (it < maxiter) {
             p_apply_matrix(&s, sv, z);
             double alpha = sigma / vdot(z, sv, n);
+            OMP_FOR
             for (int c = 0; c < n; c++) x[c] += sv[c] * alpha;
+            OMP_FOR
             for (int c = 0; c < n; c++) r[c] += z[c] * (-alpha);
             if (vabsmax_neginf(r, n) < tol) { li.status = 0; break; }
             memset(q, 0, (size_t)n * sizeof(double));
             p_apply_precon(&s, r, z, q);
             double sigma_new = vdot(z, r, n);
             double beta = sigma_new / sigma;
+            OMP_FOR
             for (int c = 0; c < n; c++) sv[c] = z[c] * 1.0 + sv[c] * beta;
             sigma = sigma_new;
             it++;
@@ -1284,6 +1309,7 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
             int it;
             success = 0;
             for (it = 0; it < maxiter; it++) {
+                OMP_FOR
                 for (int i = 0; i < n; i++) { /* multiply (sparsematrix.h:166-176) */
                     double acc = 0;
                     for (int t = 0; t < M.cnt[i]; t++)
@@ -1291,15 +1317,19 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
                     z[i] = acc;
                 }
                 double alpha = rho / vdot(sv, z, n);
+                OMP_FOR
                 for (int i = 0; i < n; i++) x[i] += alpha * sv[i];
+                OMP_FOR
                 for (int i = 0; i < n; i++) r[i] += (-alpha) * z[i];
                 double mv = 0;
+                OMP_FOR_MAX(mv)
                 for (int c = 0; c < n; c++) if (fabs(r[c]) > mv) mv = fabs(r[c]);
                 res = mv;
                 if (res <= tolabs) { iters = it + 1; success = 1; break; }
                 APPLY_PRECON(r, z);
                 double rho_new = vdot(z, r, n);
                 double beta = rho_new / rho;
+                OMP_FOR
                 for (int i = 0; i < n; i++) z[i] += beta * sv[i];
                 double *tmp = sv; sv = z; z = tmp;
                 rho = rho_new;
@@ -1372,6 +1402,7 @@ void oracle_update_particle_velocities(int I, int J, int K, float dxf, float *ao
                                        const float *V, const float *W, const float *sU, const float *sV,
                                        const float *sW, float ratio) {
     double dx = (double)dxf;
+    OMP_FOR
     for (size_t p = 0; p < n; p++) { /* fluidsimulation.cpp:341-352 */
         float *q = aos6 + 6 * p;
         float vn[3], vo[3];
@@ -1397,6 +1428,7 @@ void oracle_advect_particles(int I, int J, int K, float dxf, float dt, float *ao
     float bx = 0.0f - (float)eh, by = 0.0f - (float)eh, bz = 0.0f - (float)eh;
     bw += ev; bh += ev; bd += ev;
     int nw = I + 1, nh = J + 1, nd = K + 1;
+    OMP_FOR
     for (size_t p = 0; p < n; p++) {
         float *q = aos6 + 6 * p;
         /* _traceRK2 (fluidsimulation.cpp:535-541) */

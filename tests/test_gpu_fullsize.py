@@ -138,3 +138,43 @@ def test_auto_preconditioner_over_the_drop_and_splash(scene):
     assert np.isfinite(Q).all()
     assert len(mg) >= 60, len(mg)                            # the multigrid runs (nearly) every solve
     assert max(mg) <= 260 and max(mg[30:]) <= 110, mg        # 326 with the polluted hierarchy (substep 50)
+
+
+def test_config4_honey_buckling_at_512_properties():
+    """BASELINE configs[3] at its REAL size on one GPU (512^3, rod.ply + sheet.ply added with two add-liquid calls, nu = 50; 45 GiB of the
+    device's 288): the oracle would need hours, so size-independent properties over two default-parameter substeps --
+    the seeded particle count, a viscosity solve that converges inside the reference's cap (the multigrid: nu dt/dx^2 = 131 072), a
+    projection whose weighted divergence equals the pressure residual in every pressure cell, particles that stay finite and inside."""
+    from bench import build_workload
+    from flipviscosity3d_amd import capi
+    M = 512
+    I, J, K, dx, solid, P = build_workload("honey", M, on_device=True)
+    assert (I, J, K) == (M, M, M)
+    assert len(P) == 14528382                                   # 8 counter-jittered samples per cell inside rod + sheet (deterministic)
+    c = capi.Context(I, J, K, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(50.0)
+    c.particles = P
+    del P
+    for t in range(2):
+        st = c.substep(min(c.cfl(), 0.01))
+        v, p = st["viscosity"], st["pressure"]
+        assert v["status"] == 0 and v["preconditioner"] == 1 and v["layout"] == 2 and v["iterations"] < 700, v
+        assert v["residual"] <= 1e-6 * v["rhs_norm"] * 1.0001
+        assert p["status"] == 0, p
+    U, V, W = (c.grid(n).astype(np.float64) for n in "UVW")
+    wU, wV, wW = (c.grid("WEIGHT_" + n).astype(np.float64) for n in "UVW")
+    fx = wU * U; fy = wV * V; fz = wW * W
+    del U, V, W
+    div = (fx[:, :, 1:] - fx[:, :, :-1] + fy[:, 1:, :] - fy[:, :-1, :] + fz[1:, :, :] - fz[:-1, :, :]) / dx
+    del fx, fy, fz
+    phi = c.grid("LIQUID_PHI")
+    cells = np.zeros_like(phi, bool)
+    cells[1:-1, 1:-1, 1:-1] = phi[1:-1, 1:-1, 1:-1] < 0
+    cells &= (wU[:, :, 1:] + wU[:, :, :-1] + wV[:, 1:, :] + wV[:, :-1, :] + wW[1:, :, :] + wW[:-1, :, :]) > 0
+    assert cells.sum() == p["rows"]
+    assert np.abs(div[cells]).max() <= p["residual"] * 1.01 + 4 * 2e-8 / dx * 6, (np.abs(div[cells]).max(), p)
+    Q = c.particles
+    c.close()
+    assert len(Q) == 14528382 and np.isfinite(Q).all()
+    assert Q[:, :3].min() > dx and Q[:, :3].max() < 1.0 - dx      # clamped into the domain inset (fluidsimulation.cpp:319-320)
