@@ -125,7 +125,6 @@ int fv_brick_grid(const flipv_context *c, int nbricks, int cap);
 template <typename T> void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot);
 template <typename T> void fv_brick_init(flipv_context *c, const PcgScal &sc);
 template <typename T> void fv_brick_update(flipv_context *c, const PcgScal &sc, int it);
-int fv_brick_fused_run(flipv_context *c, const PcgScal &sc, int cap, int *conv_out);   // one kernel per Jacobi-PCG iteration (fp32)
 void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);
 template <typename T> void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int period, int withSigma, float *const z[3], float omega);
 template <typename T> void fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact);

@@ -795,9 +795,6 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                 ? +[](flipv_context *cc, const PcgScal &s2, int it) { fv_brick_spmv<float>(cc, s2, it, false); }
                 : +[](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); };
             if ((rc = fv_viscosity_pcg_mg(c, sc, capNow, mgspmv, replacePeriod, itersDone > 0 ? 1 : 0, &conv))) return rc;
-        } else if (brick && std::is_same<T, float>::value && !replacePeriod && !c->prm.two_kernel_pcg) {
-            // one kernel per iteration (k_viscosity_brick.hip: k_bpcg_fused)
-            if ((rc = fv_brick_fused_run(c, sc, capNow, &conv))) return rc;
         } else if (brick) {
             fv_brick_init<T>(c, sc);
             auto spmv = [&](int, int, int it) { fv_brick_spmv<T>(c, sc, it, !sc.noB); };

@@ -257,149 +257,11 @@ __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bri
     }
 }
 
-// ------------------------------------------------------------------ ONE kernel per Jacobi-PCG iteration (fp32 vectors)
-// The update of iteration k-1 folded into the SpMV of iteration k: the kernel recomputes, at each of the 27 (position, component)
-// pairs its lane's stencil reads, the search direction the update kernel would have written there,
-//     r' = r - alpha q ,  s' = r'/d + beta s        (alpha, beta from the previous launch's five dot products, as in K2 of pcg_common.h),
-// applies the operator to s', and -- at its own index -- stores x += alpha s, r', s' and q' = A s' and accumulates
-// sigma' = (r'/d, r'), max|r'|, a' = (s', q'), b' = (r'/d, q'), c' = (q'/d, q').  r, s and q are double-buffered (a launch reads the set the
-// previous one wrote: neighbours must see the OLD vectors while an owner stores the new ones); the second set lives in the upper half of
-// the same allocations (solver vectors are allocated fp64-sized).  Every lane computes a position's s' from the same four values with the
-// same arithmetic, so owner and neighbours agree bit for bit.
-// Cost against the two-kernel iteration (k_bvisc_spmv + k_bpcg_update): 136 algorithmic bytes per unit instead of 160 and one launch instead
-// of two, against 4x the stencil loads (r, q, d next to s at every position; they hit the lines the neighbouring bricks' owners stream
-// anyway).  F(k): k = 0 forms s = r/d and q = A s only.  *conv = k - 1 when max|r_{k-1}| passes (x is then x_{k-1}).
-template <typename T>
-struct FusedSys {
-    const float *diag[3];
-    T *x[3];
-    T *r[2][3], *s[2][3], *q[2][3];   // [set][component]; launch k reads set (k + 1) & 1 and writes set k & 1
-    const uint8_t *mask;
-    int sby, sbz;
-};
-template <typename T>
-__global__ __launch_bounds__(256) void k_bpcg_fused(const int *__restrict__ bricks, int nb, const float *__restrict__ vmU, const float *__restrict__ vmV,
-                                                    const float *__restrict__ vmW, const float *__restrict__ fC, const float *__restrict__ fEU,
-                                                    const float *__restrict__ fEV, const float *__restrict__ fEW, FusedSys<T> v, PcgScal sc, int it_arg, int parity) {
-#pragma clang fp contract(fast)
-    __shared__ double lds[8];
-    __shared__ double red[24];
-    BrickWalk w;
-    w.begin(bricks, nb, v.mask);
-    // iteration number: explicit, or the device-side counter of this launch's parity (a launch reads counter[parity] and publishes k + 1 in
-    // counter[parity ^ 1]: no block can see a counter written inside its own launch)
-    int *cnt = sc.itA;   // itA, itB are adjacent: cnt[0], cnt[1]
-    const int conv_now = *sc.conv, k = it_arg >= 0 ? it_arg : cnt[parity];
-    if (conv_now >= 0 || k >= sc.cap) return;
-    const int tid = d_tid256();
-    double alpha_d = 0.0, beta_d = 0.0;
-    if (k > 0) {   // rmax, sigma, a, b, c of launch k - 1: 5 x NSLOT contiguous doubles [sig | a | b | c | rmax]
-        const int grp = tid >> 5;
-        double val = 0.0;
-        if (grp < 5) val = sc.sig(k - 1)[tid];
-#pragma unroll
-        for (int off = NSLOT / 2; off > 0; off >>= 1) {
-            const double o = __shfl_down(val, off, NSLOT);
-            val = grp == 4 ? fmax(val, o) : val + o;
-        }
-        if (grp < 5 && (tid & (NSLOT - 1)) == 0) lds[grp] = val;
-        __syncthreads();
-        const double res = lds[4];
-        if (d_pass(sc, res)) {
-            if (blockIdx.x == 0 && tid == 0) *sc.conv = k - 1;
-            return;
-        }
-        if (sc.best) {   // stall guard (PcgScal)
-            const double bestNow = *sc.best;
-            if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > 16.0 * bestNow) {
-                if (blockIdx.x == 0 && tid == 0) { *sc.stalled = 1; *sc.conv = k - 1; }
-                return;
-            }
-            if (blockIdx.x == 0 && tid == 0 && res < bestNow) *sc.best = res;
-        }
-        const double sg = lds[0], a = lds[1];
-        alpha_d = a != 0.0 ? sg / a : 0.0;
-        double est = sg - 2.0 * alpha_d * lds[2] + alpha_d * alpha_d * lds[3];
-        if (!(est > 0.0)) est = 0.0;
-        beta_d = sg != 0.0 ? est / sg : 0.0;
-    }
-    const T alpha = (T)alpha_d;
-    const int cur = k & 1, prv = cur ^ 1;
-    const NbOff o = d_lane_off(v.sby, v.sbz);
-    // r' and s' at position p of component c, from the previous launch's vectors (k = 0: s' = r/d)
-    auto RS = [&](int c, size_t p, T &rn_out) -> T {
-        const float d = v.diag[c][p];
-        const T r = v.r[prv][c][p];
-        if (k == 0) { rn_out = r; return d != 0.0f ? (T)((float)r / d) : (T)0; }
-        const T q = v.q[prv][c][p], sv = v.s[prv][c][p];
-        const T rn = (T)((double)r - alpha_d * (double)q);
-        rn_out = rn;
-        return d != 0.0f ? (T)((double)((float)rn / d) + beta_d * (double)sv) : (T)0;
-    };
-    auto S = [&](int c, size_t p) -> T { T dummy; return RS(c, p, dummy); };
-    double dsig = 0.0, da = 0.0, db = 0.0, dc = 0.0;
-    float mx = 0.0f;
-    while (w.valid()) {
-        const size_t a = w.a;
-        const unsigned m = w.m;
-        w.next(bricks, nb, v.mask);
-        if (m == 0u) continue;
-        const float C0 = fC[a], C0l = fC[a + o.xm], Cjm = fC[a + o.ym], Ckm = fC[a + o.zm];
-        const float EW0 = fEW[a], EW0r = fEW[a + o.xp], EWjp = fEW[a + o.yp];
-        const float EV0 = fEV[a], EV0r = fEV[a + o.xp], EVkp = fEV[a + o.zp];
-        const float EU0 = fEU[a], EUjp = fEU[a + o.yp], EUkp = fEU[a + o.zp];
-        T RU, RV, RW;
-        const T U0 = RS(0, a, RU), U0l = S(0, a + o.xm), U0r = S(0, a + o.xp), Ujm = S(0, a + o.ym), Ujp = S(0, a + o.yp), Ukm = S(0, a + o.zm), Ukp = S(0, a + o.zp);
-        const T Ujmr = S(0, a + o.ym + o.xp), Ukmr = S(0, a + o.zm + o.xp);
-        const T V0 = RS(1, a, RV), V0l = S(1, a + o.xm), V0r = S(1, a + o.xp), Vjm = S(1, a + o.ym), Vjp = S(1, a + o.yp), Vkm = S(1, a + o.zm), Vkp = S(1, a + o.zp);
-        const T Vjpl = S(1, a + o.yp + o.xm), Vjpkm = S(1, a + o.yp + o.zm);
-        const T W0 = RS(2, a, RW), W0l = S(2, a + o.xm), W0r = S(2, a + o.xp), Wjm = S(2, a + o.ym), Wjp = S(2, a + o.yp), Wkm = S(2, a + o.zm), Wkp = S(2, a + o.zp);
-        const T Wkpl = S(2, a + o.zp + o.xm), Wjmkp = S(2, a + o.ym + o.zp);
-        const float MU = (m & 1u) ? vmU[a] : -1.0f, MV = (m & 2u) ? vmV[a] : -1.0f, MW = (m & 4u) ? vmW[a] : -1.0f;
-        Vec<T, 1> yU, yV, yW;
-        T ta = (T)0, tb = (T)0, tc = (T)0;
-#define V1F(x_) Vec<float, 1>{{x_}}
-#define V1T(x_) Vec<T, 1>{{x_}}
-        d_visc_rows<T, 1, true, EPI_SPMV>(V1F(MU), V1F(MV), V1F(MW), V1F(C0), V1F(Cjm), V1F(Ckm), V1F(EW0), V1F(EWjp), V1F(EV0), V1F(EVkp), V1F(EU0), V1F(EUjp),
-                                         V1F(EUkp), V1T(U0), V1T(Ujm), V1T(Ujp), V1T(Ukm), V1T(Ukp), V1T(V0), V1T(Vjm), V1T(Vjp), V1T(Vkm), V1T(Vkp), V1T(W0),
-                                         V1T(Wjm), V1T(Wjp), V1T(Wkm), V1T(Wkp), V1T(Vjpkm), V1T(Wjmkp), V1T(RU), V1T(RV), V1T(RW), C0l, EW0r, EV0r, U0l, U0r, V0l,
-                                         V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr, yU, yV, yW, ta, tb, tc, (T)0);
-#undef V1F
-#undef V1T
-        da += (double)ta; db += (double)tb; dc += (double)tc;
-        const T rn[3] = {RU, RV, RW}, sn[3] = {U0, V0, W0}, qn[3] = {yU.v[0], yV.v[0], yW.v[0]};
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            if (!((m >> c) & 1u)) continue;
-            const float d = v.diag[c][a];
-            if (k > 0) v.x[c][a] += alpha * v.s[prv][c][a];
-            v.r[cur][c][a] = rn[c];
-            v.s[cur][c][a] = sn[c];
-            v.q[cur][c][a] = qn[c];
-            if (d != 0.0f) {
-                dsig += (double)((float)rn[c] / d) * (double)rn[c];
-                mx = fmaxf(mx, fabsf((float)rn[c]));
-            }
-        }
-    }
-    // five reductions of the block with one barrier pair
-    {
-        double t0 = wave_sum(dsig), t1 = wave_sum(da), t2 = wave_sum(db), t3 = wave_sum(dc), t4 = wave_max((double)mx);
-        if ((tid & 63) == 0) { const int wv = tid >> 6; red[wv] = t0; red[4 + wv] = t1; red[8 + wv] = t2; red[12 + wv] = t3; red[16 + wv] = t4; }
-        __syncthreads();
-        if (tid == 0) {
-            const int sl = sc.my_slot();
-            const double s0 = red[0] + red[1] + red[2] + red[3], s1 = red[4] + red[5] + red[6] + red[7], s2 = red[8] + red[9] + red[10] + red[11],
-                         s3 = red[12] + red[13] + red[14] + red[15], s4 = fmax(fmax(red[16], red[17]), fmax(red[18], red[19]));
-            if (s0 != 0.0) atomicAdd(sc.sig(k) + sl, s0);
-            if (s1 != 0.0) atomicAdd(sc.a(k) + sl, s1);
-            if (s2 != 0.0) atomicAdd(sc.b(k) + sl, s2);
-            if (s3 != 0.0) atomicAdd(sc.c(k) + sl, s3);
-            if (s4 > 0.0) atomic_max_nonneg(sc.rmax(k) + sl, s4);
-            if (it_arg < 0 && blockIdx.x == 0) cnt[parity ^ 1] = k + 1;
-        }
-    }
-}
+// (One kernel per Jacobi-PCG iteration -- the update of iteration k-1 recomputed on load at the 27 (position, component) pairs of iteration
+// k's SpMV, r / s / q double-buffered: 136 algorithmic bytes per unit instead of 160, one launch instead of two -- was built and measured:
+// identical iterates, 93 us per iteration against 42 at 256^3 (65.7 against 29.1 ms per capped solve), because the stencil loads
+// quadruple (r, q, d next to s at every position: 127 dword loads per lane through L1/L2).  profiles/r3/fused_iteration_ab.log; the code
+// is in the commit that added that file.)
 
 // ------------------------------------------------------------------ residual replacement (group-wise update, van der Vorst & Ye)
 // An fp32 PCG recurrence r -= alpha q drifts away from the true residual b - A x once |r| has dropped a few orders below |b| (here:
@@ -573,72 +435,6 @@ void fv_brick_update(flipv_context *c, const PcgScal &sc, int it) {
 }
 template void fv_brick_update<float>(flipv_context *, const PcgScal &, int);
 template void fv_brick_update<double>(flipv_context *, const PcgScal &, int);
-
-// The fused loop (fp32 vectors): `every` launches + the stop-flag read-back captured into a hipGraph and replayed (pipelined like
-// pcg_run's).  On return *conv_out = index k of the residual that passed (max|r_k|), or -1 when the cap was reached.
-int fv_brick_fused_run(flipv_context *c, const PcgScal &sc, int cap, int *conv_out) {
-    FusedSys<float> v;
-    v.mask = c->vMaskB;
-    v.sby = (int)c->LB.sy * 64; v.sbz = (int)c->LB.sz * 64;
-    v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
-    const size_t half = c->solverCap;   // floats: the second set starts here (an fp64-sized allocation holds 2 x solverCap floats behind its pointer; bricks need no guard zone)
-    for (int m = 0; m < 3; m++) {
-        v.x[m] = (float *)c->vX[m];
-        v.r[1][m] = (float *)c->vR[m]; v.r[0][m] = (float *)c->vR[m] + half;   // launch 0 reads set 1: the right-hand side k_visc_setup left in vR
-        v.s[1][m] = (float *)c->vS[m]; v.s[0][m] = (float *)c->vS[m] + half;
-        v.q[1][m] = (float *)c->vZ[m]; v.q[0][m] = (float *)c->vZ[m] + half;
-    }
-    const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
-    const dim3 g(spmv_grid(c)), b(64, 4, 1);
-    auto launch = [&](int it, int parity) {
-        hipLaunchKernelGGL((k_bpcg_fused<float>), g, b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, parity);
-    };
-    int every = c->prm.check_every > 0 ? c->prm.check_every : 32;
-    every += every & 1;   // even: the device-side counters alternate by launch parity
-    int conv = -1;
-    HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
-    if (!c->prm.kernel_timing && !c->prm.no_graph_replay) {
-        hipGraph_t gr = nullptr;
-        hipGraphExec_t ge = nullptr;
-        HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int e = 0; e < every; e++) launch(-1, e & 1);
-        hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        hipError_t e2 = hipStreamEndCapture(c->stream, &gr);
-        if (e1 != hipSuccess || e2 != hipSuccess || !gr) { if (gr) (void)hipGraphDestroy(gr); c->err = "fused PCG: stream capture failed"; return FLIPV_ERR_HIP; }
-        int rc = fv_graph_exec(c, FV_GE_VISCOSITY, gr, &ge);
-        if (rc) { (void)hipGraphDestroy(gr); return rc; }
-        hipEvent_t ev[2] = {c->evPoll[0], c->evPoll[1]};
-        int slot = 0, pending = -1;
-        bool bad = false;
-        for (int done = 0; done < cap && conv < 0; done += every) {
-            bad = bad || hipGraphLaunch(ge, c->stream) != hipSuccess || hipEventRecord(ev[slot], c->stream) != hipSuccess;
-            if (pending >= 0) { bad = bad || hipEventSynchronize(ev[pending]) != hipSuccess; conv = c->h_flags[0]; }
-            if (bad) break;
-            pending = slot;
-            slot ^= 1;
-        }
-        bad = bad || hipStreamSynchronize(c->stream) != hipSuccess;
-        (void)hipGraphDestroy(gr);
-        if (bad) { c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
-        conv = c->h_flags[0];
-    } else {
-        for (int it = 0; it < cap && conv < 0;) {
-            const int stop = it + every < cap ? it + every : cap;
-            for (; it < stop; it++) launch(it, it & 1);
-            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            conv = c->h_flags[0];
-        }
-    }
-    if (conv < 0) {   // cap reached: the last launch's residual has not been tested yet
-        hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, cap - 1);
-        HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        conv = c->h_flags[0];
-    }
-    *conv_out = conv;
-    return FLIPV_OK;
-}
 
 // the multigrid's fine-level sweeps (fp32): out = in + omega (r - A in)/d (epi 1; 3 also adds (r, out) into sig(it + sig_shift)), out = r - A in (epi 2)
 void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift) {

@@ -136,11 +136,9 @@ typedef struct flipv_params {
                                     A-conjugate) and lets the SpMV skip the residual: 5-7 % faster per iteration, but on
                                     ill-conditioned systems (nu dt/dx^2 ~ 2e3: the rod + sheet scene at nu = 50) the fp32
                                     solve stagnates.  sigma itself is recomputed from the stored vectors every iteration either way. */
-    int two_kernel_pcg;          /* 1: the diagonally preconditioned viscosity loop in the brick layout runs as SpMV + update (two launches per
-                                    iteration) instead of the fused single kernel (A/B) */
     int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 (default) =
                                     chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
-    int reserved[3];             /* must be 0 */
+    int reserved[4];             /* must be 0 */
 } flipv_params;
 
 typedef struct flipv_solve_info {
