@@ -133,7 +133,10 @@ __global__ void k_halo_dirs(HaloSet hs, Lay L, DirSet D, char *__restrict__ stag
                 // cell from up to seven neighbours, each handled by another blockIdx.y): combine atomically
                 if (!recv) *p = *g;
                 else if (mode == 1) *g = *p;
-                else if (mode == 2) { const float v = *p; if (v >= 0.0f) atomicMin((int *)g, __float_as_int(v)); else atomicMax((unsigned *)g, __float_as_uint(v)); }
+                else if (mode == 2) {   // float min through integer atomics: by the SIGN BIT (-0.0f must not take the signed-int path: its pattern is INT_MIN)
+                    const float v = *p;
+                    if (__float_as_int(v) >= 0) atomicMin((int *)g, __float_as_int(v)); else atomicMax((unsigned *)g, __float_as_uint(v));
+                }
                 else atomicAdd(g, *p);
             } else if (hs.elem[a] == 8) {
                 double *g = (double *)hs.p[a] + c, *p = (double *)st + t;

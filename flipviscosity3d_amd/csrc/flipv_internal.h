@@ -211,7 +211,8 @@ struct flipv_context {
     int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits, [4,5] graph iteration counters, [6] interior tile count, [7] in-domain indices of the listed tiles / 4
     int *h_flags;     // pinned host mirror
     int viscosity_nonzero;  // cached host-side: any viscosity node > 0 (in this rank's box)
-    float viscosity_max = 1.0f;     // largest viscosity node value (the a-priori stiffness estimate nu dt/dx^2 of fv_visc_auto_pick)
+    float viscosity_max = 1.0f;     // largest viscosity node value in this rank's box; viscosity_max_any: over all ranks (the a-priori stiffness
+    float viscosity_max_any = 1.0f; // estimate nu dt/dx^2 of fv_visc_auto_pick; all-reduced at the start of every viscosity solve)
     int viscosity_nonzero_any = 1;  // ... on any rank of the communicator (all-reduced at the start of every viscosity solve)
     int vForceMultigridOnce = 0;    // set while a diagonal solve AUTO picked and that ran into the cap is being repeated with the multigrid
     int vmgSweeps = 16;             // Jacobi sweeps on the multigrid's LDS-resident coarsest level for the current solve (viscosity_solve_t picks)

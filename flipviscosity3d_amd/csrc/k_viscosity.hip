@@ -504,7 +504,7 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
 // Decisions depend on iteration counts only, never on wall-clock times, so a run is reproducible; every path converges to the same
 // tolerance, so what the history changes is the cost of a solve, not its answer beyond solver tolerance.
 static bool fv_visc_auto_pick(const flipv_context *c, float dt) {
-    if ((double)c->viscosity_max * (double)dt / ((double)c->dx * (double)c->dx) <= 64.0) return false;
+    if ((double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx) <= 64.0) return false;
     if (c->vLastPrec == 0) return true;
     const double cap = (double)c->prm.viscosity_max_iterations;
     const double MG_ITER = 7.5, MG_SETUP = 35.0, RATIO = 15.0;
@@ -550,7 +550,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const int rcv = fv_allreduce_max_f32(c, &f);
         if (rcv) return rcv;
         c->viscosity_nonzero_any = f > 0.0f;
-    } else c->viscosity_nonzero_any = c->viscosity_nonzero;
+        float vm = c->viscosity_max;   // (AUTO's stiffness rule must come out the same on every rank)
+        const int rcm = fv_allreduce_max_f32(c, &vm);
+        if (rcm) return rcm;
+        c->viscosity_max_any = vm;
+    } else { c->viscosity_nonzero_any = c->viscosity_nonzero; c->viscosity_max_any = c->viscosity_max; }
     if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
         li.status = 3;
         if (info) *info = li;
@@ -610,7 +614,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool brickOk = !c->comm && !c->isBlock && c->prm.viscosity_lane_width != 2 && forcedLayout != 1 && forcedLayout != 2;
     const bool swzOk = forcedLayout != 1;   // (also under the multigrid: its own kernels address diag / x / r / q / own volumes through sidx, its sweep vectors stay plain)
     // the preconditioner of this solve (the multigrid needs fp32 vectors over a whole, single-rank index space)
-    const bool mgPossible = std::is_same<T, float>::value && !c->comm && !c->isBlock && c->prm.viscosity_lane_width != 2 && !c->vNoMultigridOnce;
+    const bool mgPossible = std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && !c->vNoMultigridOnce;   // (block contexts too: a rank-local hierarchy, k_viscosity_mg.hip)
     const bool mgPlanned = mgPossible && (c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || c->vForceMultigridOnce ||
                                           (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && fv_visc_auto_pick(c, dt)));
     if (mgPossible && c->prm.viscosity_preconditioner != FLIPV_PRECOND_DIAGONAL && !c->vmgState) {
@@ -622,7 +626,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // iterations -- the extra sweeps only cost): 64 sweeps while nu dt/dx^2 > 1000 and the previous multigrid solve needed more than 60
     // iterations (or there is none yet), 16 otherwise.  Iteration counts only, never timings.
     {
-        const double stiff = (double)c->viscosity_max * (double)dt / ((double)c->dx * (double)c->dx);
+        const double stiff = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
         c->vmgSweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2
                        : ((stiff > 1000.0 && (c->vLastPrec != 2 || c->vLastIts > 60)) ? 64 : 16);
     }
@@ -752,7 +756,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const bool useMg = mgPlanned && c->vwV == 4;
         li.preconditioner = useMg ? 1 : 0;
         ranMg = useMg;
-        c->vOperatorExact = (refDiag && !(staged && useMg)) ? 0 : 1;   // the operator the PCG loop applies (and the multigrid hierarchy is built from)
+        // the operator the PCG loop applies (and the multigrid hierarchy is built from): under the multigrid always the exact one -- with the defect
+        // correction towards the reference's around it where that exists (fp32 bricks), without it on the plane layouts (block contexts)
+        c->vOperatorExact = (refDiag && !useMg) ? 0 : 1;
         if (useAcc) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
         int itersDone = 0, corrections = 0;
         bool correctionDue = false;

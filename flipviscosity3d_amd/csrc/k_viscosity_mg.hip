@@ -28,6 +28,7 @@
 #include "flipv_internal.h"
 #include "pcg_common.h"
 #include "brick.h"
+#include "flipv_comm.h"
 
 #include <vector>
 
@@ -299,7 +300,7 @@ __device__ __forceinline__ void d_rap_gather_child_fine(const FineOp &A, const L
     constexpr int t1 = (C + 1) % 3, t2 = (C + 2) % 3;
     int p[3];
     p[C] = 2 * I[C] + DN; p[t1] = 2 * I[t1] + A_; p[t2] = 2 * I[t2] + B_;
-    if (!d_in_lattice(L, C, p)) return;
+    if (!d_in_lattice(L, C, p) || !d_owned(L, p[0], p[1], p[2])) return;   // rows are the rank's own (block contexts: what lies beyond is a neighbour's, or not allocated at all)
     const size_t ci = A.brick ? bidx(A.LB, p[0], p[1], p[2]) : gidx(L, p[0], p[1], p[2]);
     FineChild f;
     f.m = A.mask[ci];
@@ -409,7 +410,8 @@ __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const
             for (int b = 0; b < 2; b++) {
                 int q[3];
                 q[C] = 2 * P[C] + dn; q[t1] = 2 * P[t1] + a; q[t2] = 2 * P[t2] + b;
-                if (d_in_lattice(F, C, q)) s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][FINE0 == 1 ? gidx(F, q[0], q[1], q[2]) : (FINE0 == 2 ? bidx(F, q[0], q[1], q[2]) : cidx(F, q[0], q[1], q[2]))];
+                if (d_in_lattice(F, C, q) && (FINE0 != 1 || d_owned(F, q[0], q[1], q[2])))   // (level 0 of a block context: only the rank's own indices are rows -- or allocated at all)
+                    s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][FINE0 == 1 ? gidx(F, q[0], q[1], q[2]) : (FINE0 == 2 ? bidx(F, q[0], q[1], q[2]) : cidx(F, q[0], q[1], q[2]))];
             }
     return s;
 }
@@ -967,7 +969,12 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         Box3 fb;
         const int ext0[3] = {c->L.I + 1, c->L.J + 1, c->L.K + 1};
-        for (int a = 0; a < 3; a++) { fb.lo[a] = hb[a] < 0 ? 0 : hb[a]; fb.hi[a] = hb[3 + a] > ext0[a] ? ext0[a] : hb[3 + a]; if (fb.hi[a] <= fb.lo[a]) { fb.lo[a] = 0; fb.hi[a] = 1; } }
+        for (int a = 0; a < 3; a++) {   // (tiles hang over the end of the lattices and, on a block context, of the rank's own box: the rows do not)
+            fb.lo[a] = hb[a] < c->L.olo[a] ? c->L.olo[a] : hb[a];
+            fb.hi[a] = hb[3 + a] > ext0[a] ? ext0[a] : hb[3 + a];
+            if (fb.hi[a] > c->L.ohi[a]) fb.hi[a] = c->L.ohi[a];
+            if (fb.hi[a] <= fb.lo[a]) { fb.lo[a] = c->L.olo[a]; fb.hi[a] = c->L.olo[a] + 1; }
+        }
         for (size_t l = 0; l < s->lev.size(); l++) {
             VLevel &A = s->lev[l];
             const int ext[3] = {A.L.I + 1, A.L.J + 1, A.L.K + 1};
@@ -1103,26 +1110,36 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     };
     if (!brick) replace_period = 0;
     HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
+    // Block contexts: every rank cycles the hierarchy of ITS rows with the couplings across the cut faces dropped (its sweep vectors are
+    // zero on the halo) and without any exchange -- a block-diagonal, symmetric positive definite preconditioner, like the pressure
+    // multigrid's; the CG around it applies the true operator (halo copy of p before the SpMV) and all-reduces its scalars.
+    const HaloArray ph[3] = {{p[0], sizeof(float)}, {p[1], sizeof(float)}, {p[2], sizeof(float)}};
     XR(-1);                       // za = omega r/d
     vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)
+    if (c->comm && (rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     PP(-1);                       // p = z
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
     int conv = -1;
-    auto iteration = [&](int it, bool replace) {   // it = IT_DEVICE inside the graph
+    auto iteration = [&](int it, bool replace) -> int {   // it = IT_DEVICE inside the graph
+        int r2;
+        if (c->comm && (r2 = fv_halo_copy(c, ph, 3, 1))) return r2;                                  // p on the neighbours' halo entries
         spmv(c, sc, it == IT_DEVICE ? -1 : it);
+        if (c->comm && (r2 = fv_allreduce_scalars(c, sc.a(it), NSLOT))) return r2;                    // p.q
         XR(it);
         if (replace) fv_brick_replace<float>(c, sc, it == IT_DEVICE ? -1 : it, replace_period, 0, s->za, VMG_OMEGA);
         vmg_vcycle(c, s, sc, it, 1);
+        if (c->comm && (r2 = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return r2;             // max|r| of this iteration, (r, z) of the next
         PP(it);
+        return FLIPV_OK;
     };
     // where in a chunk of `every` iterations a replacement can fall due (the kernels decide exactly, from the iteration number)
     auto may_replace = [&](int e) { return replace_period > 0 && ((e + 1) % (replace_period < every ? replace_period : every)) == 0; };
-    const bool graph = !c->prm.kernel_timing && !c->prm.no_graph_replay;
+    const bool graph = !c->comm && !c->prm.kernel_timing && !c->prm.no_graph_replay;
     if (graph) {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-        for (int e = 0; e < every; e++) iteration(IT_DEVICE, may_replace(e));
+        for (int e = 0; e < every; e++) (void)iteration(IT_DEVICE, may_replace(e));
         hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
         if (e1 != hipSuccess || e2 != hipSuccess || !g) {
@@ -1142,7 +1159,8 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         int it = 0;
         while (it < cap && conv < 0) {
             const int stop = it + every < cap ? it + every : cap;
-            for (; it < stop; it++) iteration(it, may_replace(it % every));
+            for (; it < stop; it++)
+                if ((rc = iteration(it, may_replace(it % every)))) return rc;
             HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             conv = c->h_flags[0];

@@ -267,9 +267,12 @@ bool FluidSimulation::loadState(const std::string &path) {
         int dims[3], kind = 0, hasVel = 0;
         float dx = 0, g[3], nu = 0;
         unsigned long long np = 0;
-        bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "FLIPVCK2", 8) == 0 && std::fread(dims, sizeof(int), 3, f) == 3 &&
-                  std::fread(&dx, sizeof(float), 1, f) == 1 && std::fread(g, sizeof(float), 3, f) == 3 && std::fread(&kind, sizeof(int), 1, f) == 1 &&
-                  std::fread(&nu, sizeof(float), 1, f) == 1 && std::fread(&np, sizeof(np), 1, f) == 1 && std::fread(&hasVel, sizeof(int), 1, f) == 1;
+        // "FLIPVCK1" (the previous layout) is the same file without the hasVelocity word and the MAC field: still loadable
+        bool ok = std::fread(magic, 1, 8, f) == 8 && (std::memcmp(magic, "FLIPVCK2", 8) == 0 || std::memcmp(magic, "FLIPVCK1", 8) == 0);
+        const bool v1 = ok && std::memcmp(magic, "FLIPVCK1", 8) == 0;
+        ok = ok && std::fread(dims, sizeof(int), 3, f) == 3 &&
+             std::fread(&dx, sizeof(float), 1, f) == 1 && std::fread(g, sizeof(float), 3, f) == 3 && std::fread(&kind, sizeof(int), 1, f) == 1 &&
+             std::fread(&nu, sizeof(float), 1, f) == 1 && std::fread(&np, sizeof(np), 1, f) == 1 && (v1 || std::fread(&hasVel, sizeof(int), 1, f) == 1);
         const int maxDim = 1 << 14;  // (2^14+1)^3 nodes still fit a size_t product by a wide margin
         ok = ok && dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[0] <= maxDim && dims[1] <= maxDim && dims[2] <= maxDim &&
              dx > 0 && (kind == 0 || kind == 1) && nu >= 0 && (hasVel == 0 || hasVel == 1);

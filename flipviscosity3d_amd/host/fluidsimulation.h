@@ -62,8 +62,11 @@ public:
     // Checkpoint (the reference cannot stop and resume a run): grid size, cell width, gravity, viscosity,
     // solid SDF, the particles (positions + velocities) and the MAC velocity field of the last substep -- _cfl() of the
     // next frame reads it (reference fluidsimulation.cpp:139, 241-269) -- in one little-endian binary file.  loadState()
-    // re-initialises the simulation from the file; a run resumed from a checkpoint takes the same substeps as the
-    // uninterrupted one.  Both return false on I/O or format errors (a header that does not match the file length included).
+    // re-initialises the simulation from the file; a run resumed from a checkpoint takes the same substeps (the same CFL steps from the
+    // same particles and MAC field) as the uninterrupted one.  What the library's solvers remember between solves -- the AUTO viscosity
+    // preconditioner's iteration history, the solver array layout -- is NOT in the file and need not be: every path AUTO can take converges to
+    // the same tolerance, so a resumed run's velocities agree with the uninterrupted run's to solver tolerance, not bit for bit.
+    // Both return false on I/O or format errors (a header that does not match the file length included).
     bool saveState(const std::string &path);
     bool loadState(const std::string &path);
     void setQuiet(bool q) { _quiet = q; }                  // the reference prints phase banners on stdout
