@@ -213,7 +213,6 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
     memset(c->h_flags, 0, 16 * sizeof(int));
     // solver tiles over the shared index space
-    // the geometry is chosen per solve (fv_build_tiles); FLIPV_ROWL = 16 | 64 pins it (tests, A/B measurements)
     // the geometry is chosen per solve (fv_build_tiles); flipv_params.tile_rows pins it
     c->tgP = make_tile_grid(L, 64, VW_P);
     c->tgV = make_tile_grid(L, 64, VW_V);

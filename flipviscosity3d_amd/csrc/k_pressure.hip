@@ -389,11 +389,14 @@ static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, in
     if (timed) fv_ev_begin(c, 0, (double)count * (256 * VW_P));
 #define PSPMV(D) GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pressure_spmv<T, D>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP + first, count, c->tgP, c->L, \
                        c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, c->mlistP ? c->mlistP + (size_t)first * 256 : (const unsigned *)nullptr, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it))
-#define PMARCH(D) GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pressure_spmv_march<T, D>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsP, c->nRunsP, (const unsigned *)c->rmaskP, c->tgP, c->L, \
+#define PMARCH(D, S) GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pressure_spmv_march<T, D, S>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsP, c->nRunsP, (const unsigned *)c->rmaskP, c->tgP, c->L, \
                        c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it))
     if (c->nRunsP > 0 && first == 0 && count == c->nActiveP) {   // k-marching over the run list (the whole system)
         const int nbm = pcg_grid(c, c->nRunsP);
-        if (dots == 2) PMARCH(2); else if (dots == 1) PMARCH(1); else PMARCH(0);
+        // streaming accesses once the system's 25 bytes per cell exceed the memory-side cache (ldvs, pcg_common.h)
+        const bool stream = (double)c->nActiveP * (256 * VW_P) * 25.0 > 256.0 * 1024 * 1024;
+        if (stream) { if (dots == 2) PMARCH(2, true); else if (dots == 1) PMARCH(1, true); else PMARCH(0, true); }
+        else if (dots == 2) PMARCH(2, false); else if (dots == 1) PMARCH(1, false); else PMARCH(0, false);
     } else if (dots == 2) PSPMV(2); else if (dots == 1) PSPMV(1); else PSPMV(0);
 #undef PSPMV
 #undef PMARCH

@@ -71,6 +71,30 @@ __device__ __forceinline__ void stv(double *__restrict__ p, const Vec<double, 2>
     *reinterpret_cast<double2 *>(p) = make_double2(r.v[0], r.v[1]);
 }
 
+// Streaming variants: the nontemporal hint of the load / store instruction, for arrays a kernel touches exactly once when the system
+// is larger than the 256 MB memory-side cache (measured, filled 256^3 box: pressure SpMV 82 -> 66 us; on systems that fit the cache the
+// hint costs 1-2 %, tools/micro/stream_mix.hip and DESIGN.md section 5)
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+template <bool STREAM, int N, typename S> __device__ __forceinline__ Vec<S, N> ldvs(const S *__restrict__ p) {
+    if constexpr (sizeof(S) == 4 && STREAM) {
+        Vec<S, N> r;
+        if constexpr (N == 4) { const nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4 *>(p)); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+        else { const nt_f2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f2 *>(p)); r.v[0] = t.x; r.v[1] = t.y; }
+        return r;
+    } else {
+        return ldv<N>(p);
+    }
+}
+template <bool STREAM, int N, typename S> __device__ __forceinline__ void stvs(S *__restrict__ p, const Vec<S, N> &r) {
+    if constexpr (sizeof(S) == 4 && STREAM) {
+        if constexpr (N == 4) { nt_f4 t; t.x = r.v[0]; t.y = r.v[1]; t.z = r.v[2]; t.w = r.v[3]; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4 *>(p)); }
+        else { nt_f2 t; t.x = r.v[0]; t.y = r.v[1]; __builtin_nontemporal_store(t, reinterpret_cast<nt_f2 *>(p)); }
+    } else {
+        stv(p, r);
+    }
+}
+
 // 1/d for the preconditioned dot products: hardware reciprocal (1 ulp) with fp32 vectors, a division with fp64 vectors
 template <typename T> __device__ __forceinline__ T d_recip(float d);
 template <> __device__ __forceinline__ float d_recip<float>(float d) { return __builtin_amdgcn_rcpf(d); }

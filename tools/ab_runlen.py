@@ -1,5 +1,5 @@
 """Scan of the k-marching run length (flipv_params.spmv_run_length; -1 = tile-at-a-time kernels) and the tile geometry:
-    python tools/ab_runlen.py bench|dense [N] -- <runlen> [<runlen> ...]
+    python tools/ab_runlen.py bench|dense [N] [--tile-rows 16|64] -- <runlen> [<runlen> ...]
 bench: the 256^3 bunny scene (sparse liquid), third substep's solve times + back-to-back SpMV launch times.
 dense: filled N^3 box, back-to-back SpMV launch times and algorithmic GB/s (24 B / 52 B per unit)."""
 import os
@@ -11,14 +11,15 @@ from flipviscosity3d_amd.capi import Context
 mode = sys.argv[1]
 N = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "--" else 256
 vals = [int(a) for a in sys.argv[sys.argv.index("--") + 1:]]
-tag = "ROWL=%s" % os.environ.get("FLIPV_ROWL", "auto")
+ROWL = int(sys.argv[sys.argv.index("--tile-rows") + 1]) if "--tile-rows" in sys.argv else 0
+tag = "tile_rows=%s" % (ROWL or "auto")
 if mode == "bench":
     from bench import build_scene
     dx, solid, P = build_scene(N, 5.0)
     for rl in vals:
         c = Context(N, N, N, dx)
         c.set_solid_sdf(solid); c.set_viscosity(5.0); c.particles = P
-        c.set_params(spmv_run_length=rl)
+        c.set_params(spmv_run_length=rl, tile_rows=ROWL)
         for t in range(3):
             st = c.substep(min(c.cfl(), 0.01))
         vms, _ = c.bench_spmv(1, 200)
@@ -36,7 +37,7 @@ else:
     for rl in vals:
         c = Context(N, N, N, dx)
         c.set_solid_sdf(solid); c.set_viscosity(5.0)
-        c.set_params(pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4, spmv_run_length=rl)
+        c.set_params(pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4, spmv_run_length=rl, tile_rows=ROWL)
         c.set_grid("LIQUID_PHI", np.full((N, N, N), -0.5 * dx, np.float32))
         for n in "UVW":
             c.set_grid(n, uvw[n])
