@@ -621,14 +621,15 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const int prc = fv_vmg_prepare(c);   // allocate the hierarchy now, whichever solve first uses it
         if (prc) return prc;
     }
-    // How accurately the coarsest (16^3) level is solved only matters while the system is stiff (bunny 256^3, mean iterations
-    // over the stiff stretch 108 with 16 sweeps, 77 with 64, each sweep ~1 us of a ~250 us iteration; once the liquid moves -- 17-50
-    // iterations -- the extra sweeps only cost): 64 sweeps while nu dt/dx^2 > 1000 and the previous multigrid solve needed more than 60
-    // iterations (or there is none yet), 16 otherwise.  Iteration counts only, never timings.
+    // How accurately the coarsest (16^3) level is solved only matters while the system is stiff (bunny 256^3, 12 substeps from
+    // rest, iterations summed: 2303 / 2005 / 1720 / 1476 / 1366 / 1363 with 8 / 16 / 32 / 64 / 128 / 256 Jacobi sweeps, each ~1 us of a
+    // ~300 us iteration; with Chebyshev weights -- k_viscosity_mg.hip: VMG_CHEB_KAPPA -- 8 / 16 / 32 sweeps do what 32 / 64 / 256 did):
+    // 32 sweeps while nu dt/dx^2 > 1000 and the previous multigrid solve needed more than 60 iterations (or there is none yet), 16
+    // otherwise.  Iteration counts only, never timings.  A power of two selects the Chebyshev weights, any other count plain damped Jacobi.
     {
         const double stiff = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
         c->vmgSweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2
-                       : ((stiff > 1000.0 && (c->vLastPrec != 2 || c->vLastIts > 60)) ? 64 : 16);
+                       : ((stiff > 1000.0 && (c->vLastPrec != 2 || c->vLastIts > 60)) ? 32 : 16);
     }
     const int precNow = std::is_same<T, float>::value ? 0 : 1;
     // flipv_params.exact_viscosity_operator = 0 (default): the solve applies the reference's operator INCLUDING the rounding of its float

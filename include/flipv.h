@@ -115,7 +115,9 @@ typedef struct flipv_params {
                                     wherever they are available */
     int tile_rows;               /* 16 | 64: pins the tile geometry of the plane-layout kernels (lanes of a wave along i); 0 = chosen per
                                     solve from how full the tiles are */
-    int viscosity_mg_coarsest_sweeps; /* Jacobi sweeps on the LDS-resident coarsest level of the viscosity multigrid; 0 = 16 */
+    int viscosity_mg_coarsest_sweeps; /* sweeps on the LDS-resident coarsest level of the viscosity multigrid: a power of two (4..64) = that many
+                                    Chebyshev-weighted Jacobi sweeps, any other count = plain damped Jacobi sweeps; 0 = chosen per solve (32 while
+                                    nu dt/dx^2 > 1000 and the last multigrid solve needed more than 60 iterations, else 16) */
     int viscosity_mg_min_dim;    /* the viscosity hierarchy stops at the level whose longest axis is <= this many cells; 0 = 16 */
     int pressure_mg_coarsest_sweeps; /* 0 = 8 */
     float pressure_mg_omega;     /* damping of the pressure multigrid's Jacobi sweeps; 0 = 0.9 */
@@ -138,7 +140,9 @@ typedef struct flipv_params {
                                     solve stagnates.  sigma itself is recomputed from the stored vectors every iteration either way. */
     int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 (default) =
                                     chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
-    int reserved[4];             /* must be 0 */
+    float viscosity_mg_omega_first;  /* damping of the first and of the second Jacobi sweep of the viscosity multigrid's V(2,2) smoother (pre- and */
+    float viscosity_mg_omega_second; /* post-smoothing use the same pair); 0 = the defaults (k_viscosity_mg.hip: VMG_W) */
+    int reserved[2];             /* must be 0 */
 } flipv_params;
 
 typedef struct flipv_solve_info {
