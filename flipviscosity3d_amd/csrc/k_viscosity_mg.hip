@@ -49,7 +49,10 @@ constexpr float VMG_W_DEFAULT[2] = {1.317f, 0.382f};   // the roots of the degre
 // (a sweep is ~1 us: 69 LDS reads per thread, bound by one CU's LDS bandwidth).
 // (the table cos(pi (2 j_k + 1) / (2 m)), k = 0..m-1, travels in the coarsest level's descriptor: VLevelDev::cheb)
 constexpr float VMG_LAMBDA_MAX = 3.3f;
-constexpr float VMG_CHEB_KAPPA = 100.0f;
+#ifndef VMG_KAPPA
+#define VMG_KAPPA 100.0f
+#endif
+constexpr float VMG_CHEB_KAPPA = VMG_KAPPA;
 constexpr int VMG_COARSEST_SWEEPS = 16;   // even: the sweeps ping-pong between x and y and must end in x
 constexpr int VMG_MIN_DIM = 16;           // no level below this many cells along the longest axis
 constexpr int VMG_TAIL_POS = 640;         // levels with at most this many index positions in their box go into the single-workgroup tail
@@ -667,7 +670,8 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
         d_coarsest_load<1>(A, F, ft, fine0, rowlist[1], cnt[1], W, H, RV, xs, NP);
         d_coarsest_load<2>(A, F, ft, fine0, rowlist[2], cnt[2], W, H, RW, xs, NP);
         // weights: Chebyshev on [hi / kappa, hi] when `cheb`, the fixed damping otherwise; the first one turns the zero guess into x = omega b/d
-        float mid = 0.0f, half = 0.0f;
+        float wlane = VMG_OMEGA;    // lane k of every wave holds sweep k's weight; a sweep reads its weight with v_readlane (a load from the level
+                                    // descriptor per sweep sits on the critical path: +0.75 us per sweep; a broadcast LDS read: +0.3 us)
         if (cheb) {
             __shared__ float gmax[16];
             float g = fmaxf(RU.gersh, fmaxf(RV.gersh, RW.gersh));
@@ -679,9 +683,9 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
 #pragma unroll
             for (int w = 1; w < 16; w++) g = fmaxf(g, gmax[w]);
             const float hi = fminf(g, VMG_LAMBDA_MAX), lo = hi / VMG_CHEB_KAPPA;
-            mid = 0.5f * (hi + lo); half = 0.5f * (hi - lo);
+            wlane = 1.0f / (0.5f * (hi + lo) + 0.5f * (hi - lo) * A.cheb[threadIdx.x & 63]);
         }
-        auto weight = [&](int k) { return cheb ? 1.0f / (mid + half * A.cheb[k]) : VMG_OMEGA; };
+        auto weight = [&](int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wlane), k)); };
         {
             const float w0 = weight(0);
             if (RU.has) xs[0 * NP + RU.li] = w0 * RU.b * RU.invd;
