@@ -197,22 +197,34 @@ def cpu_baseline_all_cores(viscosity, budget_size, threads):
     kind "port"), run as a child process with OMP_NUM_THREADS = `threads` on the same bounded sample.  What the reference's algorithm
     makes sequential (MIC(0)'s triangular solves) stays sequential, so this is Amdahl-bound by construction."""
     import subprocess
-    env = dict(os.environ)
-    env["OMP_NUM_THREADS"] = str(threads)
-    env["OMP_PROC_BIND"] = "close"
-    try:
-        p = subprocess.run([sys.executable, "-m", "oracle.omp_baseline", str(budget_size), "2" if budget_size < 256 else "1", repr(viscosity)], cwd=ROOT, env=env,
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
-        line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-        if p.returncode != 0 or not line:
-            return {"error": p.stderr.decode()[-400:]}
-        out = json.loads(line[-1])
-        out["sample"] = "same scene at %d^3, mean of %d substeps of 0.01 s from rest, OpenMP build of the C restatement on %d threads, %.2f s per substep" % (
-            out["size"], out["substeps"], out["cores"], out["seconds_per_substep"])
-        out["host_cpus"] = os.cpu_count()
-        return out
-    except Exception as e:   # (the baseline must never take the bench line down)
-        return {"error": repr(e)}
+    best, tried = None, {}
+    # (more threads are not faster here: the sequential sweeps pull every vector back into one core's cache each iteration; measured 64^3,
+    # 8-CPU container: 0.80 s on 1 thread, 0.58 on 4, 1.4-1.8 on 8.  Two counts are run, the better one is reported, both are listed)
+    for thr in sorted({min(threads, 8), threads}):
+        env = dict(os.environ)
+        env["OMP_NUM_THREADS"] = str(thr)
+        env["OMP_PROC_BIND"] = "close"
+        env["OMP_WAIT_POLICY"] = "active"
+        try:
+            p = subprocess.run([sys.executable, "-m", "oracle.omp_baseline", str(budget_size), "2" if budget_size < 256 else "1", repr(viscosity)], cwd=ROOT, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500)
+            line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                tried[str(thr)] = {"error": p.stderr.decode()[-400:]}
+                continue
+            out = json.loads(line[-1])
+            tried[str(thr)] = round(out["value"], 4)
+            if best is None or out["value"] > best["value"]:
+                best = out
+        except Exception as e:   # (the baseline must never take the bench line down)
+            tried[str(thr)] = {"error": repr(e)}
+    if best is None:
+        return {"error": tried}
+    best["sample"] = "same scene at %d^3, mean of %d substeps of 0.01 s from rest, OpenMP build of the C restatement on %d threads, %.2f s per substep" % (
+        best["size"], best["substeps"], best["cores"], best["seconds_per_substep"])
+    best["MCells_per_s_by_threads"] = tried
+    best["host_cpus"] = os.cpu_count()
+    return best
 
 
 def main():
