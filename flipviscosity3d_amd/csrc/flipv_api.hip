@@ -363,7 +363,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         const int rcT = fv_check_block_thickness(c, p->cfl_number, "flipv_set_params");
         if (rcT) return rcT;
     }
-    for (int r = 0; r < 2; r++)
+    for (int r = 0; r < 1; r++)
         if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
     c->prm = *p;
     return FLIPV_OK;

@@ -30,6 +30,7 @@ struct Comm {
     virtual int sendrecv(flipv_context *c, int peer, const void *sendbuf, size_t sbytes, void *recvbuf, size_t rbytes) = 0;
     virtual int end(flipv_context *c) = 0;     // close the group: after it returns the operations are enqueued
     virtual int allreduce_sum(flipv_context *c, double *dev, size_t n) = 0;
+    virtual int allreduce_sum_f32(flipv_context *c, float *dev, size_t n) = 0;   // same result on every rank (the viscosity multigrid's global levels rely on it)
     virtual int barrier(flipv_context *c) = 0;
 };
 
@@ -41,6 +42,7 @@ int fv_halo_wait(flipv_context *c);                                             
 enum { HALO_MIN_F32 = 0, HALO_ADD_F32 = 1 };
 int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op);
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n);
+int fv_allreduce_f32(flipv_context *c, float *dev, size_t n);    // in-place sum over the ranks, on c->stream
 int fv_migrate_particles(flipv_context *c);
 int fv_allreduce_max_f32(flipv_context *c, float *value);  // host value in/out (synchronises)
 // thinnest slab a multi-rank run accepts: the widest exchange moves ceil(cfl) + 3 of a rank's own planes

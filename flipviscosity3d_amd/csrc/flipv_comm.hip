@@ -293,6 +293,12 @@ int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n) {
     return cm->allreduce_sum(c, dev, n);
 }
 
+int fv_allreduce_f32(flipv_context *c, float *dev, size_t n) {
+    Comm *cm = c->comm;
+    if (!cm || n == 0) return FLIPV_OK;
+    return cm->allreduce_sum_f32(c, dev, n);
+}
+
 int fv_allreduce_max_f32(flipv_context *c, float *value) {
     Comm *cm = c->comm;
     if (!cm) return FLIPV_OK;
@@ -420,8 +426,8 @@ bool rccl_load(std::string *err) {
     return true;
 }
 
-// RCCL enum values (rccl.h): ncclInt8/ncclChar = 0, ncclFloat64/ncclDouble = 8, ncclSum = 0
-constexpr int NCCL_CHAR = 0, NCCL_DOUBLE = 8, NCCL_SUM = 0;
+// RCCL enum values (rccl.h): ncclInt8/ncclChar = 0, ncclFloat32/ncclFloat = 7, ncclFloat64/ncclDouble = 8, ncclSum = 0
+constexpr int NCCL_CHAR = 0, NCCL_FLOAT = 7, NCCL_DOUBLE = 8, NCCL_SUM = 0;
 
 struct RcclComm : Comm {
     ncclComm_t_ comm = nullptr;
@@ -440,6 +446,9 @@ struct RcclComm : Comm {
     int end(flipv_context *c) override { return chk(c, g_rccl.GroupEnd(), "ncclGroupEnd"); }
     int allreduce_sum(flipv_context *c, double *dev, size_t n) override {
         return chk(c, g_rccl.AllReduce(dev, dev, n, NCCL_DOUBLE, NCCL_SUM, comm, c->stream), "ncclAllReduce");
+    }
+    int allreduce_sum_f32(flipv_context *c, float *dev, size_t n) override {
+        return chk(c, g_rccl.AllReduce(dev, dev, n, NCCL_FLOAT, NCCL_SUM, comm, c->stream), "ncclAllReduce(float)");
     }
     int barrier(flipv_context *c) override {
         int rc = allreduce_sum(c, c->d_scal_small + 32, 1);
@@ -460,6 +469,7 @@ struct LocalGroup {
     struct Op { int peer; const void *sb; size_t sbytes; void *rb; size_t rbytes; };
     std::vector<std::vector<Op>> ops;
     std::vector<std::vector<double>> red;
+    std::vector<std::vector<float>> redf;
     void wait() {
         std::unique_lock<std::mutex> lk(m);
         const unsigned long long g = generation;
@@ -514,6 +524,22 @@ struct LocalComm : Comm {
             for (size_t t = 0; t < n; t++) sum[t] += g->red[r][t];
         g->wait();  // everybody has read every contribution
         HIPCHK(c, hipMemcpyAsync(dev, sum.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return FLIPV_OK;
+    }
+    int allreduce_sum_f32(flipv_context *c, float *dev, size_t n) override {
+        std::vector<float> &h = g->redf[rank];
+        h.resize(n);
+        HIPCHK(c, hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        g->wait();
+        std::vector<float> sum(g->redf[0]);   // rank order on every rank: bitwise the same result everywhere
+        for (int r = 1; r < g->n; r++) {
+            const float *q = g->redf[r].data();
+            for (size_t t = 0; t < n; t++) sum[t] += q[t];
+        }
+        g->wait();  // everybody has read every contribution
+        HIPCHK(c, hipMemcpyAsync(dev, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return FLIPV_OK;
     }
@@ -610,6 +636,7 @@ extern "C" int flipv_comm_init_local_grid(flipv_context **ctxs, const int *dims)
     g->n = n; g->refs = n;
     g->ops.resize((size_t)n);
     g->red.resize((size_t)n);
+    g->redf.resize((size_t)n);
     for (int r = 0; r < n; r++) {
         LocalComm *cm = new LocalComm();
         cm->rank = r; cm->nranks = n; cm->g = g;

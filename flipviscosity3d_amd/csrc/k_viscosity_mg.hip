@@ -124,6 +124,7 @@ struct VLevel {          // a coarse level (>= 1)
     Box3 box;
     int *strips = nullptr, *stripFlag = nullptr;   // capacity: the strips of the level's whole index space
     int nstrips = 0;
+    size_t per = 0;          // floats between consecutive grids of the level (coef[m][q + 1] - coef[m][q], b[m + 1] - b[m])
 };
 struct VLevelDev {       // what kernels need of a coarse level
     Lay L;
@@ -404,6 +405,7 @@ enum VmgOp { OP_RESTRICT = 0,   // b = P^T (finer level's t) ; x = omega b/d    
        OP_POST2 = 5,      // x = t + omega (b - A t)/d
        OP_SWEEP_XY = 6,   // y = x + omega (b - A x)/d     (coarsest level)
        OP_SWEEP_YX = 7,   // x = y + omega (b - A y)/d
+       OP_FIRST = 9,      // x = omega b/d from a right-hand side that is already there (the level whose b is summed over the ranks)
        OP_PROPOST = 8 };  // OP_PROLONG and OP_POST1 in one launch: t = y' + omega (b - A y')/d with y' = y + P (coarser level's x) formed at the 23 stencil positions; y itself is not updated
 // (P x)(M, p) for ANY index p of a level (rows or not): along the component's normal an even index has one parent, an odd one the mean of two --
 // written as the mean of parents (p[M] >> 1) and ((p[M] + 1) >> 1), which coincide for even p[M]; across, the parent is p >> 1
@@ -443,6 +445,7 @@ __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, con
         A.x.p[C][ci] = d != 0.0f ? A.w[0] * s / d : 0.0f;
         return;
     }
+    if (OP == OP_FIRST) { A.x.p[C][ci] = d != 0.0f ? A.w[0] * A.b.p[C][ci] / d : 0.0f; return; }
     if (d == 0.0f) return;   // no row: every vector stays 0 here
     if (OP == OP_PROLONG) {
         int Q[2][3];
@@ -520,6 +523,34 @@ __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ 
         else d_vmg_step_c<OP, 0>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
     } else if (OP == OP_PROLONG || OP == OP_PROPOST) d_vmg_step_c<OP, 0>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
     else d_vmg_step_c<OP, 0>(c, A, A.L, ft0, A.L, ft0, i, j, k);
+}
+// b of level l over its whole box from the finer level's residual, without the first sweep: the level whose right-hand side is summed
+// over the ranks (VmgState::globalFrom).  Grid: (ceil(w / 64), ceil(h / 4), 3 depth), block (64, 4)
+template <int C, int FINE0>
+__device__ __forceinline__ void d_restrict_only(const VLevelDev &A, const Lay &F, const Vec3p &ft, int i, int j, int k) {
+    const size_t ci = cidx(A.L, i, j, k);
+    const int P[3] = {i, j, k};
+    A.b.p[C][ci] = A.coef[C][slot_diag(C)][ci] != 0.0f ? d_restrict<C, FINE0>(F, ft, P) : 0.0f;
+}
+// box-shaped copy between `narr` grids of a level (array a at base + a * per, cidx addressing) and a dense buffer [narr][positions of the box]:
+// what the all-reduces of the global hierarchy move (unpack = 0: grids -> buffer, 1: buffer -> grids)
+__global__ __launch_bounds__(256) void k_vmg_box_pack(Lay L, Box3 B, float *__restrict__ base, size_t per, float *__restrict__ buf, int unpack) {
+    const int w = B.hi[0] - B.lo[0], h = B.hi[1] - B.lo[1], d = B.hi[2] - B.lo[2];
+    const size_t n = (size_t)w * h * d, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int i = B.lo[0] + (int)(t % w), j = B.lo[1] + (int)((t / w) % h), k = B.lo[2] + (int)(t / ((size_t)w * h));
+    float *g = base + (size_t)blockIdx.y * per + cidx(L, i, j, k), *q = buf + (size_t)blockIdx.y * n + t;
+    if (unpack) *g = *q; else *q = *g;
+}
+__global__ __launch_bounds__(256) void k_vmg_restrict_box(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick) {
+    if (*conv >= 0) return;
+    const VLevelDev &A = lev[l];
+    const int i = A.box.lo[0] + (int)(blockIdx.x * 64 + threadIdx.x), j = A.box.lo[1] + (int)(blockIdx.y * 4 + threadIdx.y);
+    const int c = (int)blockIdx.z % 3, k = A.box.lo[2] + (int)blockIdx.z / 3;
+    if (i >= A.box.hi[0] || j >= A.box.hi[1] || k >= A.box.hi[2]) return;
+#define RONLY(C_) do { if (l > 0) d_restrict_only<C_, 0>(A, lev[l - 1].L, lev[l - 1].t, i, j, k); else if (fineBrick) d_restrict_only<C_, 2>(A, F0, ft0, i, j, k); else d_restrict_only<C_, 1>(A, F0, ft0, i, j, k); } while (0)
+    if (c == 0) RONLY(0); else if (c == 1) RONLY(1); else RONLY(2);
+#undef RONLY
 }
 // bricks of a level's box that hold rows: flags (one wave per brick), then an ordered compaction by one workgroup
 __global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__restrict__ flag, int nbricks) {
@@ -600,7 +631,7 @@ __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, co
 // of the cycle's 520 before).  Falls back to the global-memory sweeps when the box or a component's row count does not fit.
 struct CoarseRow { float cf[VS]; float invd, b, gersh; int li; size_t ci; bool has; };
 template <int C>
-__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, int fine0, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP) {   // fine0: d_restrict's FINE0
+__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, int fine0, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP, int given) {   // fine0: d_restrict's FINE0; given: b is in A.b already
     R.has = (int)threadIdx.x < nrows;
     R.gersh = 0.0f;
     if (!R.has) return;
@@ -613,7 +644,7 @@ __device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F
 #pragma unroll
     for (int q = 0; q < VS; q++) R.cf[q] = A.coef[C][q][R.ci];
     R.invd = 1.0f / R.cf[slot_diag(C)];
-    R.b = fine0 == 1 ? d_restrict<C, 1>(F, ft, P) : (fine0 == 2 ? d_restrict<C, 2>(F, ft, P) : d_restrict<C, 0>(F, ft, P));
+    R.b = given ? A.b.p[C][R.ci] : (fine0 == 1 ? d_restrict<C, 1>(F, ft, P) : (fine0 == 2 ? d_restrict<C, 2>(F, ft, P) : d_restrict<C, 0>(F, ft, P)));
     float g = 0.0f;
 #pragma unroll
     for (int q = 0; q < VS; q++) g += fabsf(R.cf[q]);
@@ -629,7 +660,8 @@ __device__ __forceinline__ void d_coarsest_sweep(const CoarseRow &R, const float
 }
 
 // sweeps: Jacobi sweeps on the coarsest level after the one that turns the zero guess into omega b/d; cheb: they use the sweeps + 1 Chebyshev weights of lev[n - 1].cheb
-__global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, int cheb, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick) {
+// bGiven: the right-hand side of level `first` is in its b already (summed over the ranks by the caller)
+__global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, int cheb, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick, int bGiven) {
     if (*conv >= 0) return;
     // the coarsest level lives in LDS when its box and rows fit (k_vmg_coarsest_rows decided that for this solve)
     __shared__ float xs[2 * 3 * VMG_LDS_POS];
@@ -647,7 +679,8 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
     for (int l = first; l < n; l++) {   // down
         const VLevelDev &A = lev[l];
         if (l == n - 1 && coarsest_in_lds) break;   // restricted straight into registers below
-        if (l == 0) { if (fineBrick) d_tail_step<OP_RESTRICT, 2>(A, F0, ft0, A.L, ft0); else d_tail_step<OP_RESTRICT, 1>(A, F0, ft0, A.L, ft0); }
+        if (l == first && bGiven) d_tail_step<OP_FIRST>(A, A.L, ft0, A.L, ft0);
+        else if (l == 0) { if (fineBrick) d_tail_step<OP_RESTRICT, 2>(A, F0, ft0, A.L, ft0); else d_tail_step<OP_RESTRICT, 1>(A, F0, ft0, A.L, ft0); }
         else d_tail_step<OP_RESTRICT>(A, lev[l - 1].L, lev[l - 1].t, A.L, ft0);
         if (l + 1 < n) {
             d_tail_step<OP_PRE2>(A, A.L, ft0, A.L, ft0);
@@ -666,9 +699,10 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
         const Vec3p &ft = n - 1 == 0 ? ft0 : lev[n - 2].t;
         CoarseRow RU, RV, RW;
         const int fine0 = n - 1 == 0 ? (fineBrick ? 2 : 1) : 0;
-        d_coarsest_load<0>(A, F, ft, fine0, rowlist[0], cnt[0], W, H, RU, xs, NP);
-        d_coarsest_load<1>(A, F, ft, fine0, rowlist[1], cnt[1], W, H, RV, xs, NP);
-        d_coarsest_load<2>(A, F, ft, fine0, rowlist[2], cnt[2], W, H, RW, xs, NP);
+        const int given = bGiven && first == n - 1;
+        d_coarsest_load<0>(A, F, ft, fine0, rowlist[0], cnt[0], W, H, RU, xs, NP, given);
+        d_coarsest_load<1>(A, F, ft, fine0, rowlist[1], cnt[1], W, H, RV, xs, NP, given);
+        d_coarsest_load<2>(A, F, ft, fine0, rowlist[2], cnt[2], W, H, RW, xs, NP, given);
         // weights: Chebyshev on [hi / kappa, hi] when `cheb`, the fixed damping otherwise; the first one turns the zero guess into x = omega b/d
         float wlane = VMG_OMEGA;    // lane k of every wave holds sweep k's weight; a sweep reads its weight with v_readlane (a load from the level
                                     // descriptor per sweep sits on the critical path: +0.75 us per sweep; a broadcast LDS read: +0.3 us)
@@ -890,6 +924,15 @@ struct VmgState {
     VLevelDev *d_lev = nullptr;  // the level descriptors in device memory (this solve's boxes), h_lev their pinned staging copy
     VLevelDev *h_lev = nullptr;
     int tailFirst = 0;           // index into lev of the first level the tail kernel handles (this solve)
+    // Block contexts (flipv_comm.h): levels lev[0 .. globalFrom) are the rank's own (its rows only, couplings across the cuts dropped, nothing
+    // exchanged: block-Jacobi); from lev[globalFrom] on the hierarchy is the GLOBAL one, held and cycled redundantly by every rank -- its operator is
+    // the sum over the ranks of their Galerkin contributions (one all-reduce per solve), its right-hand side the sum of their restricted
+    // residuals (one all-reduce per iteration).  -1: no global level (single domain, or switched off)
+    int globalFrom = -1;
+    int rc = 0;                  // a communication error inside the V-cycle (checked by the loop around it)
+    float *stage = nullptr;      // dense staging buffer of the global hierarchy's all-reduces (grown on demand)
+    size_t stageCap = 0;
+    double *d_gbox = nullptr;    // 6 ints per rank as doubles: the ranks' boxes on lev[globalFrom], merged by a sum all-reduce over disjoint slots
     bool ready = false;          // every allocation of vmg_alloc_state succeeded
     float w[2] = {VMG_W_DEFAULT[0], VMG_W_DEFAULT[1]};   // this solve's smoother weights (VMG_W)
     float chebTab[64] = {};      // the Chebyshev table for degree chebM (0: the coarsest level is swept with the fixed damping)
@@ -897,7 +940,7 @@ struct VmgState {
     int minDim = 0;              // the coarsest level's longest axis the hierarchy was allocated for (flipv_params.viscosity_mg_min_dim)
     void *fineVecs = nullptr;    // the fine level's three sweep vectors (zeroed every solve; the coarse levels' only with a new hierarchy)
     size_t fineVecBytes = 0;
-    ~VmgState() { for (void *p : allocs) (void)hipFree(p); if (h_lev) (void)hipHostFree(h_lev); }
+    ~VmgState() { for (void *p : allocs) (void)hipFree(p); if (stage) (void)hipFree(stage); if (h_lev) (void)hipHostFree(h_lev); }
 };
 
 static int vmg_alloc(flipv_context *c, VmgState *s, size_t per, size_t count, float **base) {
@@ -923,6 +966,24 @@ static VLevelDev dev_of(const VLevel &l) {
     return d;
 }
 static long box_positions(const Box3 &b) { return (long)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); }
+// sum over the ranks of `narr` grids of level A (the first at g0, consecutive ones A.per apart) inside the level's box, through the dense staging buffer
+static int vmg_allreduce_box(flipv_context *c, VmgState *s, const VLevel &A, float *g0, int narr) {
+    const size_t n = (size_t)box_positions(A.box), tot = n * (size_t)narr;
+    if (tot > s->stageCap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (s->stage) (void)hipFree(s->stage);
+        s->stage = nullptr; s->stageCap = 0;
+        hipError_t e = hipMalloc((void **)&s->stage, tot * sizeof(float));
+        if (e != hipSuccess) { c->err = std::string("hipMalloc(viscosity multigrid staging): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
+        s->stageCap = tot;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)narr);
+    hipLaunchKernelGGL(k_vmg_box_pack, grid, dim3(256), 0, c->stream, A.L, A.box, g0, A.per, s->stage, 0);
+    const int rc = fv_allreduce_f32(c, s->stage, tot);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_vmg_box_pack, grid, dim3(256), 0, c->stream, A.L, A.box, g0, A.per, s->stage, 1);
+    return FLIPV_OK;
+}
 
 }  // namespace
 
@@ -955,6 +1016,8 @@ static int vmg_alloc_state(flipv_context *c) {
         s->allocs.push_back(s->d_rowlist);
         s->d_rowcnt = s->d_rowlist + 3 * 1024;
         s->d_stripCount = s->d_rowcnt + 4;
+        HIPCHK(c, hipMalloc((void **)&s->d_gbox, 6 * 32 * sizeof(double)));
+        s->allocs.push_back(s->d_gbox);
         HIPCHK(c, hipMalloc((void **)&s->d_lev, VMG_MAX_LEVELS * sizeof(VLevelDev)));
         s->allocs.push_back(s->d_lev);
         HIPCHK(c, hipHostMalloc((void **)&s->h_lev, VMG_MAX_LEVELS * sizeof(VLevelDev)));
@@ -977,6 +1040,7 @@ static int vmg_alloc_state(flipv_context *c) {
             float *cb, *vb;
             if ((rc = vmg_alloc(c, s, per, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, per, 12, &vb))) return rc;
             s->vecBlocks.push_back({vb, per * 12 * sizeof(float)});
+            l.per = per;
             {
                 const size_t nstr = l.L.n / 64;   // bricks of the level
                 HIPCHK(c, hipMalloc((void **)&l.strips, 2 * nstr * sizeof(int)));
@@ -1037,15 +1101,50 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             }
             fb = A.box;
         }
+        // block contexts: from the first level that is small enough on, the GLOBAL hierarchy (VmgState::globalFrom): its box is the union of the ranks' boxes
+        s->globalFrom = (c->comm && !c->prm.viscosity_mg_rank_local && !s->lev.empty()) ? 0 : -1;
+        if (s->globalFrom >= 0) {
+            const int nr = c->comm->nranks, me = c->comm->rank;
+            std::vector<double> hbx((size_t)6 * nr, 0.0);
+            VLevel &G = s->lev[s->globalFrom];
+            for (int a = 0; a < 3; a++) { hbx[(size_t)6 * me + a] = G.box.lo[a]; hbx[(size_t)6 * me + 3 + a] = G.box.hi[a]; }
+            HIPCHK(c, hipMemcpyAsync(s->d_gbox, hbx.data(), hbx.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            if ((rc = fv_allreduce_scalars(c, s->d_gbox, hbx.size()))) return rc;
+            HIPCHK(c, hipMemcpyAsync(hbx.data(), s->d_gbox, hbx.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            for (int r = 0; r < nr; r++)
+                for (int a = 0; a < 3; a++) {
+                    const int lo = (int)hbx[(size_t)6 * r + a], hi = (int)hbx[(size_t)6 * r + 3 + a];
+                    if (lo < G.box.lo[a]) G.box.lo[a] = lo;
+                    if (hi > G.box.hi[a]) G.box.hi[a] = hi;
+                }
+            Box3 gb = G.box;
+            for (size_t l = (size_t)s->globalFrom + 1; l < s->lev.size(); l++) {
+                VLevel &A = s->lev[l];
+                const int ext[3] = {A.L.I + 1, A.L.J + 1, A.L.K + 1};
+                for (int a = 0; a < 3; a++) {
+                    A.box.lo[a] = gb.lo[a] >> 1;
+                    A.box.hi[a] = (gb.hi[a] >> 1) + 1;
+                    if (A.box.hi[a] > ext[a]) A.box.hi[a] = ext[a];
+                    if (A.box.hi[a] <= A.box.lo[a]) A.box.hi[a] = A.box.lo[a] + 1;
+                }
+                gb = A.box;
+            }
+        }
         // the tail: the coarsest levels whose boxes are small enough for one workgroup (the last level always)
         s->tailFirst = (int)s->lev.size() - 1;
         while (s->tailFirst > 0 && (int)s->lev.size() - (s->tailFirst - 1) <= VMG_TAIL_MAX && box_positions(s->lev[s->tailFirst - 1].box) <= VMG_TAIL_POS) s->tailFirst--;
+        if (s->globalFrom >= 0 && s->tailFirst < s->globalFrom) s->tailFirst = s->globalFrom;   // (the rank's own levels are launches: the all-reduce sits between them and the tail)
     }
     for (auto &b : s->vecBlocks) HIPCHK(c, hipMemsetAsync(b.first, 0, b.second, c->stream));   // the coarse levels' vectors: zero off their rows
     // this solve's coarse operators, level by level, as gathers that write every entry of the level's box (rows or not): nothing has to
     // be zeroed first, and what lies outside the box is never looked at.  The rows' own volumes are those of the operator the solve
     // applies: the exact one, or the reference's float-rounded one (vr*, k_viscosity.hip: d_ref_volume) -- the defect is a diagonal term
     // and goes through the Galerkin product like the volume itself.
+    if (s->globalFrom == 0) {   // the neighbours' row masks one entry into the halo: a fine row at a cut face then carries its entries across the cut into the Galerkin sums
+        const HaloArray hm[1] = {{brick ? (void *)c->vMaskB : (void *)c->vRowMask, 1}};
+        if ((rc = fv_halo_copy(c, hm, 1, 1))) return rc;
+    }
     if (!s->lev.empty()) {
         FineOp A;
         A.swz = c->vSwz;
@@ -1055,9 +1154,14 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         A.fC = c->fC; A.fE[0] = c->fEU; A.fE[1] = c->fEV; A.fE[2] = c->fEW;
         A.mask = brick ? c->vMaskB : c->vRowMask;
 #define CGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), 3u * (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
+        // (on the first global level every rank gathers over the union box: children outside its own finer box are skipped, so what it
+        // writes is its share of every row -- zero where it has none -- and the sum over the ranks is the single-domain Galerkin operator)
         hipLaunchKernelGGL(k_vmg_rap_gather_fine, CGRID(s->lev[0].box), 0, c->stream, A, c->L, dev_of(s->lev[0]));
-        for (size_t l = 0; l + 1 < s->lev.size(); l++)
+        if (s->globalFrom == 0 && (rc = vmg_allreduce_box(c, s, s->lev[0], s->lev[0].coef[0][0], 3 * VS))) return rc;
+        for (size_t l = 0; l + 1 < s->lev.size(); l++) {
             hipLaunchKernelGGL(k_vmg_rap_gather, CGRID(s->lev[l + 1].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
+            if (s->globalFrom == (int)l + 1 && (rc = vmg_allreduce_box(c, s, s->lev[l + 1], s->lev[l + 1].coef[0][0], 3 * VS))) return rc;
+        }
 #undef CGRID
     }
     // where the rows are on the levels that run as launches (strip lists) and on the coarsest one (row lists); then the level
@@ -1121,22 +1225,36 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
     const int it_spmv = it_arg == IT_DEVICE ? -1 : it_arg;   // the SpMV kernel's spelling of "device-side counter"
     float *dg[3] = {c->vDiagU, c->vDiagV, c->vDiagW};
     const int *conv = sc.conv;
+    // with the global hierarchy the fine level is the single domain's too: every sweep reads its input with the neighbours' current values
+    auto halo3 = [&](float *const v[3]) { if (s->globalFrom == 0 && !s->rc) { const HaloArray h[3] = {{v[0], sizeof(float)}, {v[1], sizeof(float)}, {v[2], sizeof(float)}}; s->rc = fv_halo_copy(c, h, 3, 1); } };
+    halo3(s->za);
     fv_visc_sweep_f32(c, s->za, s->zb, 1, sc, it_spmv, s->w[1], 0);                         // second pre-sweep: za -> zb
     if (!s->lev.empty()) {
+        halo3(s->zb);
         fv_visc_sweep_f32(c, s->zb, s->t0, 2, sc, it_spmv, 0.0f, 0);                        // t0 = r - A zb
         const int nl = (int)s->lev.size(), t0 = s->tailFirst;
         const Lay F0 = brick ? c->LB : c->L;
         const int fb = brick ? 1 : 0;
         const Vec3p ft0 = v3(s->t0);
 #define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), dim3(cdiv(s->lev[l_].nstrips > 0 ? s->lev[l_].nstrips : 1, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv, fb)
+        const int gl = s->globalFrom;
+        // the first global level's right-hand side: every rank restricts its own residual over the union box, the sum over the ranks is b
+        auto global_rhs = [&](int l) {
+            const Box3 &B = s->lev[l].box;
+            hipLaunchKernelGGL(k_vmg_restrict_box, dim3(cdiv(B.hi[0] - B.lo[0], 64), cdiv(B.hi[1] - B.lo[1], 4), 3u * (unsigned)(B.hi[2] - B.lo[2])), dim3(64, 4, 1), 0, c->stream,
+                               (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb);
+            return vmg_allreduce_box(c, s, s->lev[l], s->lev[l].b[0], 3);
+        };
         for (int l = 0; l < t0; l++) {   // down
-            STEP(OP_RESTRICT, l);
+            if (l == gl) { if ((s->rc = global_rhs(l))) return; STEP(OP_FIRST, l); }
+            else STEP(OP_RESTRICT, l);
             STEP(OP_PRE2, l);
             STEP(OP_RESID, l);
         }
         {
             const int sweeps = c->vmgSweeps > 0 ? c->vmgSweeps : VMG_COARSEST_SWEEPS;
-            hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb);
+            if (t0 == gl && (s->rc = global_rhs(t0))) return;
+            hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
         }
         for (int l = t0 - 1; l >= 0; l--) {   // up
             STEP(OP_PROPOST, l);
@@ -1147,7 +1265,9 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
         else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
                            c->vSwz, v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
     }
+    halo3(s->zb);
     fv_visc_sweep_f32(c, s->zb, s->za, 1, sc, it_spmv, s->w[0], 0);                         // post-sweeps: zb -> za -> zb
+    halo3(s->za);
     fv_visc_sweep_f32(c, s->za, s->zb, 3, sc, it_spmv, s->w[1], sig_shift);
 }
 
@@ -1186,6 +1306,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     const HaloArray ph[3] = {{p[0], sizeof(float)}, {p[1], sizeof(float)}, {p[2], sizeof(float)}};
     XR(-1);                       // za = omega r/d
     vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)
+    if (s->rc) return s->rc;
     if (c->comm && (rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     PP(-1);                       // p = z
     const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
@@ -1198,6 +1319,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         XR(it);
         if (replace) fv_brick_replace<float>(c, sc, it == IT_DEVICE ? -1 : it, replace_period, 0, s->za, s->w[0]);
         vmg_vcycle(c, s, sc, it, 1);
+        if (s->rc) return s->rc;
         if (c->comm && (r2 = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return r2;             // max|r| of this iteration, (r, z) of the next
         PP(it);
         return FLIPV_OK;

@@ -4,7 +4,7 @@ whether any multi-rank-only code path (halo packing, combine kernels, migration,
 should, and the iteration counts show what the decomposition does to the solvers.
 
     python tools/local_ranks_bench.py weak   [ranks=2] [size=256]            copies of the bunny scene stacked along k, one slab each
-    python tools/local_ranks_bench.py strong [px,py,pz=2,2,2] [size=256] [workload=bunny] [viscosity=5]
+    python tools/local_ranks_bench.py strong [px,py,pz=2,2,2] [size=256] [workload=bunny] [viscosity=5] [key=value ...  flipv_params fields]
                                                                             ONE scene split into blocks (bench.py --scaling strong)"""
 import os
 import sys
@@ -37,7 +37,10 @@ else:
     capi.comm_init_local(ctxs, dims)
     parts = partition.split_particles_boxes(P, dx, boxes, dims)
     print("scene %dx%dx%d, %d particles, blocks %s" % (I, J, K, len(P), dims))
+extra = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[2:] if "=" in kv}
 for c, p in zip(ctxs, parts):
+    if extra:
+        c.set_params(**extra)
     c.set_solid_sdf(solid_g)
     c.set_viscosity(nu)
     c.particles = p
@@ -51,7 +54,7 @@ t0 = time.perf_counter()
 th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
 for t in th: t.start()
 for t in th: t.join()
-print("wall %.2f s for 3 substeps of %d ranks sharing one device" % (time.perf_counter() - t0, R))
+print("wall %.2f s for 3 substeps of %d ranks sharing one device" % (time.perf_counter() - t0, R), extra)
 for r, st in enumerate(out):
     print("rank", r, {k: round(v, 2) for k, v in st["phase_ms"].items()}, "total %.1f" % st["total_ms"], "its", st["viscosity"]["iterations"], st["pressure"]["iterations"],
           "rows", st["viscosity"]["rows"], "particles", ctxs[r].num_particles)
