@@ -58,7 +58,7 @@ class Params(C.Structure):
                 ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int),
                 ("viscosity_update_grid_cap", C.c_int), ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int),
                 ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
-                ("viscosity_mg_rank_local", C.c_int),
+                ("multigrid_rank_local", C.c_int),
                 ("reserved", C.c_int * 1)]
 
 LAYOUT_AUTO, LAYOUT_PLAIN, LAYOUT_SWIZZLED, LAYOUT_BRICK = 0, 1, 2, 3

@@ -14,7 +14,9 @@
 //               random right-hand side, 13 against 96 (128^3) for a smooth one.
 // Everything is matrix-free on the levels' own dense index spaces (same layout rules as the fine grid); level 0 walks the
 // solver's tile list.  Coarse levels are launch-bound (a few microseconds per kernel).
-// Block-decomposed runs: the V-cycle is RANK-LOCAL (block-Jacobi multigrid): every rank builds the hierarchy of its own
+// Block-decomposed runs, default: the single domain's V-cycle (MgState::global: level 0 sweeps after a halo copy of x0, ONE global coarse
+// hierarchy whose first operator and right-hand side are summed over the ranks).  With flipv_params.multigrid_rank_local:
+// the V-cycle is RANK-LOCAL (block-Jacobi multigrid): every rank builds the hierarchy of its own
 // box of cells, with the couplings across the box's cut faces dropped, and cycles it without any exchange; the CG around it
 // uses the true operator (halo exchange of p, two scalar all-reduces per iteration).  A block-diagonal SPD preconditioner:
 // same fixed point, a few more iterations than the global cycle, no halo traffic per level and sweep.
@@ -33,6 +35,7 @@ __constant__ float MG_OVER = 1.8f;    // (0.9,1.8) 20, (1.0,1.5) 84
 __constant__ int MG_COARSEST_SWEEPS = 8;    // even (the global-memory variant ping-pongs and must end in t); flipv_params.pressure_mg_coarsest_sweeps overrides it for scans.
                                             // The count does not move the iterations (2 ... 128 sweeps: 19.35 on the 256^3 bunny, 15.6-15.8 on the 512x256x256 sheet, 16.15 at 128^3)
 
+struct CutBox { int lo[3], hi[3]; };   // a box of cells, half-open
 struct MgLevel {
     Lay L;
     float *diag, *pi, *pj, *pk;  // operator (level 0: the context's arrays)
@@ -104,10 +107,11 @@ __device__ __forceinline__ float d_mg_up_cell(const Lay &L, const Lay &C, int i,
     return y + MG_OMEGA * (b[c] - ay) / dd;
 }
 
-// ---- Galerkin coarsening: one thread per coarse cell
+// ---- Galerkin coarsening: one thread per coarse cell.  hi: couplings towards cells at or beyond it are dropped -- the rank's box of cells (rank-local
+// hierarchy) or the domain (global hierarchy: the rank's children carry their couplings across the cuts into the sums over the ranks)
 __global__ void k_mg_coarsen(Lay F, Lay C, const float *__restrict__ df, const float *__restrict__ pif, const float *__restrict__ pjf,
                              const float *__restrict__ pkf, float *__restrict__ dc, float *__restrict__ pic, float *__restrict__ pjc,
-                             float *__restrict__ pkc) {
+                             float *__restrict__ pkc, int hi0, int hi1, int hi2) {
     const int I = C.ib + blockIdx.x * 64 + threadIdx.x, J = C.jb + blockIdx.y * 4 + threadIdx.y, K = blockIdx.z + C.kb;
     if (I >= C.ie || J >= C.je) return;
     const size_t cc = gidx(C, I, J, K);
@@ -120,9 +124,9 @@ __global__ void k_mg_coarsen(Lay F, Lay C, const float *__restrict__ df, const f
         const size_t c = gidx(F, i, j, k);
         ds += df[c];
         // coupling to the +1 neighbour: inside the aggregate / across its face; dropped where the neighbour is not the rank's
-        if (i + 1 < F.ohi[0]) { if (a == 0) ds += 2.0f * pif[c]; else si += pif[c]; }
-        if (j + 1 < F.ohi[1]) { if (b == 0) ds += 2.0f * pjf[c]; else sj += pjf[c]; }
-        if (k + 1 < F.ohi[2]) { if (e == 0) ds += 2.0f * pkf[c]; else sk += pkf[c]; }
+        if (i + 1 < hi0) { if (a == 0) ds += 2.0f * pif[c]; else si += pif[c]; }
+        if (j + 1 < hi1) { if (b == 0) ds += 2.0f * pjf[c]; else sj += pjf[c]; }
+        if (k + 1 < hi2) { if (e == 0) ds += 2.0f * pkf[c]; else sk += pkf[c]; }
     }
     dc[cc] = ds; pic[cc] = si; pjc[cc] = sj; pkc[cc] = sk;
 }
@@ -271,6 +275,24 @@ __global__ __launch_bounds__(1024) void k_mg_tail(MgTail T) {
     }
 }
 
+// ---- global hierarchy (block contexts): the box of a level's cells with an operator row, and box-shaped packing for the all-reduces
+__global__ __launch_bounds__(256) void k_mg_bbox(Lay L, const float *__restrict__ d, int *__restrict__ box) {
+    const int i = L.ib + blockIdx.x * 64 + threadIdx.x, j = L.jb + blockIdx.y * 4 + threadIdx.y, k = blockIdx.z + L.kb;
+    if (i >= L.ie || j >= L.je || d[gidx(L, i, j, k)] == 0.0f) return;
+    atomicMin(box + 0, i); atomicMin(box + 1, j); atomicMin(box + 2, k);
+    atomicMax(box + 3, i + 1); atomicMax(box + 4, j + 1); atomicMax(box + 5, k + 1);
+}
+struct Ptr4 { float *p[4]; };
+// unpack = 0: arrays -> dense buffer [blockIdx.y][cells of the box], 1: buffer -> arrays
+__global__ __launch_bounds__(256) void k_mg_box_pack(Lay L, CutBox B, Ptr4 arr, float *__restrict__ buf, int unpack) {
+    const int w = B.hi[0] - B.lo[0], h = B.hi[1] - B.lo[1], d = B.hi[2] - B.lo[2];
+    const size_t n = (size_t)w * h * d, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float *g = arr.p[blockIdx.y] + gidx(L, B.lo[0] + (int)(t % w), B.lo[1] + (int)((t / w) % h), B.lo[2] + (int)(t / ((size_t)w * h)));
+    float *q = buf + (size_t)blockIdx.y * n + t;
+    if (unpack) *g = *q; else *q = *g;
+}
+
 // ---- the level-0 kernels walk the solver's tile list: once per tile geometry (pcg_geo.inc)
 namespace g16 {
 constexpr int ROWL = 16;
@@ -291,7 +313,19 @@ struct MgState {
     float omega = 0.9f, over = 1.8f; int sweeps = 8;   // what the __constant__ scan parameters currently hold (flipv_params.pressure_mg_*)
     std::vector<void *> allocs;
     int I = 0, J = 0, K = 0;
-    ~MgState() { for (void *p : allocs) (void)hipFree(p); }
+    // Block contexts (flipv_comm.h).  global: levels 1.. are the GLOBAL hierarchy, held and cycled redundantly by every rank -- level 1's operator is the
+    // sum over the ranks of their Galerkin contributions (one all-reduce per solve), its right-hand side the sum of their restricted residuals
+    // (one all-reduce per iteration), and level 0's sweeps read the neighbours' x0 (one halo copy per iteration): the single domain's V-cycle.
+    // Otherwise (flipv_params.multigrid_rank_local) every rank cycles the hierarchy of its own box of cells, couplings across the cuts dropped.
+    bool global = false;
+    float *bacc = nullptr;       // where k_mg_down0 accumulates the rank's share of level 1's right-hand side (global: a separate array; else lev[1].b)
+    float *stage = nullptr;      // dense staging buffer of the all-reduces
+    size_t stageCap = 0;
+    int *d_bbox = nullptr;       // 6 ints
+    double *d_gbox = nullptr;    // 6 doubles per rank
+    CutBox gbox;                 // this solve's box of level-1 cells with a row, over all ranks
+    int rc = 0;                  // a communication error inside the V-cycle
+    ~MgState() { for (void *p : allocs) (void)hipFree(p); if (stage) (void)hipFree(stage); }
 };
 
 static int mg_alloc(flipv_context *c, MgState *s, const Lay &L, float **p) {
@@ -305,6 +339,7 @@ static int mg_alloc(flipv_context *c, MgState *s, const Lay &L, float **p) {
     return FLIPV_OK;
 }
 
+#define HIPCHK_VOID(c_, s_, x_) do { hipError_t e_ = (x_); if (e_ != hipSuccess) { (c_)->err = std::string(#x_) + ": " + hipGetErrorString(e_); (s_)->rc = FLIPV_ERR_HIP; return; } } while (0)
 #define MGGRID(Lv) dim3(cdiv((Lv).ie - (Lv).ib, 64), cdiv((Lv).je - (Lv).jb, 4), (unsigned)((Lv).ke - (Lv).kb)), dim3(64, 4, 1)
 
 }  // namespace
@@ -314,12 +349,39 @@ void fv_mg_free(flipv_context *c) {
     c->mgState = nullptr;
 }
 
+// sum over the ranks of `narr` arrays of a level inside s->gbox, through the dense staging buffer
+static int mg_allreduce_box(flipv_context *c, MgState *s, const Lay &L, const Ptr4 &arr, int narr) {
+    const CutBox &B = s->gbox;
+    const size_t n = (size_t)(B.hi[0] - B.lo[0]) * (B.hi[1] - B.lo[1]) * (B.hi[2] - B.lo[2]), tot = n * (size_t)narr;
+    if (tot > s->stageCap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (s->stage) (void)hipFree(s->stage);
+        s->stage = nullptr; s->stageCap = 0;
+        hipError_t e = hipMalloc((void **)&s->stage, tot * sizeof(float));
+        if (e != hipSuccess) { c->err = std::string("hipMalloc(pressure multigrid staging): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
+        s->stageCap = tot;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)narr);
+    hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, arr, s->stage, 0);
+    const int rc = fv_allreduce_f32(c, s->stage, tot);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, arr, s->stage, 1);
+    return FLIPV_OK;
+}
+
 // The level structure (allocated once per context) and this substep's coarse operators.
 static int mg_setup(flipv_context *c, MgState **out) {
     MgState *s = (MgState *)c->mgState;
+    const bool wantGlobal = c->comm && !c->prm.multigrid_rank_local;
+    if (s && s->global != wantGlobal) {   // (a communicator attached, or the switch flipped, after the first solve)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        fv_mg_free(c);
+        s = nullptr;
+    }
     if (!s) {
         s = new MgState();
         c->mgState = s;
+        s->global = wantGlobal;
         MgLevel l0;
         l0.L = c->L;
         for (int a = 0; a < 3; a++) { l0.L.olo[a] = c->cell0[a]; l0.L.ohi[a] = c->cell1[a]; }   // the rank's CELLS (all of them on a single GPU)
@@ -329,8 +391,14 @@ static int mg_setup(flipv_context *c, MgState **out) {
         int rc;
         if ((rc = mg_alloc(c, s, c->L, &l0.x)) || (rc = mg_alloc(c, s, c->L, &l0.t))) return rc;
         s->lev.push_back(l0);
+        HIPCHK(c, hipMalloc((void **)&s->d_bbox, 8 * sizeof(int)));
+        s->allocs.push_back(s->d_bbox);
+        HIPCHK(c, hipMalloc((void **)&s->d_gbox, 6 * 32 * sizeof(double)));
+        s->allocs.push_back(s->d_gbox);
+        Lay whole = l0.L;   // global hierarchy: the coarse levels are those of the whole domain's cells
+        whole.olo[0] = whole.olo[1] = whole.olo[2] = 0; whole.ohi[0] = c->L.I; whole.ohi[1] = c->L.J; whole.ohi[2] = c->L.K;
         while (true) {
-            const Lay &F = s->lev.back().L;
+            const Lay &F = (s->global && s->lev.size() == 1) ? whole : s->lev.back().L;
             const int e3[3] = {F.ohi[0] - F.olo[0], F.ohi[1] - F.olo[1], F.ohi[2] - F.olo[2]};   // the rank's box decides the depth of ITS hierarchy
             const int m = e3[0] > e3[1] ? (e3[0] > e3[2] ? e3[0] : e3[2]) : (e3[1] > e3[2] ? e3[1] : e3[2]);
             if (m <= 8 || s->lev.size() >= 8) break;
@@ -339,6 +407,10 @@ static int mg_setup(flipv_context *c, MgState **out) {
             float **arr[7] = {&l.diag, &l.pi, &l.pj, &l.pk, &l.b, &l.x, &l.t};
             for (auto a : arr) if ((rc = mg_alloc(c, s, l.L, a))) return rc;
             s->lev.push_back(l);
+        }
+        if (s->lev.size() > 1) {
+            s->bacc = s->lev[1].b;
+            if (s->global && (rc = mg_alloc(c, s, s->lev[1].L, &s->bacc))) return rc;
         }
         // the tail: the coarsest levels that are small enough for one workgroup (at least the last one, at most MG_MAX_TAIL);
         // level 0 always runs on the tile list
@@ -363,7 +435,38 @@ static int mg_setup(flipv_context *c, MgState **out) {
     for (size_t l = 0; l + 1 < s->lev.size(); l++) {
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
-        hipLaunchKernelGGL(k_mg_coarsen, MGGRID(C.L), 0, c->stream, F.L, C.L, F.diag, F.pi, F.pj, F.pk, C.diag, C.pi, C.pj, C.pk);   // (the WHOLE level: coefficients are fresh everywhere)
+        const bool cross = s->global && l == 0;   // the rank's children with their couplings across the cuts
+        hipLaunchKernelGGL(k_mg_coarsen, MGGRID(C.L), 0, c->stream, F.L, C.L, F.diag, F.pi, F.pj, F.pk, C.diag, C.pi, C.pj, C.pk,
+                           cross ? c->L.I : F.L.ohi[0], cross ? c->L.J : F.L.ohi[1], cross ? c->L.K : F.L.ohi[2]);   // (the WHOLE level: coefficients are fresh everywhere)
+        if (cross) {   // level 1's operator = the sum over the ranks, inside the union of their boxes of rows
+            int rc;
+            const int big = 0x7fffffff;
+            const int init[6] = {big, big, big, 0, 0, 0};
+            HIPCHK(c, hipMemcpyAsync(s->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_mg_bbox, MGGRID(C.L), 0, c->stream, C.L, C.diag, s->d_bbox);
+            int hb[6];
+            HIPCHK(c, hipMemcpyAsync(hb, s->d_bbox, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int nr = c->comm->nranks, me = c->comm->rank;
+            std::vector<double> hbx((size_t)6 * nr, 0.0);
+            const bool any = hb[3] > hb[0];
+            for (int a = 0; a < 3; a++) { hbx[(size_t)6 * me + a] = any ? hb[a] : big; hbx[(size_t)6 * me + 3 + a] = any ? hb[3 + a] : 0; }
+            HIPCHK(c, hipMemcpyAsync(s->d_gbox, hbx.data(), hbx.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            if ((rc = fv_allreduce_scalars(c, s->d_gbox, hbx.size()))) return rc;
+            HIPCHK(c, hipMemcpyAsync(hbx.data(), s->d_gbox, hbx.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            CutBox g = {{big, big, big}, {0, 0, 0}};
+            for (int r = 0; r < nr; r++)
+                for (int a = 0; a < 3; a++) {
+                    const int lo = (int)hbx[(size_t)6 * r + a], hi = (int)hbx[(size_t)6 * r + 3 + a];
+                    if (lo < g.lo[a]) g.lo[a] = lo;
+                    if (hi > g.hi[a]) g.hi[a] = hi;
+                }
+            for (int a = 0; a < 3; a++) if (g.hi[a] <= g.lo[a]) { g.lo[a] = 0; g.hi[a] = 1; }   // no pressure cell anywhere
+            s->gbox = g;
+            const Ptr4 op = {{C.diag, C.pi, C.pj, C.pk}};
+            if ((rc = mg_allreduce_box(c, s, C.L, op, 4))) return rc;
+        }
     }
     // Where this solve's sweeps run: the cells within reach of the liquid, halved level by level (the whole level when the liquid's
     // box is not known: multi-rank runs, operators called outside a substep).  Outside the box the vectors of a level keep whatever
@@ -377,7 +480,8 @@ static int mg_setup(flipv_context *c, MgState **out) {
             Lay Lr = s->lev[l].L;
             int *b[3] = {&Lr.ib, &Lr.jb, &Lr.kb}, *e[3] = {&Lr.ie, &Lr.je, &Lr.ke};
             for (int a = 0; a < 3; a++) {
-                if (l > 0) { lo[a] = lo[a] >> 1; hi[a] = ((hi[a] - 1) >> 1) + 1; }
+                if (s->global && l == 1) { lo[a] = s->gbox.lo[a]; hi[a] = s->gbox.hi[a]; }   // (the global levels: the box of level 1's rows over all ranks, halved level by level)
+                else if (l > 0) { lo[a] = lo[a] >> 1; hi[a] = ((hi[a] - 1) >> 1) + 1; }
                 const int l0 = lo[a] > Lr.olo[a] ? lo[a] : Lr.olo[a], h0 = hi[a] < Lr.ohi[a] ? hi[a] : Lr.ohi[a];
                 *b[a] = l0; *e[a] = h0 > l0 ? h0 : l0 + 1;
             }
@@ -394,13 +498,24 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
     const int nl = (int)s->lev.size();
     const int nb = pcg_grid(c, c->nActiveP);
     const int t0 = s->tailFirst;  // levels [t0, nl) run inside k_mg_tail
+    CutBox cut;   // level 0: couplings across these faces are dropped (the rank's cells; the whole domain under the global hierarchy)
+    for (int a = 0; a < 3; a++) { cut.lo[a] = s->global ? 0 : s->lev[0].L.olo[a]; cut.hi[a] = s->global ? (a == 0 ? c->L.I : (a == 1 ? c->L.J : c->L.K)) : s->lev[0].L.ohi[a]; }
     for (int l = 0; l < t0; l++) {  // down: level l -> right-hand side of level l+1
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0) {  // x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
-            // (C.b: zero on entry to the solve, then k_mg_up0 clears what k_mg_down0 filled)
-            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, C.b));
+            // (bacc: zero on entry to the solve, then k_mg_up0 clears what k_mg_down0 filled)
+            if (s->global) {   // the neighbours' x0 on the halo entries: level 0's sweeps are the single domain's
+                const HaloArray hx[1] = {{F.x, sizeof(float)}};
+                if ((s->rc = fv_halo_copy(c, hx, 1, 1))) return;
+            }
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, cut, F.diag, F.pi,
+                               F.pj, F.pk, c->pMask, F.x, F.b, s->bacc));
+            if (s->global) {   // level 1's right-hand side = the sum of the ranks' shares (bacc stays the rank's own: k_mg_up0 clears exactly what it filled)
+                HIPCHK_VOID(c, s, hipMemcpyAsync(C.b, s->bacc, C.L.n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+                const Ptr4 rhs = {{C.b, nullptr, nullptr, nullptr}};
+                if ((s->rc = mg_allreduce_box(c, s, C.L, rhs, 1))) return;
+            }
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
             const Lay &Fr = s->range[l];
             const Lay &Cr = l + 1 < t0 ? s->range[l + 1] : C.L;   // the first level of the tail is swept whole: its right-hand side is written everywhere
@@ -416,8 +531,8 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
         const MgLevel &F = s->lev[l];
         const MgLevel &C = s->lev[l + 1];
         if (l == 0)
-            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, C.b, sc, it_next));
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, cut, F.diag, F.pi,
+                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, s->bacc, sc, it_next));
         else
             hipLaunchKernelGGL(k_mg_up, MGGRID(s->range[l]), 0, c->stream, s->range[l], C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
     }
@@ -434,9 +549,10 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
     float *x = c->pressure, *r = (float *)c->pR, *q = (float *)c->pZ, *p = (float *)c->pS, *z = s->lev[0].t;
     float *x0 = s->lev[0].x;
     const HaloArray ph[1] = {{p, sizeof(float)}};
-    if (s->tailFirst > 0) HIPCHK(c, hipMemsetAsync(s->lev[1].b, 0, s->lev[1].L.n * sizeof(float), c->stream));   // once per solve; every cycle leaves it cleared (k_mg_up0)
+    if (s->tailFirst > 0) HIPCHK(c, hipMemsetAsync(s->bacc, 0, s->lev[1].L.n * sizeof(float), c->stream));   // once per solve; every cycle leaves it cleared (k_mg_up0)
     GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, -1));
     mg_vcycle(c, s, sc, 0);
+    if (s->rc) return s->rc;
     if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, -1));
     // an iteration after the stop is a full V-cycle (plus, multi-rank, three exchanges): poll often
@@ -484,6 +600,7 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.a(it), NSLOT))) return rc;          // p.q
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, it));
             mg_vcycle(c, s, sc, it + 1);
+            if (s->rc) return s->rc;
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;   // max|r| of this iteration, (r,z) of the next
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, it));
         }

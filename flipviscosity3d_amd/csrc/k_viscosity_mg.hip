@@ -23,6 +23,9 @@
 //                ONE single-workgroup launch (k_vmg_tail: the coarsest level in LDS), the larger ones as 6 launches per level
 //   who          flipv_params.viscosity_preconditioner: MULTIGRID always, AUTO (default) when the previous solve's iteration count
 //                predicts it to be cheaper than the diagonal (k_viscosity.hip: fv_visc_auto_pick)
+//   ranks        block contexts (flipv_comm.h): the same preconditioner -- fine-level sweeps after a halo copy of their input, ONE global coarse hierarchy
+//                (operator and first coarse right-hand side summed over the ranks, VmgState::globalFrom) cycled redundantly by every rank; or
+//                rank-local block-Jacobi (flipv_params.multigrid_rank_local)
 //   loop         PCG around it; `check_every` iterations are captured into a hipGraph once per solve and replayed
 //                (device-side iteration counters, as in pcg_common.h)
 #include "flipv_internal.h"
@@ -1102,7 +1105,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             fb = A.box;
         }
         // block contexts: from the first level that is small enough on, the GLOBAL hierarchy (VmgState::globalFrom): its box is the union of the ranks' boxes
-        s->globalFrom = (c->comm && !c->prm.viscosity_mg_rank_local && !s->lev.empty()) ? 0 : -1;
+        s->globalFrom = (c->comm && !c->prm.multigrid_rank_local && !s->lev.empty()) ? 0 : -1;
         if (s->globalFrom >= 0) {
             const int nr = c->comm->nranks, me = c->comm->rank;
             std::vector<double> hbx((size_t)6 * nr, 0.0);
@@ -1300,9 +1303,10 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     };
     if (!brick) replace_period = 0;
     HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
-    // Block contexts: every rank cycles the hierarchy of ITS rows with the couplings across the cut faces dropped (its sweep vectors are
-    // zero on the halo) and without any exchange -- a block-diagonal, symmetric positive definite preconditioner, like the pressure
-    // multigrid's; the CG around it applies the true operator (halo copy of p before the SpMV) and all-reduces its scalars.
+    // Block contexts: the V-cycle is the single domain's (VmgState::globalFrom = 0: halo copies before the fine-level sweeps, one global coarse
+    // hierarchy), or, with flipv_params.multigrid_rank_local, a cycle over the rank's OWN rows with the couplings across the cut faces dropped
+    // (its sweep vectors are zero on the halo) and no exchange -- a block-diagonal, symmetric positive definite preconditioner, like the
+    // pressure multigrid's.  Either way the CG around it applies the true operator (halo copy of p before the SpMV) and all-reduces its scalars.
     const HaloArray ph[3] = {{p[0], sizeof(float)}, {p[1], sizeof(float)}, {p[2], sizeof(float)}};
     XR(-1);                       // za = omega r/d
     vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)

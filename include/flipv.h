@@ -142,11 +142,12 @@ typedef struct flipv_params {
                                     chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
     float viscosity_mg_omega_first;  /* damping of the first and of the second Jacobi sweep of the viscosity multigrid's V(2,2) smoother (pre- and */
     float viscosity_mg_omega_second; /* post-smoothing use the same pair); 0 = the defaults (k_viscosity_mg.hip: VMG_W) */
-    int viscosity_mg_rank_local; /* several ranks (block contexts).  0 (default): the viscosity multigrid is the single domain's -- every fine-level sweep reads the
-                                    neighbours' current values (4 halo copies per iteration), the coarse hierarchy is the GLOBAL one, its operator summed over
-                                    the ranks once per solve and its first level's right-hand side once per iteration (all-reduces over the liquid's box), held
-                                    and cycled redundantly by every rank: iteration counts of a single domain.  1: every rank cycles a hierarchy of its OWN rows
-                                    with the couplings across the cuts dropped and no exchange (block-Jacobi): 3-4x the iterations on 2x2x2 blocks */
+    int multigrid_rank_local;    /* several ranks (block contexts).  0 (default): both multigrid preconditioners are the single domain's -- the fine-level sweeps read
+                                    the neighbours' current values (viscosity: 4 halo copies per iteration, pressure: 1), the coarse hierarchy is the GLOBAL one,
+                                    its first level's operator summed over the ranks once per solve and its right-hand side once per iteration (float
+                                    all-reduces over the liquid's box), held and cycled redundantly by every rank: the iteration counts of a single domain.
+                                    1: every rank cycles a hierarchy of its OWN rows / cells with the couplings across the cuts dropped and no exchange
+                                    (block-Jacobi): 3-4x the viscosity iterations and 2-3x the pressure iterations on 2x2x2 blocks */
     int reserved[1];             /* must be 0 */
 } flipv_params;
 

@@ -187,10 +187,10 @@ def test_block_decomposition_matches_single_domain(name, dims):
 @pytest.mark.parametrize("rank_local", [0, 1])
 @pytest.mark.parametrize("name,dims", [("bunny32_viscous", (2, 1, 1)), ("bunny32_viscous", (1, 2, 2)), ("bunny32_viscous", (2, 2, 2))])
 def test_block_decomposition_runs_the_viscosity_multigrid(name, dims, rank_local):
-    """Block contexts run the multigrid-preconditioned viscosity solve too.  Default (viscosity_mg_rank_local = 0): the SINGLE DOMAIN's
+    """Block contexts run the multigrid-preconditioned viscosity solve too.  Default (multigrid_rank_local = 0): the SINGLE DOMAIN's
     preconditioner -- fine-level sweeps with the neighbours' current values, the coarse hierarchy global (operator and first coarse
     right-hand side summed over the ranks, cycled redundantly by every rank) -- so the iteration count is the single domain's, up to the
-    summation order.  viscosity_mg_rank_local = 1: every rank cycles the hierarchy of ITS rows (couplings across the cut faces dropped, no
+    summation order.  multigrid_rank_local = 1: every rank cycles the hierarchy of ITS rows (couplings across the cut faces dropped, no
     exchange inside the V-cycle: block-Jacobi); more iterations, same answer.  One substep from the fixture's particles with tight
     tolerances, velocities against the single-domain run and the reference dump, every rank taking the same decisions and far fewer
     iterations than the diagonal needs (217)."""
@@ -198,7 +198,7 @@ def test_block_decomposition_runs_the_viscosity_multigrid(name, dims, rank_local
     g = Golden(name)
     I, J, K = g.dims()
     params = dict(viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7, viscosity_preconditioner=capi.PRECOND_MULTIGRID, viscosity_layout=capi.LAYOUT_SWIZZLED,
-                  exact_viscosity_operator=1, viscosity_mg_rank_local=rank_local)
+                  exact_viscosity_operator=1, multigrid_rank_local=rank_local)
     ref = capi.Context(I, J, K, g.dx)
     ref.set_solid_sdf(g["solid"]); ref.set_viscosity(g["viscosity"]); ref.set_gravity(*g.gravity); ref.set_params(**params)
     ref.particles = g["particles0"]
@@ -216,8 +216,10 @@ def test_block_decomposition_runs_the_viscosity_multigrid(name, dims, rank_local
         assert s["viscosity"]["status"] == 0 and s["viscosity"]["preconditioner"] == 1, s["viscosity"]
         assert s["viscosity"]["iterations"] == sts[0]["viscosity"]["iterations"] and s["viscosity"]["iterations"] < 120, s["viscosity"]
     print("iterations: single domain %d, %s blocks %d (rank_local=%d)" % (sr["viscosity"]["iterations"], dims, sts[0]["viscosity"]["iterations"], rank_local))
+    print("pressure iterations: single domain %d, blocks %d" % (sr["pressure"]["iterations"], sts[0]["pressure"]["iterations"]))
     if not rank_local:
         assert abs(sts[0]["viscosity"]["iterations"] - sr["viscosity"]["iterations"]) <= 3, (sr["viscosity"], sts[0]["viscosity"])
+        assert sr["pressure"]["preconditioner"] == 1 and abs(sts[0]["pressure"]["iterations"] - sr["pressure"]["iterations"]) <= 2, (sr["pressure"], sts[0]["pressure"])
     got = [assemble(ctxs, n) for n in "UVW"]
     assert rel_maxnorm3(got, [ref.grid(n) for n in "UVW"]) <= 2e-5
     assert rel_maxnorm3(got, g.uvw(0, "final")) <= 1e-4
