@@ -70,7 +70,7 @@ WORKLOADS = {
 }
 
 
-def build_workload(name, N, on_device, device=None):
+def build_workload(name, N, on_device, device=None, keep_setup_context=False):
     """Scene setup (not timed) -> (I, J, K, dx, solid SDF nodes, particles).  Host C++ path (bit-identical level sets) or, with
     on_device, the library's HIP setup kernels on a single-domain context (seconds instead of minutes at 512^3)."""
     from flipviscosity3d_amd import hostapi as H
@@ -88,6 +88,8 @@ def build_workload(name, N, on_device, device=None):
             c.add_boundary_mesh(H.load_ply(os.path.join(MESH, boundary[0])), inverted=boundary[1])
         for m in liquids:
             c.add_liquid_mesh(mesh(m), seed=0)
+        if keep_setup_context:       # a rank of a block decomposition takes its box of the solid SDF straight from this context (read_region)
+            return I, J, K, dx, c, c.particles
         solid, particles = c.grid("SOLID_PHI"), c.particles
         c.close()
         return I, J, K, dx, solid, particles
@@ -308,7 +310,8 @@ def main():
     from flipviscosity3d_amd.capi import Context
 
     N = args.size
-    GI, GJ, GK, dx, solid, particles = build_workload(args.workload, N, on_device=args.gpu_setup, device=local_rank)
+    box_handover = world > 1 and args.scaling == "strong" and args.gpu_setup   # no full-size host array of the solid SDF on any rank
+    GI, GJ, GK, dx, solid, particles = build_workload(args.workload, N, on_device=args.gpu_setup, device=local_rank, keep_setup_context=box_handover)
     decomposition = "single GPU"
     if world == 1:
         c = Context(GI, GJ, GK, dx, device=local_rank, slab=(0, GK) if args.force_comm else None)
@@ -330,7 +333,12 @@ def main():
         uid = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         c.comm_init_rccl(uid[0], rank, world, dims)
-        c.set_solid_sdf(solid)                                     # the library takes the entries of its box (owned + halo)
+        if box_handover:                                           # `solid` is the setup context: the rank's allocated box of its solid SDF, box-shaped
+            lo, hi = c.grid_box("SOLID_PHI", 1)
+            c.write_box("SOLID_PHI", solid.read_region("SOLID_PHI", lo, hi))
+            solid.close()
+        else:
+            c.set_solid_sdf(solid)                                 # the library takes the entries of its box (owned + halo)
         particles = partition.split_particles_boxes(particles, dx, boxes, dims)[rank]
         decomposition = "%dx%dx%d blocks of one %dx%dx%d scene (rank-local allocation), RCCL 6-face halo exchange + PCG scalar all-reduce + " \
                         "particle migration" % (dims[0], dims[1], dims[2], GI, GJ, GK)

@@ -25,7 +25,7 @@ SYMBOLS = [
     "flipv_default_params", "flipv_set_params", "flipv_get_params", "flipv_set_gravity",
     "flipv_set_solid_sdf", "flipv_set_viscosity_uniform", "flipv_set_viscosity",
     "flipv_upload_particles", "flipv_download_particles", "flipv_num_particles",
-    "flipv_grid_elements", "flipv_read_grid", "flipv_write_grid", "flipv_grid_box", "flipv_read_grid_box", "flipv_write_grid_box",
+    "flipv_grid_elements", "flipv_read_grid", "flipv_write_grid", "flipv_grid_box", "flipv_read_grid_box", "flipv_write_grid_box", "flipv_read_grid_region",
     "flipv_cfl", "flipv_particle_sdf", "flipv_p2g", "flipv_extrapolate", "flipv_save_velocity",
     "flipv_advect_velocity_field", "flipv_body_force", "flipv_viscosity_solve", "flipv_compute_weights",
     "flipv_pressure_solve", "flipv_apply_pressure", "flipv_constrain", "flipv_update_particle_velocities",
@@ -116,6 +116,7 @@ def load():
     L.flipv_create_setup.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(ctx)]
     L.flipv_grid_box.argtypes = [ctx, C.c_int, C.c_int, i3, i3]
     L.flipv_read_grid_box.argtypes = [ctx, C.c_int, fp]
+    L.flipv_read_grid_region.argtypes = [ctx, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), fp]
     L.flipv_write_grid_box.argtypes = [ctx, C.c_int, fp]
     L.flipv_comm_init_rccl_grid.argtypes = [ctx, C.c_void_p, C.c_int, i3]
     L.flipv_comm_init_local_grid.argtypes = [C.POINTER(ctx), i3]
@@ -360,6 +361,12 @@ class Context:
         lo, hi = self.grid_box(name, 0)
         a = np.empty((hi[2] - lo[2], hi[1] - lo[1], hi[0] - lo[0]), np.float32)
         self._chk(self.L.flipv_read_grid_box(self.h, GRID_IDS[name], _F(a)), "flipv_read_grid_box")
+        return a
+
+    def read_region(self, name, lo, hi):
+        """any box [lo, hi) of global indices (i, j, k) inside what the context allocates of the grid, box-shaped"""
+        a = np.empty((hi[2] - lo[2], hi[1] - lo[1], hi[0] - lo[0]), np.float32)
+        self._chk(self.L.flipv_read_grid_region(self.h, GRID_IDS[name], (C.c_int * 3)(*lo), (C.c_int * 3)(*hi), _F(a)), "flipv_read_grid_region")
         return a
 
     def write_box(self, name, a):

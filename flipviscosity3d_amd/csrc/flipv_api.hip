@@ -524,6 +524,20 @@ extern "C" int flipv_read_grid_box(flipv_context *c, int which, float *out) {
     if (!out || !grid_ref(c, which, &g)) { c->err = "flipv_read_grid_box: bad grid id"; return FLIPV_ERR_INVALID; }
     return read_lattice_box(c, g.lat, g.f, g.m, out);
 }
+extern "C" int flipv_read_grid_region(flipv_context *c, int which, const int *lo, const int *hi, float *out) {
+    ENTER(c);
+    GridRef g;
+    if (!out || !lo || !hi || !grid_ref(c, which, &g)) { c->err = "flipv_read_grid_region: bad argument"; return FLIPV_ERR_INVALID; }
+    int alo[3], ahi[3];
+    if (!lat_box(c, g.lat, 1, alo, ahi)) { c->err = "flipv_read_grid_region: the context holds nothing of this grid"; return FLIPV_ERR_INVALID; }
+    for (int a = 0; a < 3; a++)
+        if (lo[a] < alo[a] || hi[a] > ahi[a] || hi[a] <= lo[a]) { c->err = "flipv_read_grid_region: box outside what the context allocates"; return FLIPV_ERR_INVALID; }
+    const int rc = fv_pack(c, g.lat, g.f, g.m, c->stage, lo, hi);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out, c->stage, box_count(lo, hi) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FLIPV_OK;
+}
 extern "C" int flipv_write_grid_box(flipv_context *c, int which, const float *in) {
     ENTER(c);
     c->liqValid = c->liqPrevValid = 0;

@@ -243,6 +243,9 @@ int flipv_write_grid(flipv_context *ctx, int which, const float *in);
 int flipv_grid_box(flipv_context *ctx, int which, int kind, int *lo, int *hi);   /* kind 0 owned, 1 allocated; lo/hi: 3 ints each */
 int flipv_read_grid_box(flipv_context *ctx, int which, float *out);              /* the owned box */
 int flipv_write_grid_box(flipv_context *ctx, int which, const float *in);        /* the allocated box */
+/* any box [lo, hi) of global indices inside what the context allocates of that grid, box-shaped (x fastest): how a rank takes ITS part of a scene
+ * built on a setup context (flipv_create_setup) -- lo/hi from the block context's flipv_grid_box(kind 1) -- without a full-size host array */
+int flipv_read_grid_region(flipv_context *ctx, int which, const int *lo, const int *hi, float *out);
 
 /* ---- per-operator entry points, one per seam of advance() (fluidsimulation.cpp:138-167) ---- */
 int flipv_cfl(flipv_context *ctx, float *dt_out);                 /* _cfl                      fluidsimulation.cpp:241-269 */

@@ -315,3 +315,34 @@ def test_blocks_with_fp64_vectors_and_odd_sizes():
         for c in ctxs:
             c.close()
         ref.close()
+
+
+def test_box_shaped_handover_of_the_solid_sdf_from_a_setup_context():
+    """what a rank of `bench.py --gpus N --gpu-setup` does: the scene is built on a setup-only context, the block context takes ITS allocated
+    box of the solid SDF through flipv_read_grid_region / flipv_write_grid_box -- no full-size host array -- and ends up with exactly what
+    flipv_set_solid_sdf gives it from the full array"""
+    from flipviscosity3d_amd import capi, partition
+    from flipviscosity3d_amd import hostapi as H
+    import os
+    N = 40
+    dx = float(np.float32(1.0 / N))
+    mesh = H.load_ply(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshes", "sphere_large.ply"))
+    sc = capi.Context(N, N, N, dx, setup_only=True)
+    sc.reset_boundary()
+    sc.add_boundary_mesh(mesh, inverted=True)
+    full = sc.grid("SOLID_PHI")
+    for box in partition.block_boxes(N, N, N, (2, 2, 1)):
+        a = capi.Context(N, N, N, dx, device=0, block=box)
+        b = capi.Context(N, N, N, dx, device=0, block=box)
+        a.set_solid_sdf(full)
+        lo, hi = b.grid_box("SOLID_PHI", 1)
+        region = sc.read_region("SOLID_PHI", lo, hi)
+        assert region.shape == (hi[2] - lo[2], hi[1] - lo[1], hi[0] - lo[0])
+        assert np.array_equal(region, full[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]])
+        b.write_box("SOLID_PHI", region)
+        assert np.array_equal(a.read_box("SOLID_PHI"), b.read_box("SOLID_PHI"))
+        a.close(); b.close()
+    with pytest.raises(Exception):
+        sc.read_region("SOLID_PHI", (0, 0, 0), (N + 2, 4, 4))      # outside the lattice
+    sc.close()
+
