@@ -472,10 +472,13 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     if (NV == 4 && c->nRunsV > 0 && first == 0 && count == c->nActiveV) {   // k-marching over the run list (the whole system)
         int nbm = pcg_grid(c, c->nRunsV);
         if (nbm > cap) nbm = cap;
-#define VMARCH(P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv_march<T, P_, R_>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsV, c->nRunsV, \
+#define VMARCH(P_, R_, S_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv_march<T, P_, R_, S_>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsV, c->nRunsV, \
                            (const unsigned *)(c->vPred ? c->rmaskV : nullptr), c->tgV, c->L, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
-        if (c->vPred) { if (rdot) VMARCH(true, true); else VMARCH(true, false); }
-        else { if (rdot) VMARCH(false, true); else VMARCH(false, false); }
+        // streaming accesses on filled systems whose 52 bytes per index exceed the memory-side cache (pcg_common.h: ldvs)
+        const bool stream = !c->vPred && (double)c->nActiveV * (256 * 4) * 52.0 > 256.0 * 1024 * 1024;
+        if (c->vPred) { if (rdot) VMARCH(true, true, false); else VMARCH(true, false, false); }
+        else if (stream) { if (rdot) VMARCH(false, true, true); else VMARCH(false, false, true); }
+        else { if (rdot) VMARCH(false, true, false); else VMARCH(false, false, false); }
 #undef VMARCH
         if (timed) fv_ev_end(c);
         return;
