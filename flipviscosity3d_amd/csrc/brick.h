@@ -79,6 +79,46 @@ struct BrickWalk {
     }
 };
 
+// The walk of the kernels WITHOUT neighbour accesses (x / r / p updates): the lane <-> index map is free there, so a lane takes 4 consecutive
+// entries of one brick -- lane l of wave w of a block works on list entry 16 g + 4 w + (l >> 4), entries 4 (l & 15) .. + 3 of that brick -- and
+// every access is 16 bytes (a wave instruction moves four whole bricks instead of one).  m: the four indices' mask bytes.
+struct BrickWalkV {
+    int vb, ngroups, nvb;
+    size_t a, an;
+    unsigned m, mn;
+    __device__ __forceinline__ void fetch(int v, const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask, size_t &ao, unsigned &mo) const {
+        ao = 0; mo = 0u;
+        if (v < nvb) {
+            const int slot = d_tile_slot(v, ngroups);
+            const int e = slot * 16 + (int)threadIdx.y * 4 + ((int)threadIdx.x >> 4);
+            if (slot < ngroups && e < nb) {
+                ao = ((size_t)bricks[e] << 6) + (size_t)(((int)threadIdx.x & 15) << 2);
+                mo = *reinterpret_cast<const unsigned *>(mask + ao);
+            }
+        }
+    }
+    __device__ __forceinline__ void begin(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask) {
+        ngroups = (nb + 15) >> 4;
+        nvb = ((ngroups + 7) >> 3) << 3;
+        vb = (int)blockIdx.x;
+        fetch(vb, bricks, nb, mask, a, m);
+        fetch(vb + (int)gridDim.x, bricks, nb, mask, an, mn);
+    }
+    __device__ __forceinline__ bool valid() const { return vb < nvb; }
+    __device__ __forceinline__ void next(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask) {
+        a = an; m = mn;
+        vb += (int)gridDim.x;
+        fetch(vb + (int)gridDim.x, bricks, nb, mask, an, mn);
+    }
+    // component c has a row among the lane's four indices / at index e of them
+    __device__ __forceinline__ static bool any(unsigned mk, int c) { return ((mk >> c) & 0x01010101u) != 0u; }
+    __device__ __forceinline__ static bool row(unsigned mk, int c, int e) { return ((mk >> (8 * e + c)) & 1u) != 0u; }
+};
+static inline int fv_brickv_grid(int nbricks, int cap) {
+    const int g = (((nbricks + 15) / 16 + 7) / 8) * 8;
+    return g < 8 ? 8 : (g < cap ? g : cap);
+}
+
 // Scalar prologue of the update kernel (K2 of pcg_common.h), shared with k_pcg_update's logic (pcg_geo.inc): folds rmax(it-1), sigma(it),
 // a, b, c(it), runs the stop test and the stall guard, forms alpha and beta.  Returns false when the launch must do nothing.
 // lds: 8 doubles.  Every thread of the block must call it.

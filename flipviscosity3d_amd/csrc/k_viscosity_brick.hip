@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_bvisc_spmv(const int *__restrict__ bric
 template <typename T>
 __global__ __launch_bounds__(256) void k_bpcg_init(const int *__restrict__ bricks, int nb, BrickSys<T> v, PcgScal sc) {
     __shared__ double lds[4];
-    BrickWalk w;
+    BrickWalkV w;
     w.begin(bricks, nb, v.mask);
     double acc = 0.0;
     while (w.valid()) {
@@ -173,12 +173,17 @@ __global__ __launch_bounds__(256) void k_bpcg_init(const int *__restrict__ brick
         w.next(bricks, nb, v.mask);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            if (!((m >> c) & 1u)) continue;
-            const float d = v.diag[c][a];
-            const RT<T> r = v.r[c][a];
-            const double zd = d != 0.0f ? (double)r / (double)d : 0.0;
-            v.s[c][a] = (T)zd;
-            acc += zd * (double)r;
+            if (!BrickWalkV::any(m, c)) continue;
+            const Vec<float, 4> d = ldv<4>(v.diag[c] + a);
+            const Vec<RT<T>, 4> r = ldv<4>(v.r[c] + a);
+            Vec<T, 4> s;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const double zd = (BrickWalkV::row(m, c, e) && d.v[e] != 0.0f) ? (double)r.v[e] / (double)d.v[e] : 0.0;
+                s.v[e] = (T)zd;
+                acc += zd * (double)r.v[e];
+            }
+            stv(v.s[c] + a, s);
         }
     }
     const double tot = block_sum_256(acc, lds);
@@ -189,20 +194,20 @@ __global__ __launch_bounds__(256) void k_bpcg_init(const int *__restrict__ brick
 // (the scalar prologue, the stop test and the stall guard are k_pcg_update's, pcg_geo.inc)
 template <typename T>
 __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bricks, int nb, BrickSys<T> v, PcgScal sc, int it_arg) {
-    BrickWalk w;
+    BrickWalkV w;   // 16-byte accesses: a lane owns 4 consecutive entries of a brick (brick.h)
     w.begin(bricks, nb, v.mask);
-    // A brick's 15 values are requested as soon as its mask byte is known -- the first brick's BEFORE the scalar prologue (stop flag,
-    // iteration counter, the 160 partial sums and a barrier, none of which the data depends on), the next brick's before the current
+    // The 15 vectors of a lane are requested as soon as its mask word is known -- the first group's BEFORE the scalar prologue (stop flag,
+    // iteration counter, the 160 partial sums and a barrier, none of which the data depends on), the next group's before the current
     // one's stores (which may alias for all the compiler knows): the kernel is a chain of dependent round trips, not a stream.
-    struct Data { float d[3]; T x[3], s[3], q[3]; RT<T> r[3]; };
+    struct Data { Vec<float, 4> d[3]; Vec<T, 4> x[3], s[3], q[3]; Vec<RT<T>, 4> r[3]; };
     auto fetch = [&](size_t a, unsigned m) {
         Data D;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const bool on = (m >> c) & 1u;
-            D.d[c] = on ? v.diag[c][a] : 0.0f;
-            D.x[c] = on ? v.x[c][a] : (T)0; D.s[c] = on ? v.s[c][a] : (T)0; D.q[c] = on ? v.q[c][a] : (T)0;
-            D.r[c] = on ? v.r[c][a] : (RT<T>)0;
+            const bool on = BrickWalkV::any(m, c);
+            D.d[c] = on ? ldv<4>(v.diag[c] + a) : Vec<float, 4>{};
+            D.x[c] = on ? ldv<4>(v.x[c] + a) : Vec<T, 4>{}; D.s[c] = on ? ldv<4>(v.s[c] + a) : Vec<T, 4>{}; D.q[c] = on ? ldv<4>(v.q[c] + a) : Vec<T, 4>{};
+            D.r[c] = on ? ldv<4>(v.r[c] + a) : Vec<RT<T>, 4>{};
         }
         return D;
     };
@@ -217,25 +222,30 @@ __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bri
     double mxd = 0.0;
     while (w.valid()) {
         const size_t a = w.a;
+        const unsigned m = w.m;
         w.next(bricks, nb, v.mask);
         const Data nxt = fetch(w.a, w.m);
-        float d[3];
-        T x[3], s[3], q[3];
-        RT<T> r[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) { d[c] = cur.d[c]; x[c] = cur.x[c]; s[c] = cur.s[c]; q[c] = cur.q[c]; r[c] = cur.r[c]; }
+        Data D = cur;
         cur = nxt;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            if (d[c] == 0.0f) continue;
-            const RT<T> rn_t = (RT<T>)((double)r[c] - alpha_d * (double)q[c]);
-            const double rn = (double)rn_t;
-            const double zn = sizeof(RT<T>) == 4 ? (double)((float)rn_t / d[c]) : rn / (double)d[c];
-            v.x[c][a] = x[c] + alpha * s[c];
-            v.r[c][a] = rn_t;
-            v.s[c][a] = (T)(zn + beta_d * (double)s[c]);
-            if (sizeof(RT<T>) == 4) mxf = fmaxf(mxf, fabsf((float)rn_t)); else mxd = fmax(mxd, fabs(rn));
-            acc += zn * rn;
+            if (!BrickWalkV::any(m, c)) continue;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float d = D.d[c].v[e];
+                if (!BrickWalkV::row(m, c, e) || d == 0.0f) continue;
+                const RT<T> rn_t = (RT<T>)((double)D.r[c].v[e] - alpha_d * (double)D.q[c].v[e]);
+                const double rn = (double)rn_t;
+                const double zn = sizeof(RT<T>) == 4 ? (double)((float)rn_t / d) : rn / (double)d;
+                D.x[c].v[e] = D.x[c].v[e] + alpha * D.s[c].v[e];
+                D.r[c].v[e] = rn_t;
+                D.s[c].v[e] = (T)(zn + beta_d * (double)D.s[c].v[e]);
+                if (sizeof(RT<T>) == 4) mxf = fmaxf(mxf, fabsf((float)rn_t)); else mxd = fmax(mxd, fabs(rn));
+                acc += zn * rn;
+            }
+            stv(v.x[c] + a, D.x[c]);
+            stv(v.r[c] + a, D.r[c]);
+            stv(v.s[c] + a, D.s[c]);
         }
     }
     __shared__ double red[8];
@@ -407,6 +417,12 @@ int fv_brick_grid(const flipv_context *c, int nbricks, int cap) {
 // one resident round: 88-92 VGPRs = 5 waves per SIMD = 5 blocks per CU
 static int spmv_grid(const flipv_context *c) { return fv_brick_grid(c, c->nBricks, c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : 1280); }
 static int update_grid(const flipv_context *c) { return fv_brick_grid(c, c->nBricks, c->prm.viscosity_update_grid_cap > 0 ? c->prm.viscosity_update_grid_cap : 2048); }
+// (the kernels that walk 16 bricks per block step: BrickWalkV)
+static int updatev_grid(const flipv_context *c) {
+    int cap = c->prm.viscosity_update_grid_cap > 0 ? c->prm.viscosity_update_grid_cap : 2048;
+    if (c->prm.grid_cap > 0 && cap > ((c->prm.grid_cap + 7) / 8) * 8) cap = ((c->prm.grid_cap + 7) / 8) * 8;
+    return fv_brickv_grid(c->nBricks, cap);
+}
 
 template <typename T>
 void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot) {
@@ -424,14 +440,14 @@ template void fv_brick_spmv<double>(flipv_context *, const PcgScal &, int, bool)
 
 template <typename T>
 void fv_brick_init(flipv_context *c, const PcgScal &sc) {
-    hipLaunchKernelGGL((k_bpcg_init<T>), dim3(update_grid(c)), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, brick_sys<T>(c), sc);
+    hipLaunchKernelGGL((k_bpcg_init<T>), dim3(updatev_grid(c)), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, brick_sys<T>(c), sc);
 }
 template void fv_brick_init<float>(flipv_context *, const PcgScal &);
 template void fv_brick_init<double>(flipv_context *, const PcgScal &);
 
 template <typename T>
 void fv_brick_update(flipv_context *c, const PcgScal &sc, int it) {
-    hipLaunchKernelGGL((k_bpcg_update<T>), dim3(update_grid(c)), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, brick_sys<T>(c), sc, it);
+    hipLaunchKernelGGL((k_bpcg_update<T>), dim3(updatev_grid(c)), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, brick_sys<T>(c), sc, it);
 }
 template void fv_brick_update<float>(flipv_context *, const PcgScal &, int);
 template void fv_brick_update<double>(flipv_context *, const PcgScal &, int);

@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256) void k_bvmg_bbox(const int *__restrict__ brick
 // x += alpha p ; r -= alpha q ; rmax(it) ; z = omega r/d      (k_vpcg_xr of k_viscosity_mg_geo.inc)
 __global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask, Vec3p d, Vec3p x, Vec3p r, Vec3p p, Vec3p q,
                                                   Vec3p z, float omega, PcgScal sc, int it_arg) {
-    BrickWalk w;
+    BrickWalkV w;
     w.begin(bricks, nb, mask);
     if (*sc.conv >= 0) return;
     const int it = d_bvmg_iter(sc, it_arg);
@@ -816,28 +816,34 @@ __global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks
         const size_t a = w.a;
         const unsigned m = w.m;
         w.next(bricks, nb, mask);
-        // every load of the lane first (one round trip per brick, not one per component)
-        float dd[3], rr[3], xx[3], pp[3], qq[3];
+        if (m == 0u) continue;
+        // every load of the lane first (one round trip per group of bricks, not one per component)
+        Vec<float, 4> dd[3], rr[3], xx[3], pp[3], qq[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const bool on = (m >> c) & 1u;
-            dd[c] = on ? d.p[c][a] : 0.0f;
-            rr[c] = on ? r.p[c][a] : 0.0f;
-            xx[c] = (on && it >= 0) ? x.p[c][a] : 0.0f;
-            pp[c] = (on && it >= 0) ? p.p[c][a] : 0.0f;
-            qq[c] = (on && it >= 0) ? q.p[c][a] : 0.0f;
+            const bool on = BrickWalkV::any(m, c);
+            dd[c] = on ? ldv<4>(d.p[c] + a) : Vec<float, 4>{};
+            rr[c] = on ? ldv<4>(r.p[c] + a) : Vec<float, 4>{};
+            xx[c] = (on && it >= 0) ? ldv<4>(x.p[c] + a) : Vec<float, 4>{};
+            pp[c] = (on && it >= 0) ? ldv<4>(p.p[c] + a) : Vec<float, 4>{};
+            qq[c] = (on && it >= 0) ? ldv<4>(q.p[c] + a) : Vec<float, 4>{};
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            if (!((m >> c) & 1u)) continue;
-            if (it >= 0 && dd[c] != 0.0f) {
-                x.p[c][a] = xx[c] + alpha * pp[c];
-                rr[c] = (float)((double)rr[c] - alpha_d * (double)qq[c]);
-                r.p[c][a] = rr[c];
+            if (!BrickWalkV::any(m, c)) continue;
+            Vec<float, 4> zz;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool row = BrickWalkV::row(m, c, e) && dd[c].v[e] != 0.0f;
+                if (it >= 0 && row) {
+                    xx[c].v[e] += alpha * pp[c].v[e];
+                    rr[c].v[e] = (float)((double)rr[c].v[e] - alpha_d * (double)qq[c].v[e]);
+                    mx = fmaxf(mx, fabsf(rr[c].v[e]));
+                }
+                zz.v[e] = row ? omega * (rr[c].v[e] / dd[c].v[e]) : 0.0f;
             }
-            const float zz = dd[c] != 0.0f ? rr[c] / dd[c] : 0.0f;
-            if (it >= 0 && dd[c] != 0.0f) mx = fmaxf(mx, fabsf(rr[c]));
-            z.p[c][a] = omega * zz;
+            if (it >= 0) { stv(x.p[c] + a, xx[c]); stv(r.p[c] + a, rr[c]); }
+            stv(z.p[c] + a, zz);
         }
     }
     d_vmg_publish_max(sc, it, mx, lds);
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(256) void k_bvmg_prolong_fine(const int *__restrict
 }
 // stop test on rmax(it) ; beta = sig(it+1)/sig(it) ; p = z + beta p          (it = -1: p = z)
 __global__ __launch_bounds__(256) void k_bvpcg_p(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask, Vec3p z, Vec3p p, PcgScal sc, int it_arg) {
-    BrickWalk w;
+    BrickWalkV w;
     w.begin(bricks, nb, mask);
     if (*sc.conv >= 0) return;
     const int it = d_bvmg_iter(sc, it_arg);
@@ -891,16 +897,22 @@ __global__ __launch_bounds__(256) void k_bvpcg_p(const int *__restrict__ bricks,
         const size_t a = w.a;
         const unsigned m = w.m;
         w.next(bricks, nb, mask);
-        float zz[3], pp[3];
+        if (m == 0u) continue;
+        Vec<float, 4> zz[3], pp[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const bool on = (m >> c) & 1u;
-            zz[c] = on ? z.p[c][a] : 0.0f;
-            pp[c] = (on && it >= 0) ? p.p[c][a] : 0.0f;
+            const bool on = BrickWalkV::any(m, c);
+            zz[c] = on ? ldv<4>(z.p[c] + a) : Vec<float, 4>{};
+            pp[c] = (on && it >= 0) ? ldv<4>(p.p[c] + a) : Vec<float, 4>{};
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-            if ((m >> c) & 1u) p.p[c][a] = zz[c] + beta * pp[c];
+        for (int c = 0; c < 3; c++) {
+            if (!BrickWalkV::any(m, c)) continue;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (BrickWalkV::row(m, c, e)) pp[c].v[e] = zz[c].v[e] + beta * pp[c].v[e];
+            stv(p.p[c] + a, pp[c]);
+        }
     }
     if (it_arg == IT_DEVICE && blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0) *sc.itA = it + 1;
 }
@@ -1294,11 +1306,11 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     float *x[3] = {(float *)c->vX[0], (float *)c->vX[1], (float *)c->vX[2]}, *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
     float *p[3] = {(float *)c->vS[0], (float *)c->vS[1], (float *)c->vS[2]}, *q[3] = {(float *)c->vZ[0], (float *)c->vZ[1], (float *)c->vZ[2]};
     auto XR = [&](int it_) {
-        if (brick) hipLaunchKernelGGL(k_bvpcg_xr, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, (const uint8_t *)c->vMaskB, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), s->w[0], sc, it_);
+        if (brick) hipLaunchKernelGGL(k_bvpcg_xr, dim3(fv_brickv_grid(c->nBricks, c->prm.grid_cap > 0 ? ((c->prm.grid_cap + 7) / 8) * 8 : 2048)), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, (const uint8_t *)c->vMaskB, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), s->w[0], sc, it_);
         else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_xr, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(dg), v3(x), v3(r), v3(p), v3(q), v3(s->za), s->w[0], sc, it_));
     };
     auto PP = [&](int it_) {
-        if (brick) hipLaunchKernelGGL(k_bvpcg_p, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, (const uint8_t *)c->vMaskB, v3(s->zb), v3(p), sc, it_);
+        if (brick) hipLaunchKernelGGL(k_bvpcg_p, dim3(fv_brickv_grid(c->nBricks, c->prm.grid_cap > 0 ? ((c->prm.grid_cap + 7) / 8) * 8 : 2048)), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, (const uint8_t *)c->vMaskB, v3(s->zb), v3(p), sc, it_);
         else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vpcg_p, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, c->vRowMask, (const unsigned *)c->mlistV, c->vSwz, v3(s->zb), v3(p), sc, it_));
     };
     if (!brick) replace_period = 0;
