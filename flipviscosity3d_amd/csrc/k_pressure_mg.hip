@@ -339,7 +339,6 @@ static int mg_alloc(flipv_context *c, MgState *s, const Lay &L, float **p) {
     return FLIPV_OK;
 }
 
-#define HIPCHK_VOID(c_, s_, x_) do { hipError_t e_ = (x_); if (e_ != hipSuccess) { (c_)->err = std::string(#x_) + ": " + hipGetErrorString(e_); (s_)->rc = FLIPV_ERR_HIP; return; } } while (0)
 #define MGGRID(Lv) dim3(cdiv((Lv).ie - (Lv).ib, 64), cdiv((Lv).je - (Lv).jb, 4), (unsigned)((Lv).ke - (Lv).kb)), dim3(64, 4, 1)
 
 }  // namespace
@@ -349,8 +348,8 @@ void fv_mg_free(flipv_context *c) {
     c->mgState = nullptr;
 }
 
-// sum over the ranks of `narr` arrays of a level inside s->gbox, through the dense staging buffer
-static int mg_allreduce_box(flipv_context *c, MgState *s, const Lay &L, const Ptr4 &arr, int narr) {
+// sum over the ranks of `narr` arrays of a level inside s->gbox, through the dense staging buffer (`into`: where the sums go)
+static int mg_allreduce_box(flipv_context *c, MgState *s, const Lay &L, const Ptr4 &arr, const Ptr4 &into, int narr) {
     const CutBox &B = s->gbox;
     const size_t n = (size_t)(B.hi[0] - B.lo[0]) * (B.hi[1] - B.lo[1]) * (B.hi[2] - B.lo[2]), tot = n * (size_t)narr;
     if (tot > s->stageCap) {
@@ -365,7 +364,7 @@ static int mg_allreduce_box(flipv_context *c, MgState *s, const Lay &L, const Pt
     hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, arr, s->stage, 0);
     const int rc = fv_allreduce_f32(c, s->stage, tot);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, arr, s->stage, 1);
+    hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, into, s->stage, 1);
     return FLIPV_OK;
 }
 
@@ -465,7 +464,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
             for (int a = 0; a < 3; a++) if (g.hi[a] <= g.lo[a]) { g.lo[a] = 0; g.hi[a] = 1; }   // no pressure cell anywhere
             s->gbox = g;
             const Ptr4 op = {{C.diag, C.pi, C.pj, C.pk}};
-            if ((rc = mg_allreduce_box(c, s, C.L, op, 4))) return rc;
+            if ((rc = mg_allreduce_box(c, s, C.L, op, op, 4))) return rc;
         }
     }
     // Where this solve's sweeps run: the cells within reach of the liquid, halved level by level (the whole level when the liquid's
@@ -512,9 +511,8 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, cut, F.diag, F.pi,
                                F.pj, F.pk, c->pMask, F.x, F.b, s->bacc));
             if (s->global) {   // level 1's right-hand side = the sum of the ranks' shares (bacc stays the rank's own: k_mg_up0 clears exactly what it filled)
-                HIPCHK_VOID(c, s, hipMemcpyAsync(C.b, s->bacc, C.L.n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-                const Ptr4 rhs = {{C.b, nullptr, nullptr, nullptr}};
-                if ((s->rc = mg_allreduce_box(c, s, C.L, rhs, 1))) return;
+                const Ptr4 from = {{s->bacc, nullptr, nullptr, nullptr}}, to = {{C.b, nullptr, nullptr, nullptr}};
+                if ((s->rc = mg_allreduce_box(c, s, C.L, from, to, 1))) return;
             }
         } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
             const Lay &Fr = s->range[l];

@@ -529,11 +529,12 @@ __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ 
 }
 // b of level l over its whole box from the finer level's residual, without the first sweep: the level whose right-hand side is summed
 // over the ranks (VmgState::globalFrom).  Grid: (ceil(w / 64), ceil(h / 4), 3 depth), block (64, 4)
+// (the result goes straight into the dense staging buffer of the all-reduce: [component][position of the box, x fastest])
 template <int C, int FINE0>
-__device__ __forceinline__ void d_restrict_only(const VLevelDev &A, const Lay &F, const Vec3p &ft, int i, int j, int k) {
+__device__ __forceinline__ float d_restrict_only(const VLevelDev &A, const Lay &F, const Vec3p &ft, int i, int j, int k) {
     const size_t ci = cidx(A.L, i, j, k);
     const int P[3] = {i, j, k};
-    A.b.p[C][ci] = A.coef[C][slot_diag(C)][ci] != 0.0f ? d_restrict<C, FINE0>(F, ft, P) : 0.0f;
+    return A.coef[C][slot_diag(C)][ci] != 0.0f ? d_restrict<C, FINE0>(F, ft, P) : 0.0f;
 }
 // box-shaped copy between `narr` grids of a level (array a at base + a * per, cidx addressing) and a dense buffer [narr][positions of the box]:
 // what the all-reduces of the global hierarchy move (unpack = 0: grids -> buffer, 1: buffer -> grids)
@@ -545,15 +546,32 @@ __global__ __launch_bounds__(256) void k_vmg_box_pack(Lay L, Box3 B, float *__re
     float *g = base + (size_t)blockIdx.y * per + cidx(L, i, j, k), *q = buf + (size_t)blockIdx.y * n + t;
     if (unpack) *g = *q; else *q = *g;
 }
-__global__ __launch_bounds__(256) void k_vmg_restrict_box(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick) {
+__global__ __launch_bounds__(256) void k_vmg_restrict_box(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick, float *__restrict__ buf) {
     if (*conv >= 0) return;
     const VLevelDev &A = lev[l];
-    const int i = A.box.lo[0] + (int)(blockIdx.x * 64 + threadIdx.x), j = A.box.lo[1] + (int)(blockIdx.y * 4 + threadIdx.y);
-    const int c = (int)blockIdx.z % 3, k = A.box.lo[2] + (int)blockIdx.z / 3;
-    if (i >= A.box.hi[0] || j >= A.box.hi[1] || k >= A.box.hi[2]) return;
-#define RONLY(C_) do { if (l > 0) d_restrict_only<C_, 0>(A, lev[l - 1].L, lev[l - 1].t, i, j, k); else if (fineBrick) d_restrict_only<C_, 2>(A, F0, ft0, i, j, k); else d_restrict_only<C_, 1>(A, F0, ft0, i, j, k); } while (0)
-    if (c == 0) RONLY(0); else if (c == 1) RONLY(1); else RONLY(2);
+    const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dpt = A.box.hi[2] - A.box.lo[2];
+    const int di = (int)(blockIdx.x * 64 + threadIdx.x), dj = (int)(blockIdx.y * 4 + threadIdx.y);
+    const int c = (int)blockIdx.z % 3, dk = (int)blockIdx.z / 3;
+    if (di >= w || dj >= h || dk >= dpt) return;
+    const int i = A.box.lo[0] + di, j = A.box.lo[1] + dj, k = A.box.lo[2] + dk;
+    float v;
+#define RONLY(C_) (l > 0 ? d_restrict_only<C_, 0>(A, lev[l - 1].L, lev[l - 1].t, i, j, k) : (fineBrick ? d_restrict_only<C_, 2>(A, F0, ft0, i, j, k) : d_restrict_only<C_, 1>(A, F0, ft0, i, j, k)))
+    if (c == 0) v = RONLY(0); else if (c == 1) v = RONLY(1); else v = RONLY(2);
 #undef RONLY
+    buf[(size_t)c * ((size_t)w * h * dpt) + (size_t)di + (size_t)w * ((size_t)dj + (size_t)h * dk)] = v;
+}
+// the summed right-hand side back into the level's grids, with the first sweep x = omega b/d from the zero guess (`first`; the tail kernel does its own)
+__global__ __launch_bounds__(256) void k_vmg_unpack_rhs(const VLevelDev *__restrict__ lev, int l, const float *__restrict__ buf, const int *__restrict__ conv, int first) {
+    if (*conv >= 0) return;
+    const VLevelDev &A = lev[l];
+    const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1], dpt = A.box.hi[2] - A.box.lo[2];
+    const size_t n = (size_t)w * h * dpt, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const int c = (int)blockIdx.y;
+    const size_t ci = cidx(A.L, A.box.lo[0] + (int)(t % w), A.box.lo[1] + (int)((t / w) % h), A.box.lo[2] + (int)(t / ((size_t)w * h)));
+    const float b = buf[(size_t)c * n + t];
+    A.b.p[c][ci] = b;
+    if (first) { const float d = A.coef[c][slot_diag(c)][ci]; A.x.p[c][ci] = d != 0.0f ? A.w[0] * b / d : 0.0f; }
 }
 // bricks of a level's box that hold rows: flags (one wave per brick), then an ordered compaction by one workgroup
 __global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__restrict__ flag, int nbricks) {
@@ -982,8 +1000,7 @@ static VLevelDev dev_of(const VLevel &l) {
 }
 static long box_positions(const Box3 &b) { return (long)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]); }
 // sum over the ranks of `narr` grids of level A (the first at g0, consecutive ones A.per apart) inside the level's box, through the dense staging buffer
-static int vmg_allreduce_box(flipv_context *c, VmgState *s, const VLevel &A, float *g0, int narr) {
-    const size_t n = (size_t)box_positions(A.box), tot = n * (size_t)narr;
+static int vmg_stage_reserve(flipv_context *c, VmgState *s, size_t tot) {
     if (tot > s->stageCap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (s->stage) (void)hipFree(s->stage);
@@ -992,6 +1009,12 @@ static int vmg_allreduce_box(flipv_context *c, VmgState *s, const VLevel &A, flo
         if (e != hipSuccess) { c->err = std::string("hipMalloc(viscosity multigrid staging): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
         s->stageCap = tot;
     }
+    return FLIPV_OK;
+}
+static int vmg_allreduce_box(flipv_context *c, VmgState *s, const VLevel &A, float *g0, int narr) {
+    const size_t n = (size_t)box_positions(A.box), tot = n * (size_t)narr;
+    const int rc0 = vmg_stage_reserve(c, s, tot);
+    if (rc0) return rc0;
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)narr);
     hipLaunchKernelGGL(k_vmg_box_pack, grid, dim3(256), 0, c->stream, A.L, A.box, g0, A.per, s->stage, 0);
     const int rc = fv_allreduce_f32(c, s->stage, tot);
@@ -1254,21 +1277,26 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
 #define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), dim3(cdiv(s->lev[l_].nstrips > 0 ? s->lev[l_].nstrips : 1, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv, fb)
         const int gl = s->globalFrom;
         // the first global level's right-hand side: every rank restricts its own residual over the union box, the sum over the ranks is b
-        auto global_rhs = [&](int l) {
+        auto global_rhs = [&](int l, int first) {   // restriction into the staging buffer, all-reduce, back into b (and x = omega b/d: the first sweep)
             const Box3 &B = s->lev[l].box;
+            const size_t n = (size_t)box_positions(B);
+            int r2 = vmg_stage_reserve(c, s, 3 * n);
+            if (r2) return r2;
             hipLaunchKernelGGL(k_vmg_restrict_box, dim3(cdiv(B.hi[0] - B.lo[0], 64), cdiv(B.hi[1] - B.lo[1], 4), 3u * (unsigned)(B.hi[2] - B.lo[2])), dim3(64, 4, 1), 0, c->stream,
-                               (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb);
-            return vmg_allreduce_box(c, s, s->lev[l], s->lev[l].b[0], 3);
+                               (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, s->stage);
+            if ((r2 = fv_allreduce_f32(c, s->stage, 3 * n))) return r2;
+            hipLaunchKernelGGL(k_vmg_unpack_rhs, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, c->stream, (const VLevelDev *)s->d_lev, l, (const float *)s->stage, conv, first);
+            return (int)FLIPV_OK;
         };
         for (int l = 0; l < t0; l++) {   // down
-            if (l == gl) { if ((s->rc = global_rhs(l))) return; STEP(OP_FIRST, l); }
+            if (l == gl) { if ((s->rc = global_rhs(l, 1))) return; }
             else STEP(OP_RESTRICT, l);
             STEP(OP_PRE2, l);
             STEP(OP_RESID, l);
         }
         {
             const int sweeps = c->vmgSweeps > 0 ? c->vmgSweeps : VMG_COARSEST_SWEEPS;
-            if (t0 == gl && (s->rc = global_rhs(t0))) return;
+            if (t0 == gl && (s->rc = global_rhs(t0, 0))) return;
             hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
         }
         for (int l = t0 - 1; l >= 0; l--) {   // up

@@ -19,6 +19,8 @@ $B --workload honey --size 512 --viscosity 50 --steps 5 --warmup 2 $Q > $out/ben
 $B --workload sheet --size 1024 --steps 3 --warmup 1 $Q > $out/bench_sheet1024.json 2>/dev/null
 python3 tools/local_ranks_bench.py strong 2,2,2 256 > $out/local_ranks_222_256.log 2>&1
 python3 tools/r3_scene.py bunny 256 5 60 0 > $out/soak256_60.log 2>&1
+(python3 tools/r3_status.py bunny 256 5 400; python3 tools/r3_status.py honey 256 50 120; python3 tools/r3_status.py sheet 512 5 120; python3 tools/r3_status.py bunny 128 5 300) > $out/soak_status.log 2>&1
+bash tools/profile_round.sh ${tag}diag --gpu-setup --viscosity-preconditioner diagonal > $out/prof_${tag}diag.log 2>&1
 (cd tools/micro && hipcc --offload-arch=gfx950 -O3 stream_mix.hip -o /tmp/stream_mix && /tmp/stream_mix 16.8 30 && /tmp/stream_mix 134 10) > $out/stream_mix.log 2>&1
 for f in $out/*.json; do python3 - "$f" <<'PY'
 import json, sys
