@@ -263,9 +263,11 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     sc->best = c->d_scal_small + 49;
     sc->stall_below = 0.0;
     sc->stalled = c->d_flags + 11;
+    sc->bestIt = c->d_flags + 14;
     // reset the stall guard (enqueued before any kernel of the solve): best = 0x7f7f... = 1.4e306, "nothing seen yet"
     (void)hipMemsetAsync(sc->best, 0x7f, sizeof(double), c->stream);
     (void)hipMemsetAsync(sc->stalled, 0, sizeof(int), c->stream);
+    (void)hipMemsetAsync(sc->bestIt, 0, sizeof(int), c->stream);
     *extra = c->d_scal + 5 * n;
 }
 

@@ -886,9 +886,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     if (c->prm.verbose && nontrivial)
         fprintf(stderr, "viscosity solve %ld: %s, %s layout, %d iterations, residual %.3g (rhs %.3g), %s\n", c->viscSolves, ranMg ? "multigrid" : "diagonal",
                 brick ? "brick" : (c->vSwz ? "swizzled" : "plain"), iters, res, bnorm, success ? "converged" : (stalled ? "stalled" : "cap"));
-    // (A multigrid-preconditioned fp32 solve that STALLS two orders of magnitude or more below the right-hand side keeps its iterate: it
-    // is far closer to the solution than a capped diagonal solve gets, and is reported as "not converged" like any accepted iterate.)
-    if (ranMg && !success && !defectLimited && !(stalled && res < 1e-4 * bnorm)) {
+    // (A multigrid-preconditioned solve that stalls or runs into the cap four orders of magnitude or more below the right-hand side keeps its
+    // iterate: it is far closer to the solution than a capped diagonal solve gets -- 1e-2 at best on such systems --, and is reported as "not
+    // converged" like any accepted iterate.)
+    if (ranMg && !success && !defectLimited && !(res < 1e-4 * bnorm)) {
         // The multigrid-preconditioned solve did not reach the tolerance.  Its iterate is not used: the solve is repeated from scratch
         // with the diagonal, whose capped iterate is what the reference's acceptance rule is about.
         c->viscSolves++;

@@ -61,6 +61,7 @@ constexpr int VMG_MIN_DIM = 16;           // no level below this many cells alon
 constexpr int VMG_TAIL_POS = 640;         // levels with at most this many index positions in their box go into the single-workgroup tail
 constexpr int VMG_TAIL_MAX = 3;           // ... at most this many levels
 constexpr int VMG_MAX_LEVELS = 15;
+constexpr int VMG_NO_PROGRESS = 64;         // iterations without a 10 % gain on max|r| after which the multigrid loop gives up (d_vmg_stop_test)
 
 // slot tables: neighbour component and offset of slot s of a row of component c; inverse look-up by (c, c', offset)
 struct SlotTables {
@@ -789,6 +790,19 @@ __device__ __forceinline__ bool d_vmg_stop_test(const PcgScal &sc, int it, doubl
         if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > 16.0 * bestNow) {
             if (first) { *sc.stalled = 1; *sc.conv = it; }
             return true;
+        }
+        // No progress: max|r| has not come down by 10 % for VMG_NO_PROGRESS iterations -- an fp32 recurrence that has lost its conjugacy hovers a
+        // decade above the tolerance for hundreds of iterations (512 x 256 x 256 sheet, one solve in ~500: 700 iterations at 1.7e-5 max|rhs| where the
+        // same system converges in ~100 on other runs).  The solve stops as "stalled"; where it can (fp32 bricks) the caller restarts it from the
+        // fp64 residual.  Every block decides alike whichever of the first block's updates it sees: bestIt is written before best, and a block
+        // that still sees the old best sees progress through `res` itself.
+        if (sc.bestIt) {
+            const int bi = *sc.bestIt;
+            if (res >= 0.9 * bestNow && it - bi > VMG_NO_PROGRESS) {
+                if (first) { *sc.stalled = 1; *sc.conv = it; }
+                return true;
+            }
+            if (first && res < 0.9 * bestNow) { *sc.bestIt = it; __threadfence(); }
         }
         if (first && res < bestNow) *sc.best = res;
     }

@@ -124,6 +124,7 @@ struct PcgScal {
     // update kernel stops the solve (sets *stalled and the stop flag): the iterate of that moment is returned as "not converged".
     double *best;   // nullptr: no guard
     int *stalled;
+    int *bestIt;    // iteration at which *best last improved by 10 % (the multigrid loop's no-progress guard, k_viscosity_mg.hip: d_vmg_stop_test); nullptr: none
     double stall_below;   // the guard arms once *best <= this; 0 = 100 x tol.  (A loop restarted close to its tolerance -- iterative refinement --
                           // sets it to a fraction of the restart's residual: the first iterations of CG overshoot it in the max norm.)
     // device-side iteration counters for hipGraph replay (kernels launched with it_arg = -1): the SpMV reads itA and
