@@ -428,6 +428,10 @@ def main():
         units = last["viscosity"]["rows"] / 3.0   # this rank's rows (rank 0)
         gbs = VISC_SPMV_BYTES_PER_INDEX * units / (avg_ms * 1e-3) / 1e9
         kname = ("k_bvisc_spmv" if last["viscosity"]["layout"] == 2 else "k_visc_spmv") + ("<float>" if args.precision == 0 else "<double>")
+        # the instantiation the PCG loop itself launches (the multigrid's fine-level sweeps are other instantiations of the same kernel)
+        kvariant = None
+        if last["viscosity"]["layout"] == 2:
+            kvariant = "k_bvisc_spmv<%s, %s, 0>" % ("float" if args.precision == 0 else "double", "false" if last["viscosity"]["preconditioner"] == 1 else "true")
         roof = {"kernel": kname, "bound": "hbm",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": avg_ms * 1e3, "launches": v_n, "units_per_launch": units, "bytes_per_unit": VISC_SPMV_BYTES_PER_INDEX,
@@ -445,7 +449,11 @@ def main():
                 "units_per_launch": units, "bytes_per_unit": PRES_SPMV_BYTES_PER_CELL, "unit_definition": "pressure cell",
                 "swept_indices_per_launch": p_cells / p_n}
     if roof is not None:
-        roof.update(committed_profile(roof["kernel"].split("<")[0], N, args, world))
+        roof.update(committed_profile(kvariant if (v_n > 0 and v_ms >= p_ms and kvariant) else roof["kernel"].split("<")[0], N, args, world))
+        if v_n > 0 and v_ms >= p_ms and kvariant:
+            roof["kernel_instantiation"] = kvariant
+        if roof.get("rocprof_avg_launch_us"):   # the same algorithmic bytes over rocprofv3's kernel-only duration (the event bracket above includes the dispatch gap)
+            roof["frac_at_rocprof_duration"] = roof["bytes_per_unit"] * roof["units_per_launch"] / (roof["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
     extra = {}
     if p_n > 0:
         avg = p_ms / p_n
@@ -568,7 +576,7 @@ def committed_profile(kernel, N, args, world):
         d = json.load(open(pmc[-1]))
         for name, v in d.items():
             name = re.sub(r"^g\d+::", "", name)   # tile-geometry namespace (csrc/pcg_geo.inc)
-            if name.startswith(kernel + "<") or name == kernel:
+            if name.startswith(kernel if "<" in kernel else kernel + "<") or name == kernel:
                 out["traffic"] = v["hbm_bytes_per_launch"]
                 out["traffic_unit"] = "bytes per launch (HBM read + write, PMC)"
                 out["traffic_source"] = os.path.relpath(pmc[-1], os.path.dirname(root))
@@ -577,7 +585,7 @@ def committed_profile(kernel, N, args, world):
     if st:
         for r in csv.DictReader(open(st[-1])):
             nm = re.sub(r"^(void )?(g\d+::)?", "", r["Name"])
-            if nm.startswith(kernel + "<") or nm.startswith(kernel + "("):
+            if nm.startswith(kernel if "<" in kernel else kernel + "<") or nm.startswith(kernel + "("):
                 out["rocprof_avg_launch_us"] = float(r["AverageNs"]) / 1e3
                 out["rocprof_source"] = os.path.relpath(st[-1], os.path.dirname(root))
                 break
