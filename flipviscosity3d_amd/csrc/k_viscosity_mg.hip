@@ -681,41 +681,14 @@ __device__ __forceinline__ void d_coarsest_sweep(const CoarseRow &R, const float
     nxt[C * NP + R.li] = cur[C * NP + R.li] + omega * (R.b - ax) * R.invd;
 }
 
-// sweeps: Jacobi sweeps on the coarsest level after the one that turns the zero guess into omega b/d; cheb: they use the sweeps + 1 Chebyshev weights of lev[n - 1].cheb
-// bGiven: the right-hand side of level `first` is in its b already (summed over the ranks by the caller)
-__global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, int cheb, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick, int bGiven) {
-    if (*conv >= 0) return;
-    // the coarsest level lives in LDS when its box and rows fit (k_vmg_coarsest_rows decided that for this solve)
-    __shared__ float xs[2 * 3 * VMG_LDS_POS];
-    int W = 0, H = 0, NP = 0;
-    const int *rowlist[3] = {lev[n - 1].rowlist, lev[n - 1].rowlist + 1024, lev[n - 1].rowlist + 2048};
-    int cnt[3] = {0, 0, 0};
-    const bool coarsest_in_lds = lev[n - 1].rowcnt[3] != 0;
-    if (coarsest_in_lds) {
-        const VLevelDev &A = lev[n - 1];
-        W = A.box.hi[0] - A.box.lo[0] + 2; H = A.box.hi[1] - A.box.lo[1] + 2; NP = W * H * (A.box.hi[2] - A.box.lo[2] + 2);
-        cnt[0] = A.rowcnt[0]; cnt[1] = A.rowcnt[1]; cnt[2] = A.rowcnt[2];
-        for (int e = threadIdx.x; e < 3 * NP; e += blockDim.x) { xs[e] = 0.0f; xs[3 * VMG_LDS_POS + e] = 0.0f; }
-        __syncthreads();
-    }
-    for (int l = first; l < n; l++) {   // down
-        const VLevelDev &A = lev[l];
-        if (l == n - 1 && coarsest_in_lds) break;   // restricted straight into registers below
-        if (l == first && bGiven) d_tail_step<OP_FIRST>(A, A.L, ft0, A.L, ft0);
-        else if (l == 0) { if (fineBrick) d_tail_step<OP_RESTRICT, 2>(A, F0, ft0, A.L, ft0); else d_tail_step<OP_RESTRICT, 1>(A, F0, ft0, A.L, ft0); }
-        else d_tail_step<OP_RESTRICT>(A, lev[l - 1].L, lev[l - 1].t, A.L, ft0);
-        if (l + 1 < n) {
-            d_tail_step<OP_PRE2>(A, A.L, ft0, A.L, ft0);
-            d_tail_step<OP_RESID>(A, A.L, ft0, A.L, ft0);
-        }
-    }
-    if (!coarsest_in_lds) {   // coarsest level through global memory (its restriction was done by the loop above)
-        const VLevelDev &A = lev[n - 1];
-        for (int s = 0; s < sweeps; s += 2) {
-            d_tail_step<OP_SWEEP_XY>(A, A.L, ft0, A.L, ft0);
-            d_tail_step<OP_SWEEP_YX>(A, A.L, ft0, A.L, ft0);
-        }
-    } else {
+// The LDS-resident coarsest level: restriction (or the given right-hand side), Chebyshev / damped-Jacobi sweeps, write-back of x.  xs: 2 x 3 x VMG_LDS_POS
+// floats of LDS, zero on entry inside the box's rim.  A function of its own so that k_vmg_coarsest -- the whole tail whenever the tail is just this
+// level, which is the usual case -- is compiled without the other levels' code paths around it (inside the generic tail the register allocator
+// spilled two of a row's values and reloaded them in every sweep: 60.9 -> 53.2 us).  Measured and worse, all through spills or branches at the
+// 128-VGPR budget of a 1 024-thread block: the 23 LDS values of a sweep loaded before the sum (55.9 us), rows dealt out over all threads with the
+// component chosen at run time per row (130 us) or per wave with two rows per lane (77.9 us).
+__device__ __forceinline__ void d_coarsest_solve(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, int cheb, const Lay &F0, const Vec3p &ft0, int fineBrick, int bGiven,
+                                                 float *xs, int W, int H, int NP, const int *const rowlist[3], const int cnt[3]) {
         const VLevelDev &A = lev[n - 1];
         const Lay &F = n - 1 == 0 ? F0 : lev[n - 2].L;
         const Vec3p &ft = n - 1 == 0 ? ft0 : lev[n - 2].t;
@@ -762,6 +735,43 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
         if (RV.has) A.x.p[1][RV.ci] = cur[1 * NP + RV.li];
         if (RW.has) A.x.p[2][RW.ci] = cur[2 * NP + RW.li];
         __syncthreads();
+}
+// sweeps: Jacobi sweeps on the coarsest level after the one that turns the zero guess into omega b/d; cheb: they use the sweeps + 1 Chebyshev weights of lev[n - 1].cheb
+// bGiven: the right-hand side of level `first` is in its b already (summed over the ranks by the caller)
+__global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__ lev, int first, int n, int sweeps, int cheb, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick, int bGiven) {
+    if (*conv >= 0) return;
+    // the coarsest level lives in LDS when its box and rows fit (k_vmg_coarsest_rows decided that for this solve)
+    __shared__ float xs[2 * 3 * VMG_LDS_POS];
+    int W = 0, H = 0, NP = 0;
+    const int *rowlist[3] = {lev[n - 1].rowlist, lev[n - 1].rowlist + 1024, lev[n - 1].rowlist + 2048};
+    int cnt[3] = {0, 0, 0};
+    const bool coarsest_in_lds = lev[n - 1].rowcnt[3] != 0;
+    if (coarsest_in_lds) {
+        const VLevelDev &A = lev[n - 1];
+        W = A.box.hi[0] - A.box.lo[0] + 2; H = A.box.hi[1] - A.box.lo[1] + 2; NP = W * H * (A.box.hi[2] - A.box.lo[2] + 2);
+        cnt[0] = A.rowcnt[0]; cnt[1] = A.rowcnt[1]; cnt[2] = A.rowcnt[2];
+        for (int e = threadIdx.x; e < 3 * NP; e += blockDim.x) { xs[e] = 0.0f; xs[3 * VMG_LDS_POS + e] = 0.0f; }
+        __syncthreads();
+    }
+    for (int l = first; l < n; l++) {   // down
+        const VLevelDev &A = lev[l];
+        if (l == n - 1 && coarsest_in_lds) break;   // restricted straight into registers below
+        if (l == first && bGiven) d_tail_step<OP_FIRST>(A, A.L, ft0, A.L, ft0);
+        else if (l == 0) { if (fineBrick) d_tail_step<OP_RESTRICT, 2>(A, F0, ft0, A.L, ft0); else d_tail_step<OP_RESTRICT, 1>(A, F0, ft0, A.L, ft0); }
+        else d_tail_step<OP_RESTRICT>(A, lev[l - 1].L, lev[l - 1].t, A.L, ft0);
+        if (l + 1 < n) {
+            d_tail_step<OP_PRE2>(A, A.L, ft0, A.L, ft0);
+            d_tail_step<OP_RESID>(A, A.L, ft0, A.L, ft0);
+        }
+    }
+    if (!coarsest_in_lds) {   // coarsest level through global memory (its restriction was done by the loop above)
+        const VLevelDev &A = lev[n - 1];
+        for (int s = 0; s < sweeps; s += 2) {
+            d_tail_step<OP_SWEEP_XY>(A, A.L, ft0, A.L, ft0);
+            d_tail_step<OP_SWEEP_YX>(A, A.L, ft0, A.L, ft0);
+        }
+    } else {
+        d_coarsest_solve(lev, first, n, sweeps, cheb, F0, ft0, fineBrick, bGiven, xs, W, H, NP, rowlist, cnt);
     }
     for (int l = n - 2; l >= first; l--) {   // up
         const VLevelDev &A = lev[l];
@@ -769,6 +779,19 @@ __global__ __launch_bounds__(1024) void k_vmg_tail(const VLevelDev *__restrict__
         d_tail_step<OP_POST1>(A, A.L, ft0, A.L, ft0);
         d_tail_step<OP_POST2>(A, A.L, ft0, A.L, ft0);
     }
+}
+
+// the tail when it is just the LDS-resident coarsest level (first == n - 1 and the level fits: k_vmg_coarsest_rows)
+__global__ __launch_bounds__(1024) void k_vmg_coarsest(const VLevelDev *__restrict__ lev, int n, int sweeps, int cheb, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick, int bGiven) {
+    if (*conv >= 0) return;
+    __shared__ float xs[2 * 3 * VMG_LDS_POS];
+    const VLevelDev &A = lev[n - 1];
+    const int *rowlist[3] = {A.rowlist, A.rowlist + 1024, A.rowlist + 2048};
+    const int W = A.box.hi[0] - A.box.lo[0] + 2, H = A.box.hi[1] - A.box.lo[1] + 2, NP = W * H * (A.box.hi[2] - A.box.lo[2] + 2);
+    const int cnt[3] = {A.rowcnt[0], A.rowcnt[1], A.rowcnt[2]};
+    for (int e = threadIdx.x; e < 3 * NP; e += blockDim.x) { xs[e] = 0.0f; xs[3 * VMG_LDS_POS + e] = 0.0f; }
+    __syncthreads();
+    d_coarsest_solve(lev, n - 1, n, sweeps, cheb, F0, ft0, fineBrick, bGiven, xs, W, H, NP, rowlist, cnt);
 }
 
 // ---- what the x / r kernels of either layout publish and the p kernels test: max|r| into rmax(it)
@@ -971,6 +994,7 @@ struct VmgState {
     VLevelDev *d_lev = nullptr;  // the level descriptors in device memory (this solve's boxes), h_lev their pinned staging copy
     VLevelDev *h_lev = nullptr;
     int tailFirst = 0;           // index into lev of the first level the tail kernel handles (this solve)
+    bool coarsestInLds = false;  // k_vmg_coarsest_rows' verdict for this solve (the level's box and rows fit one workgroup's LDS and threads)
     // Block contexts (flipv_comm.h): levels lev[0 .. globalFrom) are the rank's own (its rows only, couplings across the cuts dropped, nothing
     // exchanged: block-Jacobi); from lev[globalFrom] on the hierarchy is the GLOBAL one, held and cycled redundantly by every rank -- its operator is
     // the sum over the ranks of their Galerkin contributions (one all-reduce per solve), its right-hand side the sum of their restricted
@@ -1228,10 +1252,11 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         }
         hipLaunchKernelGGL(k_vmg_coarsest_rows, dim3(1), dim3(1024), 0, c->stream, dev_of(s->lev.back()), s->d_rowlist, s->d_rowcnt);
         int counts[VMG_MAX_LEVELS];
-        if (s->tailFirst > 0) {
-            HIPCHK(c, hipMemcpyAsync(counts, s->d_stripCount, s->tailFirst * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-        }
+        int fitsLds = 0;
+        HIPCHK(c, hipMemcpyAsync(&fitsLds, s->d_rowcnt + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (s->tailFirst > 0) HIPCHK(c, hipMemcpyAsync(counts, s->d_stripCount, s->tailFirst * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        s->coarsestInLds = fitsLds != 0;
         s->w[0] = c->prm.viscosity_mg_omega_first > 0.0f ? c->prm.viscosity_mg_omega_first : VMG_W_DEFAULT[0];
         s->w[1] = c->prm.viscosity_mg_omega_second > 0.0f ? c->prm.viscosity_mg_omega_second : VMG_W_DEFAULT[1];
         {   // Chebyshev weights of the coarsest level when the sweep count is a power of two (k_vmg_tail); any other count: plain damped Jacobi
@@ -1262,6 +1287,9 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         (void)hipStreamSynchronize(c->stream);
         fprintf(stderr, "viscosity multigrid: %zu coarse levels, tail from %d, level 0 in the %s layout\n", s->lev.size(), s->tailFirst, brick ? "brick" : "plain");
         for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d), %d bricks\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2], s->lev[l].nstrips); }
+        int rcnt[4] = {0, 0, 0, 0};
+        (void)hipMemcpy(rcnt, s->d_rowcnt, sizeof(rcnt), hipMemcpyDeviceToHost);
+        fprintf(stderr, "  coarsest level: %d / %d / %d rows per component, %s\n", rcnt[0], rcnt[1], rcnt[2], rcnt[3] ? "in LDS" : "through global memory");
     }
     HIPCHK(c, hipGetLastError());
     *out = s;
@@ -1311,7 +1339,10 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
         {
             const int sweeps = c->vmgSweeps > 0 ? c->vmgSweeps : VMG_COARSEST_SWEEPS;
             if (t0 == gl && (s->rc = global_rhs(t0, 0))) return;
-            hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
+            if (t0 == nl - 1 && s->coarsestInLds)   // the tail is just the LDS-resident coarsest level: its own kernel (no other level's code around the sweeps)
+                hipLaunchKernelGGL(k_vmg_coarsest, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
         }
         for (int l = t0 - 1; l >= 0; l--) {   // up
             STEP(OP_PROPOST, l);
