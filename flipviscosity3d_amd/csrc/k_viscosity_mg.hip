@@ -850,6 +850,13 @@ __global__ __launch_bounds__(256) void k_bvmg_bbox(const int *__restrict__ brick
         if ((threadIdx.x & 63) == 0) { atomicMin(box + a, lo[a]); atomicMax(box + 3 + a, hi[a]); }
     }
 }
+// zero `narr` brick-layout arrays (array a at base + a * per) on the listed bricks
+__global__ __launch_bounds__(256) void k_bvmg_zero(const int *__restrict__ bricks, int nb, float *__restrict__ base, size_t per, int narr) {
+    for (int e = (int)blockIdx.x * 4 + (int)threadIdx.y; e < nb; e += (int)gridDim.x * 4) {
+        const size_t a = ((size_t)bricks[e] << 6) + threadIdx.x;
+        for (int q = 0; q < narr; q++) base[(size_t)q * per + a] = 0.0f;
+    }
+}
 // x += alpha p ; r -= alpha q ; rmax(it) ; z = omega r/d      (k_vpcg_xr of k_viscosity_mg_geo.inc)
 __global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks, int nb, const uint8_t *__restrict__ mask, Vec3p d, Vec3p x, Vec3p r, Vec3p p, Vec3p q,
                                                   Vec3p z, float omega, PcgScal sc, int it_arg) {
@@ -1010,6 +1017,11 @@ struct VmgState {
     int chebM = 0;
     int minDim = 0;              // the coarsest level's longest axis the hierarchy was allocated for (flipv_params.viscosity_mg_min_dim)
     void *fineVecs = nullptr;    // the fine level's three sweep vectors (zeroed every solve; the coarse levels' only with a new hierarchy)
+    // brick layout: the sweep vectors are non-zero only on the bricks the previous solve listed, so that list (a copy) is what gets zeroed, not
+    // the 9 whole arrays (705 MB at 256^3: two memsets of ~100 us per solve); -1: nothing known, zero everything
+    int *prevBricks = nullptr;
+    int prevCount = -1;
+    size_t fineStride = 0;       // floats between consecutive fine vectors
     size_t fineVecBytes = 0;
     ~VmgState() { for (void *p : allocs) (void)hipFree(p); if (stage) (void)hipFree(stage); if (h_lev) (void)hipHostFree(h_lev); }
 };
@@ -1101,6 +1113,9 @@ static int vmg_alloc_state(flipv_context *c) {
         const size_t per0 = c->L.guard + c->solverCap + c->L.guard;   // room for either layout of level 0
         if ((rc = vmg_alloc(c, s, per0, 9, &base))) return rc;
         s->fineVecs = base; s->fineVecBytes = 9 * per0 * sizeof(float);
+        s->fineStride = per0;
+        HIPCHK(c, hipMalloc((void **)&s->prevBricks, ((size_t)c->brickCap + 64) * sizeof(int)));
+        s->allocs.push_back(s->prevBricks);
         for (int m = 0; m < 3; m++) {
             s->za[m] = base + (size_t)m * per0 + c->L.guard;
             s->zb[m] = base + (size_t)(3 + m) * per0 + c->L.guard;
@@ -1148,7 +1163,13 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     VmgState *s = (VmgState *)c->vmgState;
     const bool brick = vmg_brick(c);
     // the fine level's sweep vectors must be zero wherever there is no row (the SpMV and the restriction read neighbours unmasked)
-    HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
+    if (brick && s->prevCount >= 0) {
+        if (s->prevCount > 0) hipLaunchKernelGGL(k_bvmg_zero, dim3(cdiv(s->prevCount, 4) < 2048 ? cdiv(s->prevCount, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)s->prevBricks, s->prevCount, s->za[0], s->fineStride, 9);
+    } else HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
+    if (brick) {
+        HIPCHK(c, hipMemcpyAsync(s->prevBricks, c->brickList, (size_t)c->nBricks * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        s->prevCount = c->nBricks;
+    } else s->prevCount = -1;
     // ---- a new hierarchy for every solve (a kept one over-corrects after a change of dt): the box of the rows, level by level
     {
         HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)s->d_box, 0x7fffffff, 3, c->stream));
@@ -1368,7 +1389,9 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     VmgState *s = (VmgState *)c->vmgState;
     int rc = FLIPV_OK;
     if (!restart || !s) rc = vmg_setup(c, &s);
-    else HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
+    else if (vmg_brick(c) && s->prevCount >= 0) {   // (a restart inside a solve: the same brick list)
+        if (s->prevCount > 0) hipLaunchKernelGGL(k_bvmg_zero, dim3(cdiv(s->prevCount, 4) < 2048 ? cdiv(s->prevCount, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)s->prevBricks, s->prevCount, s->za[0], s->fineStride, 9);
+    } else HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
     if (rc) return rc;
     PcgScal sc = sc_in;
     sc.noB = 1;   // this loop needs p.q only: the SpMV variant that does not read the residual
