@@ -1,4 +1,4 @@
-// k_viscosity_mg.hip -- Galerkin multigrid preconditioner for the variational viscosity PCG (single GPU, fp32 vectors).
+// k_viscosity_mg.hip -- Galerkin multigrid preconditioner for the variational viscosity PCG (fp32 vectors; one GPU or block contexts).
 //
 // The viscosity system (viscositysolver.cpp:276-664) couples the three face-velocity components through the shear
 // stresses; its rigid modes make piecewise-constant coarse spaces useless and only Galerkin coarse operators survive the
@@ -11,18 +11,22 @@
 //                same-component neighbours (normal offset -1/0/+1 times {centre, +-1 along either transverse axis}) and 4
 //                + 4 cross-component neighbours -- the fine 15-point pattern plus the normal-times-transverse diagonals.
 //                Storage: one coefficient grid per (component, slot) on the level's dense index space ("dense slots").
-//   level 0      matrix-free: the tile SpMV kernel of k_viscosity.hip with the Jacobi update / the residual as its epilogue
-//                (k_visc_spmv<.., EPI>): a sweep is ONE launch that reads the iterate with its halo and writes the next one
-//   assembly     level 1 is scattered from the matrix-free fine rows (each fine row knows its <= 15 entries and each end of an
-//                entry its <= 2 parents; a tile's contributions are summed in LDS and flushed with one atomic per coarse entry),
-//                level l+1 from level l with atomics
-//   cycle        V(2,2), damped Jacobi (omega 0.6: lambda_max(D^-1 A) ~ 3), zero initial guess; the hierarchy stops at 16^3
-//                (16 sweeps there: deeper levels bought nothing in the prototype, tests/research/vmg_proto.py)
+//   level 0      matrix-free: the SpMV kernel of the solve's layout -- k_bvisc_spmv<.., EPI> on bricks (k_viscosity_brick.hip), k_visc_spmv<.., EPI> on
+//                planes (k_viscosity.hip) -- with the Jacobi update / the residual as its epilogue: a sweep is ONE launch that reads the iterate with
+//                its halo and writes the next one
+//   assembly     Galerkin products as GATHERS, one thread per coarse row: level 1 from the matrix-free fine rows (k_vmg_rap_gather_fine: a coarse row
+//                collects w_child A(child, q) w_parent from its <= 12 children; parities and slots are compile-time constants, the 23
+//                accumulators registers), level l+1 from level l (k_vmg_rap_gather).  Every entry of a level's box is written, nothing is zeroed
+//   cycle        V(2,2), zero initial guess; the two Jacobi sweeps of a pair use the Chebyshev weights (1.317, 0.382) of [3/8, 3] (lambda_max(D^-1 A) ~ 3;
+//                VMG_W_DEFAULT); the hierarchy stops at 16^3, which is solved in LDS by 16 or 32 Chebyshev-weighted sweeps on [lambda_hi / 100, lambda_hi]
+//                (VMG_CHEB_KAPPA; lambda_hi from the level's Gershgorin bound) -- what 64 / 256 plain sweeps did (deeper levels bought nothing in the
+//                prototype, tests/research/vmg_proto.py)
 //   where        every coarse sweep covers only the strips (64 consecutive i of a (j, k) row) that hold rows, inside the box of the
 //                level's index space that the listed tiles reach; levels whose box holds <= VMG_TAIL_POS positions run inside
-//                ONE single-workgroup launch (k_vmg_tail: the coarsest level in LDS), the larger ones as 6 launches per level
-//   who          flipv_params.viscosity_preconditioner: MULTIGRID always, AUTO (default) when the previous solve's iteration count
-//                predicts it to be cheaper than the diagonal (k_viscosity.hip: fv_visc_auto_pick)
+//                ONE single-workgroup launch (k_vmg_coarsest when that is just the LDS-resident coarsest level, k_vmg_tail otherwise), the larger ones
+//                as 5 launches per level
+//   who          flipv_params.viscosity_preconditioner: MULTIGRID always; AUTO (default) on every system with nu dt/dx^2 > 64 unless the previous
+//                solve shows the diagonal to converge for less (k_viscosity.hip: fv_visc_auto_pick)
 //   ranks        block contexts (flipv_comm.h): the same preconditioner -- fine-level sweeps after a halo copy of their input, ONE global coarse hierarchy
 //                (operator and first coarse right-hand side summed over the ranks, VmgState::globalFrom) cycled redundantly by every rank; or
 //                rank-local block-Jacobi (flipv_params.multigrid_rank_local)
