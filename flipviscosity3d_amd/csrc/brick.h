@@ -130,7 +130,7 @@ __device__ __forceinline__ bool d_update_scalars(const PcgScal &sc, int it_arg, 
     const int tid = d_tid256();
     const int grp = tid >> 5;  // 0 rmax(it-1), 1 sig, 2 a, 3 b, 4 c
     double v = 0.0;
-    if (grp < 5 && (it > 0 || grp > 0)) v = (sc.sig(it) - NSLOT)[tid];
+    if (grp < 5 && (it > 0 || grp > 0)) v = grp == 0 ? sc.slot_max(sc.sig(it) - NSLOT, tid) : sc.slot_sum(sc.sig(it) - NSLOT, tid);
 #pragma unroll
     for (int off = NSLOT / 2; off > 0; off >>= 1) {
         const double o = __shfl_down(v, off, NSLOT);

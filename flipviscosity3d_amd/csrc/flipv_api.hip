@@ -974,14 +974,16 @@ extern "C" int flipv_bench_stream(flipv_context *c, size_t bytes, int reps, int 
 // out = 5 arrays of n doubles: sig, a, b, c, rmax.
 #include "pcg_common.h"
 extern "C" int fvdbg_pcg_scalars(flipv_context *c, int cap, int n, double *out) {
-    const size_t per = ((size_t)cap + 2) * NSLOT;
-    std::vector<double> h(5 * per);
-    if (hipMemcpy(h.data(), c->d_scal, 5 * per * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const size_t stride = fv_scal_stride(cap);
+    std::vector<double> h(FV_SCAL_BANKS * stride);
+    if (hipMemcpy(h.data(), c->d_scal, h.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    const int nbank = c->comm ? 1 : FV_SCAL_BANKS;
     for (int q = 0; q < 5; q++)
         for (int it = 0; it < n; it++) {
             double v = 0;
+            for (int bk = 0; bk < nbank; bk++)
             for (int s = 0; s < NSLOT; s++) {
-                const double x = h[(size_t)it * 5 * NSLOT + (size_t)q * NSLOT + s];   // block `it` = [sig | a | b | c | rmax] x NSLOT (PcgScal)
+                const double x = h[(size_t)bk * stride + (size_t)it * 5 * NSLOT + (size_t)q * NSLOT + s];   // block `it` = [sig | a | b | c | rmax] x NSLOT (PcgScal), per bank
                 v = q == 4 ? (x > v ? x : v) : v + x;
             }
             out[(size_t)q * n + it] = v;

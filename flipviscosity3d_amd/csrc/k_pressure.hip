@@ -238,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_tile_compact(const int *__restrict__ f
 
 // ------------------------------------------------------------------------------------------------
 int fv_scal_reserve(flipv_context *c, int cap) {
-    const size_t need = (size_t)5 * (cap + 2) * NSLOT + 16;
+    const size_t need = FV_SCAL_BANKS * fv_scal_stride(cap);
     if (c->d_scal && c->h_scal && c->scalCap >= need) return FLIPV_OK;
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
@@ -249,6 +249,15 @@ int fv_scal_reserve(flipv_context *c, int cap) {
     return FLIPV_OK;
 }
 
+int fv_scal_clear(flipv_context *c, int cap, bool keepExtra) {
+    const size_t slots = (size_t)5 * (cap + 2) * NSLOT, stride = fv_scal_stride(cap);
+    if (keepExtra) {
+        HIPCHK(c, hipMemsetAsync(c->d_scal, 0, slots * sizeof(double), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_scal + stride, 0, (FV_SCAL_BANKS - 1) * stride * sizeof(double), c->stream));
+    } else HIPCHK(c, hipMemsetAsync(c->d_scal, 0, FV_SCAL_BANKS * stride * sizeof(double), c->stream));
+    return FLIPV_OK;
+}
+
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     const size_t n = ((size_t)cap + 2) * NSLOT;
     sc->base = c->d_scal;
@@ -256,6 +265,8 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     const int nr = c->comm ? c->comm->nranks : 1, rk = c->comm ? c->comm->rank : 0;
     sc->nslot = NSLOT / nr > 0 ? NSLOT / nr : 1;   // disjoint slot ranges per rank (nranks <= NSLOT)
     sc->slot0 = rk * sc->nslot;
+    sc->nbank = c->comm ? 1 : FV_SCAL_BANKS;   // (a communicator's all-reduce sums bank 0 only)
+    sc->bstride = (int)fv_scal_stride(cap);
     sc->cap = cap;
     sc->noB = c->prm.beta_from_conjugacy ? 1 : 0;
     sc->itA = c->d_flags + 4;
@@ -416,7 +427,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
     const size_t nscal = (size_t)5 * (cap + 2) * NSLOT + 16;
-    HIPCHK(c, hipMemsetAsync(c->d_scal, 0, nscal * sizeof(double), c->stream));
+    if ((rc = fv_scal_clear(c, cap, false))) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));  // conv = -1
     HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));  // pressure-cell counter
     PcgScal sc;

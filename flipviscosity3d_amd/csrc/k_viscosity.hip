@@ -567,7 +567,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
     const size_t nscal = (size_t)5 * (cap + 2) * NSLOT + 16;
-    HIPCHK(c, hipMemsetAsync(c->d_scal, 0, nscal * sizeof(double), c->stream));
+    if ((rc = fv_scal_clear(c, cap, false))) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));   // conv = -1
     HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));  // row counter
     PcgScal sc;
@@ -775,7 +775,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             refinements++;
             hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, 0, bmax);
             HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->d_scal, 0, scalBytes, c->stream));
+            { const int rcc = fv_scal_clear(c, cap, true); if (rcc) return rcc; }
             HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));
             const int keepIncl = sc.tol_inclusive;
             double *dummy;
@@ -842,11 +842,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             if (st) { success = false; stalled = true; }
         }
         if (c->prm.verbose >= 2) {   // the residual history: max|r| per iteration
-            HIPCHK(c, hipMemcpy(c->h_scal, c->d_scal, nscal * sizeof(double), hipMemcpyDeviceToHost));
+            const size_t stride = fv_scal_stride(cap);
+            HIPCHK(c, hipMemcpy(c->h_scal, c->d_scal, FV_SCAL_BANKS * stride * sizeof(double), hipMemcpyDeviceToHost));
             fprintf(stderr, "  residual history (relative to max|rhs| = %.3g):", bnorm);
             for (int it = 0; it < itersNow && it < capNow; it++) {
                 double m = 0.0;
-                for (int q = 0; q < NSLOT; q++) m = fmax(m, c->h_scal[(size_t)it * 5 * NSLOT + 4 * NSLOT + q]);
+                for (int bk = 0; bk < sc.nbank; bk++)
+                    for (int q = 0; q < NSLOT; q++) m = fmax(m, c->h_scal[(size_t)bk * stride + (size_t)it * 5 * NSLOT + 4 * NSLOT + q]);
                 fprintf(stderr, " %d:%.2e", it, m / bnorm);
             }
             fprintf(stderr, "\n");

@@ -308,8 +308,10 @@ __global__ __launch_bounds__(256) void k_bflush(const int *__restrict__ bricks, 
     int it;
     if (!d_replace_now(sc, it_arg, period, force, it)) return;
     if (!force && blockIdx.x == 0 && threadIdx.y == 0 && threadIdx.x < NSLOT) {   // the replaced residual's scalars are accumulated afresh
-        sc.rmax(it)[threadIdx.x] = 0.0;
-        if (withSigma) sc.sig(it + 1)[threadIdx.x] = 0.0;
+        for (int b = 0; b < sc.nbank; b++) {
+            sc.rmax(it)[threadIdx.x + (size_t)b * sc.bstride] = 0.0;
+            if (withSigma) sc.sig(it + 1)[threadIdx.x + (size_t)b * sc.bstride] = 0.0;
+        }
 
     }
     double *xa[3] = {xaU, xaV, xaW};
@@ -498,7 +500,8 @@ void fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool
     const float *const vo[3] = {outerExact ? c->vmU : c->vrU, outerExact ? c->vmV : c->vrV, outerExact ? c->vmW : c->vrW};
     const dim3 b(64, 4, 1);
     hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0);
-    (void)hipMemsetAsync(sc.base, 0, scalBytes, c->stream);
+    (void)hipMemsetAsync(sc.base, 0, scalBytes, c->stream);   // bank 0's slot blocks (the extra scalars behind them stay), then the other banks
+    if (sc.nbank > 1) (void)hipMemsetAsync(sc.base + sc.bstride, 0, (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double), c->stream);
     hipLaunchKernelGGL((k_bresidual<T>), dim3(spmv_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v,
                        (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1],
                        (const float *)c->vB[2], (float *)nullptr, (float *)nullptr, (float *)nullptr, 0.0f, sc, 0, 0, 0, 1);

@@ -806,7 +806,7 @@ __device__ __forceinline__ void d_vmg_publish_max(const PcgScal &sc, int it, flo
 }
 // stop test and stall guard of iteration it >= 0; true: the launch returns (every thread of the block calls this)
 __device__ __forceinline__ bool d_vmg_stop_test(const PcgScal &sc, int it, double *lds) {
-    const double res = d_fold_max(sc.rmax(it), lds);
+    const double res = d_fold_max(sc, sc.rmax(it), lds);
     const bool first = blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0;
     if (d_pass(sc, res)) {
         if (first) *sc.conv = it;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks
     double alpha_d = 0.0;
     if (it >= 0) {
         double f[4];
-        d_fold_sums(sc.sig(it), sc.a(it), nullptr, nullptr, f, lds);
+        d_fold_sums(sc, sc.sig(it), sc.a(it), nullptr, nullptr, f, lds);
         alpha_d = f[1] != 0.0 ? f[0] / f[1] : 0.0;
     }
     const float alpha = (float)alpha_d;
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void k_bvpcg_p(const int *__restrict__ bricks,
     if (it >= 0) {
         if (d_vmg_stop_test(sc, it, lds)) return;
         double f[4];
-        d_fold_sums(sc.sig(it + 1), sc.sig(it), nullptr, nullptr, f, lds);
+        d_fold_sums(sc, sc.sig(it + 1), sc.sig(it), nullptr, nullptr, f, lds);
         beta = f[1] != 0.0 ? (float)(f[0] / f[1]) : 0.0f;
     }
     while (w.valid()) {

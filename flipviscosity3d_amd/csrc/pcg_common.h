@@ -115,6 +115,12 @@ struct PcgScal {
     double tol;
     int tol_inclusive;  // 1: res <= tol (pcgsolver.h:270), 0: res < tol (pressuresolver.cpp:548)
     int slot0, nslot;
+    // Banks: NSLOT slots still put ~40 blocks of a 1 280-block launch on the SAME 8-byte address, and same-address atomics serialise in L2 -- the
+    // tail of every kernel with a reduction (measured, brick SpMV at 256^3: 18.0 us with its three dot products, 13.9 without, 13.9 with the blocks
+    // spread over four copies of the slot area).  Block b accumulates into bank (b / nslot) % nbank = the same slot layout `bstride` doubles
+    // further on; consumers add (or max) the banks while they load the slots.  One bank under a communicator (the all-reduce sums bank 0).
+    int nbank;
+    int bstride;
     int cap;        // iteration cap
     int noB;        // 1: the SpMV did not form b = (r/d).q; the update uses b = a (conjugacy of successive directions)
     // Stall guard.  An fp32 solve whose attainable residual sits right at the tolerance can miss it by a hair, stagnate and --
@@ -136,21 +142,35 @@ struct PcgScal {
     __host__ __device__ double *b(int it) const { return base + (size_t)it * 5 * NSLOT + 2 * NSLOT; }
     __host__ __device__ double *c(int it) const { return base + (size_t)it * 5 * NSLOT + 3 * NSLOT; }
     __host__ __device__ double *rmax(int it) const { return base + (size_t)it * 5 * NSLOT + 4 * NSLOT; }  // max|r| after iteration it
-    __device__ int my_slot() const { return slot0 + (int)(blockIdx.x % (unsigned)nslot); }
+    __device__ int my_slot() const {   // offset of this block's partial inside a slot block (bank included)
+        const unsigned b = blockIdx.x;
+        return slot0 + (int)(b % (unsigned)nslot) + (nbank > 1 ? (int)((b / (unsigned)nslot) % (unsigned)nbank) * bstride : 0);
+    }
+    // slot i of a slot block with the banks folded in
+    __device__ __forceinline__ double slot_sum(const double *p, int i) const {
+        double v = p[i];
+        for (int b = 1; b < nbank; b++) v += p[i + (size_t)b * bstride];
+        return v;
+    }
+    __device__ __forceinline__ double slot_max(const double *p, int i) const {
+        double v = p[i];
+        for (int b = 1; b < nbank; b++) v = fmax(v, p[i + (size_t)b * bstride]);
+        return v;
+    }
 };
 
 __device__ __forceinline__ int d_tid256() { return threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); }
 
 // fold the NSLOT partials of up to four scalars (sum) -- executed by every thread of the block, one barrier
-__device__ __forceinline__ void d_fold_sums(const double *p0, const double *p1, const double *p2, const double *p3,
+__device__ __forceinline__ void d_fold_sums(const PcgScal &sc, const double *p0, const double *p1, const double *p2, const double *p3,
                                             double out[4], double *lds8) {
     const int tid = d_tid256();
     if (tid < 64) {
         const int sl = tid & (NSLOT - 1);
         const double *p = (tid < NSLOT) ? p0 : p1;
-        double v0 = p ? p[sl] : 0.0;
+        double v0 = p ? sc.slot_sum(p, sl) : 0.0;
         const double *pp = (tid < NSLOT) ? p2 : p3;
-        double v1 = pp ? pp[sl] : 0.0;
+        double v1 = pp ? sc.slot_sum(pp, sl) : 0.0;
         // lanes 0..31 hold p0/p2 partials, lanes 32..63 hold p1/p3 partials: reduce the two halves separately
 #pragma unroll
         for (int off = NSLOT / 2; off > 0; off >>= 1) {
@@ -164,10 +184,10 @@ __device__ __forceinline__ void d_fold_sums(const double *p0, const double *p1, 
     out[0] = lds8[0]; out[1] = lds8[1]; out[2] = lds8[2]; out[3] = lds8[3];
     __syncthreads();
 }
-__device__ __forceinline__ double d_fold_max(const double *p, double *lds8) {
+__device__ __forceinline__ double d_fold_max(const PcgScal &sc, const double *p, double *lds8) {
     const int tid = d_tid256();
     if (tid < NSLOT) {
-        double v = p[tid];
+        double v = sc.slot_max(p, tid);
 #pragma unroll
         for (int off = NSLOT / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, NSLOT));
         if (tid == 0) lds8[0] = v;
@@ -275,13 +295,13 @@ static __global__ void k_pcg_check(PcgScal sc, int it_last_arg) {  // <<<1, 64>>
     __shared__ double lds[8];
     const int it_last = it_last_arg >= 0 ? it_last_arg : *sc.itA - 1;
     if (it_last < 0) return;
-    const double res = d_fold_max(sc.rmax(it_last), lds);
+    const double res = d_fold_max(sc, sc.rmax(it_last), lds);
     if (threadIdx.x == 0 && *sc.conv < 0 && d_pass(sc, res)) *sc.conv = it_last;
 }
 // final residual of iteration `it` into out[0]
 static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<1, 64>>>
     __shared__ double lds[8];
-    const double res = d_fold_max(sc.rmax(it), lds);
+    const double res = d_fold_max(sc, sc.rmax(it), lds);
     if (threadIdx.x == 0) out[0] = res;
 }
 
@@ -293,7 +313,10 @@ static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<
     } while (0)
 
 // ---- host-side helpers (k_pressure.hip) ----
-int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds 5*(cap+2)*NSLOT+16 doubles
+int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds FV_SCAL_BANKS banks of 5*(cap+2)*NSLOT+16 doubles (rounded up to 512)
+int fv_scal_clear(flipv_context *c, int cap, bool keepExtra);   // zero the slot blocks of every bank (and, unless keepExtra, the 16 extra doubles behind bank 0's)
+constexpr int FV_SCAL_BANKS = 4;
+static inline size_t fv_scal_stride(int cap) { return (((size_t)5 * (cap + 2) * NSLOT + 16) + 511) / 512 * 512; }
 // never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
 static inline int pcg_grid(const flipv_context *c, int ntiles) {
     int cap = c->prm.grid_cap > 0 ? ((c->prm.grid_cap + 7) / 8) * 8 : MAX_PCG_BLOCKS;  // test hook: small grids make every block walk many tiles
