@@ -657,12 +657,12 @@ __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, co
 // of the cycle's 520 before).  Falls back to the global-memory sweeps when the box or a component's row count does not fit.
 struct CoarseRow { float cf[VS]; float invd, b, gersh; int li; size_t ci; bool has; };
 template <int C>
-__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, int fine0, const int *rowlist, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP, int given) {   // fine0: d_restrict's FINE0; given: b is in A.b already
-    R.has = (int)threadIdx.x < nrows;
+__device__ __forceinline__ void d_coarsest_load(const VLevelDev &A, const Lay &F, const Vec3p &ft, int fine0, const int *rowlist, int row, bool active, int nrows, int W, int H, CoarseRow &R, float *xs0, int NP, int given) {   // row: this thread's index into the component's row list (if active); fine0: d_restrict's FINE0; given: b is in A.b already
+    R.has = active && row < nrows;
     R.gersh = 0.0f;
     if (!R.has) return;
     const int w = A.box.hi[0] - A.box.lo[0], h = A.box.hi[1] - A.box.lo[1];
-    const int r = rowlist[threadIdx.x];
+    const int r = rowlist[row];
     const int di = r % w, dj = (r / w) % h, dk = r / (w * h);
     const int P[3] = {A.box.lo[0] + di, A.box.lo[1] + dj, A.box.lo[2] + dk};
     R.ci = cidx(A.L, P[0], P[1], P[2]);
@@ -699,9 +699,15 @@ __device__ __forceinline__ void d_coarsest_solve(const VLevelDev *__restrict__ l
         CoarseRow RU, RV, RW;
         const int fine0 = n - 1 == 0 ? (fineBrick ? 2 : 1) : 0;
         const int given = bGiven && first == n - 1;
-        d_coarsest_load<0>(A, F, ft, fine0, rowlist[0], cnt[0], W, H, RU, xs, NP, given);
-        d_coarsest_load<1>(A, F, ft, fine0, rowlist[1], cnt[1], W, H, RV, xs, NP, given);
-        d_coarsest_load<2>(A, F, ft, fine0, rowlist[2], cnt[2], W, H, RW, xs, NP, given);
+        // Who sweeps what.  With at most 512 rows per component (a 16^3 level of the bench scene has ~400) the lower eight waves take the U and V rows
+        // and the upper eight the W rows: 14 busy waves with two rows or one per lane instead of 7 with three -- the sweeps are bound by LDS latency
+        // on the critical path of the busiest wave.  The code is the same either way: a wave without rows of a component skips that block (execz).
+        const bool split = cnt[0] <= 512 && cnt[1] <= 512 && cnt[2] <= 512;
+        const int row = split ? ((int)threadIdx.x & 511) : (int)threadIdx.x;
+        const bool lower = threadIdx.x < 512;
+        d_coarsest_load<0>(A, F, ft, fine0, rowlist[0], row, !split || lower, cnt[0], W, H, RU, xs, NP, given);
+        d_coarsest_load<1>(A, F, ft, fine0, rowlist[1], row, !split || lower, cnt[1], W, H, RV, xs, NP, given);
+        d_coarsest_load<2>(A, F, ft, fine0, rowlist[2], row, !split || !lower, cnt[2], W, H, RW, xs, NP, given);
         // weights: Chebyshev on [hi / kappa, hi] when `cheb`, the fixed damping otherwise; the first one turns the zero guess into x = omega b/d
         float wlane = VMG_OMEGA;    // lane k of every wave holds sweep k's weight; a sweep reads its weight with v_readlane (a load from the level
                                     // descriptor per sweep sits on the critical path: +0.75 us per sweep; a broadcast LDS read: +0.3 us)
