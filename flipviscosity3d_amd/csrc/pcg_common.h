@@ -147,15 +147,16 @@ struct PcgScal {
         return slot0 + (int)(b % (unsigned)nslot) + (nbank > 1 ? (int)((b / (unsigned)nslot) % (unsigned)nbank) * bstride : 0);
     }
     // slot i of a slot block with the banks folded in
+    // (nbank is 1 or FV_SCAL_BANKS = 4: the four loads are issued together -- these sit in the prologue of every block of the consumer)
     __device__ __forceinline__ double slot_sum(const double *p, int i) const {
-        double v = p[i];
-        for (int b = 1; b < nbank; b++) v += p[i + (size_t)b * bstride];
-        return v;
+        if (nbank <= 1) return p[i];
+        const double v0 = p[i], v1 = p[i + (size_t)bstride], v2 = p[i + 2 * (size_t)bstride], v3 = p[i + 3 * (size_t)bstride];
+        return (v0 + v1) + (v2 + v3);
     }
     __device__ __forceinline__ double slot_max(const double *p, int i) const {
-        double v = p[i];
-        for (int b = 1; b < nbank; b++) v = fmax(v, p[i + (size_t)b * bstride]);
-        return v;
+        if (nbank <= 1) return p[i];
+        const double v0 = p[i], v1 = p[i + (size_t)bstride], v2 = p[i + 2 * (size_t)bstride], v3 = p[i + 3 * (size_t)bstride];
+        return fmax(fmax(v0, v1), fmax(v2, v3));
     }
 };
 
@@ -315,7 +316,7 @@ static __global__ void k_pcg_residual(PcgScal sc, int it, double *out) {  // <<<
 // ---- host-side helpers (k_pressure.hip) ----
 int fv_scal_reserve(flipv_context *c, int cap);  // d_scal holds FV_SCAL_BANKS banks of 5*(cap+2)*NSLOT+16 doubles (rounded up to 512)
 int fv_scal_clear(flipv_context *c, int cap, bool keepExtra);   // zero the slot blocks of every bank (and, unless keepExtra, the 16 extra doubles behind bank 0's)
-constexpr int FV_SCAL_BANKS = 4;
+constexpr int FV_SCAL_BANKS = 4;   // (PcgScal::slot_sum / slot_max spell the four banks out)
 static inline size_t fv_scal_stride(int cap) { return (((size_t)5 * (cap + 2) * NSLOT + 16) + 511) / 512 * 512; }
 // never 0: a rank without unknowns still runs the (empty) kernels so that the stop logic is identical on every rank
 static inline int pcg_grid(const flipv_context *c, int ntiles) {
