@@ -791,7 +791,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const bool correction = correctionDue;   // this round is a bounded defect-correction stage (see above)
         const int capNow = (correction && cap - itersDone > 48) ? 48 : cap - itersDone;
         sc.cap = capNow;
-        sc.tol = correction ? fmax(tolFinal, 2e-2 * resStart) : tolFinal;
+        sc.tol = correction ? fmax(tolFinal, 2e-2 * resStart) : tolFinal;   // (scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
         sc.stall_below = refinements > 0 ? fmin(100.0 * sc.tol, 0.05 * resStart) : 0.0;
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
         // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the
