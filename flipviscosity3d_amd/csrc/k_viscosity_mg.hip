@@ -1191,11 +1191,12 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         Box3 fb;
         const int ext0[3] = {c->L.I + 1, c->L.J + 1, c->L.K + 1};
+        bool noRows = false;   // (a rank of a block decomposition without liquid: its one-position stand-in box must not enter the union over the ranks)
         for (int a = 0; a < 3; a++) {   // (tiles hang over the end of the lattices and, on a block context, of the rank's own box: the rows do not)
             fb.lo[a] = hb[a] < c->L.olo[a] ? c->L.olo[a] : hb[a];
             fb.hi[a] = hb[3 + a] > ext0[a] ? ext0[a] : hb[3 + a];
             if (fb.hi[a] > c->L.ohi[a]) fb.hi[a] = c->L.ohi[a];
-            if (fb.hi[a] <= fb.lo[a]) { fb.lo[a] = c->L.olo[a]; fb.hi[a] = c->L.olo[a] + 1; }
+            if (fb.hi[a] <= fb.lo[a]) { fb.lo[a] = c->L.olo[a]; fb.hi[a] = c->L.olo[a] + 1; noRows = true; }
         }
         for (size_t l = 0; l < s->lev.size(); l++) {
             VLevel &A = s->lev[l];
@@ -1214,17 +1215,21 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             const int nr = c->comm->nranks, me = c->comm->rank;
             std::vector<double> hbx((size_t)6 * nr, 0.0);
             VLevel &G = s->lev[s->globalFrom];
-            for (int a = 0; a < 3; a++) { hbx[(size_t)6 * me + a] = G.box.lo[a]; hbx[(size_t)6 * me + 3 + a] = G.box.hi[a]; }
+            for (int a = 0; a < 3; a++) { hbx[(size_t)6 * me + a] = noRows ? 1e9 : G.box.lo[a]; hbx[(size_t)6 * me + 3 + a] = noRows ? -1e9 : G.box.hi[a]; }
             HIPCHK(c, hipMemcpyAsync(s->d_gbox, hbx.data(), hbx.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
             if ((rc = fv_allreduce_scalars(c, s->d_gbox, hbx.size()))) return rc;
             HIPCHK(c, hipMemcpyAsync(hbx.data(), s->d_gbox, hbx.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            for (int r = 0; r < nr; r++)
+            bool first = true;
+            for (int r = 0; r < nr; r++) {
+                if (hbx[(size_t)6 * r] > 1e8) continue;   // a rank without rows
                 for (int a = 0; a < 3; a++) {
                     const int lo = (int)hbx[(size_t)6 * r + a], hi = (int)hbx[(size_t)6 * r + 3 + a];
-                    if (lo < G.box.lo[a]) G.box.lo[a] = lo;
-                    if (hi > G.box.hi[a]) G.box.hi[a] = hi;
+                    if (first || lo < G.box.lo[a]) G.box.lo[a] = lo;
+                    if (first || hi > G.box.hi[a]) G.box.hi[a] = hi;
                 }
+                first = false;
+            }
             Box3 gb = G.box;
             for (size_t l = (size_t)s->globalFrom + 1; l < s->lev.size(); l++) {
                 VLevel &A = s->lev[l];

@@ -346,3 +346,48 @@ def test_box_shaped_handover_of_the_solid_sdf_from_a_setup_context():
         sc.read_region("SOLID_PHI", (0, 0, 0), (N + 2, 4, 4))      # outside the lattice
     sc.close()
 
+
+
+@pytest.mark.parametrize("dims", [(2, 2, 2), (1, 1, 4)])
+def test_decomposition_does_not_change_the_solver_path_over_several_substeps(dims):
+    """the global multigrid hierarchies make both preconditioners independent of the decomposition: over four substeps of the 64^3 bunny drop
+    (particles crossing the cuts, the liquid's box moving) 2 x 2 x 2 blocks and four slabs take the single domain's iteration counts (up to the
+    summation order) in both solves, every rank the same, and end with the single domain's velocities"""
+    from flipviscosity3d_amd import capi, partition
+    from test_oracle_compact_golden import build_host_scene
+    N = 64
+    dx, solid, P0 = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    params = dict(viscosity_layout=capi.LAYOUT_SWIZZLED, exact_viscosity_operator=1, viscosity_preconditioner=capi.PRECOND_MULTIGRID)   # the same layout and operator on both sides
+    ref = capi.Context(N, N, N, dx)
+    ref.set_solid_sdf(solid); ref.set_viscosity(5.0); ref.set_params(**params)
+    ref.particles = P0
+    boxes = partition.block_boxes(N, N, N, dims)
+    ctxs = [capi.Context(N, N, N, dx, device=0, block=b) for b in boxes]
+    capi.comm_init_local(ctxs, dims)
+    for c, p in zip(ctxs, partition.split_particles_boxes(P0, dx, boxes, dims)):
+        c.set_solid_sdf(solid); c.set_viscosity(5.0); c.set_params(**params)
+        c.particles = p
+    nsub = 4
+    single = [ref.substep(0.01) for _ in range(nsub)]
+
+    def work(r, c):
+        return [c.substep(0.01) for _ in range(nsub)]
+    ranks = run_ranks(ctxs, work)
+    for t in range(nsub):
+        sv, sp = single[t]["viscosity"], single[t]["pressure"]
+        for st in ranks:
+            v, p = st[t]["viscosity"], st[t]["pressure"]
+            assert v["status"] == 0 and p["status"] == 0 and v["preconditioner"] == 1 and p["preconditioner"] == 1
+            assert v["iterations"] == ranks[0][t]["viscosity"]["iterations"] and p["iterations"] == ranks[0][t]["pressure"]["iterations"]
+        print("substep %d: viscosity %d / %d iterations, pressure %d / %d (single domain / %s blocks)" % (
+            t, sv["iterations"], ranks[0][t]["viscosity"]["iterations"], sp["iterations"], ranks[0][t]["pressure"]["iterations"], dims))
+    for t in range(nsub):   # (the count moves by a few where max|r| plateaus just above the tolerance: summation order of the all-reduced sums)
+        assert abs(ranks[0][t]["viscosity"]["iterations"] - single[t]["viscosity"]["iterations"]) <= 3, t   # (four slabs, two of them without liquid, were 2-4 iterations off
+        # while an empty rank's stand-in box entered the union of the boxes and pushed the coarsest level out of LDS)
+        assert abs(ranks[0][t]["pressure"]["iterations"] - single[t]["pressure"]["iterations"]) <= 2, t
+    got = [assemble(ctxs, n) for n in "UVW"]
+    assert rel_maxnorm3(got, [ref.grid(n) for n in "UVW"]) <= 5e-5
+    assert sum(c.num_particles for c in ctxs) == len(P0)
+    for c in ctxs:
+        c.close()
+    ref.close()
