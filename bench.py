@@ -263,7 +263,8 @@ def main():
     ap.add_argument("--precision", type=int, default=0, help="0 fp32 vectors (default), 1 fp64 vectors")
     ap.add_argument("--exact-operator", action="store_true", help="flipv_params.exact_viscosity_operator = 1: the exact viscosity operator instead of the "
                     "reference's float-rounded one (no defect-correction stage; 1.5e-4 from the reference's converged velocities at 256^3)")
-    ap.add_argument("--dense-size", type=int, default=384, help="second size of the filled-box SpMV roofline (the first is min(--size, 256)); 0 = skip")
+    ap.add_argument("--dense-size", type=str, default="384,512", help="further sizes of the filled-box SpMV roofline, comma-separated (the first is min(--size, 256)); 0 = none.  "
+                    "384^3 does not fit the 256-wide tiles (a quarter of the lanes idle), 512^3 does")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="bunny",
                     help="bunny = BASELINE configs[2] (the metric's scene); honey = configs[3] (rod + sheet, use --viscosity 50); "
                          "sheet = configs[4] (--size is the long axis: 1024 -> 1024x512x512)")
@@ -495,9 +496,10 @@ def main():
             c.close()
             c = None
             out["roofline_dense"] = dense_roofline(min(N, 256), args.precision)
-            if args.dense_size > 0 and args.dense_size != min(N, 256):
-                # (at 256^3 an fp32 array is 64 MiB against a 256 MiB Infinity Cache; 384^3 arrays are 216 MiB each)
-                out["roofline_dense_%d" % args.dense_size] = dense_roofline(args.dense_size, args.precision, reps=20)
+            for ds in [int(v) for v in str(args.dense_size).split(",") if v.strip()]:
+                if ds > 0 and ds != min(N, 256):
+                    # (at 256^3 an fp32 array is 64 MiB against a 256 MiB Infinity Cache; 384^3 arrays are 216 MiB each, 512^3 arrays 512 MiB)
+                    out["roofline_dense_%d" % ds] = dense_roofline(ds, args.precision, reps=20 if ds < 512 else 10)
         if world == 1 and not args.no_cpu_baseline and args.workload == "bunny":
             out["cpu_baseline"] = cpu_baseline(args.viscosity, args.cpu_size)
             if args.cpu_threads != 1:
