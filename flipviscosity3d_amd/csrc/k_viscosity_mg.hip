@@ -44,6 +44,7 @@ void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3]
 namespace {
 
 constexpr int VS = 23;             // slots per row
+constexpr int VH = 11;             // 32-bit words of a row's packed off-diagonal entries (two fp16 per word; see d_row_dot)
 constexpr float VMG_OMEGA = 0.6f;           // the coarsest level's sweeps
 // damping of the first / second sweep of the V(2,2) smoother on every level above the coarsest (VLevelDev::w; flipv_params.viscosity_mg_omega_*)
 constexpr float VMG_W_DEFAULT[2] = {1.317f, 0.382f};   // the roots of the degree-2 Chebyshev polynomial on [3/8, 3]: |p| <= 0.43 there, < 1 up to lambda = 3.38
@@ -128,6 +129,8 @@ struct Vec3p { float *p[3]; };
 struct VLevel {          // a coarse level (>= 1)
     Lay L;
     float *coef[3][VS];
+    unsigned *ch[3][VH];     // the off-diagonal entries again, packed for the cycle's kernels (k_vmg_pack)
+    float *dd[3];            // ... and the diagonal that goes with them
     float *x[3], *y[3], *b[3], *t[3];
     Box3 box;
     int *strips = nullptr, *stripFlag = nullptr;   // capacity: the strips of the level's whole index space
@@ -137,6 +140,8 @@ struct VLevel {          // a coarse level (>= 1)
 struct VLevelDev {       // what kernels need of a coarse level
     Lay L;
     float *coef[3][VS];
+    const unsigned *ch[3][VH];
+    const float *dd[3];
     Vec3p x, y, b, t;
     Box3 box;
     // "strips" (the name is from the first version: 64 consecutive i of a row): the BRICKS (8 x 4 x 2 indices, cidx) of the box that hold
@@ -388,19 +393,36 @@ __global__ __launch_bounds__(256) void k_vmg_rap_gather(VLevelDev F, VLevelDev C
 }
 
 // ---- coarse levels: y = A x for one dof of component C at (i, j, k)
+// What the cycle's kernels read of a row is its fp32 diagonal and its 22 off-diagonal entries as fp16, two per 32-bit word, scaled by the power
+// of two below the diagonal (2^e <= d < 2^(e+1)): 11 + 1 loads and 48 bytes per row instead of 23 loads and 92 bytes -- the sweeps of level 1 are
+// bound by exactly that stream (2 040 bricks x 3 components x 23 grids = 36 MB per launch at 256^3, five launches per iteration).  The scale is a
+// power of two, so an entry is ROUNDED TO 11 BITS and nothing else: a_ij and a_ji round alike and the level's operator stays as symmetric as the
+// Galerkin sums left it (entries below 6e-5 of the diagonal fall into fp16's subnormals: an absolute error of 3e-8 d).  The diagonal that goes with
+// the rounded entries (VLevelDev::dd, fp32) takes up what the rounding changed in the row's SAME-COMPONENT entries, d' = d + sum (a - a'): the
+// operator is a mass term plus a viscous term that annihilates a translation of a component, the mass term is 1e-3 .. 1e-5 of the entries when the
+// system is stiff, and a rounding of 5e-4 per entry without that correction leaves the translation of a small liquid cluster with a NEGATIVE energy
+// on the coarse levels.  The fp32 grids stay what the set-up works on (Galerkin gathers, the all-reduce over the ranks, the LDS-resident level's rows).
+constexpr int off_slot(int n) { return n < 5 ? n : n + 1; }   // the n-th off-diagonal slot (slot_diag = 5)
+__device__ __forceinline__ float d_row_scale(float d) { return __uint_as_float(__float_as_uint(d) & 0x7f800000u); }
+__device__ __forceinline__ float d_half_bits(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
 template <int C>
-__device__ __forceinline__ float d_apply(const VLevelDev &A, const Vec3p &x, size_t ci, int i, int j, int k) {
-    // all coefficients, then all neighbour values, then the sum: 46 independent loads instead of 23 dependent
-    // load-test-load chains (empty slots hold 0 and the padding bricks make every neighbour address valid)
-    float v[VS], xv[VS];
-#pragma unroll
-    for (int q = 0; q < VS; q++) v[q] = A.coef[C][q][ci];
-#pragma unroll
-    for (int q = 0; q < VS; q++) xv[q] = x.p[slot_comp(C, q)][cidx(A.L, i + slot_off(C, q, 0), j + slot_off(C, q, 1), k + slot_off(C, q, 2))];
+__device__ __forceinline__ float d_row_dot(const VLevelDev &A, size_t ci, float d, const unsigned (&u)[VH], const float (&xv)[VS]) {
     float s = 0.0f;
 #pragma unroll
-    for (int q = 0; q < VS; q++) s += v[q] * xv[q];
-    return s;
+    for (int n = 0; n < 2 * VH; n++) s += d_half_bits((n & 1) ? (u[n >> 1] >> 16) : (u[n >> 1] & 0xffffu)) * xv[off_slot(n)];
+    return d_row_scale(d) * s + d * xv[slot_diag(C)];
+}
+template <int C>
+__device__ __forceinline__ float d_apply(const VLevelDev &A, const Vec3p &x, size_t ci, int i, int j, int k, float d) {
+    // all coefficients, then all neighbour values, then the sum: independent loads instead of dependent
+    // load-test-load chains (empty slots hold 0 and the padding bricks make every neighbour address valid)
+    unsigned u[VH];
+    float xv[VS];
+#pragma unroll
+    for (int w = 0; w < VH; w++) u[w] = A.ch[C][w][ci];
+#pragma unroll
+    for (int q = 0; q < VS; q++) xv[q] = x.p[slot_comp(C, q)][cidx(A.L, i + slot_off(C, q, 0), j + slot_off(C, q, 1), k + slot_off(C, q, 2))];
+    return d_row_dot<C>(A, ci, d, u, xv);
 }
 
 // The six steps of a coarse level's share of the V-cycle, for the three dofs of index (i, j, k).  Vectors of a level are zero
@@ -446,7 +468,7 @@ template <int OP, int C, int FINE0>
 __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
     const size_t ci = cidx(A.L, i, j, k);
     const int P[3] = {i, j, k};
-    const float d = A.coef[C][slot_diag(C)][ci];
+    const float d = A.dd[C][ci];
     if (OP == OP_RESTRICT) {
         const float s = d != 0.0f ? d_restrict<C, FINE0>(F, ft, P) : 0.0f;   // (a coarse dof with a fine child that is a row has a diagonal)
         A.b.p[C][ci] = s;
@@ -467,23 +489,22 @@ __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, con
     if (OP == OP_PROPOST) {
         // Entries towards indices without a row are exactly 0 on every level (an entry exists only where the neighbour is a row), so the
         // prolongated values formed at such neighbours drop out, as the zeros of y did in the two-launch form.
-        float v[VS], xv[VS];
+        unsigned u[VH];
+        float xv[VS];
 #pragma unroll
-        for (int q = 0; q < VS; q++) v[q] = A.coef[C][q][ci];
+        for (int w = 0; w < VH; w++) u[w] = A.ch[C][w][ci];
 #pragma unroll
         for (int q = 0; q < VS; q++) {
             const int pi = i + slot_off(C, q, 0), pj = j + slot_off(C, q, 1), pk = k + slot_off(C, q, 2);
             xv[q] = A.y.p[slot_comp(C, q)][cidx(A.L, pi, pj, pk)] + d_prolong_at(slot_comp(C, q), Cn, cx, pi, pj, pk);
         }
-        float ax = 0.0f;
-#pragma unroll
-        for (int q = 0; q < VS; q++) ax += v[q] * xv[q];
+        const float ax = d_row_dot<C>(A, ci, d, u, xv);
         A.t.p[C][ci] = xv[slot_diag(C)] + A.w[0] * (A.b.p[C][ci] - ax) / d;
         return;
     }
     const Vec3p &in = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.x : (OP == OP_POST2 ? A.t : A.y);
     const Vec3p &out = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.y : ((OP == OP_RESID || OP == OP_POST1) ? A.t : A.x);
-    const float ax = d_apply<C>(A, in, ci, i, j, k);
+    const float ax = d_apply<C>(A, in, ci, i, j, k, d);
     const float bb = A.b.p[C][ci];
     // first sweep of a pair: OP_POST1 (OP_RESTRICT / OP_PROPOST above); second: OP_PRE2, OP_POST2; the coarsest level's sweeps: VMG_OMEGA
     const float w = (OP == OP_SWEEP_XY || OP == OP_SWEEP_YX) ? VMG_OMEGA : A.w[OP == OP_POST1 ? 0 : 1];
@@ -576,7 +597,7 @@ __global__ __launch_bounds__(256) void k_vmg_unpack_rhs(const VLevelDev *__restr
     const size_t ci = cidx(A.L, A.box.lo[0] + (int)(t % w), A.box.lo[1] + (int)((t / w) % h), A.box.lo[2] + (int)(t / ((size_t)w * h)));
     const float b = buf[(size_t)c * n + t];
     A.b.p[c][ci] = b;
-    if (first) { const float d = A.coef[c][slot_diag(c)][ci]; A.x.p[c][ci] = d != 0.0f ? A.w[0] * b / d : 0.0f; }
+    if (first) { const float d = A.dd[c][ci]; A.x.p[c][ci] = d != 0.0f ? A.w[0] * b / d : 0.0f; }
 }
 // bricks of a level's box that hold rows: flags (one wave per brick), then an ordered compaction by one workgroup
 __global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__restrict__ flag, int nbricks) {
@@ -590,6 +611,38 @@ __global__ __launch_bounds__(256) void k_vmg_strip_flags(VLevelDev A, int *__res
     }
     const unsigned long long m = __ballot(any);
     if (threadIdx.x == 0) flag[sidx] = m != 0ull;
+}
+// the packed copy of a level's rows (d_row_dot): a wave per brick of the level's box and component
+__global__ __launch_bounds__(256) void k_vmg_pack(VLevelDev A, int nbricks) {
+    const int sidx = (int)blockIdx.x * 4 + (int)threadIdx.y;
+    if (sidx >= nbricks) return;
+    const int c = (int)blockIdx.y;
+    int i, j, k;
+    if (!d_brick_lane(A.box, sidx, (int)threadIdx.x, i, j, k)) return;
+    const size_t ci = cidx(A.L, i, j, k);
+    const float d = A.coef[c][slot_diag(c)][ci];
+    float *dd = const_cast<float *>(A.dd[c]);
+    if (d == 0.0f) { dd[ci] = 0.0f; return; }   // (inside the box every position is rewritten: an earlier solve's row may have been here)
+    float a[2 * VH];
+#pragma unroll
+    for (int n = 0; n < 2 * VH; n++) a[n] = A.coef[c][off_slot(n)][ci];
+    // rounding an entry to fp16 under a power-of-two scale is rounding it to 11 bits whatever the scale (outside the subnormals): the diagonal's
+    // correction can be formed under the scale of d and the entries packed under the scale of d'
+    auto scale_inv = [](float v) { const unsigned eb = __float_as_uint(v) & 0x7f800000u; return eb != 0u && eb < 0x7f000000u ? __uint_as_float(0x7f000000u - eb) : 0.0f; };   // 2^-e
+    auto round11 = [](float v) { return (float)(_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f); };
+    const float inv0 = scale_inv(d), sc0 = d_row_scale(d);
+    float corr = 0.0f;
+#pragma unroll
+    for (int n = 0; n < 14; n++) corr += a[n] - sc0 * round11(a[n] * inv0);   // off-diagonal slots 0..14 without 5: the row's own component
+    float dn = d + corr;
+    if (!(dn > 0.5f * d)) dn = d;
+    dd[ci] = dn;
+    const float inv = scale_inv(dn);
+#pragma unroll
+    for (int w = 0; w < VH; w++) {
+        const _Float16 h0 = (_Float16)fminf(fmaxf(a[2 * w] * inv, -65504.0f), 65504.0f), h1 = (_Float16)fminf(fmaxf(a[2 * w + 1] * inv, -65504.0f), 65504.0f);
+        const_cast<unsigned *>(A.ch[c][w])[ci] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    }
 }
 __global__ __launch_bounds__(1024) void k_vmg_strip_compact(const int *__restrict__ flag, int n, int *__restrict__ list, int *__restrict__ count) {
     __shared__ int wsum[16];
@@ -1052,6 +1105,8 @@ static VLevelDev dev_of(const VLevel &l) {
     VLevelDev d{};
     d.L = l.L;
     for (int c = 0; c < 3; c++) for (int s = 0; s < VS; s++) d.coef[c][s] = l.coef[c][s];
+    for (int c = 0; c < 3; c++) for (int w = 0; w < VH; w++) d.ch[c][w] = l.ch[c][w];
+    for (int c = 0; c < 3; c++) d.dd[c] = l.dd[c];
     d.x = v3(l.x); d.y = v3(l.y); d.b = v3(l.b); d.t = v3(l.t);
     d.box = l.box;
     d.strips = l.strips; d.nstrips = l.nstrips;
@@ -1138,8 +1193,8 @@ static int vmg_alloc_state(flipv_context *c) {
             VLevel l;
             l.L = coarse_lay(F);
             const size_t per = l.L.n + 2 * l.L.guard;
-            float *cb, *vb;
-            if ((rc = vmg_alloc(c, s, per, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, per, 12, &vb))) return rc;
+            float *cb, *vb, *hb;
+            if ((rc = vmg_alloc(c, s, per, 3 * VS, &cb)) || (rc = vmg_alloc(c, s, per, 12, &vb)) || (rc = vmg_alloc(c, s, per, 3 * (VH + 1), &hb))) return rc;
             s->vecBlocks.push_back({vb, per * 12 * sizeof(float)});
             l.per = per;
             {
@@ -1150,6 +1205,8 @@ static int vmg_alloc_state(flipv_context *c) {
             }
             for (int m = 0; m < 3; m++) {
                 for (int q = 0; q < VS; q++) l.coef[m][q] = cb + (size_t)(m * VS + q) * per + l.L.guard;
+                for (int w = 0; w < VH; w++) l.ch[m][w] = (unsigned *)(hb + (size_t)(m * VH + w) * per + l.L.guard);
+                l.dd[m] = hb + (size_t)(3 * VH + m) * per + l.L.guard;
                 l.x[m] = vb + (size_t)m * per + l.L.guard;
                 l.y[m] = vb + (size_t)(3 + m) * per + l.L.guard;
                 l.b[m] = vb + (size_t)(6 + m) * per + l.L.guard;
@@ -1285,6 +1342,12 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
                              ((((A.box.hi[2] - 1 + 2) >> 1) - ((A.box.lo[2] + 2) >> 1)) + 1);   // bricks of the box (d_brick_range)
             hipLaunchKernelGGL(k_vmg_strip_flags, dim3(cdiv(nstr, 4)), dim3(64, 4, 1), 0, c->stream, dev_of(A), A.stripFlag, nstr);
             hipLaunchKernelGGL(k_vmg_strip_compact, dim3(1), dim3(1024), 0, c->stream, (const int *)A.stripFlag, nstr, A.strips, s->d_stripCount + l);
+        }
+        for (size_t l = 0; l < s->lev.size(); l++) {   // every level's rows in the packed form the cycle reads (the LDS-resident level loads the fp32 grids)
+            const VLevel &A = s->lev[l];
+            const int nstr = ((((A.box.hi[0] - 1 + 8) >> 3) - ((A.box.lo[0] + 8) >> 3)) + 1) * ((((A.box.hi[1] - 1 + 4) >> 2) - ((A.box.lo[1] + 4) >> 2)) + 1) *
+                             ((((A.box.hi[2] - 1 + 2) >> 1) - ((A.box.lo[2] + 2) >> 1)) + 1);
+            hipLaunchKernelGGL(k_vmg_pack, dim3(cdiv(nstr, 4), 3), dim3(64, 4, 1), 0, c->stream, dev_of(A), nstr);
         }
         hipLaunchKernelGGL(k_vmg_coarsest_rows, dim3(1), dim3(1024), 0, c->stream, dev_of(s->lev.back()), s->d_rowlist, s->d_rowcnt);
         int counts[VMG_MAX_LEVELS];
