@@ -311,7 +311,7 @@ int fv_allreduce_max_f32(flipv_context *c, float *value) {
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(h.data(), buf, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    double m = 0;
+    double m = h[0];   // (every rank has written its slot: a true maximum, negative values included)
     for (double v : h) m = v > m ? v : m;
     *value = (float)m;
     return FLIPV_OK;
