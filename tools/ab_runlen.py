@@ -45,7 +45,7 @@ else:
         vi = c.viscosity_solve(0.01); pi = c.pressure_solve(0.01)
         vms, _ = c.bench_spmv(1, 50)
         pms, _ = c.bench_spmv(0, 50)
-        print(tag, "runlen %3d: visc SpMV %.1f us = %.0f GB/s (%.3f of 8 TB/s) | pressure SpMV %.1f us = %.0f GB/s (%.3f)" % (
+        print(tag, "tiles v %d p %d" % (vi["total_tiles"], pi["total_tiles"]), "runlen %3d: visc SpMV %.1f us = %.0f GB/s (%.3f of 8 TB/s) | pressure SpMV %.1f us = %.0f GB/s (%.3f)" % (
             rl, vms * 1e3, 52 * vi["rows"] / 3 / vms / 1e6, 52 * vi["rows"] / 3 / vms / 1e6 / 8000,
             pms * 1e3, 24 * pi["rows"] / pms / 1e6, 24 * pi["rows"] / pms / 1e6 / 8000), flush=True)
         c.close()
