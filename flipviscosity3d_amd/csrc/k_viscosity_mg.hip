@@ -11,6 +11,7 @@
 //                same-component neighbours (normal offset -1/0/+1 times {centre, +-1 along either transverse axis}) and 4
 //                + 4 cross-component neighbours -- the fine 15-point pattern plus the normal-times-transverse diagonals.
 //                Storage: one coefficient grid per (component, slot) on the level's dense index space ("dense slots").
+//                The cycle's kernels read a packed copy: 22 fp16 off-diagonal entries under a power-of-two scale + an fp32 diagonal (d_row_dot).
 //   level 0      matrix-free: the SpMV kernel of the solve's layout -- k_bvisc_spmv<.., EPI> on bricks (k_viscosity_brick.hip), k_visc_spmv<.., EPI> on
 //                planes (k_viscosity.hip) -- with the Jacobi update / the residual as its epilogue: a sweep is ONE launch that reads the iterate with
 //                its halo and writes the next one
@@ -28,7 +29,7 @@
 //   who          flipv_params.viscosity_preconditioner: MULTIGRID always; AUTO (default) on every system with nu dt/dx^2 > 64 unless the previous
 //                solve shows the diagonal to converge for less (k_viscosity.hip: fv_visc_auto_pick)
 //   ranks        block contexts (flipv_comm.h): the same preconditioner -- fine-level sweeps after a halo copy of their input, ONE global coarse hierarchy
-//                (operator and first coarse right-hand side summed over the ranks, VmgState::globalFrom) cycled redundantly by every rank; or
+//                (operator summed over the ranks per solve, first coarse right-hand side per iteration as the level's listed bricks, VmgState::globalFrom) cycled redundantly by every rank; or
 //                rank-local block-Jacobi (flipv_params.multigrid_rank_local)
 //   loop         PCG around it; `check_every` iterations are captured into a hipGraph once per solve and replayed
 //                (device-side iteration counters, as in pcg_common.h)
