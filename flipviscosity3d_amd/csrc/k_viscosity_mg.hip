@@ -143,6 +143,7 @@ struct VLevelDev {       // what kernels need of a coarse level
     float *coef[3][VS];
     const unsigned *ch[3][VH];
     const float *dd[3];
+    int packed;           // 1: the cycle reads ch / dd; 0: the fp32 grids (flipv_context::vmgPackedRows)
     Vec3p x, y, b, t;
     Box3 box;
     // "strips" (the name is from the first version: 64 consecutive i of a row): the BRICKS (8 x 4 x 2 indices, cidx) of the box that hold
@@ -413,12 +414,23 @@ __device__ __forceinline__ float d_row_dot(const VLevelDev &A, size_t ci, float 
     for (int n = 0; n < 2 * VH; n++) s += d_half_bits((n & 1) ? (u[n >> 1] >> 16) : (u[n >> 1] & 0xffffu)) * xv[off_slot(n)];
     return d_row_scale(d) * s + d * xv[slot_diag(C)];
 }
-template <int C>
+template <int C, bool PK>
 __device__ __forceinline__ float d_apply(const VLevelDev &A, const Vec3p &x, size_t ci, int i, int j, int k, float d) {
     // all coefficients, then all neighbour values, then the sum: independent loads instead of dependent
     // load-test-load chains (empty slots hold 0 and the padding bricks make every neighbour address valid)
-    unsigned u[VH];
     float xv[VS];
+    if (!PK) {
+        float v[VS];
+#pragma unroll
+        for (int q = 0; q < VS; q++) v[q] = A.coef[C][q][ci];
+#pragma unroll
+        for (int q = 0; q < VS; q++) xv[q] = x.p[slot_comp(C, q)][cidx(A.L, i + slot_off(C, q, 0), j + slot_off(C, q, 1), k + slot_off(C, q, 2))];
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < VS; q++) s += v[q] * xv[q];
+        return s;
+    }
+    unsigned u[VH];
 #pragma unroll
     for (int w = 0; w < VH; w++) u[w] = A.ch[C][w][ci];
 #pragma unroll
@@ -465,11 +477,12 @@ __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const
             }
     return s;
 }
-template <int OP, int C, int FINE0>
+// PK: the level's rows are read in the packed form (ch, dd); otherwise from the fp32 grids (the tail's levels always; every level when the system is too stiff for 11 bits)
+template <int OP, int C, int FINE0, bool PK>
 __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
     const size_t ci = cidx(A.L, i, j, k);
     const int P[3] = {i, j, k};
-    const float d = A.dd[C][ci];
+    const float d = PK ? A.dd[C][ci] : A.coef[C][slot_diag(C)][ci];
     if (OP == OP_RESTRICT) {
         const float s = d != 0.0f ? d_restrict<C, FINE0>(F, ft, P) : 0.0f;   // (a coarse dof with a fine child that is a row has a diagonal)
         A.b.p[C][ci] = s;
@@ -491,31 +504,41 @@ __device__ __forceinline__ void d_vmg_step(const VLevelDev &A, const Lay &F, con
         // Entries towards indices without a row are exactly 0 on every level (an entry exists only where the neighbour is a row), so the
         // prolongated values formed at such neighbours drop out, as the zeros of y did in the two-launch form.
         unsigned u[VH];
-        float xv[VS];
+        float xv[VS], v[VS];
+        if (PK) {
 #pragma unroll
-        for (int w = 0; w < VH; w++) u[w] = A.ch[C][w][ci];
+            for (int w = 0; w < VH; w++) u[w] = A.ch[C][w][ci];
+        } else {
+#pragma unroll
+            for (int q = 0; q < VS; q++) v[q] = A.coef[C][q][ci];
+        }
 #pragma unroll
         for (int q = 0; q < VS; q++) {
             const int pi = i + slot_off(C, q, 0), pj = j + slot_off(C, q, 1), pk = k + slot_off(C, q, 2);
             xv[q] = A.y.p[slot_comp(C, q)][cidx(A.L, pi, pj, pk)] + d_prolong_at(slot_comp(C, q), Cn, cx, pi, pj, pk);
         }
-        const float ax = d_row_dot<C>(A, ci, d, u, xv);
+        float ax = 0.0f;
+        if (PK) ax = d_row_dot<C>(A, ci, d, u, xv);
+        else {
+#pragma unroll
+            for (int q = 0; q < VS; q++) ax += v[q] * xv[q];
+        }
         A.t.p[C][ci] = xv[slot_diag(C)] + A.w[0] * (A.b.p[C][ci] - ax) / d;
         return;
     }
     const Vec3p &in = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.x : (OP == OP_POST2 ? A.t : A.y);
     const Vec3p &out = (OP == OP_PRE2 || OP == OP_SWEEP_XY) ? A.y : ((OP == OP_RESID || OP == OP_POST1) ? A.t : A.x);
-    const float ax = d_apply<C>(A, in, ci, i, j, k, d);
+    const float ax = d_apply<C, PK>(A, in, ci, i, j, k, d);
     const float bb = A.b.p[C][ci];
     // first sweep of a pair: OP_POST1 (OP_RESTRICT / OP_PROPOST above); second: OP_PRE2, OP_POST2; the coarsest level's sweeps: VMG_OMEGA
     const float w = (OP == OP_SWEEP_XY || OP == OP_SWEEP_YX) ? VMG_OMEGA : A.w[OP == OP_POST1 ? 0 : 1];
     out.p[C][ci] = OP == OP_RESID ? bb - ax : in.p[C][ci] + w * (bb - ax) / d;
 }
-template <int OP, int FINE0>
+template <int OP, int FINE0, bool PK>
 __device__ __forceinline__ void d_vmg_step_c(int c, const VLevelDev &A, const Lay &F, const Vec3p &ft, const Lay &Cn, const Vec3p &cx, int i, int j, int k) {
-    if (c == 0) d_vmg_step<OP, 0, FINE0>(A, F, ft, Cn, cx, i, j, k);
-    else if (c == 1) d_vmg_step<OP, 1, FINE0>(A, F, ft, Cn, cx, i, j, k);
-    else d_vmg_step<OP, 2, FINE0>(A, F, ft, Cn, cx, i, j, k);
+    if (c == 0) d_vmg_step<OP, 0, FINE0, PK>(A, F, ft, Cn, cx, i, j, k);
+    else if (c == 1) d_vmg_step<OP, 1, FINE0, PK>(A, F, ft, Cn, cx, i, j, k);
+    else d_vmg_step<OP, 2, FINE0, PK>(A, F, ft, Cn, cx, i, j, k);
 }
 // One step of one level: a wave per listed BRICK (8 x 4 x 2 indices) and component.  The list holds the bricks of the level's box
 // that carry at least one row, numbered inside the box's brick range (bx fastest); positions of an edge brick that lie outside the
@@ -539,7 +562,7 @@ __device__ __forceinline__ bool d_brick_lane(const Box3 &B, int code, int lane, 
     k = ((R.b0[2] + bz) << 1) - 2 + (lane >> 5);
     return i >= B.lo[0] && i < B.hi[0] && j >= B.lo[1] && j < B.hi[1] && k >= B.lo[2] && k < B.hi[2];
 }
-template <int OP>
+template <int OP, bool PK>
 __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick) {   // fineBrick: level 0 (F0, ft0) is in the brick layout
     if (*conv >= 0) return;
     const VLevelDev &A = lev[l];
@@ -549,10 +572,10 @@ __global__ __launch_bounds__(256) void k_vmg_step(const VLevelDev *__restrict__ 
     int i, j, k;
     if (!d_brick_lane(A.box, A.strips[sidx], (int)threadIdx.x, i, j, k)) return;
     if (OP == OP_RESTRICT) {
-        if (l == 0) { if (fineBrick) d_vmg_step_c<OP, 2>(c, A, F0, ft0, A.L, ft0, i, j, k); else d_vmg_step_c<OP, 1>(c, A, F0, ft0, A.L, ft0, i, j, k); }
-        else d_vmg_step_c<OP, 0>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
-    } else if (OP == OP_PROLONG || OP == OP_PROPOST) d_vmg_step_c<OP, 0>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
-    else d_vmg_step_c<OP, 0>(c, A, A.L, ft0, A.L, ft0, i, j, k);
+        if (l == 0) { if (fineBrick) d_vmg_step_c<OP, 2, PK>(c, A, F0, ft0, A.L, ft0, i, j, k); else d_vmg_step_c<OP, 1, PK>(c, A, F0, ft0, A.L, ft0, i, j, k); }
+        else d_vmg_step_c<OP, 0, PK>(c, A, lev[l - 1].L, lev[l - 1].t, A.L, ft0, i, j, k);
+    } else if (OP == OP_PROLONG || OP == OP_PROPOST) d_vmg_step_c<OP, 0, PK>(c, A, A.L, ft0, lev[l + 1].L, lev[l + 1].x, i, j, k);
+    else d_vmg_step_c<OP, 0, PK>(c, A, A.L, ft0, A.L, ft0, i, j, k);
 }
 // b of level l over its whole box from the finer level's residual, without the first sweep: the level whose right-hand side is summed
 // over the ranks (VmgState::globalFrom).  Grid: (ceil(w / 64), ceil(h / 4), 3 depth), block (64, 4)
@@ -655,6 +678,7 @@ __global__ __launch_bounds__(256) void k_vmg_pack(VLevelDev A, int nbricks) {
     const float d = A.coef[c][slot_diag(c)][ci];
     float *dd = const_cast<float *>(A.dd[c]);
     if (d == 0.0f) { dd[ci] = 0.0f; return; }   // (inside the box every position is rewritten: an earlier solve's row may have been here)
+    if (!A.packed) { dd[ci] = d; return; }
     float a[2 * VH];
 #pragma unroll
     for (int n = 0; n < 2 * VH; n++) a[n] = A.coef[c][off_slot(n)][ci];
@@ -732,7 +756,7 @@ __device__ __forceinline__ void d_tail_step(const VLevelDev &A, const Lay &F, co
     for (int q = threadIdx.x; q < 3 * n; q += blockDim.x) {
         const int c = q / n, r = q - c * n;
         const int i = A.box.lo[0] + r % w, j = A.box.lo[1] + (r / w) % h, k = A.box.lo[2] + r / (w * h);
-        d_vmg_step_c<OP, FINE0>(c, A, F, ft, Cn, cx, i, j, k);
+        d_vmg_step_c<OP, FINE0, false>(c, A, F, ft, Cn, cx, i, j, k);
     }
     __syncthreads();
 }
@@ -1380,7 +1404,9 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             const VLevel &A = s->lev[l];
             const int nstr = ((((A.box.hi[0] - 1 + 8) >> 3) - ((A.box.lo[0] + 8) >> 3)) + 1) * ((((A.box.hi[1] - 1 + 4) >> 2) - ((A.box.lo[1] + 4) >> 2)) + 1) *
                              ((((A.box.hi[2] - 1 + 2) >> 1) - ((A.box.lo[2] + 2) >> 1)) + 1);
-            hipLaunchKernelGGL(k_vmg_pack, dim3(cdiv(nstr, 4), 3), dim3(64, 4, 1), 0, c->stream, dev_of(A), nstr);
+            VLevelDev Ad = dev_of(A);
+            Ad.packed = c->vmgPackedRows;
+            hipLaunchKernelGGL(k_vmg_pack, dim3(cdiv(nstr, 4), 3), dim3(64, 4, 1), 0, c->stream, Ad, nstr);
         }
         hipLaunchKernelGGL(k_vmg_coarsest_rows, dim3(1), dim3(1024), 0, c->stream, dev_of(s->lev.back()), s->d_rowlist, s->d_rowcnt);
         int counts[VMG_MAX_LEVELS];
@@ -1415,6 +1441,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         for (size_t l = 0; l < s->lev.size(); l++) {
             s->lev[l].nstrips = (int)l < s->tailFirst ? counts[l] : 0;
             s->h_lev[l] = dev_of(s->lev[l]);
+            s->h_lev[l].packed = c->vmgPackedRows;
             s->h_lev[l].w[0] = s->w[0]; s->h_lev[l].w[1] = s->w[1];
             memcpy(s->h_lev[l].cheb, s->chebTab, sizeof(s->chebTab));
             s->h_lev[l].rowlist = s->d_rowlist; s->h_lev[l].rowcnt = s->d_rowcnt;
@@ -1427,7 +1454,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         for (size_t l = 0; l < s->lev.size(); l++) { const Box3 &b = s->lev[l].box; fprintf(stderr, "  level %zu box [%d,%d) x [%d,%d) x [%d,%d), %d bricks\n", l + 1, b.lo[0], b.hi[0], b.lo[1], b.hi[1], b.lo[2], b.hi[2], s->lev[l].nstrips); }
         int rcnt[4] = {0, 0, 0, 0};
         (void)hipMemcpy(rcnt, s->d_rowcnt, sizeof(rcnt), hipMemcpyDeviceToHost);
-        fprintf(stderr, "  coarsest level: %d / %d / %d rows per component, %s\n", rcnt[0], rcnt[1], rcnt[2], rcnt[3] ? "in LDS" : "through global memory");
+        fprintf(stderr, "  coarsest level: %d / %d / %d rows per component, %s; the cycle reads %s rows\n", rcnt[0], rcnt[1], rcnt[2], rcnt[3] ? "in LDS" : "through global memory", c->vmgPackedRows ? "packed fp16" : "fp32");
     }
     HIPCHK(c, hipGetLastError());
     *out = s;
@@ -1454,7 +1481,8 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
         const Lay F0 = brick ? c->LB : c->L;
         const int fb = brick ? 1 : 0;
         const Vec3p ft0 = v3(s->t0);
-#define STEP(OP_, l_) hipLaunchKernelGGL((k_vmg_step<OP_>), dim3(cdiv(s->lev[l_].nstrips > 0 ? s->lev[l_].nstrips : 1, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv, fb)
+#define STEP_(OP_, PK_, l_) hipLaunchKernelGGL((k_vmg_step<OP_, PK_>), dim3(cdiv(s->lev[l_].nstrips > 0 ? s->lev[l_].nstrips : 1, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, (int)(l_), F0, ft0, conv, fb)
+#define STEP(OP_, l_) do { if (c->vmgPackedRows) STEP_(OP_, true, l_); else STEP_(OP_, false, l_); } while (0)
         const int gl = s->globalFrom;
         // the first global level's right-hand side: every rank restricts its own residual over the union box, the sum over the ranks is b
         auto global_rhs = [&](int l, int first) {   // restriction into the staging buffer, all-reduce, back into b (and x = omega b/d: the first sweep)
@@ -1497,6 +1525,7 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
             STEP(OP_POST2, l);
         }
 #undef STEP
+#undef STEP_
         if (brick) hipLaunchKernelGGL(k_bvmg_prolong_fine, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, c->LB, s->lev[0].L, (const uint8_t *)c->vMaskB, v3(s->zb), v3(s->lev[0].x), sc, it_arg);
         else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
                            c->vSwz, v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
