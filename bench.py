@@ -480,13 +480,20 @@ def main():
             "viscosity_status_per_step": [st["viscosity"]["status"] for st in stats],                   # 0 converged, 1 cap reached / stalled (iterate accepted), 3 trivial
             "viscosity_operator": "exact (vol u - div tau)" if args.exact_operator else
                                   "the reference's (float-rounded diagonal, viscositysolver.cpp:394-446): exact-operator multigrid-PCG + one defect-correction stage",
+            # what every timed solve delivered, relative to max|rhs| (reference: 1e-6 on its operator): the Krylov loop's own residual on the exact
+            # operator when it stopped (stage 1: 1e-5 where a defect-correction stage follows, 1e-6 otherwise), and max|b - A_ref x| recomputed in fp64 at the
+            # very end (0: no defect-correction stage ran -- diagonal preconditioner, exact operator or trivial solve)
+            "viscosity_final_residual_rel": {
+                "loop_on_exact_operator_max": float(max((st["viscosity"]["residual"] / st["viscosity"]["rhs_norm"]) if st["viscosity"]["rhs_norm"] > 0 else 0.0 for st in stats)),
+                "recomputed_on_reference_operator_max": float(max((st["viscosity"].get("defect_residual", 0.0) / st["viscosity"]["rhs_norm"]) if st["viscosity"]["rhs_norm"] > 0 else 0.0 for st in stats)),
+                "recomputed_on_reference_operator_per_step": [float((st["viscosity"].get("defect_residual", 0.0) / st["viscosity"]["rhs_norm"]) if st["viscosity"]["rhs_norm"] > 0 else 0.0) for st in stats]},
             # mode B of SURVEY.md 8d (equal accuracy): every viscosity solve run to the reference's 1e-6 tolerance.  A default run IS that
             # when every timed solve converged; otherwise this object says how many did not
             "mode_b": {"value": value if all(st["viscosity"]["status"] in (0, 3) for st in stats) else None,
                        "unit": "MCells/s", "all_timed_solves_converged": all(st["viscosity"]["status"] in (0, 3) for st in stats),
                        "unconverged_solves": int(sum(st["viscosity"]["status"] not in (0, 3) for st in stats)),
                        "mean_viscosity_iterations": float(np.mean([st["viscosity"]["iterations"] for st in stats])),
-                       "note": "same run as `value`: the default parameters converge every solve inside the reference's cap of 700"},
+                       "note": "same run as `value`: the default parameters converge every solve inside the reference's cap of 700 (what 'converged' delivers: viscosity_final_residual_rel)"},
             "viscosity": {k: last["viscosity"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "roofline": roof,

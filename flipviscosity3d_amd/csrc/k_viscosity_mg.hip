@@ -38,6 +38,7 @@
 #include "brick.h"
 #include "flipv_comm.h"
 
+#include <chrono>
 #include <vector>
 
 void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);  // k_viscosity.hip (tile kernels or, in the brick layout, k_viscosity_brick.hip)
@@ -1598,16 +1599,19 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     if (graph) {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
+        const auto tc0 = std::chrono::steady_clock::now();
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         for (int e = 0; e < every; e++) (void)iteration(IT_DEVICE, may_replace(e));
         hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+        const auto tc1 = std::chrono::steady_clock::now();
         if (e1 != hipSuccess || e2 != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
             c->err = "viscosity multigrid: stream capture failed";
             return FLIPV_ERR_HIP;
         }
         if ((rc = fv_graph_exec(c, FV_GE_VISCOSITY_MG, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
+        if (c->prm.verbose) fprintf(stderr, "  multigrid loop: stream capture %.3f ms, graph executable %.3f ms (host)\n", std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
         for (int done = 0; done < cap && conv < 0; done += every) {
             hipError_t el = hipGraphLaunch(ge, c->stream);
             hipError_t es = hipStreamSynchronize(c->stream);
