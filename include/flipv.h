@@ -101,7 +101,12 @@ typedef struct flipv_params {
                                     the defect is folded into the row's own volume, no extra bytes).  Matters where nu dt/dx^2 is large: at
                                     256^3 (3 300) the reference's converged velocities are 7e-6 from this operator's and 1.5e-4 from the
                                     exact one's.  1: the exact operator vol u - div(tau) (better conditioned; what rounds differently is the
-                                    reference).   */
+                                    reference).  
+                                    Under the multigrid (fp32 vectors, brick layout) the reference's operator is reached by defect correction:
+                                    stage 1 solves the exact operator's system -- to 100 x viscosity_tolerance where nu dt/dx^2 <= 2e4, to
+                                    viscosity_tolerance beyond --, stage 2 solves A dx = b - A_ref x (fp64 residual) to 2 % of the defect, never
+                                    below viscosity_tolerance, in at most 48 iterations.  `status` 0 = both stages completed; flipv_solve_info.
+                                    residual / defect_residual say what was delivered */
     int residual_replacement;    /* n > 0 (fp32 vectors in the brick layout): every n iterations the solution accumulated so far is flushed into an
                                     fp64 accumulator and the recurrence residual is REPLACED by b - A x evaluated in fp64 (group-wise update, van
                                     der Vorst & Ye; two extra launches per n iterations), so that the stop test sees the true residual.  0
@@ -166,8 +171,9 @@ typedef struct flipv_solve_info {
     int refinements;     /* viscosity, fp32 vectors in the brick layout: how often the solve was continued on the correction equation after a stall
                             (x flushed into an fp64 accumulator, r = b - A x evaluated in fp64, PCG restarted); `iterations` counts all rounds */
     double defect_residual; /* viscosity, default operator under the multigrid: max|b - A_ref x| (fp64) after the defect-correction stage, A_ref the
-                            reference's float-rounded operator; `status` / `residual` are those of the exact-operator PCG loop.  0 when there was
-                            no such stage */
+                            reference's float-rounded operator; `status` / `residual` are those of the exact-operator PCG loop (stage 1: it
+                            stops at 100 x viscosity_tolerance where a correction stage follows, see exact_viscosity_operator).  0 when there
+                            was no such stage */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */
