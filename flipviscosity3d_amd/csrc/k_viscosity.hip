@@ -624,15 +624,16 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const int prc = fv_vmg_prepare(c);   // allocate the hierarchy now, whichever solve first uses it
         if (prc) return prc;
     }
-    // How accurately the coarsest (16^3) level is solved only matters while the system is stiff (bunny 256^3, 12 substeps from
-    // rest, iterations summed: 2303 / 2005 / 1720 / 1476 / 1366 / 1363 with 8 / 16 / 32 / 64 / 128 / 256 Jacobi sweeps, each ~1 us of a
-    // ~300 us iteration; with Chebyshev weights -- k_viscosity_mg.hip: VMG_CHEB_KAPPA -- 8 / 16 / 32 sweeps do what 32 / 64 / 256 did):
-    // 32 sweeps while nu dt/dx^2 > 1000 and the previous multigrid solve needed more than 60 iterations (or there is none yet), 16
-    // otherwise.  Iteration counts only, never timings.  A power of two selects the Chebyshev weights, any other count plain damped Jacobi.
+    // How accurately the coarsest (16^3) level is solved mattered while stage 1 of the solve ran to 1e-6 (bunny 256^3, 12 substeps from
+    // rest, iterations summed: 2303 / 2005 / 1720 / 1476 / 1366 / 1363 with 8 / 16 / 32 / 64 / 128 / 256 Jacobi sweeps, each ~1 us of a ~300 us
+    // iteration; with Chebyshev weights -- k_viscosity_mg.hip: VMG_CHEB_KAPPA -- 8 / 16 / 32 sweeps do what 32 / 64 / 256 did), and the rule was 32
+    // sweeps on stiff systems whose last solve needed more than 60 iterations, else 16.  With stage 1 stopping at 1e-4 (below) the last, slow decade of
+    // the loop is gone and 8 Chebyshev sweeps win or tie everywhere (25 substeps of the 256^3 bunny: 1 318 iterations / 407 ms with the old rule,
+    // 1 312 / 404 with 32, 1 377 / 409 with 16, 1 370 / 389-395 with 8, 1 403 / 410 with 4; honey 256^3: 450 -> 418 ms; 512^3 honey, the 512 x 256 x 256
+    // sheet, 150 substeps of the bunny: -0 ... -1 %; 128^3: -3 %).  A power of two selects the Chebyshev weights, any other count plain damped Jacobi.
     {
         const double stiff = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-        c->vmgSweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2
-                       : ((stiff > 1000.0 && (c->vLastPrec != 2 || c->vLastIts > 60)) ? 32 : 16);
+        c->vmgSweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2 : 8;
         // The packed coarse rows round an entry to 11 bits; the mass term is 1/stiff of the entries.  Measured on the 256^3 bunny: identical iteration
         // counts up to nu dt/dx^2 = 131 072 (512^3, nu = 50), but at 327 680 (256^3, nu = 500) 3-4 of 20 solves end unconverged where the fp32 rows
         // lose 2: beyond 2e5 the cycle reads the fp32 grids.
