@@ -630,10 +630,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // sweeps on stiff systems whose last solve needed more than 60 iterations, else 16.  With stage 1 stopping at 1e-4 (below) the last, slow decade of
     // the loop is gone and 8 Chebyshev sweeps win or tie everywhere (25 substeps of the 256^3 bunny: 1 318 iterations / 407 ms with the old rule,
     // 1 312 / 404 with 32, 1 377 / 409 with 16, 1 370 / 389-395 with 8, 1 403 / 410 with 4; honey 256^3: 450 -> 418 ms; 512^3 honey, the 512 x 256 x 256
-    // sheet, 150 substeps of the bunny: -0 ... -1 %; 128^3: -3 %).  A power of two selects the Chebyshev weights, any other count plain damped Jacobi.
+    // sheet, 150 substeps of the bunny: -0 ... -1 %; 128^3: -3 %) -- for THOSE solves.  A solve that runs ONE loop to 1e-6 (exact operator, block
+    // contexts, nu dt/dx^2 > 2e4) keeps the old rule: with 8 sweeps the bench's exact-operator run needs 88 instead of 74 iterations (721 -> 675
+    // MCells/s), the one-rank communicator run 120 instead of 94 (446 -> 405).  A power of two selects the Chebyshev weights, any other count plain
+    // damped Jacobi.
     {
         const double stiff = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-        c->vmgSweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2 : 8;
+        c->vmgSweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2
+                       : ((stiff > 1000.0 && (c->vLastPrec != 2 || c->vLastIts > 60)) ? 32 : 16);   // (a solve whose stage 1 stops at 1e-4 takes 8: below)
         // The packed coarse rows round an entry to 11 bits; the mass term is 1/stiff of the entries.  Measured on the 256^3 bunny: identical iteration
         // counts up to nu dt/dx^2 = 131 072 (512^3, nu = 50), but at 327 680 (256^3, nu = 500) 3-4 of 20 solves end unconverged where the fp32 rows
         // lose 2: beyond 2e5 the cycle reads the fp32 grids.
@@ -789,6 +793,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // beyond nu dt/dx^2 = 2e4 the reference's float diagonal is simply wrong (below) and stage 1, run to the final tolerance, is the answer.
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
         const double tolMain = (innerDiffers && stiffNow <= 2.0e4) ? 100.0 * tolFinal : tolFinal;
+        if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
         auto recompute_residual = [&]() -> int {

@@ -121,8 +121,9 @@ typedef struct flipv_params {
     int tile_rows;               /* 16 | 64: pins the tile geometry of the plane-layout kernels (lanes of a wave along i); 0 = chosen per
                                     solve from how full the tiles are */
     int viscosity_mg_coarsest_sweeps; /* sweeps on the LDS-resident coarsest level of the viscosity multigrid: a power of two (4..64) = that many
-                                    Chebyshev-weighted Jacobi sweeps, any other count = plain damped Jacobi sweeps; 0 = 8 (what 32 plain sweeps
-                                    do; more only pays when a solve runs one loop to 1e-6: 32 then saves 4 % of the iterations) */
+                                    Chebyshev-weighted Jacobi sweeps, any other count = plain damped Jacobi sweeps; 0 = chosen per solve: 8 where the
+                                    solve is the two-stage defect correction (exact_viscosity_operator), else 32 while nu dt/dx^2 > 1000 and the
+                                    last multigrid solve needed more than 60 iterations, else 16 */
     int viscosity_mg_min_dim;    /* the viscosity hierarchy stops at the level whose longest axis is <= this many cells; 0 = 16 */
     int pressure_mg_coarsest_sweeps; /* 0 = 8 */
     float pressure_mg_omega;     /* damping of the pressure multigrid's Jacobi sweeps; 0 = 0.9 */
