@@ -426,7 +426,6 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const int cap = c->prm.pressure_max_iterations;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
-    const size_t nscal = (size_t)5 * (cap + 2) * NSLOT + 16;
     if ((rc = fv_scal_clear(c, cap, false))) return rc;
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));  // conv = -1
     HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));  // pressure-cell counter
