@@ -778,20 +778,24 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const bool innerDiffers = staged && useMg;   // the Krylov loop runs on the exact operator, the solve is for the reference's
         // Stage 1 of the defect correction does not have to resolve the exact operator's system further than stage 2 preserves.  Stage 2 solves
         // A dx = b - A_ref x from the fp64-recomputed residual -- stage 1's remainder PLUS the defect, which is ~2e-2 max|b| in the max norm at 256^3 /
-        // nu = 5 (a few rows with tiny diagonals carry it) -- to 2 % of the defect.  Scan of the stage-1 tolerance on the 256^3 bunny (two chained
-        // substeps against the reference run to convergence; 128^3 likewise; bench = 20 substeps):
-        //     stage 1 to      1e-6          1e-5          1e-4          1e-3          3e-3
-        //     iterations      115 / 94      83 / 83       68 / 68       56 / 57       53 / 55
-        //     velocity error  3.7e-5/4.0e-5 3.7e-5/4.3e-5 3.6e-5/2.8e-5 2.2e-5/2.3e-5 2.5e-5/3.5e-5       (bar: 1e-4)
-        //     128^3           7.7e-6/1.2e-5 7.7e-6/1.2e-5 6.4e-6/1.1e-5 6.8e-6/1.1e-5 6.4e-6/1.1e-5
-        //     MCells/s        686           742           838           971           1035
-        // -- the delivered velocities do not depend on it, because what is left at the end is 2 % of the defect either way (max|b - A_ref x| = 3e-4 ..
-        // 5e-4 max|b| on the stiff substeps in every column).  Taken: 1e-4 = 100 x the final tolerance -- the loosest value at which a solve WITHOUT
-        // a defect (r2 = the remainder alone) still ends at the final tolerance inside stage 2's budget of 48 iterations, because stage 2's target is 2 %
-        // of what r2 holds BEYOND stage 1's remainder, and never below the final tolerance.  Only where the first-order correction means something:
-        // beyond nu dt/dx^2 = 2e4 the reference's float diagonal is simply wrong (below) and stage 1, run to the final tolerance, is the answer.
+        // nu = 5 (a few rows with tiny diagonals carry it) -- and what it leaves of the DEFECT is what separates the delivered velocities from the
+        // reference's.  Scans on the 256^3 bunny (two chained substeps against the reference run to convergence, 20 000 probe faces per component;
+        // 128^3 likewise; bench = 20 substeps; final library):
+        //     stage 1 to / stage 2 to    iterations   velocity error 256^3   128^3               MCells/s
+        //     1e-6 / 2e-2 of the defect  115 / 94     3.7e-5 / 4.0e-5        7.7e-6 / 1.2e-5     686        (the first version)
+        //     1e-4 / 2e-2                70 / 70      5.2e-5 / 6.1e-5        1.5e-5 / 2.0e-5     865
+        //     3e-5 / 2e-2                76 / 77      5.4e-5 / 6.0e-5        1.5e-5 / 1.7e-5     814
+        //     1e-4 / 1e-2                76 / 76      2.6e-5 / 9.2e-6        6.1e-6 / 1.3e-5     790-860
+        //     3e-4 / 1e-2                70 / 67      2.3e-5 / 1.3e-5        5.1e-6 / 8.1e-6     878        <- taken
+        //     1e-3 / 1e-2                63 / 60      1.6e-5 / 1.7e-5        3.2e-6 / 1.1e-5     911
+        //     1e-3 / 5e-3                69 / 65      2.5e-5 / 1.8e-5        1.4e-6 / 3.8e-6     892
+        // The error follows stage 2's factor, not stage 1's tolerance: with 2e-2 it is 5-6e-5 whatever stage 1 did (even 3e-3: 2.5e-5 / 3.5e-5 in an
+        // earlier build), with 1e-2 it is 1-3e-5.  Taken: stage 1 to 300 x the final tolerance, stage 2 to 1 % of what the recomputed residual holds
+        // BEYOND stage 1's remainder and never below the final tolerance (a solve without a defect then still ends at the final tolerance, stage 2
+        // reducing the remainder alone inside its 48 iterations).  Only where the first-order correction means something: beyond nu dt/dx^2 = 2e4 the
+        // reference's float diagonal is simply wrong (below) and stage 1, run to the final tolerance, is the answer.
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-        const double tolMain = (innerDiffers && stiffNow <= 2.0e4) ? 100.0 * tolFinal : tolFinal;
+        const double tolMain = (innerDiffers && stiffNow <= 2.0e4) ? 300.0 * tolFinal : tolFinal;
         if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
@@ -816,7 +820,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const bool correction = correctionDue;   // this round is a bounded defect-correction stage (see above)
         const int capNow = (correction && cap - itersDone > 48) ? 48 : cap - itersDone;
         sc.cap = capNow;
-        sc.tol = correction ? fmax(tolFinal, 2e-2 * fmax(resStart - (tolMain > tolFinal ? tolMain : 0.0), 0.0)) : tolMain;   // (scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
+        sc.tol = correction ? fmax(tolFinal, (tolMain > tolFinal ? 1e-2 : 2e-2) * fmax(resStart - (tolMain > tolFinal ? tolMain : 0.0), 0.0)) : tolMain;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
         sc.stall_below = refinements > 0 ? fmin(100.0 * sc.tol, 0.05 * resStart) : 0.0;
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
         // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the

@@ -103,9 +103,9 @@ typedef struct flipv_params {
                                     exact one's.  1: the exact operator vol u - div(tau) (better conditioned; what rounds differently is the
                                     reference).  
                                     Under the multigrid (fp32 vectors, brick layout) the reference's operator is reached by defect correction:
-                                    stage 1 solves the exact operator's system -- to 100 x viscosity_tolerance where nu dt/dx^2 <= 2e4, to
-                                    viscosity_tolerance beyond --, stage 2 solves A dx = b - A_ref x (fp64 residual) to 2 % of the defect, never
-                                    below viscosity_tolerance, in at most 48 iterations.  `status` 0 = both stages completed; flipv_solve_info.
+                                    stage 1 solves the exact operator's system -- to 300 x viscosity_tolerance where nu dt/dx^2 <= 2e4, to
+                                    viscosity_tolerance beyond --, stage 2 solves A dx = b - A_ref x (fp64 residual) to 1 % of the defect (2 % where
+                                    stage 1 ran to viscosity_tolerance), never below viscosity_tolerance, in at most 48 iterations.  `status` 0 = both stages completed; flipv_solve_info.
                                     residual / defect_residual say what was delivered */
     int residual_replacement;    /* n > 0 (fp32 vectors in the brick layout): every n iterations the solution accumulated so far is flushed into an
                                     fp64 accumulator and the recurrence residual is REPLACED by b - A x evaluated in fp64 (group-wise update, van
@@ -173,7 +173,7 @@ typedef struct flipv_solve_info {
                             (x flushed into an fp64 accumulator, r = b - A x evaluated in fp64, PCG restarted); `iterations` counts all rounds */
     double defect_residual; /* viscosity, default operator under the multigrid: max|b - A_ref x| (fp64) after the defect-correction stage, A_ref the
                             reference's float-rounded operator; `status` / `residual` are those of the exact-operator PCG loop (stage 1: it
-                            stops at 100 x viscosity_tolerance where a correction stage follows, see exact_viscosity_operator).  0 when there
+                            stops at 300 x viscosity_tolerance where a correction stage follows, see exact_viscosity_operator).  0 when there
                             was no such stage */
 } flipv_solve_info;
 
