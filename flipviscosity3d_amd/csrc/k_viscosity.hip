@@ -792,10 +792,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // The error follows stage 2's factor, not stage 1's tolerance: with 2e-2 it is 5-6e-5 whatever stage 1 did (even 3e-3: 2.5e-5 / 3.5e-5 in an
         // earlier build), with 1e-2 it is 1-3e-5.  Taken: stage 1 to 300 x the final tolerance, stage 2 to 1 % of what the recomputed residual holds
         // BEYOND stage 1's remainder and never below the final tolerance (a solve without a defect then still ends at the final tolerance, stage 2
-        // reducing the remainder alone inside its 48 iterations).  Only where the first-order correction means something: beyond nu dt/dx^2 = 2e4 the
-        // reference's float diagonal is simply wrong (below) and stage 1, run to the final tolerance, is the answer.
+        // reducing the remainder alone inside its 48 iterations).  Up to nu dt/dx^2 = 2e5 (where the cycle also stops reading packed rows: the fp32
+        // loop's accuracy floor).  The rule first stopped at 2e4; the 64^3 scene against the oracle run to convergence (profiles/r3/
+        // stiffness_scan_64.log) says it need not: at 32 768 stage 1 to 1e-6 with stage 2 at 2 % gives 4e-5 ... 9e-5 on the first substep and 7e-5 ...
+        // 2e-4 on the second, this rule 2e-5 and 1e-4 for 25-60 % fewer iterations; at 122 880 the former runs a solve into the cap (1e-4 ... 7e-4),
+        // this rule gives 1.5e-4 / 1.6e-4 -- nothing pins those regimes to 1e-4, and this is the cheaper and the more robust of the two.
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-        const double tolMain = (innerDiffers && stiffNow <= 2.0e4) ? 300.0 * tolFinal : tolFinal;
+        const double tolMain = (innerDiffers && stiffNow <= 2.0e5) ? 300.0 * tolFinal : tolFinal;
         if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars

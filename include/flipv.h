@@ -103,7 +103,7 @@ typedef struct flipv_params {
                                     exact one's.  1: the exact operator vol u - div(tau) (better conditioned; what rounds differently is the
                                     reference).  
                                     Under the multigrid (fp32 vectors, brick layout) the reference's operator is reached by defect correction:
-                                    stage 1 solves the exact operator's system -- to 300 x viscosity_tolerance where nu dt/dx^2 <= 2e4, to
+                                    stage 1 solves the exact operator's system -- to 300 x viscosity_tolerance where nu dt/dx^2 <= 2e5, to
                                     viscosity_tolerance beyond --, stage 2 solves A dx = b - A_ref x (fp64 residual) to 1 % of the defect (2 % where
                                     stage 1 ran to viscosity_tolerance), never below viscosity_tolerance, in at most 48 iterations.  `status` 0 = both stages completed; flipv_solve_info.
                                     residual / defect_residual say what was delivered */
