@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 evidence set (run through gpurun; outputs under gpurun_out/ev_r3/, copied into profiles/r3/ afterwards).  bash tools/evidence_r3.sh <tag>
-tag=${1:-r3v10}
+tag=${1:-r3v11}
 out=gpurun_out/ev_r3
 mkdir -p $out
 B="python3 bench.py --gpu-setup"
