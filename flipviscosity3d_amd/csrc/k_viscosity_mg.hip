@@ -1599,6 +1599,10 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     if (graph) {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
+        // The first iteration is launched directly: capturing the chunk and updating the graph executable takes the host ~0.35 ms, the start-up cycle
+        // above keeps the device busy for ~0.25 ms -- with one more iteration queued the capture is hidden (the device sat idle ~0.1 ms per stage).
+        int done0 = 0;
+        if (cap > 1) { if ((rc = iteration(IT_DEVICE, may_replace(0)))) return rc; done0 = 1; }
         const auto tc0 = std::chrono::steady_clock::now();
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         for (int e = 0; e < every; e++) (void)iteration(IT_DEVICE, may_replace(e));
@@ -1612,7 +1616,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         }
         if ((rc = fv_graph_exec(c, FV_GE_VISCOSITY_MG, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
         if (c->prm.verbose) fprintf(stderr, "  multigrid loop: stream capture %.3f ms, graph executable %.3f ms (host)\n", std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
-        for (int done = 0; done < cap && conv < 0; done += every) {
+        for (int done = done0; done < cap && conv < 0; done += every) {
             hipError_t el = hipGraphLaunch(ge, c->stream);
             hipError_t es = hipStreamSynchronize(c->stream);
             if (el != hipSuccess || es != hipSuccess) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
