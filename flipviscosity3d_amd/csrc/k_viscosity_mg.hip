@@ -1578,7 +1578,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     if (s->rc) return s->rc;
     if (c->comm && (rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
     PP(-1);                       // p = z
-    const int every = c->prm.check_every > 0 ? c->prm.check_every : 8;
+    const int every = c->prm.check_every > 0 ? c->prm.check_every : 4;   // (iterations per replayed chunk; 2 / 3 / 4 / 5 / 8 / 12 / 16 scanned on the bench scene: 382 / 381 / 372-378 / 384 / 382-391 / 438 / 421 ms of viscosity solves over 25 substeps)
     int conv = -1;
     auto iteration = [&](int it, bool replace) -> int {   // it = IT_DEVICE inside the graph
         int r2;

@@ -82,7 +82,8 @@ typedef struct flipv_params {
     double viscosity_accept_tolerance; /* 10.0 (viscositysolver.h:201) */
     int precision;               /* enum flipv_precision */
     int kernel_timing;           /* 1 => bracket every SpMV launch with HIP events (flipv_kernel_stats) */
-    int check_every;             /* convergence poll interval in iterations; 0 (default) = 32 on one GPU, 8 with a communicator */
+    int check_every;             /* convergence poll interval in iterations; 0 (default) = 32 on one GPU, 8 with a communicator (the diagonal loops), 4 in the
+                                    multigrid-preconditioned loops (viscosity and pressure: an iteration after the stop is a full V-cycle) */
     /* solver choice (enum flipv_preconditioner) */
     int pressure_preconditioner; /* AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
     int viscosity_preconditioner;/* DIAGONAL; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors, one rank, whole-domain context; other
