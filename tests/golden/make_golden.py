@@ -85,13 +85,15 @@ def scene(name, N, boundary, liquid, nu, nsub, dt=0.01, gravity=(0.0, -9.81, 0.0
     s.close()
 
 
-def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inputs=True, nprobe=0, vtol=0.0):
+def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inputs=True, nprobe=0, vtol=0.0, store_state=()):
     """End-of-substep dumps only, for scenes at BASELINE sizes whose phase-by-phase dump would be tens of MB:
     inputs (unless the test regenerates them bit for bit with the host library: then a particle count and
     checksums), and per substep the final velocities (whole grids, or `nprobe` seeded probe faces per
     component), the pressure, the particles (or their checksum) and the solver iteration counts.
     vcap > 0 lifts the viscosity iteration cap (ViscositySolver::_maxSolverIterations, viscositysolver.h:202)
-    so that the reference's answer is the converged one."""
+    so that the reference's answer is the converged one.
+    store_state: substeps after which the particles are stored even without store_inputs (a test can then start the NEXT substep from the
+    reference's own state instead of chaining its own)."""
     I = J = K = N
     dx = float(np.float32(1.0 / N))
     s = R.RefSim(I, J, K, dx)
@@ -131,7 +133,7 @@ def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inpu
                 d[p + "final_" + c] = a
         Pn = s.particles
         d[p + "particles_sum"] = Pn.astype(np.float64).sum(axis=0)
-        if store_inputs:
+        if store_inputs or t in store_state:
             d[p + "particles"] = Pn
         print("  substep %d: viscosity %d its (%.3e), pressure %d its" % (t, st["visc_iters"], st["visc_err"], st["pres_iters"]), flush=True)
     path = os.path.join(OUT, name + ".npz")
@@ -170,6 +172,17 @@ if __name__ == "__main__":
     #    component and substep.
     compact_scene("bunny128_nu5_converged", 128, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 2, vcap=5000,
                   store_inputs=False, nprobe=20000)
+    # H, I: BASELINE config #4's STIFFNESS regime (nu dt/dx^2 = 1.2e5 ... 1.3e5; config 4 itself: 512^3 at nu = 50 = 131 072), which no other
+    #    fixture reaches (honey64_nu50: 2 048).  Reference with its cap lifted; the particles after every substep are stored so that a test can
+    #    start each substep from the reference's own state ("unchained": at this stiffness the chained state is ill-conditioned -- a 1e-5 difference
+    #    in the first substep's velocities becomes 1e-3 in the second's whatever the solver does, profiles/r3/stiffness_scan_64.log).
+    #    H = the bunny scene of that scan (64^3, nu = 3 000: 122 880); I = rod + sheet, config 4's own scene, at 96^3 with nu = 1 422.2 (131 070).
+    #    Inputs are regenerated by the tests with the host library (bit-exact against the reference); stored: 20 000 probe faces per component
+    #    and substep, checksums, and the particles after substep 0.
+    compact_scene("bunny64_nu3000", 64, ("sphere_large.ply", True), ["stanford_bunny.ply"], 3000.0, 2, vcap=200000,
+                  store_inputs=False, nprobe=20000, store_state=(0,))
+    compact_scene("honey96_nu1422", 96, None, ["rod.ply", "sheet.ply"], 1422.2, 2, vcap=200000,
+                  store_inputs=False, nprobe=20000, store_state=(0,))
     # F: BASELINE config #3 itself -- the 256^3 bunny drop, nu = 5 -- with the reference's cap lifted (its MIC(0) solve needs well
     #    over the stock 700 iterations here): the reference's CONVERGED answer at the headline size.  ~10 minutes per substep on one
     #    core, so this one is only built when named on the command line; the oracle is not run against it (minutes per substep).

@@ -94,3 +94,39 @@ def test_bunny256_scene_setup_matches_reference():
     assert len(P) == int(g["nparticles"])
     assert np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])
     assert np.float64(solid.astype(np.float64).sum()) == g["solid_sum"]
+
+
+STIFF = [("bunny64_nu3000", 64, ("sphere_large.ply", True), ["stanford_bunny.ply"]),
+         ("honey96_nu1422", 96, None, ["rod.ply", "sheet.ply"])]
+
+
+@pytest.mark.parametrize("name,N,boundary,liquids", STIFF)
+def test_oracle_stiff_regime_goldens(oracle, name, N, boundary, liquids):
+    """BASELINE config #4's stiffness regime (nu dt/dx^2 = 1.2e5 ... 1.3e5; make_golden.py H, I): the host library's scene is the
+    reference's (count, checksums), and the oracle with its cap lifted lands on the reference's converged answer iteration for iteration
+    and bit for bit at the probe faces -- on BOTH substeps, the second started from the reference's own particles (stored in the fixture)."""
+    g = Golden(name)
+    assert g.dims() == (N, N, N) and int(g["vcap"]) >= 100000
+    stiff = float(g["nu"]) * g.dt / g.dx ** 2
+    assert 1.2e5 <= stiff <= 1.35e5, stiff
+    dx, solid, P = build_host_scene(N, boundary, liquids)
+    assert len(P) == int(g["nparticles"])
+    assert np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])
+    assert np.float64(solid.astype(np.float64).sum()) == g["solid_sum"]
+    s = oracle.OracleSim(N, N, N, dx)
+    s.set_solid(solid)
+    s.set_viscosity(float(g["nu"]))
+    s.set_solver_limits(vmaxiter=int(g["vcap"]))
+    s.particles = P
+    for t in range(g.nsub):
+        sec, vi, pi = s.substep(g.dt)
+        assert vi["iterations"] == int(g["s%d_visc_iters" % t]) and vi["iterations"] > 700 and vi["status"] == 0
+        assert pi["iterations"] == int(g["s%d_pres_iters" % t])
+        for c in "UVW":
+            a = s.grid(c).reshape(-1)
+            assert np.array_equal(a[g["s%d_probe_idx_%s" % (t, c)]], g["s%d_probe_val_%s" % (t, c)])
+            assert np.float32(np.abs(a).max()) == g["s%d_maxabs_%s" % (t, c)]
+        assert np.array_equal(s.particles.astype(np.float64).sum(axis=0), g["s%d_particles_sum" % t])
+        if t == 0:
+            assert np.array_equal(s.particles, g["s0_particles"])
+    s.close()
