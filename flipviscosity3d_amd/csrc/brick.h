@@ -8,9 +8,9 @@
 struct BrickBox { int b0[3], nb[3]; };
 static inline BrickBox brick_box(const Lay &box) {
     BrickBox R;
-    R.b0[0] = (box.ib + 8) >> 3; R.nb[0] = ((box.ie - 1 + 8) >> 3) - R.b0[0] + 1;
-    R.b0[1] = (box.jb + 4) >> 2; R.nb[1] = ((box.je - 1 + 4) >> 2) - R.b0[1] + 1;
-    R.b0[2] = (box.kb + 2) >> 1; R.nb[2] = ((box.ke - 1 + 2) >> 1) - R.b0[2] + 1;
+    R.b0[0] = (box.ib - box.ox + 8) >> 3; R.nb[0] = ((box.ie - box.ox - 1 + 8) >> 3) - R.b0[0] + 1;   // (box-local: bidx)
+    R.b0[1] = (box.jb - box.oy + 4) >> 2; R.nb[1] = ((box.je - box.oy - 1 + 4) >> 2) - R.b0[1] + 1;
+    R.b0[2] = (box.kb - box.oz + 2) >> 1; R.nb[2] = ((box.ke - box.oz - 1 + 2) >> 1) - R.b0[2] + 1;
     return R;
 }
 // linear brick id (x fastest over the whole padded brick grid) of brick `code` of the box's brick range
@@ -18,12 +18,12 @@ __device__ __forceinline__ int d_brick_of_code(const BrickBox &R, const Lay &LB,
     const int bx = code % R.nb[0], r = code / R.nb[0], by = r % R.nb[1], bz = r / R.nb[1];
     return (int)((long)(R.b0[2] + bz) * LB.sz + (long)(R.b0[1] + by) * LB.sy + (long)(R.b0[0] + bx));
 }
-// index (i, j, k) of lane `lane` of brick `brick`
+// GLOBAL index (i, j, k) of lane `lane` of brick `brick`
 __device__ __forceinline__ void d_brick_ijk(const Lay &LB, int brick, int lane, int &i, int &j, int &k) {
     const int bx = brick % (int)LB.sy, r = brick / (int)LB.sy, nby = (int)(LB.sz / LB.sy), by = r % nby, bz = r / nby;
-    i = (bx << 3) - 8 + ((lane >> 5) << 2) + (lane & 3);
-    j = (by << 2) - 4 + ((lane >> 2) & 3);
-    k = (bz << 1) - 2 + ((lane >> 4) & 1);
+    i = LB.ox + (bx << 3) - 8 + ((lane >> 5) << 2) + (lane & 3);
+    j = LB.oy + (by << 2) - 4 + ((lane >> 2) & 3);
+    k = LB.oz + (bz << 1) - 2 + ((lane >> 4) & 1);
 }
 // neighbour offsets of this lane (threadIdx.x = position inside the brick): nb_brick() from the lane's bits
 __device__ __forceinline__ NbOff d_lane_off(int sby, int sbz) {
@@ -167,5 +167,5 @@ template <typename T> void fv_brick_init(flipv_context *c, const PcgScal &sc);
 template <typename T> void fv_brick_update(flipv_context *c, const PcgScal &sc, int it);
 void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);
 template <typename T> void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int period, int withSigma, float *const z[3], float omega);
-template <typename T> void fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact);
+template <typename T> int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact);
 template <typename T> void fv_brick_writeback(flipv_context *c, const Lay &R, int m, bool withAcc, float *dst);

@@ -144,7 +144,7 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     c->k1 = L.ohi[2];
     c->LB = brick_lay(L);
     c->solverCap = L.n + L.guard;
-    if (!c->isBlock && c->LB.n > c->solverCap) c->solverCap = c->LB.n;
+    if (c->LB.n > c->solverCap) c->solverCap = c->LB.n;
     c->comm = nullptr;
     c->pScratch = nullptr; c->pScratchCap = 0;
     c->binIdx = nullptr; c->binIdxCap = 0;
@@ -206,6 +206,7 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     {
         int rc_ = plain_alloc(c, &c->d_flags, 16);
         if (!rc_) rc_ = plain_alloc(c, &c->d_scal_small, 64);
+        if (!rc_) rc_ = plain_alloc(c, &c->d_gather, 8 * NSLOT);
         if (!rc_ && !setupOnly) rc_ = plain_alloc(c, &c->actFlags, (size_t)3 * ((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8));
         if (!rc_ && !setupOnly) rc_ = plain_alloc(c, &c->actList, (size_t)((L.PX + 7) / 8) * ((L.PY + 7) / 8) * ((L.PZ + 7) / 8) + 16);
         if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; }
@@ -245,7 +246,7 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     GALLOC(c->vRowMask);
     SALLOC(c->vMaskB);
     for (int q = 0; q < 3; q++) { SALLOC(c->vB[q]); SALLOC(c->vXacc[q]); }
-    if (!c->isBlock) {
+    {
         c->brickCap = c->LB.n / 64;
         int rc_ = plain_alloc(c, &c->brickList, c->brickCap + 64);
         if (!rc_) rc_ = plain_alloc(c, &c->brickFlag, c->brickCap + 64);

@@ -35,7 +35,9 @@ struct Comm {
 };
 
 // halo helpers (flipv_comm.hip)
-struct HaloArray { void *p; size_t elem; };
+// lay: 0 = the plain layout (gidx), 1 = the brick layout of the viscosity solver's arrays (bidx over c->LB).  What travels is box-shaped
+// staging either way, so the two ends of an exchange need not use the same layout.
+struct HaloArray { void *p; size_t elem; int lay = 0; };
 int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H);
 int fv_halo_copy_begin(flipv_context *c, const HaloArray *arr, int n, int H);  // on the communication stream, overlapping c->stream
 int fv_halo_wait(flipv_context *c);                                             // c->stream waits for that exchange
@@ -45,6 +47,11 @@ int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n);
 int fv_allreduce_f32(flipv_context *c, float *dev, size_t n);    // in-place sum over the ranks, on c->stream
 int fv_migrate_particles(flipv_context *c);
 int fv_allreduce_max_f32(flipv_context *c, float *value);  // host value in/out (synchronises)
+// every rank's n <= FV_GATHER_MAX host values on every rank, all[r * n + q] = rank r's q-th value (one small all-reduce + one synchronisation,
+// whatever n: the per-solve decisions that must come out alike on all ranks are taken from ONE such exchange, not from one round trip per value).
+// Without a communicator: all = mine.
+constexpr int FV_GATHER_MAX = 8;
+int fv_allgather_f64(flipv_context *c, const double *mine, int n, double *all);
 // thinnest slab a multi-rank run accepts: the widest exchange moves ceil(cfl) + 3 of a rank's own planes
 static inline int fv_min_slab_planes(float cfl_number) { return (int)ceilf(cfl_number) + 3; }
 // FLIPV_ERR_INVALID (with c->err set) if the block is thinner than that along an axis on which it has neighbours

@@ -20,7 +20,7 @@ __global__ void k_halo_combine(float *__restrict__ dst, const float *__restrict_
 // Boxes of the index space <-> a contiguous staging buffer, for up to HALO_MAXARR arrays at once (array a's part of a box's
 // staging starts at byte offset a * boxcount * 8, whatever its element size: keeps every part 8-byte aligned): k_halo_dirs.
 constexpr int HALO_MAXARR = 6;
-struct HaloSet { void *p[HALO_MAXARR]; int elem[HALO_MAXARR]; int n; };
+struct HaloSet { void *p[HALO_MAXARR]; int elem[HALO_MAXARR]; int lay[HALO_MAXARR]; int n; };
 struct HBox { int lo[3], hi[3]; };
 // particle -> destination along one axis by the index of its cell on that axis: 0 stay, 1 previous rank, 2 next rank.
 // Output slots come from ONE global atomic per block and destination (nearly every particle stays: one atomic per
@@ -115,7 +115,7 @@ struct DirSet {
     unsigned long long scnt[HALO_MAXDIR], rcnt[HALO_MAXDIR];   // entries of the boxes
 };
 // blockIdx.y = direction; recv = 0: sbox -> staging + soff (pack); recv = 1: staging + roff -> rbox with `mode` (1 copy, 2 min, 3 add)
-__global__ void k_halo_dirs(HaloSet hs, Lay L, DirSet D, char *__restrict__ staging, int recv, int mode) {
+__global__ void k_halo_dirs(HaloSet hs, Lay L, Lay LB, DirSet D, char *__restrict__ staging, int recv, int mode) {
     const int q = blockIdx.y;
     const HBox b = recv ? D.rbox[q] : D.sbox[q];
     const int w = b.hi[0] - b.lo[0], h = b.hi[1] - b.lo[1], d = b.hi[2] - b.lo[2];
@@ -124,8 +124,9 @@ __global__ void k_halo_dirs(HaloSet hs, Lay L, DirSet D, char *__restrict__ stag
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += stride) {
         const int i = b.lo[0] + (int)(t % (size_t)w), j = b.lo[1] + (int)((t / (size_t)w) % (size_t)h), k = b.lo[2] + (int)(t / ((size_t)w * h));
-        const size_t c = gidx(L, i, j, k);
+        const size_t cp = gidx(L, i, j, k), cb = bidx(LB, i, j, k);
         for (int a = 0; a < hs.n; a++) {
+            const size_t c = hs.lay[a] ? cb : cp;
             char *st = base + (size_t)a * cnt * 8;
             if (hs.elem[a] == 4) {
                 float *g = (float *)hs.p[a] + c, *p = (float *)st + t;
@@ -194,12 +195,12 @@ static int exchange_dirs(flipv_context *c, const HaloSet &hs, DirSet &D, size_t 
     unsigned gs = grid1d(maxs), gr = grid1d(maxr);
     if (gs > 512) gs = 512;
     if (gr > 512) gr = 512;
-    hipLaunchKernelGGL(k_halo_dirs, dim3(gs, D.n), dim3(256), 0, c->xs, hs, c->L, D, c->xbuf, 0, 0);
+    hipLaunchKernelGGL(k_halo_dirs, dim3(gs, D.n), dim3(256), 0, c->xs, hs, c->L, c->LB, D, c->xbuf, 0, 0);
     if ((rc = cm->begin(c))) return rc;
     for (int q = 0; q < D.n; q++)
         if ((rc = cm->sendrecv(c, D.peer[q], c->xbuf + D.soff[q], D.scnt[q] * 8 * (size_t)hs.n, c->xbuf + D.roff[q], D.rcnt[q] * 8 * (size_t)hs.n))) return rc;
     if ((rc = cm->end(c))) return rc;
-    hipLaunchKernelGGL(k_halo_dirs, dim3(gr, D.n), dim3(256), 0, c->xs, hs, c->L, D, c->xbuf, 1, mode);
+    hipLaunchKernelGGL(k_halo_dirs, dim3(gr, D.n), dim3(256), 0, c->xs, hs, c->L, c->LB, D, c->xbuf, 1, mode);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
@@ -213,8 +214,10 @@ int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
     if (n > HALO_MAXARR) { c->err = "fv_halo_copy: too many arrays"; return FLIPV_ERR_INVALID; }
     const Lay &L = c->L;
     int rc;
-    if (c->pgrid[0] == 1 && c->pgrid[1] == 1) {
-        // slabs along k: whole contiguous planes travel straight from / into the arrays
+    bool anyBrick = false;
+    for (int a = 0; a < n; a++) anyBrick = anyBrick || arr[a].lay != 0;
+    if (c->pgrid[0] == 1 && c->pgrid[1] == 1 && !anyBrick) {
+        // slabs along k: whole contiguous planes travel straight from / into the arrays (plain layout only: a brick array's planes are not contiguous)
         if (c->pgrid[2] <= 1) return FLIPV_OK;
         const int lower = nbr_rank(c, 2, -1), upper = nbr_rank(c, 2, +1);
         const int own0 = L.olo[2], own1 = L.ohi[2];
@@ -230,7 +233,7 @@ int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
     }
     HaloSet hs;
     hs.n = n;
-    for (int a = 0; a < n; a++) { hs.p[a] = arr[a].p; hs.elem[a] = (int)arr[a].elem; }
+    for (int a = 0; a < n; a++) { hs.p[a] = arr[a].p; hs.elem[a] = (int)arr[a].elem; hs.lay[a] = arr[a].lay; }
     AxisRanges R[3];
     for (int a = 0; a < 3; a++) {
         const int o0 = L.olo[a], o1 = L.ohi[a];
@@ -273,7 +276,7 @@ int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi,
     const Lay &L = c->L;
     HaloSet hs;
     hs.n = n;
-    for (int a = 0; a < n; a++) { hs.p[a] = arr[a]; hs.elem[a] = 4; }
+    for (int a = 0; a < n; a++) { hs.p[a] = arr[a]; hs.elem[a] = 4; hs.lay[a] = 0; }
     AxisRanges R[3];
     for (int a = 0; a < 3; a++) {
         const int o0 = L.olo[a], o1 = L.ohi[a];
@@ -314,6 +317,23 @@ int fv_allreduce_max_f32(flipv_context *c, float *value) {
     double m = h[0];   // (every rank has written its slot: a true maximum, negative values included)
     for (double v : h) m = v > m ? v : m;
     *value = (float)m;
+    return FLIPV_OK;
+}
+
+int fv_allgather_f64(flipv_context *c, const double *mine, int n, double *all) {
+    Comm *cm = c->comm;
+    if (n < 1 || n > FV_GATHER_MAX) { c->err = "fv_allgather_f64: bad count"; return FLIPV_ERR_INVALID; }
+    if (!cm) { for (int q = 0; q < n; q++) all[q] = mine[q]; return FLIPV_OK; }
+    const size_t tot = (size_t)cm->nranks * (size_t)n;
+    double h[NSLOT * FV_GATHER_MAX];
+    for (size_t q = 0; q < tot; q++) h[q] = 0.0;
+    for (int q = 0; q < n; q++) h[(size_t)cm->rank * n + q] = mine[q];
+    HIPCHK(c, hipMemcpyAsync(c->d_gather, h, tot * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (h is pageable stack memory: the copy must have left it before the all-reduce overwrites nothing of it, and before h dies)
+    int rc = cm->allreduce_sum(c, c->d_gather, tot);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(all, c->d_gather, tot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return FLIPV_OK;
 }
 

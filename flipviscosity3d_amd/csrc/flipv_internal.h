@@ -60,10 +60,11 @@ __host__ __device__ __forceinline__ size_t sidx(const Lay &L, int i, int j, int 
     return (size_t)((long)(k - L.oz) * L.sz + (long)(j >> 2) * (4 * L.PX) + (long)(i >> 3) * 32 + (long)(((j & 3) << 3) + (i & 7)));
 }
 
-// Brick layout of the viscosity solver's arrays on sparse liquids (single-GPU contexts; k_viscosity_brick.hip).  The index space is cut
+// Brick layout of the viscosity solver's arrays on sparse liquids (k_viscosity_brick.hip).  The context's ALLOCATED box (the whole index
+// space on a single GPU; the rank's owned box + halo on a block context: 8 | ox, 4 | oy, oz arbitrary) is cut
 // into bricks of 8 x 4 x 2 indices = 64 entries = 256 contiguous bytes, each brick two 128-byte lines of 4 x 4 x 2 indices side by side
-// in i, bricks in x-fastest order with ONE padding brick on every side (indices -8.. and up to the padded end + 7 are addressable:
-// stencil neighbours of any in-range index need no guard zone and no bounds test).  On the reference's scenes the liquid fills a
+// in i, bricks in x-fastest order with ONE padding brick on every side (box-local indices -8.. and up to the padded end + 7 are addressable:
+// stencil neighbours of any in-range index need no guard zone and no bounds test).  Indices are GLOBAL, as everywhere: bidx subtracts the box origin.  On the reference's scenes the liquid fills a
 // few per cent of the box as a compact body: a 128-byte line that is a 32 x 1 stick of a k-plane (the plain layout) is 1.5x
 // over-fetched at the ends of the liquid's i-runs, a 4 x 4 x 2 block 1.1x (counted on the 256^3 bunny).  A wave owns one brick, a lane
 // one index; the address is SEPARABLE, bidx = f(i) + g(j) + h(k), so the offset to a neighbour along an axis depends on the lane's own
@@ -71,11 +72,11 @@ __host__ __device__ __forceinline__ size_t sidx(const Lay &L, int i, int j, int 
 // For a Lay describing this layout sy / sz hold the BRICK strides in bricks (bricks per row, bricks per plane), as for the multigrid's
 // coarse levels (k_viscosity_mg.hip: cidx); brick_lay() derives it from the context's plain Lay.
 __host__ __device__ __forceinline__ size_t bidx(const Lay &B, int i, int j, int k) {
-    const int ip = i + 8, jp = j + 4, kp = k + 2;
+    const int ip = i - B.ox + 8, jp = j - B.oy + 4, kp = k - B.oz + 2;
     return ((size_t)((long)(kp >> 1) * B.sz + (long)(jp >> 2) * B.sy + (long)(ip >> 3)) << 6) +
            (size_t)((((ip >> 2) & 1) << 5) + ((kp & 1) << 4) + ((jp & 3) << 2) + (ip & 3));
 }
-static inline Lay brick_lay(const Lay &L) {   // single-domain contexts only (ox = oy = oz = 0)
+static inline Lay brick_lay(const Lay &L) {   // (keeps L's origin and owned box: d_owned and the lattice tests work on it as on L)
     Lay B = L;
     const long nbx = L.PX / 8 + 2, nby = L.PY / 4 + 2, nbz = (L.PZ + 1) / 2 + 2;
     B.sy = nbx; B.sz = nbx * nby;
@@ -93,7 +94,8 @@ __host__ __device__ __forceinline__ NbOff nb_brick(const Lay &B, int i, int j, i
     NbOff o;
     o.xp = (i & 3) < 3 ? 1 : 29;          o.xm = (i & 3) > 0 ? -1 : -29;            // into the other half-brick / the next brick: +32 - 3
     o.yp = (j & 3) < 3 ? 4 : sby - 12;    o.ym = (j & 3) > 0 ? -4 : -(sby - 12);
-    o.zp = (k & 1) == 0 ? 16 : sbz - 16;  o.zm = (k & 1) == 1 ? -16 : -(sbz - 16);
+    const int kl = (k - B.oz) & 1;        // (i & 3, j & 3 are box-local as they are: 8 | ox, 4 | oy)
+    o.zp = kl == 0 ? 16 : sbz - 16;       o.zm = kl == 1 ? -16 : -(sbz - 16);
     return o;
 }
 // layout of the viscosity solver's arrays for the current solve
@@ -206,6 +208,7 @@ struct flipv_context {
     // scalars
     double *d_scal;   // device scalar scratch (PCG)
     double *d_scal_small;  // 64 doubles: communication scratch (counts, CFL max, barrier)
+    double *d_gather = nullptr;   // NSLOT x FV_GATHER_MAX doubles: fv_allgather_f64
     double *h_scal;   // pinned host mirror
     size_t scalCap;
     int *d_flags;     // device int scratch: [0] conv, [1] tile count, [2] row count, [3] cfl bits, [4,5] graph iteration counters, [6] interior tile count, [7] in-domain indices of the listed tiles / 4
@@ -223,7 +226,7 @@ struct flipv_context {
     TileGrid tgP, tgV;
     int vSwz = 0;        // the viscosity PCG arrays of the current solve are in the swizzled layout (vLayout == VLAYOUT_SWZ)
     int vLayout = 0;     // VLAYOUT_*: layout of the viscosity solver's arrays (factors, own volumes, diagonal, row mask copy, x, r, q, s, b) for the current solve
-    Lay LB;              // the brick layout of this context's index space (brick_lay(L)); valid on single-domain contexts
+    Lay LB;              // the brick layout of this context's allocated box (brick_lay(L))
     size_t solverCap = 0; // entries every solver array holds behind its pointer: max(plain layout + guard, brick layout)
     int *brickList = nullptr, *brickFlag = nullptr;   // active bricks of the current solve (linear brick ids, x fastest), flags of the box's bricks
     size_t brickCap = 0;

@@ -549,14 +549,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
     if (c->comm && c->comm->nranks > 1) {   // a rank whose box holds no viscous node must still take part in every collective of the solve
-        float f = c->viscosity_nonzero ? 1.0f : 0.0f;
-        const int rcv = fv_allreduce_max_f32(c, &f);
+        const double mine[2] = {c->viscosity_nonzero ? 1.0 : 0.0, (double)c->viscosity_max};   // (AUTO's stiffness rule must come out the same on every rank)
+        double all[2 * NSLOT];
+        const int rcv = fv_allgather_f64(c, mine, 2, all);
         if (rcv) return rcv;
-        c->viscosity_nonzero_any = f > 0.0f;
-        float vm = c->viscosity_max;   // (AUTO's stiffness rule must come out the same on every rank)
-        const int rcm = fv_allreduce_max_f32(c, &vm);
-        if (rcm) return rcm;
-        c->viscosity_max_any = vm;
+        double nz = 0.0, vm = all[1];
+        for (int r = 0; r < c->comm->nranks; r++) { nz = fmax(nz, all[2 * r]); vm = fmax(vm, all[2 * r + 1]); }
+        c->viscosity_nonzero_any = nz > 0.0;
+        c->viscosity_max_any = (float)vm;
     } else { c->viscosity_nonzero_any = c->viscosity_nonzero; c->viscosity_max_any = c->viscosity_max; }
     if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
         li.status = 3;
@@ -613,7 +613,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // after the set-up kernel has counted the rows, so the set-up runs in the previous solve's layout and is repeated on the rare solve
     // where the choice changes.
     const int forcedLayout = c->prm.viscosity_layout;   // 0 auto, 1 plain, 2 plain / swizzled, 3 brick
-    const bool brickOk = !c->comm && !c->isBlock && c->prm.viscosity_lane_width != 2 && forcedLayout != 1 && forcedLayout != 2;
+    const bool brickOk = c->prm.viscosity_lane_width != 2 && forcedLayout != 1 && forcedLayout != 2;   // (block contexts too: the halo exchange addresses either layout, flipv_comm.h: HaloArray::lay)
     const bool swzOk = forcedLayout != 1;   // (also under the multigrid: its own kernels address diag / x / r / q / own volumes through sidx, its sweep vectors stay plain)
     // the preconditioner of this solve (the multigrid needs fp32 vectors over a whole, single-rank index space)
     const bool mgPossible = std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && !c->vNoMultigridOnce;   // (block contexts too: a rank-local hierarchy, k_viscosity_mg.hip)
@@ -690,10 +690,25 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     if ((rc = run_setup(layoutTry, true))) return rc;
     // Lane width of the tile kernels: 4 consecutive i per lane (16-byte accesses); 2 stays selectable for measurements.
     // Sparse liquids (row fill <= 0.35): bricks where possible, the load-predicated tile SpMV otherwise.
-    const double fill = (double)c->h_flags[2] / (3.0 * (double)(L.ohi[0] - L.olo[0]) * (double)(L.ohi[1] - L.olo[1]) * (double)(L.ohi[2] - L.olo[2]));
+    const double ownVol = (double)(L.ohi[0] - L.olo[0]) * (double)(L.ohi[1] - L.olo[1]) * (double)(L.ohi[2] - L.olo[2]);
+    const double fillLocal = (double)c->h_flags[2] / (3.0 * ownVol);
+    // Several ranks: ONE exchange carries what every rank must decide alike from -- max|rhs| (the tolerance), the row count and the owned volume
+    // (the layout: a rank that took planes where another took bricks would run a different sequence of collectives; and "no rows anywhere").
+    double fill = fillLocal, rowsAll = (double)c->h_flags[2];
+    if (c->comm) {
+        const double mine[3] = {c->h_scal[0], (double)c->h_flags[2], ownVol};
+        double all[3 * NSLOT];
+        if ((rc = fv_allgather_f64(c, mine, 3, all))) return rc;
+        double bn = 0.0, rows = 0.0, vol = 0.0;
+        for (int r = 0; r < c->comm->nranks; r++) { bn = fmax(bn, all[3 * r]); rows += all[3 * r + 1]; vol += all[3 * r + 2]; }
+        c->h_scal[0] = bn;
+        rowsAll = rows;
+        fill = rows / (3.0 * vol);
+    }
+    const double bnormAll = c->h_scal[0];
     c->vwV = 4;
     if (c->prm.viscosity_lane_width == 2 || c->prm.viscosity_lane_width == 4) c->vwV = c->prm.viscosity_lane_width;  // measurement switch: forced lane width
-    c->vPred = fill <= 0.35;
+    c->vPred = fillLocal <= 0.35;   // (the plane kernels' load predication is the rank's own business)
     const bool wantBrick = brickOk && (forcedLayout == 3 || fill <= (c->vLayout == VLAYOUT_BRICK ? 0.40 : 0.30));   // (hysteresis around 0.35)
     if (wantBrick != (c->vLayout == VLAYOUT_BRICK)) {
         if ((rc = run_setup(wantBrick ? VLAYOUT_BRICK : ((swzOk && rowlNow == 16) ? VLAYOUT_SWZ : VLAYOUT_PLAIN), false))) return rc;
@@ -701,7 +716,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool brick = c->vLayout == VLAYOUT_BRICK;
     if (brick) {
         if ((rc = fv_build_bricks(c, R0))) return rc;
-        c->nActiveV = c->nBricks; c->nIntV = c->nBricks; c->nRunsV = 0;
+        c->nActiveV = c->nBricks; c->nIntV = c->comm ? 0 : c->nBricks; c->nRunsV = 0;   // (under a communicator the brick SpMV is one launch AFTER the halo exchange: no interior / cut-face split of the brick list)
     } else {
         rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3, &c->mlistV, &c->mlistCapV);
         if (rc) return rc;
@@ -711,12 +726,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         }
     }
     PcgSys<T, 3> v = visc_sys<T>(c);
-    if (c->comm) {
-        float bn = (float)c->h_scal[0];
-        if ((rc = fv_allreduce_max_f32(c, &bn))) return rc;
-        c->h_scal[0] = (double)bn;
-    }
-    const double bnorm = c->h_scal[0];
+    const double bnorm = bnormAll;   // (a repeated set-up recomputes the rank's own maximum: the merged one stands)
     li.rhs_norm = bnorm;
     li.rows = c->h_flags[2];
     li.active_tiles = c->nActiveV;
@@ -733,7 +743,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     int anyActive = c->nActiveV;
     // residual replacement (k_viscosity_brick.hip): fp32 vectors in the brick layout
     int replacePeriod = 0;
-    if (brick && std::is_same<T, float>::value && c->prm.residual_replacement > 0) replacePeriod = c->prm.residual_replacement;   // opt-in (flipv.h)
+    if (brick && !c->comm && std::is_same<T, float>::value && c->prm.residual_replacement > 0) replacePeriod = c->prm.residual_replacement;   // opt-in (flipv.h; single-domain contexts)
     // The reference's operator (exact_viscosity_operator = 0, the default) under the multigrid, fp32 vectors, brick layout: DEFECT CORRECTION.
     // A_ref = A + E, E the rounding defect of the reference's float diagonal (d_ref_volume): |E| ~ 1e-3 of what a row does to a near-rigid
     // motion, enough to make the near-rigid modes of small liquid clusters (own volumes of the size of the defect) nearly indefinite.  PCG
@@ -753,7 +763,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool canRefine = brick && std::is_same<T, float>::value;
     const bool staged = canRefine && refDiag;
     const bool useAcc = canRefine;
-    if (c->comm) { float f = (float)anyActive; if ((rc = fv_allreduce_max_f32(c, &f))) return rc; anyActive = (int)f; }
+    if (c->comm) anyActive = rowsAll > 0.0 ? 1 : 0;   // (rows somewhere = an active tile / brick somewhere)
     const bool nontrivial = !(bnorm == 0.0 || anyActive == 0);
     if (!nontrivial) {  // pcgsolver.h:254-258: zero rhs -> zero solution, success
         success = true;
@@ -764,7 +774,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         int nb = pcg_grid(c, c->nActiveV);
         if (c->prm.viscosity_update_grid_cap > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.viscosity_update_grid_cap) nb = c->prm.viscosity_update_grid_cap; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
         const dim3 blk(64, 4, 1);
-        const HaloArray sh[3] = {{c->vS[0], sizeof(T)}, {c->vS[1], sizeof(T)}, {c->vS[2], sizeof(T)}};
+        const int hl = brick ? 1 : 0;
+        const HaloArray sh[3] = {{c->vS[0], sizeof(T), hl}, {c->vS[1], sizeof(T), hl}, {c->vS[2], sizeof(T), hl}};
         const bool useMg = mgPlanned && c->vwV == 4;
         li.preconditioner = useMg ? 1 : 0;
         ranMg = useMg;
@@ -803,7 +814,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
         auto recompute_residual = [&]() -> int {
-            fv_brick_refine<T>(c, sc, scalBytes, !refDiag);
+            { const int rcr = fv_brick_refine<T>(c, sc, scalBytes, !refDiag); if (rcr) return rcr; }   // (several ranks: with the accumulator's halo copy and the all-reduce of max|r|)
             refinements++;
             hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, 0, bmax);
             HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -839,6 +850,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             if ((rc = fv_viscosity_pcg_mg(c, sc, capNow, mgspmv, replacePeriod, itersDone > 0 ? 1 : 0, &conv))) return rc;
         } else if (brick) {
             fv_brick_init<T>(c, sc);
+            if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
             auto spmv = [&](int, int, int it) { fv_brick_spmv<T>(c, sc, it, !sc.noB); };
             auto update = [&](int it) { fv_brick_update<T>(c, sc, it); };
             auto post = [&](int it) { fv_brick_replace<T>(c, sc, it, replacePeriod, 1, nullptr, 0.0f); };

@@ -495,19 +495,25 @@ template void fv_brick_replace<double>(flipv_context *, const PcgScal &, int, in
 // outerExact: which operator the recomputed residual belongs to -- the exact one, or the reference's float-rounded one (the operator the
 // SOLVE is for; the PCG loop in between may run on the exact operator, see viscosity_solve_t)
 template <typename T>
-void fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact) {
+int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact) {
     const BrickSys<T> v = brick_sys<T>(c);
     const float *const vo[3] = {outerExact ? c->vmU : c->vrU, outerExact ? c->vmV : c->vrV, outerExact ? c->vmW : c->vrW};
     const dim3 b(64, 4, 1);
     hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0);
     (void)hipMemsetAsync(sc.base, 0, scalBytes, c->stream);   // bank 0's slot blocks (the extra scalars behind them stay), then the other banks
     if (sc.nbank > 1) (void)hipMemsetAsync(sc.base + sc.bstride, 0, (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double), c->stream);
+    if (c->comm) {   // the residual's stencil reads the neighbours' accumulated solution across the cuts
+        const HaloArray xa[3] = {{c->vXacc[0], sizeof(double), 1}, {c->vXacc[1], sizeof(double), 1}, {c->vXacc[2], sizeof(double), 1}};
+        const int rc = fv_halo_copy(c, xa, 3, 1);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL((k_bresidual<T>), dim3(spmv_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v,
                        (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1],
                        (const float *)c->vB[2], (float *)nullptr, (float *)nullptr, (float *)nullptr, 0.0f, sc, 0, 0, 0, 1);
+    return fv_allreduce_scalars(c, sc.rmax(0), NSLOT);   // (ranks write disjoint slots: the sum merges their maxima)
 }
-template void fv_brick_refine<float>(flipv_context *, const PcgScal &, size_t, bool);
-template void fv_brick_refine<double>(flipv_context *, const PcgScal &, size_t, bool);
+template int fv_brick_refine<float>(flipv_context *, const PcgScal &, size_t, bool);
+template int fv_brick_refine<double>(flipv_context *, const PcgScal &, size_t, bool);
 
 // x (+ xacc) -> velocity grid over the launch box R
 template <typename T>

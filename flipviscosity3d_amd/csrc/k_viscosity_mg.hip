@@ -473,7 +473,7 @@ __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const
             for (int b = 0; b < 2; b++) {
                 int q[3];
                 q[C] = 2 * P[C] + dn; q[t1] = 2 * P[t1] + a; q[t2] = 2 * P[t2] + b;
-                if (d_in_lattice(F, C, q) && (FINE0 != 1 || d_owned(F, q[0], q[1], q[2])))   // (level 0 of a block context: only the rank's own indices are rows -- or allocated at all)
+                if (d_in_lattice(F, C, q) && (FINE0 == 0 || d_owned(F, q[0], q[1], q[2])))   // (level 0 of a block context, either layout: only the rank's own indices are rows -- or allocated at all; the halo holds the NEIGHBOURS' residuals)
                     s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][FINE0 == 1 ? gidx(F, q[0], q[1], q[2]) : (FINE0 == 2 ? bidx(F, q[0], q[1], q[2]) : cidx(F, q[0], q[1], q[2]))];
             }
     return s;
@@ -1369,7 +1369,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     // applies: the exact one, or the reference's float-rounded one (vr*, k_viscosity.hip: d_ref_volume) -- the defect is a diagonal term
     // and goes through the Galerkin product like the volume itself.
     if (s->globalFrom == 0) {   // the neighbours' row masks one entry into the halo: a fine row at a cut face then carries its entries across the cut into the Galerkin sums
-        const HaloArray hm[1] = {{brick ? (void *)c->vMaskB : (void *)c->vRowMask, 1}};
+        const HaloArray hm[1] = {{brick ? (void *)c->vMaskB : (void *)c->vRowMask, 1, brick ? 1 : 0}};
         if ((rc = fv_halo_copy(c, hm, 1, 1))) return rc;
     }
     if (!s->lev.empty()) {
@@ -1435,9 +1435,10 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         }
         s->listRhs = true;
         if (s->globalFrom >= 0 && s->globalFrom < s->tailFirst) {   // the list-shaped right-hand-side exchange needs the same list on every rank
-            float hi = (float)counts[s->globalFrom], lo = -(float)counts[s->globalFrom];
-            if ((rc = fv_allreduce_max_f32(c, &hi)) || (rc = fv_allreduce_max_f32(c, &lo))) return rc;
-            s->listRhs = hi == -lo;   // (otherwise: the box-shaped exchange)
+            const double mine[1] = {(double)counts[s->globalFrom]};
+            double all[NSLOT];
+            if ((rc = fv_allgather_f64(c, mine, 1, all))) return rc;
+            for (int r = 0; r < c->comm->nranks; r++) if (all[r] != mine[0]) s->listRhs = false;   // (then: the box-shaped exchange)
         }
         for (size_t l = 0; l < s->lev.size(); l++) {
             s->lev[l].nstrips = (int)l < s->tailFirst ? counts[l] : 0;
@@ -1472,7 +1473,8 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
     float *dg[3] = {c->vDiagU, c->vDiagV, c->vDiagW};
     const int *conv = sc.conv;
     // with the global hierarchy the fine level is the single domain's too: every sweep reads its input with the neighbours' current values
-    auto halo3 = [&](float *const v[3]) { if (s->globalFrom == 0 && !s->rc) { const HaloArray h[3] = {{v[0], sizeof(float)}, {v[1], sizeof(float)}, {v[2], sizeof(float)}}; s->rc = fv_halo_copy(c, h, 3, 1); } };
+    const int hl = brick ? 1 : 0;   // (HaloArray::lay)
+    auto halo3 = [&](float *const v[3]) { if (s->globalFrom == 0 && !s->rc) { const HaloArray h[3] = {{v[0], sizeof(float), hl}, {v[1], sizeof(float), hl}, {v[2], sizeof(float), hl}}; s->rc = fv_halo_copy(c, h, 3, 1); } };
     halo3(s->za);
     fv_visc_sweep_f32(c, s->za, s->zb, 1, sc, it_spmv, s->w[1], 0);                         // second pre-sweep: za -> zb
     if (!s->lev.empty()) {
@@ -1572,7 +1574,8 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     // hierarchy), or, with flipv_params.multigrid_rank_local, a cycle over the rank's OWN rows with the couplings across the cut faces dropped
     // (its sweep vectors are zero on the halo) and no exchange -- a block-diagonal, symmetric positive definite preconditioner, like the
     // pressure multigrid's.  Either way the CG around it applies the true operator (halo copy of p before the SpMV) and all-reduces its scalars.
-    const HaloArray ph[3] = {{p[0], sizeof(float)}, {p[1], sizeof(float)}, {p[2], sizeof(float)}};
+    const int hl = brick ? 1 : 0;
+    const HaloArray ph[3] = {{p[0], sizeof(float), hl}, {p[1], sizeof(float), hl}, {p[2], sizeof(float), hl}};
     XR(-1);                       // za = omega r/d
     vmg_vcycle(c, s, sc, 0, 0);   // z, sig(0)
     if (s->rc) return s->rc;
