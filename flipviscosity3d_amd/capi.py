@@ -59,6 +59,8 @@ class Params(C.Structure):
                 ("viscosity_update_grid_cap", C.c_int), ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int),
                 ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
                 ("multigrid_rank_local", C.c_int),
+                ("viscosity_stage1_factor", C.c_float), ("viscosity_stage2_factor", C.c_float), ("viscosity_stage2_max_iterations", C.c_int),
+                ("viscosity_stage2_rounds", C.c_int), ("viscosity_two_stage_max_stiffness", C.c_float),
                 ("reserved", C.c_int * 1)]
 
 LAYOUT_AUTO, LAYOUT_PLAIN, LAYOUT_SWIZZLED, LAYOUT_BRICK = 0, 1, 2, 3
@@ -68,7 +70,8 @@ PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID = 0, 1, 2
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("rhs_norm", C.c_double),
                 ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
-                ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int), ("defect_residual", C.c_double)]
+                ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int), ("defect_residual", C.c_double),
+                ("correction_iterations", C.c_int), ("correction_status", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -167,5 +167,6 @@ template <typename T> void fv_brick_init(flipv_context *c, const PcgScal &sc);
 template <typename T> void fv_brick_update(flipv_context *c, const PcgScal &sc, int it);
 void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);
 template <typename T> void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int period, int withSigma, float *const z[3], float omega);
-template <typename T> int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact);
+template <typename T> int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact, int flushMode = 0);
+template <typename T> void fv_brick_flush_settle(flipv_context *c, const PcgScal &sc, bool takeBack);
 template <typename T> void fv_brick_writeback(flipv_context *c, const Lay &R, int m, bool withAcc, float *dst);

@@ -366,6 +366,36 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
     }
     for (int r = 0; r < 1; r++)
         if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
+    // every field has an error path: nothing out of range is silently ignored or used as given
+    {
+        const char *bad = nullptr;
+        auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+        auto fin = [](float v, float lo, float hi) { return v >= lo && v <= hi; };   // (false for NaN)
+        if (!(p->min_frac > 0.0f && p->min_frac <= 1.0f)) bad = "min_frac";
+        else if (!fin(p->pic_ratio, 0.0f, 1.0f)) bad = "pic_ratio";
+        else if (!in(p->extrapolation_layers, 0, 64)) bad = "extrapolation_layers";
+        else if (!(p->pressure_tolerance >= 0.0) || !(p->pressure_rel_tolerance >= 0.0) || !(p->viscosity_tolerance > 0.0) || !(p->viscosity_accept_tolerance >= 0.0)) bad = "a tolerance";
+        else if (!in(p->kernel_timing, 0, 1) || !in(p->check_every, 0, 4096)) bad = "kernel_timing / check_every";
+        else if (!in(p->pressure_preconditioner, 0, 2) || !in(p->viscosity_preconditioner, 0, 2)) bad = "a preconditioner";
+        else if (!in(p->exact_viscosity_operator, 0, 1)) bad = "exact_viscosity_operator";
+        else if (!in(p->residual_replacement, 0, 1 << 20)) bad = "residual_replacement";
+        else if (!in(p->viscosity_layout, 0, 3)) bad = "viscosity_layout";
+        else if (p->tile_rows != 0 && p->tile_rows != 16 && p->tile_rows != 64) bad = "tile_rows";
+        else if (!in(p->viscosity_mg_coarsest_sweeps, 0, 1024) || !in(p->pressure_mg_coarsest_sweeps, 0, 1024)) bad = "a coarsest-level sweep count";
+        else if (!in(p->viscosity_mg_min_dim, 0, 4096)) bad = "viscosity_mg_min_dim";
+        else if (!fin(p->pressure_mg_omega, 0.0f, 2.0f) || !fin(p->pressure_mg_overcorrection, 0.0f, 4.0f)) bad = "pressure_mg_omega / pressure_mg_overcorrection";
+        else if (!fin(p->viscosity_mg_omega_first, 0.0f, 2.0f) || !fin(p->viscosity_mg_omega_second, 0.0f, 2.0f)) bad = "viscosity_mg_omega_*";
+        else if (!in(p->no_liquid_box, 0, 1) || !in(p->no_comm_overlap, 0, 1) || !in(p->verbose, 0, 2) || !in(p->no_graph_replay, 0, 1) || !in(p->unbinned_scatter, 0, 1) ||
+                 !in(p->beta_from_conjugacy, 0, 1) || !in(p->multigrid_rank_local, 0, 1)) bad = "a 0/1 switch";
+        else if (!in(p->grid_cap, 0, 1 << 20) || !in(p->viscosity_spmv_grid_cap, 0, 1 << 20) || !in(p->viscosity_update_grid_cap, 0, 1 << 20)) bad = "a grid cap";
+        else if (p->viscosity_lane_width != 0 && p->viscosity_lane_width != 2 && p->viscosity_lane_width != 4) bad = "viscosity_lane_width";
+        else if (!in(p->spmv_run_length, -1, 64) || p->spmv_run_length == 1) bad = "spmv_run_length";
+        else if (!(p->viscosity_stage1_factor == 0.0f || fin(p->viscosity_stage1_factor, 1.0f, 1e6f))) bad = "viscosity_stage1_factor (0 or >= 1)";
+        else if (!fin(p->viscosity_stage2_factor, 0.0f, 1.0f)) bad = "viscosity_stage2_factor";
+        else if (!in(p->viscosity_stage2_max_iterations, 0, 1 << 20) || !in(p->viscosity_stage2_rounds, 0, 16)) bad = "viscosity_stage2_max_iterations / viscosity_stage2_rounds";
+        else if (!(p->viscosity_two_stage_max_stiffness >= 0.0f)) bad = "viscosity_two_stage_max_stiffness";
+        if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
+    }
     c->prm = *p;
     return FLIPV_OK;
 }

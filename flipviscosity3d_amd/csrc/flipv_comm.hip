@@ -4,6 +4,7 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 
@@ -490,13 +491,19 @@ struct LocalGroup {
     std::vector<std::vector<Op>> ops;
     std::vector<std::vector<double>> red;
     std::vector<std::vector<float>> redf;
-    void wait() {
+    bool broken = false;
+    // false: a rank did not arrive within two minutes (it left its substep with an error, or took another sequence of collectives): the group is
+    // marked broken and every later rendezvous fails at once -- the verification backend reports FLIPV_ERR_COMM instead of hanging the process
+    bool wait() {
         std::unique_lock<std::mutex> lk(m);
+        if (broken) return false;
         const unsigned long long g = generation;
-        if (++arrived == n) { arrived = 0; generation++; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g; });
+        if (++arrived == n) { arrived = 0; generation++; cv.notify_all(); return true; }
+        if (!cv.wait_for(lk, std::chrono::seconds(120), [&] { return generation != g || broken; }) || broken) { broken = true; cv.notify_all(); return false; }
+        return true;
     }
 };
+#define LOCAL_WAIT(c_)  do { if (!g->wait()) { (c_)->err = "local comm: a rank did not arrive at the rendezvous (timeout): another rank failed or took a different sequence of collectives"; return FLIPV_ERR_COMM; } } while (0)
 
 struct LocalComm : Comm {
     LocalGroup *g = nullptr;
@@ -514,7 +521,7 @@ struct LocalComm : Comm {
     int end(flipv_context *c) override {
         HIPCHK(c, hipStreamSynchronize(c->xs));  // my send buffers are complete
         g->ops[rank] = mine;
-        g->wait();
+        LOCAL_WAIT(c);
         // pull: my m-th operation towards peer p matches p's m-th operation towards me
         std::vector<int> seen((size_t)g->n, 0);
         int rc = FLIPV_OK;
@@ -530,7 +537,7 @@ struct LocalComm : Comm {
             }
         }
         if (hipStreamSynchronize(c->xs) != hipSuccess) rc = FLIPV_ERR_HIP;
-        g->wait();  // everybody has read: send buffers may be reused
+        LOCAL_WAIT(c);  // everybody has read: send buffers may be reused
         return rc;
     }
     int allreduce_sum(flipv_context *c, double *dev, size_t n) override {
@@ -538,11 +545,11 @@ struct LocalComm : Comm {
         h.resize(n);
         HIPCHK(c, hipMemcpyAsync(h.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        g->wait();
+        LOCAL_WAIT(c);
         std::vector<double> sum(n, 0.0);
         for (int r = 0; r < g->n; r++)
             for (size_t t = 0; t < n; t++) sum[t] += g->red[r][t];
-        g->wait();  // everybody has read every contribution
+        LOCAL_WAIT(c);  // everybody has read every contribution
         HIPCHK(c, hipMemcpyAsync(dev, sum.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return FLIPV_OK;
@@ -552,20 +559,20 @@ struct LocalComm : Comm {
         h.resize(n);
         HIPCHK(c, hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        g->wait();
+        LOCAL_WAIT(c);
         std::vector<float> sum(g->redf[0]);   // rank order on every rank: bitwise the same result everywhere
         for (int r = 1; r < g->n; r++) {
             const float *q = g->redf[r].data();
             for (size_t t = 0; t < n; t++) sum[t] += q[t];
         }
-        g->wait();  // everybody has read every contribution
+        LOCAL_WAIT(c);  // everybody has read every contribution
         HIPCHK(c, hipMemcpyAsync(dev, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         return FLIPV_OK;
     }
     int barrier(flipv_context *c) override {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        g->wait();
+        LOCAL_WAIT(c);
         return FLIPV_OK;
     }
 };

@@ -270,7 +270,7 @@ struct flipv_context {
     void *vmgState;      // viscosity multigrid hierarchy (k_viscosity_mg.hip), created on first use
     // executables of the PCG loops' captured graphs, kept between solves: a new capture with the same topology updates the cached
     // executable in place (hipGraphExecUpdate) instead of instantiating a new one.  Slots: FV_GE_*
-    hipGraphExec_t geCache[4];
+    hipGraphExec_t geCache[6];
     unsigned *surfList;  // indices whose control volumes need the sampling path (+ the counter at [L.n]); allocated on first use
 
     // kernel timing
@@ -482,7 +482,7 @@ __device__ __forceinline__ int d_tile_slot(int b, int n) {
 // ---------------------------------------------------------------------------------------------
 // cross-file entry points (host side)
 // ---------------------------------------------------------------------------------------------
-enum { FV_GE_VISCOSITY = 0, FV_GE_PRESSURE = 1, FV_GE_PRESSURE_MG = 2, FV_GE_VISCOSITY_MG = 3 };
+enum { FV_GE_VISCOSITY = 0, FV_GE_PRESSURE = 1, FV_GE_PRESSURE_MG = 2, FV_GE_VISCOSITY_MG = 3, FV_GE_VISCOSITY_MID = 4, FV_GE_PRESSURE_MID = 5 };
 void fv_mg_free(flipv_context *c);
 void fv_vmg_free(flipv_context *c);
 int fv_particle_sdf(flipv_context *c);

@@ -325,6 +325,10 @@ struct MgState {
     double *d_gbox = nullptr;    // 6 doubles per rank
     CutBox gbox;                 // this solve's box of level-1 cells with a row, over all ranks
     int rc = 0;                  // a communication error inside the V-cycle
+    // global hierarchy: what follows the right-hand-side all-reduce of a V-cycle is kernels only (~12 small launches): captured once per solve and
+    // replayed every iteration (the executable lives in flipv_context::geCache)
+    hipGraphExec_t midExec = nullptr;
+    bool midReady = false;
     ~MgState() { for (void *p : allocs) (void)hipFree(p); if (stage) (void)hipFree(stage); }
 };
 
@@ -364,8 +368,13 @@ static int mg_allreduce_box(flipv_context *c, MgState *s, const Lay &L, const Pt
     hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, arr, s->stage, 0);
     const int rc = fv_allreduce_f32(c, s->stage, tot);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, into, s->stage, 1);
+    if (into.p[0]) hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, into, s->stage, 1);   // (no target: the caller unpacks, mg_box_take)
     return FLIPV_OK;
+}
+static void mg_box_take(flipv_context *c, MgState *s, const Lay &L, const Ptr4 &into, int narr) {
+    const CutBox &B = s->gbox;
+    const size_t n = (size_t)(B.hi[0] - B.lo[0]) * (B.hi[1] - B.lo[1]) * (B.hi[2] - B.lo[2]);
+    hipLaunchKernelGGL(k_mg_box_pack, dim3((unsigned)((n + 255) / 256), (unsigned)narr), dim3(256), 0, c->stream, L, B, into, s->stage, 1);
 }
 
 // The level structure (allocated once per context) and this substep's coarse operators.
@@ -488,6 +497,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
         }
     }
     HIPCHK(c, hipGetLastError());
+    s->midReady = false;   // (this solve's tile list, launch boxes and staging buffer: the V-cycle's captured segment is cut anew)
     *out = s;
     return FLIPV_OK;
 }
@@ -499,41 +509,62 @@ static void mg_vcycle(flipv_context *c, MgState *s, const PcgScal &sc, int it_ne
     const int t0 = s->tailFirst;  // levels [t0, nl) run inside k_mg_tail
     CutBox cut;   // level 0: couplings across these faces are dropped (the rank's cells; the whole domain under the global hierarchy)
     for (int a = 0; a < 3; a++) { cut.lo[a] = s->global ? 0 : s->lev[0].L.olo[a]; cut.hi[a] = s->global ? (a == 0 ? c->L.I : (a == 1 ? c->L.J : c->L.K)) : s->lev[0].L.ohi[a]; }
-    for (int l = 0; l < t0; l++) {  // down: level l -> right-hand side of level l+1
-        const MgLevel &F = s->lev[l];
-        const MgLevel &C = s->lev[l + 1];
-        if (l == 0) {  // x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
-            // (bacc: zero on entry to the solve, then k_mg_up0 clears what k_mg_down0 filled)
-            if (s->global) {   // the neighbours' x0 on the halo entries: level 0's sweeps are the single domain's
-                const HaloArray hx[1] = {{F.x, sizeof(float)}};
-                if ((s->rc = fv_halo_copy(c, hx, 1, 1))) return;
-            }
-            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, cut, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, s->bacc));
-            if (s->global) {   // level 1's right-hand side = the sum of the ranks' shares (bacc stays the rank's own: k_mg_up0 clears exactly what it filled)
-                const Ptr4 from = {{s->bacc, nullptr, nullptr, nullptr}}, to = {{C.b, nullptr, nullptr, nullptr}};
-                if ((s->rc = mg_allreduce_box(c, s, C.L, from, to, 1))) return;
-            }
-        } else {  // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
+    const bool sums = s->global && t0 > 0;   // level 1's right-hand side is summed over the ranks
+    if (t0 > 0) {  // level 0 -> right-hand side of level 1: x0 is in F.x already (k_mgp_xr); the residual goes straight into the coarse right-hand side
+        const MgLevel &F = s->lev[0];
+        const MgLevel &C = s->lev[1];
+        // (bacc: zero on entry to the solve, then k_mg_up0 clears what k_mg_down0 filled)
+        if (s->global) {   // the neighbours' x0 on the halo entries: level 0's sweeps are the single domain's
+            const HaloArray hx[1] = {{F.x, sizeof(float)}};
+            if ((s->rc = fv_halo_copy(c, hx, 1, 1))) return;
+        }
+        GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_down0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, cut, F.diag, F.pi,
+                           F.pj, F.pk, c->pMask, F.x, F.b, s->bacc));
+        if (sums) {   // level 1's right-hand side = the sum of the ranks' shares (bacc stays the rank's own: k_mg_up0 clears exactly what it filled)
+            const Ptr4 from = {{s->bacc, nullptr, nullptr, nullptr}}, none = {{nullptr, nullptr, nullptr, nullptr}};
+            if ((s->rc = mg_allreduce_box(c, s, C.L, from, none, 1))) return;
+        }
+    }
+    // everything after the all-reduce: kernels only
+    auto rest = [&]() {
+        if (sums) { const Ptr4 to = {{s->lev[1].b, nullptr, nullptr, nullptr}}; mg_box_take(c, s, s->lev[1].L, to, 1); }
+        for (int l = 1; l < t0; l++) {  // down: level l -> right-hand side of level l+1
+            const MgLevel &F = s->lev[l];
+            const MgLevel &C = s->lev[l + 1];
+            // (a fused sweep, one thread per coarse cell walking its eight children, measured 23 us against 14 for the pair)
             const Lay &Fr = s->range[l];
             const Lay &Cr = l + 1 < t0 ? s->range[l + 1] : C.L;   // the first level of the tail is swept whole: its right-hand side is written everywhere
             hipLaunchKernelGGL(k_mg_pre, MGGRID(Fr), 0, c->stream, Fr, F.diag, F.pi, F.pj, F.pk, F.b, F.x, F.t);
             hipLaunchKernelGGL(k_mg_restrict, MGGRID(Cr), 0, c->stream, Fr, Cr, F.t, C.b);
         }
+        MgTail T;
+        T.n = nl - t0;
+        for (int l = t0; l < nl; l++) T.lev[l - t0] = s->lev[l];
+        hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, c->stream, T);
+        for (int l = t0 - 1; l >= 0; l--) {
+            const MgLevel &F = s->lev[l];
+            const MgLevel &C = s->lev[l + 1];
+            if (l == 0)
+                GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, cut, F.diag, F.pi,
+                                   F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, s->bacc, sc, it_next));
+            else
+                hipLaunchKernelGGL(k_mg_up, MGGRID(s->range[l]), 0, c->stream, s->range[l], C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
+        }
+    };
+    // replayed only where the iteration number is the device-side counter (the loop under a communicator passes IT_DEVICE from its first iteration on)
+    const bool replay = sums && it_next == IT_DEVICE && !c->prm.kernel_timing && !c->prm.no_graph_replay;
+    if (replay && !s->midReady) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            rest();
+            const hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+            s->midReady = e2 == hipSuccess && g && fv_graph_exec(c, FV_GE_PRESSURE_MID, g, &s->midExec) == FLIPV_OK;
+            if (!s->midReady) { s->midExec = nullptr; (void)hipGetLastError(); }
+            if (g) (void)hipGraphDestroy(g);
+        } else (void)hipGetLastError();
     }
-    MgTail T;
-    T.n = nl - t0;
-    for (int l = t0; l < nl; l++) T.lev[l - t0] = s->lev[l];
-    hipLaunchKernelGGL(k_mg_tail, dim3(1), dim3(1024), 0, c->stream, T);
-    for (int l = t0 - 1; l >= 0; l--) {
-        const MgLevel &F = s->lev[l];
-        const MgLevel &C = s->lev[l + 1];
-        if (l == 0)
-            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mg_up0, dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListP, c->nActiveP, c->tgP, F.L, C.L, cut, F.diag, F.pi,
-                               F.pj, F.pk, c->pMask, F.x, F.b, C.t, F.t, s->bacc, sc, it_next));
-        else
-            hipLaunchKernelGGL(k_mg_up, MGGRID(s->range[l]), 0, c->stream, s->range[l], C.L, F.diag, F.pi, F.pj, F.pk, F.b, F.x, C.t, F.t);
-    }
+    if (replay && s->midReady) { if (hipGraphLaunch(s->midExec, c->stream) != hipSuccess) { s->rc = FLIPV_ERR_HIP; c->err = "pressure multigrid: hipGraphLaunch of the coarse segment failed"; } }
+    else rest();
 }
 
 // PCG with the V-cycle as preconditioner.  On entry the setup kernel has left r = b, x = 0 and the tile list; the
@@ -590,17 +621,22 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
         *conv_out = conv;
         return FLIPV_OK;
     }
+    // Under a communicator the kernels read the DEVICE-side iteration counter too (the host's `it` only addresses the slot blocks its all-reduces sum:
+    // the two agree as long as the solve runs, and nothing is looked at once it has stopped), so that the V-cycle's kernel-only segment can be a
+    // replayed graph (mg_vcycle).  Per-launch event timing keeps the explicit iteration numbers.
+    const bool devIt = c->comm && !c->prm.kernel_timing && !c->prm.no_graph_replay;
+    if (devIt) HIPCHK(c, hipMemsetAsync(sc.itA, 0, 2 * sizeof(int), c->stream));
     while (it < cap && conv < 0) {
         const int stop = it + every < cap ? it + every : cap;
         for (; it < stop; it++) {
             if ((rc = fv_halo_copy(c, ph, 1, 1))) return rc;                                   // p on the neighbours' boundary planes
-            spmv(c, sc, it);
+            spmv(c, sc, devIt ? -1 : it);
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.a(it), NSLOT))) return rc;          // p.q
-            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, it));
-            mg_vcycle(c, s, sc, it + 1);
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, devIt ? IT_DEVICE : it));
+            mg_vcycle(c, s, sc, devIt ? IT_DEVICE : it + 1);
             if (s->rc) return s->rc;
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;   // max|r| of this iteration, (r,z) of the next
-            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, it));
+            GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, devIt ? IT_DEVICE : it));
         }
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -165,8 +165,17 @@ __global__ void k_volume_classify(Lay L, VolLattices Q, const float *__restrict_
     }
 }
 
-// Pass 2: _estimateVolumeFractions (viscositysolver.cpp:180-270) for the listed indices, one thread per (index, lattice)
-__global__ void k_volume_sample(Lay L, VolLattices Q, const float *__restrict__ phi, const unsigned *__restrict__ list,
+// Pass 2: _estimateVolumeFractions (viscositysolver.cpp:180-270) for the listed indices, one thread per (index, lattice).
+// The reference MEMOISES the liquid phi at the corner nodes of a lattice's cubes (nodalPhi / isNodalSet, :184-252): a node's value is the one its
+// FIRST visitor computed -- the first band cube in the k-j-i scan that has the node as a corner -- at the position THAT cube derives for it,
+// centre(i', j', k') + (+-hdx, +-hdx, +-hdx) in float.  The eight cubes around a node derive positions that differ in the last bit, phi there by ~1e-8,
+// a control volume by up to 7e-6 -- and, where a corner's phi is within that of zero, the cube's classification (all corners >= 0 -> volume exactly 0):
+// a face whose seven volumes are all zero is no row (:284-354).  On the rod + sheet scene at nu dt/dx^2 = 1.3e5 (tests/golden/honey96_nu1422) evaluating
+// every corner from the cube's own centre, as this kernel did until round 4, gave a handful of rows the reference does not have -- slivers of
+// volume 1e-20 that keep their free-fall velocity, 100 % off -- and 3e-4 in the end-of-substep velocities whatever the solver did.  So the corner's
+// position is the first visitor's, found from the band mask of the 27 cubes around the index: volumes, and with them the row set, are the
+// reference's bit for bit.
+__global__ void k_volume_sample(Lay L, VolLattices Q, const float *__restrict__ phi, const uint8_t *__restrict__ valid, const unsigned *__restrict__ list,
                                 const unsigned *__restrict__ nlist, float dxf) {
     const unsigned n = *nlist;
     const double dx = (double)dxf, invdx = 1.0 / dx, hw = 0.5 * dx;
@@ -179,12 +188,37 @@ __global__ void k_volume_sample(Lay L, VolLattices Q, const float *__restrict__ 
         int w, h, d;
         lat_dims(L, Q.lat[m], w, h, d);
         if (i >= w || j >= h || k >= d) continue;
-        const float cx = Q.cs[m][0] + (float)(i * dx + hw), cy = Q.cs[m][1] + (float)(j * dx + hw), cz = Q.cs[m][2] + (float)(k * dx + hw);
+        // band cubes of this lattice among the 27 around (i, j, k): bit (dk + 1) * 9 + (dj + 1) * 3 + (di + 1)
+        unsigned vm = 0u;
+#pragma unroll
+        for (int dk = -1; dk <= 1; dk++)
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj++)
+#pragma unroll
+                for (int di = -1; di <= 1; di++) {
+                    const int ii = i + di, jj = j + dj, kk = k + dk;
+                    if (ii >= 0 && jj >= 0 && kk >= 0 && ii < w && jj < h && kk < d && valid[gidx(L, ii, jj, kk)]) vm |= 1u << ((dk + 1) * 9 + (dj + 1) * 3 + (di + 1));
+                }
         float p[8];
         int neg = 0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {  // q = 4*oi + 2*oj + ok
-            const float sx = cx + ((q & 4) ? hdx : -hdx), sy = cy + ((q & 2) ? hdx : -hdx), sz = cz + ((q & 1) ? hdx : -hdx);
+        for (int q = 0; q < 8; q++) {  // q = 4*oi + 2*oj + ok: corner node (i + oi, j + oj, k + ok)
+            const int oi = (q >> 2) & 1, oj = (q >> 1) & 1, ok = q & 1;
+            // first visitor: the band cube with the smallest (k', j', i') that has the node as its corner (a', b', c'), i' = i + oi - a' ...
+            int fa = oi, fb = oj, fc = ok;   // (this cube itself is always a candidate: it is in the band)
+            bool found = false;
+#pragma unroll
+            for (int c2 = 1; c2 >= 0; c2--)
+#pragma unroll
+                for (int b2 = 1; b2 >= 0; b2--)
+#pragma unroll
+                    for (int a2 = 1; a2 >= 0; a2--) {
+                        const int di = oi - a2, dj = oj - b2, dk = ok - c2;
+                        if (!found && ((vm >> ((dk + 1) * 9 + (dj + 1) * 3 + (di + 1))) & 1u)) { found = true; fa = a2; fb = b2; fc = c2; }
+                    }
+            const int vi = i + oi - fa, vj = j + oj - fb, vk = k + ok - fc;
+            const float cx = Q.cs[m][0] + (float)(vi * dx + hw), cy = Q.cs[m][1] + (float)(vj * dx + hw), cz = Q.cs[m][2] + (float)(vk * dx + hw);
+            const float sx = cx + (fa ? hdx : -hdx), sy = cy + (fb ? hdx : -hdx), sz = cz + (fc ? hdx : -hdx);
             p[q] = d_liquid_phi_at(sx, sy, sz, dx, invdx, hoff, phi, L);
             neg += p[q] < 0.0f;
         }
@@ -584,11 +618,12 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         hipLaunchKernelGGL(k_face_states, GRID3(F1), 0, c->stream, F1, c->scp, c->stU, c->stV, c->stW);
         c->faceStateVersion = c->solidVersion;
     }
-    const Lay R0 = fv_range_liquid(c, 0, 4), R1 = fv_range_liquid(c, 1, 4), R2 = fv_range_liquid(c, 2, 4), R3 = fv_range_liquid(c, 3, 4);
-    // band mask + the seven volume lattices (viscositysolver.cpp:135-178)
-    hipLaunchKernelGGL(k_valid_init, GRID3(R3), 0, c->stream, R3, c->phi, c->validCells);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validCells, c->validTmp);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(R1), 0, c->stream, R1, c->validTmp, c->validCells);
+    const Lay R0 = fv_range_liquid(c, 0, 4), R1 = fv_range_liquid(c, 1, 4), R2 = fv_range_liquid(c, 2, 4), R3 = fv_range_liquid(c, 3, 4), R4 = fv_range_liquid(c, 4, 4);
+    // band mask + the seven volume lattices (viscositysolver.cpp:135-178).  The mask must be final one entry beyond the volumes' range R1: a
+    // corner's first visitor is looked up among the 27 cubes around an index (k_volume_sample)
+    hipLaunchKernelGGL(k_valid_init, GRID3(R4), 0, c->stream, R4, c->phi, c->validCells);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(R3), 0, c->stream, R3, c->validCells, c->validTmp);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validTmp, c->validCells);
     const float h = (float)(0.5 * c->dx);
     const int fullVol = c->bandPrevValid ? 0 : 1;  // volumes and factors are stored only where the band is or was in the previous solve
     {
@@ -604,7 +639,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         unsigned *nlist = c->surfList + L.n;
         HIPCHK(c, hipMemsetAsync(nlist, 0, sizeof(unsigned), c->stream));
         hipLaunchKernelGGL(k_volume_classify, GRID3(R1), 0, c->stream, R1, Q, c->phi, c->validCells, c->bandPrev, fullVol, c->surfList, nlist);
-        hipLaunchKernelGGL(k_volume_sample, dim3(4096), dim3(256), 0, c->stream, c->L, Q, c->phi, c->surfList, nlist, c->dx);
+        hipLaunchKernelGGL(k_volume_sample, dim3(4096), dim3(256), 0, c->stream, c->L, Q, c->phi, (const uint8_t *)c->validCells, c->surfList, nlist, c->dx);
     }
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
@@ -735,7 +770,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     c->viscosityReady = 1;
     c->viscosityPrec = std::is_same<T, float>::value ? 0 : 1;
 
-    int conv = -1, iters = 0, refinements = 0;
+    int conv = -1, iters = 0, refinements = 0, corrIters = 0, corrStatus = 0;   // (flipv_solve_info::correction_iterations / correction_status)
     double res = bnorm;
     bool success = false, stalled = false, ranMg = false;
     const bool defectLimited = false;
@@ -782,7 +817,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // the operator the PCG loop applies (and the multigrid hierarchy is built from): under the multigrid always the exact one -- with the defect
         // correction towards the reference's around it where that exists (fp32 bricks), without it on the plane layouts (block contexts)
         c->vOperatorExact = (refDiag && !useMg) ? 0 : 1;
-        if (useAcc) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
+        if (useAcc && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
         int itersDone = 0, corrections = 0;
         bool correctionDue = false;
         double resBeforeStage = 0.0;
@@ -808,13 +843,23 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // stiffness_scan_64.log) says it need not: at 32 768 stage 1 to 1e-6 with stage 2 at 2 % gives 4e-5 ... 9e-5 on the first substep and 7e-5 ...
         // 2e-4 on the second, this rule 2e-5 and 1e-4 for 25-60 % fewer iterations; at 122 880 the former runs a solve into the cap (1e-4 ... 7e-4),
         // this rule gives 1.5e-4 / 1.6e-4 -- nothing pins those regimes to 1e-4, and this is the cheaper and the more robust of the two.
+        // The constants of the rule are flipv_params fields since FLIPV_VERSION 4 (0 = these defaults): stage 1's factor 300, the stiffness gate 2e5,
+        // a correction stage's share 1e-2 (2e-2 behind a stage 1 that ran to the final tolerance), its budget, and how many stages.
+        // MORE THAN ONE STAGE where the system is stiff: a stage contracts the distance to the reference operator's solution by |A^-1 E|, which is the
+        // 1.5e-4 of the 256^3 / nu = 5 scene (one stage: 2e-5) but grows with nu dt/dx^2 -- at 1.2e5 ... 1.3e5 (BASELINE config 4's regime) one stage
+        // leaves 1.5e-4 ... 4e-4 on the goldens cut there (tests/golden: bunny64_nu3000, honey96_nu1422), two stages 2e-5 ... 6e-5 (profiles/r4/stiff_regime_scan.log).
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-        const double tolMain = (innerDiffers && stiffNow <= 2.0e5) ? 300.0 * tolFinal : tolFinal;
+        const double f1 = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : 300.0;
+        const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5;
+        const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 96;
+        const int rounds = c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : (stiffNow > 2.0e4 ? 2 : 1);
+        const double tolMain = (innerDiffers && stiffNow <= gate) ? f1 * tolFinal : tolFinal;
+        const double f2 = c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (tolMain > tolFinal ? 1e-2 : 2e-2);
         if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
-        auto recompute_residual = [&]() -> int {
-            { const int rcr = fv_brick_refine<T>(c, sc, scalBytes, !refDiag); if (rcr) return rcr; }   // (several ranks: with the accumulator's halo copy and the all-reduce of max|r|)
+        auto recompute_residual = [&](int flushMode) -> int {   // flushMode 1: x is kept beside the accumulator until the caller has looked at the residual (fv_brick_flush_settle)
+            { const int rcr = fv_brick_refine<T>(c, sc, scalBytes, !refDiag, flushMode); if (rcr) return rcr; }   // (several ranks: with the accumulator's halo copy and the all-reduce of max|r|)
             refinements++;
             hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, 0, bmax);
             HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -832,9 +877,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // is rough on the rows (ghost-band and extrapolated faces next to P2G faces), so max|b - A u_old| came out 5 000 x max|b| at 256^3.)
         while (!success) {
         const bool correction = correctionDue;   // this round is a bounded defect-correction stage (see above)
-        const int capNow = (correction && cap - itersDone > 48) ? 48 : cap - itersDone;
+        const int capNow = (correction && cap - itersDone > cap2) ? cap2 : cap - itersDone;
         sc.cap = capNow;
-        sc.tol = correction ? fmax(tolFinal, (tolMain > tolFinal ? 1e-2 : 2e-2) * fmax(resStart - (tolMain > tolFinal ? tolMain : 0.0), 0.0)) : tolMain;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
+        // (the first correction stage starts from stage 1's remainder PLUS the defect: its target is the share of what lies beyond the remainder)
+        sc.tol = correction ? fmax(tolFinal, f2 * fmax(resStart - ((corrections == 1 && tolMain > tolFinal) ? tolMain : 0.0), 0.0)) : tolMain;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
         sc.stall_below = refinements > 0 ? fmin(100.0 * sc.tol, 0.05 * resStart) : 0.0;
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
         // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the
@@ -899,15 +945,30 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         }
         itersDone += itersNow;
         if (!correction) resBeforeStage = res;                   // the main loop's own (recurrence) residual
-        if (correction) { success = true; stalled = false; }   // a correction stage is accepted as it comes
+        if (correction) {   // a correction stage's result is kept whether or not it reached its target -- unless it RAISED the fp64 residual (below) --, but the solve says so
+            corrIters += itersNow;
+            if (!success) corrStatus = 2;
+            else if (corrStatus == 0) corrStatus = 1;
+            success = true; stalled = false;
+        }
         if (success && !innerDiffers) break;
         if (!canRefine) break;
         if (!success && !(stalled && refinements < 8 && itersDone < cap)) break;   // (cap reached: nothing to continue with)
         // converged on the exact operator (the solve is for the reference's), or stalled: what is the residual really?
         const bool wasConverged = success;
         if (c->prm.verbose) fprintf(stderr, "viscosity solve %ld: %s after %d iterations at %.3g (tolerance %.3g); recomputing the residual in fp64\n", c->viscSolves,
-                                    stalled ? "stalled" : (correction ? "correction stage done" : "converged"), itersDone, res, sc.tol);
-        if ((rc = recompute_residual())) return rc;
+                                    stalled ? "stalled" : (correction ? (corrStatus == 2 ? "correction stage ended short of its target" : "correction stage done") : "converged"), itersDone, res, sc.tol);
+        const double defectBefore = resStart;   // (a correction stage: the fp64 residual it started from)
+        if ((rc = recompute_residual(correction ? 1 : 0))) return rc;
+        bool tookBack = false;
+        if (correction) {   // the tentative flush: confirmed, or taken back when the stage made things worse (an fp32 loop that broke down)
+            tookBack = res > defectBefore;
+            fv_brick_flush_settle<T>(c, sc, tookBack);
+            if (tookBack) {
+                if (c->prm.verbose) fprintf(stderr, "viscosity solve %ld: the correction stage raised the fp64 residual (%.3g -> %.3g): taken back\n", c->viscSolves, defectBefore, res);
+                corrStatus = 3; res = defectBefore;
+            }
+        }
         stalled = false;
         success = false;
         if (res <= tolFinal) { success = true; if (innerDiffers) { defectRes = res; if (corrections >= 1) res = mainRes; } break; }
@@ -918,10 +979,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             // simply wrong -- 512^3 / nu = 50, nu dt/dx^2 = 131 072: max|E x| = 1.2 max|b|, further stages contract by 2-50x each and stop
             // contracting around 1e-5 -- and chasing it costs more than the solve (measured: 6 stages, +70 % iterations, no convergence).
             // The solve's status and residual are the exact-operator loop's; `defect_residual` reports max|b - A_ref x| at the end.
-            if (corrections >= 1 || itersDone >= cap) { success = true; defectRes = res; res = mainRes; break; }
+            if (corrections >= rounds || itersDone >= cap || tookBack) { success = true; defectRes = res; res = mainRes; break; }
             corrections++;
             correctionDue = true;
-            mainRes = resBeforeStage;
+            if (corrections == 1) mainRes = resBeforeStage;
         } else correctionDue = false;
         if (itersDone >= cap) break;
         }
@@ -929,6 +990,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     }
     li.refinements = refinements;
     li.defect_residual = defectRes;
+    li.correction_iterations = corrIters;
+    li.correction_status = corrStatus;
     if (c->prm.verbose && nontrivial)
         fprintf(stderr, "viscosity solve %ld: %s, %s layout, %d iterations, residual %.3g (rhs %.3g), %s\n", c->viscSolves, ranMg ? "multigrid" : "diagonal",
                 brick ? "brick" : (c->vSwz ? "swizzled" : "plain"), iters, res, bnorm, success ? "converged" : (stalled ? "stalled" : "cap"));
@@ -965,7 +1028,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // acceptance rule of viscositysolver.cpp:676-689
     // (a stalled solve is treated like one that ran into the cap: its iterate is used if the residual passes the acceptance bound)
     const bool accepted = success || defectLimited || ((iters == cap || stalled) && res < c->prm.viscosity_accept_tolerance);
-    li.status = success ? (iters == 0 ? 3 : 0) : (accepted ? 1 : 2);
+    const bool complete = success && corrStatus <= 1;   // (a correction stage that ran out of budget, stalled or was taken back: the result is applied, the status says "not converged")
+    li.status = success ? (iters == 0 ? 3 : (complete ? 0 : 1)) : (accepted ? 1 : 2);
     if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
         const size_t off = plane_off(L, R0.kb), cnt = (size_t)(R0.ke - R0.kb) * L.sz;
         float *uvw[3] = {c->U, c->V, c->W};
@@ -979,11 +1043,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if ((rc = fv_halo_copy(c, uv, 3, 1))) return rc;  // the pressure rhs at plane k1-1 reads W(k1)
     }
     // the accumulator is zero between solves (its halo reads rely on it)
-    if (useAcc && nontrivial) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
+    if (useAcc && nontrivial && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
     HIPCHK(c, hipGetLastError());
     if (c->prm.kernel_timing) fv_ev_collect(c);
     if (info) *info = li;
-    return success ? FLIPV_OK : (accepted ? FLIPV_WARN_NOT_CONVERGED : FLIPV_WARN_SOLVE_FAILED);
+    return complete ? FLIPV_OK : (accepted ? FLIPV_WARN_NOT_CONVERGED : FLIPV_WARN_SOLVE_FAILED);
 }
 
 // One fine-level sweep of the multigrid preconditioner (k_viscosity_mg.hip) with the solver's tile SpMV kernel: out = in + omega

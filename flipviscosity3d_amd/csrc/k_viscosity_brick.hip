@@ -302,7 +302,9 @@ __device__ __forceinline__ bool d_replace_now(const PcgScal &sc, int it_arg, int
 }
 template <typename T>
 __global__ __launch_bounds__(256) void k_bflush(const int *__restrict__ bricks, int nb, BrickSys<T> v, double *__restrict__ xaU, double *__restrict__ xaV,
-                                                double *__restrict__ xaW, PcgScal sc, int it_arg, int period, int force, int withSigma) {
+                                                double *__restrict__ xaW, PcgScal sc, int it_arg, int period, int force, int withSigma, int mode) {
+    // mode 0: xacc += x, x = 0 (the flush); 1: xacc += x, x KEPT (a tentative flush: the caller decides from the recomputed residual);
+    // 2: xacc -= x, x = 0 (the tentative flush taken back); 3: x = 0 (... or confirmed)
     BrickWalk w;
     w.begin(bricks, nb, v.mask);
     int it;
@@ -322,8 +324,9 @@ __global__ __launch_bounds__(256) void k_bflush(const int *__restrict__ bricks, 
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             if (!((m >> c) & 1u)) continue;
-            xa[c][a] += (double)v.x[c][a];
-            v.x[c][a] = (T)0;
+            if (mode == 0 || mode == 1) xa[c][a] += (double)v.x[c][a];
+            else if (mode == 2) xa[c][a] -= (double)v.x[c][a];
+            if (mode != 1) v.x[c][a] = (T)0;
         }
     }
 }
@@ -482,7 +485,7 @@ void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int perio
     const BrickSys<T> v = brick_sys<T>(c);
     const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
     const dim3 b(64, 4, 1);
-    hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, it_arg, period, 0, withSigma);
+    hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, it_arg, period, 0, withSigma, 0);
     hipLaunchKernelGGL((k_bresidual<T>), dim3(spmv_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v,
                        (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1],
                        (const float *)c->vB[2], z ? z[0] : nullptr, z ? z[1] : nullptr, z ? z[2] : nullptr, omega, sc, it_arg, period, withSigma, 0);
@@ -495,11 +498,11 @@ template void fv_brick_replace<double>(flipv_context *, const PcgScal &, int, in
 // outerExact: which operator the recomputed residual belongs to -- the exact one, or the reference's float-rounded one (the operator the
 // SOLVE is for; the PCG loop in between may run on the exact operator, see viscosity_solve_t)
 template <typename T>
-int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact) {
+int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact, int flushMode) {
     const BrickSys<T> v = brick_sys<T>(c);
     const float *const vo[3] = {outerExact ? c->vmU : c->vrU, outerExact ? c->vmV : c->vrV, outerExact ? c->vmW : c->vrW};
     const dim3 b(64, 4, 1);
-    hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0);
+    hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0, flushMode);
     (void)hipMemsetAsync(sc.base, 0, scalBytes, c->stream);   // bank 0's slot blocks (the extra scalars behind them stay), then the other banks
     if (sc.nbank > 1) (void)hipMemsetAsync(sc.base + sc.bstride, 0, (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double), c->stream);
     if (c->comm) {   // the residual's stencil reads the neighbours' accumulated solution across the cuts
@@ -512,8 +515,15 @@ int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool 
                        (const float *)c->vB[2], (float *)nullptr, (float *)nullptr, (float *)nullptr, 0.0f, sc, 0, 0, 0, 1);
     return fv_allreduce_scalars(c, sc.rmax(0), NSLOT);   // (ranks write disjoint slots: the sum merges their maxima)
 }
-template int fv_brick_refine<float>(flipv_context *, const PcgScal &, size_t, bool);
-template int fv_brick_refine<double>(flipv_context *, const PcgScal &, size_t, bool);
+template int fv_brick_refine<float>(flipv_context *, const PcgScal &, size_t, bool, int);
+template int fv_brick_refine<double>(flipv_context *, const PcgScal &, size_t, bool, int);
+// a tentative flush (fv_brick_refine with flushMode 1) confirmed (x = 0) or taken back (xacc -= x, x = 0)
+template <typename T>
+void fv_brick_flush_settle(flipv_context *c, const PcgScal &sc, bool takeBack) {
+    hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, brick_sys<T>(c), c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0, takeBack ? 2 : 3);
+}
+template void fv_brick_flush_settle<float>(flipv_context *, const PcgScal &, bool);
+template void fv_brick_flush_settle<double>(flipv_context *, const PcgScal &, bool);
 
 // x (+ xacc) -> velocity grid over the launch box R
 template <typename T>

@@ -1128,6 +1128,12 @@ struct VmgState {
     // residuals (one all-reduce per iteration).  -1: no global level (single domain, or switched off)
     int globalFrom = -1;
     int rc = 0;                  // a communication error inside the V-cycle (checked by the loop around it)
+    // Under a communicator the V-cycle cannot be one replayed graph (its collectives are host calls of the backend), but everything between the
+    // right-hand-side all-reduce of the first global level and the halo copy before the first post-sweep is kernels only -- ~17 dependent launches,
+    // most of them at the floor of a launch: that segment is captured once per solve and replayed every iteration (midExec: the cached executable,
+    // owned by flipv_context::geCache; midReady: captured for this solve's hierarchy)
+    hipGraphExec_t midExec = nullptr;
+    bool midReady = false;
     bool listRhs = true;         // the first global level's right-hand side travels as its listed bricks (every rank holds the same list), not as the union box
     float *stage = nullptr;      // dense staging buffer of the global hierarchy's all-reduces (grown on demand)
     size_t stageCap = 0;
@@ -1287,6 +1293,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     if (rc) return rc;
     VmgState *s = (VmgState *)c->vmgState;
     const bool brick = vmg_brick(c);
+    s->midReady = false;   // (a new hierarchy: new grids and lists in the captured segment)
     // the fine level's sweep vectors must be zero wherever there is no row (the SpMV and the restriction read neighbours unmasked)
     if (brick && s->prevCount >= 0) {
         if (s->prevCount > 0) hipLaunchKernelGGL(k_bvmg_zero, dim3(cdiv(s->prevCount, 4) < 2048 ? cdiv(s->prevCount, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)s->prevBricks, s->prevCount, s->za[0], s->fineStride, 9);
@@ -1488,50 +1495,67 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
 #define STEP(OP_, l_) do { if (c->vmgPackedRows) STEP_(OP_, true, l_); else STEP_(OP_, false, l_); } while (0)
         const int gl = s->globalFrom;
         // the first global level's right-hand side: every rank restricts its own residual over the union box, the sum over the ranks is b
-        auto global_rhs = [&](int l, int first) {   // restriction into the staging buffer, all-reduce, back into b (and x = omega b/d: the first sweep)
-            if (s->lev[l].nstrips > 0 && s->listRhs) {   // a level with a brick list: only the listed bricks travel
-                const size_t n = (size_t)s->lev[l].nstrips * 64;
-                int r2 = vmg_stage_reserve(c, s, 3 * n);
-                if (r2) return r2;
-                const dim3 g(cdiv(s->lev[l].nstrips, 4), 3);
-                hipLaunchKernelGGL(k_vmg_restrict_list, g, dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, s->stage);
-                if ((r2 = fv_allreduce_f32(c, s->stage, 3 * n))) return r2;
-                hipLaunchKernelGGL(k_vmg_unpack_list, g, dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, l, (const float *)s->stage, conv, first);
-                return (int)FLIPV_OK;
-            }
+        // (gl is 0 or -1: the all-reduce, if any, sits in front of level 1 = lev[0] -- in the loop below, or in front of the tail when t0 = 0)
+        const bool listed = gl >= 0 && s->lev[gl].nstrips > 0 && s->listRhs;   // a level with a brick list: only the listed bricks travel
+        auto global_rhs_send = [&](int l) {   // restriction into the staging buffer and its sum over the ranks
             const Box3 &B = s->lev[l].box;
-            const size_t n = (size_t)box_positions(B);
+            const size_t n = listed ? (size_t)s->lev[l].nstrips * 64 : (size_t)box_positions(B);
             int r2 = vmg_stage_reserve(c, s, 3 * n);
             if (r2) return r2;
-            hipLaunchKernelGGL(k_vmg_restrict_box, dim3(cdiv(B.hi[0] - B.lo[0], 64), cdiv(B.hi[1] - B.lo[1], 4), 3u * (unsigned)(B.hi[2] - B.lo[2])), dim3(64, 4, 1), 0, c->stream,
-                               (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, s->stage);
-            if ((r2 = fv_allreduce_f32(c, s->stage, 3 * n))) return r2;
-            hipLaunchKernelGGL(k_vmg_unpack_rhs, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, c->stream, (const VLevelDev *)s->d_lev, l, (const float *)s->stage, conv, first);
-            return (int)FLIPV_OK;
+            if (listed) hipLaunchKernelGGL(k_vmg_restrict_list, dim3(cdiv(s->lev[l].nstrips, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, s->stage);
+            else hipLaunchKernelGGL(k_vmg_restrict_box, dim3(cdiv(B.hi[0] - B.lo[0], 64), cdiv(B.hi[1] - B.lo[1], 4), 3u * (unsigned)(B.hi[2] - B.lo[2])), dim3(64, 4, 1), 0, c->stream,
+                                    (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, s->stage);
+            return fv_allreduce_f32(c, s->stage, 3 * n);
         };
-        for (int l = 0; l < t0; l++) {   // down
-            if (l == gl) { if ((s->rc = global_rhs(l, 1))) return; }
-            else STEP(OP_RESTRICT, l);
-            STEP(OP_PRE2, l);
-            STEP(OP_RESID, l);
-        }
-        {
-            const int sweeps = c->vmgSweeps > 0 ? c->vmgSweeps : VMG_COARSEST_SWEEPS;
-            if (t0 == gl && (s->rc = global_rhs(t0, 0))) return;
-            if (t0 == nl - 1 && s->coarsestInLds)   // the tail is just the LDS-resident coarsest level: its own kernel (no other level's code around the sweeps)
-                hipLaunchKernelGGL(k_vmg_coarsest, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
-            else
-                hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
-        }
-        for (int l = t0 - 1; l >= 0; l--) {   // up
-            STEP(OP_PROPOST, l);
-            STEP(OP_POST2, l);
+        auto global_rhs_take = [&](int l, int first) {   // back into b (and x = omega b/d: the first sweep)
+            if (listed) hipLaunchKernelGGL(k_vmg_unpack_list, dim3(cdiv(s->lev[l].nstrips, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, l, (const float *)s->stage, conv, first);
+            else { const size_t n = (size_t)box_positions(s->lev[l].box); hipLaunchKernelGGL(k_vmg_unpack_rhs, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, c->stream, (const VLevelDev *)s->d_lev, l, (const float *)s->stage, conv, first); }
+        };
+        // everything of the coarse part that follows the all-reduce (or all of it, without one): kernels only
+        auto coarse_part = [&](bool afterSend) {
+            for (int l = 0; l < t0; l++) {   // down
+                if (l == gl) { if (afterSend) global_rhs_take(l, 1); }
+                else STEP(OP_RESTRICT, l);
+                STEP(OP_PRE2, l);
+                STEP(OP_RESID, l);
+            }
+            {
+                const int sweeps = c->vmgSweeps > 0 ? c->vmgSweeps : VMG_COARSEST_SWEEPS;
+                if (t0 == gl && afterSend) global_rhs_take(t0, 0);
+                if (t0 == nl - 1 && s->coarsestInLds)   // the tail is just the LDS-resident coarsest level: its own kernel (no other level's code around the sweeps)
+                    hipLaunchKernelGGL(k_vmg_coarsest, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
+                else
+                    hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
+            }
+            for (int l = t0 - 1; l >= 0; l--) {   // up
+                STEP(OP_PROPOST, l);
+                STEP(OP_POST2, l);
+            }
+            // (inside the captured segment the iteration number is not known: the kernel only tests it against the cap, which the host's loop respects anyway)
+            const int itp = (afterSend && s->midReady) ? 0 : it_arg;
+            if (brick) hipLaunchKernelGGL(k_bvmg_prolong_fine, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, c->LB, s->lev[0].L, (const uint8_t *)c->vMaskB, v3(s->zb), v3(s->lev[0].x), sc, itp);
+            else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
+                               c->vSwz, v3(dg), v3(s->zb), v3(s->lev[0].x), sc, itp));
+        };
+        if (gl < 0) coarse_part(false);
+        else {
+            if ((s->rc = global_rhs_send(gl))) return;
+            const bool replay = !c->prm.kernel_timing && !c->prm.no_graph_replay;
+            if (replay && !s->midReady) {   // first V-cycle of this solve: capture the segment (the all-reduce it follows has been enqueued)
+                hipGraph_t g = nullptr;
+                if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    s->midReady = true;   // (coarse_part launches the iteration-free form)
+                    coarse_part(true);
+                    const hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+                    if (e2 != hipSuccess || !g || fv_graph_exec(c, FV_GE_VISCOSITY_MID, g, &s->midExec) != FLIPV_OK) { s->midReady = false; s->midExec = nullptr; (void)hipGetLastError(); }
+                    if (g) (void)hipGraphDestroy(g);
+                } else (void)hipGetLastError();
+            }
+            if (replay && s->midReady) { if (hipGraphLaunch(s->midExec, c->stream) != hipSuccess) { s->rc = FLIPV_ERR_HIP; c->err = "viscosity multigrid: hipGraphLaunch of the coarse segment failed"; return; } }
+            else coarse_part(true);
         }
 #undef STEP
 #undef STEP_
-        if (brick) hipLaunchKernelGGL(k_bvmg_prolong_fine, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, c->LB, s->lev[0].L, (const uint8_t *)c->vMaskB, v3(s->zb), v3(s->lev[0].x), sc, it_arg);
-        else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
-                           c->vSwz, v3(dg), v3(s->zb), v3(s->lev[0].x), sc, it_arg));
     }
     halo3(s->zb);
     fv_visc_sweep_f32(c, s->zb, s->za, 1, sc, it_spmv, s->w[0], 0);                         // post-sweeps: zb -> za -> zb

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define FLIPV_VERSION 3   /* 3: every behavioural switch is a flipv_params field (no environment variables); brick layout; residual replacement */
+#define FLIPV_VERSION 4   /* 3: every behavioural switch is a flipv_params field (no environment variables); brick layout; residual replacement
+                             4: the constants of the two-stage viscosity solve are flipv_params fields; flipv_solve_info reports the correction stage */
 
 typedef struct flipv_context flipv_context;
 
@@ -86,16 +87,14 @@ typedef struct flipv_params {
                                     multigrid-preconditioned loops (viscosity and pressure: an iteration after the stop is a full V-cycle) */
     /* solver choice (enum flipv_preconditioner) */
     int pressure_preconditioner; /* AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
-    int viscosity_preconditioner;/* DIAGONAL; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors, one rank, whole-domain context; other
-                                    solves fall back to the diagonal and say so in flipv_solve_info.preconditioner): 15-250 iterations
+    int viscosity_preconditioner;/* DIAGONAL; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors; single-domain AND block contexts: under a
+                                    communicator the hierarchy is the single domain's, see multigrid_rank_local; fp64 vectors and 2-wide lanes
+                                    fall back to the diagonal and say so in flipv_solve_info.preconditioner): 15-250 iterations
                                     where the diagonal needs 200-4 000.  AUTO (default) = the multigrid unless the previous solve shows
                                     that the diagonal CONVERGES for less (k_viscosity.hip: fv_visc_auto_pick); a diagonal solve AUTO
                                     picked that runs into the cap is repeated with the multigrid, so a default run never returns an
                                     iterate stopped at the cap where a converged one is affordable.  Decisions use iteration counts only,
-                                    never timings; every path converges to the same tolerance, so the history of a context changes the
-                                    cost of a solve, not its answer beyond solver tolerance.  Contexts on which the multigrid is not
-                                    available (block contexts / communicators, fp64 vectors) run the diagonal, stopped at the cap like the
-                                    reference's solve */
+                                    never timings, and are taken from all-reduced inputs: every rank of a communicator decides alike */
     /* ---- every field below: 0 = the default behaviour (a zero-initialised tail is a valid default configuration) ---- */
     int exact_viscosity_operator;/* 0 (default): the viscosity solve applies the REFERENCE's operator, including the rounding of its float
                                     diagonal (the reference sums vol + fR + fL + fT + fB + fF + fK in float, viscositysolver.cpp:394-446;
@@ -103,11 +102,13 @@ typedef struct flipv_params {
                                     256^3 (3 300) the reference's converged velocities are 7e-6 from this operator's and 1.5e-4 from the
                                     exact one's.  1: the exact operator vol u - div(tau) (better conditioned; what rounds differently is the
                                     reference).  
-                                    Under the multigrid (fp32 vectors, brick layout) the reference's operator is reached by defect correction:
-                                    stage 1 solves the exact operator's system -- to 300 x viscosity_tolerance where nu dt/dx^2 <= 2e5, to
-                                    viscosity_tolerance beyond --, stage 2 solves A dx = b - A_ref x (fp64 residual) to 1 % of the defect (2 % where
-                                    stage 1 ran to viscosity_tolerance), never below viscosity_tolerance, in at most 48 iterations.  `status` 0 = both stages completed; flipv_solve_info.
-                                    residual / defect_residual say what was delivered */
+                                    Under the multigrid (fp32 vectors) the reference's operator is reached by DEFECT CORRECTION, on single-domain and block
+                                    contexts, in every layout: stage 1 solves the exact operator's system A x = b to viscosity_stage1_factor x viscosity_tolerance
+                                    (where nu dt/dx^2 <= viscosity_two_stage_max_stiffness; to viscosity_tolerance beyond), then up to viscosity_stage2_rounds
+                                    correction stages solve A dx = b - A_ref x (fp64 residual) to viscosity_stage2_factor of the defect, never below
+                                    viscosity_tolerance, in at most viscosity_stage2_max_iterations iterations each; a correction that RAISES the fp64
+                                    residual is taken back.  flipv_solve_info: status 0 = every stage reached its target; residual = stage 1's;
+                                    defect_residual = max|b - A_ref x| delivered; correction_* = what the correction stages did */
     int residual_replacement;    /* n > 0 (fp32 vectors in the brick layout): every n iterations the solution accumulated so far is flushed into an
                                     fp64 accumulator and the recurrence residual is REPLACED by b - A x evaluated in fp64 (group-wise update, van
                                     der Vorst & Ye; two extra launches per n iterations), so that the stop test sees the true residual.  0
@@ -116,9 +117,9 @@ typedef struct flipv_params {
                                     reaches, so a periodic replacement restarts CG with a stale direction again and again (38 -> 421 iterations
                                     on the 20^3 fixture); the drift sits in rough modes and changes the velocities by 1e-8.  Kept for studies */
     int viscosity_layout;        /* layout of the viscosity solver's arrays: 0 = chosen per solve (bricks of 8 x 4 x 2 indices on sparse
-                                    liquids of a single-domain context, plain planes otherwise), 1 = plain planes, 2 = plain planes with the
-                                    own-index arrays in 8 x 4 patches under the 16-lane tile geometry (the pre-brick default), 3 = bricks
-                                    wherever they are available */
+                                    liquids -- rows filling < 30-40 % of the box, over all ranks --, plain planes otherwise), 1 = plain planes,
+                                    2 = plain planes with the own-index arrays in 8 x 4 patches under the 16-lane tile geometry (the pre-brick
+                                    default), 3 = bricks always.  Single-domain and block contexts alike */
     int tile_rows;               /* 16 | 64: pins the tile geometry of the plane-layout kernels (lanes of a wave along i); 0 = chosen per
                                     solve from how full the tiles are */
     int viscosity_mg_coarsest_sweeps; /* sweeps on the LDS-resident coarsest level of the viscosity multigrid: a power of two (4..64) = that many
@@ -155,6 +156,14 @@ typedef struct flipv_params {
                                     all-reduces over the liquid's box), held and cycled redundantly by every rank: the iteration counts of a single domain.
                                     1: every rank cycles a hierarchy of its OWN rows / cells with the couplings across the cuts dropped and no exchange
                                     (block-Jacobi): 3-4x the viscosity iterations and 2-3x the pressure iterations on 2x2x2 blocks */
+    /* the two-stage viscosity solve (see exact_viscosity_operator); 0 = the default in brackets */
+    float viscosity_stage1_factor;          /* [300] stage 1 stops at this multiple (>= 1) of viscosity_tolerance x max|rhs|; 1 = the strict solve: stage 1 to
+                                               viscosity_tolerance itself (bench.py: mode_b_strict) */
+    float viscosity_stage2_factor;          /* [1e-2; 2e-2 where stage 1 ran to viscosity_tolerance] a correction stage's target as a share of the defect it starts from */
+    int viscosity_stage2_max_iterations;    /* [96] iteration budget of ONE correction stage (inside viscosity_max_iterations overall) */
+    int viscosity_stage2_rounds;            /* [1; 2 where nu dt/dx^2 > 2e4] correction stages at most: each contracts the distance to the reference operator's solution
+                                               by |A^-1 (A_ref - A)|, which is ~1e-3 at nu dt/dx^2 = 3e3 and ~4e-2 at 1.3e5 */
+    float viscosity_two_stage_max_stiffness;/* [2e5] nu dt/dx^2 up to which stage 1 stops early (beyond: the fp32 loop's accuracy floor, stage 1 runs to viscosity_tolerance) */
     int reserved[1];             /* must be 0 */
 } flipv_params;
 
@@ -162,7 +171,8 @@ typedef struct flipv_solve_info {
     int iterations;      /* iterations run (count) */
     double residual;     /* final inf-norm residual */
     double rhs_norm;     /* max|rhs| */
-    int status;          /* 0 converged, 1 cap reached, 2 failed/rejected, 3 trivial (rhs ~ 0 or skipped) */
+    int status;          /* 0 converged (two-stage viscosity solve: every stage reached its target), 1 cap reached / a stage incomplete (the result is applied),
+                            2 failed/rejected, 3 trivial (rhs ~ 0 or skipped) */
     int rows;            /* unknowns */
     int active_tiles;    /* tiles swept per launch */
     int total_tiles;
@@ -170,12 +180,16 @@ typedef struct flipv_solve_info {
                             the Galerkin V-cycle) */
     int layout;          /* viscosity: layout of the solver's arrays in this solve, 0 plain planes, 1 plain + swizzled own-index arrays, 2 bricks
                             (active_tiles / total_tiles then count bricks of 8 x 4 x 2 indices) */
-    int refinements;     /* viscosity, fp32 vectors in the brick layout: how often the solve was continued on the correction equation after a stall
-                            (x flushed into an fp64 accumulator, r = b - A x evaluated in fp64, PCG restarted); `iterations` counts all rounds */
-    double defect_residual; /* viscosity, default operator under the multigrid: max|b - A_ref x| (fp64) after the defect-correction stage, A_ref the
-                            reference's float-rounded operator; `status` / `residual` are those of the exact-operator PCG loop (stage 1: it
-                            stops at 300 x viscosity_tolerance where a correction stage follows, see exact_viscosity_operator).  0 when there
+    int refinements;     /* viscosity, fp32 vectors: fp64 residual evaluations (x flushed into an fp64 accumulator, r = b - A x in fp64) -- after a stall
+                            (the PCG is then restarted on the correction equation) and around every defect-correction stage; `iterations` counts all rounds */
+    double defect_residual; /* viscosity, default operator under the multigrid: max|b - A_ref x| (fp64) that the solve DELIVERS, A_ref the
+                            reference's float-rounded operator; `residual` is that of the exact-operator PCG loop (stage 1: it stops at
+                            viscosity_stage1_factor x viscosity_tolerance where a correction stage follows, see exact_viscosity_operator).  0 when there
                             was no such stage */
+    int correction_iterations; /* iterations spent in defect-correction stages (part of `iterations`) */
+    int correction_status;     /* 0 no correction stage; 1 every stage reached its target; 2 a stage ran into its iteration budget or stalled first (its
+                                  result is kept if it lowered the fp64 residual; `status` is then 1); 3 the last stage RAISED the fp64 residual and was taken back
+                                  (`status` 1) */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */

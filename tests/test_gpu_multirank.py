@@ -36,7 +36,7 @@ def test_slab_decomposition_matches_single_domain(name, nranks):
     g = Golden(name)
     I, J, K = g.dims()
     params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,
-                  viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (the single-domain context would otherwise pick the multigrid and the brick layout, which block contexts do not have: the comparison is about the decomposition, bit for bit where it can be)
+                  viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (pinned so that the comparison is about the decomposition, bit for bit where it can be: the plane layouts under a communicator, tight tolerances; the DEFAULT configuration on blocks is tests/test_gpu_multirank_default.py)
     ref = capi.Context(I, J, K, g.dx)
     ref.set_solid_sdf(g["solid"]); ref.set_viscosity(g["viscosity"]); ref.set_gravity(*g.gravity); ref.set_params(**params)
     ref.particles = g["particles0"]
@@ -89,7 +89,7 @@ def test_rccl_backend_single_rank_smoke():
     b.comm_init_rccl(capi.comm_unique_id(), 0, 1)
     for c in (a, b):
         c.set_solid_sdf(g["solid"]); c.set_viscosity(g["viscosity"]); c.set_gravity(*g.gravity)
-        c.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (a context with a communicator has neither the multigrid nor the brick layout to pick)
+        c.set_params(viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (the diagonal loop on the plane layout: every collective of its iteration through RCCL)
         c.particles = g["particles0"]
     for t in range(g.nsub):
         sa, sb = a.substep(g.dt), b.substep(g.dt)
@@ -149,7 +149,7 @@ def test_block_decomposition_matches_single_domain(name, dims):
     g = Golden(name)
     I, J, K = g.dims()
     params = dict(viscosity_max_iterations=5000, viscosity_tolerance=1e-7, pressure_rel_tolerance=1e-7,
-                  viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (the single-domain context would otherwise pick the multigrid and the brick layout, which block contexts do not have: the comparison is about the decomposition, bit for bit where it can be)
+                  viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_layout=capi.LAYOUT_SWIZZLED)   # (pinned so that the comparison is about the decomposition, bit for bit where it can be: the plane layouts under a communicator, tight tolerances; the DEFAULT configuration on blocks is tests/test_gpu_multirank_default.py)
     ref = capi.Context(I, J, K, g.dx)
     ref.set_solid_sdf(g["solid"]); ref.set_viscosity(g["viscosity"]); ref.set_gravity(*g.gravity); ref.set_params(**params)
     ref.particles = g["particles0"]
@@ -357,15 +357,16 @@ def test_decomposition_does_not_change_the_solver_path_over_several_substeps(dim
     from test_oracle_compact_golden import build_host_scene
     N = 64
     dx, solid, P0 = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
-    params = dict(viscosity_layout=capi.LAYOUT_SWIZZLED, exact_viscosity_operator=1, viscosity_preconditioner=capi.PRECOND_MULTIGRID)   # the same layout and operator on both sides
+    # NO parameter is set on either side (round 3 pinned the layout and the exact operator here, because block contexts had neither bricks nor the
+    # defect-correction stage: since round 4 they run what the single domain runs)
     ref = capi.Context(N, N, N, dx)
-    ref.set_solid_sdf(solid); ref.set_viscosity(5.0); ref.set_params(**params)
+    ref.set_solid_sdf(solid); ref.set_viscosity(5.0)
     ref.particles = P0
     boxes = partition.block_boxes(N, N, N, dims)
     ctxs = [capi.Context(N, N, N, dx, device=0, block=b) for b in boxes]
     capi.comm_init_local(ctxs, dims)
     for c, p in zip(ctxs, partition.split_particles_boxes(P0, dx, boxes, dims)):
-        c.set_solid_sdf(solid); c.set_viscosity(5.0); c.set_params(**params)
+        c.set_solid_sdf(solid); c.set_viscosity(5.0)
         c.particles = p
     nsub = 4
     single = [ref.substep(0.01) for _ in range(nsub)]
@@ -378,6 +379,7 @@ def test_decomposition_does_not_change_the_solver_path_over_several_substeps(dim
         for st in ranks:
             v, p = st[t]["viscosity"], st[t]["pressure"]
             assert v["status"] == 0 and p["status"] == 0 and v["preconditioner"] == 1 and p["preconditioner"] == 1
+            assert v["layout"] == sv["layout"] == 2 and (v["defect_residual"] > 0.0) == (sv["defect_residual"] > 0.0), (v, sv)   # bricks and the two-stage solve on both sides
             assert v["iterations"] == ranks[0][t]["viscosity"]["iterations"] and p["iterations"] == ranks[0][t]["pressure"]["iterations"]
         print("substep %d: viscosity %d / %d iterations, pressure %d / %d (single domain / %s blocks)" % (
             t, sv["iterations"], ranks[0][t]["viscosity"]["iterations"], sp["iterations"], ranks[0][t]["pressure"]["iterations"], dims))

@@ -104,3 +104,25 @@ def test_headline_256_default_blocks_against_the_converged_reference(dims):
         assert d[:3].max() <= 1e-6 and d[3:].max() <= 1e-5, d
     for c in ctxs:
         c.close()
+
+
+def test_rccl_backend_single_rank_default_params():
+    """the default configuration through the RCCL backend (one-rank communicator: every collective of the two-stage viscosity solve and of both
+    multigrid V-cycles is issued for real, the kernel-only segments of the V-cycles replayed as graphs): same solver path and iteration counts as
+    the plain context, velocities within 2e-5"""
+    from flipviscosity3d_amd import capi
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    a = capi.Context(N, N, N, dx)
+    b = capi.Context(N, N, N, dx, device=0, slab=(0, N))
+    b.comm_init_rccl(capi.comm_unique_id(), 0, 1)
+    for c in (a, b):
+        c.set_solid_sdf(solid); c.set_viscosity(5.0); c.particles = P
+    for t in range(3):
+        sa, sb = a.substep(0.01), b.substep(0.01)
+        va, vb = sa["viscosity"], sb["viscosity"]
+        assert va["status"] == 0 and vb["status"] == 0 and vb["preconditioner"] == 1 and vb["layout"] == 2 and vb["defect_residual"] > 0.0, (va, vb)
+        assert abs(va["iterations"] - vb["iterations"]) <= 3 and abs(sa["pressure"]["iterations"] - sb["pressure"]["iterations"]) <= 2, (va, vb)
+        assert rel_maxnorm3([b.grid(n) for n in "UVW"], [a.grid(n) for n in "UVW"]) <= 2e-5
+    b.comm_finalize()
+    a.close(); b.close()
