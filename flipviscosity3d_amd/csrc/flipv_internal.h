@@ -234,6 +234,7 @@ struct flipv_context {
     uint8_t *vMaskB = nullptr;   // the row mask in the brick layout (vRowMask stays plain: the setup's "was a row" memory)
     float *vB[3] = {nullptr, nullptr, nullptr};      // right-hand side of the current solve (residual replacement recomputes r = b - A x from it)
     double *vXacc[3] = {nullptr, nullptr, nullptr};  // fp64 accumulator of the solution (group-wise update: x of the PCG loop is flushed into it at every residual replacement)
+    double *vQ64[3] = {nullptr, nullptr, nullptr};   // plane layouts: A xacc in fp64 (the residual's scratch, k_viscosity.hip: fv_plane_refine); allocated on first use
     int *tileListP, *tileListV;
     int *tileFlag;
     int nActiveP, nActiveV;

@@ -485,7 +485,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spm
 int fv_vmg_prepare(flipv_context *c);
 
 template <typename T, int NV>
-static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count, const PcgSys<T, 3> *sys = nullptr) {
+static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int first, int count, const PcgSys<T, 3> *sys = nullptr, int forceRdot = -1) {
     // one resident round: the 4-wide kernel holds 189 VGPRs = 2 waves per SIMD = 2 blocks per CU = 512 blocks (measured over
     // 512..1024 at 256^3: 37.2 ms per solve at 512, 38.1 at 1024, 40.8-43.6 in between); flipv_params.viscosity_spmv_grid_cap overrides
     int nb = pcg_grid(c, count);
@@ -502,7 +502,7 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
 #define VSPMV(N_, P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, N_, P_, R_>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L, \
                            vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
-    const bool rdot = sc.conv ? !sc.noB : c->prm.beta_from_conjugacy == 0;   // benchmark launches (no scalars): the variant the solve would run
+    const bool rdot = forceRdot >= 0 ? forceRdot != 0 : (sc.conv ? !sc.noB : c->prm.beta_from_conjugacy == 0);   // benchmark launches (no scalars): the variant the solve would run
     if (NV == 4 && c->nRunsV > 0 && first == 0 && count == c->nActiveV) {   // k-marching over the run list (the whole system)
         int nbm = pcg_grid(c, c->nRunsV);
         if (nbm > cap) nbm = cap;
@@ -575,6 +575,116 @@ __global__ __launch_bounds__(256) void k_brick_zero_f64(const int *__restrict__ 
         const size_t a = ((size_t)bricks[e] << 6) + threadIdx.x;
         a0[a] = 0.0; a1[a] = 0.0; a2[a] = 0.0;
     }
+}
+
+// ------------------------------------------------------------------ the fp64 accumulator on the PLANE layouts
+// What k_bflush / k_bresidual / k_unbrick_to_f32 are to the brick layout (k_viscosity_brick.hip): the solution accumulated in fp64 beside the PCG's
+// fp32 x, the residual b - A_outer xacc evaluated in fp64, so that the two-stage defect correction (viscosity_solve_t) -- and the restart of a
+// stalled fp32 loop -- exist wherever the liquid is too dense for bricks.  xacc and the residual's scratch (q64) are plain-layout arrays; x, r and
+// the own volumes follow the solve's layout (plain, or the 8 x 4 patches of sidx).  The fp64 SpMV itself is the solver's own kernel with T = double.
+// mode: as k_bflush -- 0 xacc += x, x = 0; 1 xacc += x, x kept; 2 xacc -= x, x = 0; 3 x = 0; 4 xacc = 0 (between solves)
+template <typename T>
+__global__ void k_plane_flush(Lay L, const uint8_t *__restrict__ rowmask, int swz, T *__restrict__ x0, T *__restrict__ x1, T *__restrict__ x2,
+                              double *__restrict__ a0, double *__restrict__ a1, double *__restrict__ a2, int mode) {
+    IJK_OR_RETURN(L);
+    const unsigned m = rowmask[c];
+    if (!m) return;
+    const size_t cs = swz ? sidx(L, i, j, k) : c;
+    T *x[3] = {x0, x1, x2};
+    double *a[3] = {a0, a1, a2};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        if (!((m >> q) & 1u)) continue;
+        if (mode == 4) { a[q][c] = 0.0; continue; }
+        if (mode == 0 || mode == 1) a[q][c] += (double)x[q][cs];
+        else if (mode == 2) a[q][c] -= (double)x[q][cs];
+        if (mode != 1) x[q][cs] = (T)0;
+    }
+}
+// r = b - q64 on the rows (q64 = A_outer xacc, fp64), max|r| into rmax(0)
+template <typename T>
+__global__ void k_plane_residual_finish(Lay L, const uint8_t *__restrict__ rowmask, int swz, const float *__restrict__ b0, const float *__restrict__ b1,
+                                        const float *__restrict__ b2, const double *__restrict__ q0, const double *__restrict__ q1, const double *__restrict__ q2,
+                                        RT<T> *__restrict__ r0, RT<T> *__restrict__ r1, RT<T> *__restrict__ r2, PcgScal sc) {
+    __shared__ double lds[4];
+    IJK_OF_THREAD(L);
+    double mx = 0.0;
+    if (i < L.ie && j < L.je) {
+        const size_t c = gidx(L, i, j, k);
+        const unsigned m = rowmask[c];
+        if (m) {
+            const size_t cs = swz ? sidx(L, i, j, k) : c;
+            const float *b[3] = {b0, b1, b2};
+            const double *q[3] = {q0, q1, q2};
+            RT<T> *r[3] = {r0, r1, r2};
+#pragma unroll
+            for (int e = 0; e < 3; e++)
+                if ((m >> e) & 1u) {
+                    const RT<T> rt = (RT<T>)((double)b[e][c] - q[e][cs]);
+                    r[e][cs] = rt;
+                    mx = fmax(mx, fabs((double)rt));
+                }
+        }
+    }
+    const double bm = block_max_256(mx, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) {
+        const unsigned bl = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int sl = sc.slot0 + (int)(bl % (unsigned)sc.nslot) + (sc.nbank > 1 ? (int)((bl / (unsigned)sc.nslot) % (unsigned)sc.nbank) * sc.bstride : 0);
+        atomic_max_nonneg(sc.rmax(0) + sl, bm);
+    }
+}
+// x + xacc -> velocity grid over a launch box
+template <typename T>
+__global__ void k_plane_writeback(Lay L, int swz, const T *__restrict__ x, const double *__restrict__ acc, float *__restrict__ o) {
+    IJK_OR_RETURN(L);
+    o[c] = (float)(acc[c] + (double)x[swz ? sidx(L, i, j, k) : c]);
+}
+// the three fp64 scratch arrays of the plane residual (plain layout), allocated on first use
+static int plane_q64_reserve(flipv_context *c) {
+    if (c->vQ64[0]) return FLIPV_OK;
+    const size_t n = c->L.n + 2 * c->L.guard;
+    for (int m = 0; m < 3; m++) {
+        void *q = nullptr;
+        hipError_t e = hipMalloc(&q, n * sizeof(double));
+        if (e != hipSuccess) { c->err = std::string("hipMalloc(fp64 residual scratch): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
+        c->allocs.push_back(q);
+        HIPCHK(c, hipMemsetAsync(q, 0, n * sizeof(double), c->stream));
+        c->vQ64[m] = (double *)q + c->L.guard;
+    }
+    return FLIPV_OK;
+}
+template <typename T>
+static void plane_flush(flipv_context *c, const Lay &R, int mode) {
+    hipLaunchKernelGGL((k_plane_flush<T>), GRID3(R), 0, c->stream, R, (const uint8_t *)c->vRowMask, c->vSwz, (T *)c->vX[0], (T *)c->vX[1], (T *)c->vX[2], c->vXacc[0], c->vXacc[1], c->vXacc[2], mode);
+}
+// xacc += x (flushMode, as fv_brick_refine), r = b - A_outer xacc in fp64, max|r| into rmax(0) of a cleared scalar block
+template <typename T>
+static int fv_plane_refine(flipv_context *c, const Lay &R, const PcgScal &sc, size_t scalBytes, bool outerExact, int flushMode) {
+    int rc = plane_q64_reserve(c);
+    if (rc) return rc;
+    plane_flush<T>(c, R, flushMode);
+    HIPCHK(c, hipMemsetAsync(sc.base, 0, scalBytes, c->stream));
+    if (sc.nbank > 1) HIPCHK(c, hipMemsetAsync(sc.base + sc.bstride, 0, (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double), c->stream));
+    if (c->comm) {
+        const HaloArray xa[3] = {{c->vXacc[0], sizeof(double)}, {c->vXacc[1], sizeof(double)}, {c->vXacc[2], sizeof(double)}};
+        if ((rc = fv_halo_copy(c, xa, 3, 1))) return rc;
+    }
+    // q64 = A_outer xacc with the solver's own SpMV kernel in fp64 (no scalars: an unconditional launch without dot products)
+    PcgSys<double, 3> v;
+    v.swz = c->vSwz; v.mask = c->vRowMask; v.mlist = c->mlistV;
+    v.diag[0] = c->vDiagU; v.diag[1] = c->vDiagV; v.diag[2] = c->vDiagW;
+    for (int m = 0; m < 3; m++) { v.x[m] = nullptr; v.r[m] = nullptr; v.q[m] = c->vQ64[m]; v.s[m] = c->vXacc[m]; }
+    PcgScal none;
+    memset(&none, 0, sizeof(none));
+    const int keepOp = c->vOperatorExact, keepTiming = c->prm.kernel_timing;
+    c->vOperatorExact = outerExact ? 1 : 0;
+    c->prm.kernel_timing = 0;
+    if (c->vwV == 4) launch_visc_spmv<double, 4>(c, none, 0, 0, c->nActiveV, &v, 0); else launch_visc_spmv<double, 2>(c, none, 0, 0, c->nActiveV, &v, 0);
+    c->vOperatorExact = keepOp;
+    c->prm.kernel_timing = keepTiming;
+    hipLaunchKernelGGL((k_plane_residual_finish<T>), GRID3(R), 0, c->stream, R, (const uint8_t *)c->vRowMask, c->vSwz, (const float *)c->vB[0], (const float *)c->vB[1], (const float *)c->vB[2],
+                       (const double *)c->vQ64[0], (const double *)c->vQ64[1], (const double *)c->vQ64[2], (RT<T> *)c->vR[0], (RT<T> *)c->vR[1], (RT<T> *)c->vR[2], sc);
+    return fv_allreduce_scalars(c, sc.rmax(0), NSLOT);
 }
 
 template <typename T>
@@ -710,7 +820,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         hipLaunchKernelGGL(k_visc_setup<T>, GRID3(RS), 0, c->stream, RS, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                            c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, refDiag,
-                           brick ? 1 : 0, c->LB, c->vMaskB, brick ? c->vB[0] : nullptr, brick ? c->vB[1] : nullptr, brick ? c->vB[2] : nullptr);
+                           brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2]);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));   // max|rhs|, max|u| over the rows
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // h_flags[2] = row count
@@ -795,7 +905,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // The same flush / recompute / restart step rescues any fp32 brick solve the stall guard of PcgScal stops (either operator, either
     // preconditioner); the diagonal loop applies A_ref directly and is only restarted when it stalls (it converges superlinearly:
     // a restart costs it ~2 000 iterations at 256^3).
-    const bool canRefine = brick && std::is_same<T, float>::value;
+    const bool canRefine = std::is_same<T, float>::value && (brick || c->vwV == 4);   // bricks: k_viscosity_brick.hip; planes: fv_plane_refine above
     const bool staged = canRefine && refDiag;
     const bool useAcc = canRefine;
     if (c->comm) anyActive = rowsAll > 0.0 ? 1 : 0;   // (rows somewhere = an active tile / brick somewhere)
@@ -817,7 +927,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // the operator the PCG loop applies (and the multigrid hierarchy is built from): under the multigrid always the exact one -- with the defect
         // correction towards the reference's around it where that exists (fp32 bricks), without it on the plane layouts (block contexts)
         c->vOperatorExact = (refDiag && !useMg) ? 0 : 1;
-        if (useAcc && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
+        if (useAcc && brick && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
+        if (useAcc && !brick) plane_flush<T>(c, R0, 4);
         int itersDone = 0, corrections = 0;
         bool correctionDue = false;
         double resBeforeStage = 0.0;
@@ -847,11 +958,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // a correction stage's share 1e-2 (2e-2 behind a stage 1 that ran to the final tolerance), its budget, and how many stages.
         // MORE THAN ONE STAGE where the system is stiff: a stage contracts the distance to the reference operator's solution by |A^-1 E|, which is the
         // 1.5e-4 of the 256^3 / nu = 5 scene (one stage: 2e-5) but grows with nu dt/dx^2 -- at 1.2e5 ... 1.3e5 (BASELINE config 4's regime) one stage
-        // leaves 1.5e-4 ... 4e-4 on the goldens cut there (tests/golden: bunny64_nu3000, honey96_nu1422), two stages 2e-5 ... 6e-5 (profiles/r4/stiff_regime_scan.log).
+        // leaves 1.5e-4 ... 2.9e-4 on the goldens cut there (tests/golden: bunny64_nu3000, honey96_nu1422), two stages 5e-7 ... 6e-6 for 40-50 % more
+        // iterations (profiles/r4/stiff_regime_scan.log: looser shares -- 3e-2, 1e-1 -- or three looser stages cost about the same and are less even across
+        // the two scenes, because a stage's target is a share of a max-norm that sliver rows dominate).
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
         const double f1 = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : 300.0;
         const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5;
-        const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 96;
+        const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 200;   // (round 3: 48.  A first stage takes 7-30 iterations, a second one at nu dt/dx^2 = 1.3e5 100-150)
         const int rounds = c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : (stiffNow > 2.0e4 ? 2 : 1);
         const double tolMain = (innerDiffers && stiffNow <= gate) ? f1 * tolFinal : tolFinal;
         const double f2 = c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (tolMain > tolFinal ? 1e-2 : 2e-2);
@@ -859,7 +972,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
         auto recompute_residual = [&](int flushMode) -> int {   // flushMode 1: x is kept beside the accumulator until the caller has looked at the residual (fv_brick_flush_settle)
-            { const int rcr = fv_brick_refine<T>(c, sc, scalBytes, !refDiag, flushMode); if (rcr) return rcr; }   // (several ranks: with the accumulator's halo copy and the all-reduce of max|r|)
+            { const int rcr = brick ? fv_brick_refine<T>(c, sc, scalBytes, !refDiag, flushMode) : fv_plane_refine<T>(c, R0, sc, scalBytes, !refDiag, flushMode); if (rcr) return rcr; }   // (several ranks: with the accumulator's halo copy and the all-reduce of max|r|)
             refinements++;
             hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, 0, bmax);
             HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -963,7 +1076,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         bool tookBack = false;
         if (correction) {   // the tentative flush: confirmed, or taken back when the stage made things worse (an fp32 loop that broke down)
             tookBack = res > defectBefore;
-            fv_brick_flush_settle<T>(c, sc, tookBack);
+            if (brick) fv_brick_flush_settle<T>(c, sc, tookBack); else plane_flush<T>(c, R0, tookBack ? 2 : 3);
             if (tookBack) {
                 if (c->prm.verbose) fprintf(stderr, "viscosity solve %ld: the correction stage raised the fp64 residual (%.3g -> %.3g): taken back\n", c->viscSolves, defectBefore, res);
                 corrStatus = 3; res = defectBefore;
@@ -1035,6 +1148,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         float *uvw[3] = {c->U, c->V, c->W};
         for (int m = 0; m < 3; m++) {
             if (brick) fv_brick_writeback<T>(c, R0, m, useAcc, uvw[m]);   // x (+ the fp64 accumulator refinements / replacements flushed it into)
+            else if (useAcc && refinements > 0) hipLaunchKernelGGL(k_plane_writeback<T>, GRID3(R0), 0, c->stream, R0, c->vSwz, (const T *)v.x[m], (const double *)c->vXacc[m], uvw[m]);
             else if (c->vSwz) hipLaunchKernelGGL(k_unswizzle_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);
             else if (c->pgrid[0] > 1 || c->pgrid[1] > 1) hipLaunchKernelGGL(k_box_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);   // only what the rank owns: its i / j halo holds the neighbours' velocities
             else hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[m] + off, uvw[m] + off, cnt);
@@ -1043,7 +1157,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if ((rc = fv_halo_copy(c, uv, 3, 1))) return rc;  // the pressure rhs at plane k1-1 reads W(k1)
     }
     // the accumulator is zero between solves (its halo reads rely on it)
-    if (useAcc && nontrivial && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
+    if (useAcc && nontrivial && !brick && refinements > 0) plane_flush<T>(c, R0, 4);
+    if (useAcc && nontrivial && brick && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
     HIPCHK(c, hipGetLastError());
     if (c->prm.kernel_timing) fv_ev_collect(c);
     if (info) *info = li;

@@ -160,7 +160,7 @@ typedef struct flipv_params {
     float viscosity_stage1_factor;          /* [300] stage 1 stops at this multiple (>= 1) of viscosity_tolerance x max|rhs|; 1 = the strict solve: stage 1 to
                                                viscosity_tolerance itself (bench.py: mode_b_strict) */
     float viscosity_stage2_factor;          /* [1e-2; 2e-2 where stage 1 ran to viscosity_tolerance] a correction stage's target as a share of the defect it starts from */
-    int viscosity_stage2_max_iterations;    /* [96] iteration budget of ONE correction stage (inside viscosity_max_iterations overall) */
+    int viscosity_stage2_max_iterations;    /* [200] iteration budget of ONE correction stage (inside viscosity_max_iterations overall) */
     int viscosity_stage2_rounds;            /* [1; 2 where nu dt/dx^2 > 2e4] correction stages at most: each contracts the distance to the reference operator's solution
                                                by |A^-1 (A_ref - A)|, which is ~1e-3 at nu dt/dx^2 = 3e3 and ~4e-2 at 1.3e5 */
     float viscosity_two_stage_max_stiffness;/* [2e5] nu dt/dx^2 up to which stage 1 stops early (beyond: the fp32 loop's accuracy floor, stage 1 runs to viscosity_tolerance) */

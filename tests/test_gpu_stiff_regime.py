@@ -68,3 +68,51 @@ def test_one_correction_stage_misses_the_bar_there(name, N, boundary, liquids):
     print("%s with one correction stage: velocity error %.2e" % (name, err))
     assert 1e-4 < err < 1e-3
     c.close()
+
+
+def dense_scene(N, top):
+    """a liquid box that fills most of the default box boundary: x, z in [0.06, 0.94], y in [0.06, top] (counter-seeded by the host library)"""
+    from flipviscosity3d_amd import hostapi as H
+    from test_gpu_wide import box_mesh
+    dx = float(np.float32(1.0 / N))
+    s = H.FluidSimulation()
+    s.initialize(N, N, N, dx)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 4)
+    s.addLiquid(box_mesh((0.06, 0.06, 0.06), (0.94, top, 0.94)))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    return dx, solid, P
+
+
+def test_dense_viscous_scene_defaults_against_converged_oracle(oracle):
+    """Where the liquid fills the box the solver's arrays stay in the PLANE layout (bricks are for sparse liquids) -- and until round 4 that layout had
+    no fp64 accumulator, so its default solve applied the EXACT operator and silently skipped the defect correction towards the reference's.  48^3, the
+    liquid in 46 % of the domain, nu = 150 (nu dt/dx^2 = 3 456: the headline's stiffness), the particles given a shear so that the viscous solve has
+    work to do; NO parameter set; two substeps, the second started from the oracle's particles; against the oracle with its cap lifted: <= 1e-4, and the
+    solve must report the plane layout, the multigrid and a correction stage."""
+    from flipviscosity3d_amd.capi import Context
+    N, nu, dt = 48, 150.0, 0.01
+    dx, solid, P = dense_scene(N, 0.66)
+    P = P.copy()
+    P[:, 3] = 0.8 * np.sin(7.0 * P[:, 1]) * np.cos(5.0 * P[:, 2]); P[:, 4] = -0.3 * np.cos(6.0 * P[:, 0]); P[:, 5] = 0.5 * np.sin(4.0 * P[:, 0] + 3.0 * P[:, 1])
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid); c.set_viscosity(nu)
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid); o.set_viscosity(nu); o.set_solver_limits(vmaxiter=400000)
+    o.particles = P
+    for t in range(2):
+        c.particles = o.particles
+        st = c.substep(dt)
+        sec, vi, pi = o.substep(dt)
+        v = st["viscosity"]
+        fill = v["rows"] / (3.0 * N ** 3)
+        num = max(np.abs(c.grid(n).astype(np.float64) - o.grid(n)).max() for n in "UVW")
+        den = max(np.abs(o.grid(n)).max() for n in "UVW")
+        print("dense 48^3 substep %d: rows fill %.2f, layout %d, %d iterations (%d in corrections; oracle %d), status %d / %d, defect %.1e, velocity error %.2e" % (
+            t, fill, v["layout"], v["iterations"], v["correction_iterations"], vi["iterations"], v["status"], v["correction_status"], v["defect_residual"] / v["rhs_norm"], num / den))
+        assert vi["status"] == 0
+        assert fill > 0.40 and v["layout"] in (0, 1) and v["preconditioner"] == 1, v
+        assert v["status"] == 0 and v["defect_residual"] > 0.0 and v["correction_status"] == 1, v
+        assert num / den <= 1e-4, (t, num / den)
+    c.close()
+    o.close()
