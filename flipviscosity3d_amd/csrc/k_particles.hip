@@ -644,23 +644,42 @@ int fv_particle_sdf(flipv_context *c) {
     c->liqPrevValid = c->liqValid;
     for (int a = 0; a < 3; a++) { c->liqPrevLo[a] = c->liqLo[a]; c->liqPrevHi[a] = c->liqHi[a]; }
     c->liqValid = 0;
-    // (not in a multi-rank run: a neighbour's particles scatter into this rank's boundary cells, which its own bins know nothing of)
-    if (c->inSubstep && c->np && !c->prm.unbinned_scatter && !(c->comm && c->comm->nranks > 1)) {
-        int rcb = fv_bin_particles(c);
-        if (rcb) return rcb;
-        const BinGrid B = bin_grid(c);
-        int *bb = c->d_flags + 8;   // 6 ints: min x, y, z, max x, y, z of the non-empty bins (d_flags[8..13]; [12], [13] are rewritten by the run builder later)
-        HIPCHK(c, hipMemsetAsync(bb, 0x7f, 3 * sizeof(int), c->stream));       // minima start at 0x7f7f7f7f
-        HIPCHK(c, hipMemsetAsync(bb + 3, 0xff, 3 * sizeof(int), c->stream));   // maxima at -1
-        const int nt = B.nbx * B.nby * B.nbz;
-        hipLaunchKernelGGL(k_bin_bbox, dim3(cdiv(nt, 256)), dim3(256), 0, c->stream, B, c->binCnt, bb);
-        int h[6];
-        HIPCHK(c, hipMemcpyAsync(h, bb, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (h[3] >= 0) {
+    // Several ranks: a neighbour's particles scatter into this rank's boundary cells, which its own bins know nothing of -- so the box is the UNION of
+    // the ranks' boxes (one all-gather of 7 values per substep; every rank then clips it to what it allocates, fv_range_liquid): whatever lies outside it
+    // is trivial on every rank, halo entries included.
+    const bool multi = c->comm && c->comm->nranks > 1;
+    if (c->inSubstep && (c->np || multi) && !c->prm.unbinned_scatter) {
+        double mine[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // [valid, lo x y z, hi x y z]
+        if (c->np) {
+            int rcb = fv_bin_particles(c);
+            if (rcb) return rcb;
+            const BinGrid B = bin_grid(c);
+            int *bb = c->d_flags + 8;   // 6 ints: min x, y, z, max x, y, z of the non-empty bins (d_flags[8..13]; [12], [13] are rewritten by the run builder later)
+            HIPCHK(c, hipMemsetAsync(bb, 0x7f, 3 * sizeof(int), c->stream));       // minima start at 0x7f7f7f7f
+            HIPCHK(c, hipMemsetAsync(bb + 3, 0xff, 3 * sizeof(int), c->stream));   // maxima at -1
+            const int nt = B.nbx * B.nby * B.nbz;
+            hipLaunchKernelGGL(k_bin_bbox, dim3(cdiv(nt, 256)), dim3(256), 0, c->stream, B, c->binCnt, bb);
+            int h[6];
+            HIPCHK(c, hipMemcpyAsync(h, bb, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (h[3] >= 0) {
+                mine[0] = 1.0;
+                for (int a = 0; a < 3; a++) {
+                    mine[1 + a] = B.c0[a] + h[a] * BIN_T - LIQ_MARGIN;
+                    mine[4 + a] = B.c0[a] + (h[3 + a] + 1) * BIN_T + LIQ_MARGIN;
+                }
+            }
+        }
+        double all[7 * NSLOT];
+        const int nr = multi ? c->comm->nranks : 1;
+        if (multi) { const int rcg = fv_allgather_f64(c, mine, 7, all); if (rcg) return rcg; }
+        else for (int q = 0; q < 7; q++) all[q] = mine[q];
+        for (int r = 0; r < nr; r++) {
+            if (all[7 * r] == 0.0) continue;
             for (int a = 0; a < 3; a++) {
-                c->liqLo[a] = B.c0[a] + h[a] * BIN_T - LIQ_MARGIN;
-                c->liqHi[a] = B.c0[a] + (h[3 + a] + 1) * BIN_T + LIQ_MARGIN;
+                const int lo = (int)all[7 * r + 1 + a], hi = (int)all[7 * r + 4 + a];
+                if (!c->liqValid || lo < c->liqLo[a]) c->liqLo[a] = lo;
+                if (!c->liqValid || hi > c->liqHi[a]) c->liqHi[a] = hi;
             }
             c->liqValid = 1;
         }

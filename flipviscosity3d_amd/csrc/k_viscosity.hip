@@ -956,18 +956,27 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // this rule gives 1.5e-4 / 1.6e-4 -- nothing pins those regimes to 1e-4, and this is the cheaper and the more robust of the two.
         // The constants of the rule are flipv_params fields since FLIPV_VERSION 4 (0 = these defaults): stage 1's factor 300, the stiffness gate 2e5,
         // a correction stage's share 1e-2 (2e-2 behind a stage 1 that ran to the final tolerance), its budget, and how many stages.
-        // MORE THAN ONE STAGE where the system is stiff: a stage contracts the distance to the reference operator's solution by |A^-1 E|, which is the
-        // 1.5e-4 of the 256^3 / nu = 5 scene (one stage: 2e-5) but grows with nu dt/dx^2 -- at 1.2e5 ... 1.3e5 (BASELINE config 4's regime) one stage
-        // leaves 1.5e-4 ... 2.9e-4 on the goldens cut there (tests/golden: bunny64_nu3000, honey96_nu1422), two stages 5e-7 ... 6e-6 for 40-50 % more
-        // iterations (profiles/r4/stiff_regime_scan.log: looser shares -- 3e-2, 1e-1 -- or three looser stages cost about the same and are less even across
-        // the two scenes, because a stage's target is a share of a max-norm that sliver rows dominate).
+        // THE SHARE TIGHTENS WHERE THE SYSTEM IS STIFF.  A stage contracts the distance to the reference operator's solution by |A^-1 E| at best, and only as
+        // far as its own target lets it; the defect grows with nu dt/dx^2.  Measured against the reference / the oracle run to convergence, every substep
+        // started from the reference's particles, worse of two substeps, iterations of the second (profiles/r4/stiff_regime_scan*.log):
+        //     nu dt/dx^2   one stage to 1e-2     one stage to 3e-3     one stage to 1e-3     two stages to 1e-2
+        //     8 192        1.9e-5  104           6.3e-6  112           1.4e-6  129           3e-7    193
+        //     20 480       2.3e-5  131           9e-6    141           1.8e-6  162           8e-7    237
+        //     32 768       3.0e-5  138           2.3e-5  147           2.9e-6  181           4.5e-7  224
+        //     52 429       1.4e-4  164           1.6e-5  193           1.4e-5  200           1.8e-6  261
+        //     81 920       8.9e-5  166           4.8e-5  194           1.2e-5  203           6e-7    262
+        //     122 880      1.7e-4  174           2.9e-5  210           2.8e-5  214           5.5e-6  260      (tests/golden/bunny64_nu3000)
+        //     131 070      2.9e-4  198           2.5e-5  234           1.1e-5  255           5e-7    339      (tests/golden/honey96_nu1422: config 4's scene)
+        // Round 3 shipped the first column everywhere (with a budget of 48): it misses the 1e-4 bar from 5e4 on.  Taken: ONE stage, to 1e-2 of the defect up
+        // to nu dt/dx^2 = 2e4 (the headline's 3 277: 2.3e-5 at 256^3) and to 1e-3 beyond -- <= 3e-5 everywhere for +25 % iterations where two stages cost +60 %.
+        // viscosity_stage2_rounds = 2 buys the last column.
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
         const double f1 = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : 300.0;
         const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5;
         const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 200;   // (round 3: 48.  A first stage takes 7-30 iterations, a second one at nu dt/dx^2 = 1.3e5 100-150)
-        const int rounds = c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : (stiffNow > 2.0e4 ? 2 : 1);
+        const int rounds = c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : 1;
         const double tolMain = (innerDiffers && stiffNow <= gate) ? f1 * tolFinal : tolFinal;
-        const double f2 = c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (tolMain > tolFinal ? 1e-2 : 2e-2);
+        const double f2 = c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (stiffNow > 2.0e4 ? 1e-3 : (tolMain > tolFinal ? 1e-2 : 2e-2));
         if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars

@@ -45,27 +45,27 @@ def test_default_params_at_config4_stiffness_unchained(name, N, boundary, liquid
         assert v["preconditioner"] == 1 and v["layout"] == 2 and v["iterations"] <= 700, v     # inside the stock cap, where the reference needs 2 200 - 4 100
         assert v["status"] == 0 and v["correction_status"] == 1 and v["defect_residual"] > 0.0, v   # every stage reached its target
         assert st["pressure"]["status"] in (0, 3)
-        assert err <= 1e-4, (t, err)
+        assert err <= 5e-5, (t, err)    # (the bar is 1e-4; measured 1e-5 ... 3e-5)
         d = np.abs(c.particles.astype(np.float64).sum(axis=0) - g["s%d_particles_sum" % t]) / len(P)
         assert d[:3].max() <= 1e-6 and d[3:].max() <= 1e-5, d
     c.close()
 
 
 @pytest.mark.parametrize("name,N,boundary,liquids", STIFF[1:])
-def test_one_correction_stage_misses_the_bar_there(name, N, boundary, liquids):
-    """what round 3 shipped (one correction stage of at most 48 iterations) measured against the same fixture: it does NOT meet 1e-4 on the first
-    substep -- the reason the rule takes two stages beyond nu dt/dx^2 = 2e4.  (If this starts passing the bar, the second stage can go.)"""
+def test_round3_rule_misses_the_bar_there(name, N, boundary, liquids):
+    """what round 3 shipped (one correction stage to 1 % of the defect in at most 48 iterations) measured against the same fixture: it does NOT meet 1e-4
+    on the first substep -- the reason the stage's share is 0.1 % beyond nu dt/dx^2 = 2e4.  (If this starts passing the bar, the looser share can come back.)"""
     from flipviscosity3d_amd.capi import Context
     g = Golden(name)
     dx, solid, P = build_host_scene(N, boundary, liquids)
     c = Context(N, N, N, dx)
     c.set_solid_sdf(solid)
     c.set_viscosity(float(g["nu"]))
-    c.set_params(viscosity_stage2_rounds=1, viscosity_stage2_max_iterations=48)
+    c.set_params(viscosity_stage2_rounds=1, viscosity_stage2_factor=1e-2, viscosity_stage2_max_iterations=48)
     c.particles = P
     c.substep(g.dt)
     err = probe_error(c, g, 0)
-    print("%s with one correction stage: velocity error %.2e" % (name, err))
+    print("%s with round 3's rule: velocity error %.2e" % (name, err))
     assert 1e-4 < err < 1e-3
     c.close()
 
@@ -113,6 +113,34 @@ def test_dense_viscous_scene_defaults_against_converged_oracle(oracle):
         assert vi["status"] == 0
         assert fill > 0.40 and v["layout"] in (0, 1) and v["preconditioner"] == 1, v
         assert v["status"] == 0 and v["defect_residual"] > 0.0 and v["correction_status"] == 1, v
+        assert num / den <= 1e-4, (t, num / den)
+    c.close()
+    o.close()
+
+
+@pytest.mark.parametrize("nu", [500.0, 1280.0, 2000.0])
+def test_default_params_between_headline_and_config4_stiffness(oracle, nu):
+    """nu dt/dx^2 = 20 480, 52 429 (the 1024 x 512 x 512 sheet's) and 81 920 on config 1's scene at 64^3, against the live oracle with its cap lifted (2 100 -
+    2 700 iterations), NO parameter set, both substeps started from the oracle's particles: <= 1e-4 (measured 2e-6 ... 2.3e-5; round 3's rule: 1.4e-4 at 52 429)."""
+    from flipviscosity3d_amd.capi import Context
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid); o.set_viscosity(nu); o.set_solver_limits(vmaxiter=400000)
+    o.particles = P
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid); c.set_viscosity(nu)
+    for t in range(2):
+        c.particles = o.particles
+        sec, vi, pi = o.substep(0.01)
+        st = c.substep(0.01)
+        v = st["viscosity"]
+        num = max(np.abs(c.grid(n).astype(np.float64) - o.grid(n)).max() for n in "UVW")
+        den = max(np.abs(o.grid(n)).max() for n in "UVW")
+        print("64^3 nu %g (nu dt/dx^2 = %.0f) substep %d: %d iterations (%d in the correction stage; oracle %d), status %d / %d, velocity error %.2e" % (
+            nu, nu * 0.01 / dx ** 2, t, v["iterations"], v["correction_iterations"], vi["iterations"], v["status"], v["correction_status"], num / den))
+        assert vi["status"] == 0 and vi["iterations"] > 700
+        assert v["status"] == 0 and v["correction_status"] == 1 and v["iterations"] <= 700, v
         assert num / den <= 1e-4, (t, num / den)
     c.close()
     o.close()
