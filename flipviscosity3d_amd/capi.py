@@ -71,7 +71,7 @@ class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("rhs_norm", C.c_double),
                 ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
                 ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int), ("defect_residual", C.c_double),
-                ("correction_iterations", C.c_int), ("correction_status", C.c_int)]
+                ("correction_iterations", C.c_int), ("comm_bytes_setup", C.c_double), ("comm_bytes_per_iteration", C.c_double), ("correction_status", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -219,6 +219,7 @@ struct flipv_context {
     int viscosity_nonzero_any = 1;  // ... on any rank of the communicator (all-reduced at the start of every viscosity solve)
     int vForceMultigridOnce = 0;    // set while a diagonal solve AUTO picked and that ran into the cap is being repeated with the multigrid
     int vmgSweeps = 16;             // Jacobi sweeps on the multigrid's LDS-resident coarsest level for the current solve (viscosity_solve_t picks)
+    double commBytesSetup = 0.0, commBytesIter = 0.0;   // what the current solve's multigrid all-reduces: once, and per iteration (flipv_solve_info::comm_bytes_*)
     int vmgPackedRows = 1;          // ... and whether its cycle reads the coarse rows in the packed fp16 form (k_viscosity_mg.hip: d_row_dot) or the fp32 grids
     int facValid = 0;               // the factor arrays hold the current layout's values wherever the band was
 

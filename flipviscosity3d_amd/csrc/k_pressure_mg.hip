@@ -368,6 +368,7 @@ static int mg_allreduce_box(flipv_context *c, MgState *s, const Lay &L, const Pt
     hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, arr, s->stage, 0);
     const int rc = fv_allreduce_f32(c, s->stage, tot);
     if (rc) return rc;
+    if (narr > 1) c->commBytesSetup += (double)tot * sizeof(float); else c->commBytesIter = (double)tot * sizeof(float);
     if (into.p[0]) hipLaunchKernelGGL(k_mg_box_pack, grid, dim3(256), 0, c->stream, L, B, into, s->stage, 1);   // (no target: the caller unpacks, mg_box_take)
     return FLIPV_OK;
 }

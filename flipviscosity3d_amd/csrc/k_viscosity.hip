@@ -692,6 +692,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const Lay &L = c->L;
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
+    c->commBytesSetup = c->commBytesIter = 0.0;
     if (c->comm && c->comm->nranks > 1) {   // a rank whose box holds no viscous node must still take part in every collective of the solve
         const double mine[2] = {c->viscosity_nonzero ? 1.0 : 0.0, (double)c->viscosity_max};   // (AUTO's stiffness rule must come out the same on every rank)
         double all[2 * NSLOT];
@@ -1112,6 +1113,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     }
     li.refinements = refinements;
     li.defect_residual = defectRes;
+    li.comm_bytes_setup = c->commBytesSetup; li.comm_bytes_per_iteration = c->commBytesIter;
     li.correction_iterations = corrIters;
     li.correction_status = corrStatus;
     if (c->prm.verbose && nontrivial)

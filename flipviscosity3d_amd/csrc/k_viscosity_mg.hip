@@ -1198,6 +1198,7 @@ static int vmg_allreduce_box(flipv_context *c, VmgState *s, const VLevel &A, flo
     hipLaunchKernelGGL(k_vmg_box_pack, grid, dim3(256), 0, c->stream, A.L, A.box, g0, A.per, s->stage, 0);
     const int rc = fv_allreduce_f32(c, s->stage, tot);
     if (rc) return rc;
+    c->commBytesSetup += (double)tot * sizeof(float);
     hipLaunchKernelGGL(k_vmg_box_pack, grid, dim3(256), 0, c->stream, A.L, A.box, g0, A.per, s->stage, 1);
     return FLIPV_OK;
 }
@@ -1505,6 +1506,7 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
             if (listed) hipLaunchKernelGGL(k_vmg_restrict_list, dim3(cdiv(s->lev[l].nstrips, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, s->stage);
             else hipLaunchKernelGGL(k_vmg_restrict_box, dim3(cdiv(B.hi[0] - B.lo[0], 64), cdiv(B.hi[1] - B.lo[1], 4), 3u * (unsigned)(B.hi[2] - B.lo[2])), dim3(64, 4, 1), 0, c->stream,
                                     (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, s->stage);
+            c->commBytesIter = (double)(3 * n) * sizeof(float);
             return fv_allreduce_f32(c, s->stage, 3 * n);
         };
         auto global_rhs_take = [&](int l, int first) {   // back into b (and x = omega b/d: the first sweep)
@@ -1621,7 +1623,11 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         return FLIPV_OK;
     };
     // where in a chunk of `every` iterations a replacement can fall due (the kernels decide exactly, from the iteration number)
-    auto may_replace = [&](int e) { return replace_period > 0 && ((e + 1) % (replace_period < every ? replace_period : every)) == 0; };
+    // (the kernels decide from the ABSOLUTE iteration number; a replayed chunk does not know where it sits in the solve -- its first position shifts with the
+    // directly launched first iteration, and a period that does not divide the chunk length falls due at a different position every replay -- so a chunk
+    // carries the (mostly empty) replacement launches at EVERY position; the kernel-by-kernel loop launches them where they are due)
+    auto may_replace = [&](int e) { (void)e; return replace_period > 0; };
+    auto due_at = [&](int it) { return replace_period > 0 && ((it + 1) % replace_period) == 0; };
     const bool graph = !c->comm && !c->prm.kernel_timing && !c->prm.no_graph_replay;
     if (graph) {
         hipGraph_t g = nullptr;
@@ -1655,7 +1661,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         while (it < cap && conv < 0) {
             const int stop = it + every < cap ? it + every : cap;
             for (; it < stop; it++)
-                if ((rc = iteration(it, may_replace(it % every)))) return rc;
+                if ((rc = iteration(it, due_at(it)))) return rc;
             HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             conv = c->h_flags[0];

@@ -380,10 +380,13 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
     // all-reduce in a multi-rank run; a poll costs a read-back and a host wake-up (~14 us)
     const int every = c->prm.check_every > 0 ? c->prm.check_every : (c->comm ? 8 : 32);
     int conv = -1, rc;
-    auto post_due = [&](int e) { return postPeriod > 0 && ((e + 1) % (postPeriod < every ? postPeriod : every)) == 0; };   // e: position inside a chunk of `every`
+    // post: a replayed chunk (it = -1) carries the launch at every position -- the kernels re-test the absolute iteration number themselves and the chunk
+    // does not know where it sits in the solve --, the kernel-by-kernel loop launches it where it is due
+    auto post_due = [&](int it) { return postPeriod > 0 && (it < 0 || ((it + 1) % postPeriod) == 0); };
     auto launch_iter = [&](int it, int e) -> int {
         int r;
-        if (!c->comm) { spmv(0, nAct, it); update(it); if (post_due(e)) post(it); return FLIPV_OK; }
+        (void)e;
+        if (!c->comm) { spmv(0, nAct, it); update(it); if (post_due(it)) post(it); return FLIPV_OK; }
         if ((r = fv_halo_copy_begin(c, sh, nsh, 1))) return r;
         if (nInt > 0) spmv(0, nInt, it);
         if ((r = fv_halo_wait(c))) return r;

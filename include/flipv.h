@@ -188,6 +188,9 @@ typedef struct flipv_solve_info {
                             viscosity_stage1_factor x viscosity_tolerance where a correction stage follows, see exact_viscosity_operator).  0 when there
                             was no such stage */
     int correction_iterations; /* iterations spent in defect-correction stages (part of `iterations`) */
+    double comm_bytes_setup;   /* several ranks, multigrid preconditioner with the global coarse hierarchy: bytes this solve ALL-REDUCED once (the first coarse level's
+                                  operator) ... */
+    double comm_bytes_per_iteration; /* ... and per iteration (that level's right-hand side); 0 on one rank / with the diagonal */
     int correction_status;     /* 0 no correction stage; 1 every stage reached its target; 2 a stage ran into its iteration budget or stalled first (its
                                   result is kept if it lowered the fp64 residual; `status` is then 1); 3 the last stage RAISED the fp64 residual and was taken back
                                   (`status` 1) */

@@ -390,3 +390,33 @@ def test_config5_miniature_eight_slabs_along_the_long_axis():
     for c in ctxs:
         c.close()
     ref.close()
+
+
+def test_moving_liquid_default_params_unchained_after_25_reference_substeps(oracle):
+    """Every default-parameter comparison above starts from rest (at most three chained substeps).  Here the oracle runs config 1's scene (64^3 bunny drop,
+    nu = 5) for 25 substeps with its viscosity cap lifted -- the bunny is falling at 2.4 m/s and deforming --, then ONE substep is taken on both sides from
+    the oracle's particles (positions AND velocities: the whole state of a FLIP substep), the GPU with NO parameter set: velocities <= 1e-4, particles <= 1e-5."""
+    from flipviscosity3d_amd.capi import Context
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid); o.set_viscosity(5.0); o.set_solver_limits(vmaxiter=100000)
+    o.particles = P
+    for t in range(25):
+        sec, vi, pi = o.substep(0.01)
+        assert vi["status"] == 0
+    start = o.particles.copy()
+    assert np.abs(start[:, 4]).max() > 1.0            # it moves
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid); c.set_viscosity(5.0)
+    c.particles = start
+    st = c.substep(0.01)
+    sec, vi, pi = o.substep(0.01)
+    v = st["viscosity"]
+    err = vel_err(c, [o.grid(n) for n in "UVW"])
+    perr = np.abs(c.particles[:, :3] - o.particles[:, :3]).max()
+    print("moving 64^3 bunny, substep 26: viscosity %d iterations (oracle %d), status %d, velocity error %.2e, particle positions %.1e" % (v["iterations"], vi["iterations"], v["status"], err, perr))
+    assert v["status"] == 0 and st["pressure"]["status"] == 0
+    assert err <= VEL_TOL and perr <= 1e-5
+    c.close()
+    o.close()

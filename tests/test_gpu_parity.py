@@ -548,3 +548,36 @@ def test_k_marching_single_spmv_is_the_same_operator(rowl):
         assert vi["rows"] == res[0][0]["rows"] and pi["rows"] == res[0][2]["rows"]
         assert rel_maxnorm3(uvw, res[0][1]) <= 1e-5
         assert rel_maxnorm(pr, res[0][3]) <= 1e-5
+
+
+@pytest.mark.parametrize("precond", ["diagonal", "multigrid"])
+@pytest.mark.parametrize("period", [3, 4, 5])
+def test_residual_replacement_fires_under_graph_replay(precond, period):
+    """flipv_params.residual_replacement (opt-in): the replacement launches of a REPLAYED chunk re-test the absolute iteration number themselves, so they
+    must sit at every position of the chunk -- round 3 placed them by chunk position, which the directly launched first iteration shifted (period 4: never
+    fired) and which a period that does not divide the chunk length misses on most replays.  The kernel-by-kernel loop launches them where they are due: both
+    must take the SAME path through the solve -- a replacement changes the recurrence, so the iteration counts differ as soon as one of them skips one."""
+    from flipviscosity3d_amd.capi import PRECOND_DIAGONAL, PRECOND_MULTIGRID
+    g = Golden("bunny32_viscous")
+    its = []
+    for no_graph in (0, 1):
+        c = make_ctx(g, viscosity_max_iterations=3000, exact_viscosity_operator=1, residual_replacement=period, no_graph_replay=no_graph,
+                     viscosity_preconditioner=PRECOND_MULTIGRID if precond == "multigrid" else PRECOND_DIAGONAL)
+        c.set_grid("LIQUID_PHI", g["s0_phi"])
+        load_uvw(c, g.uvw(0, "force"))
+        info = c.viscosity_solve(g.dt)
+        assert info["layout"] == 2, info
+        its.append((info["iterations"], [c.grid(n) for n in "UVW"]))
+        c.close()
+    base = make_ctx(g, viscosity_max_iterations=3000, exact_viscosity_operator=1, viscosity_preconditioner=PRECOND_MULTIGRID if precond == "multigrid" else PRECOND_DIAGONAL)
+    base.set_grid("LIQUID_PHI", g["s0_phi"])
+    load_uvw(base, g.uvw(0, "force"))
+    n0 = base.viscosity_solve(g.dt)["iterations"]
+    base.close()
+    print("%s, period %d: %d iterations replayed, %d kernel by kernel, %d without replacement" % (precond, period, its[0][0], its[1][0], n0))
+    assert abs(its[0][0] - its[1][0]) <= 2, its[0][0:1] + its[1][0:1]
+    assert its[0][0] != n0 or its[1][0] == n0        # (the replacements do something: the count moves away from the plain solve's -- in both modes or in neither)
+    masks = fluid_face_masks(g["s0_phi"])
+    num = max(np.abs((a - b)[m]).max() for a, b, m in zip(its[0][1], its[1][1], masks))
+    den = max(np.abs(b[m]).max() for b, m in zip(its[1][1], masks))
+    assert num / den <= 1e-4

@@ -37,7 +37,7 @@ else:
     capi.comm_init_local(ctxs, dims)
     parts = partition.split_particles_boxes(P, dx, boxes, dims)
     print("scene %dx%dx%d, %d particles, blocks %s" % (I, J, K, len(P), dims))
-extra = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[2:] if "=" in kv}
+extra = {kv.split("=")[0]: (float(kv.split("=")[1]) if "." in kv.split("=")[1] or "e" in kv.split("=")[1] else int(kv.split("=")[1])) for kv in sys.argv[2:] if "=" in kv}
 for c, p in zip(ctxs, parts):
     if extra:
         c.set_params(**extra)
@@ -58,3 +58,7 @@ print("wall %.2f s for 3 substeps of %d ranks sharing one device" % (time.perf_c
 for r, st in enumerate(out):
     print("rank", r, {k: round(v, 2) for k, v in st["phase_ms"].items()}, "total %.1f" % st["total_ms"], "its", st["viscosity"]["iterations"], st["pressure"]["iterations"],
           "rows", st["viscosity"]["rows"], "particles", ctxs[r].num_particles)
+v, p = out[0]["viscosity"], out[0]["pressure"]
+print("viscosity solve: layout %d, preconditioner %d, %d iterations (%d in correction stages), status %d / %d; all-reduced by the global hierarchy: %.2f MB once per solve, %.3f MB per iteration" % (
+    v["layout"], v["preconditioner"], v["iterations"], v["correction_iterations"], v["status"], v["correction_status"], v["comm_bytes_setup"] / 1e6, v["comm_bytes_per_iteration"] / 1e6))
+print("pressure solve: %d iterations; all-reduced: %.2f MB once per solve, %.3f MB per iteration" % (p["iterations"], p["comm_bytes_setup"] / 1e6, p["comm_bytes_per_iteration"] / 1e6))

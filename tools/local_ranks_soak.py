@@ -7,7 +7,7 @@ from bench import build_workload
 from flipviscosity3d_amd import capi, partition
 dims = tuple(int(v) for v in sys.argv[1].split(","))
 N, wl, nu, nsub = int(sys.argv[2]), sys.argv[3], float(sys.argv[4]), int(sys.argv[5])
-extra = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[6:]}
+extra = {kv.split("=")[0]: (float(kv.split("=")[1]) if "." in kv.split("=")[1] or "e" in kv.split("=")[1] else int(kv.split("=")[1])) for kv in sys.argv[6:]}
 I, J, K, dx, solid, P = build_workload(wl, N, on_device=True)
 boxes = partition.block_boxes(I, J, K, dims)
 R = len(boxes)

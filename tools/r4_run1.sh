@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-4 measurement batch 1 (run on the GPU box through gpurun): multi-rank tests, bench lines of the four workloads, in-process 2x2x2 blocks
-O=gpurun_out/r4b; mkdir -p $O
-(timeout 1500 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_multirank_default.py tests/test_gpu_baseline_sizes.py -q --timeout 900 > $O/tests_mr.log 2>&1; echo rc=$? >> $O/tests_mr.log)
+O=gpurun_out/r4c; mkdir -p $O
+(timeout 1500 python -m pytest tests/test_gpu_multirank.py tests/test_gpu_multirank_default.py tests/test_gpu_baseline_sizes.py tests/test_gpu_stiff_regime.py tests/test_gpu_fullsize.py -q --timeout 900 > $O/tests_mr.log 2>&1; echo rc=$? >> $O/tests_mr.log)
 tail -4 $O/tests_mr.log
 B="--gpu-setup --no-cpu-baseline --no-dense"
 timeout 300 python bench.py --steps 20 --warmup 5 $B > $O/bench256_default_20.json 2> $O/bench256_default_20.err
