@@ -58,7 +58,7 @@ class Params(C.Structure):
                 ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int),
                 ("viscosity_update_grid_cap", C.c_int), ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int),
                 ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
-                ("multigrid_rank_local", C.c_int),
+                ("multigrid_rank_local", C.c_int), ("multigrid_distributed_levels", C.c_int),
                 ("viscosity_stage1_factor", C.c_float), ("viscosity_stage2_factor", C.c_float), ("viscosity_stage2_max_iterations", C.c_int),
                 ("viscosity_stage2_rounds", C.c_int), ("viscosity_two_stage_max_stiffness", C.c_float),
                 ("reserved", C.c_int * 1)]

@@ -387,6 +387,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!fin(p->viscosity_mg_omega_first, 0.0f, 2.0f) || !fin(p->viscosity_mg_omega_second, 0.0f, 2.0f)) bad = "viscosity_mg_omega_*";
         else if (!in(p->no_liquid_box, 0, 1) || !in(p->no_comm_overlap, 0, 1) || !in(p->verbose, 0, 2) || !in(p->no_graph_replay, 0, 1) || !in(p->unbinned_scatter, 0, 1) ||
                  !in(p->beta_from_conjugacy, 0, 1) || !in(p->multigrid_rank_local, 0, 1)) bad = "a 0/1 switch";
+        else if (!in(p->multigrid_distributed_levels, -1, 1)) bad = "multigrid_distributed_levels";
         else if (!in(p->grid_cap, 0, 1 << 20) || !in(p->viscosity_spmv_grid_cap, 0, 1 << 20) || !in(p->viscosity_update_grid_cap, 0, 1 << 20)) bad = "a grid cap";
         else if (p->viscosity_lane_width != 0 && p->viscosity_lane_width != 2 && p->viscosity_lane_width != 4) bad = "viscosity_lane_width";
         else if (!in(p->spmv_run_length, -1, 64) || p->spmv_run_length == 1) bad = "spmv_run_length";

@@ -43,6 +43,10 @@ int fv_halo_copy_begin(flipv_context *c, const HaloArray *arr, int n, int H);  /
 int fv_halo_wait(flipv_context *c);                                             // c->stream waits for that exchange
 enum { HALO_MIN_F32 = 0, HALO_ADD_F32 = 1 };
 int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi, int op);
+// The same two exchanges for fp32 arrays of a DISTRIBUTED coarse level of the viscosity multigrid (cidx layout over the level's global Lay LC): this rank owns
+// the level's indices [olo, ohi) -- the boxes of the ranks tile the level like their blocks tile the domain --, H entries travel.  add = 0: owner -> neighbours
+// (copy into their halo entries); add = 1: neighbours -> owner (what they accumulated in their halo entries is added to the owner's).  n <= 6 arrays per call.
+int fv_halo_level(flipv_context *c, const Lay &LC, const int olo[3], const int ohi[3], float *const *arr, int n, int H, int add);
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n);
 int fv_allreduce_f32(flipv_context *c, float *dev, size_t n);    // in-place sum over the ranks, on c->stream
 int fv_migrate_particles(flipv_context *c);

@@ -116,7 +116,7 @@ struct DirSet {
     unsigned long long scnt[HALO_MAXDIR], rcnt[HALO_MAXDIR];   // entries of the boxes
 };
 // blockIdx.y = direction; recv = 0: sbox -> staging + soff (pack); recv = 1: staging + roff -> rbox with `mode` (1 copy, 2 min, 3 add)
-__global__ void k_halo_dirs(HaloSet hs, Lay L, Lay LB, DirSet D, char *__restrict__ staging, int recv, int mode) {
+__global__ void k_halo_dirs(HaloSet hs, Lay L, Lay LB, DirSet D, char *__restrict__ staging, int recv, int mode) {   // (hs.lay: 0 gidx(L), 1 bidx(LB), 2 cidx(LB): a coarse level's Lay travels in LB's place)
     const int q = blockIdx.y;
     const HBox b = recv ? D.rbox[q] : D.sbox[q];
     const int w = b.hi[0] - b.lo[0], h = b.hi[1] - b.lo[1], d = b.hi[2] - b.lo[2];
@@ -125,7 +125,7 @@ __global__ void k_halo_dirs(HaloSet hs, Lay L, Lay LB, DirSet D, char *__restric
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < cnt; t += stride) {
         const int i = b.lo[0] + (int)(t % (size_t)w), j = b.lo[1] + (int)((t / (size_t)w) % (size_t)h), k = b.lo[2] + (int)(t / ((size_t)w * h));
-        const size_t cp = gidx(L, i, j, k), cb = bidx(LB, i, j, k);
+        const size_t cp = hs.lay[0] == 2 ? 0 : gidx(L, i, j, k), cb = hs.lay[0] == 2 ? cidx(LB, i, j, k) : bidx(LB, i, j, k);   // (an exchange is all-level or all-fine)
         for (int a = 0; a < hs.n; a++) {
             const size_t c = hs.lay[a] ? cb : cp;
             char *st = base + (size_t)a * cnt * 8;
@@ -155,8 +155,9 @@ __global__ void k_halo_dirs(HaloSet hs, Lay L, Lay LB, DirSet D, char *__restric
 // per axis as [lo, hi) pairs by the caller: a copy sends owned entries and receives halo entries, a reduction the other way
 // round); with offset 0 both are the owned range.
 struct AxisRanges { int sLo[2], sHi[2], rLo[2], rHi[2]; };   // [lo, hi) towards the lower / upper neighbour
-static void build_dirs(const flipv_context *c, const AxisRanges R[3], int narr, DirSet *D, size_t *sendBytes, size_t *recvBytes) {
-    const Lay &L = c->L;
+static void build_dirs(const flipv_context *c, const AxisRanges R[3], int narr, DirSet *D, size_t *sendBytes, size_t *recvBytes, const int *ownLo = nullptr, const int *ownHi = nullptr) {
+    Lay L = c->L;
+    if (ownLo) for (int a = 0; a < 3; a++) { L.olo[a] = ownLo[a]; L.ohi[a] = ownHi[a]; }   // (a coarse level's owned box)
     D->n = 0;
     size_t so = 0, ro = 0;
     for (int dz = -1; dz <= 1; dz++)
@@ -186,7 +187,7 @@ static void build_dirs(const flipv_context *c, const AxisRanges R[3], int narr, 
     *sendBytes = so; *recvBytes = ro;
     for (int q = 0; q < D->n; q++) D->roff[q] += so;   // the receive staging follows the send staging
 }
-static int exchange_dirs(flipv_context *c, const HaloSet &hs, DirSet &D, size_t sendBytes, size_t recvBytes, int mode) {
+static int exchange_dirs(flipv_context *c, const HaloSet &hs, DirSet &D, size_t sendBytes, size_t recvBytes, int mode, const Lay *LC = nullptr) {
     Comm *cm = c->comm;
     int rc;
     if (D.n == 0) return FLIPV_OK;
@@ -196,12 +197,12 @@ static int exchange_dirs(flipv_context *c, const HaloSet &hs, DirSet &D, size_t 
     unsigned gs = grid1d(maxs), gr = grid1d(maxr);
     if (gs > 512) gs = 512;
     if (gr > 512) gr = 512;
-    hipLaunchKernelGGL(k_halo_dirs, dim3(gs, D.n), dim3(256), 0, c->xs, hs, c->L, c->LB, D, c->xbuf, 0, 0);
+    hipLaunchKernelGGL(k_halo_dirs, dim3(gs, D.n), dim3(256), 0, c->xs, hs, c->L, LC ? *LC : c->LB, D, c->xbuf, 0, 0);
     if ((rc = cm->begin(c))) return rc;
     for (int q = 0; q < D.n; q++)
         if ((rc = cm->sendrecv(c, D.peer[q], c->xbuf + D.soff[q], D.scnt[q] * 8 * (size_t)hs.n, c->xbuf + D.roff[q], D.rcnt[q] * 8 * (size_t)hs.n))) return rc;
     if ((rc = cm->end(c))) return rc;
-    hipLaunchKernelGGL(k_halo_dirs, dim3(gr, D.n), dim3(256), 0, c->xs, hs, c->L, c->LB, D, c->xbuf, 1, mode);
+    hipLaunchKernelGGL(k_halo_dirs, dim3(gr, D.n), dim3(256), 0, c->xs, hs, c->L, LC ? *LC : c->LB, D, c->xbuf, 1, mode);
     HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
@@ -289,6 +290,30 @@ int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi,
     size_t sb, rb;
     build_dirs(c, R, n, &D, &sb, &rb);
     return exchange_dirs(c, hs, D, sb, rb, op == HALO_MIN_F32 ? 2 : 3);
+}
+
+int fv_halo_level(flipv_context *c, const Lay &LC, const int olo[3], const int ohi[3], float *const *arr, int n, int H, int add) {
+    Comm *cm = c->comm;
+    if (!cm || H <= 0) return FLIPV_OK;
+    if (n > HALO_MAXARR) { c->err = "fv_halo_level: too many arrays"; return FLIPV_ERR_INVALID; }
+    HaloSet hs;
+    hs.n = n;
+    for (int a = 0; a < n; a++) { hs.p[a] = arr[a]; hs.elem[a] = 4; hs.lay[a] = 2; }
+    AxisRanges R[3];
+    for (int a = 0; a < 3; a++) {
+        const int o0 = olo[a], o1 = ohi[a];
+        if (!add) {   // copy: owned entries out, halo entries in
+            R[a].sLo[0] = o0; R[a].sLo[1] = o0 + H; R[a].rLo[0] = o0 - H; R[a].rLo[1] = o0;
+            R[a].sHi[0] = o1 - H; R[a].sHi[1] = o1; R[a].rHi[0] = o1; R[a].rHi[1] = o1 + H;
+        } else {      // reduction: halo entries out, owned entries in
+            R[a].sLo[0] = o0 - H; R[a].sLo[1] = o0; R[a].rLo[0] = o0; R[a].rLo[1] = o0 + H;
+            R[a].sHi[0] = o1; R[a].sHi[1] = o1 + H; R[a].rHi[0] = o1 - H; R[a].rHi[1] = o1;
+        }
+    }
+    DirSet D;
+    size_t sb, rb;
+    build_dirs(c, R, n, &D, &sb, &rb, olo, ohi);
+    return exchange_dirs(c, hs, D, sb, rb, add ? 3 : 1, &LC);
 }
 
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n) {

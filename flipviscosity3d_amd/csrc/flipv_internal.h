@@ -98,6 +98,13 @@ __host__ __device__ __forceinline__ NbOff nb_brick(const Lay &B, int i, int j, i
     o.zp = kl == 0 ? 16 : sbz - 16;       o.zm = kl == 1 ? -16 : -(sbz - 16);
     return o;
 }
+// Coarse levels of the viscosity multigrid (k_viscosity_mg.hip) are stored in bricks of 8 x 4 x 2 indices too, whole rows of 8 along i in a 128-byte line,
+// over the level's GLOBAL index space (origin 0) with one brick of padding on every side; sy / sz of such a Lay are brick strides.  (Here because the
+// halo exchange of a DISTRIBUTED coarse level addresses it: flipv_comm.h: fv_halo_level.)
+__host__ __device__ __forceinline__ size_t cidx(const Lay &L, int i, int j, int k) {
+    const int ip = i + 8, jp = j + 4, kp = k + 2;
+    return ((size_t)((long)(kp >> 1) * L.sz + (long)(jp >> 2) * L.sy + (long)(ip >> 3)) << 6) + (size_t)(((kp & 1) << 5) + ((jp & 3) << 3) + (ip & 7));
+}
 // layout of the viscosity solver's arrays for the current solve
 enum { VLAYOUT_PLAIN = 0, VLAYOUT_SWZ = 1, VLAYOUT_BRICK = 2 };
 
@@ -219,6 +226,7 @@ struct flipv_context {
     int viscosity_nonzero_any = 1;  // ... on any rank of the communicator (all-reduced at the start of every viscosity solve)
     int vForceMultigridOnce = 0;    // set while a diagonal solve AUTO picked and that ran into the cap is being repeated with the multigrid
     int vmgSweeps = 16;             // Jacobi sweeps on the multigrid's LDS-resident coarsest level for the current solve (viscosity_solve_t picks)
+    double vRowsAll = 0.0;      // rows of the current viscosity system over all ranks (viscosity_solve_t's all-gather)
     double commBytesSetup = 0.0, commBytesIter = 0.0;   // what the current solve's multigrid all-reduces: once, and per iteration (flipv_solve_info::comm_bytes_*)
     int vmgPackedRows = 1;          // ... and whether its cycle reads the coarse rows in the packed fp16 form (k_viscosity_mg.hip: d_row_dot) or the fp32 grids
     int facValid = 0;               // the factor arrays hold the current layout's values wherever the band was

@@ -852,6 +852,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         fill = rows / (3.0 * vol);
     }
     const double bnormAll = c->h_scal[0];
+    c->vRowsAll = rowsAll;
     c->vwV = 4;
     if (c->prm.viscosity_lane_width == 2 || c->prm.viscosity_lane_width == 4) c->vwV = c->prm.viscosity_lane_width;  // measurement switch: forced lane width
     c->vPred = fillLocal <= 0.35;   // (the plane kernels' load predication is the rank's own business)

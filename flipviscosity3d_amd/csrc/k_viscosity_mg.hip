@@ -173,10 +173,7 @@ struct FineOp {          // the matrix-free level 0 (k_viscosity.hip's arrays)
 // -- a compact 8 x 4 x 2 piece of space, far fuller wherever the liquid is at all -- and its own-index accesses are 256 contiguous
 // bytes.  One brick of padding on every side: indices -1 and PX..PX+7 are addressable, nothing needs a guard zone.
 // For a coarse level Lay::sy / Lay::sz hold the BRICK strides (bricks per row, bricks per plane), not index strides.
-__host__ __device__ __forceinline__ size_t cidx(const Lay &L, int i, int j, int k) {
-    const int ip = i + 8, jp = j + 4, kp = k + 2;
-    return ((size_t)((long)(kp >> 1) * L.sz + (long)(jp >> 2) * L.sy + (long)(ip >> 3)) << 6) + (size_t)(((kp & 1) << 5) + ((jp & 3) << 3) + (ip & 7));
-}
+// (cidx itself: flipv_internal.h)
 static Lay coarse_lay(const Lay &F) {
     Lay C;
     C.I = (F.I + 1) / 2; C.J = (F.J + 1) / 2; C.K = (F.K + 1) / 2;
@@ -473,7 +470,7 @@ __device__ __forceinline__ float d_restrict(const Lay &F, const Vec3p &ft, const
             for (int b = 0; b < 2; b++) {
                 int q[3];
                 q[C] = 2 * P[C] + dn; q[t1] = 2 * P[t1] + a; q[t2] = 2 * P[t2] + b;
-                if (d_in_lattice(F, C, q) && (FINE0 == 0 || d_owned(F, q[0], q[1], q[2])))   // (level 0 of a block context, either layout: only the rank's own indices are rows -- or allocated at all; the halo holds the NEIGHBOURS' residuals)
+                if (d_in_lattice(F, C, q) && d_owned(F, q[0], q[1], q[2]))   // (level 0 of a block context, either layout, and a distributed coarse level: only the rank's own indices are ITS rows; the halo holds the neighbours' residuals.  A global level's Lay owns everything)
                     s += (dn == 0 ? 1.0f : 0.5f) * ft.p[C][FINE0 == 1 ? gidx(F, q[0], q[1], q[2]) : (FINE0 == 2 ? bidx(F, q[0], q[1], q[2]) : cidx(F, q[0], q[1], q[2]))];
             }
     return s;
@@ -610,6 +607,20 @@ __global__ __launch_bounds__(256) void k_vmg_restrict_box(const VLevelDev *__res
     if (c == 0) v = RONLY(0); else if (c == 1) v = RONLY(1); else v = RONLY(2);
 #undef RONLY
     buf[(size_t)c * ((size_t)w * h * dpt) + (size_t)di + (size_t)w * ((size_t)dj + (size_t)h * dk)] = v;
+}
+// b of a DISTRIBUTED level l over the box `R` (its owned box widened by one entry): the rank's share of P^T t -- its own finer rows only (d_restrict's
+// ownership test) --, written straight into the level's b; the shares of the entries beyond the owned box then travel to their owners (fv_halo_level, add)
+__global__ __launch_bounds__(256) void k_vmg_restrict_partial(const VLevelDev *__restrict__ lev, int l, Lay F0, Vec3p ft0, const int *__restrict__ conv, int fineBrick, Box3 R) {
+    if (*conv >= 0) return;
+    const VLevelDev &A = lev[l];
+    const int i = R.lo[0] + (int)(blockIdx.x * 64 + threadIdx.x), j = R.lo[1] + (int)(blockIdx.y * 4 + threadIdx.y);
+    const int c = (int)blockIdx.z % 3, k = R.lo[2] + (int)blockIdx.z / 3;
+    if (i >= R.hi[0] || j >= R.hi[1] || k >= R.hi[2]) return;
+    float v;
+#define RONLY(C_) (l > 0 ? d_restrict_only<C_, 0>(A, lev[l - 1].L, lev[l - 1].t, i, j, k) : (fineBrick ? d_restrict_only<C_, 2>(A, F0, ft0, i, j, k) : d_restrict_only<C_, 1>(A, F0, ft0, i, j, k)))
+    if (c == 0) v = RONLY(0); else if (c == 1) v = RONLY(1); else v = RONLY(2);
+#undef RONLY
+    A.b.p[c][cidx(A.L, i, j, k)] = v;
 }
 // the summed right-hand side back into the level's grids, with the first sweep x = omega b/d from the zero guess (`first`; the tail kernel does its own)
 __global__ __launch_bounds__(256) void k_vmg_unpack_rhs(const VLevelDev *__restrict__ lev, int l, const float *__restrict__ buf, const int *__restrict__ conv, int first) {
@@ -1127,6 +1138,14 @@ struct VmgState {
     // the sum over the ranks of their Galerkin contributions (one all-reduce per solve), its right-hand side the sum of their restricted
     // residuals (one all-reduce per iteration).  -1: no global level (single domain, or switched off)
     int globalFrom = -1;
+    // DISTRIBUTED coarse levels (round 4): lev[0 .. nDist) are cycled by their owners only -- rank r owns the indices P of such a level whose fine
+    // ancestor 2^(l+1) P it owns (own[l]: a tiling of the level like the blocks tile the domain); a sweep's input vector gets a 1-entry halo copy first
+    // (fv_halo_level), right-hand sides and Galerkin sums that children on both sides of a cut contribute to are halo-REDUCED to the owner -- exactly what
+    // happens on level 0.  The global, redundantly cycled hierarchy then starts at lev[nDist] = lev[globalFrom]: its operator (once per solve) and
+    // right-hand side (once per iteration) are 1/8 per distributed level of what level 1 would all-reduce, and nobody cycles level 1 of the WHOLE
+    // domain any more (at 512^3 on 8 ranks that level is as much work as a rank's share of the fine level).  nDist is 0 or 1.
+    int nDist = 0;
+    Box3 own[VMG_MAX_LEVELS], rbox[VMG_MAX_LEVELS];   // owned box of a distributed level; the same widened by one entry (clipped to the level): where partial sums are formed
     int rc = 0;                  // a communication error inside the V-cycle (checked by the loop around it)
     // Under a communicator the V-cycle cannot be one replayed graph (its collectives are host calls of the backend), but everything between the
     // right-hand-side all-reduce of the first global level and the halo copy before the first post-sweep is kernels only -- ~17 dependent launches,
@@ -1332,8 +1351,35 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             }
             fb = A.box;
         }
-        // block contexts: from the first level that is small enough on, the GLOBAL hierarchy (VmgState::globalFrom): its box is the union of the ranks' boxes
-        s->globalFrom = (c->comm && !c->prm.multigrid_rank_local && !s->lev.empty()) ? 0 : -1;
+        // block contexts: the levels every rank cycles for itself -- DISTRIBUTED ones, lev[0 .. nDist), where the system is large (VmgState::nDist; the decision
+        // is taken from the all-gathered row count, so every rank takes it alike) -- and from lev[nDist] on the GLOBAL hierarchy (VmgState::globalFrom): its
+        // box is the union of the ranks' boxes
+        const bool commMg = c->comm && !c->prm.multigrid_rank_local && !s->lev.empty();
+        s->nDist = 0;
+        if (commMg && c->comm->nranks > 1 && s->lev.size() >= 2) {
+            const int want = c->prm.multigrid_distributed_levels;   // 0 = by size, 1 = level 1 distributed, -1 = none
+            if (want > 0 || (want == 0 && c->vRowsAll > 4.5e6)) s->nDist = 1;   // (4.5e6 rows ~ a 512^3-class liquid: level 1 has then > ~3 000 bricks of rows)
+        }
+        s->globalFrom = commMg ? s->nDist : -1;
+        for (size_t l = 0; l < s->lev.size(); l++) {   // a global level's Lay owns all of it; a distributed level's owned box: the indices whose fine ancestor the rank owns
+            Lay &LL = s->lev[l].L;
+            LL.olo[0] = LL.olo[1] = LL.olo[2] = 0; LL.ohi[0] = LL.PX; LL.ohi[1] = LL.PY; LL.ohi[2] = LL.PZ;
+        }
+        {
+            int lo[3] = {c->L.olo[0], c->L.olo[1], c->L.olo[2]}, hi[3] = {c->L.ohi[0], c->L.ohi[1], c->L.ohi[2]};
+            for (int l = 0; l < s->nDist; l++) {
+                VLevel &A = s->lev[l];
+                const int ext[3] = {A.L.I + 1, A.L.J + 1, A.L.K + 1};
+                for (int a = 0; a < 3; a++) {
+                    lo[a] = (lo[a] + 1) >> 1; hi[a] = (hi[a] + 1) >> 1;   // index P is the rank's iff 2 P is
+                    s->own[l].lo[a] = lo[a]; s->own[l].hi[a] = hi[a] > ext[a] ? ext[a] : hi[a];
+                    if (s->own[l].hi[a] < s->own[l].lo[a]) s->own[l].hi[a] = s->own[l].lo[a];
+                    s->rbox[l].lo[a] = s->own[l].lo[a] > 0 ? s->own[l].lo[a] - 1 : 0;
+                    s->rbox[l].hi[a] = s->own[l].hi[a] + 1 > ext[a] ? ext[a] : s->own[l].hi[a] + 1;
+                    A.L.olo[a] = s->own[l].lo[a]; A.L.ohi[a] = s->own[l].hi[a];
+                }
+            }
+        }
         if (s->globalFrom >= 0) {
             const int nr = c->comm->nranks, me = c->comm->rank;
             std::vector<double> hbx((size_t)6 * nr, 0.0);
@@ -1366,6 +1412,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
                 gb = A.box;
             }
         }
+        for (int l = 0; l < s->nDist; l++) s->lev[l].box = s->own[l];   // (what the sweeps, the lists and the packing of a distributed level cover: the rank's own indices)
         // the tail: the coarsest levels whose boxes are small enough for one workgroup (the last level always)
         s->tailFirst = (int)s->lev.size() - 1;
         while (s->tailFirst > 0 && (int)s->lev.size() - (s->tailFirst - 1) <= VMG_TAIL_MAX && box_positions(s->lev[s->tailFirst - 1].box) <= VMG_TAIL_POS) s->tailFirst--;
@@ -1376,7 +1423,7 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     // be zeroed first, and what lies outside the box is never looked at.  The rows' own volumes are those of the operator the solve
     // applies: the exact one, or the reference's float-rounded one (vr*, k_viscosity.hip: d_ref_volume) -- the defect is a diagonal term
     // and goes through the Galerkin product like the volume itself.
-    if (s->globalFrom == 0) {   // the neighbours' row masks one entry into the halo: a fine row at a cut face then carries its entries across the cut into the Galerkin sums
+    if (s->globalFrom >= 0) {   // the neighbours' row masks one entry into the halo: a fine row at a cut face then carries its entries across the cut into the Galerkin sums
         const HaloArray hm[1] = {{brick ? (void *)c->vMaskB : (void *)c->vRowMask, 1, brick ? 1 : 0}};
         if ((rc = fv_halo_copy(c, hm, 1, 1))) return rc;
     }
@@ -1391,7 +1438,19 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
 #define CGRID(B) dim3(cdiv((B).hi[0] - (B).lo[0], 64), cdiv((B).hi[1] - (B).lo[1], 4), 3u * (unsigned)((B).hi[2] - (B).lo[2])), dim3(64, 4, 1)
         // (on the first global level every rank gathers over the union box: children outside its own finer box are skipped, so what it
         // writes is its share of every row -- zero where it has none -- and the sum over the ranks is the single-domain Galerkin operator)
-        hipLaunchKernelGGL(k_vmg_rap_gather_fine, CGRID(s->lev[0].box), 0, c->stream, A, c->L, dev_of(s->lev[0]));
+        if (s->nDist > 0) {   // level 1 distributed: the rank's share of the rows of its own box AND of the ring around it, the ring's shares then go to their owners
+            VLevelDev D0 = dev_of(s->lev[0]);
+            D0.box = s->rbox[0];
+            hipLaunchKernelGGL(k_vmg_rap_gather_fine, CGRID(s->rbox[0]), 0, c->stream, A, c->L, D0);
+            for (int g0 = 0; g0 < 3 * VS; g0 += 6) {
+                float *arr[6];
+                const int n = 3 * VS - g0 < 6 ? 3 * VS - g0 : 6;
+                for (int q = 0; q < n; q++) arr[q] = s->lev[0].coef[0][0] + (size_t)(g0 + q) * s->lev[0].per;
+                if ((rc = fv_halo_level(c, s->lev[0].L, s->own[0].lo, s->own[0].hi, arr, n, 1, 1))) return rc;
+            }
+            const long ring = box_positions(s->rbox[0]) - box_positions(s->own[0]);
+            c->commBytesSetup += (double)(ring > 0 ? ring : 0) * 3 * VS * sizeof(float);   // (point to point, to the <= 26 neighbours: what leaves this rank)
+        } else hipLaunchKernelGGL(k_vmg_rap_gather_fine, CGRID(s->lev[0].box), 0, c->stream, A, c->L, dev_of(s->lev[0]));
         if (s->globalFrom == 0 && (rc = vmg_allreduce_box(c, s, s->lev[0], s->lev[0].coef[0][0], 3 * VS))) return rc;
         for (size_t l = 0; l + 1 < s->lev.size(); l++) {
             hipLaunchKernelGGL(k_vmg_rap_gather, CGRID(s->lev[l + 1].box), 0, c->stream, dev_of(s->lev[l]), dev_of(s->lev[l + 1]));
@@ -1482,7 +1541,7 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
     const int *conv = sc.conv;
     // with the global hierarchy the fine level is the single domain's too: every sweep reads its input with the neighbours' current values
     const int hl = brick ? 1 : 0;   // (HaloArray::lay)
-    auto halo3 = [&](float *const v[3]) { if (s->globalFrom == 0 && !s->rc) { const HaloArray h[3] = {{v[0], sizeof(float), hl}, {v[1], sizeof(float), hl}, {v[2], sizeof(float), hl}}; s->rc = fv_halo_copy(c, h, 3, 1); } };
+    auto halo3 = [&](float *const v[3]) { if (s->globalFrom >= 0 && !s->rc) { const HaloArray h[3] = {{v[0], sizeof(float), hl}, {v[1], sizeof(float), hl}, {v[2], sizeof(float), hl}}; s->rc = fv_halo_copy(c, h, 3, 1); } };
     halo3(s->za);
     fv_visc_sweep_f32(c, s->za, s->zb, 1, sc, it_spmv, s->w[1], 0);                         // second pre-sweep: za -> zb
     if (!s->lev.empty()) {
@@ -1513,9 +1572,17 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
             if (listed) hipLaunchKernelGGL(k_vmg_unpack_list, dim3(cdiv(s->lev[l].nstrips, 4), 3), dim3(64, 4, 1), 0, c->stream, (const VLevelDev *)s->d_lev, l, (const float *)s->stage, conv, first);
             else { const size_t n = (size_t)box_positions(s->lev[l].box); hipLaunchKernelGGL(k_vmg_unpack_rhs, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, c->stream, (const VLevelDev *)s->d_lev, l, (const float *)s->stage, conv, first); }
         };
-        // everything of the coarse part that follows the all-reduce (or all of it, without one): kernels only
-        auto coarse_part = [&](bool afterSend) {
-            for (int l = 0; l < t0; l++) {   // down
+        // A distributed level's vectors: 1-entry halo copy of one of them (0 x, 1 y, 3 t) before the sweep that reads it; its right-hand side: halo REDUCTION
+        const int nd = s->nDist;
+        auto lvl_copy = [&](int l, int which) {
+            if (s->rc) return;
+            VLevel &A = s->lev[l];
+            float *const *v = which == 0 ? A.x : (which == 1 ? A.y : A.t);
+            s->rc = fv_halo_level(c, A.L, s->own[l].lo, s->own[l].hi, v, 3, 1, 0);
+        };
+        // the levels below the all-reduce (or all of them, without one), down, tail and up again: kernels only
+        auto global_part = [&](bool afterSend, int from) {
+            for (int l = from; l < t0; l++) {   // down
                 if (l == gl) { if (afterSend) global_rhs_take(l, 1); }
                 else STEP(OP_RESTRICT, l);
                 STEP(OP_PRE2, l);
@@ -1529,32 +1596,57 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
                 else
                     hipLaunchKernelGGL(k_vmg_tail, dim3(1), dim3(1024), 0, c->stream, (const VLevelDev *)s->d_lev, t0, nl, s->chebM ? sweeps - 1 : sweeps, s->chebM ? 1 : 0, F0, ft0, conv, fb, t0 == gl ? 1 : 0);
             }
-            for (int l = t0 - 1; l >= 0; l--) {   // up
+            for (int l = t0 - 1; l >= from; l--) {   // up
                 STEP(OP_PROPOST, l);
                 STEP(OP_POST2, l);
             }
-            // (inside the captured segment the iteration number is not known: the kernel only tests it against the cap, which the host's loop respects anyway)
-            const int itp = (afterSend && s->midReady) ? 0 : it_arg;
+        };
+        auto prolong_fine = [&](int itp) {
             if (brick) hipLaunchKernelGGL(k_bvmg_prolong_fine, dim3(nb), blk, 0, c->stream, (const int *)c->brickList, c->nBricks, c->LB, s->lev[0].L, (const uint8_t *)c->vMaskB, v3(s->zb), v3(s->lev[0].x), sc, itp);
             else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_prolong_fine, dim3(nb), blk, 0, c->stream, c->tileListV, c->nActiveV, c->tgV, c->L, s->lev[0].L, c->vRowMask, (const unsigned *)c->mlistV,
                                c->vSwz, v3(dg), v3(s->zb), v3(s->lev[0].x), sc, itp));
         };
-        if (gl < 0) coarse_part(false);
+        if (gl < 0) { global_part(false, 0); prolong_fine(it_arg); }
         else {
+            // ---- the distributed levels, down: the rank's share of the right-hand side over its box + ring, the ring's shares to their owners, then the
+            // sweeps on the rank's own rows, each after a halo copy of its input
+            for (int l = 0; l < nd; l++) {
+                const Box3 &R = s->rbox[l];
+                hipLaunchKernelGGL(k_vmg_restrict_partial, dim3(cdiv(R.hi[0] - R.lo[0], 64), cdiv(R.hi[1] - R.lo[1], 4), 3u * (unsigned)(R.hi[2] - R.lo[2])), dim3(64, 4, 1), 0, c->stream,
+                                   (const VLevelDev *)s->d_lev, l, F0, ft0, conv, fb, R);
+                if ((s->rc = fv_halo_level(c, s->lev[l].L, s->own[l].lo, s->own[l].hi, s->lev[l].b, 3, 1, 1))) return;
+                STEP(OP_FIRST, l);
+                lvl_copy(l, 0);
+                STEP(OP_PRE2, l);
+                lvl_copy(l, 1);
+                STEP(OP_RESID, l);
+                if (s->rc) return;
+            }
+            // ---- the global hierarchy: right-hand side summed over the ranks, then kernels only (captured once per solve, replayed)
             if ((s->rc = global_rhs_send(gl))) return;
             const bool replay = !c->prm.kernel_timing && !c->prm.no_graph_replay;
             if (replay && !s->midReady) {   // first V-cycle of this solve: capture the segment (the all-reduce it follows has been enqueued)
                 hipGraph_t g = nullptr;
                 if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                    s->midReady = true;   // (coarse_part launches the iteration-free form)
-                    coarse_part(true);
+                    global_part(true, gl);
+                    if (nd == 0) prolong_fine(0);   // (inside the captured segment the iteration number is not known: the kernel only tests it against the cap, which the host's loop respects anyway)
                     const hipError_t e2 = hipStreamEndCapture(c->stream, &g);
-                    if (e2 != hipSuccess || !g || fv_graph_exec(c, FV_GE_VISCOSITY_MID, g, &s->midExec) != FLIPV_OK) { s->midReady = false; s->midExec = nullptr; (void)hipGetLastError(); }
+                    s->midReady = e2 == hipSuccess && g && fv_graph_exec(c, FV_GE_VISCOSITY_MID, g, &s->midExec) == FLIPV_OK;
+                    if (!s->midReady) { s->midExec = nullptr; (void)hipGetLastError(); }
                     if (g) (void)hipGraphDestroy(g);
                 } else (void)hipGetLastError();
             }
             if (replay && s->midReady) { if (hipGraphLaunch(s->midExec, c->stream) != hipSuccess) { s->rc = FLIPV_ERR_HIP; c->err = "viscosity multigrid: hipGraphLaunch of the coarse segment failed"; return; } }
-            else coarse_part(true);
+            else { global_part(true, gl); if (nd == 0) prolong_fine(it_arg); }
+            // ---- the distributed levels, up
+            for (int l = nd - 1; l >= 0; l--) {
+                STEP(OP_PROPOST, l);     // (reads y with the halo the residual step's copy left, and the coarser level's x: global, or halo-copied below)
+                lvl_copy(l, 3);
+                STEP(OP_POST2, l);
+                lvl_copy(l, 0);          // x for the finer level's prolongation
+                if (s->rc) return;
+            }
+            if (nd > 0) prolong_fine(it_arg);
         }
 #undef STEP
 #undef STEP_

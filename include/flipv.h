@@ -156,6 +156,9 @@ typedef struct flipv_params {
                                     all-reduces over the liquid's box), held and cycled redundantly by every rank: the iteration counts of a single domain.
                                     1: every rank cycles a hierarchy of its OWN rows / cells with the couplings across the cuts dropped and no exchange
                                     (block-Jacobi): 3-4x the viscosity iterations and 2-3x the pressure iterations on 2x2x2 blocks */
+    int multigrid_distributed_levels; /* several ranks, viscosity multigrid with the global hierarchy: 0 = level 1 is DISTRIBUTED (cycled by the rows' owners with
+                                    1-entry halo exchanges, like level 0; the global, redundantly cycled hierarchy starts one level further down) where the system has more
+                                    than 4.5e6 rows over all ranks; 1 = always; -1 = never (level 1 global: one all-reduce of its right-hand side per iteration) */
     /* the two-stage viscosity solve (see exact_viscosity_operator); 0 = the default in brackets */
     float viscosity_stage1_factor;          /* [300] stage 1 stops at this multiple (>= 1) of viscosity_tolerance x max|rhs|; 1 = the strict solve: stage 1 to
                                                viscosity_tolerance itself (bench.py: mode_b_strict) */

@@ -126,3 +126,36 @@ def test_rccl_backend_single_rank_default_params():
         assert rel_maxnorm3([b.grid(n) for n in "UVW"], [a.grid(n) for n in "UVW"]) <= 2e-5
     b.comm_finalize()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("N,dims", [(64, (1, 1, 2)), (64, (2, 2, 2)), (128, (2, 2, 2)), (128, (4, 1, 1))])
+def test_distributed_level_1_is_the_same_preconditioner(N, dims):
+    """flipv_params.multigrid_distributed_levels = 1 (the default where the system has > 4.5e6 rows: config 4): level 1 of the viscosity hierarchy is cycled by
+    the rows' owners with halo exchanges instead of redundantly by every rank after an all-reduce of its right-hand side -- the SAME V-cycle, so the
+    iteration counts are the single domain's (up to the summation order) and the velocities agree; what the global hierarchy still all-reduces per
+    iteration shrinks by about 8 x.  Everything else at its default; the bunny scene at 64^3 (one global level left: the LDS-resident one) and 128^3."""
+    from flipviscosity3d_amd import capi
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    ref = capi.Context(N, N, N, dx)
+    ref.set_solid_sdf(solid); ref.set_viscosity(5.0); ref.particles = P
+    glob = make_blocks(N, dx, solid, P, 5.0, dims, dict(multigrid_distributed_levels=-1))
+    dist = make_blocks(N, dx, solid, P, 5.0, dims, dict(multigrid_distributed_levels=1))
+    for t in range(2):
+        sr = ref.substep(0.01)
+        sg = run_ranks(glob, lambda r, c: c.substep(0.01))
+        sd = run_ranks(dist, lambda r, c: c.substep(0.01))
+        assert_same_solve_on_every_rank(sd)
+        vr, vg, vd = sr["viscosity"], sg[0]["viscosity"], sd[0]["viscosity"]
+        print("%d^3 %s substep %d: viscosity iterations single %d / global level 1 %d / distributed %d; all-reduced per iteration %.3f -> %.3f MB, once per solve %.2f -> %.2f MB" % (
+            N, dims, t, vr["iterations"], vg["iterations"], vd["iterations"], vg["comm_bytes_per_iteration"] / 1e6, vd["comm_bytes_per_iteration"] / 1e6,
+            vg["comm_bytes_setup"] / 1e6, vd["comm_bytes_setup"] / 1e6))
+        assert vd["status"] == 0 and vd["preconditioner"] == 1 and vd["layout"] == 2, vd
+        assert abs(vd["iterations"] - vr["iterations"]) <= 6 and abs(vg["iterations"] - vr["iterations"]) <= 6, (vr, vg, vd)
+        assert vd["comm_bytes_per_iteration"] < 0.3 * vg["comm_bytes_per_iteration"], (vg, vd)
+        got = [assemble(dist, n) for n in "UVW"]
+        err = rel_maxnorm3(got, [ref.grid(n) for n in "UVW"])
+        print("   velocity difference to the single domain %.2e" % err)
+        assert err <= 5e-5, (t, err)
+    for c in glob + dist:
+        c.close()
+    ref.close()
