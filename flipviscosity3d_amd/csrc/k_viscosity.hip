@@ -973,7 +973,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // to nu dt/dx^2 = 2e4 (the headline's 3 277: 2.3e-5 at 256^3) and to 1e-3 beyond -- <= 3e-5 everywhere for +25 % iterations where two stages cost +60 %.
         // viscosity_stage2_rounds = 2 buys the last column.
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-        const double f1 = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : 300.0;
+        // Stage 1's factor: the delivered velocities do NOT depend on it between 300 and 10 000 -- the correction stage starts from the fp64-recomputed residual,
+        // stage 1's remainder included (profiles/r4/stage1_factor_scan.log: 256^3 1.6e-5 ... 2.5e-5 from the reference's converged velocities with 300, 1 000 and
+        // 3 000; 128^3, the stiff fixtures and the oracle scans from 8e3 to 8e4 likewise) -- the iteration count does: a restarted loop has lost its Krylov
+        // space, so on a mildly stiff system (64^3 at nu = 5: nu dt/dx^2 = 205) stopping earlier costs 50 -> 63 iterations, on a stiff one it saves (256^3:
+        // 70 -> 62, bench 879 -> 957 MCells/s; 64^3 nu = 200: 104 -> 87; nu = 800: 181 -> 156).  300 up to nu dt/dx^2 = 1 000, 3 000 beyond.
+        const double f1 = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : (stiffNow > 1000.0 ? 3000.0 : 300.0);
+
         const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5;
         const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 200;   // (round 3: 48.  A first stage takes 7-30 iterations, a second one at nu dt/dx^2 = 1.3e5 100-150)
         const int rounds = c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : 1;

@@ -160,8 +160,9 @@ typedef struct flipv_params {
                                     1-entry halo exchanges, like level 0; the global, redundantly cycled hierarchy starts one level further down) where the system has more
                                     than 4.5e6 rows over all ranks; 1 = always; -1 = never (level 1 global: one all-reduce of its right-hand side per iteration) */
     /* the two-stage viscosity solve (see exact_viscosity_operator); 0 = the default in brackets */
-    float viscosity_stage1_factor;          /* [300] stage 1 stops at this multiple (>= 1) of viscosity_tolerance x max|rhs|; 1 = the strict solve: stage 1 to
-                                               viscosity_tolerance itself (bench.py: mode_b_strict) */
+    float viscosity_stage1_factor;          /* [300 up to nu dt/dx^2 = 1 000, 3 000 beyond] stage 1 stops at this multiple (>= 1) of viscosity_tolerance x max|rhs|; the delivered
+                                               velocities do not depend on it (the correction stage starts from the fp64 residual), the iteration count does.
+                                               1 = the strict solve: stage 1 to viscosity_tolerance itself (bench.py: mode_b_strict) */
     float viscosity_stage2_factor;          /* [1e-2 up to nu dt/dx^2 = 2e4, 1e-3 beyond; 2e-2 where stage 1 ran to viscosity_tolerance] a correction stage's target as a share of
                                                the defect it starts from.  Scanned against the reference run to convergence from 8e3 to 1.3e5 (k_viscosity.hip: viscosity_solve_t) */
     int viscosity_stage2_max_iterations;    /* [200] iteration budget of ONE correction stage (inside viscosity_max_iterations overall) */

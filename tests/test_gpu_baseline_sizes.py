@@ -80,7 +80,7 @@ def run_against_live_oracle(oracle, N, dx, solid, P, nu, nsub, dt=0.01, lift_cap
 def test_stiff_scene_64_nu200_defaults_match_converged_oracle(oracle):
     """config 1's scene with nu = 200 (nu dt/dx^2 = 8 192, 2.5 x the stiffness of the 256^3 headline): the GPU with NO parameter touched against the
     oracle with its viscosity cap lifted (it needs 1 249 / 948 iterations), two chained substeps, <= 1e-4 (measured 8e-6 / 3.5e-5).  The default
-    solve here is the two-stage defect correction (stage 1 to 3e-4 on the exact operator, stage 2 to 1 % of the defect): this pins what it delivers
+    solve here is the two-stage defect correction (stage 1 to 3e-3 on the exact operator, stage 2 to 1 % of the defect): this pins what it delivers
     at a stiffness between the 256^3 fixture's (3 277) and the rule's limit (2e4)."""
     from flipviscosity3d_amd.capi import Context
     dx, solid, P = build_host_scene(64, ("sphere_large.ply", True), ["stanford_bunny.ply"])
@@ -99,7 +99,7 @@ def test_stiff_scene_64_nu200_defaults_match_converged_oracle(oracle):
         v = st["viscosity"]
         assert vi["status"] == 0 and vi["iterations"] > 700                      # the reference converges, beyond its stock cap
         assert v["status"] == 0 and v["preconditioner"] == 1 and v["layout"] == 2 and v["iterations"] < 200, v
-        assert v["residual"] <= 3e-4 * v["rhs_norm"] * 1.0001 and v["defect_residual"] > 0.0, v   # stage 1's tolerance; a stage 2 ran
+        assert v["residual"] <= 3e-3 * v["rhs_norm"] * 1.0001 and v["defect_residual"] > 0.0, v   # stage 1's tolerance (3 000 x 1e-6 beyond nu dt/dx^2 = 1 000); a stage 2 ran
         err = vel_err(c, [o.grid(n) for n in "UVW"])
         print("64^3 nu 200 substep %d: %d iterations (oracle %d), velocity error %.3e" % (t, v["iterations"], vi["iterations"], err))
         assert err <= VEL_TOL, (t, err)

@@ -160,7 +160,7 @@ def test_config4_honey_buckling_at_512_properties():
         st = c.substep(min(c.cfl(), 0.01))
         v, p = st["viscosity"], st["pressure"]
         assert v["status"] == 0 and v["preconditioner"] == 1 and v["layout"] == 2 and v["iterations"] < 700, v
-        assert v["residual"] <= 3e-4 * v["rhs_norm"] * 1.0001 and v["defect_residual"] > 0.0   # stage 1 of the two-stage solve stops at 300 x the tolerance; a stage 2 ran (include/flipv.h: exact_viscosity_operator)
+        assert v["residual"] <= 3e-3 * v["rhs_norm"] * 1.0001 and v["defect_residual"] > 0.0   # stage 1 of the two-stage solve stops at 3 000 x the tolerance; a stage 2 ran (include/flipv.h: exact_viscosity_operator)
         assert p["status"] == 0, p
     U, V, W = (c.grid(n).astype(np.float64) for n in "UVW")
     wU, wV, wW = (c.grid("WEIGHT_" + n).astype(np.float64) for n in "UVW")

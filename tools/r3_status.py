@@ -1,4 +1,4 @@
-"""long default-parameter run with a summary of the viscosity solves: python tools/r3_status.py workload size viscosity substeps"""
+"""long default-parameter run with a summary of the viscosity solves: python tools/r3_status.py workload size viscosity substeps [flipv_params field=value ...]"""
 import os, sys, time, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,6 +8,9 @@ wl, N, nu, nsub = sys.argv[1], int(sys.argv[2]), float(sys.argv[3]), int(sys.arg
 I, J, K, dx, solid, P = build_workload(wl, N, on_device=True)
 c = Context(I, J, K, dx)
 c.set_solid_sdf(solid); c.set_viscosity(nu)
+extra = {kv.split("=")[0]: (float(kv.split("=")[1]) if "." in kv.split("=")[1] or "e" in kv.split("=")[1] else int(kv.split("=")[1])) for kv in sys.argv[5:] if "=" in kv}   # flipv_params fields
+if extra:
+    c.set_params(**extra)
 c.particles = P
 status, prec, its, ms = collections.Counter(), collections.Counter(), [], []
 t0 = time.perf_counter()

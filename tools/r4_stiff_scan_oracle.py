@@ -24,7 +24,7 @@ for nu in [float(v) for v in (sys.argv[1:] or ["200", "500", "800", "1280", "200
         oits.append(vi["iterations"])
     o.close()
     print("== 64^3 nu %g (nu dt/dx^2 = %.0f), oracle iterations %s" % (nu, nu * 0.01 / dx ** 2, oits), flush=True)
-    for prm in [dict(), dict(viscosity_stage2_factor=1e-2), dict(viscosity_stage2_factor=3e-3), dict(viscosity_stage2_factor=1e-3), dict(viscosity_stage2_rounds=2, viscosity_stage2_factor=1e-2)]:
+    for prm in [dict(), dict(viscosity_stage1_factor=1000.0), dict(viscosity_stage1_factor=3000.0), dict(viscosity_stage1_factor=10000.0)]:
         c = Context(N, N, N, dx)
         c.set_solid_sdf(solid); c.set_viscosity(nu); c.set_params(**prm)
         for t in range(2):
