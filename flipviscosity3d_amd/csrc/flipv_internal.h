@@ -226,6 +226,7 @@ struct flipv_context {
     int viscosity_nonzero_any = 1;  // ... on any rank of the communicator (all-reduced at the start of every viscosity solve)
     int vForceMultigridOnce = 0;    // set while a diagonal solve AUTO picked and that ran into the cap is being repeated with the multigrid
     int vmgSweeps = 16;             // Jacobi sweeps on the multigrid's LDS-resident coarsest level for the current solve (viscosity_solve_t picks)
+    int vMixed64 = 0;           // the current viscosity solve is precision = FP64 under the multigrid: fp32 Krylov loops refined to the fp64 tolerance
     double vRowsAll = 0.0;      // rows of the current viscosity system over all ranks (viscosity_solve_t's all-gather)
     double commBytesSetup = 0.0, commBytesIter = 0.0;   // what the current solve's multigrid all-reduces: once, and per iteration (flipv_solve_info::comm_bytes_*)
     int vmgPackedRows = 1;          // ... and whether its cycle reads the coarse rows in the packed fp16 form (k_viscosity_mg.hip: d_row_dot) or the fp32 grids

@@ -763,7 +763,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool swzOk = forcedLayout != 1;   // (also under the multigrid: its own kernels address diag / x / r / q / own volumes through sidx, its sweep vectors stay plain)
     // the preconditioner of this solve (the multigrid needs fp32 vectors over a whole, single-rank index space)
     const bool mgPossible = std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && !c->vNoMultigridOnce;   // (block contexts too: a rank-local hierarchy, k_viscosity_mg.hip)
-    const bool mgPlanned = mgPossible && (c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || c->vForceMultigridOnce ||
+    const bool mgPlanned = mgPossible && (c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || c->vForceMultigridOnce || c->vMixed64 ||
                                           (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && fv_visc_auto_pick(c, dt)));
     if (mgPossible && c->prm.viscosity_preconditioner != FLIPV_PRECOND_DIAGONAL && !c->vmgState) {
         const int prc = fv_vmg_prepare(c);   // allocate the hierarchy now, whichever solve first uses it
@@ -908,7 +908,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // preconditioner); the diagonal loop applies A_ref directly and is only restarted when it stalls (it converges superlinearly:
     // a restart costs it ~2 000 iterations at 256^3).
     const bool canRefine = std::is_same<T, float>::value && (brick || c->vwV == 4);   // bricks: k_viscosity_brick.hip; planes: fv_plane_refine above
-    const bool staged = canRefine && refDiag;
+    const bool staged = canRefine && (refDiag || c->vMixed64);   // (mixed fp64 mode: refinement towards whichever operator the solve is for)
     const bool useAcc = canRefine;
     if (c->comm) anyActive = rowsAll > 0.0 ? 1 : 0;   // (rows somewhere = an active tile / brick somewhere)
     const bool nontrivial = !(bnorm == 0.0 || anyActive == 0);
@@ -982,9 +982,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
 
         const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5;
         const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 200;   // (round 3: 48.  A first stage takes 7-30 iterations, a second one at nu dt/dx^2 = 1.3e5 100-150)
-        const int rounds = c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : 1;
+        const int rounds = c->vMixed64 ? 8 : (c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : 1);   // (vMixed64: refinement to the fp64 tolerance, fv_viscosity_solve)
         const double tolMain = (innerDiffers && stiffNow <= gate) ? f1 * tolFinal : tolFinal;
-        const double f2 = c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (stiffNow > 2.0e4 ? 1e-3 : (tolMain > tolFinal ? 1e-2 : 2e-2));
+        const double f2 = c->vMixed64 ? 1e-2 : (c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (stiffNow > 2.0e4 ? 1e-3 : (tolMain > tolFinal ? 1e-2 : 2e-2)));
         if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
@@ -1109,7 +1109,11 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             // simply wrong -- 512^3 / nu = 50, nu dt/dx^2 = 131 072: max|E x| = 1.2 max|b|, further stages contract by 2-50x each and stop
             // contracting around 1e-5 -- and chasing it costs more than the solve (measured: 6 stages, +70 % iterations, no convergence).
             // The solve's status and residual are the exact-operator loop's; `defect_residual` reports max|b - A_ref x| at the end.
-            if (corrections >= rounds || itersDone >= cap || tookBack) { success = true; defectRes = res; res = mainRes; break; }
+            if (corrections >= rounds || itersDone >= cap || tookBack) {
+                success = true; defectRes = res; res = mainRes;
+                if (c->vMixed64 && defectRes > tolFinal && corrStatus <= 1) corrStatus = 2;   // (the fp64 residual is this mode's criterion)
+                break;
+            }
             corrections++;
             correctionDue = true;
             if (corrections == 1) mainRes = resBeforeStage;
@@ -1202,7 +1206,22 @@ void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3]
 }
 
 int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) {
-    if (c->prm.precision == FLIPV_PRECISION_FP64) return viscosity_solve_t<double>(c, dt, info);
+    c->vMixed64 = 0;
+    if (c->prm.precision == FLIPV_PRECISION_FP64) {
+        // flipv_params.precision = FP64 = the reference's own vector type (pcgsolver.h:241-295 with T = double).  Under the diagonal preconditioner the PCG's
+        // vectors ARE fp64 (viscosity_solve_t<double>).  Under the multigrid (whose V-cycle is fp32) the fp64 answer is reached by MIXED-PRECISION ITERATIVE
+        // REFINEMENT, which is what the two-stage solve already is: the solution is accumulated and the residual b - A_ref x evaluated in fp64, the Krylov
+        // loops between them run in fp32 -- here repeated (up to 8 correction stages, each to 1 % of what is left) until the FP64 residual meets
+        // viscosity_tolerance x max|rhs|, the reference's own criterion; status 1 if it does not inside the iteration cap.  (Until round 4 fp64 vectors
+        // took the diagonal whatever was asked for: at 256^3 that is an iterate stopped at the cap.)
+        const double stiff = (double)c->viscosity_max * (double)dt / ((double)c->dx * (double)c->dx);
+        const bool wantsMg = c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && stiff > 64.0);
+        if (!wantsMg || c->prm.viscosity_lane_width == 2) return viscosity_solve_t<double>(c, dt, info);
+        c->vMixed64 = 1;
+        const int rc = viscosity_solve_t<float>(c, dt, info);
+        c->vMixed64 = 0;
+        return rc;
+    }
     return viscosity_solve_t<float>(c, dt, info);
 }
 

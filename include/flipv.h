@@ -63,7 +63,9 @@ enum flipv_preconditioner { FLIPV_PRECOND_AUTO = 0, FLIPV_PRECOND_DIAGONAL = 1, 
 
 enum flipv_precision {
     FLIPV_PRECISION_FP32 = 0, /* solver vectors fp32, every reduction and scalar fp64 (default) */
-    FLIPV_PRECISION_FP64 = 1  /* solver vectors fp64 like the reference's VectorXd / std::vector<double> */
+    FLIPV_PRECISION_FP64 = 1  /* solver vectors fp64 like the reference's VectorXd / std::vector<double>.  Pressure and the diagonally preconditioned viscosity solve: fp64
+                                 PCG vectors.  Viscosity under the multigrid (an fp32 V-cycle): mixed-precision iterative refinement -- solution and residual b - A_ref x in
+                                 fp64, the Krylov loops in fp32, repeated until the FP64 residual meets viscosity_tolerance (status 1 if it does not) */
 };
 
 /* Tunables.  Defaults = the reference's private constants (fluidsimulation.h:121,128-130,
@@ -108,7 +110,13 @@ typedef struct flipv_params {
                                     correction stage(s) solve A dx = b - A_ref x (fp64 residual) to viscosity_stage2_factor of the defect, never below
                                     viscosity_tolerance, in at most viscosity_stage2_max_iterations iterations each; a correction that RAISES the fp64
                                     residual is taken back.  flipv_solve_info: status 0 = every stage reached its target; residual = stage 1's;
-                                    defect_residual = max|b - A_ref x| delivered; correction_* = what the correction stages did */
+                                    defect_residual = max|b - A_ref x| delivered; correction_* = what the correction stages did.
+                                    REPRODUCIBILITY: scatters and dot products sum in arrival order, so two runs agree to solver tolerance, not bit for bit.  With the
+                                    reference's operator that can be coarser LOCALLY: its rounded diagonal leaves the near-rigid modes of tiny detached liquid clusters
+                                    (own volumes of the size of the defect, which may even come out slightly negative) ill-determined -- two runs of one
+                                    configuration were seen 4e-2 apart on the faces of such a cluster on the substep where a body touches the wall
+                                    (tests/test_gpu_wide.py: test_liquid_box_restriction_over_a_long_run pins the exact operator for that reason); the reference itself
+                                    has the same indeterminacy, it only sums in a fixed order.  exact_viscosity_operator = 1 does not */
     int residual_replacement;    /* n > 0 (fp32 vectors in the brick layout): every n iterations the solution accumulated so far is flushed into an
                                     fp64 accumulator and the recurrence residual is REPLACED by b - A x evaluated in fp64 (group-wise update, van
                                     der Vorst & Ye; two extra launches per n iterations), so that the stop test sees the true residual.  0

@@ -420,3 +420,31 @@ def test_moving_liquid_default_params_unchained_after_25_reference_substeps(orac
     assert err <= VEL_TOL and perr <= 1e-5
     c.close()
     o.close()
+
+
+@pytest.mark.parametrize("N,nu", [(64, 200.0), (128, 5.0)])
+def test_fp64_precision_under_the_multigrid_meets_the_references_own_criterion(oracle, N, nu):
+    """flipv_params.precision = FP64 (the reference's vector type) with the default preconditioner: until round 4 that took the diagonal and, where the
+    system is stiff, handed back an iterate stopped at the cap.  Now: mixed-precision iterative refinement under the multigrid -- fp64 solution and fp64
+    residual on the reference's operator, fp32 Krylov loops -- until the FP64 residual meets 1e-6 max|rhs|, the reference's own criterion
+    (pcgsolver.h:259): status 0, defect_residual <= 1e-6 rhs, inside the cap of 700, velocities within 1e-5 of the oracle run to convergence."""
+    from flipviscosity3d_amd.capi import Context
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid); c.set_viscosity(nu); c.set_params(precision=1)
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid); o.set_viscosity(nu); o.set_solver_limits(vmaxiter=400000)
+    c.particles = P
+    o.particles = P
+    st = c.substep(0.01)
+    sec, vi, pi = o.substep(0.01)
+    v = st["viscosity"]
+    err = vel_err(c, [o.grid(n) for n in "UVW"])
+    print("%d^3 nu %g, precision fp64: %d iterations (%d in %d refinement evaluations; oracle %d), status %d, fp64 residual %.2e rhs, velocity error %.2e" % (
+        N, nu, v["iterations"], v["correction_iterations"], v["refinements"], vi["iterations"], v["status"], v["defect_residual"] / v["rhs_norm"], err))
+    assert vi["status"] == 0
+    assert v["status"] == 0 and v["preconditioner"] == 1 and v["iterations"] <= 700, v
+    assert 0.0 < v["defect_residual"] <= 1.0000001e-6 * v["rhs_norm"], v
+    assert err <= 1e-5, err
+    c.close()
+    o.close()

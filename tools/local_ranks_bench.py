@@ -45,10 +45,13 @@ for c, p in zip(ctxs, parts):
     c.set_viscosity(nu)
     c.particles = p
 out = [None] * R
+hist = []
 def work(r):
     c = ctxs[r]
     for t in range(3):
         st = c.substep(min(c.cfl(), 0.01))
+        if r == 0:
+            hist.append((st["viscosity"]["iterations"], st["pressure"]["iterations"]))
     out[r] = st
 t0 = time.perf_counter()
 th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
@@ -58,6 +61,19 @@ print("wall %.2f s for 3 substeps of %d ranks sharing one device" % (time.perf_c
 for r, st in enumerate(out):
     print("rank", r, {k: round(v, 2) for k, v in st["phase_ms"].items()}, "total %.1f" % st["total_ms"], "its", st["viscosity"]["iterations"], st["pressure"]["iterations"],
           "rows", st["viscosity"]["rows"], "particles", ctxs[r].num_particles)
+print("iterations per substep (viscosity, pressure):", hist)
+if mode != "weak":   # the single domain on the same three substeps
+    del ctxs
+    ref = capi.Context(I, J, K, dx, device=0)
+    if extra:
+        ref.set_params(**extra)
+    ref.set_solid_sdf(solid_g); ref.set_viscosity(nu); ref.particles = P
+    single = []
+    for t in range(3):
+        st = ref.substep(min(ref.cfl(), 0.01))
+        single.append((st["viscosity"]["iterations"], st["pressure"]["iterations"]))
+    print("single domain, the same three substeps:           ", single)
+    ref.close()
 v, p = out[0]["viscosity"], out[0]["pressure"]
 print("viscosity solve: layout %d, preconditioner %d, %d iterations (%d in correction stages), status %d / %d; all-reduced by the global hierarchy: %.2f MB once per solve, %.3f MB per iteration" % (
     v["layout"], v["preconditioner"], v["iterations"], v["correction_iterations"], v["status"], v["correction_status"], v["comm_bytes_setup"] / 1e6, v["comm_bytes_per_iteration"] / 1e6))
