@@ -577,6 +577,42 @@ __global__ __launch_bounds__(256) void k_brick_zero_f64(const int *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ the system's geometry (functions of the liquid and the solid SDF only), on stream `st`
+static int visc_geometry(flipv_context *c, hipStream_t st) {
+    const Lay &L = c->L;
+    // face states
+    if (c->faceStateVersion != c->solidVersion) {  // functions of the solid SDF only: everywhere
+        const Lay F1 = fv_range(c, 1), F2 = fv_range(c, 2);
+        hipLaunchKernelGGL(k_solid_center, GRID3(F2), 0, st, F2, c->solid, c->scp);
+        hipLaunchKernelGGL(k_face_states, GRID3(F1), 0, st, F1, c->scp, c->stU, c->stV, c->stW);
+        c->faceStateVersion = c->solidVersion;
+    }
+    const Lay R1 = fv_range_liquid(c, 1, 4), R2 = fv_range_liquid(c, 2, 4), R3 = fv_range_liquid(c, 3, 4), R4 = fv_range_liquid(c, 4, 4);
+    // band mask + the seven volume lattices (viscositysolver.cpp:135-178).  The mask must be final one entry beyond the volumes' range R1: a
+    // corner's first visitor is looked up among the 27 cubes around an index (k_volume_sample)
+    hipLaunchKernelGGL(k_valid_init, GRID3(R4), 0, st, R4, c->phi, c->validCells);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(R3), 0, st, R3, c->validCells, c->validTmp);
+    hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, st, R2, c->validTmp, c->validCells);
+    const float h = (float)(0.5 * c->dx);
+    const int fullVol = c->bandPrevValid ? 0 : 1;  // volumes and factors are stored only where the band is or was in the previous solve
+    VolLattices Q;
+    float *vols[7] = {c->volC, c->volU, c->volV, c->volW, c->volEU, c->volEV, c->volEW};
+    const int lats[7] = {LAT_CELL, LAT_U, LAT_V, LAT_W, LAT_EU, LAT_EV, LAT_EW};
+    const float cs[7][3] = {{h, h, h}, {0, h, h}, {h, 0, h}, {h, h, 0}, {h, 0, 0}, {0, h, 0}, {0, 0, h}};  // viscositysolver.cpp:171-177
+    for (int q = 0; q < 7; q++) { Q.vol[q] = vols[q]; Q.lat[q] = lats[q]; Q.cs[q][0] = cs[q][0]; Q.cs[q][1] = cs[q][1]; Q.cs[q][2] = cs[q][2]; }
+    if (!c->surfList) {
+        hipError_t e = hipMalloc((void **)&c->surfList, (L.n + 64) * sizeof(unsigned));
+        if (e != hipSuccess) { c->err = std::string("hipMalloc(surface list): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
+    }
+    unsigned *nlist = c->surfList + L.n;
+    HIPCHK(c, hipMemsetAsync(nlist, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(k_volume_classify, GRID3(R1), 0, st, R1, Q, c->phi, c->validCells, c->bandPrev, fullVol, c->surfList, nlist);
+    hipLaunchKernelGGL(k_volume_sample, dim3(4096), dim3(256), 0, st, c->L, Q, c->phi, (const uint8_t *)c->validCells, c->surfList, nlist, c->dx);
+    return FLIPV_OK;
+}
+// (Measured in round 4 and dropped: the geometry on a SIDE STREAM started right after the particle level set, beside P2G + extrapolation + body force, which
+// touch none of its arrays.  The P2G phase grew from 0.75 to 0.98 ms, the viscosity phase shrank from 12.46 to 12.1-12.3: 946-960 MCells/s against 954-961.)
+
 // ------------------------------------------------------------------ the fp64 accumulator on the PLANE layouts
 // What k_bflush / k_bresidual / k_unbrick_to_f32 are to the brick layout (k_viscosity_brick.hip): the solution accumulated in fp64 beside the PCG's
 // fp32 x, the residual b - A_outer xacc evaluated in fp64, so that the two-stage defect correction (viscosity_solve_t) -- and the restart of a
@@ -722,36 +758,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
 
     // Everything up to the factors is evaluated redundantly on the halo planes a neighbour-owned row would need
     // (inputs: phi with a 4-plane halo, the replicated solid SDF), so the setup needs no exchange of its own.
-    // face states
-    if (c->faceStateVersion != c->solidVersion) {  // functions of the solid SDF only: everywhere
-        const Lay F1 = fv_range(c, 1), F2 = fv_range(c, 2);
-        hipLaunchKernelGGL(k_solid_center, GRID3(F2), 0, c->stream, F2, c->solid, c->scp);
-        hipLaunchKernelGGL(k_face_states, GRID3(F1), 0, c->stream, F1, c->scp, c->stU, c->stV, c->stW);
-        c->faceStateVersion = c->solidVersion;
-    }
-    const Lay R0 = fv_range_liquid(c, 0, 4), R1 = fv_range_liquid(c, 1, 4), R2 = fv_range_liquid(c, 2, 4), R3 = fv_range_liquid(c, 3, 4), R4 = fv_range_liquid(c, 4, 4);
-    // band mask + the seven volume lattices (viscositysolver.cpp:135-178).  The mask must be final one entry beyond the volumes' range R1: a
-    // corner's first visitor is looked up among the 27 cubes around an index (k_volume_sample)
-    hipLaunchKernelGGL(k_valid_init, GRID3(R4), 0, c->stream, R4, c->phi, c->validCells);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(R3), 0, c->stream, R3, c->validCells, c->validTmp);
-    hipLaunchKernelGGL(k_valid_dilate, GRID3(R2), 0, c->stream, R2, c->validTmp, c->validCells);
-    const float h = (float)(0.5 * c->dx);
+    // The GEOMETRY of the system -- face states, band mask, the seven control-volume lattices: functions of the liquid SDF and the solid SDF alone (visc_geometry).
+    const Lay R0 = fv_range_liquid(c, 0, 4), R1 = fv_range_liquid(c, 1, 4);
     const int fullVol = c->bandPrevValid ? 0 : 1;  // volumes and factors are stored only where the band is or was in the previous solve
-    {
-        VolLattices Q;
-        float *vols[7] = {c->volC, c->volU, c->volV, c->volW, c->volEU, c->volEV, c->volEW};
-        const int lats[7] = {LAT_CELL, LAT_U, LAT_V, LAT_W, LAT_EU, LAT_EV, LAT_EW};
-        const float cs[7][3] = {{h, h, h}, {0, h, h}, {h, 0, h}, {h, h, 0}, {h, 0, 0}, {0, h, 0}, {0, 0, h}};  // viscositysolver.cpp:171-177
-        for (int q = 0; q < 7; q++) { Q.vol[q] = vols[q]; Q.lat[q] = lats[q]; Q.cs[q][0] = cs[q][0]; Q.cs[q][1] = cs[q][1]; Q.cs[q][2] = cs[q][2]; }
-        if (!c->surfList) {
-            hipError_t e = hipMalloc((void **)&c->surfList, (L.n + 64) * sizeof(unsigned));
-            if (e != hipSuccess) { c->err = std::string("hipMalloc(surface list): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
-        }
-        unsigned *nlist = c->surfList + L.n;
-        HIPCHK(c, hipMemsetAsync(nlist, 0, sizeof(unsigned), c->stream));
-        hipLaunchKernelGGL(k_volume_classify, GRID3(R1), 0, c->stream, R1, Q, c->phi, c->validCells, c->bandPrev, fullVol, c->surfList, nlist);
-        hipLaunchKernelGGL(k_volume_sample, dim3(4096), dim3(256), 0, c->stream, c->L, Q, c->phi, (const uint8_t *)c->validCells, c->surfList, nlist, c->dx);
-    }
+    if ((rc = visc_geometry(c, c->stream))) return rc;
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
     // ---- which layout the solver's arrays take (flipv_internal.h: VLAYOUT_*).  Bricks on sparse liquids of a single-domain context, the
