@@ -66,13 +66,18 @@ def test_fullsize_projection_is_divergence_free(scene, precision):
     c = ctx(scene, precision=precision, pressure_rel_tolerance=1e-6 if precision == 0 else 0.0)
     st = c.substep(0.01)
     assert st["pressure"]["status"] == 0
-    # the default viscosity solve converges inside the reference's cap (fp32: the multigrid-preconditioned loop; fp64 vectors run the
-    # diagonal, which stops at the cap and is accepted because the residual is below 10, viscositysolver.cpp:676-689)
+    # the default viscosity solve converges inside the reference's cap: fp32 vectors -- the multigrid-preconditioned two-stage solve; precision = FP64 -- the same
+    # loops refined until the FP64 residual on the reference's operator meets 1e-6 max|rhs| or a further stage stops paying (status 1 then; until round 4 fp64
+    # vectors took the diagonal and stopped at the cap here)
     v = st["viscosity"]
+    print("256^3, precision %d: %d viscosity iterations (%d in correction stages), status %d / %d, fp64 residual %.2e rhs" % (
+        precision, v["iterations"], v["correction_iterations"], v["status"], v["correction_status"], v["defect_residual"] / v["rhs_norm"]))
     if precision == 0:
         assert v["status"] == 0 and v["preconditioner"] == 1 and v["iterations"] < 700, v
     else:
-        assert v["iterations"] == 700 and v["status"] == 1 and v["residual"] < 10.0, v
+        assert v["preconditioner"] == 1 and v["iterations"] < 700 and v["status"] in (0, 1), v
+        assert 0.0 < v["defect_residual"] <= 1e-5 * v["rhs_norm"], v
+        assert v["status"] == (0 if v["defect_residual"] <= 1.0000001e-6 * v["rhs_norm"] else 1), v
     U, V, W = (c.grid(n).astype(np.float64) for n in "UVW")
     wU, wV, wW = (c.grid("WEIGHT_" + n).astype(np.float64) for n in "UVW")
     phi = c.grid("LIQUID_PHI")

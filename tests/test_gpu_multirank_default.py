@@ -128,7 +128,7 @@ def test_rccl_backend_single_rank_default_params():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("N,dims", [(64, (1, 1, 2)), (64, (2, 2, 2)), (128, (2, 2, 2)), (128, (4, 1, 1))])
+@pytest.mark.parametrize("N,dims", [(64, (1, 1, 2)), (64, (2, 2, 2)), (64, (1, 1, 4)), (128, (2, 2, 2)), (128, (4, 1, 1))])   # (1 x 1 x 4 at 64^3: the last slab holds no liquid)
 def test_distributed_level_1_is_the_same_preconditioner(N, dims):
     """flipv_params.multigrid_distributed_levels = 1 (the default where the system has > 4.5e6 rows: config 4): level 1 of the viscosity hierarchy is cycled by
     the rows' owners with halo exchanges instead of redundantly by every rank after an all-reduce of its right-hand side -- the SAME V-cycle, so the
