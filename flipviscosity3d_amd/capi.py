@@ -61,7 +61,7 @@ class Params(C.Structure):
                 ("multigrid_rank_local", C.c_int), ("multigrid_distributed_levels", C.c_int),
                 ("viscosity_stage1_factor", C.c_float), ("viscosity_stage2_factor", C.c_float), ("viscosity_stage2_max_iterations", C.c_int),
                 ("viscosity_stage2_rounds", C.c_int), ("viscosity_two_stage_max_stiffness", C.c_float),
-                ("reserved", C.c_int * 1)]
+                ("viscosity_defect_predictor", C.c_int)]
 
 LAYOUT_AUTO, LAYOUT_PLAIN, LAYOUT_SWIZZLED, LAYOUT_BRICK = 0, 1, 2, 3
 PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID = 0, 1, 2

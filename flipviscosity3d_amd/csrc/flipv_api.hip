@@ -364,8 +364,6 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         const int rcT = fv_check_block_thickness(c, p->cfl_number, "flipv_set_params");
         if (rcT) return rcT;
     }
-    for (int r = 0; r < 1; r++)
-        if (p->reserved[r] != 0) { c->err = "flipv_set_params: reserved fields must be 0"; return FLIPV_ERR_INVALID; }
     // every field has an error path: nothing out of range is silently ignored or used as given
     {
         const char *bad = nullptr;
@@ -395,6 +393,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!fin(p->viscosity_stage2_factor, 0.0f, 1.0f)) bad = "viscosity_stage2_factor";
         else if (!in(p->viscosity_stage2_max_iterations, 0, 1 << 20) || !in(p->viscosity_stage2_rounds, 0, 16)) bad = "viscosity_stage2_max_iterations / viscosity_stage2_rounds";
         else if (!(p->viscosity_two_stage_max_stiffness >= 0.0f)) bad = "viscosity_two_stage_max_stiffness";
+        else if (!in(p->viscosity_defect_predictor, -1, 0)) bad = "viscosity_defect_predictor";
         if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     }
     c->prm = *p;

@@ -348,7 +348,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 RHS(SW[c - 1], W[c - 1], -fK);
                 dg[0] = vol + fR + fL + fT + fB + fF + fK;
                 rv[0] = dg[0] != 0.0f ? rval : 0.0f;
-                if (dg[0] != 0.0f) { vm[0] = vol; vr[0] = refdiag ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[0]) : vol; }
+                if (dg[0] != 0.0f) { vm[0] = vol; vr[0] = (refdiag & 1) ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[0]) : vol; }
             }
         }
         if (d_row_range(1, i, j, k, L) && SV[c] == ST_FLUID) {  // ---- V face (viscositysolver.cpp:472-568)
@@ -373,7 +373,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 RHS(SW[c - sy], W[c - sy], -fK);
                 dg[1] = vol + fR + fL + fT + fB + fF + fK;
                 rv[1] = dg[1] != 0.0f ? rval : 0.0f;
-                if (dg[1] != 0.0f) { vm[1] = vol; vr[1] = refdiag ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[1]) : vol; }
+                if (dg[1] != 0.0f) { vm[1] = vol; vr[1] = (refdiag & 1) ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[1]) : vol; }
             }
         }
         if (d_row_range(2, i, j, k, L) && SW[c] == ST_FLUID) {  // ---- W face (viscositysolver.cpp:570-664)
@@ -398,7 +398,7 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 RHS(SV[c - sz], V[c - sz], -fB);
                 dg[2] = vol + fR + fL + fT + fB + fF + fK;
                 rv[2] = dg[2] != 0.0f ? rval : 0.0f;
-                if (dg[2] != 0.0f) { vm[2] = vol; vr[2] = refdiag ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[2]) : vol; }
+                if (dg[2] != 0.0f) { vm[2] = vol; vr[2] = (refdiag & 1) ? d_ref_volume(vol, fR, fL, fT, fB, fF, fK, dg[2]) : vol; }
             }
         }
     store:
@@ -415,7 +415,9 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                 if (bU) { bU[cp] = rv[0]; bV[cp] = rv[1]; bW[cp] = rv[2]; }
 #pragma unroll
                 for (int m = 0; m < 3; m++) {
-                    v.r[m][cs] = (RT<T>)rv[m]; v.x[m][cs] = (T)0; v.s[m][cp] = (T)0;
+                    const float uo = m == 0 ? U[c] : (m == 1 ? V[c] : W[c]);
+                    const float r0 = ((refdiag & 2) && dg[m] != 0.0f) ? rv[m] - (vr[m] - vm[m]) * uo : rv[m];   // (bit 1: the defect predictor, viscosity_solve_t: b - E u_old)
+                    v.r[m][cs] = (RT<T>)r0; v.x[m][cs] = (T)0; v.s[m][cp] = (T)0;
                     babs = fmax(babs, fabs((double)rv[m]));
                     rows += dg[m] != 0.0f;
                 }
@@ -802,6 +804,17 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // flipv_params.exact_viscosity_operator = 0 (default): the solve applies the reference's operator INCLUDING the rounding of its float
     // diagonal (d_ref_volume) -- at 256^3 the reference's converged answer is 7e-6 from this operator's and 1.5e-4 from the exact one's.
     const int refDiag = c->prm.exact_viscosity_operator ? 0 : 1;
+    // DEFECT PREDICTOR (the two-stage solve below: the Krylov loop runs on the exact operator A, the solve is for the reference's A_ref = A + E, E diagonal):
+    // stage 1 solves A x = b - E u_old, u_old = the incoming velocity of the row -- one step of the fixed point x <- A^-1 (b - E x) started from u_old
+    // instead of from 0.  What stage 1 then leaves of the defect is E (x - u_old) instead of E x, so the correction stage starts closer: the same or fewer
+    // iterations for the same or better velocities on every fixture (tools/r4_predict_scan.py, profiles/r4/predictor_scan.log: 256^3 62/59 -> 60/59 iterations,
+    // 1.9e-5/2.5e-5 -> 1.5e-5/2.6e-5; nu dt/dx^2 = 1.2e5: 199/149 -> 162/149, 2.5e-5/3.9e-6 -> 1.6e-5/1.9e-5; config 4's scene 233/234 -> 233/219).
+    // The correction stage stays: SKIPPING it where the prediction looks good was measured too -- bench 957 -> 1 107 MCells/s, 256^3 still 2.1e-5/2.6e-5, but
+    // 1.1e-4/2.2e-4 at nu dt/dx^2 = 1.2e5, and neither max|b - A_ref x| nor what one multigrid cycle on that residual moves (3e-6 ... 1e-5 of max|u| in every
+    // case) tells the two apart: the defect's error sits in the near-rigid modes a residual does not show.  The right-hand side's copy (vB) stays b: the
+    // fp64 residual after stage 1 is b - A_ref x.  (Not with the opt-in residual replacement, which recomputes the LOOP's residual from vB.)
+    const bool predict = refDiag && mgPlanned && std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && c->prm.viscosity_defect_predictor >= 0 &&
+                         c->prm.residual_replacement <= 0;
     auto run_setup = [&](int layout, bool first) -> int {
         const bool brick = layout == VLAYOUT_BRICK;
         if (c->viscStateValid && (c->vLayout == VLAYOUT_BRICK) != brick) {
@@ -830,7 +843,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const Lay RS = full ? fv_range(c, 0) : R0;
         hipLaunchKernelGGL(k_visc_setup<T>, GRID3(RS), 0, c->stream, RS, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
-                           c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, refDiag,
+                           c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, (refDiag ? 1 : 0) | (predict ? 2 : 0),
                            brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2]);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));   // max|rhs|, max|u| over the rows
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -988,13 +1001,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // 3 000; 128^3, the stiff fixtures and the oracle scans from 8e3 to 8e4 likewise) -- the iteration count does: a restarted loop has lost its Krylov
         // space, so on a mildly stiff system (64^3 at nu = 5: nu dt/dx^2 = 205) stopping earlier costs 50 -> 63 iterations, on a stiff one it saves (256^3:
         // 70 -> 62, bench 879 -> 957 MCells/s; 64^3 nu = 200: 104 -> 87; nu = 800: 181 -> 156).  300 up to nu dt/dx^2 = 1 000, 3 000 beyond.
-        const double f1 = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : (stiffNow > 1000.0 ? 3000.0 : 300.0);
-
+        const double f1user = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : 0.0;
         const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5;
         const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 200;   // (round 3: 48.  A first stage takes 7-30 iterations, a second one at nu dt/dx^2 = 1.3e5 100-150)
         const int rounds = c->vMixed64 ? 8 : (c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : 1);   // (vMixed64: refinement to the fp64 tolerance, fv_viscosity_solve)
-        const double tolMain = (innerDiffers && stiffNow <= gate) ? f1 * tolFinal : tolFinal;
-        const double f2 = c->vMixed64 ? 1e-2 : (c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (stiffNow > 2.0e4 ? 1e-3 : (tolMain > tolFinal ? 1e-2 : 2e-2)));
+        const bool early = innerDiffers && stiffNow <= gate && f1user != 1.0;   // stage 1 stops short of the final tolerance
+        const double f2 = c->vMixed64 ? 1e-2 : (c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (stiffNow > 2.0e4 ? 1e-3 : (early ? 1e-2 : 2e-2)));
+        const double tolMain = !early ? tolFinal : (f1user > 0.0 ? f1user : (stiffNow > 1000.0 ? 3000.0 : 300.0)) * tolFinal;
         if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
         const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
@@ -1015,6 +1028,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         };
         // (A warm start -- xacc = the incoming velocity, the loop solving for the correction only -- was tried and dropped: the incoming field
         // is rough on the rows (ghost-band and extrapolated faces next to P2G faces), so max|b - A u_old| came out 5 000 x max|b| at 256^3.)
+        void (*mgspmv)(flipv_context *, const PcgScal &, int) = brick
+            ? +[](flipv_context *cc, const PcgScal &s2, int it) { fv_brick_spmv<float>(cc, s2, it, false); }
+            : +[](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); };
         while (!success) {
         const bool correction = correctionDue;   // this round is a bounded defect-correction stage (see above)
         const int capNow = (correction && cap - itersDone > cap2) ? cap2 : cap - itersDone;
@@ -1030,9 +1046,6 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // systems on the diagonal instead (fv_visc_auto_pick).)
         conv = -1;
         if (useMg) {
-            void (*mgspmv)(flipv_context *, const PcgScal &, int) = brick
-                ? +[](flipv_context *cc, const PcgScal &s2, int it) { fv_brick_spmv<float>(cc, s2, it, false); }
-                : +[](flipv_context *cc, const PcgScal &s2, int it) { launch_visc_spmv<float, 4>(cc, s2, it, 0, cc->nActiveV); };
             if ((rc = fv_viscosity_pcg_mg(c, sc, capNow, mgspmv, replacePeriod, itersDone > 0 ? 1 : 0, &conv))) return rc;
         } else if (brick) {
             fv_brick_init<T>(c, sc);
