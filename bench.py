@@ -584,7 +584,7 @@ def main():
         dist.destroy_process_group()
 
 
-def dense_roofline(N, precision, reps=50):
+def dense_roofline(N, precision, reps=50, **extra):
     """The two SpMV kernels on a completely filled N^3 box (every interior cell liquid): active ~ swept cells, a launch
     streams hundreds of MB, so achieved GB/s against the HBM peak measures the kernels themselves.  flipv_bench_spmv
     launches the solver's own kernel `reps` times back to back between two HIP events on the library's stream."""
@@ -598,7 +598,7 @@ def dense_roofline(N, precision, reps=50):
     c = Context(N, N, N, dx)
     c.set_solid_sdf(solid)
     c.set_viscosity(5.0)
-    c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4)
+    c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4, **extra)
     rng = np.random.default_rng(0)
     c.set_grid("LIQUID_PHI", np.full((N, N, N), -0.5 * dx, np.float32))
     for n, shp in (("U", (N, N, N + 1)), ("V", (N, N + 1, N)), ("W", (N + 1, N, N))):
@@ -617,7 +617,7 @@ def dense_roofline(N, precision, reps=50):
                      "frac": gbs / HBM_PEAK_GBS, "swept_indices_per_launch": swept}
     out["viscosity_spmv"]["variant"] = "the diagonal-preconditioned loop's launch: reads the residual for the fused (r/d, q) as well (64 B per unit move, 52 are counted)"
     # the variant the multigrid-preconditioned loop launches (what AUTO runs on a stiff system): q = A p and p.q only, exactly the 52 B per unit
-    c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4, beta_from_conjugacy=1)
+    c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4, beta_from_conjugacy=1, **extra)
     ms, swept = c.bench_spmv(1, reps)
     gbs = VISC_SPMV_BYTES_PER_INDEX * (vi["rows"] / 3.0) / (ms * 1e-3) / 1e9
     out["viscosity_spmv_multigrid_loop"] = {"avg_launch_us": ms * 1e3, "units_per_launch": vi["rows"] / 3.0, "bytes_per_unit": VISC_SPMV_BYTES_PER_INDEX, "achieved": gbs,

@@ -214,6 +214,8 @@ struct flipv_context {
     size_t stageCap;
     // scalars
     double *d_scal;   // device scalar scratch (PCG)
+    int geoMemoP = 0, geoMemoV = 0;   // fv_build_tiles: a tile geometry tried and turned down (pressure, viscosity)
+    double tileFill;       // fv_build_tiles: unknowns per index of the listed tiles inside the lattices' extent (the last list built)
     double *d_scal_small;  // 64 doubles: communication scratch (counts, CFL max, barrier)
     double *d_gather = nullptr;   // NSLOT x FV_GATHER_MAX doubles: fv_allgather_f64
     double *h_scal;   // pinned host mirror

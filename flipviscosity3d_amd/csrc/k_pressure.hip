@@ -333,20 +333,37 @@ static int gather_masks(flipv_context *c, const TileGrid &tg, int vw, const uint
 }
 
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap) {
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap, double minLanes, int *memo) {
     const int forceRowl = (c->prm.tile_rows == 16 || c->prm.tile_rows == 64) ? c->prm.tile_rows : 0;
     int rowl = forceRowl ? forceRowl : tg->rowl;
     *tg = make_tile_grid(c->L, rowl, vw);
     int rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior);
     if (rc) return rc;
+    // how full the tiles are: indices with unknowns / indices of the listed tiles inside the lattices' extent
+    auto fill_now = [&]() { return c->h_flags[7] > 0 ? ((double)*hostCount / perIndex) / (4.0 * (double)c->h_flags[7]) : 1.0; };
+    // ... and how much of the listed tiles lies inside the extent at all: a 256-wide row on a 385-wide lattice idles a quarter of its lanes
+    // (filled boxes, profiles/r4/dense_geometry_scan.log: the viscosity SpMV at 320^3 / 384^3 / 448^3 -- 0.63 / 0.75 / 0.875 of the wide rows' lanes inside --
+    // runs at 0.36 / 0.48 / 0.51 of the HBM peak in 256-wide rows and at 0.57 / 0.53 / 0.55 in 64-wide ones, the pressure SpMV at 0.46 / 0.52 / 0.52 and
+    // 0.60 / 0.49 / 0.49; at 512^3 wide rows win both.  minLanes = the share below which the caller's kernel is better off in narrow rows.)
+    auto lanes_now = [&]() { return *nActive > 0 ? 4.0 * (double)c->h_flags[7] / ((double)*nActive * 256.0 * vw) : 1.0; };
+    c->tileFill = fill_now();
     if (!forceRowl && *nActive > 0) {
-        // how full the tiles are: indices with unknowns / indices of the listed tiles inside the lattices' extent
-        const double fill = c->h_flags[7] > 0 ? ((double)*hostCount / perIndex) / (4.0 * (double)c->h_flags[7]) : 1.0;
-        const int want = (rowl == 64 && fill < 0.45) ? 16 : ((rowl == 16 && fill > 0.65) ? 64 : rowl);
-        if (want != rowl) {
-            *tg = make_tile_grid(c->L, want, vw);
-            if ((rc = build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior))) return rc;
+        // *memo remembers a geometry tried and turned down, so that a steady scene does not pay for the trial every solve: n > 0 = narrow rows were no better
+        // when the wide list had n tiles, n < 0 = wide rows idled too many lanes when the narrow list had -n
+        auto same = [&](int then) { return then > 0 && abs(*nActive - then) <= then / 10; };
+        auto rebuild = [&](int r) { *tg = make_tile_grid(c->L, r, vw); return build_tiles_once(c, *tg, vw, nc, d0, d1, d2, mask, list, nActive, nInterior); };
+        const double fill = c->tileFill, lanes = lanes_now();
+        if (rowl == 64 && fill < 0.45) { if ((rc = rebuild(16))) return rc; *memo = 0; }
+        else if (rowl == 64 && lanes < minLanes && !same(*memo)) {
+            const int n64 = *nActive;
+            if ((rc = rebuild(16))) return rc;
+            if (lanes_now() < 1.1 * lanes) { if ((rc = rebuild(64))) return rc; *memo = n64; } else *memo = 0;
+        } else if (rowl == 16 && fill > 0.65 && !same(-*memo)) {
+            const int n16 = *nActive;
+            if ((rc = rebuild(64))) return rc;
+            if (lanes_now() < minLanes && lanes >= 1.1 * lanes_now()) { if ((rc = rebuild(16))) return rc; *memo = -n16; } else *memo = 0;
         }
+        c->tileFill = fill_now();
     }
     return gather_masks(c, *tg, vw, mask, list, *nActive, mlist, mlistCap);
 }
@@ -444,9 +461,9 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->dx, dt, c->prm.min_frac);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->pMask, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1, &c->mlistP, &c->mlistCapP);  // synchronises: h_scal[0] = max|b|
+    rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->pMask, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1, &c->mlistP, &c->mlistCapP, 0.70, &c->geoMemoP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
-    if ((rc = fv_build_runs(c, c->tgP, VW_P, c->nActiveP, c->tgP.rowl == 64, c->pMask, &c->runsP, &c->runCapP, &c->nRunsP, &c->runLenP, &c->rmaskP, &c->rmaskCapP))) return rc;
+    if ((rc = fv_build_runs(c, c->tgP, VW_P, c->nActiveP, c->tgP.rowl == 64 || c->tileFill > 0.65, c->pMask, &c->runsP, &c->runCapP, &c->nRunsP, &c->runLenP, &c->rmaskP, &c->rmaskCapP))) return rc;
     {
         float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)
         double bd = c->h_scal[0];

@@ -888,7 +888,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if ((rc = fv_build_bricks(c, R0))) return rc;
         c->nActiveV = c->nBricks; c->nIntV = c->comm ? 0 : c->nBricks; c->nRunsV = 0;   // (under a communicator the brick SpMV is one launch AFTER the halo exchange: no interior / cut-face split of the brick list)
     } else {
-        rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3, &c->mlistV, &c->mlistCapV);
+        rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3, &c->mlistV, &c->mlistCapV, 0.90, &c->geoMemoV);
         if (rc) return rc;
         if ((rc = fv_build_runs(c, c->tgV, c->vwV, c->nActiveV, !c->vPred, c->vRowMask, &c->runsV, &c->runCapV, &c->nRunsV, &c->runLenV, &c->rmaskV, &c->rmaskCapV))) return rc;
         if (c->vSwz != (swzOk && c->tgV.rowl == 16 ? 1 : 0)) {  // the geometry changed: the vectors go into the other layout

@@ -330,7 +330,7 @@ static inline int pcg_grid(const flipv_context *c, int ntiles) {
 // inside the lattices' extent that carry unknowns).  `hostCount` (read after the internal
 // synchronisation) = unknowns of this rank, `perIndex` unknowns per index (1 pressure, 3 viscosity).
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
-                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap);
+                   const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap, double minLanes, int *memo);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
 // Runs of the tile list fv_build_tiles just built (call right after it: uses its tile flags).  *nruns = 0 when the k-marching
 // kernels are not to be used (multi-rank runs, lane width 2, flipv_params.spmv_run_length = -1).

@@ -66,12 +66,15 @@ def test_wide_domain_substeps_match_oracle(oracle, precision):
     o.close()
 
 
-def test_tile_geometry_follows_the_liquid():
+@pytest.mark.parametrize("I,J,filled_rows", [(248, 20, 64), (288, 20, 64), (288, 31, 16)])
+def test_tile_geometry_follows_the_liquid(I, J, filled_rows):
     """the solver tiles switch between the two geometries (csrc/pcg_geo.inc) as the liquid changes: a small blob in the
-    wide domain is solved on 64 x 16 tiles, the filled domain on 256 x 4 tiles again, and a context that went through the
-    switch gives the velocities of a fresh one"""
+    wide domain is solved on 64 x 16 tiles, the filled domain on 256 x 4 tiles again -- where those fit the lattice: 249 indices
+    are one 256-wide row; 289 idle 44 % of two, and the filled domain stays on the narrow tiles where THEIR lanes are better used (32 rows: two 16-row tiles,
+    0.90 against 0.56; with 21 rows the second narrow tile is mostly outside, 0.59 against 0.56, and fv_build_tiles asks for 10 %) --,
+    and a context that went through the switch gives the velocities of a fresh one"""
     from flipviscosity3d_amd import capi, hostapi as H
-    I, J, K = 288, 20, 24
+    K = 24
     dx = float(np.float32(1.0 / I))
     s = H.FluidSimulation()
     s.initialize(I, J, K, dx)
@@ -87,6 +90,8 @@ def test_tile_geometry_follows_the_liquid():
     full[:, 3] = 0.4 * np.sin(4 * np.pi * x)
     full[:, 4] = 0.12 * np.cos(6 * np.pi * x)
     blob = full[(np.abs(pos[:, 0] - 40.0) < 10.0) & (pos[:, 1] < 12.0)]
+    if J > 20:
+        full = full[pos[:, 1] < J - 3.0]   # (a free surface: this velocity field in a box filled to the lid has no divergence-free projection)
     assert len(blob) > 5000
     px, py = 8 * ((I + 1 + 7) // 8), 4 * ((J + 1 + 3) // 4)
     tiles = lambda rowl: -(-px // (4 * rowl)) * -(-py // (4 * (64 // rowl))) * (K + 1)
@@ -105,11 +110,11 @@ def test_tile_geometry_follows_the_liquid():
     a.particles = full
     st = a.substep(0.005)
     assert st["viscosity"]["status"] == 0 and st["pressure"]["status"] == 0
-    assert st["pressure"]["total_tiles"] == tiles(64) and st["viscosity"]["total_tiles"] == tiles(64), st
+    assert st["pressure"]["total_tiles"] == tiles(filled_rows) and st["viscosity"]["total_tiles"] == tiles(filled_rows), st
     b = ctx()
     b.particles = full
     st = b.substep(0.005)
-    assert st["pressure"]["total_tiles"] == tiles(64) and st["viscosity"]["total_tiles"] == tiles(64), st
+    assert st["pressure"]["total_tiles"] == tiles(filled_rows) and st["viscosity"]["total_tiles"] == tiles(filled_rows), st
     va, vb = [a.grid(n_) for n_ in "UVW"], [b.grid(n_) for n_ in "UVW"]
     assert rel_maxnorm3(va, vb) <= 1e-4   # two runs differ by the order of the fp32 scatter atomics, amplified by the solves (measured 4e-5)
     a.close()
