@@ -143,7 +143,8 @@ def transfer(comp, ijk, dims, mode="lin"):
 
 class MG:
     def __init__(self, A, comp, ijk, dims, nu1=2, nu2=2, omega=0.6, min_dim=4, smoother="jacobi", cheb_deg=2, f32=False, mode="lin", coarse_sweeps=8,
-                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0, gamma_at=-1, omega_coarse=0.0, nu_deep=0, deep_from=2):
+                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0, gamma_at=-1, omega_coarse=0.0, nu_deep=0, deep_from=2, skip=-1):
+        self.skip = skip
         self.lev = []
         self.nu1, self.nu2, self.omega, self.smoother, self.cheb_deg, self.coarse_sweeps, self.cheb_lo = nu1, nu2, omega, smoother, cheb_deg, coarse_sweeps, cheb_lo
         self.alpha, self.gamma, self.nu_fine, self.nu_coarse = alpha, gamma, nu_fine, nu_coarse
@@ -226,6 +227,8 @@ class MG:
             # top level additive: z = S r + P Mc P^T r, S = `additive` symmetric Jacobi sweeps from zero; the two terms are independent
             xs = self.smooth(0, None, b, self.additive)
             return xs + self.alpha * (L["P"] @ self.cycle(1, L["P"].T @ b))
+        if l == self.skip:   # this level only passes through (a 4:1 transfer between its neighbours: the composite of the two 2:1 ones)
+            return L["P"] @ self.cycle(l + 1, L["P"].T @ b)
         nu1, nu2 = (self.nu_fine, self.nu_fine) if (l == 0 and self.nu_fine) else (self.nu1, self.nu2)
         if l > 0 and self.nu_coarse:
             nu1 = nu2 = self.nu_coarse
