@@ -1095,6 +1095,18 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                 fprintf(stderr, " %d:%.2e", it, m / bnorm);
             }
             fprintf(stderr, "\n");
+            // the energy the iterations added to the iterate: |x_k+1|_A^2 - |x_k|_A^2 = alpha_k sigma_k = sigma_k^2 / (p_k, A p_k)   (Hestenes-Stiefel)
+            fprintf(stderr, "  energy terms alpha sigma:");
+            for (int it = 0; it < itersNow && it < capNow; it++) {
+                double sg = 0.0, pq = 0.0;
+                for (int bk = 0; bk < sc.nbank; bk++)
+                    for (int q = 0; q < NSLOT; q++) {
+                        sg += c->h_scal[(size_t)bk * stride + (size_t)it * 5 * NSLOT + q];
+                        pq += c->h_scal[(size_t)bk * stride + (size_t)it * 5 * NSLOT + NSLOT + q];
+                    }
+                fprintf(stderr, " %d:%.3e", it, pq != 0.0 ? sg * sg / pq : 0.0);
+            }
+            fprintf(stderr, "\n");
         }
         itersDone += itersNow;
         if (!correction) resBeforeStage = res;                   // the main loop's own (recurrence) residual
