@@ -492,6 +492,27 @@ def test_empty_and_degenerate_inputs():
     c.close()
 
 
+def test_set_params_rejects_out_of_range_values():
+    """flipv_set_params: every field has an error path -- nothing out of range is silently ignored or used as given; the message names the field, the
+    parameters in force stay what they were"""
+    from flipviscosity3d_amd.capi import Context, FlipvError
+    c = Context(8, 6, 5, 0.125)
+    bad = [("min_frac", 0.0), ("pic_ratio", 1.5), ("extrapolation_layers", -1), ("viscosity_tolerance", 0.0), ("check_every", -2), ("viscosity_preconditioner", 3),
+           ("exact_viscosity_operator", 2), ("residual_replacement", -1), ("viscosity_layout", 4), ("tile_rows", 32), ("viscosity_mg_coarsest_sweeps", -3),
+           ("pressure_mg_omega", float("nan")), ("viscosity_mg_omega_first", 2.5), ("verbose", 3), ("multigrid_distributed_levels", 2), ("grid_cap", -1),
+           ("viscosity_lane_width", 3), ("spmv_run_length", 1), ("viscosity_stage1_factor", 0.5), ("viscosity_stage2_factor", 1.5), ("viscosity_stage2_rounds", 17),
+           ("viscosity_two_stage_max_stiffness", -1.0), ("viscosity_defect_predictor", 1), ("viscosity_defect_predictor", -2)]
+    before = c.get_params()
+    for field, value in bad:
+        with pytest.raises(FlipvError) as e:
+            c.set_params(**{field: value})
+        assert "out of range" in str(e.value) or "invalid" in str(e.value), (field, str(e.value))
+        assert getattr(c.get_params(), field) == getattr(before, field), field
+    c.set_params(viscosity_defect_predictor=-1, viscosity_stage1_factor=1.0, multigrid_distributed_levels=-1)   # the legal extremes
+    assert c.get_params().viscosity_defect_predictor == -1
+    c.close()
+
+
 @pytest.mark.parametrize("name", ["bunny32_viscous", "twobody20_varvisc", "cube24_inviscid"])
 @pytest.mark.parametrize("runlen", [2, 5, 32])
 def test_k_marching_spmv_matches_tile_kernels(name, runlen):
