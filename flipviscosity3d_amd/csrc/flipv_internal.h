@@ -515,6 +515,10 @@ int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info);
 int fv_pack(flipv_context *c, int lat, const float *src_f32, const uint8_t *src_u8, float *linear, const int lo[3], const int hi[3]);
 int fv_unpack(flipv_context *c, int lat, const float *linear, float *dst_f32, uint8_t *dst_u8, const int lo[3], const int hi[3]);
 int fv_fill(flipv_context *c, float *p, size_t n, float v);
+// Several memsets as ONE launch on c->stream (or `st`).  hipMemsetAsync costs a dispatch of ~4.7 us on this device however small -- and TWO where address or size
+// is not a multiple of 8 --, and a substep issued ~100 of them (flags, counters, scalar blocks, accumulators).  byte = the value every byte takes, like memset.
+struct FillJob { void *p; size_t bytes; int byte; };
+int fv_fill_list(flipv_context *c, const FillJob *jobs, int n, hipStream_t st = nullptr);
 int fv_fill_cells(flipv_context *c, float *p, float v, int halo);
 int fv_fill_cells_liquid(flipv_context *c, float *p, float v, int halo, int site);   // the same over fv_range_liquid
 

@@ -366,6 +366,44 @@ int fv_sdf_finish(flipv_context *c) {
     return FLIPV_OK;
 }
 
+// ---- several memsets as one launch (flipv_internal.h: fv_fill_list)
+struct FillDev { void *p[8]; unsigned long long bytes[8]; unsigned word[8]; int n; };
+__global__ __launch_bounds__(256) void k_fill_list(FillDev f) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+    for (int q = 0; q < f.n; q++) {
+        uint8_t *b = (uint8_t *)f.p[q];
+        const size_t n = f.bytes[q];
+        const size_t head = n < 16 ? n : ((16 - ((size_t)b & 15)) & 15);   // bytes up to the first 16-byte boundary (short jobs: bytewise altogether)
+        const size_t vecs = (n - head) / 16, tail = n - head - vecs * 16;
+        const uint4 w = make_uint4(f.word[q], f.word[q], f.word[q], f.word[q]);
+        uint4 *v = (uint4 *)(b + head);
+        for (size_t i = t; i < vecs; i += nt) v[i] = w;
+        if (t < head) b[t] = (uint8_t)f.word[q];
+        if (t < tail) b[head + vecs * 16 + t] = (uint8_t)f.word[q];
+    }
+}
+int fv_fill_list(flipv_context *c, const FillJob *jobs, int n, hipStream_t st) {
+    for (int at = 0; at < n; at += 8) {
+        FillDev f;
+        size_t most = 0;
+        f.n = 0;
+        for (int q = at; q < n && q < at + 8; q++) {
+            if (!jobs[q].bytes) continue;
+            const unsigned bt = (unsigned)jobs[q].byte & 255u;
+            f.p[f.n] = jobs[q].p; f.bytes[f.n] = jobs[q].bytes; f.word[f.n] = bt * 0x01010101u;
+            if (jobs[q].bytes > most) most = jobs[q].bytes;
+            f.n++;
+        }
+        if (!f.n) continue;
+        size_t nb = (most / 16 + 1023) / 1024;   // ~4 16-byte stores per thread on the largest job
+        if (nb < 1) nb = 1;
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(k_fill_list, dim3((unsigned)nb), dim3(256), 0, st ? st : c->stream, f);
+    }
+    HIPCHK(c, hipGetLastError());
+    return FLIPV_OK;
+}
+
 int fv_fill(flipv_context *c, float *p, size_t n, float v) {
     hipLaunchKernelGGL(k_fill_f32, dim3(grid1d(n)), dim3(256), 0, c->stream, p, n, v);
     return FLIPV_OK;
@@ -407,8 +445,7 @@ int fv_extrapolate(flipv_context *c) {
     }
     const int nact = A.nx * A.ny * A.nz;
     uint8_t *actA = c->actFlags, *actB = c->actFlags + nact, *unk = c->actFlags + 2 * (size_t)nact;
-    HIPCHK(c, hipMemsetAsync(actA, 0, (size_t)nact, c->stream));
-    HIPCHK(c, hipMemsetAsync(unk, 0, (size_t)nact, c->stream));
+    { const FillJob z[2] = {{actA, (size_t)nact, 0}, {unk, (size_t)nact, 0}}; if ((rc = fv_fill_list(c, z, 2))) return rc; }
     hipLaunchKernelGGL(k_extrap_init, GRID3(R1), 0, c->stream, R1, A, c->vU, c->vV, c->vW, c->stampU, c->stampV, c->stampW, actA, unk);
     for (int q = 0; q < (layers + ACT_B - 1) / ACT_B; q++) {
         hipLaunchKernelGGL(k_act_dilate, dim3(cdiv(nact, 256)), dim3(256), 0, c->stream, A, actA, actB, F);

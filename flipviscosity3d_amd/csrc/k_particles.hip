@@ -655,8 +655,8 @@ int fv_particle_sdf(flipv_context *c) {
             if (rcb) return rcb;
             const BinGrid B = bin_grid(c);
             int *bb = c->d_flags + 8;   // 6 ints: min x, y, z, max x, y, z of the non-empty bins (d_flags[8..13]; [12], [13] are rewritten by the run builder later)
-            HIPCHK(c, hipMemsetAsync(bb, 0x7f, 3 * sizeof(int), c->stream));       // minima start at 0x7f7f7f7f
-            HIPCHK(c, hipMemsetAsync(bb + 3, 0xff, 3 * sizeof(int), c->stream));   // maxima at -1
+            { const FillJob z[2] = {{bb, 3 * sizeof(int), 0x7f}, {bb + 3, 3 * sizeof(int), 0xff}};   // minima start at 0x7f7f7f7f, maxima at -1
+              const int rcz = fv_fill_list(c, z, 2); if (rcz) return rcz; }
             const int nt = B.nbx * B.nby * B.nbz;
             hipLaunchKernelGGL(k_bin_bbox, dim3(cdiv(nt, 256)), dim3(256), 0, c->stream, B, c->binCnt, bb);
             int h[6];
@@ -712,7 +712,7 @@ int fv_p2g(flipv_context *c) {
     const Lay R = fv_range_liquid(c, 2, 1);  // planes this rank's particles can reach (whole allocated planes are cleared)
     const size_t off = plane_off(c->L, R.kb), bytes = (size_t)(R.ke - R.kb) * c->L.sz * 4;
     float *acc[6] = {c->accU, c->accV, c->accW, c->wgtU, c->wgtV, c->wgtW};
-    for (int q = 0; q < 6; q++) HIPCHK(c, hipMemsetAsync(acc[q] + off, 0, bytes, c->stream));
+    { FillJob z[6]; for (int q = 0; q < 6; q++) z[q] = {acc[q] + off, bytes, 0}; const int rcz = fv_fill_list(c, z, 6); if (rcz) return rcz; }
     if (c->np) {
         if (c->prm.unbinned_scatter) {  // un-binned scatter (kept for A/B measurements)
             hipLaunchKernelGGL(k_p2g_scatter, dim3(cdiv(c->np, 256)), dim3(256), 0, c->stream, c->L, c->particles, c->np,

@@ -249,16 +249,47 @@ int fv_scal_reserve(flipv_context *c, int cap) {
     return FLIPV_OK;
 }
 
-int fv_scal_clear(flipv_context *c, int cap, bool keepExtra) {
+// the fill jobs that zero the slot blocks of every bank (and, unless keepExtra, the 16 extra doubles behind bank 0's)
+static int scal_clear_jobs(flipv_context *c, int cap, bool keepExtra, FillJob *z) {
     const size_t slots = (size_t)5 * (cap + 2) * NSLOT, stride = fv_scal_stride(cap);
     if (keepExtra) {
-        HIPCHK(c, hipMemsetAsync(c->d_scal, 0, slots * sizeof(double), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_scal + stride, 0, (FV_SCAL_BANKS - 1) * stride * sizeof(double), c->stream));
-    } else HIPCHK(c, hipMemsetAsync(c->d_scal, 0, FV_SCAL_BANKS * stride * sizeof(double), c->stream));
-    return FLIPV_OK;
+        z[0] = {c->d_scal, slots * sizeof(double), 0};
+        z[1] = {c->d_scal + stride, (FV_SCAL_BANKS - 1) * stride * sizeof(double), 0};
+        return 2;
+    }
+    z[0] = {c->d_scal, FV_SCAL_BANKS * stride * sizeof(double), 0};
+    return 1;
+}
+int fv_scal_clear(flipv_context *c, int cap, bool keepExtra) {
+    FillJob z[2];
+    const int n = scal_clear_jobs(c, cap, keepExtra, z);
+    return fv_fill_list(c, z, n);
 }
 
+static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **extra);
+// reset the stall guard (enqueued before any kernel of the solve): best = 0x7f7f... = 1.4e306, "nothing seen yet"
+static int guard_jobs(const PcgScal *sc, FillJob *z) {
+    z[0] = {sc->best, sizeof(double), 0x7f}; z[1] = {sc->stalled, sizeof(int), 0}; z[2] = {sc->bestIt, sizeof(int), 0};
+    return 3;
+}
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
+    scal_views_host(c, cap, sc, extra);
+    FillJob z[3];
+    (void)fv_fill_list(c, z, guard_jobs(sc, z));
+}
+// What a PCG loop's start needs, as ONE launch: the scalars cleared (fv_scal_clear), the stop flag at -1, the stall guard and the device-side iteration
+// counters reset, optionally one more int zeroed (the set-up kernel's row counter); *sc, *extra as fv_scal_views leaves them
+int fv_pcg_reset(flipv_context *c, int cap, bool keepExtra, PcgScal *sc, double **extra, int *alsoZero) {
+    scal_views_host(c, cap, sc, extra);
+    FillJob z[8];
+    int n = scal_clear_jobs(c, cap, keepExtra, z);
+    z[n++] = {c->d_flags, sizeof(int), 0xff};   // conv = -1
+    if (alsoZero) z[n++] = {alsoZero, sizeof(int), 0};
+    n += guard_jobs(sc, z + n);
+    z[n++] = {sc->itA, 2 * sizeof(int), 0};      // itA, itB
+    return fv_fill_list(c, z, n);
+}
+static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     const size_t n = ((size_t)cap + 2) * NSLOT;
     sc->base = c->d_scal;
     sc->conv = c->d_flags;
@@ -275,10 +306,6 @@ void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
     sc->stall_below = 0.0;
     sc->stalled = c->d_flags + 11;
     sc->bestIt = c->d_flags + 14;
-    // reset the stall guard (enqueued before any kernel of the solve): best = 0x7f7f... = 1.4e306, "nothing seen yet"
-    (void)hipMemsetAsync(sc->best, 0x7f, sizeof(double), c->stream);
-    (void)hipMemsetAsync(sc->stalled, 0, sizeof(int), c->stream);
-    (void)hipMemsetAsync(sc->bestIt, 0, sizeof(int), c->stream);
     *extra = c->d_scal + 5 * n;
 }
 
@@ -444,12 +471,9 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const int cap = c->prm.pressure_max_iterations;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
-    if ((rc = fv_scal_clear(c, cap, false))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));  // conv = -1
-    HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));  // pressure-cell counter
     PcgScal sc;
     double *bmax;
-    fv_scal_views(c, cap, &sc, &bmax);
+    if ((rc = fv_pcg_reset(c, cap, false, &sc, &bmax, c->d_flags + 2))) return rc;   // (scalars, conv = -1, the pressure-cell counter, the guard, the counters: one launch)
     sc.tol_inclusive = 0;
     sc.tol = 0.0;
 

@@ -701,8 +701,8 @@ static int fv_plane_refine(flipv_context *c, const Lay &R, const PcgScal &sc, si
     int rc = plane_q64_reserve(c);
     if (rc) return rc;
     plane_flush<T>(c, R, flushMode);
-    HIPCHK(c, hipMemsetAsync(sc.base, 0, scalBytes, c->stream));
-    if (sc.nbank > 1) HIPCHK(c, hipMemsetAsync(sc.base + sc.bstride, 0, (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double), c->stream));
+    { const FillJob z[2] = {{sc.base, scalBytes, 0}, {sc.base + sc.bstride, sc.nbank > 1 ? (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double) : 0, 0}};
+      if ((rc = fv_fill_list(c, z, 2))) return rc; }
     if (c->comm) {
         const HaloArray xa[3] = {{c->vXacc[0], sizeof(double)}, {c->vXacc[1], sizeof(double)}, {c->vXacc[2], sizeof(double)}};
         if ((rc = fv_halo_copy(c, xa, 3, 1))) return rc;
@@ -749,12 +749,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const int cap = c->prm.viscosity_max_iterations;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
-    if ((rc = fv_scal_clear(c, cap, false))) return rc;
-    HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));   // conv = -1
-    HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));  // row counter
     PcgScal sc;
     double *bmax;
-    fv_scal_views(c, cap, &sc, &bmax);
+    if ((rc = fv_pcg_reset(c, cap, false, &sc, &bmax, c->d_flags + 2))) return rc;   // (scalars, conv = -1, the row counter, the guard, the counters: one launch)
     sc.tol_inclusive = 1;
     sc.tol = 0.0;
 
@@ -836,8 +833,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             c->bandPrevValid = 1;
         }
         PcgSys<T, 3> vs = visc_sys<T>(c);
-        HIPCHK(c, hipMemsetAsync(bmax, 0, 2 * sizeof(double), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_flags + 2, 0, sizeof(int), c->stream));
+        { const FillJob z[2] = {{bmax, 2 * sizeof(double), 0}, {c->d_flags + 2, sizeof(int), 0}}; const int rcz = fv_fill_list(c, z, 2); if (rcz) return rcz; }
         // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane); a change
         // of layout or precision rewrites every entry, not only those near the liquid
         const Lay RS = full ? fv_range(c, 0) : R0;
@@ -1016,11 +1012,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             refinements++;
             hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, 0, bmax);
             HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            { const int rcc = fv_scal_clear(c, cap, true); if (rcc) return rcc; }
-            HIPCHK(c, hipMemsetAsync(c->d_flags, 0xff, sizeof(int), c->stream));
             const int keepIncl = sc.tol_inclusive;
             double *dummy;
-            fv_scal_views(c, cap, &sc, &dummy);
+            { const int rcc = fv_pcg_reset(c, cap, true, &sc, &dummy, nullptr); if (rcc) return rcc; }
             sc.tol_inclusive = keepIncl;
             HIPCHK(c, hipStreamSynchronize(c->stream));
             res = resStart = c->h_scal[0];

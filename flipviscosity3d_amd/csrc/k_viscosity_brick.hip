@@ -503,8 +503,11 @@ int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool 
     const float *const vo[3] = {outerExact ? c->vmU : c->vrU, outerExact ? c->vmV : c->vrV, outerExact ? c->vmW : c->vrW};
     const dim3 b(64, 4, 1);
     hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0, flushMode);
-    (void)hipMemsetAsync(sc.base, 0, scalBytes, c->stream);   // bank 0's slot blocks (the extra scalars behind them stay), then the other banks
-    if (sc.nbank > 1) (void)hipMemsetAsync(sc.base + sc.bstride, 0, (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double), c->stream);
+    {   // bank 0's slot blocks (the extra scalars behind them stay), then the other banks
+        const FillJob z[2] = {{sc.base, scalBytes, 0}, {sc.base + sc.bstride, sc.nbank > 1 ? (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double) : 0, 0}};
+        const int rcz = fv_fill_list(c, z, 2);
+        if (rcz) return rcz;
+    }
     if (c->comm) {   // the residual's stencil reads the neighbours' accumulated solution across the cuts
         const HaloArray xa[3] = {{c->vXacc[0], sizeof(double), 1}, {c->vXacc[1], sizeof(double), 1}, {c->vXacc[2], sizeof(double), 1}};
         const int rc = fv_halo_copy(c, xa, 3, 1);

@@ -332,6 +332,7 @@ static inline int pcg_grid(const flipv_context *c, int ntiles) {
 int fv_build_tiles(flipv_context *c, TileGrid *tg, int vw, int nc, const float *d0, const float *d1, const float *d2,
                    const uint8_t *mask, int *list, int *nActive, int *nInterior, const int *hostCount, int perIndex, unsigned **mlist, size_t *mlistCap, double minLanes, int *memo);
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra);
+int fv_pcg_reset(flipv_context *c, int cap, bool keepExtra, PcgScal *sc, double **extra, int *alsoZero);   // clear + views + stop flag + counters: one launch
 // Runs of the tile list fv_build_tiles just built (call right after it: uses its tile flags).  *nruns = 0 when the k-marching
 // kernels are not to be used (multi-rank runs, lane width 2, flipv_params.spmv_run_length = -1).
 // `dense`: the liquid fills the listed tiles (what flipv_params.spmv_run_length = 0 decides by: k-marching pays where the
