@@ -810,8 +810,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // 1.1e-4/2.2e-4 at nu dt/dx^2 = 1.2e5, and neither max|b - A_ref x| nor what one multigrid cycle on that residual moves (3e-6 ... 1e-5 of max|u| in every
     // case) tells the two apart: the defect's error sits in the near-rigid modes a residual does not show.  The right-hand side's copy (vB) stays b: the
     // fp64 residual after stage 1 is b - A_ref x.  (Not with the opt-in residual replacement, which recomputes the LOOP's residual from vB.)
+    // Only where stage 1 stops early (the rule further down): a stage 1 run to the final tolerance itself -- viscosity_stage1_factor = 1, or nu dt/dx^2 beyond the
+    // gate -- stagnates on b - E u_old (E u_old is rough and largest on the sliver rows: the fp32 loop's accuracy floor; bench.py's mode_b_strict: 155 iterations,
+    // 5.7e-6 instead of 99 and 1e-6).
+    const double stiffSolve = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
+    const bool stage1Early = c->prm.viscosity_stage1_factor != 1.0f && stiffSolve <= (c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5);
     const bool predict = refDiag && mgPlanned && std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && c->prm.viscosity_defect_predictor >= 0 &&
-                         c->prm.residual_replacement <= 0;
+                         c->prm.residual_replacement <= 0 && stage1Early;
     auto run_setup = [&](int layout, bool first) -> int {
         const bool brick = layout == VLAYOUT_BRICK;
         if (c->viscStateValid && (c->vLayout == VLAYOUT_BRICK) != brick) {

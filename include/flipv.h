@@ -179,7 +179,8 @@ typedef struct flipv_params {
     float viscosity_two_stage_max_stiffness;/* [2e5] nu dt/dx^2 up to which stage 1 stops early (beyond: the fp32 loop's accuracy floor, stage 1 runs to viscosity_tolerance) */
     int viscosity_defect_predictor;         /* [0 = on] stage 1 solves A x = b - E u_old (E = the reference's diagonal defect, u_old = the incoming velocities) instead of A x = b:
                                                the correction stage starts from E (x - u_old) instead of E x -- the same or fewer iterations for the same velocities
-                                               (up to -18 % at nu dt/dx^2 = 1.2e5).  -1 = off */
+                                               (up to -18 % at nu dt/dx^2 = 1.2e5).  Only where stage 1 stops early: not with viscosity_stage1_factor = 1 or beyond
+                                               viscosity_two_stage_max_stiffness (an fp32 loop run to the final tolerance stagnates on that right-hand side).  -1 = off */
 } flipv_params;
 
 typedef struct flipv_solve_info {

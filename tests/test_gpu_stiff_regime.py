@@ -169,3 +169,26 @@ def test_defect_predictor_changes_the_iteration_count_not_the_velocities(name, N
         its[pred] = v["iterations"]
         c.close()
     assert its[0] <= its[-1] + 3, its
+
+
+def test_strict_stage_1_converges_to_the_reference_tolerance():
+    """flipv_params.viscosity_stage1_factor = 1 (bench.py: mode_b_strict): stage 1 of the two-stage solve runs to viscosity_tolerance x max|rhs| itself -- on the plain
+    right-hand side (the defect predictor's b - E u_old is for a stage 1 that stops early: an fp32 loop run to 1e-6 stagnates on it) -- inside the stock cap, and the
+    velocities are the default's."""
+    from flipviscosity3d_amd.capi import Context
+    name, N = "bunny128_nu5_converged", 128
+    g = Golden(name)
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid)
+    c.set_viscosity(float(g["nu"]))
+    c.set_params(viscosity_stage1_factor=1.0)
+    c.particles = P
+    for t in range(g.nsub):
+        st = c.substep(g.dt)
+        v = st["viscosity"]
+        err = probe_error(c, g, t)
+        print("strict, substep %d: %d iterations (%d correction), loop residual %.2e of max|rhs|, velocity error %.2e" % (t, v["iterations"], v["correction_iterations"], v["residual"] / v["rhs_norm"], err))
+        assert v["status"] == 0 and v["iterations"] <= 300 and v["residual"] <= 1.0e-6 * v["rhs_norm"], v
+        assert err <= 3e-5, (t, err)
+    c.close()
