@@ -19,6 +19,8 @@ $B --workload honey --size 512 --viscosity 50 --steps 5 --warmup 2 $Q > $out/ben
 $B --workload sheet --size 1024 --steps 3 --warmup 1 $Q --no-strict > $out/bench_sheet1024.json 2>/dev/null
 python3 tools/local_ranks_bench.py strong 2,2,2 256 > $out/local_ranks_222_256.log 2>&1
 python3 tools/local_ranks_bench.py strong 2,2,2 512 honey 50 > $out/local_ranks_222_512.log 2>&1
+(python3 tools/r4_predict_scan.py 0 1 -1; python3 tools/r4_predict_scan.py 0 1 0) > $out/predictor_on_off.log 2>&1
+python3 tools/r4_dense_geo_scan.py 256,320,384,448,512 > $out/dense_geometry_scan.log 2>&1
 (python3 tools/r3_status.py bunny 256 5 2000; python3 tools/r3_status.py honey 256 50 200; python3 tools/r3_status.py sheet 512 5 200; python3 tools/r3_status.py bunny 128 5 500; python3 tools/r3_status.py honey 512 50 30) > $out/soak_status.log 2>&1
 for f in $out/*.json; do python3 - "$f" <<'PY'
 import json, sys
