@@ -21,7 +21,7 @@ for name, N in (("bunny128_nu5_converged", 128), ("bunny256_nu5_converged", 256)
     dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
     c = Context(N, N, N, dx)
     c.set_solid_sdf(solid); c.set_viscosity(float(g["nu"])); c.particles = P
-    c.set_params(viscosity_stage1_factor=f, viscosity_defect_predictor=pred, verbose=int(os.environ.get('SCAN_VERBOSE', '0')))
+    c.set_params(viscosity_stage1_factor=f, viscosity_defect_predictor=pred, verbose=int(os.environ.get('SCAN_VERBOSE', '0')), viscosity_stage2_factor=float(os.environ.get('SCAN_F2', '0')))
     out = []
     for t in range(g.nsub):
         st = c.substep(g.dt)
@@ -32,7 +32,7 @@ for name, N in (("bunny128_nu5_converged", 128), ("bunny256_nu5_converged", 256)
     if N == 256 and len(sys.argv) > 2 and int(sys.argv[2]):
         c = Context(N, N, N, dx)
         c.set_solid_sdf(solid); c.set_viscosity(5.0); c.particles = P
-        c.set_params(viscosity_stage1_factor=f, viscosity_defect_predictor=pred, verbose=int(os.environ.get('SCAN_VERBOSE', '0')))
+        c.set_params(viscosity_stage1_factor=f, viscosity_defect_predictor=pred, verbose=int(os.environ.get('SCAN_VERBOSE', '0')), viscosity_stage2_factor=float(os.environ.get('SCAN_F2', '0')))
         for _ in range(5):
             c.substep(min(c.cfl(), 0.01))
         c.synchronize()
@@ -49,7 +49,7 @@ for name, N, boundary, liquids in STIFF:
     dx, solid, P = build_host_scene(N, boundary, liquids)
     c = Context(N, N, N, dx)
     c.set_solid_sdf(solid); c.set_viscosity(float(g["nu"]))
-    c.set_params(viscosity_stage1_factor=f, viscosity_defect_predictor=pred, verbose=int(os.environ.get('SCAN_VERBOSE', '0')))
+    c.set_params(viscosity_stage1_factor=f, viscosity_defect_predictor=pred, verbose=int(os.environ.get('SCAN_VERBOSE', '0')), viscosity_stage2_factor=float(os.environ.get('SCAN_F2', '0')))
     out = []
     for t in range(g.nsub):
         c.particles = P if t == 0 else g["s%d_particles" % (t - 1)]
