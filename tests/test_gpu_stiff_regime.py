@@ -192,3 +192,38 @@ def test_strict_stage_1_converges_to_the_reference_tolerance():
         assert v["status"] == 0 and v["iterations"] <= 300 and v["residual"] <= 1.0e-6 * v["rhs_norm"], v
         assert err <= 3e-5, (t, err)
     c.close()
+
+
+def test_sheared_start_where_the_defect_predictor_has_nothing_to_go_on(oracle):
+    """The defect predictor assumes a substep changes the velocities little (stage 1 solves A x = b - E u_old).  Here it cannot: config 1's scene at nu = 200
+    (nu dt/dx^2 = 8 192) with the particles' velocities overwritten by a strong shear, which this viscosity flattens within the substep -- the solution is far
+    from the incoming field, the predicted defect is wrong by about as much as no prediction, and the correction stage has to do what it did before the
+    predictor existed.  Default parameters against the oracle with its cap lifted, one substep: <= 1e-4."""
+    from flipviscosity3d_amd.capi import Context
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    P = P.copy()
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    P[:, 3] = 1.5 * np.sin(14.0 * np.pi * y)
+    P[:, 4] = -0.8 * np.cos(10.0 * np.pi * z) - 0.5
+    P[:, 5] = 1.0 * np.sin(12.0 * np.pi * x)
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid); o.set_viscosity(200.0); o.set_solver_limits(vmaxiter=400000)
+    o.particles = P
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid); c.set_viscosity(200.0)
+    c.particles = P
+    st = c.substep(0.01)
+    sec, vi, pi = o.substep(0.01)
+    v = st["viscosity"]
+    ref = [o.grid(n) for n in "UVW"]
+    den = max(float(np.abs(r).max()) for r in ref)
+    err = max(float(np.abs(c.grid(n).astype(np.float64) - r).max()) for n, r in zip("UVW", ref)) / den
+    change = float(np.abs(o.particles[:, 3:] - P[:, 3:]).max()) / float(np.abs(P[:, 3:]).max())   # (the FLIP update hands the grid's change to the particles)
+    print("sheared start: %d iterations (%d correction; oracle %d), velocity error %.2e; the substep changed the particles' velocities by %.2f of their maximum" % (
+        v["iterations"], v["correction_iterations"], vi["iterations"], err, change))
+    assert vi["status"] == 0 and v["status"] == 0 and v["correction_iterations"] > 0, (vi, v)
+    assert change > 0.3            # the premise: the incoming velocities say little about the outgoing ones
+    assert err <= 1e-4, err
+    c.close()
+    o.close()
