@@ -19,7 +19,8 @@ for t in range(nsub):
     v = st["viscosity"]
     status[v["status"]] += 1; prec[v["preconditioner"]] += 1; its.append(v["iterations"]); ms.append(st["total_ms"])
     if v["status"] != 0:
-        print("substep %d: status %d after %d iterations, residual/rhs %.2e, preconditioner %d" % (t, v["status"], v["iterations"], v["residual"] / max(v["rhs_norm"], 1e-300), v["preconditioner"]), flush=True)
+        print("substep %d: status %d after %d iterations (%d in correction stages, correction status %d), residual/rhs %.2e, defect residual/rhs %.2e, preconditioner %d" % (
+            t, v["status"], v["iterations"], v["correction_iterations"], v["correction_status"], v["residual"] / max(v["rhs_norm"], 1e-300), v["defect_residual"] / max(v["rhs_norm"], 1e-300), v["preconditioner"]), flush=True)
 c.synchronize()
 wall = (time.perf_counter() - t0) * 1e3 / nsub
 print("%s %dx%dx%d nu %g, %d substeps: %.2f ms per substep (wall), GPU mean %.2f; viscosity status %s, preconditioner %s, iterations min/mean/max %d/%.1f/%d; last 5: %s" % (
