@@ -805,7 +805,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // stage 1 solves A x = b - E u_old, u_old = the incoming velocity of the row -- one step of the fixed point x <- A^-1 (b - E x) started from u_old
     // instead of from 0.  What stage 1 then leaves of the defect is E (x - u_old) instead of E x, so the correction stage starts closer: the same or fewer
     // iterations for the same or better velocities on every fixture (tools/r4_predict_scan.py, profiles/r4/predictor_scan.log: 256^3 62/59 -> 60/59 iterations,
-    // 1.9e-5/2.5e-5 -> 1.5e-5/2.6e-5; nu dt/dx^2 = 1.2e5: 199/149 -> 162/149, 2.5e-5/3.9e-6 -> 1.6e-5/1.9e-5; config 4's scene 233/234 -> 233/219).
+    // 1.9e-5/2.5e-5 -> 1.5e-5/2.6e-5; nu dt/dx^2 = 1.2e5: 199/149 -> 162/149, 2.5e-5/3.9e-6 -> 1.6e-5/1.9e-5; config 4's scene 233/234 -> 233/219;
+    // bench lines: 512^3 bunny 1 160 -> 1 365 MCells/s, honey 512^3 1 325 -> 1 468, the 1024 x 512 x 512 sheet 603 -> 699 -- the stiffer and larger, the more it saves).
     // The correction stage stays: SKIPPING it where the prediction looks good was measured too -- bench 957 -> 1 107 MCells/s, 256^3 still 2.1e-5/2.6e-5, but
     // 1.1e-4/2.2e-4 at nu dt/dx^2 = 1.2e5, and neither max|b - A_ref x| nor what one multigrid cycle on that residual moves (3e-6 ... 1e-5 of max|u| in every
     // case) tells the two apart: the defect's error sits in the near-rigid modes a residual does not show.  The right-hand side's copy (vB) stays b: the
