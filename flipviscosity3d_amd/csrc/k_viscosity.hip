@@ -957,7 +957,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (useAcc && brick && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
         if (useAcc && !brick) plane_flush<T>(c, R0, 4);
         int itersDone = 0, corrections = 0;
-        bool correctionDue = false;
+        bool correctionDue = false, extraStage = false;
+        double lastTarget = 0.0;
         double resBeforeStage = 0.0;
         const bool innerDiffers = staged && useMg;   // the Krylov loop runs on the exact operator, the solve is for the reference's
         // Stage 1 of the defect correction does not have to resolve the exact operator's system further than stage 2 preserves.  Stage 2 solves
@@ -1036,7 +1037,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const int capNow = (correction && cap - itersDone > cap2) ? cap2 : cap - itersDone;
         sc.cap = capNow;
         // (the first correction stage starts from stage 1's remainder PLUS the defect: its target is the share of what lies beyond the remainder)
-        sc.tol = correction ? fmax(tolFinal, f2 * fmax(resStart - ((corrections == 1 && tolMain > tolFinal) ? tolMain : 0.0), 0.0)) : tolMain;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
+        sc.tol = correction ? ((extraStage && lastTarget > 0.0) ? lastTarget   // (the restart of a stage that ended short: towards the target that stage had)
+                                                                : fmax(tolFinal, f2 * fmax(resStart - ((corrections == 1 && tolMain > tolFinal) ? tolMain : 0.0), 0.0))) : tolMain;
+        if (correction) lastTarget = sc.tol;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
         sc.stall_below = refinements > 0 ? fmin(100.0 * sc.tol, 0.05 * resStart) : 0.0;
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
         // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the
@@ -1112,8 +1115,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (!correction) resBeforeStage = res;                   // the main loop's own (recurrence) residual
         if (correction) {   // a correction stage's result is kept whether or not it reached its target -- unless it RAISED the fp64 residual (below) --, but the solve says so
             corrIters += itersNow;
-            if (!success) corrStatus = 2;
-            else if (corrStatus == 0) corrStatus = 1;
+            if (corrStatus != 3) corrStatus = success ? 1 : 2;   // (the LAST stage's outcome; a stage taken back stays on record)
             success = true; stalled = false;
         }
         if (success && !innerDiffers) break;
@@ -1144,7 +1146,12 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             // simply wrong -- 512^3 / nu = 50, nu dt/dx^2 = 131 072: max|E x| = 1.2 max|b|, further stages contract by 2-50x each and stop
             // contracting around 1e-5 -- and chasing it costs more than the solve (measured: 6 stages, +70 % iterations, no convergence).
             // The solve's status and residual are the exact-operator loop's; `defect_residual` reports max|b - A_ref x| at the end.
-            if (corrections >= rounds || itersDone >= cap || tookBack) {
+            // A stage that ENDED SHORT (stalled, or out of its budget: an fp32 recurrence that has lost its conjugacy, typically within a factor of a few of its
+            // target -- honey 256^3 at nu = 50, 16 of 1 500 substeps: 1.2e-6 ... 3.4e-6 max|rhs| where 1e-6 was asked for) is restarted ONCE from the fp64
+            // residual just recomputed, like any stalled loop; its own outcome is what the solve reports.
+            const bool again = !c->vMixed64 && corrStatus == 2 && corrections == rounds && !extraStage && !tookBack && itersDone < cap;
+            if (again) extraStage = true;
+            if ((corrections >= rounds && !again) || itersDone >= cap || tookBack) {
                 success = true; defectRes = res; res = mainRes;
                 if (c->vMixed64 && defectRes > tolFinal && corrStatus <= 1) corrStatus = 2;   // (the fp64 residual is this mode's criterion)
                 break;
