@@ -109,7 +109,7 @@ typedef struct flipv_params {
                                     (where nu dt/dx^2 <= viscosity_two_stage_max_stiffness; to viscosity_tolerance beyond), then viscosity_stage2_rounds
                                     correction stage(s) solve A dx = b - A_ref x (fp64 residual) to viscosity_stage2_factor of the defect, never below
                                     viscosity_tolerance, in at most viscosity_stage2_max_iterations iterations each; a correction that RAISES the fp64
-                                    residual is taken back.  flipv_solve_info: status 0 = every stage reached its target; residual = stage 1's;
+                                    residual is taken back, one that ends short of its target is restarted once from the recomputed fp64 residual.  flipv_solve_info: status 0 = every stage reached its target; residual = stage 1's;
                                     defect_residual = max|b - A_ref x| delivered; correction_* = what the correction stages did.
                                     REPRODUCIBILITY: scatters and dot products sum in arrival order, so two runs agree to solver tolerance, not bit for bit.  With the
                                     reference's operator that can be coarser LOCALLY: its rounded diagonal leaves the near-rigid modes of tiny detached liquid clusters
@@ -206,8 +206,8 @@ typedef struct flipv_solve_info {
     double comm_bytes_setup;   /* several ranks, multigrid preconditioner with the global coarse hierarchy: bytes this solve ALL-REDUCED once (the first coarse level's
                                   operator) ... */
     double comm_bytes_per_iteration; /* ... and per iteration (that level's right-hand side); 0 on one rank / with the diagonal */
-    int correction_status;     /* 0 no correction stage; 1 every stage reached its target; 2 a stage ran into its iteration budget or stalled first (its
-                                  result is kept if it lowered the fp64 residual; `status` is then 1); 3 the last stage RAISED the fp64 residual and was taken back
+    int correction_status;     /* 0 no correction stage; 1 the (last) stage reached its target; 2 it ran into its iteration budget or stalled first -- also after the
+                                  one restart such a stage gets -- (its result is kept if it lowered the fp64 residual; `status` is then 1); 3 the last stage RAISED the fp64 residual and was taken back
                                   (`status` 1) */
 } flipv_solve_info;
 
