@@ -1037,8 +1037,13 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const int capNow = (correction && cap - itersDone > cap2) ? cap2 : cap - itersDone;
         sc.cap = capNow;
         // (the first correction stage starts from stage 1's remainder PLUS the defect: its target is the share of what lies beyond the remainder)
+        // (... and no stage is asked for more than three orders of magnitude below stage 1's tolerance: where the defect is small its share collapses to the final
+        // tolerance, and an fp32 loop restarted from an fp64 residual does not take its right-hand side down by 3 000 on the hard systems -- honey 256^3 at
+        // nu = 200, nu dt/dx^2 = 1.3e5: 7 of 600 substeps ended at 1.4e-6 ... 2.7e-6 max|rhs| after 170-270 iterations, restart included.  With stage 1 at 300 x
+        // the tolerance this floor is below the final tolerance, i.e. void; viscosity_stage2_rounds = 2 goes further.  Not in the mixed fp64 mode.)
+        const double stageFloor = c->vMixed64 ? tolFinal : fmax(tolFinal, 1e-3 * tolMain);
         sc.tol = correction ? ((extraStage && lastTarget > 0.0) ? lastTarget   // (the restart of a stage that ended short: towards the target that stage had)
-                                                                : fmax(tolFinal, f2 * fmax(resStart - ((corrections == 1 && tolMain > tolFinal) ? tolMain : 0.0), 0.0))) : tolMain;
+                                                                : fmax(stageFloor, f2 * fmax(resStart - ((corrections == 1 && tolMain > tolFinal) ? tolMain : 0.0), 0.0))) : tolMain;
         if (correction) lastTarget = sc.tol;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
         sc.stall_below = refinements > 0 ? fmin(100.0 * sc.tol, 0.05 * resStart) : 0.0;
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --

@@ -108,7 +108,7 @@ typedef struct flipv_params {
                                     contexts, in every layout: stage 1 solves the exact operator's system A x = b to viscosity_stage1_factor x viscosity_tolerance
                                     (where nu dt/dx^2 <= viscosity_two_stage_max_stiffness; to viscosity_tolerance beyond), then viscosity_stage2_rounds
                                     correction stage(s) solve A dx = b - A_ref x (fp64 residual) to viscosity_stage2_factor of the defect, never below
-                                    viscosity_tolerance, in at most viscosity_stage2_max_iterations iterations each; a correction that RAISES the fp64
+                                    viscosity_tolerance nor below 1e-3 of stage 1's tolerance (what one restarted fp32 loop can deliver), in at most viscosity_stage2_max_iterations iterations each; a correction that RAISES the fp64
                                     residual is taken back, one that ends short of its target is restarted once from the recomputed fp64 residual.  flipv_solve_info: status 0 = every stage reached its target; residual = stage 1's;
                                     defect_residual = max|b - A_ref x| delivered; correction_* = what the correction stages did.
                                     REPRODUCIBILITY: scatters and dot products sum in arrival order, so two runs agree to solver tolerance, not bit for bit.  With the
