@@ -28,6 +28,8 @@ for t in th: t.start()
 for t in th: t.join()
 same = all(tuple(x[:5] for x in log[r]) == tuple(x[:5] for x in log[0]) for r in range(R))
 print("%s blocks of %s %dx%dx%d nu %g, %d substeps %s: every rank took the same solver path: %s" % (dims, wl, I, J, K, nu, nsub, extra, same))
+import collections
+print("viscosity status %s, preconditioner %s; pressure status %s" % (dict(collections.Counter(x[1] for x in log[0])), dict(collections.Counter(x[2] for x in log[0])), dict(collections.Counter(x[4] for x in log[0]))))
 print("viscosity iterations", [x[0] for x in log[0]], "status", sorted(set(x[1] for x in log[0])), "preconditioner", sorted(set(x[2] for x in log[0])))
 print("pressure iterations ", [x[3] for x in log[0]], "status", sorted(set(x[4] for x in log[0])))
 print("particles per rank at the end", [l[-1][5] for l in log], "total", sum(l[-1][5] for l in log), "of", len(P))
