@@ -535,10 +535,10 @@ extern "C" int flipv_write_grid(flipv_context *c, int which, const float *in) {
     if (which == FLIPV_GRID_WEIGHT_U || which == FLIPV_GRID_WEIGHT_V || which == FLIPV_GRID_WEIGHT_W) c->weightsVersion = -1;
     if (which == FLIPV_GRID_VISCOSITY) {
         const size_t n = lat_count(c->L, g.lat);
-        float vmax = 0.0f;
-        for (size_t t = 0; t < n; t++) if (in[t] > vmax) vmax = in[t];
+        float vmax = 0.0f, vmin = n ? in[0] : 0.0f;
+        for (size_t t = 0; t < n; t++) { if (in[t] > vmax) vmax = in[t]; if (in[t] < vmin) vmin = in[t]; }
         c->viscosity_nonzero = vmax > 0.0f;
-        c->viscosity_max = vmax;
+        c->viscosity_max = vmax; c->viscosity_min = vmin;
     }
     return write_lattice(c, g.lat, in, g.f, g.m);
 }
@@ -578,10 +578,10 @@ extern "C" int flipv_write_grid_box(flipv_context *c, int which, const float *in
     if (which == FLIPV_GRID_WEIGHT_U || which == FLIPV_GRID_WEIGHT_V || which == FLIPV_GRID_WEIGHT_W) c->weightsVersion = -1;
     if (which == FLIPV_GRID_VISCOSITY) {
         int lo[3], hi[3];
-        float vmax = 0.0f;
-        if (lat_box(c, g.lat, 1, lo, hi)) { const size_t n = box_count(lo, hi); for (size_t t = 0; t < n; t++) if (in[t] > vmax) vmax = in[t]; }
+        float vmax = 0.0f, vmin = 0.0f;
+        if (lat_box(c, g.lat, 1, lo, hi)) { const size_t n = box_count(lo, hi); vmin = n ? in[0] : 0.0f; for (size_t t = 0; t < n; t++) { if (in[t] > vmax) vmax = in[t]; if (in[t] < vmin) vmin = in[t]; } }
         c->viscosity_nonzero = vmax > 0.0f;   // this rank's box; the solve all-reduces it (k_viscosity.hip) so that every rank takes the same path
-        c->viscosity_max = vmax;
+        c->viscosity_max = vmax; c->viscosity_min = vmin;
     }
     return write_lattice_box(c, g.lat, in, g.f, g.m);
 }
@@ -602,7 +602,7 @@ extern "C" int flipv_set_viscosity_uniform(flipv_context *c, float value) {
     std::vector<float> v(box_count(lo, hi), value);
     const int rc = flipv_write_grid_box(c, FLIPV_GRID_VISCOSITY, v.data());
     c->viscosity_nonzero = value > 0.0f;
-    c->viscosity_max = value;
+    c->viscosity_max = value; c->viscosity_min = value;
     return rc;
 }
 

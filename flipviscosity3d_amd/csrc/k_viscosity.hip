@@ -287,10 +287,7 @@ __device__ __forceinline__ bool d_row_range(int dir, int i, int j, int k, const 
 // reference's: the defect is fl(diagonal) minus the exact sum of the same seven floats (exact in fp64).  Values stay >= -0.02; the
 // "no row" marker is -1.  Opt-in (FLIPV_REF_DIAG=1, see viscosity_solve_t): the reference's operator is visibly worse conditioned than
 // the exact one (its own MIC(0) PCG needs 7 689 iterations for 1e-6 and 42 223 for 1e-8 at 256^3).
-__device__ __forceinline__ float d_ref_volume(float vol, float fR, float fL, float fT, float fB, float fF, float fK, float dgf) {
-    const double exact = (double)vol + (double)fR + (double)fL + (double)fT + (double)fB + (double)fF + (double)fK;
-    return (float)((double)vol + ((double)dgf - exact));
-}
+// (d_ref_volume itself: visc_rows.h)
 template <typename T>
 __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__restrict__ V,
                              const float *__restrict__ W, const uint8_t *__restrict__ SU,
@@ -732,15 +729,18 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     memset(&li, 0, sizeof(li));
     c->commBytesSetup = c->commBytesIter = 0.0;
     if (c->comm && c->comm->nranks > 1) {   // a rank whose box holds no viscous node must still take part in every collective of the solve
-        const double mine[2] = {c->viscosity_nonzero ? 1.0 : 0.0, (double)c->viscosity_max};   // (AUTO's stiffness rule must come out the same on every rank)
-        double all[2 * NSLOT];
-        const int rcv = fv_allgather_f64(c, mine, 2, all);
+        const double mine[3] = {c->viscosity_nonzero ? 1.0 : 0.0, (double)c->viscosity_max, (double)c->viscosity_min};   // (AUTO's stiffness rule must come out the same on every rank)
+        double all[3 * NSLOT];
+        const int rcv = fv_allgather_f64(c, mine, 3, all);
         if (rcv) return rcv;
-        double nz = 0.0, vm = all[1];
-        for (int r = 0; r < c->comm->nranks; r++) { nz = fmax(nz, all[2 * r]); vm = fmax(vm, all[2 * r + 1]); }
+        double nz = 0.0, vm = all[1], vlo = all[2];
+        for (int r = 0; r < c->comm->nranks; r++) { nz = fmax(nz, all[3 * r]); vm = fmax(vm, all[3 * r + 1]); vlo = fmin(vlo, all[3 * r + 2]); }
         c->viscosity_nonzero_any = nz > 0.0;
         c->viscosity_max_any = (float)vm;
-    } else { c->viscosity_nonzero_any = c->viscosity_nonzero; c->viscosity_max_any = c->viscosity_max; }
+        c->vPerRowFactors = vlo != vm ? 1 : 0;
+    } else { c->viscosity_nonzero_any = c->viscosity_nonzero; c->viscosity_max_any = c->viscosity_max; c->vPerRowFactors = c->viscosity_min != c->viscosity_max ? 1 : 0; }
+    // (vPerRowFactors: a VARIABLE viscosity field -- the fp64 residual of the two-stage solve then forms the reference's rows with their own factors,
+    // k_viscosity_brick.hip: d_ref_row_factors; brick layout only)
     if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
         li.status = 3;
         if (info) *info = li;
@@ -763,6 +763,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     if ((rc = visc_geometry(c, c->stream))) return rc;
     const float invdx = 1.0f / c->dx;
     const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
+    c->vFactorNow = factor;
     // ---- which layout the solver's arrays take (flipv_internal.h: VLAYOUT_*).  Bricks on sparse liquids of a single-domain context, the
     // plain planes (with the swizzled own-index arrays under the 16-lane tile geometry) otherwise.  How sparse the liquid is is only known
     // after the set-up kernel has counted the rows, so the set-up runs in the previous solve's layout and is repeated on the rare solve

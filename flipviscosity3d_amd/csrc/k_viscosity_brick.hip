@@ -330,6 +330,47 @@ __global__ __launch_bounds__(256) void k_bflush(const int *__restrict__ bricks, 
         }
     }
 }
+// The six factors of the U, V and W row at plain index c AS THE REFERENCE FORMS THEM (viscositysolver.cpp:394-427, 491-524, 589-622): every row averages the
+// four viscosity values around an edge in its own order -- (a + b + c + d) in float is not symmetric -- so with a VARIABLE viscosity field the two rows that
+// share an edge carry factors one ulp apart, and the reference's matrix is not the symmetric one the stored factors (k_visc_factors: one value per edge) give.
+// One ulp of a factor is ~6e-8 nu dt/dx^2 of what a row does to a near-rigid motion -- like the float-rounded diagonal, a defect of A_ref against the operator
+// the Krylov loop applies, and corrected the same way: the fp64 residual b - A_ref x uses THESE factors (order: right, left, top, bottom, front, back).
+struct RefRowFactors { float U[6], V[6], W[6]; };
+__device__ __forceinline__ RefRowFactors d_ref_row_factors(const float *__restrict__ nu, const float *__restrict__ vC, const float *__restrict__ vEU,
+                                                           const float *__restrict__ vEV, const float *__restrict__ vEW, size_t c, long sy, long sz, float factor) {
+    RefRowFactors F;
+    const float f2 = 2 * factor, n0 = nu[c];
+    const float nim = nu[c - 1], nip = nu[c + 1], njm = nu[c - sy], njp = nu[c + sy], nkm = nu[c - sz], nkp = nu[c + sz];
+    float v;
+    // U row at (i, j, k)
+    F.U[0] = (f2 * n0) * vC[c];
+    F.U[1] = (f2 * nim) * vC[c - 1];
+    v = 0.25f * (((nu[c - 1 + sy] + nim) + njp) + n0);             F.U[2] = (factor * v) * vEW[c + sy];
+    v = 0.25f * (((nim + nu[c - 1 - sy]) + n0) + njm);             F.U[3] = (factor * v) * vEW[c];
+    v = 0.25f * (((nu[c - 1 + sz] + nim) + nkp) + n0);             F.U[4] = (factor * v) * vEV[c + sz];
+    v = 0.25f * (((nim + nu[c - 1 - sz]) + n0) + nkm);             F.U[5] = (factor * v) * vEV[c];
+    // V row
+    v = 0.25f * (((njm + nu[c + 1 - sy]) + n0) + nip);             F.V[0] = (factor * v) * vEW[c + 1];
+    v = 0.25f * (((njm + nu[c - 1 - sy]) + n0) + nim);             F.V[1] = (factor * v) * vEW[c];
+    F.V[2] = (f2 * n0) * vC[c];
+    F.V[3] = (f2 * njm) * vC[c - sy];
+    v = 0.25f * (((njm + nu[c - sy + sz]) + n0) + nkp);            F.V[4] = (factor * v) * vEU[c + sz];
+    v = 0.25f * (((njm + nu[c - sy - sz]) + n0) + nkm);            F.V[5] = (factor * v) * vEU[c];
+    // W row
+    v = 0.25f * (((n0 + nkm) + nip) + nu[c + 1 - sz]);             F.W[0] = (factor * v) * vEV[c + 1];
+    v = 0.25f * (((n0 + nkm) + nim) + nu[c - 1 - sz]);             F.W[1] = (factor * v) * vEV[c];
+    v = 0.25f * (((n0 + nkm) + njp) + nu[c + sy - sz]);            F.W[2] = (factor * v) * vEU[c + sy];
+    v = 0.25f * (((n0 + nkm) + njm) + nu[c - sy - sz]);            F.W[3] = (factor * v) * vEU[c];
+    F.W[4] = (f2 * n0) * vC[c];
+    F.W[5] = (f2 * nkm) * vC[c - sz];
+    return F;
+}
+struct RefRowInputs {   // perRow != 0: the plain-layout arrays the factors above are formed from, and the rows' exact own volumes (brick layout)
+    const float *nu, *vC, *vEU, *vEV, *vEW, *xmU, *xmV, *xmW;
+    Lay L, LB;
+    float factor;
+    int perRow;
+};
 template <typename T>
 __global__ __launch_bounds__(256) void k_bresidual(const int *__restrict__ bricks, int nb, const float *__restrict__ vmU, const float *__restrict__ vmV,
                                                    const float *__restrict__ vmW, const float *__restrict__ fC, const float *__restrict__ fEU,
@@ -337,7 +378,7 @@ __global__ __launch_bounds__(256) void k_bresidual(const int *__restrict__ brick
                                                    const double *__restrict__ xu, const double *__restrict__ xv, const double *__restrict__ xw,
                                                    const float *__restrict__ bU, const float *__restrict__ bV, const float *__restrict__ bW,
                                                    float *__restrict__ zU, float *__restrict__ zV, float *__restrict__ zW, float omega,
-                                                   PcgScal sc, int it_arg, int period, int withSigma, int force) {
+                                                   PcgScal sc, int it_arg, int period, int withSigma, int force, RefRowInputs ref) {
     __shared__ double red[8];
     BrickWalk w;
     w.begin(bricks, nb, v.mask);
@@ -370,6 +411,38 @@ __global__ __launch_bounds__(256) void k_bresidual(const int *__restrict__ brick
                                                    V1F(EUjp), V1F(EUkp), V1D(U0), V1D(Ujm), V1D(Ujp), V1D(Ukm), V1D(Ukp), V1D(V0), V1D(Vjm), V1D(Vjp), V1D(Vkm),
                                                    V1D(Vkp), V1D(W0), V1D(Wjm), V1D(Wjp), V1D(Wkm), V1D(Wkp), V1D(Vjpkm), V1D(Wjmkp), V1D(RU), V1D(RV), V1D(RW),
                                                    C0l, EW0r, EV0r, U0l, U0r, V0l, V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr, yU, yV, yW, ta, tb, tc, 0.0);
+        if (ref.perRow) {   // the reference's rows, each with its own six factors and its own float-rounded diagonal (three passes: one component's row each)
+            int pi, pj, pk;
+            d_brick_ijk(ref.LB, (int)(a >> 6), (int)threadIdx.x, pi, pj, pk);
+            const RefRowFactors F = d_ref_row_factors(ref.nu, ref.vC, ref.vEU, ref.vEV, ref.vEW, gidx(ref.L, pi, pj, pk), ref.L.sy, ref.L.sz, ref.factor);
+            auto refvol = [](float vol, const float *f) {
+                const float dg = vol + f[0] + f[1] + f[2] + f[3] + f[4] + f[5];
+                return dg != 0.0f ? d_ref_volume(vol, f[0], f[1], f[2], f[3], f[4], f[5], dg) : -1.0f;
+            };
+            const float none = -1.0f;
+            Vec<double, 1> d0, d1, d2;
+            if (m & 1u) {
+                const float M = refvol(ref.xmU[a], F.U);
+                d_visc_rows<double, 1, true, EPI_RESIDUAL>(V1F(M), V1F(none), V1F(none), V1F(F.U[0]), V1F(Cjm), V1F(Ckm), V1F(F.U[3]), V1F(F.U[2]), V1F(F.U[5]), V1F(F.U[4]), V1F(EU0),
+                                                           V1F(EUjp), V1F(EUkp), V1D(U0), V1D(Ujm), V1D(Ujp), V1D(Ukm), V1D(Ukp), V1D(V0), V1D(Vjm), V1D(Vjp), V1D(Vkm),
+                                                           V1D(Vkp), V1D(W0), V1D(Wjm), V1D(Wjp), V1D(Wkm), V1D(Wkp), V1D(Vjpkm), V1D(Wjmkp), V1D(RU), V1D(RV), V1D(RW),
+                                                           F.U[1], EW0r, EV0r, U0l, U0r, V0l, V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr, yU, d1, d2, ta, tb, tc, 0.0);
+            }
+            if (m & 2u) {
+                const float M = refvol(ref.xmV[a], F.V);
+                d_visc_rows<double, 1, true, EPI_RESIDUAL>(V1F(none), V1F(M), V1F(none), V1F(F.V[2]), V1F(F.V[3]), V1F(Ckm), V1F(F.V[1]), V1F(EWjp), V1F(EV0), V1F(EVkp), V1F(F.V[5]),
+                                                           V1F(EUjp), V1F(F.V[4]), V1D(U0), V1D(Ujm), V1D(Ujp), V1D(Ukm), V1D(Ukp), V1D(V0), V1D(Vjm), V1D(Vjp), V1D(Vkm),
+                                                           V1D(Vkp), V1D(W0), V1D(Wjm), V1D(Wjp), V1D(Wkm), V1D(Wkp), V1D(Vjpkm), V1D(Wjmkp), V1D(RU), V1D(RV), V1D(RW),
+                                                           C0l, F.V[0], EV0r, U0l, U0r, V0l, V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr, d0, yV, d2, ta, tb, tc, 0.0);
+            }
+            if (m & 4u) {
+                const float M = refvol(ref.xmW[a], F.W);
+                d_visc_rows<double, 1, true, EPI_RESIDUAL>(V1F(none), V1F(none), V1F(M), V1F(F.W[4]), V1F(Cjm), V1F(F.W[5]), V1F(EW0), V1F(EWjp), V1F(F.W[1]), V1F(EVkp), V1F(F.W[3]),
+                                                           V1F(F.W[2]), V1F(EUkp), V1D(U0), V1D(Ujm), V1D(Ujp), V1D(Ukm), V1D(Ukp), V1D(V0), V1D(Vjm), V1D(Vjp), V1D(Vkm),
+                                                           V1D(Vkp), V1D(W0), V1D(Wjm), V1D(Wjp), V1D(Wkm), V1D(Wkp), V1D(Vjpkm), V1D(Wjmkp), V1D(RU), V1D(RV), V1D(RW),
+                                                           C0l, EW0r, F.W[0], U0l, U0r, V0l, V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr, d0, d1, yW, ta, tb, tc, 0.0);
+            }
+        }
 #undef V1F
 #undef V1D
         const double rr[3] = {yU.v[0], yV.v[0], yW.v[0]};
@@ -488,7 +561,7 @@ void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int perio
     hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, it_arg, period, 0, withSigma, 0);
     hipLaunchKernelGGL((k_bresidual<T>), dim3(spmv_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v,
                        (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1],
-                       (const float *)c->vB[2], z ? z[0] : nullptr, z ? z[1] : nullptr, z ? z[2] : nullptr, omega, sc, it_arg, period, withSigma, 0);
+                       (const float *)c->vB[2], z ? z[0] : nullptr, z ? z[1] : nullptr, z ? z[2] : nullptr, omega, sc, it_arg, period, withSigma, 0, RefRowInputs{});
 }
 template void fv_brick_replace<float>(flipv_context *, const PcgScal &, int, int, int, float *const[3], float);
 template void fv_brick_replace<double>(flipv_context *, const PcgScal &, int, int, int, float *const[3], float);
@@ -502,6 +575,12 @@ int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool 
     const BrickSys<T> v = brick_sys<T>(c);
     const float *const vo[3] = {outerExact ? c->vmU : c->vrU, outerExact ? c->vmV : c->vrV, outerExact ? c->vmW : c->vrW};
     const dim3 b(64, 4, 1);
+    RefRowInputs ref{};
+    if (!outerExact && c->vPerRowFactors) {   // a variable viscosity field: the reference's rows with their own factors (d_ref_row_factors)
+        ref.nu = c->visc; ref.vC = c->volC; ref.vEU = c->volEU; ref.vEV = c->volEV; ref.vEW = c->volEW;
+        ref.xmU = c->vmU; ref.xmV = c->vmV; ref.xmW = c->vmW;
+        ref.L = c->L; ref.LB = c->LB; ref.factor = c->vFactorNow; ref.perRow = 1;
+    }
     hipLaunchKernelGGL((k_bflush<T>), dim3(update_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, v, c->vXacc[0], c->vXacc[1], c->vXacc[2], sc, 0, 0, 1, 0, flushMode);
     {   // bank 0's slot blocks (the extra scalars behind them stay), then the other banks
         const FillJob z[2] = {{sc.base, scalBytes, 0}, {sc.base + sc.bstride, sc.nbank > 1 ? (size_t)(sc.nbank - 1) * sc.bstride * sizeof(double) : 0, 0}};
@@ -515,7 +594,7 @@ int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool 
     }
     hipLaunchKernelGGL((k_bresidual<T>), dim3(spmv_grid(c)), b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v,
                        (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1],
-                       (const float *)c->vB[2], (float *)nullptr, (float *)nullptr, (float *)nullptr, 0.0f, sc, 0, 0, 0, 1);
+                       (const float *)c->vB[2], (float *)nullptr, (float *)nullptr, (float *)nullptr, 0.0f, sc, 0, 0, 0, 1, ref);
     return fv_allreduce_scalars(c, sc.rmax(0), NSLOT);   // (ranks write disjoint slots: the sum merges their maxima)
 }
 template int fv_brick_refine<float>(flipv_context *, const PcgScal &, size_t, bool, int);

@@ -4,6 +4,12 @@
 #pragma once
 #include "pcg_common.h"
 
+// own volume + the rounding defect of the reference's float diagonal: fl(vol + fR + ... + fK) minus the exact sum of the same seven floats (k_viscosity.hip: k_visc_setup)
+__device__ __forceinline__ float d_ref_volume(float vol, float fR, float fL, float fT, float fB, float fF, float fK, float dgf) {
+    const double exact = (double)vol + (double)fR + (double)fL + (double)fT + (double)fB + (double)fF + (double)fK;
+    return (float)((double)vol + ((double)dgf - exact));
+}
+
 #define LSH(a, al, e) ((e) > 0 ? (a).v[(e) > 0 ? (e)-1 : 0] : (al))
 #define RSH(a, ar, e) ((e) < NV - 1 ? (a).v[(e) < NV - 1 ? (e) + 1 : NV - 1] : (ar))
 // The U, V and W rows of a lane's NV indices (difference form, see above) and this lane's share of the three dot products.

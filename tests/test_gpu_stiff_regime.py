@@ -227,3 +227,36 @@ def test_sheared_start_where_the_defect_predictor_has_nothing_to_go_on(oracle):
     assert err <= 1e-4, err
     c.close()
     o.close()
+
+
+def test_variable_viscosity_field_at_64_defaults_against_converged_oracle(oracle):
+    """SURVEY 8 f4 at a size where the multigrid and the two-stage solve run: config 1's scene with a NODAL viscosity field (viscositysolver.cpp:394-427 reads it at
+    cell centres and edges) -- 200 below y = 0.42, 5 above, a smooth ramp of four cells between, so the bunny's feet are 40 x as viscous as its ears
+    (nu dt/dx^2 from 205 to 8 192 inside one system).  Default parameters against the oracle with its cap lifted, two chained substeps, <= 1e-4.
+    With a variable field the reference's rows average the four viscosities around an edge each in its own order, so its matrix is one ulp off the symmetric
+    one on the edge factors; the fp64 residual of the two-stage solve forms those rows as the reference does (k_viscosity_brick.hip: d_ref_row_factors):
+    1.7e-5 / 4.2e-5 here (unchained 1.7e-5 / 1.4e-5), 4.5e-5 / 6.7e-5 with the stored symmetric factors."""
+    from flipviscosity3d_amd.capi import Context
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    y = (np.arange(N + 1) * dx)[None, :, None]
+    ramp = np.clip((0.42 + 2.0 * dx - y) / (4.0 * dx), 0.0, 1.0)
+    nu = np.broadcast_to(5.0 + 195.0 * ramp, (N + 1, N + 1, N + 1)).astype(np.float32).copy()
+    assert nu.min() == 5.0 and nu.max() == 200.0
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid); c.set_viscosity(nu)
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid); o.set_viscosity(nu); o.set_solver_limits(vmaxiter=400000)
+    c.particles = P
+    o.particles = P
+    for t in range(2):
+        st = c.substep(0.01)
+        sec, vi, pi = o.substep(0.01)
+        v = st["viscosity"]
+        ref = [o.grid(n) for n in "UVW"]
+        err = max(float(np.abs(c.grid(n).astype(np.float64) - r).max()) for n, r in zip("UVW", ref)) / max(float(np.abs(r).max()) for r in ref)
+        print("variable viscosity 64^3 substep %d: %d iterations (%d correction; oracle %d), status %d, velocity error %.2e" % (t, v["iterations"], v["correction_iterations"], vi["iterations"], v["status"], err))
+        assert vi["status"] == 0 and v["status"] == 0 and v["preconditioner"] == 1 and v["iterations"] < 300, (vi, v)
+        assert err <= 1e-4, (t, err)
+    c.close()
+    o.close()
