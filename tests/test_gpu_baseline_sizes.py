@@ -453,3 +453,36 @@ def test_fp64_precision_under_the_multigrid_meets_the_references_own_criterion(o
     assert err <= 1e-5, err
     c.close()
     o.close()
+
+
+def test_moving_liquid_against_a_tightly_converged_oracle(oracle):
+    """What separates the GPU from the reference on a moving liquid is the two sides' SOLVER tolerances, nothing else in the substep: the same state as above (config 1's
+    scene after 25 oracle substeps), but the oracle's 26th substep run to 1e-10 / 1e-13 instead of the reference's 1e-6 / 1e-9.  Against that the default GPU substep is
+    ~2e-5 off (the reference's own default substep is ~5e-5 off it: the 5.2e-5 of the test above is mostly the reference's tolerance), with the solves tightened 7e-7 in
+    fp32 vectors and ~1.5e-7 with `precision = 1`: SDF, P2G, extrapolation, control volumes, both operators, the pressure update and advection agree to fp32 rounding."""
+    from flipviscosity3d_amd.capi import Context
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    o = oracle.OracleSim(N, N, N, dx)
+    o.set_solid(solid); o.set_viscosity(5.0); o.set_solver_limits(vmaxiter=100000)
+    o.particles = P
+    for t in range(25):
+        o.substep(0.01)
+    start = o.particles.copy()
+    o.set_solver_limits(vmaxiter=400000, vtol=1e-10, ptol=1e-13)
+    o.substep(0.01)
+    ref = [o.grid(n) for n in "UVW"]
+    errs = {}
+    for name, kw in (("default", {}), ("tight fp32", dict(pressure_rel_tolerance=1e-8, viscosity_tolerance=1e-8, viscosity_stage1_factor=1.0)),
+                     ("tight fp64", dict(precision=1, viscosity_tolerance=1e-9, pressure_rel_tolerance=1e-9))):
+        c = Context(N, N, N, dx)
+        c.set_solid_sdf(solid); c.set_viscosity(5.0)
+        if kw:
+            c.set_params(**kw)
+        c.particles = start
+        st = c.substep(0.01)
+        errs[name] = vel_err(c, ref)
+        print("moving 64^3 bunny against the oracle at 1e-10, %s: viscosity %d iterations, pressure %d, velocity error %.2e" % (name, st["viscosity"]["iterations"], st["pressure"]["iterations"], errs[name]))
+        c.close()
+    o.close()
+    assert errs["default"] <= 5e-5 and errs["tight fp32"] <= 5e-6 and errs["tight fp64"] <= 2e-6, errs
