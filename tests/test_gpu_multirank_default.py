@@ -159,3 +159,30 @@ def test_distributed_level_1_is_the_same_preconditioner(N, dims):
     for c in glob + dist:
         c.close()
     ref.close()
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 2), (2, 2, 1)])
+def test_variable_viscosity_blocks_run_the_single_domains_solve(dims):
+    """a NODAL viscosity field (5 above, 200 below a four-cell ramp: tests/test_gpu_stiff_regime.py) on block contexts: every rank forms the reference's per-row edge
+    factors in its fp64 residual from its own box of the field and the control volumes (their halo entries are computed redundantly), so the decomposed run is the
+    single domain's -- iteration counts within a few, velocities within 5e-5 -- over two chained substeps, default parameters."""
+    from flipviscosity3d_amd import capi
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    y = (np.arange(N + 1) * dx)[None, :, None]
+    nu = np.broadcast_to(5.0 + 195.0 * np.clip((0.42 + 2.0 * dx - y) / (4.0 * dx), 0.0, 1.0), (N + 1, N + 1, N + 1)).astype(np.float32).copy()
+    ref = capi.Context(N, N, N, dx)
+    ref.set_solid_sdf(solid); ref.set_viscosity(nu); ref.particles = P
+    ctxs = make_blocks(N, dx, solid, P, nu, dims)
+    for t in range(2):
+        sr = ref.substep(0.01)
+        sts = run_ranks(ctxs, lambda r, c: c.substep(0.01))
+        assert_same_solve_on_every_rank(sts)
+        v, vr = sts[0]["viscosity"], sr["viscosity"]
+        err = rel_maxnorm3([assemble(ctxs, n) for n in "UVW"], [ref.grid(n) for n in "UVW"])
+        print("variable viscosity, %s blocks, substep %d: %d iterations (single domain %d), velocity difference %.2e" % (dims, t, v["iterations"], vr["iterations"], err))
+        assert v["status"] == 0 and vr["status"] == 0 and v["layout"] == 2 and abs(v["iterations"] - vr["iterations"]) <= 6, (v, vr)
+        assert err <= 5e-5, (t, err)
+    for c in ctxs:
+        c.close()
+    ref.close()
