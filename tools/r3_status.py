@@ -13,15 +13,17 @@ if extra:
     c.set_params(**extra)
 c.particles = P
 status, prec, its, ms = collections.Counter(), collections.Counter(), [], []
+pstatus, pits = collections.Counter(), []
 t0 = time.perf_counter()
 for t in range(nsub):
     st = c.substep(min(c.cfl(), 0.01))
     v = st["viscosity"]
+    pstatus[st["pressure"]["status"]] += 1; pits.append(st["pressure"]["iterations"])
     status[v["status"]] += 1; prec[v["preconditioner"]] += 1; its.append(v["iterations"]); ms.append(st["total_ms"])
     if v["status"] != 0:
         print("substep %d: status %d after %d iterations (%d in correction stages, correction status %d), residual/rhs %.2e, defect residual/rhs %.2e, preconditioner %d" % (
             t, v["status"], v["iterations"], v["correction_iterations"], v["correction_status"], v["residual"] / max(v["rhs_norm"], 1e-300), v["defect_residual"] / max(v["rhs_norm"], 1e-300), v["preconditioner"]), flush=True)
 c.synchronize()
 wall = (time.perf_counter() - t0) * 1e3 / nsub
-print("%s %dx%dx%d nu %g, %d substeps: %.2f ms per substep (wall), GPU mean %.2f; viscosity status %s, preconditioner %s, iterations min/mean/max %d/%.1f/%d; last 5: %s" % (
-    wl, I, J, K, nu, nsub, wall, sum(ms) / nsub, dict(status), dict(prec), min(its), sum(its) / nsub, max(its), its[-5:]))
+print("%s %dx%dx%d nu %g, %d substeps: %.2f ms per substep (wall), GPU mean %.2f; viscosity status %s, preconditioner %s, iterations min/mean/max %d/%.1f/%d; last 5: %s; pressure status %s, iterations min/mean/max %d/%.1f/%d" % (
+    wl, I, J, K, nu, nsub, wall, sum(ms) / nsub, dict(status), dict(prec), min(its), sum(its) / nsub, max(its), its[-5:], dict(pstatus), min(pits), sum(pits) / nsub, max(pits)))
