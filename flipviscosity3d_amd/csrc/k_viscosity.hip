@@ -668,6 +668,75 @@ __global__ void k_plane_residual_finish(Lay L, const uint8_t *__restrict__ rowma
         atomic_max_nonneg(sc.rmax(0) + sl, bm);
     }
 }
+// The same residual with the REFERENCE's rows formed one by one -- each row's six factors in its own float arithmetic, its own float-rounded diagonal
+// (visc_rows.h: d_ref_row_factors) -- for a variable viscosity field: r = b - A_ref xacc in fp64, max|r| into rmax(0).  One thread per index of the launch box.
+template <typename T>
+__global__ void k_plane_residual_ref(Lay L, const uint8_t *__restrict__ rowmask, int swz, const float *__restrict__ nu, const float *__restrict__ vC,
+                                     const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor,
+                                     const float *__restrict__ xmU, const float *__restrict__ xmV, const float *__restrict__ xmW,
+                                     const double *__restrict__ xu, const double *__restrict__ xv, const double *__restrict__ xw,
+                                     const float *__restrict__ bU, const float *__restrict__ bV, const float *__restrict__ bW,
+                                     RT<T> *__restrict__ r0, RT<T> *__restrict__ r1, RT<T> *__restrict__ r2, PcgScal sc) {
+    __shared__ double lds[4];
+    IJK_OF_THREAD(L);
+    double mx = 0.0;
+    if (i < L.ie && j < L.je) {
+        const size_t a = gidx(L, i, j, k);
+        const unsigned m = rowmask[a];
+        if (m) {
+            const size_t cs = swz ? sidx(L, i, j, k) : a;
+            const NbOff o = nb_plain(L);
+            const double U0 = xu[a], U0l = xu[a + o.xm], U0r = xu[a + o.xp], Ujm = xu[a + o.ym], Ujp = xu[a + o.yp], Ukm = xu[a + o.zm], Ukp = xu[a + o.zp];
+            const double Ujmr = xu[a + o.ym + o.xp], Ukmr = xu[a + o.zm + o.xp];
+            const double V0 = xv[a], V0l = xv[a + o.xm], V0r = xv[a + o.xp], Vjm = xv[a + o.ym], Vjp = xv[a + o.yp], Vkm = xv[a + o.zm], Vkp = xv[a + o.zp];
+            const double Vjpl = xv[a + o.yp + o.xm], Vjpkm = xv[a + o.yp + o.zm];
+            const double W0 = xw[a], W0l = xw[a + o.xm], W0r = xw[a + o.xp], Wjm = xw[a + o.ym], Wjp = xw[a + o.yp], Wkm = xw[a + o.zm], Wkp = xw[a + o.zp];
+            const double Wkpl = xw[a + o.zp + o.xm], Wjmkp = xw[a + o.ym + o.zp];
+            const double RU = (m & 1u) ? (double)bU[a] : 0.0, RV = (m & 2u) ? (double)bV[a] : 0.0, RW = (m & 4u) ? (double)bW[a] : 0.0;
+            const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, a, L.sy, L.sz, factor);
+            auto refvol = [](float vol, const float *f) {
+                const float dg = vol + f[0] + f[1] + f[2] + f[3] + f[4] + f[5];
+                return dg != 0.0f ? d_ref_volume(vol, f[0], f[1], f[2], f[3], f[4], f[5], dg) : -1.0f;
+            };
+            const float none = -1.0f, z = 0.0f;
+            Vec<double, 1> yU, yV, yW, d0, d1, d2;
+            double ta = 0.0, tb = 0.0, tc = 0.0;
+#define V1F(x_) Vec<float, 1>{{x_}}
+#define V1D(x_) Vec<double, 1>{{x_}}
+#define XARGS V1D(U0), V1D(Ujm), V1D(Ujp), V1D(Ukm), V1D(Ukp), V1D(V0), V1D(Vjm), V1D(Vjp), V1D(Vkm), V1D(Vkp), V1D(W0), V1D(Wjm), V1D(Wjp), V1D(Wkm), V1D(Wkp), V1D(Vjpkm), V1D(Wjmkp), V1D(RU), V1D(RV), V1D(RW)
+#define XTAIL U0l, U0r, V0l, V0r, W0l, W0r, Vjpl, Wkpl, Ujmr, Ukmr
+            RT<T> *r[3] = {r0, r1, r2};
+            if (m & 1u) {   // U row: right, left = C0, C0l; top, bottom = EWjp, EW0; front, back = EVkp, EV0
+                const float M = refvol(xmU[cs], F.U);
+                d_visc_rows<double, 1, true, EPI_RESIDUAL>(V1F(M), V1F(none), V1F(none), V1F(F.U[0]), V1F(z), V1F(z), V1F(F.U[3]), V1F(F.U[2]), V1F(F.U[5]), V1F(F.U[4]), V1F(z), V1F(z), V1F(z),
+                                                           XARGS, F.U[1], z, z, XTAIL, yU, d1, d2, ta, tb, tc, 0.0);
+                const RT<T> rt = (RT<T>)yU.v[0]; r[0][cs] = rt; mx = fmax(mx, fabs((double)rt));
+            }
+            if (m & 2u) {   // V row: right, left = EW0r, EW0; top, bottom = C0, Cjm; front, back = EUkp, EU0
+                const float M = refvol(xmV[cs], F.V);
+                d_visc_rows<double, 1, true, EPI_RESIDUAL>(V1F(none), V1F(M), V1F(none), V1F(F.V[2]), V1F(F.V[3]), V1F(z), V1F(F.V[1]), V1F(z), V1F(z), V1F(z), V1F(F.V[5]), V1F(z), V1F(F.V[4]),
+                                                           XARGS, z, F.V[0], z, XTAIL, d0, yV, d2, ta, tb, tc, 0.0);
+                const RT<T> rt = (RT<T>)yV.v[0]; r[1][cs] = rt; mx = fmax(mx, fabs((double)rt));
+            }
+            if (m & 4u) {   // W row: right, left = EV0r, EV0; top, bottom = EUjp, EU0; front, back = C0, Ckm
+                const float M = refvol(xmW[cs], F.W);
+                d_visc_rows<double, 1, true, EPI_RESIDUAL>(V1F(none), V1F(none), V1F(M), V1F(F.W[4]), V1F(z), V1F(F.W[5]), V1F(z), V1F(z), V1F(F.W[1]), V1F(z), V1F(F.W[3]), V1F(F.W[2]), V1F(z),
+                                                           XARGS, z, z, F.W[0], XTAIL, d0, d1, yW, ta, tb, tc, 0.0);
+                const RT<T> rt = (RT<T>)yW.v[0]; r[2][cs] = rt; mx = fmax(mx, fabs((double)rt));
+            }
+#undef V1F
+#undef V1D
+#undef XARGS
+#undef XTAIL
+        }
+    }
+    const double bm = block_max_256(mx, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) {
+        const unsigned bl = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int sl = sc.slot0 + (int)(bl % (unsigned)sc.nslot) + (sc.nbank > 1 ? (int)((bl / (unsigned)sc.nslot) % (unsigned)sc.nbank) * sc.bstride : 0);
+        atomic_max_nonneg(sc.rmax(0) + sl, bm);
+    }
+}
 // x + xacc -> velocity grid over a launch box
 template <typename T>
 __global__ void k_plane_writeback(Lay L, int swz, const T *__restrict__ x, const double *__restrict__ acc, float *__restrict__ o) {
@@ -703,6 +772,13 @@ static int fv_plane_refine(flipv_context *c, const Lay &R, const PcgScal &sc, si
     if (c->comm) {
         const HaloArray xa[3] = {{c->vXacc[0], sizeof(double)}, {c->vXacc[1], sizeof(double)}, {c->vXacc[2], sizeof(double)}};
         if ((rc = fv_halo_copy(c, xa, 3, 1))) return rc;
+    }
+    if (!outerExact && c->vPerRowFactors) {   // a variable viscosity field: the reference's rows one by one (k_plane_residual_ref)
+        hipLaunchKernelGGL((k_plane_residual_ref<T>), GRID3(R), 0, c->stream, R, (const uint8_t *)c->vRowMask, c->vSwz, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU,
+                           (const float *)c->volEV, (const float *)c->volEW, c->vFactorNow, (const float *)c->vmU, (const float *)c->vmV, (const float *)c->vmW,
+                           (const double *)c->vXacc[0], (const double *)c->vXacc[1], (const double *)c->vXacc[2], (const float *)c->vB[0], (const float *)c->vB[1], (const float *)c->vB[2],
+                           (RT<T> *)c->vR[0], (RT<T> *)c->vR[1], (RT<T> *)c->vR[2], sc);
+        return fv_allreduce_scalars(c, sc.rmax(0), NSLOT);
     }
     // q64 = A_outer xacc with the solver's own SpMV kernel in fp64 (no scalars: an unconditional launch without dot products)
     PcgSys<double, 3> v;
@@ -740,7 +816,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         c->vPerRowFactors = vlo != vm ? 1 : 0;
     } else { c->viscosity_nonzero_any = c->viscosity_nonzero; c->viscosity_max_any = c->viscosity_max; c->vPerRowFactors = c->viscosity_min != c->viscosity_max ? 1 : 0; }
     // (vPerRowFactors: a VARIABLE viscosity field -- the fp64 residual of the two-stage solve then forms the reference's rows with their own factors,
-    // k_viscosity_brick.hip: d_ref_row_factors; brick layout only)
+    // visc_rows.h: d_ref_row_factors; k_bresidual on bricks, k_plane_residual_ref on the plane layouts)
     if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
         li.status = 3;
         if (info) *info = li;

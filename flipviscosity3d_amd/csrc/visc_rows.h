@@ -107,3 +107,38 @@ __device__ __forceinline__ void d_visc_rows(
     }
 }
 
+// The six factors of the U, V and W row at plain index c AS THE REFERENCE FORMS THEM (viscositysolver.cpp:394-427, 491-524, 589-622): every row averages the
+// four viscosity values around an edge in its own order -- (a + b + c + d) in float is not symmetric -- so with a VARIABLE viscosity field the two rows that
+// share an edge carry factors one ulp apart, and the reference's matrix is not the symmetric one the stored factors (k_visc_factors: one value per edge) give.
+// One ulp of a factor is ~6e-8 nu dt/dx^2 of what a row does to a near-rigid motion -- like the float-rounded diagonal, a defect of A_ref against the operator
+// the Krylov loop applies, and corrected the same way: the fp64 residual b - A_ref x uses THESE factors (order: right, left, top, bottom, front, back).
+struct RefRowFactors { float U[6], V[6], W[6]; };
+__device__ __forceinline__ RefRowFactors d_ref_row_factors(const float *__restrict__ nu, const float *__restrict__ vC, const float *__restrict__ vEU,
+                                                           const float *__restrict__ vEV, const float *__restrict__ vEW, size_t c, long sy, long sz, float factor) {
+    RefRowFactors F;
+    const float f2 = 2 * factor, n0 = nu[c];
+    const float nim = nu[c - 1], nip = nu[c + 1], njm = nu[c - sy], njp = nu[c + sy], nkm = nu[c - sz], nkp = nu[c + sz];
+    float v;
+    // U row at (i, j, k)
+    F.U[0] = (f2 * n0) * vC[c];
+    F.U[1] = (f2 * nim) * vC[c - 1];
+    v = 0.25f * (((nu[c - 1 + sy] + nim) + njp) + n0);             F.U[2] = (factor * v) * vEW[c + sy];
+    v = 0.25f * (((nim + nu[c - 1 - sy]) + n0) + njm);             F.U[3] = (factor * v) * vEW[c];
+    v = 0.25f * (((nu[c - 1 + sz] + nim) + nkp) + n0);             F.U[4] = (factor * v) * vEV[c + sz];
+    v = 0.25f * (((nim + nu[c - 1 - sz]) + n0) + nkm);             F.U[5] = (factor * v) * vEV[c];
+    // V row
+    v = 0.25f * (((njm + nu[c + 1 - sy]) + n0) + nip);             F.V[0] = (factor * v) * vEW[c + 1];
+    v = 0.25f * (((njm + nu[c - 1 - sy]) + n0) + nim);             F.V[1] = (factor * v) * vEW[c];
+    F.V[2] = (f2 * n0) * vC[c];
+    F.V[3] = (f2 * njm) * vC[c - sy];
+    v = 0.25f * (((njm + nu[c - sy + sz]) + n0) + nkp);            F.V[4] = (factor * v) * vEU[c + sz];
+    v = 0.25f * (((njm + nu[c - sy - sz]) + n0) + nkm);            F.V[5] = (factor * v) * vEU[c];
+    // W row
+    v = 0.25f * (((n0 + nkm) + nip) + nu[c + 1 - sz]);             F.W[0] = (factor * v) * vEV[c + 1];
+    v = 0.25f * (((n0 + nkm) + nim) + nu[c - 1 - sz]);             F.W[1] = (factor * v) * vEV[c];
+    v = 0.25f * (((n0 + nkm) + njp) + nu[c + sy - sz]);            F.W[2] = (factor * v) * vEU[c + sy];
+    v = 0.25f * (((n0 + nkm) + njm) + nu[c - sy - sz]);            F.W[3] = (factor * v) * vEU[c];
+    F.W[4] = (f2 * n0) * vC[c];
+    F.W[5] = (f2 * nkm) * vC[c - sz];
+    return F;
+}

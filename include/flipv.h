@@ -112,7 +112,7 @@ typedef struct flipv_params {
                                     residual is taken back, one that ends short of its target is restarted once from the recomputed fp64 residual.  flipv_solve_info: status 0 = every stage reached its target; residual = stage 1's;
                                     defect_residual = max|b - A_ref x| delivered; correction_* = what the correction stages did.
                                     With a VARIABLE viscosity field (flipv_set_viscosity with differing node values) A_ref also means the reference's per-row edge factors --
-                                    each row averages the four viscosities around an edge in its own float order --: the fp64 residual forms them row by row (brick layout).
+                                    each row averages the four viscosities around an edge in its own float order --: the fp64 residual forms them row by row.
                                     REPRODUCIBILITY: scatters and dot products sum in arrival order, so two runs agree to solver tolerance, not bit for bit.  With the
                                     reference's operator that can be coarser LOCALLY: its rounded diagonal leaves the near-rigid modes of tiny detached liquid clusters
                                     (own volumes of the size of the defect, which may even come out slightly negative) ill-determined -- two runs of one

@@ -292,3 +292,39 @@ def test_the_references_operator_is_reproduced_not_approximated(oracle, nu):
     o.close()
     assert errs["default"] <= 3e-5 and errs["two correction stages"] <= 5e-6, errs
     assert errs["exact operator to 1e-9"] >= 5.0 * errs["default"], errs       # a different linear system
+
+
+@pytest.mark.parametrize("scene", ["sparse (bricks)", "dense (planes)"])
+def test_per_row_factor_residual_equals_the_stored_factor_residual_where_the_field_is_uniform(scene):
+    """The fp64 residual that forms the reference's rows one by one (a variable viscosity field: k_bresidual with RefRowInputs on bricks, k_plane_residual_ref on
+    the plane layouts) against the one that reads the stored edge factors: the viscosity field is uniform except for ONE node buried in the solid wall -- enough to
+    switch the per-row path on, nowhere near a row -- so every factor is what the stored one is and the two runs must deliver the same velocities (the residual kernels
+    differ, the arithmetic does not: <= 2e-6; both layouts)."""
+    from flipviscosity3d_amd.capi import Context
+    if scene.startswith("sparse"):
+        N, nu0 = 64, 200.0
+        dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+        layout = 2
+    else:
+        N, nu0 = 48, 150.0
+        dx, solid, P = dense_scene(N, 0.66)
+        P = P.copy()
+        P[:, 3] = 0.8 * np.sin(7.0 * P[:, 1]) * np.cos(5.0 * P[:, 2]); P[:, 4] = -0.3 * np.cos(6.0 * P[:, 0]); P[:, 5] = 0.5 * np.sin(4.0 * P[:, 0] + 3.0 * P[:, 1])
+        layout = 1
+    out = []
+    for bump in (0.0, 1.0):
+        nu = np.full((N + 1, N + 1, N + 1), nu0, np.float32)
+        nu[0, 0, 0] += bump                     # a corner node of the domain: solid, no row within reach
+        c = Context(N, N, N, dx)
+        c.set_solid_sdf(solid); c.set_viscosity(nu)
+        c.particles = P
+        st = c.substep(0.01)
+        v = st["viscosity"]
+        assert v["status"] == 0 and v["layout"] in ((2,) if layout == 2 else (0, 1)) and v["correction_iterations"] > 0, v
+        out.append(([c.grid(n) for n in "UVW"], v["iterations"]))
+        c.close()
+    (a, ia), (b, ib) = out
+    den = max(float(np.abs(x).max()) for x in a)
+    err = max(float(np.abs(x.astype(np.float64) - y).max()) for x, y in zip(a, b)) / den
+    print("%s: stored factors %d iterations, per-row factors %d, velocity difference %.2e" % (scene, ia, ib, err))
+    assert abs(ia - ib) <= 3 and err <= 2e-6, (ia, ib, err)
