@@ -225,6 +225,7 @@ struct flipv_context {
     int viscosity_nonzero;  // cached host-side: any viscosity node > 0 (in this rank's box)
     float viscosity_min = 1.0f;     // smallest viscosity node value in this rank's box (min != max: a variable field; k_viscosity_brick.hip: the per-row factors of the fp64 residual)
     float vFactorNow = 0.0f;       // dt / dx^2 of the running viscosity solve (viscositysolver.cpp:379-380)
+    int vZeroRegion = 0;           // the viscosity field is exactly zero on part of the nodes and positive elsewhere (two correction stages: k_viscosity.hip)
     int vPerRowFactors = 0;        // this solve's fp64 residual on the reference's operator forms every row's six factors in the reference's own arithmetic
     float viscosity_max = 1.0f;     // largest viscosity node value in this rank's box; viscosity_max_any: over all ranks (the a-priori stiffness
     float viscosity_max_any = 1.0f; // estimate nu dt/dx^2 of fv_visc_auto_pick; all-reduced at the start of every viscosity solve)

@@ -176,7 +176,7 @@ typedef struct flipv_params {
     float viscosity_stage2_factor;          /* [1e-2 up to nu dt/dx^2 = 2e4, 1e-3 beyond; 2e-2 where stage 1 ran to viscosity_tolerance] a correction stage's target as a share of
                                                the defect it starts from.  Scanned against the reference run to convergence from 8e3 to 1.3e5 (k_viscosity.hip: viscosity_solve_t) */
     int viscosity_stage2_max_iterations;    /* [200] iteration budget of ONE correction stage (inside viscosity_max_iterations overall) */
-    int viscosity_stage2_rounds;            /* [1] correction stages at most; 2 brings the velocities to <= 6e-6 of the reference's at every stiffness measured, for ~35 % more
+    int viscosity_stage2_rounds;            /* [1; 2 where the viscosity field is exactly 0 on part of the nodes and positive elsewhere] correction stages at most; 2 brings the velocities to <= 6e-6 of the reference's at every stiffness measured, for ~35 % more
                                                iterations than one stage at the default share */
     float viscosity_two_stage_max_stiffness;/* [2e5] nu dt/dx^2 up to which stage 1 stops early (beyond: the fp32 loop's accuracy floor, stage 1 runs to viscosity_tolerance) */
     int viscosity_defect_predictor;         /* [0 = on] stage 1 solves A x = b - E u_old (E = the reference's diagonal defect, u_old = the incoming velocities) instead of A x = b:
