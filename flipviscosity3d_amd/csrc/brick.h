@@ -119,7 +119,7 @@ static inline int fv_brickv_grid(int nbricks, int cap) {
     return g < 8 ? 8 : (g < cap ? g : cap);
 }
 
-// Scalar prologue of the update kernel (K2 of pcg_common.h), shared with k_pcg_update's logic (pcg_geo.inc): folds rmax(it-1), sigma(it),
+// Scalar prologue of the update kernel (K2 of pcg_common.h), shared with k_pcg_update's logic (pcg_geo.inc): folds rmax(it-1), step(it-1), sigma(it),
 // a, b, c(it), runs the stop test and the stall guard, forms alpha and beta.  Returns false when the launch must do nothing.
 // lds: 8 doubles.  Every thread of the block must call it.
 __device__ __forceinline__ bool d_update_scalars(const PcgScal &sc, int it_arg, double *lds, int &it, double &alpha_d, double &beta_d) {
@@ -128,17 +128,17 @@ __device__ __forceinline__ bool d_update_scalars(const PcgScal &sc, int it_arg, 
     it = itB_now;
     if (it >= sc.cap) return false;
     const int tid = d_tid256();
-    const int grp = tid >> 5;  // 0 rmax(it-1), 1 sig, 2 a, 3 b, 4 c
+    const int grp = tid >> 5;  // 0 rmax(it-1), 1 step(it-1), 2 sig, 3 a, 4 b, 5 c
     double v = 0.0;
-    if (grp < 5 && (it > 0 || grp > 0)) v = grp == 0 ? sc.slot_max(sc.sig(it) - NSLOT, tid) : sc.slot_sum(sc.sig(it) - NSLOT, tid);
+    if (grp < 6 && (it > 0 || grp > 1)) v = grp <= 1 ? sc.slot_max(sc.sig(it) - 2 * NSLOT + grp * NSLOT, tid & (NSLOT - 1)) : sc.slot_sum(sc.sig(it) + (grp - 2) * NSLOT, tid & (NSLOT - 1));
 #pragma unroll
     for (int off = NSLOT / 2; off > 0; off >>= 1) {
         const double o = __shfl_down(v, off, NSLOT);
-        v = grp == 0 ? fmax(v, o) : v + o;
+        v = grp <= 1 ? fmax(v, o) : v + o;
     }
-    if (grp < 5 && (tid & (NSLOT - 1)) == 0) lds[grp] = v;
+    if (grp < 6 && (tid & (NSLOT - 1)) == 0) lds[grp] = v;
     __syncthreads();
-    if (it > 0 && d_pass(sc, lds[0])) {
+    if (it > 0 && d_pass(sc, lds[0]) && d_steps_small(sc, it - 1, lds)) {   // (with the velocity criterion where the loop carries one: PcgScal::vel_tol)
         if (blockIdx.x == 0 && tid == 0) *sc.conv = it - 1;
         return false;
     }
@@ -150,10 +150,10 @@ __device__ __forceinline__ bool d_update_scalars(const PcgScal &sc, int it_arg, 
         }
         if (blockIdx.x == 0 && tid == 0 && res < bestNow) *sc.best = res;
     }
-    const double sg = lds[1], a = lds[2];
+    const double sg = lds[2], a = lds[3];
     alpha_d = a != 0.0 ? sg / a : 0.0;
-    const double bdot = sc.noB ? a : lds[3];
-    double est = sg - 2.0 * alpha_d * bdot + alpha_d * alpha_d * lds[4];
+    const double bdot = sc.noB ? a : lds[4];
+    double est = sg - 2.0 * alpha_d * bdot + alpha_d * alpha_d * lds[5];
     if (!(est > 0.0)) est = 0.0;
     beta_d = sg != 0.0 ? est / sg : 0.0;
     return true;

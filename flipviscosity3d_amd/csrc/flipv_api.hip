@@ -394,6 +394,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!in(p->viscosity_stage2_max_iterations, 0, 1 << 20) || !in(p->viscosity_stage2_rounds, 0, 16)) bad = "viscosity_stage2_max_iterations / viscosity_stage2_rounds";
         else if (!(p->viscosity_two_stage_max_stiffness >= 0.0f)) bad = "viscosity_two_stage_max_stiffness";
         else if (!in(p->viscosity_defect_predictor, -1, 0)) bad = "viscosity_defect_predictor";
+        else if (!(p->viscosity_velocity_tolerance == -1.0f || fin(p->viscosity_velocity_tolerance, 0.0f, 1.0f)) || !in(p->viscosity_velocity_window, 0, 8)) bad = "viscosity_velocity_tolerance (-1, or 0 ... 1) / viscosity_velocity_window (0 ... 8)";
         if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     }
     c->prm = *p;
@@ -972,23 +973,57 @@ __global__ __launch_bounds__(256) void k_stream(const float4 *__restrict__ a, fl
     }
     if (mode == 0 && acc == 123.456f) *sink = acc;  // keeps the loads alive
 }
+// The same three mixes the way a tuned streaming kernel moves them (modes 3 read, 4 copy, 5 = FIVE reads per write: the byte mix of the 7-point pressure
+// SpMV, 5 x 4 B read + 4 B written per cell): each lane keeps four independent 16-byte accesses in flight, a block walks contiguous 16 KiB chunks, loads
+// and stores are nontemporal (nothing is read twice).  bytes = the size of ONE array; GB/s counts every byte moved.
+typedef float fv_v4f __attribute__((ext_vector_type(4)));
+template <int NREAD, bool WRITE>
+__global__ __launch_bounds__(256) void k_stream_tuned(const fv_v4f *__restrict__ a, fv_v4f *__restrict__ b, size_t n, float *__restrict__ sink) {
+    fv_v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t base = (size_t)blockIdx.x * 1024; base < n; base += (size_t)gridDim.x * 1024) {
+        fv_v4f v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t t = base + (size_t)u * 256 + threadIdx.x;
+            v[u] = fv_v4f{0.0f, 0.0f, 0.0f, 0.0f};
+            if (t < n) {
+#pragma unroll
+                for (int m = 0; m < NREAD; m++) v[u] += __builtin_nontemporal_load(a + (size_t)m * n + t);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const size_t t = base + (size_t)u * 256 + threadIdx.x;
+            if (WRITE) { if (t < n) __builtin_nontemporal_store(v[u], b + t); }
+            else acc += v[u];
+        }
+    }
+    if (!WRITE && acc.x + acc.y + acc.z + acc.w == 123.456f) *sink = acc.x;
+}
 extern "C" int flipv_bench_stream(flipv_context *c, size_t bytes, int reps, int mode, double *gbps_out) {
     ENTER(c);
-    if (!gbps_out || reps < 1 || bytes < 4096 || mode < 0 || mode > 2) return FLIPV_ERR_INVALID;
+    if (!gbps_out || reps < 1 || bytes < 4096 || mode < 0 || mode > 5) return FLIPV_ERR_INVALID;
     void *a = nullptr, *b = nullptr;
-    HIPCHK(c, hipMalloc(&a, bytes));
+    const int nread = mode == 5 ? 5 : 1;
+    HIPCHK(c, hipMalloc(&a, bytes * nread));
     if (hipMalloc(&b, bytes + 64) != hipSuccess) { (void)hipFree(a); c->err = "flipv_bench_stream: out of memory"; return FLIPV_ERR_OOM; }
-    (void)hipMemsetAsync(a, 0, bytes, c->stream);
+    (void)hipMemsetAsync(a, 0, bytes * nread, c->stream);
     (void)hipMemsetAsync(b, 0, bytes + 64, c->stream);
     const size_t n = bytes / 16;
     const unsigned grid = 256 * 8 * 4;  // 32 blocks per CU
     float *sink = (float *)((char *)b + bytes);
-    hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n, mode, sink);
+    auto launch = [&]() {
+        if (mode <= 2) hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n, mode, sink);
+        else if (mode == 3) hipLaunchKernelGGL((k_stream_tuned<1, false>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
+        else if (mode == 4) hipLaunchKernelGGL((k_stream_tuned<1, true>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
+        else hipLaunchKernelGGL((k_stream_tuned<5, true>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
+    };
+    launch();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, c->stream);
-    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n, mode, sink);
+    for (int r = 0; r < reps; r++) launch();
     (void)hipEventRecord(e1, c->stream);
     (void)hipEventSynchronize(e1);
     float ms = 0;
@@ -997,7 +1032,8 @@ extern "C" int flipv_bench_stream(flipv_context *c, size_t bytes, int reps, int 
     (void)hipEventDestroy(e1);
     (void)hipFree(a);
     (void)hipFree(b);
-    *gbps_out = (mode == 1 ? 2.0 : 1.0) * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;
+    const double moved = mode == 1 || mode == 4 ? 2.0 : (mode == 5 ? 6.0 : 1.0);
+    *gbps_out = moved * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;
     return FLIPV_OK;
 }
 
@@ -1014,7 +1050,7 @@ extern "C" int fvdbg_pcg_scalars(flipv_context *c, int cap, int n, double *out) 
             double v = 0;
             for (int bk = 0; bk < nbank; bk++)
             for (int s = 0; s < NSLOT; s++) {
-                const double x = h[(size_t)bk * stride + (size_t)it * 5 * NSLOT + (size_t)q * NSLOT + s];   // block `it` = [sig | a | b | c | rmax] x NSLOT (PcgScal), per bank
+                const double x = h[(size_t)bk * stride + (size_t)it * FV_NSC * NSLOT + (size_t)q * NSLOT + s];   // block `it` = [sig | a | b | c | rmax | step] x NSLOT (PcgScal), per bank
                 v = q == 4 ? (x > v ? x : v) : v + x;
             }
             out[(size_t)q * n + it] = v;

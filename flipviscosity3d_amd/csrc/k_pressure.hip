@@ -251,7 +251,7 @@ int fv_scal_reserve(flipv_context *c, int cap) {
 
 // the fill jobs that zero the slot blocks of every bank (and, unless keepExtra, the 16 extra doubles behind bank 0's)
 static int scal_clear_jobs(flipv_context *c, int cap, bool keepExtra, FillJob *z) {
-    const size_t slots = (size_t)5 * (cap + 2) * NSLOT, stride = fv_scal_stride(cap);
+    const size_t slots = (size_t)FV_NSC * (cap + 2) * NSLOT, stride = fv_scal_stride(cap);
     if (keepExtra) {
         z[0] = {c->d_scal, slots * sizeof(double), 0};
         z[1] = {c->d_scal + stride, (FV_SCAL_BANKS - 1) * stride * sizeof(double), 0};
@@ -306,7 +306,8 @@ static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **ext
     sc->stall_below = 0.0;
     sc->stalled = c->d_flags + 11;
     sc->bestIt = c->d_flags + 14;
-    *extra = c->d_scal + 5 * n;
+    sc->vel_tol = 0.0; sc->vel_window = 0;   // (the velocity criterion: set by the viscosity solve for its last loop)
+    *extra = c->d_scal + FV_NSC * n;
 }
 
 static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc, const float *d0, const float *d1, const float *d2,

@@ -636,7 +636,7 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_xr, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, x, r, p, q, x0, sc, devIt ? IT_DEVICE : it));
             mg_vcycle(c, s, sc, devIt ? IT_DEVICE : it + 1);
             if (s->rc) return s->rc;
-            if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return rc;   // max|r| of this iteration, (r,z) of the next
+            if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 3 * NSLOT))) return rc;   // max|r| of this iteration, (the unused step slot,) (r,z) of the next
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, devIt ? IT_DEVICE : it));
         }
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -302,7 +302,8 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
                              float *__restrict__ vmW, float *__restrict__ vrU, float *__restrict__ vrV, float *__restrict__ vrW,
                              uint8_t *__restrict__ rowmask, const uint8_t *__restrict__ band,
                              int full, PcgSys<T, 3> v, double *__restrict__ bmax, int *__restrict__ nrows, int refdiag,
-                             int brick, Lay LB, uint8_t *__restrict__ maskB, float *__restrict__ bU, float *__restrict__ bV, float *__restrict__ bW) {
+                             int brick, Lay LB, uint8_t *__restrict__ maskB, float *__restrict__ bU, float *__restrict__ bV, float *__restrict__ bW,
+                             const float *__restrict__ phi) {
     // v.swz: diag, vm, r, x in the swizzled plane layout.  brick: the factor arrays are read, and EVERY output but `rowmask` (which
     // stays plain: it is this kernel's memory of where rows were) is written, in the brick layout; maskB = the brick-layout copy of the
     // row mask.  bU/bV/bW (optional) = a copy of the right-hand side in the layout of s (residual replacement recomputes r = b - A x)
@@ -400,7 +401,16 @@ __global__ void k_visc_setup(Lay L, const float *__restrict__ U, const float *__
         }
     store:
         {
-            const uint8_t now = (uint8_t)((dg[0] != 0.0f) | ((dg[1] != 0.0f) << 1) | ((dg[2] != 0.0f) << 2));
+            // bits 0-2: component m has a row here; bits 3-5: ... and that row's velocity is one the substep USES -- its face borders a liquid cell (phi < 0), which is what
+            // makes a face valid after the projection (fluidsimulation.cpp:598-688); every other row's value is overwritten by the extrapolation.  The velocity criterion
+            // of the solve watches these rows only (PcgScal::step): the others include massless specks whose near-null modes CG moves by O(max|u|) for ever.
+            uint8_t now = (uint8_t)((dg[0] != 0.0f) | ((dg[1] != 0.0f) << 1) | ((dg[2] != 0.0f) << 2));
+            if (now) {
+                const bool l0 = phi[c] < 0.0f;
+                if ((now & 1) && (l0 || phi[c - 1] < 0.0f)) now |= 8;
+                if ((now & 2) && (l0 || phi[c - sy] < 0.0f)) now |= 16;
+                if ((now & 4) && (l0 || phi[c - sz] < 0.0f)) now |= 32;
+            }
             if (now || prev || full) {  // off-row values (diag 0, volume -1, x = s = 0) persist between solves where nothing was a row
                 const size_t cs = brick ? cf : (v.swz ? sidx(L, i, j, k) : c);   // own-index arrays
                 const size_t cp = brick ? cf : c;                                  // s (and b), read with their halo
@@ -798,12 +808,9 @@ static int fv_plane_refine(flipv_context *c, const Lay &R, const PcgScal &sc, si
     return fv_allreduce_scalars(c, sc.rmax(0), NSLOT);
 }
 
-template <typename T>
-static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info) {
-    const Lay &L = c->L;
-    flipv_solve_info li;
-    memset(&li, 0, sizeof(li));
-    c->commBytesSetup = c->commBytesIter = 0.0;
+// What every rank of a communicator must decide alike from (the preconditioner, the stiffness rule, the vector type of an FP64 solve): the viscosity field's
+// facts over ALL ranks, one small all-gather at the start of every solve -- before anything that chooses a sequence of collectives.
+static int visc_gather_field_facts(flipv_context *c) {
     if (c->comm && c->comm->nranks > 1) {   // a rank whose box holds no viscous node must still take part in every collective of the solve
         const double mine[3] = {c->viscosity_nonzero ? 1.0 : 0.0, (double)c->viscosity_max, (double)c->viscosity_min};   // (AUTO's stiffness rule must come out the same on every rank)
         double all[3 * NSLOT];
@@ -820,6 +827,15 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         c->vPerRowFactors = c->viscosity_min != c->viscosity_max ? 1 : 0;
         c->vZeroRegion = (c->viscosity_min == 0.0f && c->viscosity_max > 0.0f) ? 1 : 0;
     }
+    return FLIPV_OK;
+}
+
+template <typename T>
+static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info) {
+    const Lay &L = c->L;
+    flipv_solve_info li;
+    memset(&li, 0, sizeof(li));
+    c->commBytesSetup = c->commBytesIter = 0.0;
     // (vPerRowFactors: a VARIABLE viscosity field -- the fp64 residual of the two-stage solve then forms the reference's rows with their own factors,
     // visc_rows.h: d_ref_row_factors; k_bresidual on bricks, k_plane_residual_ref on the plane layouts)
     if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
@@ -928,7 +944,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         hipLaunchKernelGGL(k_visc_setup<T>, GRID3(RS), 0, c->stream, RS, c->U, c->V, c->W, c->stU, c->stV, c->stW, c->volU, c->volV,
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                            c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, (refDiag ? 1 : 0) | (predict ? 2 : 0),
-                           brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2]);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
+                           brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2], c->phi);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
         HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));   // max|rhs|, max|u| over the rows
         HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));  // h_flags[2] = row count
@@ -949,16 +965,18 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // (the layout: a rank that took planes where another took bricks would run a different sequence of collectives; and "no rows anywhere").
     double fill = fillLocal, rowsAll = (double)c->h_flags[2];
     if (c->comm) {
-        const double mine[3] = {c->h_scal[0], (double)c->h_flags[2], ownVol};
-        double all[3 * NSLOT];
-        if ((rc = fv_allgather_f64(c, mine, 3, all))) return rc;
-        double bn = 0.0, rows = 0.0, vol = 0.0;
-        for (int r = 0; r < c->comm->nranks; r++) { bn = fmax(bn, all[3 * r]); rows += all[3 * r + 1]; vol += all[3 * r + 2]; }
+        const double mine[4] = {c->h_scal[0], (double)c->h_flags[2], ownVol, c->h_scal[1]};
+        double all[4 * NSLOT];
+        if ((rc = fv_allgather_f64(c, mine, 4, all))) return rc;
+        double bn = 0.0, rows = 0.0, vol = 0.0, um = 0.0;
+        for (int r = 0; r < c->comm->nranks; r++) { bn = fmax(bn, all[4 * r]); rows += all[4 * r + 1]; vol += all[4 * r + 2]; um = fmax(um, all[4 * r + 3]); }
         c->h_scal[0] = bn;
+        c->h_scal[1] = um;
         rowsAll = rows;
         fill = rows / (3.0 * vol);
     }
     const double bnormAll = c->h_scal[0];
+    const double umaxAll = c->h_scal[1];   // max|u| over the rows, all ranks: the scale of the velocity criterion (PcgScal::vel_tol)
     c->vRowsAll = rowsAll;
     c->vwV = 4;
     if (c->prm.viscosity_lane_width == 2 || c->prm.viscosity_lane_width == 4) c->vwV = c->prm.viscosity_lane_width;  // measurement switch: forced lane width
@@ -994,6 +1012,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     bool success = false, stalled = false, ranMg = false;
     const bool defectLimited = false;
     double defectRes = 0.0, mainRes = 0.0;   // max|b - A_ref x| after the defect-correction stage; the exact-operator loop's own final residual
+    double velStep = 0.0;
     int anyActive = c->nActiveV;
     // residual replacement (k_viscosity_brick.hip): fp32 vectors in the brick layout
     int replacePeriod = 0;
@@ -1097,7 +1116,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const double f2 = c->vMixed64 ? 1e-2 : (c->prm.viscosity_stage2_factor > 0.0f ? (double)c->prm.viscosity_stage2_factor : (stiffNow > 2.0e4 ? 1e-3 : (early ? 1e-2 : 2e-2)));
         const double tolMain = !early ? tolFinal : (f1user > 0.0 ? f1user : (stiffNow > 1000.0 ? 3000.0 : 300.0)) * tolFinal;
         if (tolMain > tolFinal && c->prm.viscosity_mg_coarsest_sweeps <= 0) c->vmgSweeps = 8;   // (the rule above is for one loop to the final tolerance)
-        const size_t scalBytes = (size_t)5 * (cap + 2) * NSLOT * sizeof(double);
+        const size_t scalBytes = (size_t)FV_NSC * (cap + 2) * NSLOT * sizeof(double);
         // recompute r = b - A_outer (xacc + x) in fp64 (x flushed into xacc), fetch max|r|, hand the loop a fresh set of scalars
         auto recompute_residual = [&](int flushMode) -> int {   // flushMode 1: x is kept beside the accumulator until the caller has looked at the residual (fv_brick_flush_settle)
             { const int rcr = brick ? fv_brick_refine<T>(c, sc, scalBytes, !refDiag, flushMode) : fv_plane_refine<T>(c, R0, sc, scalBytes, !refDiag, flushMode); if (rcr) return rcr; }   // (several ranks: with the accumulator's halo copy and the all-reduce of max|r|)
@@ -1131,6 +1150,15 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                                                                 : fmax(stageFloor, f2 * fmax(resStart - ((corrections == 1 && tolMain > tolFinal) ? tolMain : 0.0), 0.0))) : tolMain;
         if (correction) lastTarget = sc.tol;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
         sc.stall_below = refinements > 0 ? fmin(100.0 * sc.tol, 0.05 * resStart) : 0.0;
+        // THE VELOCITY CRITERION of the solve's last loop (flipv_params.viscosity_velocity_tolerance; pcg_common.h: PcgScal::vel_tol): the loop that delivers the
+        // result -- the last correction stage, its restart, or the one loop of a solve without stages -- is converged when max|r| passes its target AND its last
+        // `viscosity_velocity_window` iterations together moved no velocity by more than that share of max|u|.  Stages in between stop on the residual alone.
+        {
+            const bool lastLoop = !innerDiffers || (correction && (corrections >= rounds || extraStage));
+            const double eta = c->prm.viscosity_velocity_tolerance > 0.0f ? (double)c->prm.viscosity_velocity_tolerance : (c->prm.viscosity_velocity_tolerance < 0.0f ? 0.0 : 3.0e-5);
+            sc.vel_tol = (lastLoop && !c->vMixed64) ? eta * umaxAll : 0.0;
+            sc.vel_window = c->prm.viscosity_velocity_window > 0 ? c->prm.viscosity_velocity_window : 4;
+        }
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
         // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the
         // mildly stiff twobody20 fixture leaves 3-5 faces of tiny liquid clusters 30 % off at a converged max|r|: their near-rigid modes
@@ -1165,10 +1193,12 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if ((rc = pcg_run(c, sc, capNow, sh, 3, c->nIntV, c->nActiveV, spmv, update, &conv, FV_GE_VISCOSITY))) return rc;
         }
         const int last = conv >= 0 ? conv : capNow - 1;
-        hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
-        HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax, 1);
+        HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         res = c->h_scal[0];
+        if (sc.vel_tol > 0.0) velStep = umaxAll > 0.0 ? c->h_scal[1] / umaxAll : 0.0;   // (the delivering loop's: flipv_solve_info.velocity_step)
+        const bool velUnmet = sc.vel_tol > 0.0 && c->h_scal[1] > sc.vel_tol;   // the loop ended (stalled, out of budget) while its last iterations were still moving velocities
         const int itersNow = conv >= 0 ? conv + 1 : capNow;
         success = conv >= 0;
         stalled = false;
@@ -1184,7 +1214,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             for (int it = 0; it < itersNow && it < capNow; it++) {
                 double m = 0.0;
                 for (int bk = 0; bk < sc.nbank; bk++)
-                    for (int q = 0; q < NSLOT; q++) m = fmax(m, c->h_scal[(size_t)bk * stride + (size_t)it * 5 * NSLOT + 4 * NSLOT + q]);
+                    for (int q = 0; q < NSLOT; q++) m = fmax(m, c->h_scal[(size_t)bk * stride + (size_t)it * FV_NSC * NSLOT + 4 * NSLOT + q]);
                 fprintf(stderr, " %d:%.2e", it, m / bnorm);
             }
             fprintf(stderr, "\n");
@@ -1194,8 +1224,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                 double sg = 0.0, pq = 0.0;
                 for (int bk = 0; bk < sc.nbank; bk++)
                     for (int q = 0; q < NSLOT; q++) {
-                        sg += c->h_scal[(size_t)bk * stride + (size_t)it * 5 * NSLOT + q];
-                        pq += c->h_scal[(size_t)bk * stride + (size_t)it * 5 * NSLOT + NSLOT + q];
+                        sg += c->h_scal[(size_t)bk * stride + (size_t)it * FV_NSC * NSLOT + q];
+                        pq += c->h_scal[(size_t)bk * stride + (size_t)it * FV_NSC * NSLOT + NSLOT + q];
                     }
                 fprintf(stderr, " %d:%.3e", it, pq != 0.0 ? sg * sg / pq : 0.0);
             }
@@ -1228,7 +1258,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         }
         stalled = false;
         success = false;
-        if (res <= tolFinal) { success = true; if (innerDiffers) { defectRes = res; if (corrections >= 1) res = mainRes; } break; }
+        // (a loop the stall guard stopped while the velocity criterion was unmet -- CG's residual jumps when it finally resolves a light, nearly detached part -- is restarted
+        // from the fp64 residual even where that residual already passes: the criterion is what the loop was still running for)
+        const bool restartForVelocity = !innerDiffers && velUnmet && !wasConverged && refinements < 8 && itersDone < cap;
+        if (res <= tolFinal && !restartForVelocity) { success = true; if (innerDiffers) { defectRes = res; if (corrections >= 1) res = mainRes; } break; }
         if (innerDiffers && wasConverged) {
             // The defect E x the exact-operator loop left behind: ONE bounded correction stage, accepted as it comes -- a first-order
             // correction.  |A^-1 E| is ~1e-3 at 256^3 / nu = 5: what is left is 2 % of the first order plus the second, and the velocities
@@ -1259,6 +1292,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     li.comm_bytes_setup = c->commBytesSetup; li.comm_bytes_per_iteration = c->commBytesIter;
     li.correction_iterations = corrIters;
     li.correction_status = corrStatus;
+    li.velocity_step = velStep;
     if (c->prm.verbose && nontrivial)
         fprintf(stderr, "viscosity solve %ld: %s, %s layout, %d iterations, residual %.3g (rhs %.3g), %s\n", c->viscSolves, ranMg ? "multigrid" : "diagonal",
                 brick ? "brick" : (c->vSwz ? "swizzled" : "plain"), iters, res, bnorm, success ? "converged" : (stalled ? "stalled" : "cap"));
@@ -1339,6 +1373,7 @@ void fv_visc_sweep_f32(flipv_context *c, float *const in[3], float *const out[3]
 
 int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) {
     c->vMixed64 = 0;
+    { const int rcf = visc_gather_field_facts(c); if (rcf) return rcf; }
     if (c->prm.precision == FLIPV_PRECISION_FP64) {
         // flipv_params.precision = FP64 = the reference's own vector type (pcgsolver.h:241-295 with T = double).  Under the diagonal preconditioner the PCG's
         // vectors ARE fp64 (viscosity_solve_t<double>).  Under the multigrid (whose V-cycle is fp32) the fp64 answer is reached by MIXED-PRECISION ITERATIVE
@@ -1346,7 +1381,7 @@ int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) {
         // loops between them run in fp32 -- here repeated (up to 8 correction stages, each to 1 % of what is left) until the FP64 residual meets
         // viscosity_tolerance x max|rhs|, the reference's own criterion; status 1 if it does not inside the iteration cap.  (Until round 4 fp64 vectors
         // took the diagonal whatever was asked for: at 256^3 that is an iterate stopped at the cap.)
-        const double stiff = (double)c->viscosity_max * (double)dt / ((double)c->dx * (double)c->dx);
+        const double stiff = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);   // (over all ranks: a rank whose own box is inviscid must take the same path)
         const bool wantsMg = c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && stiff > 64.0);
         if (!wantsMg || c->prm.viscosity_lane_width == 2) return viscosity_solve_t<double>(c, dt, info);
         c->vMixed64 = 1;

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bri
     if (!d_update_scalars(sc, it_arg, lds, it, alpha_d, beta_d)) return;
     const T alpha = (T)alpha_d;
     double acc = 0.0;
-    float mxf = 0.0f;
+    float mxf = 0.0f, mxs = 0.0f;   // max|r|, max|alpha s| (PcgScal::step)
     double mxd = 0.0;
     while (w.valid()) {
         const size_t a = w.a;
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bri
                 const double rn = (double)rn_t;
                 const double zn = sizeof(RT<T>) == 4 ? (double)((float)rn_t / d) : rn / (double)d;
                 D.x[c].v[e] = D.x[c].v[e] + alpha * D.s[c].v[e];
+                if ((m >> (8 * e + 3 + c)) & 1u) mxs = fmaxf(mxs, fabsf((float)(alpha * D.s[c].v[e])));   // (rows whose velocity the substep uses: k_visc_setup)
                 D.r[c].v[e] = rn_t;
                 D.s[c].v[e] = (T)(zn + beta_d * (double)D.s[c].v[e]);
                 if (sizeof(RT<T>) == 4) mxf = fmaxf(mxf, fabsf((float)rn_t)); else mxd = fmax(mxd, fabs(rn));
@@ -259,21 +260,23 @@ __global__ __launch_bounds__(256) void k_bpcg_update(const int *__restrict__ bri
             stv(v.s[c] + a, D.s[c]);
         }
     }
-    __shared__ double red[8];
-    double tot = wave_sum(acc), bm = wave_max(fmax((double)mxf, mxd));
+    __shared__ double red[12];
+    double tot = wave_sum(acc), bm = wave_max(fmax((double)mxf, mxd)), bs = wave_max((double)mxs);
     {
         const int tid = d_tid256();
-        if ((tid & 63) == 0) { red[tid >> 6] = tot; red[4 + (tid >> 6)] = bm; }
+        if ((tid & 63) == 0) { red[tid >> 6] = tot; red[4 + (tid >> 6)] = bm; red[8 + (tid >> 6)] = bs; }
         __syncthreads();
         if (tid == 0) {
             tot = red[0] + red[1] + red[2] + red[3];
             bm = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+            bs = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
         }
     }
     if (threadIdx.x == 0 && threadIdx.y == 0) {
         const int sl = sc.my_slot();
         if (tot != 0.0) atomicAdd(sc.sig(it + 1) + sl, tot);
         if (bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sl, bm);
+        if (bs > 0.0) atomic_max_nonneg(sc.step(it) + sl, bs);
         if (it_arg < 0 && blockIdx.x == 0) *sc.itA = it + 1;
     }
 }

@@ -926,16 +926,20 @@ __global__ __launch_bounds__(1024) void k_vmg_coarsest(const VLevelDev *__restri
 }
 
 // ---- what the x / r kernels of either layout publish and the p kernels test: max|r| into rmax(it)
-__device__ __forceinline__ void d_vmg_publish_max(const PcgScal &sc, int it, float mx, double *lds) {
+__device__ __forceinline__ void d_vmg_publish_max(const PcgScal &sc, int it, float mx, float mxs, double *lds) {   // mxs: max|alpha p| (PcgScal::step)
     if (it < 0) return;
     const double bm = block_max_256((double)mx, lds);
-    if (threadIdx.x == 0 && threadIdx.y == 0 && bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sc.my_slot(), bm);
+    const double bs = block_max_256((double)mxs, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        if (bm > 0.0) atomic_max_nonneg(sc.rmax(it) + sc.my_slot(), bm);
+        if (bs > 0.0) atomic_max_nonneg(sc.step(it) + sc.my_slot(), bs);
+    }
 }
 // stop test and stall guard of iteration it >= 0; true: the launch returns (every thread of the block calls this)
 __device__ __forceinline__ bool d_vmg_stop_test(const PcgScal &sc, int it, double *lds) {
     const double res = d_fold_max(sc, sc.rmax(it), lds);
     const bool first = blockIdx.x == 0 && threadIdx.x == 0 && threadIdx.y == 0;
-    if (d_pass(sc, res)) {
+    if (d_pass(sc, res) && d_steps_small(sc, it, lds)) {   // (with the velocity criterion where the loop carries one: PcgScal::vel_tol)
         if (first) *sc.conv = it;
         return true;
     }
@@ -1004,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks
         alpha_d = f[1] != 0.0 ? f[0] / f[1] : 0.0;
     }
     const float alpha = (float)alpha_d;
-    float mx = 0.0f;
+    float mx = 0.0f, mxs = 0.0f;
     while (w.valid()) {
         const size_t a = w.a;
         const unsigned m = w.m;
@@ -1030,6 +1034,7 @@ __global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks
                 const bool row = BrickWalkV::row(m, c, e) && dd[c].v[e] != 0.0f;
                 if (it >= 0 && row) {
                     xx[c].v[e] += alpha * pp[c].v[e];
+                    if ((m >> (8 * e + 3 + c)) & 1u) mxs = fmaxf(mxs, fabsf(alpha * pp[c].v[e]));   // (rows whose velocity the substep uses: k_visc_setup)
                     rr[c].v[e] = (float)((double)rr[c].v[e] - alpha_d * (double)qq[c].v[e]);
                     mx = fmaxf(mx, fabsf(rr[c].v[e]));
                 }
@@ -1039,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_bvpcg_xr(const int *__restrict__ bricks
             stv(z.p[c] + a, zz);
         }
     }
-    d_vmg_publish_max(sc, it, mx, lds);
+    d_vmg_publish_max(sc, it, mx, mxs, lds);
 }
 // z += P xc on the rows (the coarse correction of level 1)
 __global__ __launch_bounds__(256) void k_bvmg_prolong_fine(const int *__restrict__ bricks, int nb, Lay LB, Lay C, const uint8_t *__restrict__ mask, Vec3p z, Vec3p xc,
@@ -1710,7 +1715,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         if (replace) fv_brick_replace<float>(c, sc, it == IT_DEVICE ? -1 : it, replace_period, 0, s->za, s->w[0]);
         vmg_vcycle(c, s, sc, it, 1);
         if (s->rc) return s->rc;
-        if (c->comm && (r2 = fv_allreduce_scalars(c, sc.rmax(it), 2 * NSLOT))) return r2;             // max|r| of this iteration, (r, z) of the next
+        if (c->comm && (r2 = fv_allreduce_scalars(c, sc.rmax(it), 3 * NSLOT))) return r2;             // max|r| and max|alpha p| of this iteration, (r, z) of the next
         PP(it);
         return FLIPV_OK;
     };

@@ -186,3 +186,35 @@ def test_variable_viscosity_blocks_run_the_single_domains_solve(dims):
     for c in ctxs:
         c.close()
     ref.close()
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_ranks_decide_alike_when_one_box_is_inviscid(precision):
+    """with precision = FP64 the solve chose its vector type (fp64 diagonal PCG | fp32 multigrid under mixed-precision refinement) from the
+    RANK's own largest viscosity -- under a variable field one rank's box can be inviscid while the other's is stiff, and the two ran different sequences
+    of collectives (a hang under RCCL, a timeout in the in-process backend).  The decision now comes from the all-gathered field facts.  1 x 1 x 2 slabs of
+    the 32^3 bunny with nu = 0 on every node of the lower slab's box (halo included) and 300 above: both ranks report the same solve, AUTO picks the
+    multigrid on both (nu dt/dx^2 = 3 072 somewhere), the result equals the single domain's."""
+    from flipviscosity3d_amd import capi
+    N = 32
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    nu = np.zeros((N + 1, N + 1, N + 1), np.float32)
+    nu[N // 2 + 9:, :, :] = 300.0          # k-nodes beyond the lower slab's owned box + its 8-entry halo
+    prm = dict(precision=precision)
+    ref = capi.Context(N, N, N, dx)
+    ref.set_solid_sdf(solid); ref.set_viscosity(nu); ref.set_params(**prm); ref.particles = P
+    ctxs = make_blocks(N, dx, solid, P, nu, (1, 1, 2), prm)
+    sr = ref.substep(0.01)
+    sts = run_ranks(ctxs, lambda r, c: c.substep(0.01))
+    assert_same_solve_on_every_rank(sts)
+    v, vr = sts[0]["viscosity"], sr["viscosity"]
+    print("precision %d: blocks %d iterations / preconditioner %d / status %d, single domain %d / %d / %d" % (
+        precision, v["iterations"], v["preconditioner"], v["status"], vr["iterations"], vr["preconditioner"], vr["status"]))
+    assert v["preconditioner"] == vr["preconditioner"] == 1
+    got = [assemble(ctxs, n) for n in "UVW"]
+    err = rel_maxnorm3(got, [ref.grid(n) for n in "UVW"])
+    print("   velocity difference to the single domain %.2e" % err)
+    assert err <= 5e-5, err
+    for c in ctxs:
+        c.close()
+    ref.close()
