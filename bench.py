@@ -437,28 +437,31 @@ def main():
     # reference's own tolerance, viscosity_stage1_factor = 1 (what a user sets who does not want the early stop); not part of `value`
     strict = None
     if world == 1 and not args.no_strict and not args.exact_operator and args.precision == 0 and args.viscosity > 0:
-        c2 = Context(GI, GJ, GK, dx, device=local_rank)
-        c2.set_solid_sdf(solid)
-        c2.set_viscosity(args.viscosity)
-        c2.set_gravity(0.0, -9.81, 0.0)
-        c2.set_params(viscosity_max_iterations=args.viscosity_cap, viscosity_stage1_factor=1.0)
-        if args.viscosity_preconditioner != "auto":
-            c2.set_params(viscosity_preconditioner=capi.PRECOND_MULTIGRID if args.viscosity_preconditioner == "multigrid" else capi.PRECOND_DIAGONAL)
-        c2.particles = particles
-        for _ in range(args.warmup):
-            c2.substep(min(c2.cfl(), 0.01))
-        c2.synchronize()
-        ts = time.perf_counter()
-        st2 = [c2.substep(min(c2.cfl(), 0.01)) for _ in range(args.steps)]
-        c2.synchronize()
-        el2 = time.perf_counter() - ts
-        c2.close()
-        strict = {"value": float(GI) * GJ * GK / 1e6 / (el2 / args.steps), "unit": "MCells/s", "ms_per_step": el2 * 1e3 / args.steps,
-                  "viscosity_stage1_factor": 1.0,
-                  "all_timed_solves_converged": all(st["viscosity"]["status"] in (0, 3) for st in st2),
-                  "mean_viscosity_iterations": float(np.mean([st["viscosity"]["iterations"] for st in st2])),
-                  "loop_residual_rel_max": float(max((st["viscosity"]["residual"] / st["viscosity"]["rhs_norm"]) if st["viscosity"]["rhs_norm"] > 0 else 0.0 for st in st2)),
-                  "note": "stage 1 of the two-stage solve to viscosity_tolerance (1e-6 max|rhs|) itself; same scene, warm-up and step counts as `value`"}
+      try:   # (a second full context beside the first: an out-of-memory or solver error of this untimed re-run must not discard the measured headline)
+          c2 = Context(GI, GJ, GK, dx, device=local_rank)
+          c2.set_solid_sdf(solid)
+          c2.set_viscosity(args.viscosity)
+          c2.set_gravity(0.0, -9.81, 0.0)
+          c2.set_params(viscosity_max_iterations=args.viscosity_cap, viscosity_stage1_factor=1.0)
+          if args.viscosity_preconditioner != "auto":
+              c2.set_params(viscosity_preconditioner=capi.PRECOND_MULTIGRID if args.viscosity_preconditioner == "multigrid" else capi.PRECOND_DIAGONAL)
+          c2.particles = particles
+          for _ in range(args.warmup):
+              c2.substep(min(c2.cfl(), 0.01))
+          c2.synchronize()
+          ts = time.perf_counter()
+          st2 = [c2.substep(min(c2.cfl(), 0.01)) for _ in range(args.steps)]
+          c2.synchronize()
+          el2 = time.perf_counter() - ts
+          c2.close()
+          strict = {"value": float(GI) * GJ * GK / 1e6 / (el2 / args.steps), "unit": "MCells/s", "ms_per_step": el2 * 1e3 / args.steps,
+                    "viscosity_stage1_factor": 1.0,
+                    "all_timed_solves_stage_complete": all(st["viscosity"]["status"] in (0, 3) for st in st2),
+                    "mean_viscosity_iterations": float(np.mean([st["viscosity"]["iterations"] for st in st2])),
+                    "loop_residual_rel_max": float(max((st["viscosity"]["residual"] / st["viscosity"]["rhs_norm"]) if st["viscosity"]["rhs_norm"] > 0 else 0.0 for st in st2)),
+                    "note": "stage 1 of the two-stage solve to viscosity_tolerance (1e-6 max|rhs|) itself; same scene, warm-up and step counts as `value`"}
+      except Exception as e:   # noqa: BLE001
+        strict = {"error": "%s: %s" % (type(e).__name__, e)}
 
     def its(key):
         v = [st[key]["iterations"] for st in stats]
@@ -546,12 +549,16 @@ def main():
             # tests/test_gpu_baseline_sizes.py pins its velocities to 1e-4 of the reference run to convergence at 128^3 and 256^3); otherwise this object
             # says how many did not
             "mode_b": {"value": value if all(st["viscosity"]["status"] in (0, 3) for st in stats) else None,
-                       "unit": "MCells/s", "all_timed_solves_converged": all(st["viscosity"]["status"] in (0, 3) for st in stats),
-                       "unconverged_solves": int(sum(st["viscosity"]["status"] not in (0, 3) for st in stats)),
+                       "unit": "MCells/s", "all_timed_solves_stage_complete": all(st["viscosity"]["status"] in (0, 3) for st in stats),
+                       "incomplete_solves": int(sum(st["viscosity"]["status"] not in (0, 3) for st in stats)),
+                       "timed_solves_within_reference_residual": int(sum((st["viscosity"].get("defect_residual", 0.0) or st["viscosity"]["residual"]) <= 1.0000001e-6 * st["viscosity"]["rhs_norm"] for st in stats)),
                        "mean_viscosity_iterations": float(np.mean([st["viscosity"]["iterations"] for st in stats])),
-                       "note": "same run as `value`: 'converged' = status 0 = every stage of the two-stage solve reached its target inside the reference's cap of 700 "
-                               "(stage 1: 3e-3 max|rhs| on the exact operator at this stiffness; the correction stage: 1 % of the fp64 defect -- 0.1 % beyond nu dt/dx^2 = 2e4); what that delivers: viscosity_final_residual_rel "
-                               "and the parity tests"},
+                       "note": "same run as `value`.  'stage complete' = status 0 = every stage of the default viscosity solve (include/flipv.h: THE DEFAULT VISCOSITY SOLVE) reached its "
+                               "target inside the reference's cap of 700 -- NOT 'max|b - A_ref x| <= 1e-6 max|rhs|', the reference's own stop test: the stages' targets are shares of "
+                               "min(max|rhs|, 100 max|u|) and the delivering loop carries a velocity criterion, which is tighter than the reference's test once the liquid touches a wall and "
+                               "looser on the sliver rows of a stiff start (timed_solves_within_reference_residual counts the solves whose fp64 residual on the reference's operator passes "
+                               "that test too; viscosity_final_residual_rel has the values; mode_b_strict runs stage 1 to 1e-6 max|rhs|).  What the default delivers in the velocities is "
+                               "pinned by the parity tests: <= 1e-4 of the reference run to convergence from rest AND in late states (tests/test_gpu_late_states.py)"},
             "mode_b_strict": strict,
             "viscosity": {k: last["viscosity"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},
             "pressure": {k: last["pressure"][k] for k in ("iterations", "residual", "rhs_norm", "status", "rows", "active_tiles", "total_tiles")},

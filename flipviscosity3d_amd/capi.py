@@ -22,7 +22,8 @@ VOLUME_IDS = dict(center=0, U=1, V=2, W=3, edgeU=4, edgeV=5, edgeW=6)
 SYMBOLS = [
     "flipv_create", "flipv_create_on_device", "flipv_create_slab", "flipv_slab_range", "flipv_create_block", "flipv_block_range", "flipv_create_setup",
     "flipv_destroy", "flipv_last_error", "flipv_device_name",
-    "flipv_default_params", "flipv_set_params", "flipv_get_params", "flipv_set_gravity",
+    "flipv_abi_version", "flipv_default_params", "flipv_set_params", "flipv_get_params", "flipv_default_debug_params", "flipv_set_debug_params",
+    "flipv_get_debug_params", "flipv_set_gravity",
     "flipv_set_solid_sdf", "flipv_set_viscosity_uniform", "flipv_set_viscosity",
     "flipv_upload_particles", "flipv_download_particles", "flipv_num_particles",
     "flipv_grid_elements", "flipv_read_grid", "flipv_write_grid", "flipv_grid_box", "flipv_read_grid_box", "flipv_write_grid_box", "flipv_read_grid_region",
@@ -43,25 +44,47 @@ class FlipvError(RuntimeError):
 
 
 class Params(C.Structure):
+    """flipv_params (include/flipv.h, FLIPV_VERSION 5)"""
     _fields_ = [("cfl_number", C.c_float), ("min_frac", C.c_float), ("pic_ratio", C.c_float),
                 ("extrapolation_layers", C.c_int), ("pressure_tolerance", C.c_double),
                 ("pressure_rel_tolerance", C.c_double), ("pressure_max_iterations", C.c_int),
                 ("viscosity_tolerance", C.c_double), ("viscosity_max_iterations", C.c_int),
-                ("viscosity_accept_tolerance", C.c_double), ("precision", C.c_int),
-                ("kernel_timing", C.c_int), ("check_every", C.c_int),
+                ("viscosity_accept_tolerance", C.c_double), ("precision", C.c_int), ("check_every", C.c_int),
                 ("pressure_preconditioner", C.c_int), ("viscosity_preconditioner", C.c_int),
-                ("exact_viscosity_operator", C.c_int), ("residual_replacement", C.c_int), ("viscosity_layout", C.c_int), ("tile_rows", C.c_int),
-                ("viscosity_mg_coarsest_sweeps", C.c_int), ("viscosity_mg_min_dim", C.c_int), ("pressure_mg_coarsest_sweeps", C.c_int),
-                ("pressure_mg_omega", C.c_float), ("pressure_mg_overcorrection", C.c_float),
-                ("no_liquid_box", C.c_int), ("no_comm_overlap", C.c_int), ("verbose", C.c_int),
-                ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
-                ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int),
-                ("viscosity_update_grid_cap", C.c_int), ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int),
-                ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
-                ("multigrid_rank_local", C.c_int), ("multigrid_distributed_levels", C.c_int),
+                ("exact_viscosity_operator", C.c_int), ("viscosity_layout", C.c_int),
+                ("multigrid_rank_local", C.c_int), ("multigrid_distributed_levels", C.c_int), ("verbose", C.c_int),
                 ("viscosity_stage1_factor", C.c_float), ("viscosity_stage2_factor", C.c_float), ("viscosity_stage2_max_iterations", C.c_int),
                 ("viscosity_stage2_rounds", C.c_int), ("viscosity_two_stage_max_stiffness", C.c_float),
-                ("viscosity_defect_predictor", C.c_int), ("viscosity_velocity_tolerance", C.c_float), ("viscosity_velocity_window", C.c_int)]
+                ("viscosity_defect_predictor", C.c_int), ("viscosity_velocity_tolerance", C.c_float), ("viscosity_velocity_window", C.c_int),
+                ("viscosity_mass_scale", C.c_float)]
+
+
+class DebugParams(C.Structure):
+    """flipv_debug_params: A/B, profiling and test switches"""
+    _fields_ = [("kernel_timing", C.c_int), ("tile_rows", C.c_int), ("viscosity_mg_coarsest_sweeps", C.c_int), ("viscosity_mg_min_dim", C.c_int),
+                ("pressure_mg_coarsest_sweeps", C.c_int), ("pressure_mg_omega", C.c_float), ("pressure_mg_overcorrection", C.c_float),
+                ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
+                ("no_liquid_box", C.c_int), ("no_comm_overlap", C.c_int), ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
+                ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int), ("viscosity_update_grid_cap", C.c_int),
+                ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int)]
+
+
+_PRODUCT_FIELDS = {f for f, _ in Params._fields_}
+_DEBUG_FIELDS = {f for f, _ in DebugParams._fields_}
+
+
+class AllParams:
+    """both structs behind one attribute namespace (what Context.get_params returns)"""
+    def __init__(self, p, d):
+        self.product, self.debug = p, d
+
+    def __getattr__(self, k):
+        if k in _PRODUCT_FIELDS:
+            return getattr(self.product, k)
+        if k in _DEBUG_FIELDS:
+            return getattr(self.debug, k)
+        raise AttributeError(k)
+
 
 LAYOUT_AUTO, LAYOUT_PLAIN, LAYOUT_SWIZZLED, LAYOUT_BRICK = 0, 1, 2, 3
 PRECOND_AUTO, PRECOND_DIAGONAL, PRECOND_MULTIGRID = 0, 1, 2
@@ -134,6 +157,10 @@ def load():
     L.flipv_default_params.argtypes = [C.POINTER(Params)]
     L.flipv_set_params.argtypes = [ctx, C.POINTER(Params)]
     L.flipv_get_params.argtypes = [ctx, C.POINTER(Params)]
+    L.flipv_set_debug_params.argtypes = [ctx, C.POINTER(DebugParams)]
+    L.flipv_get_debug_params.argtypes = [ctx, C.POINTER(DebugParams)]
+    L.flipv_default_debug_params.argtypes = [C.POINTER(DebugParams)]
+    L.flipv_abi_version.restype = C.c_int
     L.flipv_set_gravity.argtypes = [ctx, C.c_float, C.c_float, C.c_float]
     L.flipv_set_solid_sdf.argtypes = [ctx, fp]
     L.flipv_set_viscosity_uniform.argtypes = [ctx, C.c_float]
@@ -294,17 +321,26 @@ class Context:
         return buf.value.decode()
 
     def get_params(self):
-        p = Params()
+        p, d = Params(), DebugParams()
         self._chk(self.L.flipv_get_params(self.h, C.byref(p)), "flipv_get_params")
-        return p
+        self._chk(self.L.flipv_get_debug_params(self.h, C.byref(d)), "flipv_get_debug_params")
+        return AllParams(p, d)
 
     def set_params(self, **kw):
-        p = self.get_params()
+        """fields of flipv_params and of flipv_debug_params alike: each goes to its own struct"""
+        a = self.get_params()
+        touched = set()
         for k, v in kw.items():
-            if not hasattr(p, k):
+            if k in _PRODUCT_FIELDS:
+                setattr(a.product, k, v); touched.add("p")
+            elif k in _DEBUG_FIELDS:
+                setattr(a.debug, k, v); touched.add("d")
+            else:
                 raise AttributeError(k)
-            setattr(p, k, v)
-        self._chk(self.L.flipv_set_params(self.h, C.byref(p)), "flipv_set_params")
+        if "p" in touched:
+            self._chk(self.L.flipv_set_params(self.h, C.byref(a.product)), "flipv_set_params")
+        if "d" in touched:
+            self._chk(self.L.flipv_set_debug_params(self.h, C.byref(a.debug)), "flipv_set_debug_params")
 
     def set_gravity(self, gx, gy, gz):
         self._chk(self.L.flipv_set_gravity(self.h, gx, gy, gz), "flipv_set_gravity")

@@ -45,6 +45,7 @@ static int plain_alloc(flipv_context *c, T **p, size_t n) {
     return FLIPV_OK;
 }
 
+extern "C" int flipv_abi_version(void) { return FLIPV_VERSION; }
 extern "C" int flipv_default_params(flipv_params *p) {
     if (!p) return FLIPV_ERR_INVALID;
     memset(p, 0, sizeof(*p));
@@ -59,8 +60,12 @@ extern "C" int flipv_default_params(flipv_params *p) {
     p->viscosity_max_iterations = 700;
     p->viscosity_accept_tolerance = 10.0;
     p->precision = FLIPV_PRECISION_FP32;
-    p->kernel_timing = 0;
     p->check_every = 0;
+    return FLIPV_OK;
+}
+extern "C" int flipv_default_debug_params(flipv_debug_params *p) {
+    if (!p) return FLIPV_ERR_INVALID;
+    memset(p, 0, sizeof(*p));
     return FLIPV_OK;
 }
 
@@ -172,6 +177,7 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     c->viscosity_nonzero = 1;
     memset(&c->kstats, 0, sizeof(c->kstats));
     flipv_default_params(&c->prm);
+    flipv_default_debug_params(&c->prm);
     c->gravity[0] = 0.0f; c->gravity[1] = -9.81f; c->gravity[2] = 0.0f;  // fluidsimulation.cpp:40
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_create_error = std::string(#call) + ": " + hipGetErrorString(e_); flipv_destroy(c); return FLIPV_ERR_HIP; } } while (0)
 #define GALLOC(ptr) do { int rc_ = grid_alloc(c, &(ptr)); if (rc_) { g_create_error = c->err; flipv_destroy(c); return rc_; } } while (0)
@@ -364,7 +370,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         const int rcT = fv_check_block_thickness(c, p->cfl_number, "flipv_set_params");
         if (rcT) return rcT;
     }
-    // every field has an error path: nothing out of range is silently ignored or used as given
+    // every field has an error path: nothing out of its documented range is silently ignored or used as given
     {
         const char *bad = nullptr;
         auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
@@ -373,36 +379,53 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!fin(p->pic_ratio, 0.0f, 1.0f)) bad = "pic_ratio";
         else if (!in(p->extrapolation_layers, 0, 64)) bad = "extrapolation_layers";
         else if (!(p->pressure_tolerance >= 0.0) || !(p->pressure_rel_tolerance >= 0.0) || !(p->viscosity_tolerance > 0.0) || !(p->viscosity_accept_tolerance >= 0.0)) bad = "a tolerance";
-        else if (!in(p->kernel_timing, 0, 1) || !in(p->check_every, 0, 4096)) bad = "kernel_timing / check_every";
+        else if (!in(p->check_every, 0, 4096)) bad = "check_every";
         else if (!in(p->pressure_preconditioner, 0, 2) || !in(p->viscosity_preconditioner, 0, 2)) bad = "a preconditioner";
         else if (!in(p->exact_viscosity_operator, 0, 1)) bad = "exact_viscosity_operator";
-        else if (!in(p->residual_replacement, 0, 1 << 20)) bad = "residual_replacement";
         else if (!in(p->viscosity_layout, 0, 3)) bad = "viscosity_layout";
-        else if (p->tile_rows != 0 && p->tile_rows != 16 && p->tile_rows != 64) bad = "tile_rows";
-        else if (!in(p->viscosity_mg_coarsest_sweeps, 0, 1024) || !in(p->pressure_mg_coarsest_sweeps, 0, 1024)) bad = "a coarsest-level sweep count";
-        else if (!in(p->viscosity_mg_min_dim, 0, 4096)) bad = "viscosity_mg_min_dim";
-        else if (!fin(p->pressure_mg_omega, 0.0f, 2.0f) || !fin(p->pressure_mg_overcorrection, 0.0f, 4.0f)) bad = "pressure_mg_omega / pressure_mg_overcorrection";
-        else if (!fin(p->viscosity_mg_omega_first, 0.0f, 2.0f) || !fin(p->viscosity_mg_omega_second, 0.0f, 2.0f)) bad = "viscosity_mg_omega_*";
-        else if (!in(p->no_liquid_box, 0, 1) || !in(p->no_comm_overlap, 0, 1) || !in(p->verbose, 0, 2) || !in(p->no_graph_replay, 0, 1) || !in(p->unbinned_scatter, 0, 1) ||
-                 !in(p->beta_from_conjugacy, 0, 1) || !in(p->multigrid_rank_local, 0, 1)) bad = "a 0/1 switch";
+        else if (!in(p->verbose, 0, 2) || !in(p->multigrid_rank_local, 0, 1)) bad = "verbose / multigrid_rank_local";
         else if (!in(p->multigrid_distributed_levels, -1, 1)) bad = "multigrid_distributed_levels";
-        else if (!in(p->grid_cap, 0, 1 << 20) || !in(p->viscosity_spmv_grid_cap, 0, 1 << 20) || !in(p->viscosity_update_grid_cap, 0, 1 << 20)) bad = "a grid cap";
-        else if (p->viscosity_lane_width != 0 && p->viscosity_lane_width != 2 && p->viscosity_lane_width != 4) bad = "viscosity_lane_width";
-        else if (!in(p->spmv_run_length, -1, 64) || p->spmv_run_length == 1) bad = "spmv_run_length";
         else if (!(p->viscosity_stage1_factor == 0.0f || fin(p->viscosity_stage1_factor, 1.0f, 1e6f))) bad = "viscosity_stage1_factor (0 or >= 1)";
-        else if (!fin(p->viscosity_stage2_factor, 0.0f, 1.0f)) bad = "viscosity_stage2_factor";
+        else if (!fin(p->viscosity_stage2_factor, 0.0f, 0.5f)) bad = "viscosity_stage2_factor (0 ... 0.5: a stage that reduces nothing is no stage)";
         else if (!in(p->viscosity_stage2_max_iterations, 0, 1 << 20) || !in(p->viscosity_stage2_rounds, 0, 16)) bad = "viscosity_stage2_max_iterations / viscosity_stage2_rounds";
+        else if (p->viscosity_stage2_max_iterations > p->viscosity_max_iterations) bad = "viscosity_stage2_max_iterations (beyond viscosity_max_iterations)";
         else if (!(p->viscosity_two_stage_max_stiffness >= 0.0f)) bad = "viscosity_two_stage_max_stiffness";
         else if (!in(p->viscosity_defect_predictor, -1, 0)) bad = "viscosity_defect_predictor";
         else if (!(p->viscosity_velocity_tolerance == -1.0f || fin(p->viscosity_velocity_tolerance, 0.0f, 1.0f)) || !in(p->viscosity_velocity_window, 0, 8)) bad = "viscosity_velocity_tolerance (-1, or 0 ... 1) / viscosity_velocity_window (0 ... 8)";
+        else if (!(p->viscosity_mass_scale == -1.0f || fin(p->viscosity_mass_scale, 0.0f, 1e9f))) bad = "viscosity_mass_scale (-1, or >= 0)";
         if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     }
-    c->prm = *p;
+    static_cast<flipv_params &>(c->prm) = *p;
+    return FLIPV_OK;
+}
+extern "C" int flipv_set_debug_params(flipv_context *c, const flipv_debug_params *p) {
+    if (!c || !p) return FLIPV_ERR_INVALID;
+    const char *bad = nullptr;
+    auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+    auto fin = [](float v, float lo, float hi) { return v >= lo && v <= hi; };
+    auto sweeps = [](int v) { return v >= 0 && v <= 64; };
+    if (!in(p->kernel_timing, 0, 1)) bad = "kernel_timing";
+    else if (p->tile_rows != 0 && p->tile_rows != 16 && p->tile_rows != 64) bad = "tile_rows";
+    else if (!sweeps(p->viscosity_mg_coarsest_sweeps) || !sweeps(p->pressure_mg_coarsest_sweeps)) bad = "a coarsest-level sweep count (0 ... 64)";
+    else if (!in(p->viscosity_mg_min_dim, 0, 4096)) bad = "viscosity_mg_min_dim";
+    else if (!fin(p->pressure_mg_omega, 0.0f, 2.0f) || !fin(p->pressure_mg_overcorrection, 0.0f, 4.0f)) bad = "pressure_mg_omega / pressure_mg_overcorrection";
+    else if (!fin(p->viscosity_mg_omega_first, 0.0f, 2.0f) || !fin(p->viscosity_mg_omega_second, 0.0f, 2.0f)) bad = "viscosity_mg_omega_*";
+    else if (!in(p->no_liquid_box, 0, 1) || !in(p->no_comm_overlap, 0, 1) || !in(p->no_graph_replay, 0, 1) || !in(p->unbinned_scatter, 0, 1) || !in(p->beta_from_conjugacy, 0, 1)) bad = "a 0/1 switch";
+    else if (!in(p->grid_cap, 0, 1 << 20) || !in(p->viscosity_spmv_grid_cap, 0, 1 << 20) || !in(p->viscosity_update_grid_cap, 0, 1 << 20)) bad = "a grid cap";
+    else if (p->viscosity_lane_width != 0 && p->viscosity_lane_width != 2 && p->viscosity_lane_width != 4) bad = "viscosity_lane_width";
+    else if (!in(p->spmv_run_length, -2, 64) || p->spmv_run_length == 1) bad = "spmv_run_length";
+    if (bad) { c->err = std::string("flipv_set_debug_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
+    static_cast<flipv_debug_params &>(c->prm) = *p;
+    return FLIPV_OK;
+}
+extern "C" int flipv_get_debug_params(flipv_context *c, flipv_debug_params *p) {
+    if (!c || !p) return FLIPV_ERR_INVALID;
+    *p = static_cast<const flipv_debug_params &>(c->prm);
     return FLIPV_OK;
 }
 extern "C" int flipv_get_params(flipv_context *c, flipv_params *p) {
     if (!c || !p) return FLIPV_ERR_INVALID;
-    *p = c->prm;
+    *p = static_cast<const flipv_params &>(c->prm);
     return FLIPV_OK;
 }
 extern "C" int flipv_set_gravity(flipv_context *c, float gx, float gy, float gz) {

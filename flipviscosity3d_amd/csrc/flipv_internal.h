@@ -149,6 +149,8 @@ constexpr int NSLOT = 32;
 // number on such a context.
 constexpr int FV_HALO = 8;
 
+struct FvParams : flipv_params, flipv_debug_params {};
+
 struct flipv_context {
     Lay L;           // launch box = the whole allocated box; per-launch ranges come from fv_range()
     // Block decomposition: this rank owns cells [cell0, cell1) per axis, i.e. indices [L.olo, L.ohi) (the closing face / node
@@ -178,7 +180,7 @@ struct flipv_context {
     float dx;
     int device;
     hipStream_t stream;
-    flipv_params prm;
+    FvParams prm;   // flipv_params + flipv_debug_params (distinct field names: c->prm.x reaches either)
     float gravity[3];
     std::string err;
     std::vector<void *> allocs;
@@ -215,6 +217,7 @@ struct flipv_context {
     // scalars
     double *d_scal;   // device scalar scratch (PCG)
     int geoMemoP = 0, geoMemoV = 0;   // fv_build_tiles: a tile geometry tried and turned down (pressure, viscosity)
+    double tileFillP = 0.0; // ... of the pressure solve's list (launch_pressure_spmv picks its kernel by it)
     double tileFill;       // fv_build_tiles: unknowns per index of the listed tiles inside the lattices' extent (the last list built)
     double *d_scal_small;  // 64 doubles: communication scratch (counts, CFL max, barrier)
     double *d_gather = nullptr;   // NSLOT x FV_GATHER_MAX doubles: fv_allgather_f64

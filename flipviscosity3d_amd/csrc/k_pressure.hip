@@ -127,6 +127,113 @@ constexpr int ROWL = 64;
 #include "k_pressure_geo.inc"
 }  // namespace g64
 
+
+// K12 on FILLED boxes beyond the memory-side cache: the box swept in ADDRESS order, tile by tile, two adjacent rows per lane.
+// The k-marching kernel above keeps 1 024 blocks walking 1 024 different columns of the box: 6 000 concurrent streams of 1 KB pieces a plane apart, which HBM serves at
+// 4.4-4.5 TB/s however the march is shaped (tools/micro/spmv7_variants.hip, 512^3: 256 x 4 / x 8 / x 16 tiles, runs of 32-128 planes, with or without nontemporal
+// accesses: 0.55-0.62 of the 8 TB/s peak), while a stencil-free stream of the same 5 reads + 1 write reaches 5.6-5.85 (0.70-0.73).  What the march saves -- the k +- 1
+// planes of s and pk fetched once -- the caches give for free when ALL blocks work on the same few planes at the same time: three planes of s are 3 MB at 512^2.
+// So: units (tx, pair of tile rows, k) enumerated x fastest = in address order, one block per unit (launch_pressure_spmv says why), a lane owning 4 consecutive i of TWO adjacent rows (the j-neighbours between them come from registers: 19 vector loads per 8 cells
+// instead of 22), coefficients and q nontemporal.  Same arithmetic, term by term, as the kernels above.  Measured: 5.3 TB/s = 0.66 of peak at 512^3 (march: 0.557).
+// Single-rank contexts (a block context's tiles split into interior / cut-face lists).
+template <typename T, int DOTS, int RL>
+__global__ __launch_bounds__(256) void k_pressure_spmv_sweep(TileGrid tg, Lay L, int k0, int nk, const float *__restrict__ diag, const float *__restrict__ pi,
+                                                             const float *__restrict__ pj, const float *__restrict__ pk, const T *__restrict__ s,
+                                                             const RT<T> *__restrict__ r, T *__restrict__ q, PcgScal sc, int it_arg) {
+    // RL lanes along i: 64 (a wave = one row of 256 indices: one contiguous 1 KB per access) or 32 (a wave = 2 row groups of 128 indices) where the extent fits 256-wide
+    // tiles badly (384 = 1.5 x 256: a quarter of the lanes idle; launch_pressure_spmv picks).  Tile = (4 RL) i x (8 x 64 / RL) j, two adjacent rows per lane.
+    constexpr int RG = 64 / RL, RPB = 8 * RG, TW = 4 * RL;
+    __shared__ double lds[12];
+    bool stop;
+    const int it = d_iter_spmv(sc, it_arg, stop);
+    if (stop) return;
+    // Units and XCDs.  The hardware deals consecutive workgroups to the 8 XCDs in turn, and each XCD has its own L2: a unit's k +- 1 and j +- 1 neighbour rows are L2
+    // hits only if the units that own them run on the SAME XCD.  So XCD x = blockIdx & 7 takes a contiguous slab of the plane's row pairs, for every plane, and walks
+    // it tx fastest, then rows, then k: all 8 XCDs sweep the same planes at the same time (DRAM sees one front), and inside a slab every neighbour but the two border
+    // rows is the XCD's own.  (Units dealt out in plain address order put plane k + 1 on another XCD whenever the units per plane are no multiple of 8 -- 195 at
+    // 512^3 with the padded columns: PMC 1.7 x the bytes, 0.55 of peak; this mapping: profiles/r5.)
+    const int ntx = (L.I - tg.ox + TW - 1) / TW, nrow2 = (L.J - tg.oy + RPB - 1) / RPB;   // tiles that hold cells (not the padding behind the last cell)
+    const int x = (int)blockIdx.x & 7, l = (int)blockIdx.x >> 3;
+    const int base = nrow2 >> 3, rem = nrow2 & 7, r0s = x * base + (x < rem ? x : rem), cnt = base + (x < rem ? 1 : 0);
+    const int per = ntx * cnt;
+    const int lane = (int)threadIdx.x & (RL - 1), rg = (int)threadIdx.x / RL;
+    const long sy = L.sy, sz = L.sz;
+    double da = 0.0, db = 0.0, dc = 0.0;
+    if (cnt > 0 && l < per * nk) {
+        const int kz = l / per, rr = l - kz * per, ty2 = r0s + rr / ntx, tx = rr % ntx;
+        const int i0 = tg.ox + tx * TW + lane * 4, j0 = tg.oy + ty2 * RPB + ((int)threadIdx.y * RG + rg) * 2, k = k0 + kz;
+        if (i0 < L.ox + L.PX && j0 + 1 < L.oy + L.PY) {   // inside the allocated box (whole rows of a wave at a time)
+        const bool lfirst = lane == 0 && i0 > 0, llast = lane == RL - 1 && i0 + 4 < L.I;
+        const size_t c0 = gidx(L, i0, j0, k), c1 = c0 + sy;
+        const bool own0 = i0 < L.I && j0 < L.J, own1 = i0 < L.I && j0 + 1 < L.J;   // rows / lanes that hold cells; the others load nothing (every coefficient towards them is zero)
+        Vec<float, 4> dg0{}, dg1{}, ci0{}, ci1{}, cj0{}, cj1{}, cjm{}, ck0{}, ck1{}, ckm0{}, ckm1{};
+        Vec<T, 4> s0{}, s1{}, sjm{}, sjp{}, skm0{}, skm1{}, skp0{}, skp1{};
+        Vec<RT<T>, 4> r0{}, r1{};
+        if (own0) {
+            dg0 = ldvs<true, 4>(diag + c0); ci0 = ldvs<true, 4>(pi + c0); cj0 = ldv<4>(pj + c0); cjm = ldv<4>(pj + c0 - sy); ck0 = ldv<4>(pk + c0); ckm0 = ldv<4>(pk + c0 - sz);
+            s0 = ldv<4>(s + c0); sjm = ldv<4>(s + c0 - sy); skm0 = ldv<4>(s + c0 - sz); skp0 = ldv<4>(s + c0 + sz);
+            if (DOTS == 2) r0 = ldv<4>(r + c0);
+        }
+        if (own1) {
+            dg1 = ldvs<true, 4>(diag + c1); ci1 = ldvs<true, 4>(pi + c1); cj1 = ldv<4>(pj + c1); ck1 = ldv<4>(pk + c1); ckm1 = ldv<4>(pk + c1 - sz);
+            s1 = ldv<4>(s + c1); sjp = ldv<4>(s + c1 + sy); skm1 = ldv<4>(s + c1 - sz); skp1 = ldv<4>(s + c1 + sz);
+            if (DOTS == 2) r1 = ldv<4>(r + c1);
+        }
+        T esl0 = (T)0, esl1 = (T)0, esr0 = (T)0, esr1 = (T)0;
+        float ecl0 = 0.0f, ecl1 = 0.0f;
+        if (lfirst && own0) { esl0 = s[c0 - 1]; ecl0 = pi[c0 - 1]; }
+        if (lfirst && own1) { esl1 = s[c1 - 1]; ecl1 = pi[c1 - 1]; }
+        if (llast && own0) esr0 = s[c0 + 4];
+        if (llast && own1) esr1 = s[c1 + 4];
+        T ta = (T)0, tb = (T)0, tc = (T)0;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const Vec<float, 4> &dg = t ? dg1 : dg0, &ci = t ? ci1 : ci0, &cj = t ? cj1 : cj0, &cjmm = t ? cj0 : cjm, &ck = t ? ck1 : ck0, &ckm = t ? ckm1 : ckm0;
+            const Vec<T, 4> &sc4 = t ? s1 : s0, &sm = t ? s0 : sjm, &sp = t ? sjp : s1, &skm = t ? skm1 : skm0, &skp = t ? skp1 : skp0;
+            const Vec<RT<T>, 4> &r4 = t ? r1 : r0;
+            // (32-lane rows shift across the whole wave like 64-lane ones: the first / last lane of a row takes its neighbour from memory either way)
+            T sl = RL != 16 ? g64::wave_up1(sc4.v[3]) : g16::wave_up1(sc4.v[3]), sr = RL != 16 ? g64::wave_down1(sc4.v[0]) : g16::wave_down1(sc4.v[0]);
+            float cil = RL != 16 ? g64::wave_up1(ci.v[3]) : g16::wave_up1(ci.v[3]);
+            if (lane == 0) { sl = t ? esl1 : esl0; cil = t ? ecl1 : ecl0; }
+            if (lane == RL - 1) sr = t ? esr1 : esr0;
+            const bool own = t ? own1 : own0;
+            Vec<T, 4> y;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const T smi = e > 0 ? sc4.v[e - 1] : sl;
+                const T spi = e < 3 ? sc4.v[e + 1] : sr;
+                const float cim = e > 0 ? ci.v[e - 1] : cil;
+                T acc = smi * (T)cim;
+                acc += spi * (T)ci.v[e];
+                acc += sm.v[e] * (T)cjmm.v[e];
+                acc += sp.v[e] * (T)cj.v[e];
+                acc += skm.v[e] * (T)ckm.v[e];
+                acc += skp.v[e] * (T)ck.v[e];
+                acc += sc4.v[e] * (T)dg.v[e];
+                y.v[e] = acc;
+                if (own && dg.v[e] != 0.0f) {
+                    ta += sc4.v[e] * acc;
+                    if (DOTS >= 1) {
+                        const T yi = acc * d_recip<T>(dg.v[e]);
+                        if (DOTS == 2) tb += (T)r4.v[e] * yi;
+                        tc += acc * yi;
+                    }
+                }
+            }
+            if (own) stvs<true, 4>(q + (t ? c1 : c0), y);
+        }
+        da += (double)ta; db += (double)tb; dc += (double)tc;
+        }
+    }
+    block_sum3_256(da, db, dc, lds);
+    if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
+        const int sl = sc.my_slot();
+        if (da != 0.0) atomicAdd(sc.a(it) + sl, da);
+        if (db != 0.0) atomicAdd(sc.b(it) + sl, db);
+        if (dc != 0.0) atomicAdd(sc.c(it) + sl, dc);
+    }
+}
+
 // ---- run candidates (pcg_geo.inc explains runs)
 
 // flag per (column, k-chunk): first active plane and the length up to the last active one (holes are walked)
@@ -269,7 +376,7 @@ int fv_scal_clear(flipv_context *c, int cap, bool keepExtra) {
 static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **extra);
 // reset the stall guard (enqueued before any kernel of the solve): best = 0x7f7f... = 1.4e306, "nothing seen yet"
 static int guard_jobs(const PcgScal *sc, FillJob *z) {
-    z[0] = {sc->best, sizeof(double), 0x7f}; z[1] = {sc->stalled, sizeof(int), 0}; z[2] = {sc->bestIt, sizeof(int), 0};
+    z[0] = {sc->best, sizeof(double), 0x7f}; z[1] = {sc->stalled, sizeof(int), 0}; z[2] = {sc->bestIt, 2 * sizeof(int), 0};   // (bestIt and passIt: adjacent ints)
     return 3;
 }
 void fv_scal_views(flipv_context *c, int cap, PcgScal *sc, double **extra) {
@@ -306,7 +413,7 @@ static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **ext
     sc->stall_below = 0.0;
     sc->stalled = c->d_flags + 11;
     sc->bestIt = c->d_flags + 14;
-    sc->vel_tol = 0.0; sc->vel_window = 0;   // (the velocity criterion: set by the viscosity solve for its last loop)
+    sc->vel_tol = 0.0; sc->vel_window = 0; sc->vel_patience = 48; sc->passIt = c->d_flags + 15;   // (the velocity criterion: set by the viscosity solve for its last loop)
     *extra = c->d_scal + FV_NSC * n;
 }
 
@@ -449,11 +556,35 @@ static void launch_pressure_spmv(flipv_context *c, const PcgScal &sc, int it, in
                        c->pDiag, c->pPi, c->pPj, c->pPk, c->pMask, c->mlistP ? c->mlistP + (size_t)first * 256 : (const unsigned *)nullptr, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it))
 #define PMARCH(D, S) GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL((k_pressure_spmv_march<T, D, S>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsP, c->nRunsP, (const unsigned *)c->rmaskP, c->tgP, c->L, \
                        c->pDiag, c->pPi, c->pPj, c->pPk, (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it))
-    if (c->nRunsP > 0 && first == 0 && count == c->nActiveP) {   // k-marching over the run list (the whole system)
-        const int nbm = pcg_grid(c, c->nRunsP);
-        // streaming accesses once the system's 25 bytes per cell exceed the memory-side cache (ldvs, pcg_common.h)
-        const bool stream = (double)c->nActiveP * (256 * VW_P) * 25.0 > 256.0 * 1024 * 1024;
-        if (stream) { if (dots == 2) PMARCH(2, true); else if (dots == 1) PMARCH(1, true); else PMARCH(0, true); }
+    // streaming accesses once the system's 25 bytes per cell exceed the memory-side cache (ldvs, pcg_common.h)
+    const bool stream = (double)c->nActiveP * (256 * VW_P) * 25.0 > 256.0 * 1024 * 1024;
+    // filled boxes: the sweep in address order (k_pressure_spmv_sweep; spmv_run_length = -2 forces it on any single-rank box: tests)
+    const bool sweep = !c->comm && std::is_same<T, float>::value && first == 0 && count == c->nActiveP &&
+                       (c->prm.spmv_run_length == -2 || (c->prm.spmv_run_length == 0 && c->nRunsP > 0 && c->tileFillP > 0.65));
+    if (sweep || (c->nRunsP > 0 && first == 0 && count == c->nActiveP)) {   // the whole system: sweep, or k-marching over the run list
+        const int nbm = pcg_grid(c, c->nRunsP > 0 ? c->nRunsP : 8);
+        if (sweep) {
+            const Lay R = fv_range_liquid(c, 1, 5);
+            const int kb = R.kb > c->tgP.oz ? R.kb : c->tgP.oz, ke0 = R.ke < c->tgP.oz + c->tgP.ntz ? R.ke : c->tgP.oz + c->tgP.ntz, ke = ke0 < c->L.K ? ke0 : c->L.K;   // planes that hold cells
+            // ONE BLOCK PER UNIT: the hardware starts a block the moment another retires, so the loads of a fresh unit overlap the stores of its predecessors; a resident
+            // grid walking units b, b + G, ... serialises each wave's load -> compute -> store chain (512^3: 0.51-0.59 of peak with G = 1 024 ... 8 192 against 0.66-0.70;
+            // profiles/r5/spmv7_variants_512.log).  The price is one fp64 atomic per block and scalar -- 65 536 fire-and-forget atomics onto 128 slot words at 512^3,
+            // hidden in the 600 us of the launch.  8 x (the largest XCD slab's units): the kernel's own XCD mapping.
+            // lanes of a row: 64 (tiles of 256 i) unless those fit the extent badly and 128-wide ones better -- 384 = 1.5 x 256 leaves a quarter of the lanes idle:
+            // 0.55 of peak in 64-lane rows, 0.62 in 32-lane rows; at 448 and 512 the 64-lane rows win (0.64 / 0.67 against 0.52 / 0.62), 16-lane rows lose everywhere
+            // (profiles/r5/pressure_sweep_probe.log).  tile_rows = 64 pins the wide rows.
+            const int ext = c->L.I - c->tgP.ox;
+            const double use64 = (double)ext / (((ext + 255) / 256) * 256.0), use32 = (double)ext / (((ext + 127) / 128) * 128.0);
+            const int rl = (c->prm.tile_rows != 64 && use64 < 0.8 && use32 > 1.1 * use64) ? 32 : 64;
+            const int tw = 4 * rl, rpb = 8 * (64 / rl);
+            const int ntx = (ext + tw - 1) / tw, nrow2 = (c->L.J - c->tgP.oy + rpb - 1) / rpb;
+            const int g = ke > kb ? 8 * ntx * ((nrow2 + 7) / 8) * (ke - kb) : 8;
+#define PSWEEP(D, R) hipLaunchKernelGGL((k_pressure_spmv_sweep<T, D, R>), dim3(g), dim3(64, 4, 1), 0, c->stream, c->tgP, c->L, kb, ke > kb ? ke - kb : 0, c->pDiag, c->pPi, c->pPj, c->pPk, \
+                                        (const T *)c->pS, (const RT<T> *)c->pR, (T *)c->pZ, sc, it)
+            if (rl == 64) { if (dots == 2) PSWEEP(2, 64); else if (dots == 1) PSWEEP(1, 64); else PSWEEP(0, 64); }
+            else { if (dots == 2) PSWEEP(2, 32); else if (dots == 1) PSWEEP(1, 32); else PSWEEP(0, 32); }
+#undef PSWEEP
+        } else if (stream) { if (dots == 2) PMARCH(2, true); else if (dots == 1) PMARCH(1, true); else PMARCH(0, true); }
         else if (dots == 2) PMARCH(2, false); else if (dots == 1) PMARCH(1, false); else PMARCH(0, false);
     } else if (dots == 2) PSPMV(2); else if (dots == 1) PSPMV(1); else PSPMV(0);
 #undef PSPMV
@@ -488,6 +619,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->pMask, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1, &c->mlistP, &c->mlistCapP, 0.70, &c->geoMemoP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
+    c->tileFillP = c->tileFill;
     if ((rc = fv_build_runs(c, c->tgP, VW_P, c->nActiveP, c->tgP.rowl == 64 || c->tileFill > 0.65, c->pMask, &c->runsP, &c->runCapP, &c->nRunsP, &c->runLenP, &c->rmaskP, &c->rmaskCapP))) return rc;
     {
         float bn = (float)c->h_scal[0];   // global max|b| (fp32 is enough for a tolerance scale)

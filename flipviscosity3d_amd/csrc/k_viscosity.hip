@@ -549,8 +549,11 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
 //   after a multigrid solve of m iterations                     -> diagonal if 15 m is safely inside the cap and cheaper than 35 + 7.5 m (m < ~5)
 // Decisions depend on iteration counts only, never on wall-clock times, so a run is reproducible; every path converges to the same
 // tolerance, so what the history changes is the cost of a solve, not its answer beyond solver tolerance.
+// nu dt/dx^2 up to which AUTO takes the diagonal without asking: 8.  (64 until round 5: the holdout sweep's draws between 10 and 64 needed 104 ... 677 diagonal
+// iterations -- one of them the cap's worth -- where the multigrid takes 13 ... 35, and left 6e-3 / 2e-2 of max|u| on two of them: profiles/r5/holdout_sweep.log)
+constexpr double FV_AUTO_DIAGONAL_STIFFNESS = 8.0;
 static bool fv_visc_auto_pick(const flipv_context *c, float dt) {
-    if ((double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx) <= 64.0) return false;
+    if ((double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx) <= FV_AUTO_DIAGONAL_STIFFNESS) return false;
     if (c->vLastPrec == 0) return true;
     const double cap = (double)c->prm.viscosity_max_iterations;
     const double MG_ITER = 7.5, MG_SETUP = 35.0, RATIO = 15.0;
@@ -821,11 +824,11 @@ static int visc_gather_field_facts(flipv_context *c) {
         c->viscosity_nonzero_any = nz > 0.0;
         c->viscosity_max_any = (float)vm;
         c->vPerRowFactors = vlo != vm ? 1 : 0;
-        c->vZeroRegion = (vlo == 0.0 && vm > 0.0) ? 1 : 0;
+        c->vZeroRegion = (vm > 0.0 && vlo * 1.0e4 < vm) ? 1 : 0;
     } else {
         c->viscosity_nonzero_any = c->viscosity_nonzero; c->viscosity_max_any = c->viscosity_max;
         c->vPerRowFactors = c->viscosity_min != c->viscosity_max ? 1 : 0;
-        c->vZeroRegion = (c->viscosity_min == 0.0f && c->viscosity_max > 0.0f) ? 1 : 0;
+        c->vZeroRegion = (c->viscosity_max > 0.0f && (double)c->viscosity_min * 1.0e4 < (double)c->viscosity_max) ? 1 : 0;   // (a contrast beyond 1e4 -- zero included --: two correction stages, below)
     }
     return FLIPV_OK;
 }
@@ -913,9 +916,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // gate -- stagnates on b - E u_old (E u_old is rough and largest on the sliver rows: the fp32 loop's accuracy floor; bench.py's mode_b_strict: 155 iterations,
     // 5.7e-6 instead of 99 and 1e-6).
     const double stiffSolve = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-    const bool stage1Early = c->prm.viscosity_stage1_factor != 1.0f && stiffSolve <= (c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5);
+    const bool stage1Early = c->prm.viscosity_stage1_factor != 1.0f && stiffSolve <= (c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 1.0e6);
     const bool predict = refDiag && mgPlanned && std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && c->prm.viscosity_defect_predictor >= 0 &&
-                         c->prm.residual_replacement <= 0 && stage1Early;
+                         stage1Early;
     auto run_setup = [&](int layout, bool first) -> int {
         const bool brick = layout == VLAYOUT_BRICK;
         if (c->viscStateValid && (c->vLayout == VLAYOUT_BRICK) != brick) {
@@ -1014,9 +1017,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     double defectRes = 0.0, mainRes = 0.0;   // max|b - A_ref x| after the defect-correction stage; the exact-operator loop's own final residual
     double velStep = 0.0;
     int anyActive = c->nActiveV;
-    // residual replacement (k_viscosity_brick.hip): fp32 vectors in the brick layout
-    int replacePeriod = 0;
-    if (brick && !c->comm && std::is_same<T, float>::value && c->prm.residual_replacement > 0) replacePeriod = c->prm.residual_replacement;   // opt-in (flipv.h; single-domain contexts)
+    int replacePeriod = 0;   // (periodic residual replacement inside a loop -- k_viscosity_brick.hip: fv_brick_replace -- was an opt-in study until version 4 of the ABI: it restarts CG with a stale direction again and again, HISTORY.md; the kernels remain as the refinement steps' building blocks)
     // The reference's operator (exact_viscosity_operator = 0, the default) under the multigrid, fp32 vectors, brick layout: DEFECT CORRECTION.
     // A_ref = A + E, E the rounding defect of the reference's float diagonal (d_ref_volume): |E| ~ 1e-3 of what a row does to a near-rigid
     // motion, enough to make the near-rigid modes of small liquid clusters (own volumes of the size of the defect) nearly indefinite.  PCG
@@ -1042,7 +1043,16 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         success = true;
         replacePeriod = 0;
     } else {
-        const double tolFinal = c->prm.viscosity_tolerance * bnorm;
+        // THE SCALE OF THE RESIDUAL TEST.  The reference stops at max|r| <= 1e-6 max|rhs| (pcgsolver.h:259-272).  While the liquid is clear of the walls a row's right-hand side is
+        // its own volume x velocity and max|rhs| ~ max|u|; once it touches a wall the rows next to solid faces carry nu dt/dx^2 x (the solid faces' stored velocities) and
+        // max|rhs| jumps by that factor (256^3 bunny: 2 900 against max|u| = 1.4), so that the same test lets the bulk of the liquid -- rows whose near-rigid motions have
+        // residual = volume x error -- be wrong by 3e-3 of a volume x velocity: the reference's own iterate is then 1e-4 ... 1e-3 max|u| off the solution of its system on
+        // tens of thousands of faces (round 4's rule at 256^3, 35 substeps in: 9.4e-4 on 53 000 faces; profiles/r5/eta_scan_256.log).  So the norm every tolerance of
+        // this solve is a share of is capped at viscosity_mass_scale x max|u| (100: with viscosity_tolerance = 1e-6 the final target is never above 1e-4 of one full
+        // control volume moving at max|u|; 30 and 10 cost 10 % / 30 % more iterations at 256^3 for the same 3e-6 ... 5e-6, profiles/r5/eta_scan_256.log).  flipv_solve_info.rhs_norm stays max|rhs|.
+        const double massScale = c->prm.viscosity_mass_scale > 0.0f ? (double)c->prm.viscosity_mass_scale : (c->prm.viscosity_mass_scale < 0.0f ? 0.0 : 100.0);
+        const double bnormEff = (massScale > 0.0 && umaxAll > 0.0 && !c->vMixed64) ? fmin(bnorm, massScale * umaxAll) : bnorm;
+        const double tolFinal = c->prm.viscosity_tolerance * bnormEff;
         double resStart = bnorm;
         int nb = pcg_grid(c, c->nActiveV);
         if (c->prm.viscosity_update_grid_cap > 0) { nb = ((c->nActiveV + 7) / 8) * 8; if (nb > c->prm.viscosity_update_grid_cap) nb = c->prm.viscosity_update_grid_cap; if (nb < 8) nb = 8; }  // measurement switch: grid cap of init/update
@@ -1062,53 +1072,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         double lastTarget = 0.0;
         double resBeforeStage = 0.0;
         const bool innerDiffers = staged && useMg;   // the Krylov loop runs on the exact operator, the solve is for the reference's
-        // Stage 1 of the defect correction does not have to resolve the exact operator's system further than stage 2 preserves.  Stage 2 solves
-        // A dx = b - A_ref x from the fp64-recomputed residual -- stage 1's remainder PLUS the defect, which is ~2e-2 max|b| in the max norm at 256^3 /
-        // nu = 5 (a few rows with tiny diagonals carry it) -- and what it leaves of the DEFECT is what separates the delivered velocities from the
-        // reference's.  Scans on the 256^3 bunny (two chained substeps against the reference run to convergence, 20 000 probe faces per component;
-        // 128^3 likewise; bench = 20 substeps; final library):
-        //     stage 1 to / stage 2 to    iterations   velocity error 256^3   128^3               MCells/s
-        //     1e-6 / 2e-2 of the defect  115 / 94     3.7e-5 / 4.0e-5        7.7e-6 / 1.2e-5     686        (the first version)
-        //     1e-4 / 2e-2                70 / 70      5.2e-5 / 6.1e-5        1.5e-5 / 2.0e-5     865
-        //     3e-5 / 2e-2                76 / 77      5.4e-5 / 6.0e-5        1.5e-5 / 1.7e-5     814
-        //     1e-4 / 1e-2                76 / 76      2.6e-5 / 9.2e-6        6.1e-6 / 1.3e-5     790-860
-        //     3e-4 / 1e-2                70 / 67      2.3e-5 / 1.3e-5        5.1e-6 / 8.1e-6     878        <- taken
-        //     1e-3 / 1e-2                63 / 60      1.6e-5 / 1.7e-5        3.2e-6 / 1.1e-5     911
-        //     1e-3 / 5e-3                69 / 65      2.5e-5 / 1.8e-5        1.4e-6 / 3.8e-6     892
-        // The error follows stage 2's factor, not stage 1's tolerance: with 2e-2 it is 5-6e-5 whatever stage 1 did (even 3e-3: 2.5e-5 / 3.5e-5 in an
-        // earlier build), with 1e-2 it is 1-3e-5.  Taken: stage 1 to 300 x the final tolerance, stage 2 to 1 % of what the recomputed residual holds
-        // BEYOND stage 1's remainder and never below the final tolerance (a solve without a defect then still ends at the final tolerance, stage 2
-        // reducing the remainder alone inside its 48 iterations).  Up to nu dt/dx^2 = 2e5 (where the cycle also stops reading packed rows: the fp32
-        // loop's accuracy floor).  The rule first stopped at 2e4; the 64^3 scene against the oracle run to convergence (profiles/r3/
-        // stiffness_scan_64.log) says it need not: at 32 768 stage 1 to 1e-6 with stage 2 at 2 % gives 4e-5 ... 9e-5 on the first substep and 7e-5 ...
-        // 2e-4 on the second, this rule 2e-5 and 1e-4 for 25-60 % fewer iterations; at 122 880 the former runs a solve into the cap (1e-4 ... 7e-4),
-        // this rule gives 1.5e-4 / 1.6e-4 -- nothing pins those regimes to 1e-4, and this is the cheaper and the more robust of the two.
-        // The constants of the rule are flipv_params fields since FLIPV_VERSION 4 (0 = these defaults): stage 1's factor 300, the stiffness gate 2e5,
-        // a correction stage's share 1e-2 (2e-2 behind a stage 1 that ran to the final tolerance), its budget, and how many stages.
-        // THE SHARE TIGHTENS WHERE THE SYSTEM IS STIFF.  A stage contracts the distance to the reference operator's solution by |A^-1 E| at best, and only as
-        // far as its own target lets it; the defect grows with nu dt/dx^2.  Measured against the reference / the oracle run to convergence, every substep
-        // started from the reference's particles, worse of two substeps, iterations of the second (profiles/r4/stiff_regime_scan*.log):
-        //     nu dt/dx^2   one stage to 1e-2     one stage to 3e-3     one stage to 1e-3     two stages to 1e-2
-        //     8 192        1.9e-5  104           6.3e-6  112           1.4e-6  129           3e-7    193
-        //     20 480       2.3e-5  131           9e-6    141           1.8e-6  162           8e-7    237
-        //     32 768       3.0e-5  138           2.3e-5  147           2.9e-6  181           4.5e-7  224
-        //     52 429       1.4e-4  164           1.6e-5  193           1.4e-5  200           1.8e-6  261
-        //     81 920       8.9e-5  166           4.8e-5  194           1.2e-5  203           6e-7    262
-        //     122 880      1.7e-4  174           2.9e-5  210           2.8e-5  214           5.5e-6  260      (tests/golden/bunny64_nu3000)
-        //     131 070      2.9e-4  198           2.5e-5  234           1.1e-5  255           5e-7    339      (tests/golden/honey96_nu1422: config 4's scene)
-        // Round 3 shipped the first column everywhere (with a budget of 48): it misses the 1e-4 bar from 5e4 on.  Taken: ONE stage, to 1e-2 of the defect up
-        // to nu dt/dx^2 = 2e4 (the headline's 3 277: 2.3e-5 at 256^3) and to 1e-3 beyond -- <= 3e-5 everywhere for +25 % iterations where two stages cost +60 %.
-        // viscosity_stage2_rounds = 2 buys the last column.
+        // The constants of the two-stage rule: include/flipv.h ("THE DEFAULT VISCOSITY SOLVE") states them once; the scans they come from -- stage 1's factor, the
+        // correction stage's share by stiffness, one stage against two -- are in HISTORY.md ("Round 3-4: the scans behind the two-stage rule") and profiles/r4/.
         const double stiffNow = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-        // Stage 1's factor: the delivered velocities do NOT depend on it between 300 and 10 000 -- the correction stage starts from the fp64-recomputed residual,
-        // stage 1's remainder included (profiles/r4/stage1_factor_scan.log: 256^3 1.6e-5 ... 2.5e-5 from the reference's converged velocities with 300, 1 000 and
-        // 3 000; 128^3, the stiff fixtures and the oracle scans from 8e3 to 8e4 likewise) -- the iteration count does: a restarted loop has lost its Krylov
-        // space, so on a mildly stiff system (64^3 at nu = 5: nu dt/dx^2 = 205) stopping earlier costs 50 -> 63 iterations, on a stiff one it saves (256^3:
-        // 70 -> 62, bench 879 -> 957 MCells/s; 64^3 nu = 200: 104 -> 87; nu = 800: 181 -> 156).  300 up to nu dt/dx^2 = 1 000, 3 000 beyond.
         const double f1user = c->prm.viscosity_stage1_factor >= 1.0f ? (double)c->prm.viscosity_stage1_factor : 0.0;
-        const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 2.0e5;
+        const double gate = c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 1.0e6;
         const int cap2 = c->prm.viscosity_stage2_max_iterations > 0 ? c->prm.viscosity_stage2_max_iterations : 200;   // (round 3: 48.  A first stage takes 7-30 iterations, a second one at nu dt/dx^2 = 1.3e5 100-150)
-        // (A field that is EXACTLY ZERO on part of the nodes and viscous elsewhere takes two stages: the inviscid faces are pure mass rows that pin the viscous body along
+        // (A field whose CONTRAST exceeds 1e4 -- nearly or exactly inviscid on part of the nodes, viscous elsewhere -- takes two stages (holdout sweep: 1e-4 | 200 needs them as
+        // 0 | 200 does, smooth 1 ... 1 000 does not): the inviscid faces are pure mass rows that pin the viscous body along
         // the interface like a wall with a prescribed velocity, and what one stage leaves there is 3.3e-4 in the velocities at nu = 0 | 200, 64^3 -- 4e-6 with two;
         // 0.5 | 200 is 1.5e-5 with one.  tests/test_gpu_stiff_regime.py)
         const int rounds = c->vMixed64 ? 8 : (c->prm.viscosity_stage2_rounds > 0 ? c->prm.viscosity_stage2_rounds : (c->vZeroRegion ? 2 : 1));   // (vMixed64: refinement to the fp64 tolerance, fv_viscosity_solve)
@@ -1151,10 +1122,10 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (correction) lastTarget = sc.tol;   // (stage 1 at 1e-6, scanned at 256^3: 2e-2 -> 3.7e-5 / 4.0e-5 from the reference's converged velocities, 5e-2 -> 9.1e-5 / 1.15e-4, 1e-1 -> 1.3e-4)
         sc.stall_below = refinements > 0 ? fmin(100.0 * sc.tol, 0.05 * resStart) : 0.0;
         // THE VELOCITY CRITERION of the solve's last loop (flipv_params.viscosity_velocity_tolerance; pcg_common.h: PcgScal::vel_tol): the loop that delivers the
-        // result -- the last correction stage, its restart, or the one loop of a solve without stages -- is converged when max|r| passes its target AND its last
+        // result -- a correction stage, its restart, or the one loop of a solve without stages -- is converged when max|r| passes its target AND its last
         // `viscosity_velocity_window` iterations together moved no velocity by more than that share of max|u|.  Stages in between stop on the residual alone.
         {
-            const bool lastLoop = !innerDiffers || (correction && (corrections >= rounds || extraStage));
+            const bool lastLoop = !innerDiffers || correction;   // (every correction stage: the solve ends after whichever of them leaves the fp64 residual below the tolerance)
             const double eta = c->prm.viscosity_velocity_tolerance > 0.0f ? (double)c->prm.viscosity_velocity_tolerance : (c->prm.viscosity_velocity_tolerance < 0.0f ? 0.0 : 3.0e-5);
             sc.vel_tol = (lastLoop && !c->vMixed64) ? eta * umaxAll : 0.0;
             sc.vel_window = c->prm.viscosity_velocity_window > 0 ? c->prm.viscosity_velocity_window : 4;
@@ -1382,7 +1353,7 @@ int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) {
         // viscosity_tolerance x max|rhs|, the reference's own criterion; status 1 if it does not inside the iteration cap.  (Until round 4 fp64 vectors
         // took the diagonal whatever was asked for: at 256^3 that is an iterate stopped at the cap.)
         const double stiff = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);   // (over all ranks: a rank whose own box is inviscid must take the same path)
-        const bool wantsMg = c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && stiff > 64.0);
+        const bool wantsMg = c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && stiff > FV_AUTO_DIAGONAL_STIFFNESS);
         if (!wantsMg || c->prm.viscosity_lane_width == 2) return viscosity_solve_t<double>(c, dt, info);
         c->vMixed64 = 1;
         const int rc = viscosity_solve_t<float>(c, dt, info);

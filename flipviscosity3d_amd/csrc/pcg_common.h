@@ -147,6 +147,8 @@ struct PcgScal {
     // the residual test passes (64^3 bunny resting on the wall at nu = 200: 2.7e-4 from the converged reference at 2.4e-6 max|rhs|; profiles/r5).
     double vel_tol;
     int vel_window;
+    int vel_patience;   // the criterion holds a loop whose residual has passed for at most this many further iterations (then the loop ends as converged; flipv_solve_info.velocity_step says what was left)
+    int *passIt;        // device: 1 + the iteration at which the residual test first passed while the velocity criterion did not (0: not yet); the int behind bestIt
     __host__ __device__ double *sig(int it) const { return base + (size_t)it * FV_NSC * NSLOT; }          // (r,z) entering iteration it
     __host__ __device__ double *a(int it) const { return base + (size_t)it * FV_NSC * NSLOT + NSLOT; }
     __host__ __device__ double *b(int it) const { return base + (size_t)it * FV_NSC * NSLOT + 2 * NSLOT; }
@@ -290,6 +292,7 @@ __device__ __forceinline__ bool d_pass(const PcgScal &sc, double res) { return s
 __device__ __forceinline__ bool d_steps_small(const PcgScal &sc, int it_last, double *lds8) {
     if (!(sc.vel_tol > 0.0)) return true;
     const int tid = d_tid256();
+    const int passed = sc.passIt ? *sc.passIt - 1 : -1;   // (stored + 1: zero = not yet)   // (written by an EARLIER launch, or in this one by block 0 with this very it_last: every block decides alike either way)
     if (tid < 64) {
         double sum = 0.0;
         for (int w = 0; w < sc.vel_window; w++) {
@@ -305,7 +308,12 @@ __device__ __forceinline__ bool d_steps_small(const PcgScal &sc, int it_last, do
     __syncthreads();
     const double s = lds8[7];
     __syncthreads();
-    return s <= sc.vel_tol;
+    if (s <= sc.vel_tol) return true;
+    // A light speck whose velocity the system barely determines keeps CG moving it for ever: the criterion holds the loop for vel_patience iterations past
+    // the residual test, no longer.
+    if (passed >= 0 && it_last - passed >= sc.vel_patience) return true;
+    if (passed < 0 && sc.passIt && blockIdx.x == 0 && tid == 0) *sc.passIt = it_last + 1;
+    return false;
 }
 
 // K1 prologue shared by both SpMV kernels: returns true if the launch must do nothing
@@ -342,6 +350,7 @@ static __global__ void k_pcg_residual(PcgScal sc, int it, double *out, int withS
     if (withSteps) {
         PcgScal t = sc;
         t.vel_tol = 1.0;
+        t.passIt = nullptr;
         if (t.vel_window < 1) t.vel_window = 4;
         (void)d_steps_small(t, it, lds);
         if (threadIdx.x == 0) out[1] = lds[7];

@@ -32,7 +32,8 @@ extern "C" {
 
 #define FLIPV_VERSION 5   /* 3: every behavioural switch is a flipv_params field (no environment variables); brick layout; residual replacement
                              4: the constants of the two-stage viscosity solve are flipv_params fields; flipv_solve_info reports the correction stage
-                             5: the velocity criterion of the viscosity solve (viscosity_velocity_tolerance / _window; flipv_solve_info.velocity_step) */
+                             5: the velocity criterion and the mass scale of the viscosity solve (flipv_solve_info.velocity_step); A/B and measurement switches moved to
+                                flipv_debug_params; residual_replacement removed; flipv_abi_version() */
 
 typedef struct flipv_context flipv_context;
 
@@ -69,8 +70,27 @@ enum flipv_precision {
                                  fp64, the Krylov loops in fp32, repeated until the FP64 residual meets viscosity_tolerance (status 1 if it does not) */
 };
 
+/* THE DEFAULT VISCOSITY SOLVE, stated once (k_viscosity.hip: viscosity_solve_t implements this table; DESIGN.md 4 gives the measurements behind every number).
+ *   S = nu_max dt/dx^2, the a-priori stiffness (all ranks).                     N = the norm every tolerance is a share of = min(max|rhs|, viscosity_mass_scale x max|u|)
+ *   preconditioner (AUTO)    S <= 8: diagonal PCG on the reference's operator A_ref (one loop to viscosity_tolerance x N).   S > 8: Galerkin multigrid V(2,2), unless
+ *                            the previous solve shows the diagonal to converge for less; a diagonal solve AUTO picked that hits the cap is repeated with the multigrid
+ *   under the multigrid      defect correction towards A_ref = A + E (E: the rounding of the reference's float diagonal; with a viscosity FIELD also its per-row edge factors):
+ *     stage 1                PCG on the exact operator A, right-hand side b - E u_old (viscosity_defect_predictor), to viscosity_stage1_factor x viscosity_tolerance x N:
+ *                            factor 300 for S <= 1 000, 3 000 for 1 000 < S <= viscosity_two_stage_max_stiffness (1e6; 2e5 until round 5: at 256^3 / nu = 500,
+ *                            S = 3.3e5, the early stop halves the iterations and ends the capped solves), 1 beyond (and no predictor there)
+ *     correction stage(s)    x flushed to fp64, r = b - A_ref x in fp64, PCG on A dx = r to max(floor, share x (|r| - stage 1's target)), share = viscosity_stage2_factor:
+ *                            1e-2 for S <= 2e4, 1e-3 beyond (2e-2 behind a stage 1 that ran to the tolerance); floor = max(viscosity_tolerance x N, 1e-3 x stage 1's target);
+ *                            at most viscosity_stage2_max_iterations (200) each; viscosity_stage2_rounds = 1 stage -- 2 where the viscosity field's contrast max / min exceeds 1e4
+ *                            (zero included); a stage that RAISES the fp64 residual is taken back, one that ends short of its target is restarted once
+ *   the delivering loop      (a correction stage, its restart, or the one loop of a solve without stages) also needs the VELOCITY CRITERION: its last
+ *                            viscosity_velocity_window (4) iterations together moved no velocity the substep uses by more than viscosity_velocity_tolerance (3e-5) x max|u|;
+ *                            a loop the stall guard stops with the criterion unmet is restarted from the fp64 residual
+ *   status                   0 = every stage reached its target; 1 = cap / stalled / a stage ended short or was taken back (the result is applied, like the reference's
+ *                            accepted iterate); flipv_solve_info: residual (stage 1's), defect_residual = max|b - A_ref x| delivered, velocity_step, correction_* */
+
 /* Tunables.  Defaults = the reference's private constants (fluidsimulation.h:121,128-130,
- * pressuresolver.h:224-226, viscositysolver.h:200-202). */
+ * pressuresolver.h:224-226, viscositysolver.h:200-202).  Every field below check_every: 0 = the default behaviour (a zero-initialised tail is a valid
+ * default configuration).  Switches that exist for A/B measurements and tests live in flipv_debug_params, not here. */
 typedef struct flipv_params {
     float cfl_number;            /* 5.0   _CFLConditionNumber */
     float min_frac;              /* 0.01  _minfrac */
@@ -81,120 +101,83 @@ typedef struct flipv_params {
                                       reach 1e-9 absolute when |b| ~ 1; default 1e-6 for FP32, 0 for FP64 */
     int pressure_max_iterations; /* 200 in the reference (MIC(0)); the GPU preconditioner needs more iterations for the
                                     same residual, default 2000 */
-    double viscosity_tolerance;  /* 1e-6 relative to max|rhs| (pcgsolver.h:259) */
+    double viscosity_tolerance;  /* 1e-6 relative to the norm N of the table above (pcgsolver.h:259: max|rhs|) */
     int viscosity_max_iterations;/* 700 (viscositysolver.h:202) */
     double viscosity_accept_tolerance; /* 10.0 (viscositysolver.h:201) */
     int precision;               /* enum flipv_precision */
-    int kernel_timing;           /* 1 => bracket every SpMV launch with HIP events (flipv_kernel_stats) */
     int check_every;             /* convergence poll interval in iterations; 0 (default) = 32 on one GPU, 8 with a communicator (the diagonal loops), 4 in the
                                     multigrid-preconditioned loops (viscosity and pressure: an iteration after the stop is a full V-cycle) */
-    /* solver choice (enum flipv_preconditioner) */
-    int pressure_preconditioner; /* AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
-    int viscosity_preconditioner;/* DIAGONAL; MULTIGRID = Galerkin multigrid V(2,2) (fp32 vectors; single-domain AND block contexts: under a
-                                    communicator the hierarchy is the single domain's, see multigrid_rank_local; fp64 vectors and 2-wide lanes
-                                    fall back to the diagonal and say so in flipv_solve_info.preconditioner): 15-250 iterations
-                                    where the diagonal needs 200-4 000.  AUTO (default) = the multigrid unless the previous solve shows
-                                    that the diagonal CONVERGES for less (k_viscosity.hip: fv_visc_auto_pick); a diagonal solve AUTO
-                                    picked that runs into the cap is repeated with the multigrid, so a default run never returns an
-                                    iterate stopped at the cap where a converged one is affordable.  Decisions use iteration counts only,
-                                    never timings, and are taken from all-reduced inputs: every rank of a communicator decides alike */
-    /* ---- every field below: 0 = the default behaviour (a zero-initialised tail is a valid default configuration) ---- */
-    int exact_viscosity_operator;/* 0 (default): the viscosity solve applies the REFERENCE's operator, including the rounding of its float
-                                    diagonal (the reference sums vol + fR + fL + fT + fB + fF + fK in float, viscositysolver.cpp:394-446;
-                                    the defect is folded into the row's own volume, no extra bytes).  Matters where nu dt/dx^2 is large: at
-                                    256^3 (3 300) the reference's converged velocities are 7e-6 from this operator's and 1.5e-4 from the
-                                    exact one's.  1: the exact operator vol u - div(tau) (better conditioned; what rounds differently is the
-                                    reference).  
-                                    Under the multigrid (fp32 vectors) the reference's operator is reached by DEFECT CORRECTION, on single-domain and block
-                                    contexts, in every layout: stage 1 solves the exact operator's system A x = b to viscosity_stage1_factor x viscosity_tolerance
-                                    (where nu dt/dx^2 <= viscosity_two_stage_max_stiffness; to viscosity_tolerance beyond), then viscosity_stage2_rounds
-                                    correction stage(s) solve A dx = b - A_ref x (fp64 residual) to viscosity_stage2_factor of the defect, never below
-                                    viscosity_tolerance nor below 1e-3 of stage 1's tolerance (what one restarted fp32 loop can deliver), in at most viscosity_stage2_max_iterations iterations each; a correction that RAISES the fp64
-                                    residual is taken back, one that ends short of its target is restarted once from the recomputed fp64 residual.  flipv_solve_info: status 0 = every stage reached its target; residual = stage 1's;
-                                    defect_residual = max|b - A_ref x| delivered; correction_* = what the correction stages did.
-                                    With a VARIABLE viscosity field (flipv_set_viscosity with differing node values) A_ref also means the reference's per-row edge factors --
-                                    each row averages the four viscosities around an edge in its own float order --: the fp64 residual forms them row by row.
+    int pressure_preconditioner; /* enum flipv_preconditioner; AUTO = aggregation multigrid with fp32 vectors on grids above 16^3, the diagonal otherwise */
+    int viscosity_preconditioner;/* enum flipv_preconditioner; the table above.  Decisions use iteration counts and all-reduced scalars only, never timings: every rank
+                                    of a communicator decides alike, and a run is reproducible up to summation order */
+    int exact_viscosity_operator;/* 0 (default): the solve is for the REFERENCE's operator A_ref, including the rounding of its float diagonal (the reference sums
+                                    vol + fR + fL + fT + fB + fF + fK in float, viscositysolver.cpp:394-446) -- at 256^3 (nu dt/dx^2 = 3 300) the reference's converged
+                                    velocities are 7e-6 from this operator's and 1.5e-4 from the exact one's.  1: the exact operator vol u - div(tau) (better
+                                    conditioned; what rounds differently is the reference): one multigrid-PCG loop, no defect correction.
                                     REPRODUCIBILITY: scatters and dot products sum in arrival order, so two runs agree to solver tolerance, not bit for bit.  With the
                                     reference's operator that can be coarser LOCALLY: its rounded diagonal leaves the near-rigid modes of tiny detached liquid clusters
-                                    (own volumes of the size of the defect, which may even come out slightly negative) ill-determined -- two runs of one
-                                    configuration were seen 4e-2 apart on the faces of such a cluster on the substep where a body touches the wall
-                                    (tests/test_gpu_wide.py: test_liquid_box_restriction_over_a_long_run pins the exact operator for that reason); the reference itself
-                                    has the same indeterminacy, it only sums in a fixed order.  exact_viscosity_operator = 1 does not */
-    int residual_replacement;    /* n > 0 (fp32 vectors in the brick layout): every n iterations the solution accumulated so far is flushed into an
-                                    fp64 accumulator and the recurrence residual is REPLACED by b - A x evaluated in fp64 (group-wise update, van
-                                    der Vorst & Ye; two extra launches per n iterations), so that the stop test sees the true residual.  0
-                                    (default) = off: measured here, an fp32 x drifts from its recurrence residual by ~3e-5 max|b| within 15
-                                    iterations (rounding of x += alpha s times a diagonal of nu dt/dx^2 ~ 1e3), far above the 1e-6 the recurrence
-                                    reaches, so a periodic replacement restarts CG with a stale direction again and again (38 -> 421 iterations
-                                    on the 20^3 fixture); the drift sits in rough modes and changes the velocities by 1e-8.  Kept for studies */
+                                    (own volumes of the size of the defect, which may even come out slightly negative) ill-determined -- two runs of one configuration
+                                    were seen 4e-2 apart on the faces of such a cluster on the substep where a body touches the wall; the reference itself has the same
+                                    indeterminacy, it only sums in a fixed order.  exact_viscosity_operator = 1 does not */
     int viscosity_layout;        /* layout of the viscosity solver's arrays: 0 = chosen per solve (bricks of 8 x 4 x 2 indices on sparse
                                     liquids -- rows filling < 30-40 % of the box, over all ranks --, plain planes otherwise), 1 = plain planes,
-                                    2 = plain planes with the own-index arrays in 8 x 4 patches under the 16-lane tile geometry (the pre-brick
-                                    default), 3 = bricks always.  Single-domain and block contexts alike */
-    int tile_rows;               /* 16 | 64: pins the tile geometry of the plane-layout kernels (lanes of a wave along i); 0 = chosen per
-                                    solve from how full the tiles are */
-    int viscosity_mg_coarsest_sweeps; /* sweeps on the LDS-resident coarsest level of the viscosity multigrid: a power of two (4..64) = that many
-                                    Chebyshev-weighted Jacobi sweeps, any other count = plain damped Jacobi sweeps; 0 = chosen per solve: 8 where the
-                                    solve is the two-stage defect correction (exact_viscosity_operator), else 32 while nu dt/dx^2 > 1000 and the
-                                    last multigrid solve needed more than 60 iterations, else 16 */
+                                    2 = plain planes with the own-index arrays in 8 x 4 patches under the 16-lane tile geometry, 3 = bricks always */
+    int multigrid_rank_local;    /* several ranks (block contexts).  0 (default): both multigrid preconditioners are the single domain's -- the fine-level sweeps read
+                                    the neighbours' current values, the coarse hierarchy is the GLOBAL one: the iteration counts of a single domain.
+                                    1: every rank cycles a hierarchy of its OWN rows / cells with the couplings across the cuts dropped and no exchange
+                                    (block-Jacobi): 3-4x the viscosity iterations and 2-3x the pressure iterations on 2x2x2 blocks */
+    int multigrid_distributed_levels; /* several ranks, viscosity multigrid with the global hierarchy: 0 = level 1 is DISTRIBUTED (cycled by the rows' owners with
+                                    1-entry halo exchanges, like level 0) where the system has more than 4.5e6 rows over all ranks; 1 = always; -1 = never */
+    int verbose;                 /* 1: one line per viscosity solve and the multigrid's level table on stderr; 2: also the residual history */
+    /* the two-stage viscosity solve (the table above); 0 = the default in brackets */
+    float viscosity_stage1_factor;          /* [300 | 3 000] >= 1; 1 = the strict solve: stage 1 to viscosity_tolerance itself (bench.py: mode_b_strict) */
+    float viscosity_stage2_factor;          /* [1e-2 | 1e-3 | 2e-2] a correction stage's target as a share of the defect it starts from; 0 < share <= 0.5 */
+    int viscosity_stage2_max_iterations;    /* [200] iteration budget of ONE correction stage (inside viscosity_max_iterations overall) */
+    int viscosity_stage2_rounds;            /* [1 | 2] correction stages at most; 2 brings the velocities to <= 6e-6 of the reference's at every stiffness measured, for ~35 %
+                                               more iterations than one stage at the default share */
+    float viscosity_two_stage_max_stiffness;/* [1e6] nu dt/dx^2 up to which stage 1 stops early */
+    int viscosity_defect_predictor;         /* [0 = on] -1 = off */
+    /* what certifies the stop in late states (FLIPV_VERSION 5) */
+    float viscosity_velocity_tolerance;     /* [3e-5; -1 = off] the velocity criterion of the delivering loop.  The reference's test, max|r| <= 1e-6 max|rhs| (pcgsolver.h:259-272),
+                                               does not bound the velocity error where the liquid holds light, weakly attached parts -- films and specks whose control volumes
+                                               sum to a few per cent of a cell: residual = mass x error -- and in such states (the fringe of a splash, a body resting on the wall)
+                                               CG still moves velocities by 1e-4 of their maximum per iteration when the residual test passes: the reference's own 1e-6 iterate is
+                                               then 1e-4 ... 3e-1 of max|u| from the solution of its system on one substep in eight (profiles/r5/late_states.log).  Costs nothing
+                                               where the iteration has settled when the residual passes (a compact falling body), 5-50 iterations in the states above */
+    int viscosity_velocity_window;          /* [4] iterations the criterion sums over (1..8) */
+    float viscosity_mass_scale;             /* [100; -1 = off] N = min(max|rhs|, viscosity_mass_scale x max|u|).  Once the liquid touches a wall max|rhs| is set by the rows next to
+                                               solid faces (nu dt/dx^2 x the solid faces' velocities: 2 900 at 256^3 where max|u| = 1.4) and the reference's test no longer says
+                                               anything about the bulk, whose near-rigid motions have residual = volume x error: round 4's rule left 3e-4 ... 9e-4 of max|u| on
+                                               25 000 - 80 000 faces of the 256^3 bunny from the impact on (profiles/r5/eta_scan_256.log).  100 x 1e-6 = the final residual never
+                                               above 1e-4 of a full control volume moving at max|u| */
+} flipv_params;
+
+/* Switches for A/B measurements, profiling and tests (flipv_set_debug_params).  Results do not depend on them beyond solver tolerance; none of them is needed to
+ * run a simulation.  All zero = the product's behaviour. */
+typedef struct flipv_debug_params {
+    int kernel_timing;           /* 1 => bracket every SpMV launch with HIP events (flipv_kernel_stats) */
+    int tile_rows;               /* 16 | 64: pins the tile geometry of the plane-layout kernels (lanes of a wave along i); 0 = chosen per solve */
+    int viscosity_mg_coarsest_sweeps; /* sweeps on the LDS-resident coarsest level of the viscosity multigrid: a power of two (4..64) = that many Chebyshev-weighted Jacobi
+                                    sweeps, any other count <= 64 = plain damped Jacobi sweeps; 0 = chosen per solve (8 under the two-stage solve) */
     int viscosity_mg_min_dim;    /* the viscosity hierarchy stops at the level whose longest axis is <= this many cells; 0 = 16 */
-    int pressure_mg_coarsest_sweeps; /* 0 = 8 */
+    int pressure_mg_coarsest_sweeps; /* 0 = 8; <= 64 */
     float pressure_mg_omega;     /* damping of the pressure multigrid's Jacobi sweeps; 0 = 0.9 */
     float pressure_mg_overcorrection; /* scaling of its coarse-grid correction; 0 = 1.8 */
-    int no_liquid_box;           /* 1: every sweep of a substep covers the whole box instead of the neighbourhood of the liquid (A/B, tests) */
+    float viscosity_mg_omega_first;  /* damping of the first and of the second Jacobi sweep of the viscosity multigrid's V(2,2) smoother; 0 = the defaults */
+    float viscosity_mg_omega_second;
+    int no_liquid_box;           /* 1: every sweep of a substep covers the whole box instead of the neighbourhood of the liquid */
     int no_comm_overlap;         /* 1: the halo exchange of the PCG search direction does not overlap the interior SpMV */
-    int verbose;                 /* 1: one line per viscosity solve and the multigrid's level table on stderr */
-    /* measurement / test switches; results do not depend on them beyond solver tolerance */
-    int no_graph_replay;         /* 1: the PCG loop is launched kernel by kernel instead of replayed as a hipGraph */
-    int unbinned_scatter;        /* 1: particle scatters with global atomics instead of LDS tiles (A/B) */
+    int no_graph_replay;         /* 1: the PCG loops are launched kernel by kernel instead of replayed as hipGraphs */
+    int unbinned_scatter;        /* 1: particle scatters with global atomics instead of LDS tiles */
     int grid_cap;                /* n>0: cap of the PCG kernels' grids in blocks (tests: every block walks many tiles) */
     int viscosity_lane_width;    /* 2|4: forced lane width of the viscosity tile kernels (2 excludes the brick layout and the multigrid) */
     int viscosity_spmv_grid_cap; /* n>0: grid cap of the viscosity SpMV kernel alone */
     int viscosity_update_grid_cap; /* n>0: grid cap of the viscosity init/update kernels */
-    int beta_from_conjugacy;     /* 0 (default): the PCG's beta = (sigma - 2 alpha (r/d,q) + alpha^2 (q,q/d))/sigma, with the residual
-                                    read by the SpMV for (r/d,q) (+12 B per index, +4 B per pressure cell).  1: (r/d,q) is
-                                    replaced by (s,q), which is equal in exact arithmetic (successive search directions are
-                                    A-conjugate) and lets the SpMV skip the residual: 5-7 % faster per iteration, but on
-                                    ill-conditioned systems (nu dt/dx^2 ~ 2e3: the rod + sheet scene at nu = 50) the fp32
-                                    solve stagnates.  sigma itself is recomputed from the stored vectors every iteration either way. */
-    int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 (default) =
-                                    chosen per solve from the number of active tiles; -1 = the tile-at-a-time kernels */
-    float viscosity_mg_omega_first;  /* damping of the first and of the second Jacobi sweep of the viscosity multigrid's V(2,2) smoother (pre- and */
-    float viscosity_mg_omega_second; /* post-smoothing use the same pair); 0 = the defaults (k_viscosity_mg.hip: VMG_W) */
-    int multigrid_rank_local;    /* several ranks (block contexts).  0 (default): both multigrid preconditioners are the single domain's -- the fine-level sweeps read
-                                    the neighbours' current values (viscosity: 4 halo copies per iteration, pressure: 1), the coarse hierarchy is the GLOBAL one,
-                                    its first level's operator summed over the ranks once per solve and its right-hand side once per iteration (float
-                                    all-reduces over the liquid's box), held and cycled redundantly by every rank: the iteration counts of a single domain.
-                                    1: every rank cycles a hierarchy of its OWN rows / cells with the couplings across the cuts dropped and no exchange
-                                    (block-Jacobi): 3-4x the viscosity iterations and 2-3x the pressure iterations on 2x2x2 blocks */
-    int multigrid_distributed_levels; /* several ranks, viscosity multigrid with the global hierarchy: 0 = level 1 is DISTRIBUTED (cycled by the rows' owners with
-                                    1-entry halo exchanges, like level 0; the global, redundantly cycled hierarchy starts one level further down) where the system has more
-                                    than 4.5e6 rows over all ranks; 1 = always; -1 = never (level 1 global: one all-reduce of its right-hand side per iteration) */
-    /* the two-stage viscosity solve (see exact_viscosity_operator); 0 = the default in brackets */
-    float viscosity_stage1_factor;          /* [300 up to nu dt/dx^2 = 1 000, 3 000 beyond] stage 1 stops at this multiple (>= 1) of viscosity_tolerance x max|rhs|; the delivered
-                                               velocities do not depend on it (the correction stage starts from the fp64 residual), the iteration count does.
-                                               1 = the strict solve: stage 1 to viscosity_tolerance itself (bench.py: mode_b_strict) */
-    float viscosity_stage2_factor;          /* [1e-2 up to nu dt/dx^2 = 2e4, 1e-3 beyond; 2e-2 where stage 1 ran to viscosity_tolerance] a correction stage's target as a share of
-                                               the defect it starts from.  Scanned against the reference run to convergence from 8e3 to 1.3e5 (k_viscosity.hip: viscosity_solve_t) */
-    int viscosity_stage2_max_iterations;    /* [200] iteration budget of ONE correction stage (inside viscosity_max_iterations overall) */
-    int viscosity_stage2_rounds;            /* [1; 2 where the viscosity field is exactly 0 on part of the nodes and positive elsewhere] correction stages at most; 2 brings the velocities to <= 6e-6 of the reference's at every stiffness measured, for ~35 % more
-                                               iterations than one stage at the default share */
-    float viscosity_two_stage_max_stiffness;/* [2e5] nu dt/dx^2 up to which stage 1 stops early (beyond: the fp32 loop's accuracy floor, stage 1 runs to viscosity_tolerance) */
-    int viscosity_defect_predictor;         /* [0 = on] stage 1 solves A x = b - E u_old (E = the reference's diagonal defect, u_old = the incoming velocities) instead of A x = b:
-                                               the correction stage starts from E (x - u_old) instead of E x -- the same or fewer iterations for the same velocities
-                                               (up to -18 % at nu dt/dx^2 = 1.2e5).  Only where stage 1 stops early: not with viscosity_stage1_factor = 1 or beyond
-                                               viscosity_two_stage_max_stiffness (an fp32 loop run to the final tolerance stagnates on that right-hand side).  -1 = off */
-    /* the velocity criterion of the viscosity solve (FLIPV_VERSION 5) */
-    float viscosity_velocity_tolerance;     /* [3e-5; -1 = off] the loop that delivers the solve's result (the last correction stage, or the one loop of a solve without stages) is
-                                               converged when max|r| has passed its residual target AND its last viscosity_velocity_window iterations together changed no velocity
-                                               by more than this share of max|u| (the sum of their max|alpha p|).  The reference's test, max|r| <= 1e-6 max|rhs| (pcgsolver.h:259-272),
-                                               does not bound the velocity error where the liquid holds light, weakly attached parts -- films and specks whose control volumes
-                                               sum to a few per cent of a cell: residual = mass x error -- and in such states (a body resting on the wall, the fringe of a splash)
-                                               CG still moves velocities by 1e-4 of their maximum per iteration when the residual test passes: the reference's own 1e-6 iterate is
-                                               then 1e-4 ... 1e-1 from the solution of its system (profiles/r5/late_states.log).  Costs nothing where the iteration has settled
-                                               when the residual passes (a compact falling body), 5-25 iterations in the states above */
-    int viscosity_velocity_window;          /* [4] iterations the criterion sums over (1..8) */
-} flipv_params;
+    int beta_from_conjugacy;     /* 1: the diagonal PCG's (r/d,q) is replaced by (s,q) -- equal in exact arithmetic -- and the SpMV skips the residual: 5-7 % faster per
+                                    iteration, but on ill-conditioned systems the fp32 solve stagnates */
+    int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 = chosen per solve; -1 = the tile-at-a-time kernels; -2 = the pressure
+                                    SpMV's address-order sweep kernel (filled boxes in 64-lane rows) whatever the size */
+} flipv_debug_params;
 
 typedef struct flipv_solve_info {
     int iterations;      /* iterations run (count) */
@@ -276,9 +259,15 @@ int flipv_destroy(flipv_context *ctx);
 const char *flipv_last_error(flipv_context *ctx); /* ctx may be NULL for create-time errors */
 int flipv_device_name(flipv_context *ctx, char *buf, size_t len);
 
+/* FLIPV_VERSION the library was built from: a binding compiled against another version of this header must not pass its structs (their layout changes with the
+ * version: 4 -> 5 split flipv_params, added fields to flipv_solve_info) */
+int flipv_abi_version(void);
 int flipv_default_params(flipv_params *p);
-int flipv_set_params(flipv_context *ctx, const flipv_params *p);
+int flipv_set_params(flipv_context *ctx, const flipv_params *p);   /* FLIPV_ERR_INVALID (flipv_last_error names the field) when a field is out of its documented range */
 int flipv_get_params(flipv_context *ctx, flipv_params *p);
+int flipv_default_debug_params(flipv_debug_params *p);
+int flipv_set_debug_params(flipv_context *ctx, const flipv_debug_params *p);
+int flipv_get_debug_params(flipv_context *ctx, flipv_debug_params *p);
 
 /* setGravity (fluidsimulation.cpp:126-132) */
 int flipv_set_gravity(flipv_context *ctx, float gx, float gy, float gz);

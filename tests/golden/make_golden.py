@@ -142,6 +142,62 @@ def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inpu
     s.close()
 
 
+def late_state(name, N, boundary, liquid, nu, nsub_before, nprobe=100000, ntop=5000, vtol=1e-13, dt=0.01):
+    """A LATE state and the solution of the reference's systems from it: the reference carries the scene through `nsub_before` substeps at
+    its defaults; the particles it then holds ARE the state of a FLIP substep and are stored.  From them ONE substep with the viscosity cap lifted and the viscosity
+    tolerance at `vtol` (at the stock 1e-6, and even at 1e-10, the reference has not converged in such states: tests/test_gpu_late_states.py) -- stored as `nprobe`
+    seeded probe faces per component plus the `ntop` faces of largest |u|, and per-octant checksums of the particles -- and ONE substep at the defaults from the same
+    state, of which only its distance to the converged one is kept."""
+    I = J = K = N
+    dx = float(np.float32(1.0 / N))
+    s = R.RefSim(I, J, K, dx)
+    if boundary is not None:
+        bv, bt = load_ply(os.path.join(MESH, boundary[0]))
+        s.add_boundary(bv, bt, boundary[1])
+    R.lib().ref_srand(1)
+    for m in liquid:
+        lv, lt = load_ply(os.path.join(MESH, m))
+        s.add_liquid(lv, lt)
+    s.set_viscosity(nu)
+    for t in range(nsub_before):
+        s.substep(dt)
+        st = s.solver_stats()
+        if t % 5 == 4:
+            print("  substep %d: viscosity %d its, pressure %d its" % (t, st["visc_iters"], st["pres_iters"]), flush=True)
+    state = s.particles
+    d = dict(I=I, J=J, K=K, dx=np.float32(dx), dt=np.float32(dt), gravity=np.array((0.0, -9.81, 0.0), np.float32), nu=np.float32(nu), nsub_before=nsub_before,
+             vtol=np.float64(vtol), state=state, state_sum=np.float64(state.astype(np.float64).sum()), solid_sum=np.float64(s.grid("SOLID_PHI").astype(np.float64).sum()))
+    s.substep(dt)                                  # at the reference's defaults
+    st = s.solver_stats()
+    d["defaults_visc_iters"] = st["visc_iters"]
+    dflt = [s.grid(c) for c in "UVW"]
+    s.particles = state
+    s.set_viscosity_solver(maxiter=3000000, tol=vtol)
+    s.substep(dt)
+    st = s.solver_stats()
+    d["visc_iters"] = st["visc_iters"]; d["visc_err"] = st["visc_err"]; d["pres_iters"] = st["pres_iters"]
+    conv = [s.grid(c) for c in "UVW"]
+    den = max(np.abs(a).max() for a in conv)
+    d["maxabs"] = np.float32(den)
+    d["defaults_vs_converged"] = np.float64(max(np.abs(a.astype(np.float64) - b).max() for a, b in zip(dflt, conv)) / den)
+    rng = np.random.default_rng(2025)
+    for c, a in zip("UVW", conv):
+        flat = a.reshape(-1)
+        nz = np.flatnonzero(flat)
+        top = nz[np.argsort(np.abs(flat[nz]))[::-1][:ntop]]
+        idx = np.unique(np.concatenate([rng.choice(nz, size=min(nprobe, len(nz)), replace=False), top]))
+        d["probe_idx_" + c] = idx.astype(np.int64)
+        d["probe_val_" + c] = flat[idx]
+    Pn = s.particles
+    oct_ = (Pn[:, 0] > 0.5).astype(int) + 2 * (Pn[:, 1] > 0.25).astype(int) + 4 * (Pn[:, 2] > 0.5).astype(int)
+    d["particles_octant_sum"] = np.stack([Pn[oct_ == o].astype(np.float64).sum(axis=0) if (oct_ == o).any() else np.zeros(6) for o in range(8)])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("%-28s %8d particles  %6.0f KiB; converged %d viscosity iterations (defaults %d), the reference at its defaults is %.2e from it" % (
+        name, len(state), os.path.getsize(path) / 1024, d["visc_iters"], d["defaults_visc_iters"], float(d["defaults_vs_converged"])))
+    s.close()
+
+
 def layered_viscosity(I, J, K):
     # node-sampled, varies with height and x: exercises setViscosity(Array3d<float>&) (fluidsimulation.cpp:110-124)
     k, j, i = np.meshgrid(np.arange(K + 1), np.arange(J + 1), np.arange(I + 1), indexing="ij")
@@ -193,6 +249,11 @@ if __name__ == "__main__":
     #    answer at its own 1e-6 is itself 1.5e-4 away from the solution of the linear system (every GPU variant -- either preconditioner,
     #    fp32 or fp64 vectors, tolerance 1e-6 or 1e-7 -- agrees with every other to 2e-6 and differs from fixture F by 1.45e-4), so the
     #    1e-4 bar needs a reference that is converged beyond its stock tolerance.
+    # J: a LATE state at 128^3 (round 5): the bunny lying on the container wall at nu = 200 (nu dt/dx^2 = 32 768), 45 substeps in.  ~15 minutes; only when named.
+    if "bunny128_nu200_late" in only:
+        late_state("bunny128_nu200_late", 128, ("sphere_large.ply", True), ["stanford_bunny.ply"], 200.0, 45)
+    if "bunny128_nu5_late" in only:
+        late_state("bunny128_nu5_late", 128, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 40)
     if "bunny256_nu5_tight" in only:
         compact_scene("bunny256_nu5_tight", 256, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 1, vcap=60000, vtol=1e-8,
                       store_inputs=False, nprobe=20000)

@@ -38,8 +38,8 @@ def test_struct_layouts_match_header():
     import subprocess
     import tempfile
     from flipviscosity3d_amd import capi
-    code = '#include <stdio.h>\n#include "flipv.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(flipv_params), ' \
-           'sizeof(flipv_solve_info), sizeof(flipv_stats), sizeof(flipv_kernel_stats));return 0;}\n'
+    code = '#include <stdio.h>\n#include "flipv.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(flipv_params), ' \
+           'sizeof(flipv_solve_info), sizeof(flipv_stats), sizeof(flipv_kernel_stats), sizeof(flipv_debug_params));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "s.c")
         open(src, "w").write(code)
@@ -47,7 +47,16 @@ def test_struct_layouts_match_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(capi.Params), ctypes.sizeof(capi.SolveInfo), ctypes.sizeof(capi.Stats),
-                     ctypes.sizeof(capi.KernelStats)]
+                     ctypes.sizeof(capi.KernelStats), ctypes.sizeof(capi.DebugParams)]
+
+
+def test_abi_version_is_the_headers():
+    """flipv_abi_version(): what a binding checks before it passes a struct (the structs' layout changes with FLIPV_VERSION)"""
+    import re
+    from flipviscosity3d_amd import capi
+    L = capi.load()
+    hdr = open(os.path.join(ROOT, "include", "flipv.h")).read()
+    assert L.flipv_abi_version() == int(re.search(r"#define FLIPV_VERSION (\d+)", hdr).group(1)) == 5
 
 
 def test_default_params_are_the_reference_constants():

@@ -125,7 +125,7 @@ def test_auto_preconditioner_over_the_drop_and_splash(scene):
     """70 substeps of the bench scene with the default (AUTO) viscosity preconditioner: the multigrid from the first solve on, the
     liquid moving all the while, i.e. every solve assembles its hierarchy next to the leftovers of one assembled several cells away.
     EVERY solve of a default run must converge (status 0), and in the number of iterations a clean hierarchy needs (<= 200 in the stiff
-    start, 33-64 once the liquid moves).  (A Galerkin gather that read children outside the finer level's
+    start, 50-120 once the liquid has hit the wall).  (A Galerkin gather that read children outside the finer level's
     current box -- another solve's rows -- went from 63 to 326 iterations at substep 50 of `tools/soak.py 256 150 auto` and into the
     diagonal fallback a few substeps later; that failure depends on exactly when AUTO switches and does not reproduce on every
     trajectory, so this test is the guard for the whole mechanism rather than a reproducer of that one bug.)"""
@@ -142,7 +142,9 @@ def test_auto_preconditioner_over_the_drop_and_splash(scene):
     c.close()
     assert np.isfinite(Q).all()
     assert len(mg) >= 60, len(mg)                            # the multigrid runs (nearly) every solve
-    assert max(mg) <= 260 and max(mg[30:]) <= 110, mg        # 326 with the polluted hierarchy (substep 50)
+    # (round 5: from the impact on the solves carry the velocity criterion and the mass scale -- 50-120 iterations where round 4's rule took 33-64 and left 3e-4 ... 9e-4 of
+    # max|u| on tens of thousands of faces, profiles/r5/eta_scan_256.log; the polluted hierarchy's 326 stays far outside)
+    assert max(mg) <= 260 and max(mg[30:]) <= 170, mg
 
 
 def test_config4_honey_buckling_at_512_properties():

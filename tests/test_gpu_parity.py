@@ -498,9 +498,10 @@ def test_set_params_rejects_out_of_range_values():
     from flipviscosity3d_amd.capi import Context, FlipvError
     c = Context(8, 6, 5, 0.125)
     bad = [("min_frac", 0.0), ("pic_ratio", 1.5), ("extrapolation_layers", -1), ("viscosity_tolerance", 0.0), ("check_every", -2), ("viscosity_preconditioner", 3),
-           ("exact_viscosity_operator", 2), ("residual_replacement", -1), ("viscosity_layout", 4), ("tile_rows", 32), ("viscosity_mg_coarsest_sweeps", -3),
+           ("exact_viscosity_operator", 2), ("viscosity_layout", 4), ("tile_rows", 32), ("viscosity_mg_coarsest_sweeps", -3),
            ("pressure_mg_omega", float("nan")), ("viscosity_mg_omega_first", 2.5), ("verbose", 3), ("multigrid_distributed_levels", 2), ("grid_cap", -1),
-           ("viscosity_lane_width", 3), ("spmv_run_length", 1), ("viscosity_stage1_factor", 0.5), ("viscosity_stage2_factor", 1.5), ("viscosity_stage2_rounds", 17),
+           ("viscosity_lane_width", 3), ("spmv_run_length", 1), ("viscosity_stage1_factor", 0.5), ("viscosity_stage2_factor", 0.75), ("viscosity_stage2_rounds", 17), ("viscosity_stage2_max_iterations", 701),
+           ("viscosity_mg_coarsest_sweeps", 65), ("viscosity_velocity_tolerance", -0.5), ("viscosity_velocity_window", 9), ("viscosity_mass_scale", -2.0),
            ("viscosity_two_stage_max_stiffness", -1.0), ("viscosity_defect_predictor", 1), ("viscosity_defect_predictor", -2)]
     before = c.get_params()
     for field, value in bad:
@@ -514,7 +515,7 @@ def test_set_params_rejects_out_of_range_values():
 
 
 @pytest.mark.parametrize("name", ["bunny32_viscous", "twobody20_varvisc", "cube24_inviscid"])
-@pytest.mark.parametrize("runlen", [2, 5, 32])
+@pytest.mark.parametrize("runlen", [2, 5, 32, -2])
 def test_k_marching_spmv_matches_tile_kernels(name, runlen):
     """The k-marching SpMV kernels (runs of `runlen` tiles along k, planes k-1 / k carried in registers) against the
     tile-at-a-time kernels (flipv_params.spmv_run_length = -1): same operator, so the solves agree to rounding -- checked on
@@ -522,7 +523,8 @@ def test_k_marching_spmv_matches_tile_kernels(name, runlen):
     g = Golden(name)
     out = []
     for rl in (-1, runlen):
-        c = make_ctx(g, spmv_run_length=rl, pressure_preconditioner=PRECOND_DIAGONAL)   # the diagonal loop runs many SpMVs
+        # (the diagonal loop runs many SpMVs; -2 = the pressure SpMV's address-order sweep kernel, which a box of this size would not pick itself)
+        c = make_ctx(g, spmv_run_length=rl, pressure_preconditioner=PRECOND_DIAGONAL)
         c.particles = g["particles0"]
         st = c.substep(g.dt)
         out.append((st, [c.grid(n) for n in "UVW"]))
@@ -551,7 +553,7 @@ def test_k_marching_single_spmv_is_the_same_operator(rowl):
     s.close()
     P[:, 3] = 0.3 * np.sin(9 * P[:, 1]); P[:, 4] = -0.2 * np.cos(7 * P[:, 0]); P[:, 5] = 0.1 * np.sin(5 * P[:, 2] + P[:, 0])
     res = []
-    for rl in (-1, 3, 32):
+    for rl in (-1, 3, 32, -2):   # (-2: the pressure SpMV's address-order sweep; I = 70: 32-lane rows)
         c = capi.Context(I, J, K, dx)
         c.set_solid_sdf(solid)
         c.set_viscosity(3.0)
@@ -571,34 +573,3 @@ def test_k_marching_single_spmv_is_the_same_operator(rowl):
         assert rel_maxnorm(pr, res[0][3]) <= 1e-5
 
 
-@pytest.mark.parametrize("precond", ["diagonal", "multigrid"])
-@pytest.mark.parametrize("period", [3, 4, 5])
-def test_residual_replacement_fires_under_graph_replay(precond, period):
-    """flipv_params.residual_replacement (opt-in): the replacement launches of a REPLAYED chunk re-test the absolute iteration number themselves, so they
-    must sit at every position of the chunk -- round 3 placed them by chunk position, which the directly launched first iteration shifted (period 4: never
-    fired) and which a period that does not divide the chunk length misses on most replays.  The kernel-by-kernel loop launches them where they are due: both
-    must take the SAME path through the solve -- a replacement changes the recurrence, so the iteration counts differ as soon as one of them skips one."""
-    from flipviscosity3d_amd.capi import PRECOND_DIAGONAL, PRECOND_MULTIGRID
-    g = Golden("bunny32_viscous")
-    its = []
-    for no_graph in (0, 1):
-        c = make_ctx(g, viscosity_max_iterations=3000, exact_viscosity_operator=1, residual_replacement=period, no_graph_replay=no_graph,
-                     viscosity_preconditioner=PRECOND_MULTIGRID if precond == "multigrid" else PRECOND_DIAGONAL)
-        c.set_grid("LIQUID_PHI", g["s0_phi"])
-        load_uvw(c, g.uvw(0, "force"))
-        info = c.viscosity_solve(g.dt)
-        assert info["layout"] == 2, info
-        its.append((info["iterations"], [c.grid(n) for n in "UVW"]))
-        c.close()
-    base = make_ctx(g, viscosity_max_iterations=3000, exact_viscosity_operator=1, viscosity_preconditioner=PRECOND_MULTIGRID if precond == "multigrid" else PRECOND_DIAGONAL)
-    base.set_grid("LIQUID_PHI", g["s0_phi"])
-    load_uvw(base, g.uvw(0, "force"))
-    n0 = base.viscosity_solve(g.dt)["iterations"]
-    base.close()
-    print("%s, period %d: %d iterations replayed, %d kernel by kernel, %d without replacement" % (precond, period, its[0][0], its[1][0], n0))
-    assert abs(its[0][0] - its[1][0]) <= 2, its[0][0:1] + its[1][0:1]
-    assert its[0][0] != n0 or its[1][0] == n0        # (the replacements do something: the count moves away from the plain solve's -- in both modes or in neither)
-    masks = fluid_face_masks(g["s0_phi"])
-    num = max(np.abs((a - b)[m]).max() for a, b, m in zip(its[0][1], its[1][1], masks))
-    den = max(np.abs(b[m]).max() for b, m in zip(its[1][1], masks))
-    assert num / den <= 1e-4

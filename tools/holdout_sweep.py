@@ -183,7 +183,7 @@ def prepare_one(args):
     return d["id"], time.time() - t0
 
 
-def run(cache, only):
+def run(cache, only, params=None):
     from flipviscosity3d_amd.capi import Context
     worst = 0.0
     fails = []
@@ -200,6 +200,8 @@ def run(cache, only):
         nu = viscosity_of(d["visc"], I, J, K, dx)
         c = Context(I, J, K, dx)
         c.set_solid_sdf(solid); c.set_viscosity(nu); c.set_gravity(*g)
+        if params:
+            c.set_params(**params)   # (exploration only: the sweep proper runs with NO parameter set)
         c.particles = z["state"]
         st = c.substep(float(np.float32(d["dt"])))
         den = float(z["den"])
@@ -228,6 +230,7 @@ def main():
     ap.add_argument("--cache", default=os.path.join(ROOT, "tools", "holdout_cache"))
     ap.add_argument("--workers", type=int, default=6)
     ap.add_argument("--only", default="")
+    ap.add_argument("--params", default="", help="exploration: k=v,k=v parameter overrides (the sweep proper sets none)")
     a = ap.parse_args()
     only = [int(x) for x in a.only.split(",")] if a.only else []
     if a.cmd == "list":
@@ -243,7 +246,13 @@ def main():
             for i, sec in pool.imap_unordered(prepare_one, todo):
                 print("draw %d prepared in %.0f s" % (i, sec), flush=True)
         return
-    run(a.cache, only)
+    prm = {}
+    for kv in a.params.split(",") if a.params else []:
+        k, v = kv.split("=")
+        prm[k] = float(v) if any(ch in v for ch in ".e") else int(v)
+    if prm:
+        print("# EXPLORATION with", prm)
+    run(a.cache, only, prm)
 
 
 if __name__ == "__main__":

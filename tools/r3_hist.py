@@ -21,7 +21,7 @@ else:
     c = Context(I, J, K, float(z["dx"]))
     c.set_solid_sdf(z["solid"]); c.set_viscosity(z["viscosity"]); c.set_gravity(*[float(v) for v in z["gravity"]])
     P, dt = z["particles0"], float(z["dt"])
-c.set_params(viscosity_layout=lay, viscosity_preconditioner=pre, residual_replacement=rep, verbose=2, exact_viscosity_operator=exact)
+c.set_params(viscosity_layout=lay, viscosity_preconditioner=pre, verbose=2, exact_viscosity_operator=exact)
 c.particles = P
 for t in range(nsub):
     st = c.substep(min(c.cfl(), dt))

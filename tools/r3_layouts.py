@@ -34,7 +34,7 @@ def fixture(name):
             for rep in (0, -1):
                 c = Context(I, J, K, dx)
                 c.set_solid_sdf(z["solid"]); c.set_viscosity(z["viscosity"]); c.set_gravity(*g)
-                c.set_params(viscosity_layout=lv, viscosity_preconditioner=pv, residual_replacement=rep, exact_viscosity_operator=1, check_every=4)
+                c.set_params(viscosity_layout=lv, viscosity_preconditioner=pv, exact_viscosity_operator=1, check_every=4)
                 c.particles = z["particles0"]
                 errs = []
                 for t in range(2):

@@ -13,7 +13,10 @@ from oracle import oraclebind as O
 
 VARIANTS = {
     "default": {},
-    "old": dict(viscosity_velocity_tolerance=-1.0),
+    "old": dict(viscosity_velocity_tolerance=-1.0, viscosity_mass_scale=-1.0),
+    "critonly": dict(viscosity_mass_scale=-1.0),
+    "massonly": dict(viscosity_velocity_tolerance=-1.0),
+    "c1e-4": dict(viscosity_velocity_tolerance=1e-4),
     "eta1e-5": dict(viscosity_velocity_tolerance=1e-5),
     "eta1e-4": dict(viscosity_velocity_tolerance=1e-4),
     "win8": dict(viscosity_velocity_window=8),
