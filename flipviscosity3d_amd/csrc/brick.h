@@ -162,10 +162,10 @@ __device__ __forceinline__ bool d_update_scalars(const PcgScal &sc, int it_arg, 
 // ---- host entry points of k_viscosity_brick.hip
 int fv_build_bricks(flipv_context *c, const Lay &box);     // c->brickList / c->nBricks from c->vMaskB inside the launch box
 int fv_brick_grid(const flipv_context *c, int nbricks, int cap);
-template <typename T> void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot);
+template <typename T> void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot, int first = 0, int count = -1);   // list entries [first, first + count); count < 0: all
 template <typename T> void fv_brick_init(flipv_context *c, const PcgScal &sc);
 template <typename T> void fv_brick_update(flipv_context *c, const PcgScal &sc, int it);
-void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift);
+void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift, int first = 0, int count = -1);
 template <typename T> void fv_brick_replace(flipv_context *c, const PcgScal &sc, int it_arg, int period, int withSigma, float *const z[3], float omega);
 template <typename T> int fv_brick_refine(flipv_context *c, const PcgScal &sc, size_t scalBytes, bool outerExact, int flushMode = 0);
 template <typename T> void fv_brick_flush_settle(flipv_context *c, const PcgScal &sc, bool takeBack);

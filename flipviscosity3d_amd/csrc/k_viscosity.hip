@@ -991,7 +991,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool brick = c->vLayout == VLAYOUT_BRICK;
     if (brick) {
         if ((rc = fv_build_bricks(c, R0))) return rc;
-        c->nActiveV = c->nBricks; c->nIntV = c->comm ? 0 : c->nBricks; c->nRunsV = 0;   // (under a communicator the brick SpMV is one launch AFTER the halo exchange: no interior / cut-face split of the brick list)
+        c->nActiveV = c->nBricks; c->nRunsV = 0;   // (c->nIntV: fv_build_bricks -- under a communicator the bricks interior to the rank's box, listed first; the SpMV and the fine sweeps over them run beside the halo exchange)
     } else {
         rc = fv_build_tiles(c, &c->tgV, c->vwV, 3, c->vDiagU, c->vDiagV, c->vDiagW, c->vRowMask, c->tileListV, &c->nActiveV, &c->nIntV, c->h_flags + 2, 3, &c->mlistV, &c->mlistCapV, 0.90, &c->geoMemoV);
         if (rc) return rc;
@@ -1051,7 +1051,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // this solve is a share of is capped at viscosity_mass_scale x max|u| (100: with viscosity_tolerance = 1e-6 the final target is never above 1e-4 of one full
         // control volume moving at max|u|; 30 and 10 cost 10 % / 30 % more iterations at 256^3 for the same 3e-6 ... 5e-6, profiles/r5/eta_scan_256.log).  flipv_solve_info.rhs_norm stays max|rhs|.
         const double massScale = c->prm.viscosity_mass_scale > 0.0f ? (double)c->prm.viscosity_mass_scale : (c->prm.viscosity_mass_scale < 0.0f ? 0.0 : 100.0);
-        const double bnormEff = (massScale > 0.0 && umaxAll > 0.0 && !c->vMixed64) ? fmin(bnorm, massScale * umaxAll) : bnorm;
+        // (... and never below 3e-2 max|rhs|: a liquid almost at rest next to solid faces that still hold old velocities has max|u| / max|rhs| ~ 1e-5, and a target of
+        // 1e-10 max|rhs| is beyond what fp32 correction stages reach -- 200 substeps of the resting 512 x 256 x 256 sheet: two solves ended short at 1.4e-9)
+        const double bnormEff = (massScale > 0.0 && umaxAll > 0.0 && !c->vMixed64) ? fmin(bnorm, fmax(massScale * umaxAll, 3.0e-2 * bnorm)) : bnorm;
         const double tolFinal = c->prm.viscosity_tolerance * bnormEff;
         double resStart = bnorm;
         int nb = pcg_grid(c, c->nActiveV);
@@ -1142,7 +1144,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         } else if (brick) {
             fv_brick_init<T>(c, sc);
             if ((rc = fv_allreduce_scalars(c, sc.sig(0), NSLOT))) return rc;
-            auto spmv = [&](int, int, int it) { fv_brick_spmv<T>(c, sc, it, !sc.noB); };
+            auto spmv = [&](int first, int count, int it) { fv_brick_spmv<T>(c, sc, it, !sc.noB, first, count); };
             auto update = [&](int it) { fv_brick_update<T>(c, sc, it); };
             auto post = [&](int it) { fv_brick_replace<T>(c, sc, it, replacePeriod, 1, nullptr, 0.0f); };
             if ((rc = pcg_run(c, sc, capNow, sh, 3, c->nIntV, c->nActiveV, spmv, update, &conv, FV_GE_VISCOSITY, post, replacePeriod))) return rc;

@@ -24,14 +24,24 @@
 // flag per brick of the box's brick range and the number of flagged bricks per chunk of 1024: one workgroup per chunk, one thread per brick (its 64
 // mask bytes as four 16-byte loads; consecutive codes of a brick row are consecutive in memory).  (One wave per brick with an atomic per flagged brick on
 // the few dozen chunk counters took 110 us at 256^3.)
-__global__ __launch_bounds__(1024) void k_brick_flags(BrickBox R, Lay LB, const uint8_t *__restrict__ maskB, int *__restrict__ flag, int *__restrict__ chunkCount, int n) {
+// Cut: which bricks are INTERIOR to a rank's owned box -- none of their 8 x 4 x 2 indices lies in the first / last owned entry along an axis that has a neighbour rank on that
+// side, so that no row of theirs reads a halo entry.  want: 0 every active brick, 1 the interior ones, 2 the others (the bricks along the cut faces).
+struct BrickCut { int lo[3], hi[3]; };   // an index p is "inner" along axis a iff lo[a] <= p < hi[a]  (lo = olo + 1 with a lower neighbour, else -inf; hi = ohi - 1 with an upper one)
+__global__ __launch_bounds__(1024) void k_brick_flags(BrickBox R, Lay LB, const uint8_t *__restrict__ maskB, int *__restrict__ flag, int *__restrict__ chunkCount, int n, BrickCut cut, int want) {
     __shared__ int wcount[16];
     const int code = (int)blockIdx.x * 1024 + (int)threadIdx.x;
     bool any = false;
     if (code < n) {
-        const uint4 *m = reinterpret_cast<const uint4 *>(maskB + ((size_t)d_brick_of_code(R, LB, code) << 6));
+        const int brick = d_brick_of_code(R, LB, code);
+        const uint4 *m = reinterpret_cast<const uint4 *>(maskB + ((size_t)brick << 6));
         const uint4 a = m[0], b = m[1], c = m[2], d = m[3];
         any = ((a.x | a.y | a.z | a.w) | (b.x | b.y | b.z | b.w) | (c.x | c.y | c.z | c.w) | (d.x | d.y | d.z | d.w)) != 0u;
+        if (any && want) {
+            int i0, j0, k0;
+            d_brick_ijk(LB, brick, 0, i0, j0, k0);
+            const bool inner = i0 >= cut.lo[0] && i0 + 8 <= cut.hi[0] && j0 >= cut.lo[1] && j0 + 4 <= cut.hi[1] && k0 >= cut.lo[2] && k0 + 2 <= cut.hi[2];
+            any = inner == (want == 1);
+        }
         flag[code] = any ? 1 : 0;
     }
     const unsigned long long bal = __ballot(any);
@@ -88,12 +98,28 @@ int fv_build_bricks(flipv_context *c, const Lay &box) {
     const int n = R.nb[0] * R.nb[1] * R.nb[2];
     const int nchunks = (n + 1023) / 1024;
     int *chunk = c->brickFlag + c->brickCap - nchunks - 1;   // the tail of the flag array: the box's bricks never fill it (padding bricks are never in a box)
-    hipLaunchKernelGGL(k_brick_flags, dim3(nchunks), dim3(1024), 0, c->stream, R, LB, (const uint8_t *)c->vMaskB, c->brickFlag, chunk, n);
-    hipLaunchKernelGGL(k_brick_scan, dim3(1), dim3(1024), 0, c->stream, chunk, nchunks, c->d_flags + 1);
-    hipLaunchKernelGGL(k_brick_scatter, dim3(nchunks), dim3(1024), 0, c->stream, R, LB, (const int *)c->brickFlag, (const int *)chunk, n, c->brickList);
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->nBricks = c->h_flags[1];
+    // Several ranks: the list is [interior bricks | bricks along the cut faces] -- the SpMV and the multigrid's fine-level sweeps run over the first part while the halo of
+    // their input travels on the communication stream, over the second part once it has arrived (fv_viscosity_pcg_mg, vmg_vcycle; c->nIntV = the split).
+    const bool split = c->comm && c->comm->nranks > 1 && !c->prm.no_comm_overlap;
+    BrickCut cut;
+    for (int a = 0; a < 3; a++) {
+        const bool lower = split && c->pcoord[a] > 0, upper = split && c->pcoord[a] + 1 < c->pgrid[a];
+        cut.lo[a] = lower ? c->L.olo[a] + 1 : -(1 << 30);
+        cut.hi[a] = upper ? c->L.ohi[a] - 1 : (1 << 30);
+    }
+    int total = 0;
+    c->nIntV = 0;
+    for (int pass = split ? 1 : 0; pass <= (split ? 2 : 0); pass++) {
+        hipLaunchKernelGGL(k_brick_flags, dim3(nchunks), dim3(1024), 0, c->stream, R, LB, (const uint8_t *)c->vMaskB, c->brickFlag, chunk, n, cut, pass);
+        hipLaunchKernelGGL(k_brick_scan, dim3(1), dim3(1024), 0, c->stream, chunk, nchunks, c->d_flags + 1);
+        hipLaunchKernelGGL(k_brick_scatter, dim3(nchunks), dim3(1024), 0, c->stream, R, LB, (const int *)c->brickFlag, (const int *)chunk, n, c->brickList + total);
+        HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        total += c->h_flags[1];
+        if (pass == 1) c->nIntV = total;
+    }
+    c->nBricks = total;
+    if (!split) c->nIntV = c->comm ? 0 : total;
     return FLIPV_OK;
 }
 
@@ -483,18 +509,20 @@ static int updatev_grid(const flipv_context *c) {
 }
 
 template <typename T>
-void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot) {
-    const bool timed = c->prm.kernel_timing && (it & 7) == 0;
-    if (timed) fv_ev_begin(c, 1, (double)c->nBricks * 64);
+void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot, int first, int count) {
+    if (count < 0) { first = 0; count = c->nBricks; }
+    const bool timed = c->prm.kernel_timing && (it & 7) == 0 && first == 0;
+    if (timed) fv_ev_begin(c, 1, (double)count * 64);
     const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
     const BrickSys<T> v = brick_sys<T>(c);
-    const dim3 g(spmv_grid(c)), b(64, 4, 1);
-    if (rdot) hipLaunchKernelGGL((k_bvisc_spmv<T, true, EPI_SPMV>), g, b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
-    else hipLaunchKernelGGL((k_bvisc_spmv<T, false, EPI_SPMV>), g, b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
+    const dim3 g(fv_brick_grid(c, count, c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : 1280)), b(64, 4, 1);
+    const int *list = (const int *)c->brickList + first;
+    if (rdot) hipLaunchKernelGGL((k_bvisc_spmv<T, true, EPI_SPMV>), g, b, 0, c->stream, list, count, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
+    else hipLaunchKernelGGL((k_bvisc_spmv<T, false, EPI_SPMV>), g, b, 0, c->stream, list, count, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
     if (timed) fv_ev_end(c);
 }
-template void fv_brick_spmv<float>(flipv_context *, const PcgScal &, int, bool);
-template void fv_brick_spmv<double>(flipv_context *, const PcgScal &, int, bool);
+template void fv_brick_spmv<float>(flipv_context *, const PcgScal &, int, bool, int, int);
+template void fv_brick_spmv<double>(flipv_context *, const PcgScal &, int, bool, int, int);
 
 template <typename T>
 void fv_brick_init(flipv_context *c, const PcgScal &sc) {
@@ -511,12 +539,15 @@ template void fv_brick_update<float>(flipv_context *, const PcgScal &, int);
 template void fv_brick_update<double>(flipv_context *, const PcgScal &, int);
 
 // the multigrid's fine-level sweeps (fp32): out = in + omega (r - A in)/d (epi 1; 3 also adds (r, out) into sig(it + sig_shift)), out = r - A in (epi 2)
-void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift) {
+void fv_brick_sweep_f32(flipv_context *c, float *const in[3], float *const out[3], int epi, const PcgScal &sc, int it_arg, float omega, int sig_shift, int first, int count) {
+    if (count < 0) { first = 0; count = c->nBricks; }
+    if (count == 0) return;
     BrickSys<float> v = brick_sys<float>(c);
     for (int m = 0; m < 3; m++) { v.s[m] = in[m]; v.q[m] = out[m]; }
     const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
-    const dim3 g(spmv_grid(c)), b(64, 4, 1);
-#define BSWEEP(E_) hipLaunchKernelGGL((k_bvisc_spmv<float, true, E_>), g, b, 0, c->stream, (const int *)c->brickList, c->nBricks, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it_arg, omega, sig_shift)
+    const dim3 g(fv_brick_grid(c, count, c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : 1280)), b(64, 4, 1);
+    const int *list = (const int *)c->brickList + first;
+#define BSWEEP(E_) hipLaunchKernelGGL((k_bvisc_spmv<float, true, E_>), g, b, 0, c->stream, list, count, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it_arg, omega, sig_shift)
     if (epi == 1) BSWEEP(EPI_JACOBI); else if (epi == 2) BSWEEP(EPI_RESIDUAL); else BSWEEP(EPI_JACOBI_DOT);
 #undef BSWEEP
 }

@@ -1547,11 +1547,20 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
     // with the global hierarchy the fine level is the single domain's too: every sweep reads its input with the neighbours' current values
     const int hl = brick ? 1 : 0;   // (HaloArray::lay)
     auto halo3 = [&](float *const v[3]) { if (s->globalFrom >= 0 && !s->rc) { const HaloArray h[3] = {{v[0], sizeof(float), hl}, {v[1], sizeof(float), hl}, {v[2], sizeof(float), hl}}; s->rc = fv_halo_copy(c, h, 3, 1); } };
-    halo3(s->za);
-    fv_visc_sweep_f32(c, s->za, s->zb, 1, sc, it_spmv, s->w[1], 0);                         // second pre-sweep: za -> zb
+    // A fine-level sweep under a communicator: the 1-entry halo of its input travels on the communication stream while the sweep runs over the bricks interior to the
+    // rank's box; the bricks along the cut faces follow once it has arrived (brick layout: fv_build_bricks lists the interior bricks first; plane layouts: the exchange first).
+    auto sweep = [&](float *const in[3], float *const out[3], int epi, float omega, int sshift) {
+        const bool overlap = brick && s->globalFrom >= 0 && c->comm && c->comm->nranks > 1 && !c->prm.no_comm_overlap && c->nIntV > 0 && !s->rc;
+        if (!overlap) { halo3(in); fv_visc_sweep_f32(c, in, out, epi, sc, it_spmv, omega, sshift); return; }
+        const HaloArray h[3] = {{in[0], sizeof(float), 1}, {in[1], sizeof(float), 1}, {in[2], sizeof(float), 1}};
+        s->rc = fv_halo_copy_begin(c, h, 3, 1);
+        fv_brick_sweep_f32(c, in, out, epi, sc, it_spmv, omega, sshift, 0, c->nIntV);
+        if (!s->rc) s->rc = fv_halo_wait(c);
+        fv_brick_sweep_f32(c, in, out, epi, sc, it_spmv, omega, sshift, c->nIntV, c->nBricks - c->nIntV);
+    };
+    sweep(s->za, s->zb, 1, s->w[1], 0);                                                      // second pre-sweep: za -> zb
     if (!s->lev.empty()) {
-        halo3(s->zb);
-        fv_visc_sweep_f32(c, s->zb, s->t0, 2, sc, it_spmv, 0.0f, 0);                        // t0 = r - A zb
+        sweep(s->zb, s->t0, 2, 0.0f, 0);                                                    // t0 = r - A zb
         const int nl = (int)s->lev.size(), t0 = s->tailFirst;
         const Lay F0 = brick ? c->LB : c->L;
         const int fb = brick ? 1 : 0;
@@ -1656,10 +1665,8 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
 #undef STEP
 #undef STEP_
     }
-    halo3(s->zb);
-    fv_visc_sweep_f32(c, s->zb, s->za, 1, sc, it_spmv, s->w[0], 0);                         // post-sweeps: zb -> za -> zb
-    halo3(s->za);
-    fv_visc_sweep_f32(c, s->za, s->zb, 3, sc, it_spmv, s->w[1], sig_shift);
+    sweep(s->zb, s->za, 1, s->w[0], 0);                                                      // post-sweeps: zb -> za -> zb
+    sweep(s->za, s->zb, 3, s->w[1], sig_shift);
 }
 
 // PCG with the V-cycle as preconditioner.  On entry k_visc_setup has left r = rhs, x = 0, s (= p) = 0 and the tile / brick list;
@@ -1708,8 +1715,16 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     int conv = -1;
     auto iteration = [&](int it, bool replace) -> int {   // it = IT_DEVICE inside the graph
         int r2;
-        if (c->comm && (r2 = fv_halo_copy(c, ph, 3, 1))) return r2;                                  // p on the neighbours' halo entries
-        spmv(c, sc, it == IT_DEVICE ? -1 : it);
+        // p on the neighbours' halo entries -- in the brick layout beside the SpMV over the bricks interior to the rank's box (fv_build_bricks: listed first)
+        if (c->comm && brick && c->comm->nranks > 1 && !c->prm.no_comm_overlap && c->nIntV > 0) {
+            if ((r2 = fv_halo_copy_begin(c, ph, 3, 1))) return r2;
+            fv_brick_spmv<float>(c, sc, it == IT_DEVICE ? -1 : it, false, 0, c->nIntV);
+            if ((r2 = fv_halo_wait(c))) return r2;
+            if (c->nBricks > c->nIntV) fv_brick_spmv<float>(c, sc, it == IT_DEVICE ? -1 : it, false, c->nIntV, c->nBricks - c->nIntV);
+        } else {
+            if (c->comm && (r2 = fv_halo_copy(c, ph, 3, 1))) return r2;
+            spmv(c, sc, it == IT_DEVICE ? -1 : it);
+        }
         if (c->comm && (r2 = fv_allreduce_scalars(c, sc.a(it), NSLOT))) return r2;                    // p.q
         XR(it);
         if (replace) fv_brick_replace<float>(c, sc, it == IT_DEVICE ? -1 : it, replace_period, 0, s->za, s->w[0]);

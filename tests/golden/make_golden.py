@@ -85,7 +85,7 @@ def scene(name, N, boundary, liquid, nu, nsub, dt=0.01, gravity=(0.0, -9.81, 0.0
     s.close()
 
 
-def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inputs=True, nprobe=0, vtol=0.0, store_state=()):
+def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inputs=True, nprobe=0, vtol=0.0, store_state=(), ntop=0, surface_stride=0):
     """End-of-substep dumps only, for scenes at BASELINE sizes whose phase-by-phase dump would be tens of MB:
     inputs (unless the test regenerates them bit for bit with the host library: then a particle count and
     checksums), and per substep the final velocities (whole grids, or `nprobe` seeded probe faces per
@@ -126,13 +126,26 @@ def compact_scene(name, N, boundary, liquid, nu, nsub, vcap, dt=0.01, store_inpu
             d[p + "maxabs_" + c] = np.float32(np.abs(a).max())
             if nprobe:
                 nz = np.flatnonzero(a)                      # probes on faces that carry a velocity
-                idx = np.sort(rng.choice(nz, size=min(nprobe, len(nz)), replace=False))
+                idx = rng.choice(nz, size=min(nprobe, len(nz)), replace=False)
+                flat = a.reshape(-1)
+                if ntop:                                    # ... the faces of largest |u| among them
+                    idx = np.concatenate([idx, nz[np.argsort(np.abs(flat[nz]))[::-1][:ntop]]])
+                if surface_stride:                          # ... and every surface_stride-th face within one cell of the free surface (|phi| < dx at the face's cell)
+                    phi = s.grid("LIQUID_PHI")
+                    near = np.zeros(a.shape, bool)
+                    sl = tuple(slice(0, n) for n in phi.shape)
+                    near[sl] = np.abs(phi) < dx
+                    cand = np.flatnonzero(near.reshape(-1) & (flat != 0))
+                    idx = np.concatenate([idx, cand[::surface_stride]])
+                idx = np.unique(idx)
                 d[p + "probe_idx_" + c] = idx.astype(np.int64)
-                d[p + "probe_val_" + c] = a.reshape(-1)[idx]
+                d[p + "probe_val_" + c] = flat[idx]
             else:
                 d[p + "final_" + c] = a
         Pn = s.particles
         d[p + "particles_sum"] = Pn.astype(np.float64).sum(axis=0)
+        oct_ = (Pn[:, 0] > 0.5).astype(int) + 2 * (Pn[:, 1] > 0.25).astype(int) + 4 * (Pn[:, 2] > 0.5).astype(int)
+        d[p + "particles_octant_sum"] = np.stack([Pn[oct_ == o].astype(np.float64).sum(axis=0) if (oct_ == o).any() else np.zeros(6) for o in range(8)])
         if store_inputs or t in store_state:
             d[p + "particles"] = Pn
         print("  substep %d: viscosity %d its (%.3e), pressure %d its" % (t, st["visc_iters"], st["visc_err"], st["pres_iters"]), flush=True)
@@ -254,6 +267,11 @@ if __name__ == "__main__":
         late_state("bunny128_nu200_late", 128, ("sphere_large.ply", True), ["stanford_bunny.ply"], 200.0, 45)
     if "bunny128_nu5_late" in only:
         late_state("bunny128_nu5_late", 128, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 40)
+    # F2 (round 5): F again with the whole field in view -- 200 000 probe faces per component, the 5 000 of largest |u|, every 4th face within one cell of the free surface,
+    #    per-octant particle checksums ("the headline-size parity is a 3 % sample")
+    if "bunny256_nu5_converged_wide" in only:
+        compact_scene("bunny256_nu5_converged_wide", 256, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 2, vcap=20000,
+                      store_inputs=False, nprobe=200000, ntop=5000, surface_stride=4)
     if "bunny256_nu5_tight" in only:
         compact_scene("bunny256_nu5_tight", 256, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 1, vcap=60000, vtol=1e-8,
                       store_inputs=False, nprobe=20000)
