@@ -615,7 +615,10 @@ def dense_roofline(N, precision, reps=50, **extra):
     pi = c.pressure_solve(0.01)
     out = {"workload": "filled %d^3 box, every interior cell liquid" % N, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "device_copy_GBs": c.bench_copy(1 << 30, 10),
-           "attainable_GBs": {"read": c.bench_stream(0), "copy": c.bench_stream(1), "write": c.bench_stream(2)}}
+           "attainable_GBs": {"read": c.bench_stream(0), "copy": c.bench_stream(1), "write": c.bench_stream(2),
+                              "read_tuned": c.bench_stream(3), "copy_tuned": c.bench_stream(4), "mix_5to1": c.bench_stream(5),
+                              "note": "stencil-free kernels over 1 GiB; *_tuned and mix_5to1 (the pressure SpMV's own five reads : one write) move 16 B per lane with "
+                                      "nontemporal loads/stores from a grid sized to the CUs (flipv_bench_stream modes 3-5)"}}
     for which, name, b, units in ((0, "pressure_spmv", PRES_SPMV_BYTES_PER_CELL, float(pi["rows"])),
                                   (1, "viscosity_spmv", VISC_SPMV_BYTES_PER_INDEX, vi["rows"] / 3.0)):
         ms, swept = c.bench_spmv(which, reps)

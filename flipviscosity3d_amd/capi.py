@@ -511,7 +511,7 @@ class Context:
         return ms.value, cells.value
 
     def bench_stream(self, mode, nbytes=1 << 30, reps=10):
-        """plain streaming kernel: mode 0 read-only, 1 copy, 2 write-only -> GB/s of bytes moved"""
+        """plain streaming kernel: mode 0 read-only, 1 copy, 2 write-only; 3 / 4 / 5 = read / copy / five reads : one write in the tuned form (flipv.h) -> GB/s of bytes moved"""
         g = C.c_double()
         self._chk(self.L.flipv_bench_stream(self.h, C.c_size_t(nbytes), reps, mode, C.byref(g)), "flipv_bench_stream")
         return g.value

@@ -356,7 +356,9 @@ int flipv_synchronize(flipv_context *ctx);
 int flipv_bench_spmv(flipv_context *ctx, int which, int reps, double *ms_out, double *cells_out);
 /* device-to-device copy bandwidth (attainable HBM peak): bytes moved (read+write) per second */
 int flipv_bench_copy(flipv_context *ctx, size_t bytes, int reps, double *gbps_out);
-/* plain streaming kernels on `bytes` of device memory: mode 0 read-only, 1 copy, 2 write-only; GB/s of bytes moved */
+/* plain streaming kernels on `bytes` of device memory: mode 0 read-only, 1 copy, 2 write-only (one float4 per lane, grid = the array);
+ * 3 read-only, 4 copy, 5 five reads : one write -- the pressure SpMV's own byte mix -- in the tuned form (16 B per lane, grid sized to the
+ * CUs, nontemporal loads and stores): the ceiling a stencil kernel of that mix is judged against.  GB/s of bytes moved */
 int flipv_bench_stream(flipv_context *ctx, size_t bytes, int reps, int mode, double *gbps_out);
 
 /* ---- multi-GPU: communicator of a slab decomposition (one context per rank) ----
