@@ -186,6 +186,8 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     c->stream = c->xs = c->commStream = nullptr;
     c->evMain = c->evHalo = nullptr;
     c->evPoll[0] = c->evPoll[1] = nullptr;
+    c->h_pub = c->d_pubMap = c->d_pubSeq = nullptr;
+    c->pubSeq = c->pubUsed = c->pubPendingN = 0;
     c->nIntP = c->nIntV = 0;
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) c->phaseEv[q] = nullptr;
     CHK(hipSetDevice(dev));
@@ -219,6 +221,11 @@ static int create_context(int I, int J, int K, float dx, int dev, const int *cel
     }
     CHK(hipHostMalloc((void **)&c->h_flags, 16 * sizeof(int)));
     memset(c->h_flags, 0, 16 * sizeof(int));
+    CHK(hipHostMalloc((void **)&c->h_pub, (FV_PUB_DATA + FV_PUB_WORDS) * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_pub, 0, (FV_PUB_DATA + FV_PUB_WORDS) * sizeof(int));
+    CHK(hipHostGetDevicePointer((void **)&c->d_pubMap, c->h_pub, 0));
+    CHK(hipMalloc((void **)&c->d_pubSeq, sizeof(int)));
+    CHK(hipMemset(c->d_pubSeq, 0, sizeof(int)));
     // solver tiles over the shared index space
     // the geometry is chosen per solve (fv_build_tiles); flipv_params.tile_rows pins it
     c->tgP = make_tile_grid(L, 64, VW_P);
@@ -335,6 +342,8 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->d_scal) (void)hipFree(c->d_scal);
     if (c->h_scal) (void)hipHostFree(c->h_scal);
     if (c->h_flags) (void)hipHostFree(c->h_flags);
+    if (c->h_pub) (void)hipHostFree(c->h_pub);
+    if (c->d_pubSeq) (void)hipFree(c->d_pubSeq);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) if (c->phaseEv[q]) (void)hipEventDestroy(c->phaseEv[q]);
     if (c->evMain) (void)hipEventDestroy(c->evMain);
@@ -495,7 +504,7 @@ static int read_lattice_box(flipv_context *c, int lat, const float *srcf, const 
     int rc = fv_pack(c, lat, srcf, srcb, c->stage, lo, hi);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(out, c->stage, box_count(lo, hi) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     return FLIPV_OK;
 }
 // host -> device: the ALLOCATED part of the lattice, box-shaped in `in`; entries of the allocated box outside the lattice are zeroed
@@ -505,7 +514,7 @@ static int write_lattice_box(flipv_context *c, int lat, const float *in, float *
     HIPCHK(c, hipMemcpyAsync(c->stage, in, box_count(lo, hi) * 4, hipMemcpyHostToDevice, c->stream));
     int rc = fv_unpack(c, lat, c->stage, dstf, dstb, lo, hi);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     return FLIPV_OK;
 }
 // Full-size Array3d at the ABI.  A single-domain context's box IS the lattice; a block context moves its box only: a read
@@ -541,7 +550,7 @@ static int write_lattice(flipv_context *c, int lat, const float *in, float *dstf
 
 #define NOT_SETUP_ONLY(c) do { if ((c)->setupOnly) { (c)->err = "this context was created by flipv_create_setup: it only serves the scene-setup entry points"; return FLIPV_ERR_INVALID; } } while (0)
 #define ENTER(c) do { if (!(c)) return FLIPV_ERR_INVALID; hipError_t e_ = hipSetDevice((c)->device); if (e_ != hipSuccess) { (c)->err = hipGetErrorString(e_); return FLIPV_ERR_HIP; } } while (0)
-#define SYNC_RET(c, rc) do { int rc__ = (rc); hipError_t e_ = hipStreamSynchronize((c)->stream); if (e_ != hipSuccess) { (c)->err = std::string("stream sync: ") + hipGetErrorString(e_); return FLIPV_ERR_HIP; } return rc__; } while (0)
+#define SYNC_RET(c, rc) do { const int rc__ = (rc); const int rs__ = fv_sync(c); return rs__ ? rs__ : rc__; } while (0)
 
 extern "C" int flipv_read_grid(flipv_context *c, int which, float *out) {
     ENTER(c);
@@ -590,7 +599,7 @@ extern "C" int flipv_read_grid_region(flipv_context *c, int which, const int *lo
     const int rc = fv_pack(c, g.lat, g.f, g.m, c->stage, lo, hi);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(out, c->stage, box_count(lo, hi) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     return FLIPV_OK;
 }
 extern "C" int flipv_write_grid_box(flipv_context *c, int which, const float *in) {
@@ -742,7 +751,7 @@ extern "C" int flipv_upload_particles(flipv_context *c, const float *aos6, size_
     }
     if (n) {
         HIPCHK(c, hipMemcpyAsync(c->particles, aos6, n * 6 * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
     }
     c->np = n;
     c->binsValid = 0;
@@ -755,7 +764,7 @@ extern "C" int flipv_download_particles(flipv_context *c, float *aos6, size_t ca
     if (c->np) {
         if (!aos6) return FLIPV_ERR_INVALID;
         HIPCHK(c, hipMemcpyAsync(aos6, c->particles, c->np * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
     }
     return FLIPV_OK;
 }
@@ -945,7 +954,7 @@ extern "C" int flipv_kernel_stats_get(flipv_context *c, flipv_kernel_stats *out)
 }
 extern "C" int flipv_synchronize(flipv_context *c) {
     ENTER(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     return FLIPV_OK;
 }
 

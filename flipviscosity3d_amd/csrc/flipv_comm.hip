@@ -94,7 +94,7 @@ int fv_check_block_thickness(flipv_context *c, float cfl_number, const char *who
 static int xbuf_reserve(flipv_context *c, size_t bytes) {
     const size_t need = 4 * bytes + 64;
     if (need <= c->xbufCap) return FLIPV_OK;
-    if (c->xbuf) { HIPCHK(c, hipStreamSynchronize(c->xs)); HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->xbuf); c->xbuf = nullptr; c->xbufCap = 0; }
+    if (c->xbuf) { HIPCHK(c, hipStreamSynchronize(c->xs)); FV_SYNC(c); (void)hipFree(c->xbuf); c->xbuf = nullptr; c->xbufCap = 0; }
     const size_t cap = need + need / 4;
     HIPCHK(c, hipMalloc((void **)&c->xbuf, cap));
     c->xbufCap = cap;
@@ -339,7 +339,7 @@ int fv_allreduce_max_f32(flipv_context *c, float *value) {
     int rc = cm->allreduce_sum(c, buf, h.size());
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(h.data(), buf, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     double m = h[0];   // (every rank has written its slot: a true maximum, negative values included)
     for (double v : h) m = v > m ? v : m;
     *value = (float)m;
@@ -355,11 +355,11 @@ int fv_allgather_f64(flipv_context *c, const double *mine, int n, double *all) {
     for (size_t q = 0; q < tot; q++) h[q] = 0.0;
     for (int q = 0; q < n; q++) h[(size_t)cm->rank * n + q] = mine[q];
     HIPCHK(c, hipMemcpyAsync(c->d_gather, h, tot * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // (h is pageable stack memory: the copy must have left it before the all-reduce overwrites nothing of it, and before h dies)
+    FV_SYNC(c);   // (h is pageable stack memory: the copy must have left it before the all-reduce overwrites nothing of it, and before h dies)
     int rc = cm->allreduce_sum(c, c->d_gather, tot);
     if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(all, c->d_gather, tot * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     return FLIPV_OK;
 }
 
@@ -394,7 +394,7 @@ static int migrate_axis(flipv_context *c, int axis) {
     if (rc) return rc;
     unsigned long long h[8];
     HIPCHK(c, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     const size_t nStay = h[0], nToPrev = h[1], nToNext = h[2], nFromPrev = h[4], nFromNext = h[5];
     const size_t nNew = nStay + nFromPrev + nFromNext;
     if (nNew > c->pcap) {  // grow the particle store; contents are rebuilt below
@@ -499,7 +499,7 @@ struct RcclComm : Comm {
     int barrier(flipv_context *c) override {
         int rc = allreduce_sum(c, c->d_scal_small + 32, 1);
         if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         return FLIPV_OK;
     }
 };
@@ -569,21 +569,21 @@ struct LocalComm : Comm {
         std::vector<double> &h = g->red[rank];
         h.resize(n);
         HIPCHK(c, hipMemcpyAsync(h.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         LOCAL_WAIT(c);
         std::vector<double> sum(n, 0.0);
         for (int r = 0; r < g->n; r++)
             for (size_t t = 0; t < n; t++) sum[t] += g->red[r][t];
         LOCAL_WAIT(c);  // everybody has read every contribution
         HIPCHK(c, hipMemcpyAsync(dev, sum.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         return FLIPV_OK;
     }
     int allreduce_sum_f32(flipv_context *c, float *dev, size_t n) override {
         std::vector<float> &h = g->redf[rank];
         h.resize(n);
         HIPCHK(c, hipMemcpyAsync(h.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         LOCAL_WAIT(c);
         std::vector<float> sum(g->redf[0]);   // rank order on every rank: bitwise the same result everywhere
         for (int r = 1; r < g->n; r++) {
@@ -592,11 +592,11 @@ struct LocalComm : Comm {
         }
         LOCAL_WAIT(c);  // everybody has read every contribution
         HIPCHK(c, hipMemcpyAsync(dev, sum.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         return FLIPV_OK;
     }
     int barrier(flipv_context *c) override {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         LOCAL_WAIT(c);
         return FLIPV_OK;
     }

@@ -177,6 +177,10 @@ struct flipv_context {
     hipStream_t xs, commStream;
     hipEvent_t evMain, evHalo;
     hipEvent_t evPoll[2];  // stop-flag read-backs of the PCG loop (two in flight)
+    // small device values the host waits for (fv_read_small): mapped host block [0] = sequence word, [FV_PUB_DATA ..) = data; the device's counter; the host's expectation
+    int *h_pub, *d_pubMap, *d_pubSeq;
+    int pubSeq, pubUsed, pubPendingN;
+    struct PubPending { void *host; int at, words; } pubPending[16];
     float dx;
     int device;
     hipStream_t stream;
@@ -526,6 +530,23 @@ int fv_fill(flipv_context *c, float *p, size_t n, float v);
 // is not a multiple of 8 --, and a substep issued ~100 of them (flags, counters, scalar blocks, accumulators).  byte = the value every byte takes, like memset.
 struct FillJob { void *p; size_t bytes; int byte; };
 int fv_fill_list(flipv_context *c, const FillJob *jobs, int n, hipStream_t st = nullptr);
+// Small device values the host waits for (stop flags, counts, maxima) WITHOUT a copy dispatch: a one-wave kernel stores them into mapped host memory and then bumps a
+// sequence word there; the host spins on that word.  (A 4-byte hipMemcpyAsync device -> host is a blit kernel of ~12 us on this device, and hipStreamSynchronize wakes the
+// host some 10 us after it; a substep issued ~55 such reads.)  words: 4-byte words; <= 6 jobs per call, <= FV_PUB_WORDS words between two waits.
+constexpr int FV_PUB_REPLAY = 8, FV_PUB_DATA = 16, FV_PUB_WORDS = 1008;   // h_pub: [0] sequence | [8, 16) a replayed launch's values | [16 ..) fv_read_small's
+struct ReadJob { void *host; const void *dev; int words; };
+int fv_read_small(flipv_context *c, const ReadJob *jobs, int n);   // enqueue on c->stream
+int fv_read_wait(flipv_context *c);                                 // everything enqueued so far has arrived and sits in the jobs' host locations
+int fv_read_wait_seq(flipv_context *c, int seq);                    // the publication number `seq` (c->pubSeq at the time it was enqueued) has arrived
+// the same for a launch that is CAPTURED and replayed: `words` (<= 8) words from dev to h_pub[FV_PUB_REPLAY ..) at every replay; the host calls fv_read_replayed after each
+// hipGraphLaunch of that graph and then fv_read_wait; the values are then at c->h_pub + FV_PUB_REPLAY
+// the stream's synchronisation point: pending small reads are waited for by spinning (and copied out), then the stream itself (returns at once when it has drained)
+int fv_sync(flipv_context *c);
+#define FV_SYNC(ctx) do { const int rcs_ = fv_sync(ctx); if (rcs_) return rcs_; } while (0)
+#define FV_READ(ctx, host_, dev_, bytes_) do { const ReadJob rj_{(void *)(host_), (const void *)(dev_), (int)((bytes_) / 4)}; const int rcr_ = fv_read_small(ctx, &rj_, 1); if (rcr_) return rcr_; } while (0)
+inline int fv_read_now(flipv_context *c, void *host, const void *dev, int words) { const ReadJob j{host, dev, words}; const int rc = fv_read_small(c, &j, 1); return rc ? rc : fv_read_wait(c); }
+int fv_read_capture(flipv_context *c, const void *dev, int words);
+void fv_read_replayed(flipv_context *c);
 int fv_fill_cells(flipv_context *c, float *p, float v, int halo);
 int fv_fill_cells_liquid(flipv_context *c, float *p, float v, int halo, int site);   // the same over fv_range_liquid
 

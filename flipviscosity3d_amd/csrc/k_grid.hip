@@ -4,6 +4,7 @@
 // (flipv_internal.h): block (64,4,1), grid (ceil(PX/64), ceil(PY/4), PZ), so each global access of a wave is
 // a whole number of aligned 256-byte lines and no integer division is needed to recover (i,j,k).
 // All of these are HBM-bound with 5..20 B per face.
+#include <chrono>
 #include "flipv_internal.h"
 #include "flipv_comm.h"
 
@@ -421,6 +422,78 @@ int fv_fill_list(flipv_context *c, const FillJob *jobs, int n, hipStream_t st) {
     return FLIPV_OK;
 }
 
+// ---- small reads without a copy dispatch (flipv_internal.h: fv_read_small)
+struct PubDev { const int *src[6]; int words[6], at[6], n; };
+__global__ __launch_bounds__(64) void k_publish(PubDev j, int *__restrict__ host, int *__restrict__ seq) {
+    for (int q = 0; q < j.n; q++)
+        for (int w = (int)threadIdx.x; w < j.words[q]; w += 64) __hip_atomic_store(host + j.at[q] + w, j.src[q][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();   // (every lane's stores have landed before lane 0 announces them)
+    if (threadIdx.x == 0) {
+        const int s = (int)((unsigned)*seq + 1u);
+        *seq = s;
+        __hip_atomic_store(host, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+int fv_read_small(flipv_context *c, const ReadJob *jobs, int n) {
+    if (n < 1 || n > 6) { c->err = "fv_read_small: 1..6 jobs"; return FLIPV_ERR_INVALID; }
+    int need = 0;
+    for (int q = 0; q < n; q++) need += jobs[q].words;
+    if (c->pubPendingN + n > 16 || c->pubUsed + need > FV_PUB_WORDS) {
+        const int rc = fv_read_wait(c);
+        if (rc) return rc;
+        if (need > FV_PUB_WORDS) { c->err = "fv_read_small: too many words"; return FLIPV_ERR_INVALID; }
+    }
+    PubDev j;
+    j.n = n;
+    for (int q = 0; q < n; q++) {
+        j.src[q] = (const int *)jobs[q].dev; j.words[q] = jobs[q].words; j.at[q] = FV_PUB_DATA + c->pubUsed;
+        c->pubPending[c->pubPendingN++] = {jobs[q].host, j.at[q], jobs[q].words};
+        c->pubUsed += jobs[q].words;
+    }
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, j, c->d_pubMap, c->d_pubSeq);
+    c->pubSeq = (int)((unsigned)c->pubSeq + 1u);
+    HIPCHK(c, hipGetLastError());
+    return FLIPV_OK;
+}
+int fv_read_capture(flipv_context *c, const void *dev, int words) {
+    PubDev j;
+    j.n = 1; j.src[0] = (const int *)dev; j.words[0] = words; j.at[0] = FV_PUB_REPLAY;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, j, c->d_pubMap, c->d_pubSeq);
+    return hipGetLastError() == hipSuccess ? FLIPV_OK : FLIPV_ERR_HIP;
+}
+void fv_read_replayed(flipv_context *c) { c->pubSeq = (int)((unsigned)c->pubSeq + 1u); }
+int fv_read_wait_seq(flipv_context *c, int want) {
+    auto arrived = [&]() { return (int)((unsigned)__atomic_load_n(c->h_pub, __ATOMIC_ACQUIRE) - (unsigned)want) >= 0; };
+    if (arrived()) return FLIPV_OK;
+    // spin on the mapped word; hand over to the runtime's wait if the device takes long (long kernels in front of the read) or has failed
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        bool ok = false;
+        for (int q = 0; q < 256 && !(ok = arrived()); q++) __builtin_ia32_pause();
+        if (ok) return FLIPV_OK;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (want - c->pubSeq == 0 && !arrived()) { c->err = "fv_read_wait: the stream drained without the published values"; return FLIPV_ERR_HIP; }
+            return FLIPV_OK;
+        }
+    }
+}
+int fv_read_wait(flipv_context *c) {
+    const int rc = fv_read_wait_seq(c, c->pubSeq);
+    if (rc) return rc;
+    for (int q = 0; q < c->pubPendingN; q++)
+        if (c->pubPending[q].host) memcpy(c->pubPending[q].host, c->h_pub + c->pubPending[q].at, (size_t)c->pubPending[q].words * 4);
+    c->pubPendingN = 0;
+    c->pubUsed = 0;
+    return FLIPV_OK;
+}
+
+int fv_sync(flipv_context *c) {
+    if (c->pubPendingN) { const int rc = fv_read_wait(c); if (rc) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FLIPV_OK;
+}
+
 int fv_fill(flipv_context *c, float *p, size_t n, float v) {
     hipLaunchKernelGGL(k_fill_f32, dim3(grid1d(n)), dim3(256), 0, c->stream, p, n, v);
     return FLIPV_OK;
@@ -521,8 +594,8 @@ int fv_cfl(flipv_context *c, float *dt_out) {
     HIPCHK(c, hipMemsetAsync(bits, 0, sizeof(unsigned), c->stream));
     if (c->comm) hipLaunchKernelGGL(k_absmax3_box, GRID3(R), 0, c->stream, R, c->U, c->V, c->W, bits);
     else hipLaunchKernelGGL(k_absmax3, dim3(grid1d(n)), dim3(256), 0, c->stream, c->U + off, c->V + off, c->W + off, n, bits);
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 3, bits, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_READ(c, c->h_flags + 3, bits, sizeof(unsigned));
+    FV_SYNC(c);
     unsigned b = *(unsigned *)(c->h_flags + 3);
     float maxvel;
     memcpy(&maxvel, &b, 4);

@@ -660,8 +660,8 @@ int fv_particle_sdf(flipv_context *c) {
             const int nt = B.nbx * B.nby * B.nbz;
             hipLaunchKernelGGL(k_bin_bbox, dim3(cdiv(nt, 256)), dim3(256), 0, c->stream, B, c->binCnt, bb);
             int h[6];
-            HIPCHK(c, hipMemcpyAsync(h, bb, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            FV_READ(c, h, bb, sizeof(h));
+            FV_SYNC(c);
             if (h[3] >= 0) {
                 mine[0] = 1.0;
                 for (int a = 0; a < 3; a++) {

@@ -430,9 +430,9 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
     if (!split) {
         hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 0, cm,
                            (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
-        HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_READ(c, c->h_flags + 7, c->d_flags + 7, sizeof(int));
+        FV_READ(c, c->h_flags + 1, c->d_flags + 1, sizeof(int));
+        FV_SYNC(c);
         *nActive = *nInterior = c->h_flags[1];
         return FLIPV_OK;
     }
@@ -441,10 +441,10 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
                        (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
     hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 2, cm,
                        (const int *)(c->d_flags + 6), tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 7, c->d_flags + 7, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 6, c->d_flags + 6, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_READ(c, c->h_flags + 7, c->d_flags + 7, sizeof(int));
+    FV_READ(c, c->h_flags + 1, c->d_flags + 1, sizeof(int));
+    FV_READ(c, c->h_flags + 6, c->d_flags + 6, sizeof(int));
+    FV_SYNC(c);
     *nActive = c->h_flags[1];
     *nInterior = c->h_flags[6];
     return FLIPV_OK;
@@ -455,7 +455,7 @@ static int gather_masks(flipv_context *c, const TileGrid &tg, int vw, const uint
                         size_t *cap) {
     if (!mask || !mlist || nActive <= 0) return FLIPV_OK;
     if ((size_t)nActive > *cap) {
-        if (*mlist) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(*mlist); *mlist = nullptr; *cap = 0; }
+        if (*mlist) { FV_SYNC(c); (void)hipFree(*mlist); *mlist = nullptr; *cap = 0; }
         const size_t want = (size_t)nActive + (size_t)nActive / 4 + 64;
         hipError_t e = hipMalloc((void **)mlist, want * 256 * sizeof(unsigned));
         if (e != hipSuccess) { c->err = std::string("hipMalloc(mask list): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
@@ -521,7 +521,7 @@ int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, boo
     const size_t ncand = (size_t)tg.ntx * tg.nty * nchunk;
     auto grow = [&](void **p, size_t *cap, size_t want, size_t elem) -> int {
         if (want <= *cap) return FLIPV_OK;
-        if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(*p); *p = nullptr; *cap = 0; }
+        if (*p) { FV_SYNC(c); (void)hipFree(*p); *p = nullptr; *cap = 0; }
         const size_t n = want + want / 4 + 64;
         hipError_t e = hipMalloc(p, n * elem);
         if (e != hipSuccess) { c->err = std::string("hipMalloc(run list): ") + hipGetErrorString(e); return FLIPV_ERR_OOM; }
@@ -533,8 +533,8 @@ int fv_build_runs(flipv_context *c, const TileGrid &tg, int vw, int nActive, boo
     if ((rc = grow((void **)runs, runCap, ncand, sizeof(Run)))) return rc;
     hipLaunchKernelGGL(k_run_flags, dim3(cdiv(ncand, 256)), dim3(256), 0, c->stream, tg, (const int *)c->tileFlag, 0, nk, JCH, runlen, nchunk, c->runCand);
     hipLaunchKernelGGL(k_run_compact, dim3(1), dim3(1024), 0, c->stream, (const Run *)c->runCand, (int)ncand, *runs, c->d_flags + 12);
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 12, c->d_flags + 12, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_READ(c, c->h_flags + 12, c->d_flags + 12, 2 * sizeof(int));
+    FV_SYNC(c);
     const int n = c->h_flags[12];
     if (n <= 0) return FLIPV_OK;
     if (mask) {
@@ -615,8 +615,8 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const Lay R1 = fv_range_liquid(c, 1, 5);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->dx, dt, c->prm.min_frac);
-    HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FV_READ(c, c->h_flags + 2, c->d_flags + 2, sizeof(int));
+    FV_READ(c, c->h_scal, bmax, sizeof(double));
     rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->pMask, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1, &c->mlistP, &c->mlistCapP, 0.70, &c->geoMemoP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
     c->tileFillP = c->tileFill;
@@ -675,9 +675,9 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     }
     const int last = conv >= 0 ? conv : cap - 1;
     hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax);
-    HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    FV_READ(c, c->h_scal, bmax, sizeof(double));
     if (!f32) hipLaunchKernelGGL(k_copy_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)x, c->pressure, L.n);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    FV_SYNC(c);
     li.iterations = conv >= 0 ? conv + 1 : cap;
     li.residual = c->h_scal[0];
     li.status = conv >= 0 ? 0 : 1;

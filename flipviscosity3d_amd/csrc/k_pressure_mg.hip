@@ -357,7 +357,7 @@ static int mg_allreduce_box(flipv_context *c, MgState *s, const Lay &L, const Pt
     const CutBox &B = s->gbox;
     const size_t n = (size_t)(B.hi[0] - B.lo[0]) * (B.hi[1] - B.lo[1]) * (B.hi[2] - B.lo[2]), tot = n * (size_t)narr;
     if (tot > s->stageCap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         if (s->stage) (void)hipFree(s->stage);
         s->stage = nullptr; s->stageCap = 0;
         hipError_t e = hipMalloc((void **)&s->stage, tot * sizeof(float));
@@ -383,7 +383,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
     MgState *s = (MgState *)c->mgState;
     const bool wantGlobal = c->comm && !c->prm.multigrid_rank_local;
     if (s && s->global != wantGlobal) {   // (a communicator attached, or the switch flipped, after the first solve)
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         fv_mg_free(c);
         s = nullptr;
     }
@@ -434,7 +434,7 @@ static int mg_setup(flipv_context *c, MgState **out) {
         const float om = c->prm.pressure_mg_omega > 0.0f ? c->prm.pressure_mg_omega : 0.9f, ov = c->prm.pressure_mg_overcorrection > 0.0f ? c->prm.pressure_mg_overcorrection : 1.8f;
         const int sw = c->prm.pressure_mg_coarsest_sweeps > 0 ? (c->prm.pressure_mg_coarsest_sweeps + 1) / 2 * 2 : 8;
         if (om != s->omega || ov != s->over || sw != s->sweeps) {
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            FV_SYNC(c);
             HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OMEGA), &om, sizeof(float)));
             HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_OVER), &ov, sizeof(float)));
             HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(MG_COARSEST_SWEEPS), &sw, sizeof(int)));
@@ -454,16 +454,16 @@ static int mg_setup(flipv_context *c, MgState **out) {
             HIPCHK(c, hipMemcpyAsync(s->d_bbox, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
             hipLaunchKernelGGL(k_mg_bbox, MGGRID(C.L), 0, c->stream, C.L, C.diag, s->d_bbox);
             int hb[6];
-            HIPCHK(c, hipMemcpyAsync(hb, s->d_bbox, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            FV_READ(c, hb, s->d_bbox, sizeof(hb));
+            FV_SYNC(c);
             const int nr = c->comm->nranks, me = c->comm->rank;
             std::vector<double> hbx((size_t)6 * nr, 0.0);
             const bool any = hb[3] > hb[0];
             for (int a = 0; a < 3; a++) { hbx[(size_t)6 * me + a] = any ? hb[a] : big; hbx[(size_t)6 * me + 3 + a] = any ? hb[3 + a] : 0; }
             HIPCHK(c, hipMemcpyAsync(s->d_gbox, hbx.data(), hbx.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
             if ((rc = fv_allreduce_scalars(c, s->d_gbox, hbx.size()))) return rc;
-            HIPCHK(c, hipMemcpyAsync(hbx.data(), s->d_gbox, hbx.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            FV_READ(c, hbx.data(), s->d_gbox, hbx.size() * sizeof(double));
+            FV_SYNC(c);
             CutBox g = {{big, big, big}, {0, 0, 0}};
             for (int r = 0; r < nr; r++)
                 for (int a = 0; a < 3; a++) {
@@ -602,22 +602,19 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
             mg_vcycle(c, s, sc, IT_DEVICE);
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, IT_DEVICE));
         }
-        hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        const int e1 = fv_read_capture(c, c->d_flags, 1);   // the stop flag, published to the host at the end of every replay
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
-        if (e1 != hipSuccess || e2 != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); c->err = "multigrid PCG: stream capture failed"; return FLIPV_ERR_HIP; }
+        if (e1 != FLIPV_OK || e2 != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); c->err = "multigrid PCG: stream capture failed"; return FLIPV_ERR_HIP; }
         if ((rc = fv_graph_exec(c, FV_GE_PRESSURE_MG, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
+        if ((rc = fv_read_wait(c))) { (void)hipGraphDestroy(g); return rc; }
         for (; it < cap && conv < 0; it += every) {
             hipError_t el = hipGraphLaunch(ge, c->stream);
-            hipError_t es = hipStreamSynchronize(c->stream);
-            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
-            conv = c->h_flags[0];
+            fv_read_replayed(c);
+            if (el != hipSuccess || fv_read_wait(c) != FLIPV_OK) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+            conv = c->h_pub[FV_PUB_REPLAY];
         }
         (void)hipGraphDestroy(g);
-        if (conv < 0) {   // cap reached: the stop test of the last iteration ran inside k_mgp_p already; nothing left to check
-            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            conv = c->h_flags[0];
-        }
+        // (cap reached: the stop test of the last iteration ran inside k_mgp_p already, and the last replay published its flag)
         HIPCHK(c, hipGetLastError());
         *conv_out = conv;
         return FLIPV_OK;
@@ -639,8 +636,7 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 3 * NSLOT))) return rc;   // max|r| of this iteration, (the unused step slot,) (r,z) of the next
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, devIt ? IT_DEVICE : it));
         }
-        HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if ((rc = fv_read_now(c, c->h_flags, c->d_flags, 1))) return rc;
         conv = c->h_flags[0];
     }
     HIPCHK(c, hipGetLastError());

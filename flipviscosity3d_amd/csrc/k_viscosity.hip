@@ -948,9 +948,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                            c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, (refDiag ? 1 : 0) | (predict ? 2 : 0),
                            brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2], c->phi);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
-        HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));   // max|rhs|, max|u| over the rows
-        HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));  // h_flags[2] = row count
+        FV_READ(c, c->h_scal, bmax, 2 * sizeof(double));   // max|rhs|, max|u| over the rows
+        FV_READ(c, c->h_flags + 2, c->d_flags + 2, sizeof(int));
+        FV_SYNC(c);  // h_flags[2] = row count
         return FLIPV_OK;
     };
     const int rowlNow = c->prm.tile_rows == 16 || c->prm.tile_rows == 64 ? c->prm.tile_rows : c->tgV.rowl;
@@ -1095,12 +1095,12 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             { const int rcr = brick ? fv_brick_refine<T>(c, sc, scalBytes, !refDiag, flushMode) : fv_plane_refine<T>(c, R0, sc, scalBytes, !refDiag, flushMode); if (rcr) return rcr; }   // (several ranks: with the accumulator's halo copy and the all-reduce of max|r|)
             refinements++;
             hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, 0, bmax);
-            HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            FV_READ(c, c->h_scal, bmax, sizeof(double));
             const int keepIncl = sc.tol_inclusive;
             double *dummy;
             { const int rcc = fv_pcg_reset(c, cap, true, &sc, &dummy, nullptr); if (rcc) return rcc; }
             sc.tol_inclusive = keepIncl;
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            FV_SYNC(c);
             res = resStart = c->h_scal[0];
             return FLIPV_OK;
         };
@@ -1167,8 +1167,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         }
         const int last = conv >= 0 ? conv : capNow - 1;
         hipLaunchKernelGGL(k_pcg_residual, dim3(1), dim3(64), 0, c->stream, sc, last, bmax, 1);
-        HIPCHK(c, hipMemcpyAsync(c->h_scal, bmax, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_READ(c, c->h_scal, bmax, 2 * sizeof(double));
+        FV_SYNC(c);
         res = c->h_scal[0];
         if (sc.vel_tol > 0.0) velStep = umaxAll > 0.0 ? c->h_scal[1] / umaxAll : 0.0;   // (the delivering loop's: flipv_solve_info.velocity_step)
         const bool velUnmet = sc.vel_tol > 0.0 && c->h_scal[1] > sc.vel_tol;   // the loop ended (stalled, out of budget) while its last iterations were still moving velocities

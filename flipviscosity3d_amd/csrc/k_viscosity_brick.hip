@@ -113,8 +113,8 @@ int fv_build_bricks(flipv_context *c, const Lay &box) {
         hipLaunchKernelGGL(k_brick_flags, dim3(nchunks), dim3(1024), 0, c->stream, R, LB, (const uint8_t *)c->vMaskB, c->brickFlag, chunk, n, cut, pass);
         hipLaunchKernelGGL(k_brick_scan, dim3(1), dim3(1024), 0, c->stream, chunk, nchunks, c->d_flags + 1);
         hipLaunchKernelGGL(k_brick_scatter, dim3(nchunks), dim3(1024), 0, c->stream, R, LB, (const int *)c->brickFlag, (const int *)chunk, n, c->brickList + total);
-        HIPCHK(c, hipMemcpyAsync(c->h_flags + 1, c->d_flags + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_READ(c, c->h_flags + 1, c->d_flags + 1, sizeof(int));
+        FV_SYNC(c);
         total += c->h_flags[1];
         if (pass == 1) c->nIntV = total;
     }

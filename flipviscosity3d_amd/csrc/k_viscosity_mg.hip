@@ -1205,7 +1205,7 @@ static long box_positions(const Box3 &b) { return (long)(b.hi[0] - b.lo[0]) * (b
 // sum over the ranks of `narr` grids of level A (the first at g0, consecutive ones A.per apart) inside the level's box, through the dense staging buffer
 static int vmg_stage_reserve(flipv_context *c, VmgState *s, size_t tot) {
     if (tot > s->stageCap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         if (s->stage) (void)hipFree(s->stage);
         s->stage = nullptr; s->stageCap = 0;
         hipError_t e = hipMalloc((void **)&s->stage, tot * sizeof(float));
@@ -1241,7 +1241,7 @@ static int vmg_alloc_state(flipv_context *c) {
     VmgState *s = (VmgState *)c->vmgState;
     int rc;
     if (s && (!s->ready || s->minDim != vmg_min_dim(c))) {   // an earlier attempt ran out of memory half way, or another depth is asked for: start over
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_SYNC(c);
         fv_vmg_free(c);
         s = nullptr;
     }
@@ -1334,8 +1334,8 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         if (brick) hipLaunchKernelGGL(k_bvmg_bbox, dim3(64), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->LB, s->d_box);
         else GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL(k_vmg_tile_bbox, dim3(64), dim3(64, 4, 1), 0, c->stream, c->tileListV, c->nActiveV, c->tgV, s->d_box));
         int hb[6];
-        HIPCHK(c, hipMemcpyAsync(hb, s->d_box, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_READ(c, hb, s->d_box, sizeof(hb));
+        FV_SYNC(c);
         Box3 fb;
         const int ext0[3] = {c->L.I + 1, c->L.J + 1, c->L.K + 1};
         bool noRows = false;   // (a rank of a block decomposition without liquid: its one-position stand-in box must not enter the union over the ranks)
@@ -1392,8 +1392,8 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
             for (int a = 0; a < 3; a++) { hbx[(size_t)6 * me + a] = noRows ? 1e9 : G.box.lo[a]; hbx[(size_t)6 * me + 3 + a] = noRows ? -1e9 : G.box.hi[a]; }
             HIPCHK(c, hipMemcpyAsync(s->d_gbox, hbx.data(), hbx.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
             if ((rc = fv_allreduce_scalars(c, s->d_gbox, hbx.size()))) return rc;
-            HIPCHK(c, hipMemcpyAsync(hbx.data(), s->d_gbox, hbx.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            FV_READ(c, hbx.data(), s->d_gbox, hbx.size() * sizeof(double));
+            FV_SYNC(c);
             bool first = true;
             for (int r = 0; r < nr; r++) {
                 if (hbx[(size_t)6 * r] > 1e8) continue;   // a rank without rows
@@ -1484,9 +1484,9 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         hipLaunchKernelGGL(k_vmg_coarsest_rows, dim3(1), dim3(1024), 0, c->stream, dev_of(s->lev.back()), s->d_rowlist, s->d_rowcnt);
         int counts[VMG_MAX_LEVELS];
         int fitsLds = 0;
-        HIPCHK(c, hipMemcpyAsync(&fitsLds, s->d_rowcnt + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        if (s->tailFirst > 0) HIPCHK(c, hipMemcpyAsync(counts, s->d_stripCount, s->tailFirst * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        FV_READ(c, &fitsLds, s->d_rowcnt + 3, sizeof(int));
+        if (s->tailFirst > 0) FV_READ(c, counts, s->d_stripCount, s->tailFirst * sizeof(int));
+        FV_SYNC(c);
         s->coarsestInLds = fitsLds != 0;
         s->w[0] = c->prm.viscosity_mg_omega_first > 0.0f ? c->prm.viscosity_mg_omega_first : VMG_W_DEFAULT[0];
         s->w[1] = c->prm.viscosity_mg_omega_second > 0.0f ? c->prm.viscosity_mg_omega_second : VMG_W_DEFAULT[1];
@@ -1751,21 +1751,22 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         const auto tc0 = std::chrono::steady_clock::now();
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         for (int e = 0; e < every; e++) (void)iteration(IT_DEVICE, may_replace(e));
-        hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        const int e1 = fv_read_capture(c, c->d_flags, 1);   // the stop flag, published to the host at the end of every replay
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
         const auto tc1 = std::chrono::steady_clock::now();
-        if (e1 != hipSuccess || e2 != hipSuccess || !g) {
+        if (e1 != FLIPV_OK || e2 != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
             c->err = "viscosity multigrid: stream capture failed";
             return FLIPV_ERR_HIP;
         }
         if ((rc = fv_graph_exec(c, FV_GE_VISCOSITY_MG, g, &ge))) { (void)hipGraphDestroy(g); return rc; }
         if (c->prm.verbose) fprintf(stderr, "  multigrid loop: stream capture %.3f ms, graph executable %.3f ms (host)\n", std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
+        if ((rc = fv_read_wait(c))) { (void)hipGraphDestroy(g); return rc; }
         for (int done = done0; done < cap && conv < 0; done += every) {
             hipError_t el = hipGraphLaunch(ge, c->stream);
-            hipError_t es = hipStreamSynchronize(c->stream);
-            if (el != hipSuccess || es != hipSuccess) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
-            conv = c->h_flags[0];
+            fv_read_replayed(c);
+            if (el != hipSuccess || fv_read_wait(c) != FLIPV_OK) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
+            conv = c->h_pub[FV_PUB_REPLAY];
         }
         (void)hipGraphDestroy(g);
     } else {
@@ -1774,8 +1775,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
             const int stop = it + every < cap ? it + every : cap;
             for (; it < stop; it++)
                 if ((rc = iteration(it, due_at(it)))) return rc;
-            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if ((rc = fv_read_now(c, c->h_flags, c->d_flags, 1))) return rc;
             conv = c->h_flags[0];
         }
     }

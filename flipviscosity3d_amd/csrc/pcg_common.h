@@ -456,9 +456,9 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
         rc = FLIPV_OK;
         for (int e = 0; e < every && rc == FLIPV_OK; e++) rc = launch_iter(-1, e);
-        hipError_t e1 = hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+        const int e1 = fv_read_capture(c, c->d_flags, 1);   // the stop flag, published to the host at the end of every replay
         hipError_t e2 = hipStreamEndCapture(c->stream, &g);
-        if (rc != FLIPV_OK || e1 != hipSuccess || e2 != hipSuccess || !g) {
+        if (rc != FLIPV_OK || e1 != FLIPV_OK || e2 != hipSuccess || !g) {
             if (g) (void)hipGraphDestroy(g);
             c->err = "pcg_run: stream capture failed";
             return rc != FLIPV_OK ? rc : FLIPV_ERR_HIP;
@@ -469,19 +469,19 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         // from -1 to an iteration number, so whichever replay's copy the host reads is valid; a solve that stops early leaves one
         // replay of launches that return at once behind it.
         {
-            hipEvent_t ev[2] = {c->evPoll[0], c->evPoll[1]};
-            int slot = 0, pending = -1;
+            int pending = 0;   // the publication number of the replay before the one just enqueued (0: none)
             bool bad = false;
+            if ((rc = fv_read_wait(c))) { (void)hipGraphDestroy(g); return rc; }
             for (int done = 0; done < cap && conv < 0; done += every) {
-                bad = bad || hipGraphLaunch(ge, c->stream) != hipSuccess || hipEventRecord(ev[slot], c->stream) != hipSuccess;
-                if (pending >= 0) { bad = bad || hipEventSynchronize(ev[pending]) != hipSuccess; conv = c->h_flags[0]; }
+                bad = bad || hipGraphLaunch(ge, c->stream) != hipSuccess;
+                fv_read_replayed(c);
+                if (pending) { bad = bad || fv_read_wait_seq(c, pending) != FLIPV_OK; conv = __atomic_load_n(c->h_pub + FV_PUB_REPLAY, __ATOMIC_ACQUIRE); }
                 if (bad) break;
-                pending = slot;
-                slot ^= 1;
+                pending = c->pubSeq;
             }
-            bad = bad || hipStreamSynchronize(c->stream) != hipSuccess;
+            bad = bad || fv_read_wait(c) != FLIPV_OK;
             if (bad) { (void)hipGraphDestroy(g); c->err = "hipGraphLaunch failed"; return FLIPV_ERR_HIP; }
-            conv = c->h_flags[0];
+            conv = c->h_pub[FV_PUB_REPLAY];
         }
         (void)hipGraphDestroy(g);
     } else {
@@ -520,8 +520,8 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         if (conv < 0) {  // cap reached: the last iteration's residual has not been merged or tested yet
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(cap - 1), NSLOT))) return rc;
             hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, cap - 1);
-            HIPCHK(c, hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            FV_READ(c, c->h_flags, c->d_flags, sizeof(int));
+            FV_SYNC(c);
             conv = c->h_flags[0];
         }
     }
