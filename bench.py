@@ -616,8 +616,8 @@ def dense_roofline(N, precision, reps=50, **extra):
     out = {"workload": "filled %d^3 box, every interior cell liquid" % N, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "device_copy_GBs": c.bench_copy(1 << 30, 10),
            "attainable_GBs": {"read": c.bench_stream(0), "copy": c.bench_stream(1), "write": c.bench_stream(2),
-                              "read_tuned": c.bench_stream(3), "copy_tuned": c.bench_stream(4), "mix_5to1": c.bench_stream(5),
-                              "note": "stencil-free kernels over 1 GiB; *_tuned and mix_5to1 (the pressure SpMV's own five reads : one write) move 16 B per lane with "
+                              "read_tuned": c.bench_stream(3), "copy_tuned": c.bench_stream(4), "mix_5to1": c.bench_stream(5), "mix_10to3": c.bench_stream(6, nbytes=1 << 29),
+                              "note": "stencil-free kernels over 1 GiB; *_tuned, mix_5to1 (the pressure SpMV's own five reads : one write) and mix_10to3 (the viscosity SpMV's) move 16 B per lane with "
                                       "nontemporal loads/stores from a grid sized to the CUs (flipv_bench_stream modes 3-5)"}}
     for which, name, b, units in ((0, "pressure_spmv", PRES_SPMV_BYTES_PER_CELL, float(pi["rows"])),
                                   (1, "viscosity_spmv", VISC_SPMV_BYTES_PER_INDEX, vi["rows"] / 3.0)):

@@ -94,7 +94,8 @@ class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int), ("residual", C.c_double), ("rhs_norm", C.c_double),
                 ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
                 ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int), ("defect_residual", C.c_double),
-                ("correction_iterations", C.c_int), ("comm_bytes_setup", C.c_double), ("comm_bytes_per_iteration", C.c_double), ("velocity_step", C.c_double), ("correction_status", C.c_int)]
+                ("correction_iterations", C.c_int), ("comm_bytes_setup", C.c_double), ("comm_bytes_per_iteration", C.c_double), ("velocity_step", C.c_double),
+                ("halo_exchanges_per_iteration", C.c_int), ("allreduces_per_iteration", C.c_int), ("correction_status", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -511,7 +512,7 @@ class Context:
         return ms.value, cells.value
 
     def bench_stream(self, mode, nbytes=1 << 30, reps=10):
-        """plain streaming kernel: mode 0 read-only, 1 copy, 2 write-only; 3 / 4 / 5 = read / copy / five reads : one write in the tuned form (flipv.h) -> GB/s of bytes moved"""
+        """plain streaming kernel: mode 0 read-only, 1 copy, 2 write-only; 3 / 4 / 5 / 6 = read / copy / five reads : one write / ten reads : three writes in the tuned form (flipv.h) -> GB/s of bytes moved"""
         g = C.c_double()
         self._chk(self.L.flipv_bench_stream(self.h, C.c_size_t(nbytes), reps, mode, C.byref(g)), "flipv_bench_stream")
         return g.value

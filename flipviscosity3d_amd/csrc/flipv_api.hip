@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_stream(const float4 *__restrict__ a, fl
 // SpMV, 5 x 4 B read + 4 B written per cell): each lane keeps four independent 16-byte accesses in flight, a block walks contiguous 16 KiB chunks, loads
 // and stores are nontemporal (nothing is read twice).  bytes = the size of ONE array; GB/s counts every byte moved.
 typedef float fv_v4f __attribute__((ext_vector_type(4)));
-template <int NREAD, bool WRITE>
+template <int NREAD, int NWRITE>
 __global__ __launch_bounds__(256) void k_stream_tuned(const fv_v4f *__restrict__ a, fv_v4f *__restrict__ b, size_t n, float *__restrict__ sink) {
     fv_v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
     for (size_t base = (size_t)blockIdx.x * 1024; base < n; base += (size_t)gridDim.x * 1024) {
@@ -1026,29 +1026,34 @@ __global__ __launch_bounds__(256) void k_stream_tuned(const fv_v4f *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const size_t t = base + (size_t)u * 256 + threadIdx.x;
-            if (WRITE) { if (t < n) __builtin_nontemporal_store(v[u], b + t); }
-            else acc += v[u];
+            if (NWRITE) {
+                if (t < n) {
+#pragma unroll
+                    for (int m = 0; m < NWRITE; m++) __builtin_nontemporal_store(v[u], b + (size_t)m * n + t);
+                }
+            } else acc += v[u];
         }
     }
-    if (!WRITE && acc.x + acc.y + acc.z + acc.w == 123.456f) *sink = acc.x;
+    if (!NWRITE && acc.x + acc.y + acc.z + acc.w == 123.456f) *sink = acc.x;
 }
 extern "C" int flipv_bench_stream(flipv_context *c, size_t bytes, int reps, int mode, double *gbps_out) {
     ENTER(c);
-    if (!gbps_out || reps < 1 || bytes < 4096 || mode < 0 || mode > 5) return FLIPV_ERR_INVALID;
+    if (!gbps_out || reps < 1 || bytes < 4096 || mode < 0 || mode > 6) return FLIPV_ERR_INVALID;
     void *a = nullptr, *b = nullptr;
-    const int nread = mode == 5 ? 5 : 1;
+    const int nread = mode == 5 ? 5 : (mode == 6 ? 10 : 1), nwrite = mode == 6 ? 3 : 1;
     HIPCHK(c, hipMalloc(&a, bytes * nread));
-    if (hipMalloc(&b, bytes + 64) != hipSuccess) { (void)hipFree(a); c->err = "flipv_bench_stream: out of memory"; return FLIPV_ERR_OOM; }
+    if (hipMalloc(&b, bytes * nwrite + 64) != hipSuccess) { (void)hipFree(a); c->err = "flipv_bench_stream: out of memory"; return FLIPV_ERR_OOM; }
     (void)hipMemsetAsync(a, 0, bytes * nread, c->stream);
     (void)hipMemsetAsync(b, 0, bytes + 64, c->stream);
     const size_t n = bytes / 16;
     const unsigned grid = 256 * 8 * 4;  // 32 blocks per CU
-    float *sink = (float *)((char *)b + bytes);
+    float *sink = (float *)((char *)b + bytes * nwrite);
     auto launch = [&]() {
         if (mode <= 2) hipLaunchKernelGGL(k_stream, dim3(grid), dim3(256), 0, c->stream, (const float4 *)a, (float4 *)b, n, mode, sink);
-        else if (mode == 3) hipLaunchKernelGGL((k_stream_tuned<1, false>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
-        else if (mode == 4) hipLaunchKernelGGL((k_stream_tuned<1, true>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
-        else hipLaunchKernelGGL((k_stream_tuned<5, true>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
+        else if (mode == 3) hipLaunchKernelGGL((k_stream_tuned<1, 0>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
+        else if (mode == 4) hipLaunchKernelGGL((k_stream_tuned<1, 1>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
+        else if (mode == 5) hipLaunchKernelGGL((k_stream_tuned<5, 1>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
+        else hipLaunchKernelGGL((k_stream_tuned<10, 3>), dim3(256 * 8), dim3(256), 0, c->stream, (const fv_v4f *)a, (fv_v4f *)b, n, sink);
     };
     launch();
     hipEvent_t e0, e1;
@@ -1064,7 +1069,7 @@ extern "C" int flipv_bench_stream(flipv_context *c, size_t bytes, int reps, int 
     (void)hipEventDestroy(e1);
     (void)hipFree(a);
     (void)hipFree(b);
-    const double moved = mode == 1 || mode == 4 ? 2.0 : (mode == 5 ? 6.0 : 1.0);
+    const double moved = mode == 1 || mode == 4 ? 2.0 : (mode == 5 ? 6.0 : (mode == 6 ? 13.0 : 1.0));
     *gbps_out = moved * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;
     return FLIPV_OK;
 }

@@ -214,6 +214,7 @@ int fv_halo_copy(flipv_context *c, const HaloArray *arr, int n, int H) {
     Comm *cm = c->comm;
     if (!cm || H <= 0) return FLIPV_OK;
     if (n > HALO_MAXARR) { c->err = "fv_halo_copy: too many arrays"; return FLIPV_ERR_INVALID; }
+    c->nExchanges++;
     const Lay &L = c->L;
     int rc;
     bool anyBrick = false;
@@ -275,6 +276,7 @@ int fv_halo_reduce(flipv_context *c, float *const *arr, int n, int Hlo, int Hhi,
     Comm *cm = c->comm;
     if (!cm) return FLIPV_OK;
     if (n > HALO_MAXARR) { c->err = "fv_halo_reduce: too many arrays"; return FLIPV_ERR_INVALID; }
+    c->nExchanges++;
     const Lay &L = c->L;
     HaloSet hs;
     hs.n = n;
@@ -296,6 +298,7 @@ int fv_halo_level(flipv_context *c, const Lay &LC, const int olo[3], const int o
     Comm *cm = c->comm;
     if (!cm || H <= 0) return FLIPV_OK;
     if (n > HALO_MAXARR) { c->err = "fv_halo_level: too many arrays"; return FLIPV_ERR_INVALID; }
+    c->nExchanges++;
     HaloSet hs;
     hs.n = n;
     for (int a = 0; a < n; a++) { hs.p[a] = arr[a]; hs.elem[a] = 4; hs.lay[a] = 2; }
@@ -319,12 +322,14 @@ int fv_halo_level(flipv_context *c, const Lay &LC, const int olo[3], const int o
 int fv_allreduce_scalars(flipv_context *c, double *dev, size_t n) {
     Comm *cm = c->comm;
     if (!cm) return FLIPV_OK;
+    c->nAllReduces++;
     return cm->allreduce_sum(c, dev, n);
 }
 
 int fv_allreduce_f32(flipv_context *c, float *dev, size_t n) {
     Comm *cm = c->comm;
     if (!cm || n == 0) return FLIPV_OK;
+    c->nAllReduces++;
     return cm->allreduce_sum_f32(c, dev, n);
 }
 

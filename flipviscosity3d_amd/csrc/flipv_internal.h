@@ -241,6 +241,8 @@ struct flipv_context {
     int vmgSweeps = 16;             // Jacobi sweeps on the multigrid's LDS-resident coarsest level for the current solve (viscosity_solve_t picks)
     int vMixed64 = 0;           // the current viscosity solve is precision = FP64 under the multigrid: fp32 Krylov loops refined to the fp64 tolerance
     double vRowsAll = 0.0;      // rows of the current viscosity system over all ranks (viscosity_solve_t's all-gather)
+    long nExchanges = 0, nAllReduces = 0;   // neighbour exchanges (halo copies / reductions, one per call whatever the number of neighbours) and all-reduces issued so far (flipv_comm.hip)
+    int exchIter = 0, allrIter = 0;         // ... by ONE iteration of the current solve's loop (flipv_solve_info::halo_exchanges_per_iteration, allreduces_per_iteration)
     double commBytesSetup = 0.0, commBytesIter = 0.0;   // what the current solve's multigrid all-reduces: once, and per iteration (flipv_solve_info::comm_bytes_*)
     int vmgPackedRows = 1;          // ... and whether its cycle reads the coarse rows in the packed fp16 form (k_viscosity_mg.hip: d_row_dot) or the fp32 grids
     int facValid = 0;               // the factor arrays hold the current layout's values wherever the band was

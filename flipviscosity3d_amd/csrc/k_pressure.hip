@@ -600,6 +600,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
     c->commBytesSetup = c->commBytesIter = 0.0;
+    c->exchIter = c->allrIter = 0;
     const int cap = c->prm.pressure_max_iterations;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
@@ -688,6 +689,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     }
     if (c->prm.kernel_timing) fv_ev_collect(c);
     li.comm_bytes_setup = c->commBytesSetup; li.comm_bytes_per_iteration = c->commBytesIter;
+    li.halo_exchanges_per_iteration = c->exchIter; li.allreduces_per_iteration = c->allrIter;
     if (info) *info = li;
     {
         const HaloArray ph[1] = {{c->pressure, 4}};  // the gradient at plane k0 reads p(k0-1)

@@ -627,6 +627,7 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
     while (it < cap && conv < 0) {
         const int stop = it + every < cap ? it + every : cap;
         for (; it < stop; it++) {
+            const long ex0 = c->nExchanges, ar0 = c->nAllReduces;
             if ((rc = fv_halo_copy(c, ph, 1, 1))) return rc;                                   // p on the neighbours' boundary planes
             spmv(c, sc, devIt ? -1 : it);
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.a(it), NSLOT))) return rc;          // p.q
@@ -635,6 +636,7 @@ int fv_pressure_pcg_mg(flipv_context *c, const PcgScal &sc, int cap, void (*spmv
             if (s->rc) return s->rc;
             if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(it), 3 * NSLOT))) return rc;   // max|r| of this iteration, (the unused step slot,) (r,z) of the next
             GEO_RUN(c->tgP.rowl, hipLaunchKernelGGL(k_mgp_p, dim3(nb), blk, 0, c->stream, c->tileListP, c->nActiveP, c->tgP, c->L, c->pDiag, z, p, sc, devIt ? IT_DEVICE : it));
+            c->exchIter = (int)(c->nExchanges - ex0); c->allrIter = (int)(c->nAllReduces - ar0);
         }
         if ((rc = fv_read_now(c, c->h_flags, c->d_flags, 1))) return rc;
         conv = c->h_flags[0];

@@ -839,6 +839,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     flipv_solve_info li;
     memset(&li, 0, sizeof(li));
     c->commBytesSetup = c->commBytesIter = 0.0;
+    c->exchIter = c->allrIter = 0;
     // (vPerRowFactors: a VARIABLE viscosity field -- the fp64 residual of the two-stage solve then forms the reference's rows with their own factors,
     // visc_rows.h: d_ref_row_factors; k_bresidual on bricks, k_plane_residual_ref on the plane layouts)
     if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
@@ -1263,6 +1264,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     li.refinements = refinements;
     li.defect_residual = defectRes;
     li.comm_bytes_setup = c->commBytesSetup; li.comm_bytes_per_iteration = c->commBytesIter;
+    li.halo_exchanges_per_iteration = c->exchIter; li.allreduces_per_iteration = c->allrIter;
     li.correction_iterations = corrIters;
     li.correction_status = corrStatus;
     li.velocity_step = velStep;

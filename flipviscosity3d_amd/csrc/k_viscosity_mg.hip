@@ -1715,6 +1715,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     int conv = -1;
     auto iteration = [&](int it, bool replace) -> int {   // it = IT_DEVICE inside the graph
         int r2;
+        const long ex0 = c->nExchanges, ar0 = c->nAllReduces;
         // p on the neighbours' halo entries -- in the brick layout beside the SpMV over the bricks interior to the rank's box (fv_build_bricks: listed first)
         if (c->comm && brick && c->comm->nranks > 1 && !c->prm.no_comm_overlap && c->nIntV > 0) {
             if ((r2 = fv_halo_copy_begin(c, ph, 3, 1))) return r2;
@@ -1732,6 +1733,7 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
         if (s->rc) return s->rc;
         if (c->comm && (r2 = fv_allreduce_scalars(c, sc.rmax(it), 3 * NSLOT))) return r2;             // max|r| and max|alpha p| of this iteration, (r, z) of the next
         PP(it);
+        c->exchIter = (int)(c->nExchanges - ex0); c->allrIter = (int)(c->nAllReduces - ar0);
         return FLIPV_OK;
     };
     // where in a chunk of `every` iterations a replacement can fall due (the kernels decide exactly, from the iteration number)

@@ -439,6 +439,7 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         int r;
         (void)e;
         if (!c->comm) { spmv(0, nAct, it); update(it); if (post_due(it)) post(it); return FLIPV_OK; }
+        const long ex0 = c->nExchanges, ar0 = c->nAllReduces;
         if ((r = fv_halo_copy_begin(c, sh, nsh, 1))) return r;
         if (nInt > 0) spmv(0, nInt, it);
         if ((r = fv_halo_wait(c))) return r;
@@ -446,6 +447,7 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
         r = it == 0 ? fv_allreduce_scalars(c, sc.a(0), 3 * NSLOT) : fv_allreduce_scalars(c, sc.rmax(it - 1), 6 * NSLOT);   // [rmax step](it - 1) [sig a b c](it)
         if (r) return r;
         update(it);
+        c->exchIter = (int)(c->nExchanges - ex0); c->allrIter = (int)(c->nAllReduces - ar0);
         return FLIPV_OK;
     };
     const bool graph = !c->comm && !c->prm.kernel_timing && !c->prm.no_graph_replay;

@@ -204,6 +204,8 @@ typedef struct flipv_solve_info {
     double comm_bytes_per_iteration; /* ... and per iteration (that level's right-hand side); 0 on one rank / with the diagonal */
     double velocity_step;      /* viscosity: what the last viscosity_velocity_window iterations of the delivering loop moved, as a share of max|u| (the quantity the velocity
                                   criterion tests; 0 when the criterion is off) */
+    int halo_exchanges_per_iteration; /* several ranks: neighbour exchanges (a halo copy or reduction to all <= 26 neighbours = 1) ... */
+    int allreduces_per_iteration;     /* ... and all-reduces ONE iteration of this solve's (last) loop issued; 0 on one rank */
     int correction_status;     /* 0 no correction stage; 1 the (last) stage reached its target; 2 it ran into its iteration budget or stalled first -- also after the
                                   one restart such a stage gets -- (its result is kept if it lowered the fp64 residual; `status` is then 1); 3 the last stage RAISED the fp64 residual and was taken back
                                   (`status` 1) */
@@ -357,7 +359,7 @@ int flipv_bench_spmv(flipv_context *ctx, int which, int reps, double *ms_out, do
 /* device-to-device copy bandwidth (attainable HBM peak): bytes moved (read+write) per second */
 int flipv_bench_copy(flipv_context *ctx, size_t bytes, int reps, double *gbps_out);
 /* plain streaming kernels on `bytes` of device memory: mode 0 read-only, 1 copy, 2 write-only (one float4 per lane, grid = the array);
- * 3 read-only, 4 copy, 5 five reads : one write -- the pressure SpMV's own byte mix -- in the tuned form (16 B per lane, grid sized to the
+ * 3 read-only, 4 copy, 5 five reads : one write -- the pressure SpMV's own byte mix --, 6 ten reads : three writes -- the viscosity SpMV's -- in the tuned form (16 B per lane, grid sized to the
  * CUs, nontemporal loads and stores): the ceiling a stencil kernel of that mix is judged against.  GB/s of bytes moved */
 int flipv_bench_stream(flipv_context *ctx, size_t bytes, int reps, int mode, double *gbps_out);
 

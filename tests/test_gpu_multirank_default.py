@@ -152,6 +152,11 @@ def test_distributed_level_1_is_the_same_preconditioner(N, dims):
         assert vd["status"] == 0 and vd["preconditioner"] == 1 and vd["layout"] == 2, vd
         assert abs(vd["iterations"] - vr["iterations"]) <= 6 and abs(vg["iterations"] - vr["iterations"]) <= 6, (vr, vg, vd)
         assert vd["comm_bytes_per_iteration"] < 0.3 * vg["comm_bytes_per_iteration"], (vg, vd)
+        # what one iteration issues (flipv_solve_info): p's halo + the four fine sweeps' inputs (+ the distributed level's own exchanges); [p.q] and [max|r|, step, (r, z)]
+        # (+ the global hierarchy's right-hand side).  None on one rank.
+        assert vr["halo_exchanges_per_iteration"] == 0 and vr["allreduces_per_iteration"] == 0, vr
+        assert 5 <= vg["halo_exchanges_per_iteration"] <= 6 and vg["allreduces_per_iteration"] == 3, vg
+        assert vg["halo_exchanges_per_iteration"] < vd["halo_exchanges_per_iteration"] <= 14 and vd["allreduces_per_iteration"] == 3, vd
         got = [assemble(dist, n) for n in "UVW"]
         err = rel_maxnorm3(got, [ref.grid(n) for n in "UVW"])
         print("   velocity difference to the single domain %.2e" % err)

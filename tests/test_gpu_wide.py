@@ -212,3 +212,65 @@ def test_liquid_box_restriction_over_a_long_run():
     # the liquid really travelled
     assert np.abs(a.particles[:, :3].mean(axis=0) - P[:, :3].mean(axis=0)).max() > 5 * dx
     a.close(); b.close()
+
+
+def test_liquid_box_restriction_over_a_long_run_with_default_parameters(oracle):
+    """The same question with NO solver parameter set: the reference's float-rounded operator, AUTO, the two-stage solve and its velocity
+    criterion.  Three contexts per substep from the same particles: a (defaults), a2 (defaults again: what two runs of ONE configuration differ by -- the P2G
+    atomics' summation order) and b (no_liquid_box: every sweep over the whole grid).  Stated bounds, relative max-norm over every face:
+      * a against b: <= 1e-4 on every substep (an entry that was not swept shows as a difference of the order of the velocity itself; measured 1.5e-6 at most --
+        with round 4's rule two runs of ONE configuration differed by 4e-2 where the body meets the wall, which is why the older test above pins the exact operator);
+      * a against a2: printed; a against b must not exceed 20 x the run-to-run figure of the same substep or 1e-4, whichever is larger;
+      * every 8th substep against the oracle run to 1e-13 from the same particles: <= 1e-4 (the parity bar)."""
+    import os
+    from flipviscosity3d_amd import capi, hostapi as H
+    mesh = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshes")
+    N = 64
+    dx = float(np.float32(1.0 / N))
+    s = H.FluidSimulation()
+    s.initialize(N, N, N, dx)
+    s.addBoundary(H.load_ply(os.path.join(mesh, "sphere_large.ply")), True)
+    s.setSeeding(H.FluidSimulation.SEED_COUNTER, 2)
+    s.addLiquid(H.load_ply(os.path.join(mesh, "stanford_bunny.ply")))
+    solid, P = s.solid_sdf(), s.particles
+    s.close()
+    P[:, 3:] = np.array([0.9, -2.5, 0.6], np.float32)
+    ctx = [capi.Context(N, N, N, dx) for _ in range(3)]
+    a, a2, b = ctx
+    b.set_params(no_liquid_box=1)
+    for c in ctx:
+        c.set_solid_sdf(solid); c.set_viscosity(0.5)
+    a.particles = P
+    d_ab, d_aa, d_or = [], [], []
+    for t in range(40):
+        Pa = a.particles
+        ua = [a.grid(n) for n in "UVW"]
+        for c in (a2, b):
+            c.particles = Pa
+            for n, g in zip("UVW", ua):
+                c.set_grid(n, g)
+        dt = min(a.cfl(), 0.01)
+        sa, sa2, sb = a.substep(dt), a2.substep(dt), b.substep(dt)
+        assert sa["viscosity"]["status"] == 0 and sb["viscosity"]["status"] == 0, (t, sa, sb)
+        assert sa["viscosity"]["rows"] == sb["viscosity"]["rows"] and sa["pressure"]["rows"] == sb["pressure"]["rows"], t
+        assert np.array_equal(a.grid("LIQUID_PHI"), b.grid("LIQUID_PHI")), t
+        va, va2, vb = ([c.grid(n) for n in "UVW"] for c in (a, a2, b))
+        d_ab.append(rel_maxnorm3(va, vb)); d_aa.append(rel_maxnorm3(va, va2))
+        assert d_ab[-1] <= 1e-4, (t, d_ab[-1])
+        assert d_ab[-1] <= max(20.0 * d_aa[-1], 1e-4), (t, d_ab[-1], d_aa[-1])
+        if t % 8 == 7:
+            o = oracle.OracleSim(N, N, N, dx)
+            o.set_solid(solid); o.set_viscosity(0.5)
+            o.set_solver_limits(vmaxiter=3000000, vtol=1e-13, ptol=1e-13)
+            o.particles = Pa
+            for n, g in zip("UVW", ua):
+                o.set_grid(n, g)
+            o.substep(dt)
+            d_or.append(rel_maxnorm3(va, [o.grid(n) for n in "UVW"]))
+            o.close()
+    print("default parameters, 40 substeps: a vs no_liquid_box max %.2e median %.2e | two runs of one configuration max %.2e median %.2e | against the converged oracle %s"
+          % (max(d_ab), float(np.median(d_ab)), max(d_aa), float(np.median(d_aa)), ["%.1e" % e for e in d_or]))
+    assert max(d_or) <= 1e-4, d_or
+    assert np.abs(a.particles[:, :3].mean(axis=0) - P[:, :3].mean(axis=0)).max() > 5 * dx
+    for c in ctx:
+        c.close()

@@ -78,3 +78,4 @@ v, p = out[0]["viscosity"], out[0]["pressure"]
 print("viscosity solve: layout %d, preconditioner %d, %d iterations (%d in correction stages), status %d / %d; all-reduced by the global hierarchy: %.2f MB once per solve, %.3f MB per iteration" % (
     v["layout"], v["preconditioner"], v["iterations"], v["correction_iterations"], v["status"], v["correction_status"], v["comm_bytes_setup"] / 1e6, v["comm_bytes_per_iteration"] / 1e6))
 print("pressure solve: %d iterations; all-reduced: %.2f MB once per solve, %.3f MB per iteration" % (p["iterations"], p["comm_bytes_setup"] / 1e6, p["comm_bytes_per_iteration"] / 1e6))
+print("one iteration issues: viscosity %d neighbour exchanges + %d all-reduces, pressure %d + %d" % (v["halo_exchanges_per_iteration"], v["allreduces_per_iteration"], p["halo_exchanges_per_iteration"], p["allreduces_per_iteration"]))
