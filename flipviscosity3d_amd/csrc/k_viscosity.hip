@@ -1376,8 +1376,9 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
     c->prm.kernel_timing = 0;
     PcgScal sc;
     memset(&sc, 0, sizeof(sc));
-    if (c->vLayout == VLAYOUT_BRICK) {   // the brick kernel (the variant the solve runs: beta from the residual unless flipv_params.beta_from_conjugacy)
-        const bool rdot = c->prm.beta_from_conjugacy == 0;
+    if (c->vLayout == VLAYOUT_BRICK) {   // the brick kernel, in the variant the last solve's loop launched: with the fused (r, q) dots in the diagonal loop
+        // (unless flipv_params.beta_from_conjugacy), q = A p and p.q alone in the multigrid loop
+        const bool rdot = c->prm.beta_from_conjugacy == 0 && c->vLastPrec != 2;
         for (int w = 0; w < 3; w++) { if (c->viscosityPrec) fv_brick_spmv<double>(c, sc, 0, rdot); else fv_brick_spmv<float>(c, sc, 0, rdot); }
         HIPCHK(c, hipEventRecord(a, c->stream));
         for (int r = 0; r < reps; r++) { if (c->viscosityPrec) fv_brick_spmv<double>(c, sc, 0, rdot); else fv_brick_spmv<float>(c, sc, 0, rdot); }
