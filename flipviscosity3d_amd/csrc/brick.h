@@ -35,6 +35,43 @@ __device__ __forceinline__ NbOff d_lane_off(int sby, int sbz) {
     return o;
 }
 
+// x-neighbours inside a brick WITHOUT a load.  A brick is two halves of 4 x 4 x 2 (lanes 0..31: x = 0..3, lanes 32..63: x = 4..7), x fastest inside a half: the value at
+// x - 1 / x + 1 sits in the lane's own quad, or -- at the seam between the halves -- in the other half's quad (v_permlane32_swap + a DPP quad permute), or in the neighbouring
+// brick: only the 8 lanes of a brick face load it (`edge`).  (13 of the SpMV's 46 loads per lane are x-shifted; a load whose lanes straddle two bricks costs the vector cache
+// two passes: with them the launch on the bench scene takes 12.4 us, with the shifted addresses replaced by aligned ones 10.1.)
+typedef unsigned fv_v2u __attribute__((ext_vector_type(2)));
+// v_permlane32_swap of a register with itself: .x = the LOWER half's values in both halves (what an upper-half lane needs from lane l - 32), .y = the UPPER half's in
+// both (what a lower-half lane needs from lane l + 32) -- no select: d_xm reads the other half only from upper-half lanes, d_xp only from lower-half lanes
+__device__ __forceinline__ fv_v2u d_halves_u(unsigned v) { return __builtin_amdgcn_permlane32_swap(v, v, false, false); }
+template <int CTRL> __device__ __forceinline__ unsigned d_quad_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+// both x-neighbours of a value at once: lo = the value at x - 1, hi = at x + 1 (same j, k); eL / eR = what a lane of the brick's x = 0 / x = 7 face loaded
+// quad_perm [0,0,1,2] = 0x90, [3,3,3,3] = 0xFF, [1,2,3,3] = 0xF9, [0,0,0,0] = 0x00
+__device__ __forceinline__ void d_xnb(float v, float eL, float eR, float &lo, float &hi) {
+    const unsigned u = __float_as_uint(v);
+    const fv_v2u hv = d_halves_u(u);
+    const int li = (int)threadIdx.x & 3;
+    const bool upper = ((int)threadIdx.x & 32) != 0;
+    // (every shuffle as an unconditional statement: inside a ?: it would run under the lanes' branch, and a DPP read of an inactive lane returns nothing)
+    const float ql = __uint_as_float(d_quad_u<0x90>(u)), hl = __uint_as_float(d_quad_u<0xFF>(hv.x));
+    const float qh = __uint_as_float(d_quad_u<0xF9>(u)), hh = __uint_as_float(d_quad_u<0x00>(hv.y));
+    lo = li ? ql : (upper ? hl : eL);
+    hi = li < 3 ? qh : (upper ? eR : hh);
+}
+__device__ __forceinline__ void d_xnb(double v, double eL, double eR, double &lo, double &hi) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned l = (unsigned)b, h = (unsigned)(b >> 32);
+    const fv_v2u hl = d_halves_u(l), hh = d_halves_u(h);
+    const int li = (int)threadIdx.x & 3;
+    const bool upper = ((int)threadIdx.x & 32) != 0;
+    auto pack = [](unsigned a, unsigned c) { return __longlong_as_double((long long)(((unsigned long long)c << 32) | a)); };
+    const double ql = pack(d_quad_u<0x90>(l), d_quad_u<0x90>(h)), sl = pack(d_quad_u<0xFF>(hl.x), d_quad_u<0xFF>(hh.x));
+    const double qh = pack(d_quad_u<0xF9>(l), d_quad_u<0xF9>(h)), sh = pack(d_quad_u<0x00>(hl.y), d_quad_u<0x00>(hh.y));
+    lo = li ? ql : (upper ? sl : eL);
+    hi = li < 3 ? qh : (upper ? eR : sh);
+}
+template <typename T> __device__ __forceinline__ T d_xm(T v, T e) { T lo, hi; d_xnb(v, e, e, lo, hi); return lo; }
+template <typename T> __device__ __forceinline__ T d_xp(T v, T e) { T lo, hi; d_xnb(v, e, e, lo, hi); return hi; }
+
 // the system's arrays, all in the brick layout
 template <typename T>
 struct BrickSys {

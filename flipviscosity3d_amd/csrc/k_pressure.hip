@@ -413,7 +413,7 @@ static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **ext
     sc->stall_below = 0.0;
     sc->stalled = c->d_flags + 11;
     sc->bestIt = c->d_flags + 14;
-    sc->vel_tol = 0.0; sc->vel_window = 0; sc->vel_patience = 48; sc->passIt = c->d_flags + 15;   // (the velocity criterion: set by the viscosity solve for its last loop)
+    sc->vel_tol = 0.0; sc->vel_stall = 0.0; sc->vel_window = 0; sc->vel_patience = 48; sc->passIt = c->d_flags + 15;   // (the velocity criterion: set by the viscosity solve for its last loop)
     *extra = c->d_scal + FV_NSC * n;
 }
 

@@ -1132,6 +1132,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             const double eta = c->prm.viscosity_velocity_tolerance > 0.0f ? (double)c->prm.viscosity_velocity_tolerance : (c->prm.viscosity_velocity_tolerance < 0.0f ? 0.0 : 3.0e-5);
             sc.vel_tol = (lastLoop && !c->vMixed64) ? eta * umaxAll : 0.0;
             sc.vel_window = c->prm.viscosity_velocity_window > 0 ? c->prm.viscosity_velocity_window : 4;
+            sc.vel_stall = c->prm.viscosity_velocity_stall_ratio > 0.0f ? (double)c->prm.viscosity_velocity_stall_ratio : (c->prm.viscosity_velocity_stall_ratio < 0.0f ? 0.0 : 0.5);
         }
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
         // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the
@@ -1192,6 +1193,16 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                 fprintf(stderr, " %d:%.2e", it, m / bnorm);
             }
             fprintf(stderr, "\n");
+            if (sc.vel_tol > 0.0) {   // what each iteration moved (max|alpha p| over the rows the substep uses), relative to max|u|
+                fprintf(stderr, "  step history (relative to max|u| = %.3g; criterion: %d iterations together <= %.1e):", umaxAll, sc.vel_window, umaxAll > 0.0 ? sc.vel_tol / umaxAll : 0.0);
+                for (int it = 0; it < itersNow && it < capNow; it++) {
+                    double m = 0.0;
+                    for (int bk = 0; bk < sc.nbank; bk++)
+                        for (int q = 0; q < NSLOT; q++) m = fmax(m, c->h_scal[(size_t)bk * stride + (size_t)it * FV_NSC * NSLOT + 5 * NSLOT + q]);
+                    fprintf(stderr, " %d:%.1e", it, umaxAll > 0.0 ? m / umaxAll : 0.0);
+                }
+                fprintf(stderr, "\n");
+            }
             // the energy the iterations added to the iterate: |x_k+1|_A^2 - |x_k|_A^2 = alpha_k sigma_k = sigma_k^2 / (p_k, A p_k)   (Hestenes-Stiefel)
             fprintf(stderr, "  energy terms alpha sigma:");
             for (int it = 0; it < itersNow && it < capNow; it++) {

@@ -142,25 +142,44 @@ __global__ __launch_bounds__(256) void k_bvisc_spmv(const int *__restrict__ bric
     const NbOff o = d_lane_off(v.sby, v.sbz);
     const T *__restrict__ xu = v.s[0], *__restrict__ xv = v.s[1], *__restrict__ xw = v.s[2];
     double da = 0.0, db = 0.0, dc = 0.0;
+    const bool faceL = ((int)threadIdx.x & 35) == 0, faceR = ((int)threadIdx.x & 35) == 35;   // the brick's two x faces: x = 0 (lower half, li = 0), x = 7 (upper half, li = 3)
     while (w.valid()) {
         const size_t a = w.a;
         const unsigned m = w.m;
         w.next(bricks, nb, v.mask);
-        if (m == 0u) continue;
-        // every load of the lane first (46 independent loads; a lane without rows issues none)
-        const float C0 = fC[a], C0l = fC[a + o.xm], Cjm = fC[a + o.ym], Ckm = fC[a + o.zm];
-        const float EW0 = fEW[a], EW0r = fEW[a + o.xp], EWjp = fEW[a + o.yp];
-        const float EV0 = fEV[a], EV0r = fEV[a + o.xp], EVkp = fEV[a + o.zp];
+        if (!__any(m != 0u)) continue;   // (wave-uniform: the lane shuffles below need every lane of a brick that holds rows)
+        // Every load first.  The ten values an x-neighbour may need come from EVERY lane of the brick (the same wave instructions and cache lines as before) ...
+        const float C0 = fC[a], EW0 = fEW[a], EV0 = fEV[a];
+        const T U0 = xu[a], V0 = xv[a], W0 = xw[a];
+        const T Ujm = xu[a + o.ym], Ukm = xu[a + o.zm], Vjp = xv[a + o.yp], Wkp = xw[a + o.zp];
+        // ... what lies across an x face of the brick from the 8 + 8 lanes of the two faces, a left and a right quantity per instruction ...
+        float e1 = 0.0f, e2 = 0.0f;
+        T e3 = (T)0, e4 = (T)0, e5 = (T)0, e6 = (T)0, e7 = (T)0;
+        if (faceL || faceR) {
+            const int ox = faceL ? o.xm : o.xp;
+            e1 = (faceL ? fC : fEW)[a + ox];                                   // C0l | EW0r
+            e2 = fEV[a + ox];                                                  //     | EV0r
+            e3 = xu[a + ox]; e4 = xv[a + ox]; e5 = xw[a + ox];                 // U0l V0l W0l | U0r V0r W0r
+            e6 = faceL ? xv[a + o.yp + ox] : xu[a + o.ym + ox];                // Vjpl | Ujmr
+            e7 = faceL ? xw[a + o.zp + ox] : xu[a + o.zm + ox];                // Wkpl | Ukmr
+        }
+        // ... and the other 23, unpredicated (a brick with rows is loaded whole: zero-initialised values under a per-lane branch cost 60 moves per lane, and the kernel
+        // is bound by VALU issue as much as by the vector cache -- ~320 VALU instructions per brick on 12.5 waves per SIMD).
+        const float Cjm = fC[a + o.ym], Ckm = fC[a + o.zm];
+        const float EWjp = fEW[a + o.yp], EVkp = fEV[a + o.zp];
         const float EU0 = fEU[a], EUjp = fEU[a + o.yp], EUkp = fEU[a + o.zp];
-        const T U0 = xu[a], U0l = xu[a + o.xm], U0r = xu[a + o.xp], Ujm = xu[a + o.ym], Ujp = xu[a + o.yp], Ukm = xu[a + o.zm], Ukp = xu[a + o.zp];
-        const T Ujmr = xu[a + o.ym + o.xp], Ukmr = xu[a + o.zm + o.xp];
-        const T V0 = xv[a], V0l = xv[a + o.xm], V0r = xv[a + o.xp], Vjm = xv[a + o.ym], Vjp = xv[a + o.yp], Vkm = xv[a + o.zm], Vkp = xv[a + o.zp];
-        const T Vjpl = xv[a + o.yp + o.xm], Vjpkm = xv[a + o.yp + o.zm];
-        const T W0 = xw[a], W0l = xw[a + o.xm], W0r = xw[a + o.xp], Wjm = xw[a + o.ym], Wjp = xw[a + o.yp], Wkm = xw[a + o.zm], Wkp = xw[a + o.zp];
-        const T Wkpl = xw[a + o.zp + o.xm], Wjmkp = xw[a + o.ym + o.zp];
+        const T Ujp = xu[a + o.yp], Ukp = xu[a + o.zp];
+        const T Vjm = xv[a + o.ym], Vkm = xv[a + o.zm], Vkp = xv[a + o.zp], Vjpkm = xv[a + o.yp + o.zm];
+        const T Wjm = xw[a + o.ym], Wjp = xw[a + o.yp], Wkm = xw[a + o.zm], Wjmkp = xw[a + o.ym + o.zp];
         const float MU = (m & 1u) ? vmU[a] : -1.0f, MV = (m & 2u) ? vmV[a] : -1.0f, MW = (m & 4u) ? vmW[a] : -1.0f;
         RT<T> RU = (RT<T>)0, RV = (RT<T>)0, RW = (RT<T>)0;
         if (RDOT) { RU = v.r[0][a]; RV = v.r[1][a]; RW = v.r[2][a]; }
+        // x - 1 / x + 1 by lane shuffles inside the brick (brick.h: d_xm, d_xp); every lane takes part
+        const float C0l = d_xm(C0, e1), EW0r = d_xp(EW0, e1), EV0r = d_xp(EV0, e2);
+        T U0l, U0r, V0l, V0r, W0l, W0r;
+        d_xnb(U0, e3, e3, U0l, U0r); d_xnb(V0, e4, e4, V0l, V0r); d_xnb(W0, e5, e5, W0l, W0r);
+        const T Vjpl = d_xm(Vjp, e6), Ujmr = d_xp(Ujm, e6), Wkpl = d_xm(Wkp, e7), Ukmr = d_xp(Ukm, e7);
+        // (no per-lane exit: a lane without rows carries -1 in all three volumes, d_visc_rows gives it y = 0 and no share of the sums, and nothing is stored)
         Vec<T, 1> yU, yV, yW;
         T ta = (T)0, tb = (T)0, tc = (T)0;
 #define V1F(x_) Vec<float, 1>{{x_}}

@@ -146,6 +146,7 @@ struct PcgScal {
     // cell: their near-rigid modes have residual = mass x error -- and there CG is still moving velocities by 1e-4 of their maximum per iteration when
     // the residual test passes (64^3 bunny resting on the wall at nu = 200: 2.7e-4 from the converged reference at 2.4e-6 max|rhs|; profiles/r5).
     double vel_tol;
+    double vel_stall;   // > 0: the loop also ends once its residual has passed and the window's movement is >= vel_stall x the previous window's, within 10 x vel_tol (d_steps_small)
     int vel_window;
     int vel_patience;   // the criterion holds a loop whose residual has passed for at most this many further iterations (then the loop ends as converged; flipv_solve_info.velocity_step says what was left)
     int *passIt;        // device: 1 + the iteration at which the residual test first passed while the velocity criterion did not (0: not yet); the int behind bestIt
@@ -294,21 +295,26 @@ __device__ __forceinline__ bool d_steps_small(const PcgScal &sc, int it_last, do
     const int tid = d_tid256();
     const int passed = sc.passIt ? *sc.passIt - 1 : -1;   // (stored + 1: zero = not yet)   // (written by an EARLIER launch, or in this one by block 0 with this very it_last: every block decides alike either way)
     if (tid < 64) {
-        double sum = 0.0;
-        for (int w = 0; w < sc.vel_window; w++) {
+        double sum = 0.0, before = 0.0;   // this window's movement; the window before it (only where the stall exit is on and the loop is old enough)
+        const int nw = sc.vel_stall > 0.0 && it_last + 1 >= 2 * sc.vel_window ? 2 * sc.vel_window : sc.vel_window;
+        for (int w = 0; w < nw; w++) {
             const int j = it_last - w;
             if (j < 0) break;
             double v = tid < NSLOT ? sc.slot_max(sc.step(j), tid) : 0.0;
 #pragma unroll
             for (int off = NSLOT / 2; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, NSLOT));
-            sum += v;
+            if (w < sc.vel_window) sum += v; else before += v;
         }
-        if (tid == 0) lds8[7] = sum;
+        if (tid == 0) { lds8[7] = sum; lds8[6] = nw > sc.vel_window ? before : -1.0; }
     }
     __syncthreads();
-    const double s = lds8[7];
+    const double s = lds8[7], sb = lds8[6];
     __syncthreads();
     if (s <= sc.vel_tol) return true;
+    // The movement has stopped shrinking (this window >= vel_stall x the window before it) within 10 x the tolerance: what still moves is a part the system does not
+    // determine at this precision -- massless fringe rows, a speck -- and CG goes on moving it by 1e-5 ... 1e-3 max|u| per iteration while max|r| falls by three more
+    // orders (256^3 bunny on the wall, 40 % of the substeps: profiles/r5/step_history_256.log).  More iterations add nothing there but a random walk of those rows.
+    if (sc.vel_stall > 0.0 && sb >= 0.0 && s <= 10.0 * sc.vel_tol && s >= sc.vel_stall * sb) return true;
     // A light speck whose velocity the system barely determines keeps CG moving it for ever: the criterion holds the loop for vel_patience iterations past
     // the residual test, no longer.
     if (passed >= 0 && it_last - passed >= sc.vel_patience) return true;
