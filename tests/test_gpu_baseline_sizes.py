@@ -251,8 +251,18 @@ def converged_probe_run(name, N, variant, vel_tol=VEL_TOL, precision=0):
         print("%s %s substep %d: %d iterations, velocity error %.3e (reference: %d iterations)" % (name, variant, t, st["viscosity"]["iterations"], num / den, int(g["s%d_visc_iters" % t])))
         assert num / den <= vel_tol, (t, num / den)
         # particle checksums: mean position within 1e-6, mean velocity within 1e-5
-        d = np.abs(c.particles.astype(np.float64).sum(axis=0) - g["s%d_particles_sum" % t]) / len(P)
+        Pn = c.particles
+        d = np.abs(Pn.astype(np.float64).sum(axis=0) - g["s%d_particles_sum" % t]) / len(P)
         assert d[:3].max() <= 1e-6 and d[3:].max() <= 1e-5, d
+        if "s%d_particles_octant_sum" % t in g.z.files:   # per-octant checksums (make_golden.py compact_scene): mean position within 1e-6, mean velocity within 1e-5 of an octant's particles
+            oct_ = (Pn[:, 0] > 0.5).astype(int) + 2 * (Pn[:, 1] > 0.25).astype(int) + 4 * (Pn[:, 2] > 0.5).astype(int)
+            ref = g["s%d_particles_octant_sum" % t]
+            for o in range(8):
+                n = int((oct_ == o).sum())
+                if n < 1000:   # (a handful of particles next to an octant's border may sit on the other side of it)
+                    continue
+                do = np.abs(Pn[oct_ == o].astype(np.float64).sum(axis=0) - ref[o]) / n
+                assert do[:3].max() <= 5e-6 and do[3:].max() <= 5e-5, (t, o, n, do)
     c.close()
 
 
@@ -283,6 +293,17 @@ def test_config3_headline_256_converged_reference_probes(variant):
     if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged.npz")):
         pytest.skip("fixture not built")
     converged_probe_run("bunny256_nu5_converged", 256, variant, vel_tol=2.5e-4 if variant == "exact_operator" else VEL_TOL)
+
+
+def test_config3_headline_256_whole_field_probes():
+    """The same comparison with the whole field in view (tests/golden/make_golden.py bunny256_nu5_converged_wide): ~337 000 probe faces per
+    component and substep -- 200 000 seeded ones, the 5 000 of largest |u|, every 4th face within one cell of the free surface -- and per-octant particle checksums.
+    NO parameter set: <= 1e-4."""
+    import os
+    from helpers import GOLDEN
+    if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged_wide.npz")):
+        pytest.skip("fixture not built")
+    converged_probe_run("bunny256_nu5_converged_wide", 256, "default")
 
 
 @pytest.mark.parametrize("variant", ["default", "two_correction_stages", "fp64_diagonal", "exact_operator"])

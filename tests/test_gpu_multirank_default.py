@@ -77,9 +77,11 @@ def test_headline_256_default_blocks_against_the_converged_reference(dims):
     """BASELINE configs[2] ITSELF (256^3 bunny drop, nu = 5) on 1 x 1 x 2 slabs and 2 x 2 x 2 blocks, NO parameter set, two chained substeps
     against the reference run to convergence (bunny256_nu5_converged: 7 689 / 13 160 reference iterations), 20 000 probe faces per component:
     <= 1e-4, every solve converged inside the stock cap, the two-stage solve on every rank."""
-    if not os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged.npz")):
+    # (the whole-field fixture where it is built -- ~337 000 probe faces per component incl. the 5 000 of largest |u| and the free surface at a stride -- else the 20 000-probe one)
+    name = "bunny256_nu5_converged_wide" if os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged_wide.npz")) else "bunny256_nu5_converged"
+    if not os.path.exists(os.path.join(GOLDEN, name + ".npz")):
         pytest.skip("fixture not built")
-    g = Golden("bunny256_nu5_converged")
+    g = Golden(name)
     N = 256
     dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
     assert len(P) == int(g["nparticles"]) and np.array_equal(P.astype(np.float64).sum(axis=0), g["particles0_sum"])

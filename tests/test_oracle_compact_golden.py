@@ -96,6 +96,27 @@ def test_bunny256_scene_setup_matches_reference():
     assert np.float64(solid.astype(np.float64).sum()) == g["solid_sum"]
 
 
+def test_bunny256_whole_field_fixture_is_the_same_reference_run():
+    """bunny256_nu5_converged_wide (round 5: ~337 000 probe faces per component -- 200 000 seeded, the 5 000 of largest |u|, every 4th face within one cell of the
+    free surface -- and per-octant particle checksums) is the SAME reference run as bunny256_nu5_converged: same scene, same iteration counts, and bit-identical
+    velocities on every probe face the two fixtures share; its probes reach the top of the velocity range."""
+    if not (os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged.npz")) and os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_converged_wide.npz"))):
+        pytest.skip("fixtures not built")
+    a, b = Golden("bunny256_nu5_converged"), Golden("bunny256_nu5_converged_wide")
+    assert b.dims() == (256, 256, 256) and np.array_equal(a["particles0_sum"], b["particles0_sum"]) and a["solid_sum"] == b["solid_sum"]
+    for t in range(2):
+        assert int(a["s%d_visc_iters" % t]) == int(b["s%d_visc_iters" % t]) and int(a["s%d_pres_iters" % t]) == int(b["s%d_pres_iters" % t])
+        assert np.array_equal(a["s%d_particles_sum" % t], b["s%d_particles_sum" % t])
+        assert np.allclose(b["s%d_particles_octant_sum" % t].sum(axis=0), b["s%d_particles_sum" % t], rtol=1e-12)
+        for c in "UVW":
+            ia, ib = a["s%d_probe_idx_%s" % (t, c)], b["s%d_probe_idx_%s" % (t, c)]
+            assert len(ib) >= 200000 and len(np.unique(ib)) == len(ib)
+            common, pa, pb = np.intersect1d(ia, ib, return_indices=True)
+            assert len(common) > 50
+            assert np.array_equal(a["s%d_probe_val_%s" % (t, c)][pa], b["s%d_probe_val_%s" % (t, c)][pb])
+            assert float(np.abs(b["s%d_probe_val_%s" % (t, c)]).max()) == float(b["s%d_maxabs_%s" % (t, c)])   # (the largest |u| IS among the probes)
+
+
 STIFF = [("bunny64_nu3000", 64, ("sphere_large.ply", True), ["stanford_bunny.ply"]),
          ("honey96_nu1422", 96, None, ["rod.ply", "sheet.ply"])]
 
