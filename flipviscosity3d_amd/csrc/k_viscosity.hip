@@ -1132,7 +1132,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             const double eta = c->prm.viscosity_velocity_tolerance > 0.0f ? (double)c->prm.viscosity_velocity_tolerance : (c->prm.viscosity_velocity_tolerance < 0.0f ? 0.0 : 3.0e-5);
             sc.vel_tol = (lastLoop && !c->vMixed64) ? eta * umaxAll : 0.0;
             sc.vel_window = c->prm.viscosity_velocity_window > 0 ? c->prm.viscosity_velocity_window : 4;
-            sc.vel_stall = c->prm.viscosity_velocity_stall_ratio > 0.0f ? (double)c->prm.viscosity_velocity_stall_ratio : (c->prm.viscosity_velocity_stall_ratio < 0.0f ? 0.0 : 0.5);
+            sc.vel_stall = c->prm.viscosity_velocity_stall_ratio > 0.0f ? (double)c->prm.viscosity_velocity_stall_ratio : 0.0;   // (off by default: flipv.h)
         }
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
         // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the

@@ -84,8 +84,7 @@ enum flipv_precision {
  *                            (zero included); a stage that RAISES the fp64 residual is taken back, one that ends short of its target is restarted once
  *   the delivering loop      (a correction stage, its restart, or the one loop of a solve without stages) also needs the VELOCITY CRITERION: its last
  *                            viscosity_velocity_window (4) iterations together moved no velocity the substep uses by more than viscosity_velocity_tolerance (3e-5) x max|u|;
- *                            -- or, within 10 x that, this window's movement is no smaller than viscosity_velocity_stall_ratio (0.5) x the window's before it: what
- *                            still moves is then a part the system does not determine (massless fringe rows, a speck), and more iterations only walk it about;
+ *                            (held for at most 48 iterations past the residual test; optional early way out: viscosity_velocity_stall_ratio, off by default);
  *                            a loop the stall guard stops with the criterion unmet is restarted from the fp64 residual
  *   status                   0 = every stage reached its target; 1 = cap / stalled / a stage ended short or was taken back (the result is applied, like the reference's
  *                            accepted iterate); flipv_solve_info: residual (stage 1's), defect_residual = max|b - A_ref x| delivered, velocity_step, correction_* */
@@ -152,11 +151,13 @@ typedef struct flipv_params {
                                                anything about the bulk, whose near-rigid motions have residual = volume x error: round 4's rule left 3e-4 ... 9e-4 of max|u| on
                                                25 000 - 80 000 faces of the 256^3 bunny from the impact on (profiles/r5/eta_scan_256.log).  100 x 1e-6 = the final residual never
                                                above 1e-4 of a full control volume moving at max|u| */
-    float viscosity_velocity_stall_ratio;   /* [0.5; -1 = off] the velocity criterion's second way out: the residual has passed, the last window moved the velocities by no more
-                                               than 10 x viscosity_velocity_tolerance, and by no less than this ratio x what the window before it moved.  On the 256^3 bunny
-                                               lying on the wall 40 % of the solves end like this: the movement stays at 2e-5 ... 4e-4 max|u| per iteration -- on rows the system
-                                               barely determines -- while max|r| falls three more orders; before round 5's second half those solves ran 48 iterations on
-                                               (profiles/r5/step_history_256.log) */
+    float viscosity_velocity_stall_ratio;   /* [0 = off] OPT-IN early way out of the velocity criterion: the residual has passed, the last window moved the velocities by no more than
+                                               10 x viscosity_velocity_tolerance, and by no less than this ratio (e.g. 0.5) x what the window before it moved.  On the 256^3 bunny lying
+                                               on the wall 40 % of the solves sit on such a plateau -- 2e-5 ... 4e-4 max|u| per iteration on rows the system barely determines, while
+                                               max|r| falls three more orders (profiles/r5/step_history_256.log) -- and run out the criterion's patience of 48 iterations: with 0.5 the
+                                               first 400 substeps of that scene take 14.6 instead of 15.9 ms.  NOT the default: a plateau can also be a light part CG has not resolved YET
+                                               (64^3, nu = 0.5, one substep of the impact: 9.5e-4 from the converged reference with the exit, 1e-6 without) and nothing in the
+                                               iteration's history tells the two apart */
 } flipv_params;
 
 /* Switches for A/B measurements, profiling and tests (flipv_set_debug_params).  Results do not depend on them beyond solver tolerance; none of them is needed to

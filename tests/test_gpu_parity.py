@@ -501,7 +501,7 @@ def test_set_params_rejects_out_of_range_values():
            ("exact_viscosity_operator", 2), ("viscosity_layout", 4), ("tile_rows", 32), ("viscosity_mg_coarsest_sweeps", -3),
            ("pressure_mg_omega", float("nan")), ("viscosity_mg_omega_first", 2.5), ("verbose", 3), ("multigrid_distributed_levels", 2), ("grid_cap", -1),
            ("viscosity_lane_width", 3), ("spmv_run_length", 1), ("viscosity_stage1_factor", 0.5), ("viscosity_stage2_factor", 0.75), ("viscosity_stage2_rounds", 17), ("viscosity_stage2_max_iterations", 701),
-           ("viscosity_mg_coarsest_sweeps", 65), ("viscosity_velocity_tolerance", -0.5), ("viscosity_velocity_window", 9), ("viscosity_mass_scale", -2.0),
+           ("viscosity_mg_coarsest_sweeps", 65), ("viscosity_velocity_tolerance", -0.5), ("viscosity_velocity_window", 9), ("viscosity_mass_scale", -2.0), ("viscosity_velocity_stall_ratio", 1.5), ("viscosity_velocity_stall_ratio", -1.0),
            ("viscosity_two_stage_max_stiffness", -1.0), ("viscosity_defect_predictor", 1), ("viscosity_defect_predictor", -2)]
     before = c.get_params()
     for field, value in bad:
