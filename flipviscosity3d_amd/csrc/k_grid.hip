@@ -471,7 +471,7 @@ int fv_read_wait_seq(flipv_context *c, int want) {
         bool ok = false;
         for (int q = 0; q < 256 && !(ok = arrived()); q++) __builtin_ia32_pause();
         if (ok) return FLIPV_OK;
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2500)) {   // (a replayed chunk of four multigrid-PCG iterations takes ~1 ms at 256^3)
             HIPCHK(c, hipStreamSynchronize(c->stream));
             if (want - c->pubSeq == 0 && !arrived()) { c->err = "fv_read_wait: the stream drained without the published values"; return FLIPV_ERR_HIP; }
             return FLIPV_OK;
