@@ -546,6 +546,9 @@ int fv_read_wait_seq(flipv_context *c, int seq);                    // the publi
 int fv_sync(flipv_context *c);
 #define FV_SYNC(ctx) do { const int rcs_ = fv_sync(ctx); if (rcs_) return rcs_; } while (0)
 #define FV_READ(ctx, host_, dev_, bytes_) do { const ReadJob rj_{(void *)(host_), (const void *)(dev_), (int)((bytes_) / 4)}; const int rcr_ = fv_read_small(ctx, &rj_, 1); if (rcr_) return rcr_; } while (0)
+// (several adjacent reads as ONE publishing launch)
+#define FV_READ_JOBS(ctx, ...) do { const ReadJob rjs_[] = {__VA_ARGS__}; const int rcr_ = fv_read_small(ctx, rjs_, (int)(sizeof(rjs_) / sizeof(rjs_[0]))); if (rcr_) return rcr_; } while (0)
+#define FV_JOB(host_, dev_, bytes_) ReadJob{(void *)(host_), (const void *)(dev_), (int)((bytes_) / 4)}
 inline int fv_read_now(flipv_context *c, void *host, const void *dev, int words) { const ReadJob j{host, dev, words}; const int rc = fv_read_small(c, &j, 1); return rc ? rc : fv_read_wait(c); }
 int fv_read_capture(flipv_context *c, const void *dev, int words);
 void fv_read_replayed(flipv_context *c);

@@ -430,8 +430,7 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
     if (!split) {
         hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 0, cm,
                            (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
-        FV_READ(c, c->h_flags + 7, c->d_flags + 7, sizeof(int));
-        FV_READ(c, c->h_flags + 1, c->d_flags + 1, sizeof(int));
+        FV_READ_JOBS(c, FV_JOB(c->h_flags + 7, c->d_flags + 7, sizeof(int)), FV_JOB(c->h_flags + 1, c->d_flags + 1, sizeof(int)));
         FV_SYNC(c);
         *nActive = *nInterior = c->h_flags[1];
         return FLIPV_OK;
@@ -441,9 +440,7 @@ static int build_tiles_once(flipv_context *c, const TileGrid &tg, int vw, int nc
                        (const int *)nullptr, tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
     hipLaunchKernelGGL(k_tile_compact, dim3(1), dim3(1024), 0, c->stream, c->tileFlag, nt, list, c->d_flags + 1, tg, 0, nk, 2, cm,
                        (const int *)(c->d_flags + 6), tg.rowl * vw, geo_ty(tg.rowl), c->L.I + 1, c->L.J + 1, c->d_flags + 7);
-    FV_READ(c, c->h_flags + 7, c->d_flags + 7, sizeof(int));
-    FV_READ(c, c->h_flags + 1, c->d_flags + 1, sizeof(int));
-    FV_READ(c, c->h_flags + 6, c->d_flags + 6, sizeof(int));
+    FV_READ_JOBS(c, FV_JOB(c->h_flags + 7, c->d_flags + 7, sizeof(int)), FV_JOB(c->h_flags + 1, c->d_flags + 1, sizeof(int)), FV_JOB(c->h_flags + 6, c->d_flags + 6, sizeof(int)));
     FV_SYNC(c);
     *nActive = c->h_flags[1];
     *nInterior = c->h_flags[6];
@@ -616,8 +613,7 @@ static int pressure_solve_t(flipv_context *c, float dt, flipv_solve_info *info) 
     const Lay R1 = fv_range_liquid(c, 1, 5);  // one halo plane: s is zeroed there, the coefficients towards it are the neighbour's business
     hipLaunchKernelGGL(k_pressure_setup<T>, GRID3(R1), 0, c->stream, R1, c->phi, c->U, c->V, c->W, c->wU, c->wV, c->wW,
                        c->pDiag, c->pPi, c->pPj, c->pPk, (RT<T> *)c->pR, x, (T *)c->pS, c->pMask, bmax, c->d_flags + 2, c->dx, dt, c->prm.min_frac);
-    FV_READ(c, c->h_flags + 2, c->d_flags + 2, sizeof(int));
-    FV_READ(c, c->h_scal, bmax, sizeof(double));
+    FV_READ_JOBS(c, FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int)), FV_JOB(c->h_scal, bmax, sizeof(double)));
     rc = fv_build_tiles(c, &c->tgP, VW_P, 1, c->pDiag, nullptr, nullptr, c->pMask, c->tileListP, &c->nActiveP, &c->nIntP, c->h_flags + 2, 1, &c->mlistP, &c->mlistCapP, 0.70, &c->geoMemoP);  // synchronises: h_scal[0] = max|b|
     if (rc) return rc;
     c->tileFillP = c->tileFill;

@@ -949,8 +949,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                            c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, (refDiag ? 1 : 0) | (predict ? 2 : 0),
                            brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2], c->phi);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
-        FV_READ(c, c->h_scal, bmax, 2 * sizeof(double));   // max|rhs|, max|u| over the rows
-        FV_READ(c, c->h_flags + 2, c->d_flags + 2, sizeof(int));
+        FV_READ_JOBS(c, FV_JOB(c->h_scal, bmax, 2 * sizeof(double)), FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int)));   // max|rhs|, max|u| over the rows; the row count
         FV_SYNC(c);  // h_flags[2] = row count
         return FLIPV_OK;
     };

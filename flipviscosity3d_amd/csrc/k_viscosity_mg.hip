@@ -1484,8 +1484,8 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
         hipLaunchKernelGGL(k_vmg_coarsest_rows, dim3(1), dim3(1024), 0, c->stream, dev_of(s->lev.back()), s->d_rowlist, s->d_rowcnt);
         int counts[VMG_MAX_LEVELS];
         int fitsLds = 0;
-        FV_READ(c, &fitsLds, s->d_rowcnt + 3, sizeof(int));
-        if (s->tailFirst > 0) FV_READ(c, counts, s->d_stripCount, s->tailFirst * sizeof(int));
+        if (s->tailFirst > 0) FV_READ_JOBS(c, FV_JOB(&fitsLds, s->d_rowcnt + 3, sizeof(int)), FV_JOB(counts, s->d_stripCount, s->tailFirst * sizeof(int)));
+        else FV_READ(c, &fitsLds, s->d_rowcnt + 3, sizeof(int));
         FV_SYNC(c);
         s->coarsestInLds = fitsLds != 0;
         s->w[0] = c->prm.viscosity_mg_omega_first > 0.0f ? c->prm.viscosity_mg_omega_first : VMG_W_DEFAULT[0];
