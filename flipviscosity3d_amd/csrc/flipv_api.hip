@@ -403,6 +403,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!(p->viscosity_velocity_tolerance == -1.0f || fin(p->viscosity_velocity_tolerance, 0.0f, 1.0f)) || !in(p->viscosity_velocity_window, 0, 8)) bad = "viscosity_velocity_tolerance (-1, or 0 ... 1) / viscosity_velocity_window (0 ... 8)";
         else if (!(p->viscosity_mass_scale == -1.0f || fin(p->viscosity_mass_scale, 0.0f, 1e9f))) bad = "viscosity_mass_scale (-1, or >= 0)";
         else if (!fin(p->viscosity_velocity_stall_ratio, 0.0f, 1.0f)) bad = "viscosity_velocity_stall_ratio (0 .. 1)";
+        else if (!fin(p->viscosity_mass_floor, 0.0f, 1.0f)) bad = "viscosity_mass_floor (0 .. 1)";
         if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     }
     static_cast<flipv_params &>(c->prm) = *p;

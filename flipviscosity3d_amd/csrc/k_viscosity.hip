@@ -1053,7 +1053,12 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const double massScale = c->prm.viscosity_mass_scale > 0.0f ? (double)c->prm.viscosity_mass_scale : (c->prm.viscosity_mass_scale < 0.0f ? 0.0 : 100.0);
         // (... and never below 3e-2 max|rhs|: a liquid almost at rest next to solid faces that still hold old velocities has max|u| / max|rhs| ~ 1e-5, and a target of
         // 1e-10 max|rhs| is beyond what fp32 correction stages reach -- 200 substeps of the resting 512 x 256 x 256 sheet: two solves ended short at 1.4e-9)
-        const double bnormEff = (massScale > 0.0 && umaxAll > 0.0 && !c->vMixed64) ? fmin(bnorm, fmax(massScale * umaxAll, 3.0e-2 * bnorm)) : bnorm;
+        // ... and the floor grows with the stiffness: what an fp32 correction stage reaches scales with |A| ~ S.  256^3 honey (S = 32 768) settling on the floor, floor 0.03:
+        // the stage's target is 9e-8 max|rhs|, 26 ... 86 of 330 solves run out of its 200 iterations and their one restart (status 1, 250-440 iterations); floor 0.3: 2 of 330,
+        // 20 % less time, the late states within 4e-5 of the tightened solve either way (profiles/r5/mass_floor_scan.log).  At S = 3 277 (256^3 bunny, nu = 5) the floor stays
+        // 0.033: there 0.3 would loosen the bulk from < 1e-5 to 7e-5.
+        const double massFloor = c->prm.viscosity_mass_floor > 0.0f ? (double)c->prm.viscosity_mass_floor : fmax(3.0e-2, fmin(0.3, fmin(1.0e-5 * stiffSolve, 1.0e4 / fmax(stiffSolve, 1.0))));   // (1e-6 x floor x S, the bound on the bulk's relative error, stays <= 1e-2: holdout draw 7, S = 2.1e5, is 1.0e-4 at 0.3 and 3e-5 at 0.03)
+        const double bnormEff = (massScale > 0.0 && umaxAll > 0.0 && !c->vMixed64) ? fmin(bnorm, fmax(massScale * umaxAll, massFloor * bnorm)) : bnorm;
         const double tolFinal = c->prm.viscosity_tolerance * bnormEff;
         double resStart = bnorm;
         int nb = pcg_grid(c, c->nActiveV);

@@ -71,7 +71,7 @@ enum flipv_precision {
 };
 
 /* THE DEFAULT VISCOSITY SOLVE, stated once (k_viscosity.hip: viscosity_solve_t implements this table; DESIGN.md 4 gives the measurements behind every number).
- *   S = nu_max dt/dx^2, the a-priori stiffness (all ranks).                     N = the norm every tolerance is a share of = min(max|rhs|, viscosity_mass_scale x max|u|)
+ *   S = nu_max dt/dx^2, the a-priori stiffness (all ranks).                     N = the norm every tolerance is a share of = min(max|rhs|, max(viscosity_mass_scale x max|u|, viscosity_mass_floor x max|rhs|))
  *   preconditioner (AUTO)    S <= 8: diagonal PCG on the reference's operator A_ref (one loop to viscosity_tolerance x N).   S > 8: Galerkin multigrid V(2,2), unless
  *                            the previous solve shows the diagonal to converge for less; a diagonal solve AUTO picked that hits the cap is repeated with the multigrid
  *   under the multigrid      defect correction towards A_ref = A + E (E: the rounding of the reference's float diagonal; with a viscosity FIELD also its per-row edge factors):
@@ -151,6 +151,9 @@ typedef struct flipv_params {
                                                anything about the bulk, whose near-rigid motions have residual = volume x error: round 4's rule left 3e-4 ... 9e-4 of max|u| on
                                                25 000 - 80 000 faces of the 256^3 bunny from the impact on (profiles/r5/eta_scan_256.log).  100 x 1e-6 = the final residual never
                                                above 1e-4 of a full control volume moving at max|u| */
+    float viscosity_mass_floor;             /* [0 = by stiffness: max(0.03, min(0.3, 1e-5 S, 1e4 / S))] ... and N is never below this share of max|rhs|: a liquid almost at rest next to solid faces
+                                               that still hold old velocities has max|u| / max|rhs| ~ 1e-5, and what an fp32 correction stage reaches scales with S: 256^3 honey
+                                               (S = 32 768) settling on the floor ran 26 ... 86 of 330 solves out of their stage budget at 0.03, 2 at 0.3 (profiles/r5/mass_floor_scan.log) */
     float viscosity_velocity_stall_ratio;   /* [0 = off] OPT-IN early way out of the velocity criterion: the residual has passed, the last window moved the velocities by no more than
                                                10 x viscosity_velocity_tolerance, and by no less than this ratio (e.g. 0.5) x what the window before it moved.  On the 256^3 bunny lying
                                                on the wall 40 % of the solves sit on such a plateau -- 2e-5 ... 4e-4 max|u| per iteration on rows the system barely determines, while

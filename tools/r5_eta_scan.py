@@ -23,7 +23,10 @@ VAR = [("tight", dict(precision=1, viscosity_tolerance=1e-9, pressure_rel_tolera
        ("default (3e-5, 100)", {}),
        ("3e-5, mass scale 30", dict(viscosity_mass_scale=30.0)),
        ("3e-5, mass scale 10", dict(viscosity_mass_scale=10.0)),
-       ("1e-4, mass scale 100", dict(viscosity_velocity_tolerance=1e-4))]
+       ("1e-4, mass scale 100", dict(viscosity_velocity_tolerance=1e-4)),
+       ("mass floor 0.1", dict(viscosity_mass_floor=0.1)), ("mass floor 0.3", dict(viscosity_mass_floor=0.3))]
+if os.environ.get("R5_FLOORS_ONLY"):
+    VAR = [v for v in VAR if v[0] in ("tight", "round 4's rule", "default (3e-5, 100)", "mass floor 0.1", "mass floor 0.3")]
 print("# %s %d^3 nu %g: one substep from the state after k default substeps; error = distance to the 'tight' run of the same state, relative max-norm over all faces" % (scene, N, nu))
 for t in at:
     ref = None
