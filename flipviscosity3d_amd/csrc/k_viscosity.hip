@@ -1133,7 +1133,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // `viscosity_velocity_window` iterations together moved no velocity by more than that share of max|u|.  Stages in between stop on the residual alone.
         {
             const bool lastLoop = !innerDiffers || correction;   // (every correction stage: the solve ends after whichever of them leaves the fp64 residual below the tolerance)
-            const double eta = c->prm.viscosity_velocity_tolerance > 0.0f ? (double)c->prm.viscosity_velocity_tolerance : (c->prm.viscosity_velocity_tolerance < 0.0f ? 0.0 : 3.0e-5);
+            // (1e-5 beyond S = 5e4: the stiffer the system the less one iteration moves of what is still missing -- 256^3 bunny at nu = 200, S = 1.3e5, 25 substeps in: 3e-5 leaves
+            // 1.25e-4 on 6 500 faces against the tightened solve, 1e-5 leaves 8e-6 for 16 % more iterations; profiles/r5/eta_scan_256_nu200.log)
+            const double eta = c->prm.viscosity_velocity_tolerance > 0.0f ? (double)c->prm.viscosity_velocity_tolerance : (c->prm.viscosity_velocity_tolerance < 0.0f ? 0.0 : (stiffSolve > 5.0e4 ? 1.0e-5 : 3.0e-5));
             sc.vel_tol = (lastLoop && !c->vMixed64) ? eta * umaxAll : 0.0;
             sc.vel_window = c->prm.viscosity_velocity_window > 0 ? c->prm.viscosity_velocity_window : 4;
             sc.vel_stall = c->prm.viscosity_velocity_stall_ratio > 0.0f ? (double)c->prm.viscosity_velocity_stall_ratio : 0.0;   // (off by default: flipv.h)

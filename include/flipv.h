@@ -83,7 +83,7 @@ enum flipv_precision {
  *                            at most viscosity_stage2_max_iterations (200) each; viscosity_stage2_rounds = 1 stage -- 2 where the viscosity field's contrast max / min exceeds 1e4
  *                            (zero included); a stage that RAISES the fp64 residual is taken back, one that ends short of its target is restarted once
  *   the delivering loop      (a correction stage, its restart, or the one loop of a solve without stages) also needs the VELOCITY CRITERION: its last
- *                            viscosity_velocity_window (4) iterations together moved no velocity the substep uses by more than viscosity_velocity_tolerance (3e-5) x max|u|;
+ *                            viscosity_velocity_window (4) iterations together moved no velocity the substep uses by more than viscosity_velocity_tolerance (3e-5; 1e-5 where S > 5e4) x max|u|;
  *                            (held for at most 48 iterations past the residual test; optional early way out: viscosity_velocity_stall_ratio, off by default);
  *                            a loop the stall guard stops with the criterion unmet is restarted from the fp64 residual
  *   status                   0 = every stage reached its target; 1 = cap / stalled / a stage ended short or was taken back (the result is applied, like the reference's
@@ -139,7 +139,7 @@ typedef struct flipv_params {
     float viscosity_two_stage_max_stiffness;/* [1e6] nu dt/dx^2 up to which stage 1 stops early */
     int viscosity_defect_predictor;         /* [0 = on] -1 = off */
     /* what certifies the stop in late states (FLIPV_VERSION 5) */
-    float viscosity_velocity_tolerance;     /* [3e-5; -1 = off] the velocity criterion of the delivering loop.  The reference's test, max|r| <= 1e-6 max|rhs| (pcgsolver.h:259-272),
+    float viscosity_velocity_tolerance;     /* [0 = 3e-5, and 1e-5 where S > 5e4; -1 = off] the velocity criterion of the delivering loop.  The reference's test, max|r| <= 1e-6 max|rhs| (pcgsolver.h:259-272),
                                                does not bound the velocity error where the liquid holds light, weakly attached parts -- films and specks whose control volumes
                                                sum to a few per cent of a cell: residual = mass x error -- and in such states (the fringe of a splash, a body resting on the wall)
                                                CG still moves velocities by 1e-4 of their maximum per iteration when the residual test passes: the reference's own 1e-6 iterate is
