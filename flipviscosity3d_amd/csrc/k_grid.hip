@@ -438,10 +438,13 @@ int fv_read_small(flipv_context *c, const ReadJob *jobs, int n) {
     if (n < 1 || n > 6) { c->err = "fv_read_small: 1..6 jobs"; return FLIPV_ERR_INVALID; }
     int need = 0;
     for (int q = 0; q < n; q++) need += jobs[q].words;
+    if (need > FV_PUB_WORDS) {   // (a gather over very many ranks: the plain copies; the caller's synchronisation point completes them)
+        for (int q = 0; q < n; q++) HIPCHK(c, hipMemcpyAsync(jobs[q].host, jobs[q].dev, (size_t)jobs[q].words * 4, hipMemcpyDeviceToHost, c->stream));
+        return FLIPV_OK;
+    }
     if (c->pubPendingN + n > 16 || c->pubUsed + need > FV_PUB_WORDS) {
         const int rc = fv_read_wait(c);
         if (rc) return rc;
-        if (need > FV_PUB_WORDS) { c->err = "fv_read_small: too many words"; return FLIPV_ERR_INVALID; }
     }
     PubDev j;
     j.n = n;
