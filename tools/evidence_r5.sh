@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 evidence set (run through gpurun; outputs under gpurun_out/ev_r5/, copied into profiles/r5/ afterwards).  bash tools/evidence_r5.sh <tag> [part]
-tag=${1:-r5v3}
+tag=${1:-r5v4}
 part=${2:-all}
 out=gpurun_out/ev_r5
 mkdir -p $out
