@@ -523,8 +523,7 @@ int fv_brick_grid(const flipv_context *c, int nbricks, int cap) {
     if (nb > cap) nb = cap;
     return nb < 8 ? 8 : nb;
 }
-// 1280 blocks = 5 per CU (the kernels hold 73-84 VGPRs since the x-neighbours come from lane shuffles: 6 waves per SIMD would fit; 1536 measured slower, 2048 the same
-// over a substep: profiles/r5/brick_spmv_shuffles.log)
+// 1280 blocks = 5 per CU = one resident round at 93-100 VGPRs (1536 measured slower, 2048 the same over a substep: profiles/r5/brick_spmv_shuffles.log)
 static int spmv_grid(const flipv_context *c) { return fv_brick_grid(c, c->nBricks, c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : 1280); }
 static int update_grid(const flipv_context *c) { return fv_brick_grid(c, c->nBricks, c->prm.viscosity_update_grid_cap > 0 ? c->prm.viscosity_update_grid_cap : 2048); }
 // (the kernels that walk 16 bricks per block step: BrickWalkV)
