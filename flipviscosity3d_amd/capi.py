@@ -56,7 +56,7 @@ class Params(C.Structure):
                 ("viscosity_stage1_factor", C.c_float), ("viscosity_stage2_factor", C.c_float), ("viscosity_stage2_max_iterations", C.c_int),
                 ("viscosity_stage2_rounds", C.c_int), ("viscosity_two_stage_max_stiffness", C.c_float),
                 ("viscosity_defect_predictor", C.c_int), ("viscosity_velocity_tolerance", C.c_float), ("viscosity_velocity_window", C.c_int),
-                ("viscosity_mass_scale", C.c_float), ("viscosity_mass_floor", C.c_float), ("viscosity_velocity_stall_ratio", C.c_float)]
+                ("viscosity_mass_scale", C.c_float), ("viscosity_mass_floor", C.c_float), ("viscosity_massless_polish", C.c_int), ("viscosity_velocity_stall_ratio", C.c_float)]
 
 
 class DebugParams(C.Structure):

@@ -344,6 +344,7 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->h_flags) (void)hipHostFree(c->h_flags);
     if (c->h_pub) (void)hipHostFree(c->h_pub);
     if (c->d_pubSeq) (void)hipFree(c->d_pubSeq);
+    if (c->polishList) (void)hipFree(c->polishList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) if (c->phaseEv[q]) (void)hipEventDestroy(c->phaseEv[q]);
     if (c->evMain) (void)hipEventDestroy(c->evMain);
@@ -404,6 +405,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!(p->viscosity_mass_scale == -1.0f || fin(p->viscosity_mass_scale, 0.0f, 1e9f))) bad = "viscosity_mass_scale (-1, or >= 0)";
         else if (!fin(p->viscosity_velocity_stall_ratio, 0.0f, 1.0f)) bad = "viscosity_velocity_stall_ratio (0 .. 1)";
         else if (!fin(p->viscosity_mass_floor, 0.0f, 1.0f)) bad = "viscosity_mass_floor (0 .. 1)";
+        else if (!in(p->viscosity_massless_polish, -1, 0)) bad = "viscosity_massless_polish (0 on, -1 off)";
         if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     }
     static_cast<flipv_params &>(c->prm) = *p;

@@ -241,6 +241,7 @@ struct flipv_context {
     int vmgSweeps = 16;             // Jacobi sweeps on the multigrid's LDS-resident coarsest level for the current solve (viscosity_solve_t picks)
     int vMixed64 = 0;           // the current viscosity solve is precision = FP64 under the multigrid: fp32 Krylov loops refined to the fp64 tolerance
     double vRowsAll = 0.0;      // rows of the current viscosity system over all ranks (viscosity_solve_t's all-gather)
+    unsigned long long *polishList = nullptr;   // k_visc_massless_find's list of edges (k_viscosity.hip)
     long nExchanges = 0, nAllReduces = 0;   // neighbour exchanges (halo copies / reductions, one per call whatever the number of neighbours) and all-reduces issued so far (flipv_comm.hip)
     int exchIter = 0, allrIter = 0;         // ... by ONE iteration of the current solve's loop (flipv_solve_info::halo_exchanges_per_iteration, allreduces_per_iteration)
     double commBytesSetup = 0.0, commBytesIter = 0.0;   // what the current solve's multigrid all-reduces: once, and per iteration (flipv_solve_info::comm_bytes_*)

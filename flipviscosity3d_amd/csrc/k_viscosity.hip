@@ -811,6 +811,138 @@ static int fv_plane_refine(flipv_context *c, const Lay &R, const PcgScal &sc, si
     return fv_allreduce_scalars(c, sc.rmax(0), NSLOT);
 }
 
+// ------------------------------------------------------------------ massless clusters (flipv_params.viscosity_massless_polish)
+// A row without own volume whose diagonal is one stress term -- the factor of ONE edge of the control-volume lattice, >= 0.99 of the row's diagonal -- shares that term
+// with up to three other rows around the edge; where two or more of them are such rows, the system pins their common stress down and leaves their split to couplings
+// 1e-5 of it: a mode of Jacobi-scaled eigenvalue ~1e-6 that fp32 CG neither sees in its residual nor moves (holdout draws 20 and 30: ONE such face the substep uses was
+// 2.2e-4 / 3.8e-4 from the reference's converged answer, and the projection and the extrapolation carried it to 8 / 180 faces; profiles/r5/holdout_misses_20_30.log).  The
+// reference's MIC(0)-PCG resolves it given enough iterations.  Here: after the solve, every such cluster (<= 4 rows) is solved exactly in fp64 with everything around it
+// held -- the reference's rows (viscositysolver.cpp:394-446, 491-568, 589-664) with the reference's float factors (d_ref_row_factors) and float diagonal.
+// entry t (0 .. 14) of the reference's row of component `comp` with the six factors F = (right, left, top, bottom, front, back) and float diagonal `diag`:
+// which component, at which offset from the row's own index, with which coefficient
+__device__ __forceinline__ void d_polish_entry(int comp, int t, const float F[6], float diag, long sy, long sz, int &ec, long &eo, double &coef) {
+    const long own[7] = {0, 1, -1, sy, -sy, sz, -sz};
+    if (t < 7) { ec = comp; eo = own[t]; coef = t == 0 ? (double)diag : -(double)F[t - 1]; return; }
+    const int q = t - 7;   // the eight cross terms: two per stress term the row shares with another component
+    // per component: (other component, offset, factor slot, sign) x 8  -- viscositysolver.cpp:437-446, 544-553, 642-651
+    if (comp == 0) {
+        const int oc[8] = {1, 1, 1, 1, 2, 2, 2, 2}; const long of[8] = {sy, sy - 1, 0, -1, sz, sz - 1, 0, -1}; const int sl[8] = {2, 2, 3, 3, 4, 4, 5, 5}; const int sg[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+        ec = oc[q]; eo = of[q]; coef = sg[q] * (double)F[sl[q]];
+    } else if (comp == 1) {
+        const int oc[8] = {0, 0, 0, 0, 2, 2, 2, 2}; const long of[8] = {1, 1 - sy, 0, -sy, sz, sz - sy, 0, -sy}; const int sl[8] = {0, 0, 1, 1, 4, 4, 5, 5}; const int sg[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+        ec = oc[q]; eo = of[q]; coef = sg[q] * (double)F[sl[q]];
+    } else {
+        const int oc[8] = {0, 0, 0, 0, 1, 1, 1, 1}; const long of[8] = {1, 1 - sz, 0, -sz, sy, sy - sz, 0, -sz}; const int sl[8] = {0, 0, 1, 1, 2, 2, 3, 3}; const int sg[8] = {-1, 1, 1, -1, -1, 1, 1, -1};
+        ec = oc[q]; eo = of[q]; coef = sg[q] * (double)F[sl[q]];
+    }
+}
+// pass 1, every index of the liquid's range: the edges with a PARTIAL volume (a row dominated by an edge of full volume would need every other volume around it to
+// vanish: not at a full edge) and at least two massless rows around them, appended to a list (list[0] = their number)
+constexpr int FV_POLISH_CAP = 1 << 16;
+__global__ void k_visc_massless_find(Lay L, const float *__restrict__ volEU, const float *__restrict__ volEV, const float *__restrict__ volEW, const float *__restrict__ volU,
+                                     const float *__restrict__ volV, const float *__restrict__ volW, const uint8_t *__restrict__ rowmask, unsigned long long *__restrict__ list) {
+    IJK_OR_RETURN(L);
+    const long sy = L.sy, sz = L.sz;
+    if (rowmask[c] == 0) return;   // (each of the three edges at c has a row AT c among its four)
+    if (i < 2 || j < 2 || k < 2 || i > L.I - 2 || j > L.J - 2 || k > L.K - 2) return;
+    const float ev[3] = {volEV[c], volEW[c], volEU[c]};
+    const float *const vol[3] = {volU, volV, volW};
+    const int rc_[3][4] = {{0, 0, 2, 2}, {0, 0, 1, 1}, {1, 1, 2, 2}};
+    const long ro[3][4] = {{0, -sz, 0, -1}, {0, -sy, 0, -1}, {0, -sz, 0, -sy}};
+    for (int fam = 0; fam < 3; fam++) {
+        if (!(ev[fam] > 0.0f && ev[fam] < 1.0f)) continue;
+        int cand = 0, used = 0;   // massless rows around the edge; those among them whose velocity the substep uses (mask bits 3-5: the others are overwritten by the extrapolation)
+        for (int q = 0; q < 4; q++) {
+            const size_t p = c + ro[fam][q];
+            const unsigned mk = rowmask[p];
+            const int is = ((mk >> rc_[fam][q]) & 1u) && vol[rc_[fam][q]][p] == 0.0f;
+            cand += is; used += is && ((mk >> (3 + rc_[fam][q])) & 1u);
+        }
+        if (cand < 2 || used < 1) continue;
+        const unsigned long long at = atomicAdd(list, 1ull);
+        if (at < (unsigned long long)FV_POLISH_CAP) list[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)fam;
+    }
+}
+// pass 2, one thread per listed edge (no large per-thread arrays: a kernel with kilobytes of scratch per lane pays ~100 us of scratch set-up per dispatch)
+__global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float *__restrict__ nu, const float *__restrict__ volC, const float *__restrict__ volEU, const float *__restrict__ volEV,
+                                       const float *__restrict__ volEW, const float *__restrict__ volU, const float *__restrict__ volV, const float *__restrict__ volW,
+                                       const uint8_t *__restrict__ rowmask, float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float factor, int inner,
+                                       const unsigned long long *__restrict__ list, int *__restrict__ count) {
+    const long sy = L.sy, sz = L.sz;
+    const float *const vol[3] = {volU, volV, volW};
+    float *const X[3] = {U, V, W};
+    unsigned long long nlist = list[0];
+    if (nlist > (unsigned long long)FV_POLISH_CAP) nlist = FV_POLISH_CAP;
+    // the three edge families: their four rows as (component, offset from the edge's index, slot of the edge among the row's six factors)
+    //   edgeV (tau_xz): U(c) back, U(c - sz) front, W(c) left, W(c - 1) right;  edgeW (tau_xy): U(c) bottom, U(c - sy) top, V(c) left, V(c - 1) right;
+    //   edgeU (tau_yz): V(c) back, V(c - sz) front, W(c) bottom, W(c - sy) top
+    const int rc_[3][4] = {{0, 0, 2, 2}, {0, 0, 1, 1}, {1, 1, 2, 2}};
+    const long ro[3][4] = {{0, -sz, 0, -1}, {0, -sy, 0, -1}, {0, -sz, 0, -sy}};
+    const int rs[3][4] = {{5, 4, 1, 0}, {3, 2, 1, 0}, {5, 4, 3, 2}};
+    for (unsigned long long item = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; item < nlist; item += (unsigned long long)gridDim.x * blockDim.x) {
+        const size_t c = (size_t)(list[1 + item] >> 2);
+        const int fam = (int)(list[1 + item] & 3ull);
+        const int k = (int)(c / (size_t)sz) + L.oz, j = (int)((c % (size_t)sz) / (size_t)sy) + L.oy, i = (int)(c % (size_t)sy) + L.ox;   // (the inverse of gidx: for the block-context test)
+        int mc[4];
+        size_t mp[4];
+        float mF[4][6], md[4];
+        int n = 0;
+        for (int q = 0; q < 4; q++) {
+            const int comp = rc_[fam][q];
+            const size_t p = c + ro[fam][q];
+            if (!((rowmask[p] >> comp) & 1) || vol[comp][p] != 0.0f) continue;
+            if (inner) {   // (a block context: rows whose stencil stays inside what the rank holds current values of)
+                const int pi = i + (ro[fam][q] == -1 ? -1 : 0), pj = j + (ro[fam][q] == -sy ? -1 : 0), pk = k + (ro[fam][q] == -sz ? -1 : 0);
+                if (pi - 1 < L.olo[0] || pi + 1 >= L.ohi[0] || pj - 1 < L.olo[1] || pj + 1 >= L.ohi[1] || pk - 1 < L.olo[2] || pk + 1 >= L.ohi[2]) continue;
+            }
+            const RefRowFactors F = d_ref_row_factors(nu, volC, volEU, volEV, volEW, p, sy, sz, factor);
+            const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
+            const float diag = 0.0f + f[0] + f[1] + f[2] + f[3] + f[4] + f[5];   // (own volume 0; the reference's float sum, in its order)
+            if (!(diag > 0.0f) || f[rs[fam][q]] < 0.99f * diag) continue;
+            mc[n] = comp; mp[n] = p; md[n] = diag;
+            for (int t = 0; t < 6; t++) mF[n][t] = f[t];
+            n++;
+        }
+        if (n < 2) continue;
+        double A[4][5];
+        for (int r = 0; r < n; r++) {
+            for (int m = 0; m <= n; m++) A[r][m] = 0.0;
+            for (int t = 0; t < 15; t++) {
+                int ec; long eo; double coef;
+                d_polish_entry(mc[r], t, mF[r], md[r], sy, sz, ec, eo, coef);
+                if (coef == 0.0) continue;
+                const size_t at = mp[r] + eo;
+                int hit = -1;
+                for (int m = 0; m < n; m++) if (mc[m] == ec && mp[m] == at) hit = m;
+                if (hit >= 0) A[r][hit] += coef; else A[r][n] -= coef * (double)X[ec][at];   // (massless rows: the right-hand side is what the neighbours contribute)
+            }
+        }
+        // Gaussian elimination with partial pivoting; a singular cluster (nothing pins the split at all) is left as it is
+        bool ok = true;
+        double amax = 0.0;
+        for (int r = 0; r < n; r++) for (int m = 0; m < n; m++) amax = fmax(amax, fabs(A[r][m]));
+        for (int col = 0; col < n && ok; col++) {
+            int piv = col;
+            for (int r = col + 1; r < n; r++) if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+            if (!(fabs(A[piv][col]) > 1.0e-11 * amax)) { ok = false; break; }
+            if (piv != col) for (int m = 0; m <= n; m++) { const double t = A[col][m]; A[col][m] = A[piv][m]; A[piv][m] = t; }
+            for (int r = col + 1; r < n; r++) {
+                const double f_ = A[r][col] / A[col][col];
+                for (int m = col; m <= n; m++) A[r][m] -= f_ * A[col][m];
+            }
+        }
+        if (!ok) continue;
+        double x[4];
+        for (int r = n - 1; r >= 0; r--) {
+            double t = A[r][n];
+            for (int m = r + 1; m < n; m++) t -= A[r][m] * x[m];
+            x[r] = t / A[r][r];
+        }
+        for (int r = 0; r < n; r++) X[mc[r]][mp[r]] = (float)x[r];
+        if (count) atomicAdd(count, n);
+    }
+}
+
 // What every rank of a communicator must decide alike from (the preconditioner, the stiffness rule, the vector type of an FP64 solve): the viscosity field's
 // facts over ALL ranks, one small all-gather at the start of every solve -- before anything that chooses a sequence of collectives.
 static int visc_gather_field_facts(flipv_context *c) {
@@ -1332,6 +1464,22 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             else if (c->vSwz) hipLaunchKernelGGL(k_unswizzle_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);
             else if (c->pgrid[0] > 1 || c->pgrid[1] > 1) hipLaunchKernelGGL(k_box_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);   // only what the rank owns: its i / j halo holds the neighbours' velocities
             else hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[m] + off, uvw[m] + off, cnt);
+        }
+        if (c->prm.verbose) HIPCHK(c, hipMemsetAsync(c->d_flags + 13, 0, sizeof(int), c->stream));   // (the count the verbose line below prints; the word is fv_build_runs' otherwise)
+        if (nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0)   // (the clusters the iteration leaves where fp32 cannot see them: k_visc_massless_polish)
+        {
+            if (!c->polishList) HIPCHK(c, hipMalloc((void **)&c->polishList, (size_t)(FV_POLISH_CAP + 1) * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->polishList, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(k_visc_massless_find, GRID3(R0), 0, c->stream, R0, (const float *)c->volEU, (const float *)c->volEV, (const float *)c->volEW, (const float *)c->volU,
+                               (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, c->polishList);
+            hipLaunchKernelGGL(k_visc_massless_polish, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
+                               (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, c->U, c->V, c->W,
+                               c->vFactorNow, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, c->prm.verbose ? c->d_flags + 13 : (int *)nullptr);
+        }
+        if (c->prm.verbose && nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {
+            int np = 0;
+            HIPCHK(c, hipMemcpy(&np, c->d_flags + 13, sizeof(int), hipMemcpyDeviceToHost));   // (d_flags[13]: the run builder's second word, rewritten by every fv_build_runs)
+            fprintf(stderr, "viscosity solve %ld: %d rows of massless clusters solved apart\n", c->viscSolves, np);
         }
         const HaloArray uv[3] = {{c->U, 4}, {c->V, 4}, {c->W, 4}};
         if ((rc = fv_halo_copy(c, uv, 3, 1))) return rc;  // the pressure rhs at plane k1-1 reads W(k1)

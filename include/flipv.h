@@ -154,6 +154,10 @@ typedef struct flipv_params {
     float viscosity_mass_floor;             /* [0 = by stiffness: max(0.03, min(0.3, 1e-5 S, 1e4 / S))] ... and N is never below this share of max|rhs|: a liquid almost at rest next to solid faces
                                                that still hold old velocities has max|u| / max|rhs| ~ 1e-5, and what an fp32 correction stage reaches scales with S: 256^3 honey
                                                (S = 32 768) settling on the floor ran 26 ... 86 of 330 solves out of their stage budget at 0.03, 2 at 0.3 (profiles/r5/mass_floor_scan.log) */
+    int viscosity_massless_polish;          /* [0 = on; -1 = off] after the solve, clusters of <= 4 rows WITHOUT own volume that share one dominant stress term (>= 0.99 of each row's
+                                               diagonal) are solved exactly in fp64 with everything around them held: their common stress is what the system determines, their split
+                                               hangs on couplings 1e-5 of it -- a mode fp32 CG neither sees nor moves (holdout draws 20, 30: one used face 2e-4 ... 4e-4 from the
+                                               reference's converged answer, carried to 8 ... 180 faces by the projection and the extrapolation; profiles/r5/holdout_misses_20_30.log) */
     float viscosity_velocity_stall_ratio;   /* [0 = off] OPT-IN early way out of the velocity criterion: the residual has passed, the last window moved the velocities by no more than
                                                10 x viscosity_velocity_tolerance, and by no less than this ratio (e.g. 0.5) x what the window before it moved.  On the 256^3 bunny lying
                                                on the wall 40 % of the solves sit on such a plateau -- 2e-5 ... 4e-4 max|u| per iteration on rows the system barely determines, while

@@ -17,7 +17,9 @@ for t in range(max(at) + 1):
     c.substep(0.01)
 c.close()
 VAR = [("tight", dict(precision=1, viscosity_tolerance=1e-9, pressure_rel_tolerance=1e-9, viscosity_max_iterations=5000, viscosity_velocity_tolerance=1e-6)),
-       ("round 4's rule", dict(viscosity_velocity_tolerance=-1.0, viscosity_mass_scale=-1.0)),
+       ("round 4's rule", dict(viscosity_velocity_tolerance=-1.0, viscosity_mass_scale=-1.0, viscosity_massless_polish=-1)),
+       ("clusters + mass scale, no criterion", dict(viscosity_velocity_tolerance=-1.0)),
+       ("no cluster solve", dict(viscosity_massless_polish=-1)),
        ("velocity criterion only", dict(viscosity_mass_scale=-1.0)),
        ("mass scale only", dict(viscosity_velocity_tolerance=-1.0)),
        ("default (3e-5, 100)", {}),
@@ -26,7 +28,7 @@ VAR = [("tight", dict(precision=1, viscosity_tolerance=1e-9, pressure_rel_tolera
        ("1e-4, mass scale 100", dict(viscosity_velocity_tolerance=1e-4)),
        ("mass floor 0.1", dict(viscosity_mass_floor=0.1)), ("mass floor 0.3", dict(viscosity_mass_floor=0.3))]
 if os.environ.get("R5_FLOORS_ONLY"):
-    VAR = [v for v in VAR if v[0] in ("tight", "round 4's rule", "default (3e-5, 100)", "mass floor 0.1", "mass floor 0.3")]
+    VAR = [v for v in VAR if v[0] in ("tight", "round 4's rule", "default (3e-5, 100)", "clusters + mass scale, no criterion", "no cluster solve")]
 print("# %s %d^3 nu %g: one substep from the state after k default substeps; error = distance to the 'tight' run of the same state, relative max-norm over all faces" % (scene, N, nu))
 for t in at:
     ref = None

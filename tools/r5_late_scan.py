@@ -13,9 +13,12 @@ from oracle import oraclebind as O
 
 VARIANTS = {
     "default": {},
-    "old": dict(viscosity_velocity_tolerance=-1.0, viscosity_mass_scale=-1.0),
+    "old": dict(viscosity_velocity_tolerance=-1.0, viscosity_mass_scale=-1.0, viscosity_massless_polish=-1),   # round 4's rule
     "critonly": dict(viscosity_mass_scale=-1.0),
     "massonly": dict(viscosity_velocity_tolerance=-1.0),
+    "nopolish": dict(viscosity_massless_polish=-1),                                                            # round 5 before the massless clusters were solved apart
+    "polishonly": dict(viscosity_velocity_tolerance=-1.0, viscosity_mass_scale=-1.0),                          # round 4's rule + the clusters
+    "polishmass": dict(viscosity_velocity_tolerance=-1.0),                                                     # ... + the mass scale, no velocity criterion
     "c1e-4": dict(viscosity_velocity_tolerance=1e-4),
     "eta1e-5": dict(viscosity_velocity_tolerance=1e-5),
     "eta1e-4": dict(viscosity_velocity_tolerance=1e-4),
