@@ -86,6 +86,7 @@ enum flipv_precision {
  *                            viscosity_velocity_window (4) iterations together moved no velocity the substep uses by more than viscosity_velocity_tolerance (3e-5; 1e-5 where S > 5e4) x max|u|;
  *                            (held for at most 48 iterations past the residual test; optional early way out: viscosity_velocity_stall_ratio, off by default);
  *                            a loop the stall guard stops with the criterion unmet is restarted from the fp64 residual
+ *   after the solve          clusters of <= 4 rows without own volume that share one dominant stress term are solved exactly in fp64 (viscosity_massless_polish)
  *   status                   0 = every stage reached its target; 1 = cap / stalled / a stage ended short or was taken back (the result is applied, like the reference's
  *                            accepted iterate); flipv_solve_info: residual (stage 1's), defect_residual = max|b - A_ref x| delivered, velocity_step, correction_* */
 
