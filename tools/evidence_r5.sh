@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 evidence set (run through gpurun; outputs under gpurun_out/ev_r5/, copied into profiles/r5/ afterwards).  bash tools/evidence_r5.sh <tag> [part]
-tag=${1:-r5v4}
+tag=${1:-r5v5}
 part=${2:-all}
 out=gpurun_out/ev_r5
 mkdir -p $out
@@ -38,7 +38,7 @@ if [ $part = all ] || [ $part = soak ]; then
 (python3 tools/r3_status.py bunny 256 5 2000; python3 tools/r3_status.py honey 256 50 200; python3 tools/r3_status.py sheet 512 5 200; python3 tools/r3_status.py bunny 128 5 500; python3 tools/r3_status.py honey 512 50 30) > $out/soak_status.log 2>&1
 fi
 if [ $part = all ] || [ $part = parity ]; then
-V=default,old,critonly,massonly
+V=default,old,nopolish,polishonly,polishmass,critonly,massonly
 (python3 tools/r5_late_scan.py bunny 64 200 70 1,40,70 $V; python3 tools/r5_late_scan.py bunny 64 5 110 18,69,86,110 $V; python3 tools/r5_late_scan.py bunny 64 0.001 36 3,5,25,36 $V) > $out/late_states.log 2>&1
 python3 tools/r5_eta_scan.py 256 20,35,50,70 > $out/eta_scan_256.log 2>&1
 python3 tools/r5_eta_scan.py 128 20,40,80,120 > $out/eta_scan_128.log 2>&1
