@@ -864,10 +864,13 @@ __global__ void k_visc_massless_find(Lay L, const float *__restrict__ volEU, con
     }
 }
 // pass 2, one thread per listed edge (no large per-thread arrays: a kernel with kilobytes of scratch per lane pays ~100 us of scratch set-up per dispatch)
+// MARK: before the solve -- the rows of every cluster the kernel will replace afterwards lose their "watched" bit (mask bits 3-5, plain and brick copy): CG moves exactly
+// these rows by 1e-5 ... 1e-3 max|u| per iteration for ever, which is most of what held the velocity criterion's patience on a liquid lying on the wall; nothing is solved.
+template <bool MARK>
 __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float *__restrict__ nu, const float *__restrict__ volC, const float *__restrict__ volEU, const float *__restrict__ volEV,
                                        const float *__restrict__ volEW, const float *__restrict__ volU, const float *__restrict__ volV, const float *__restrict__ volW,
-                                       const uint8_t *__restrict__ rowmask, float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float factor, int inner,
-                                       const unsigned long long *__restrict__ list, int *__restrict__ count) {
+                                       uint8_t *__restrict__ rowmask, float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float factor, int inner,
+                                       const unsigned long long *__restrict__ list, int *__restrict__ count, uint8_t *__restrict__ maskB, Lay LB) {
     const long sy = L.sy, sz = L.sz;
     const float *const vol[3] = {volU, volV, volW};
     float *const X[3] = {U, V, W};
@@ -904,6 +907,18 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
             n++;
         }
         if (n < 2) continue;
+        if (MARK) {
+            for (int r = 0; r < n; r++) {   // clear bit 3 + component of the row's mask byte: an atomic AND on the word that holds it (two clusters may meet in one byte)
+                const unsigned clear = ~((8u << mc[r]) << (8u * (unsigned)(mp[r] & 3)));
+                atomicAnd(reinterpret_cast<unsigned *>(rowmask + (mp[r] & ~(size_t)3)), clear);
+                if (maskB) {
+                    const int pk = (int)(mp[r] / (size_t)sz) + L.oz, pj = (int)((mp[r] % (size_t)sz) / (size_t)sy) + L.oy, pi = (int)(mp[r] % (size_t)sy) + L.ox;
+                    const size_t b = bidx(LB, pi, pj, pk);
+                    atomicAnd(reinterpret_cast<unsigned *>(maskB + (b & ~(size_t)3)), ~((8u << mc[r]) << (8u * (unsigned)(b & 3))));
+                }
+            }
+            continue;
+        }
         double A[4][5];
         for (int r = 0; r < n; r++) {
             for (int m = 0; m <= n; m++) A[r][m] = 0.0;
@@ -1081,6 +1096,15 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                            c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, (refDiag ? 1 : 0) | (predict ? 2 : 0),
                            brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2], c->phi);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
+        if (!c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {   // the massless clusters: listed now and taken out of the velocity criterion's sight, solved after the solve
+            if (!c->polishList) HIPCHK(c, hipMalloc((void **)&c->polishList, (size_t)(FV_POLISH_CAP + 1) * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->polishList, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(k_visc_massless_find, GRID3(RS), 0, c->stream, RS, (const float *)c->volEU, (const float *)c->volEV, (const float *)c->volEW, (const float *)c->volU,
+                               (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, c->polishList);
+            hipLaunchKernelGGL(k_visc_massless_polish<true>, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
+                               (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
+                               factor, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, (int *)nullptr, brick ? c->vMaskB : (uint8_t *)nullptr, c->LB);
+        }
         FV_READ_JOBS(c, FV_JOB(c->h_scal, bmax, 2 * sizeof(double)), FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int)));   // max|rhs|, max|u| over the rows; the row count
         FV_SYNC(c);  // h_flags[2] = row count
         return FLIPV_OK;
@@ -1467,15 +1491,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         }
         if (c->prm.verbose) HIPCHK(c, hipMemsetAsync(c->d_flags + 13, 0, sizeof(int), c->stream));   // (the count the verbose line below prints; the word is fv_build_runs' otherwise)
         if (nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0)   // (the clusters the iteration leaves where fp32 cannot see them: k_visc_massless_polish)
-        {
-            if (!c->polishList) HIPCHK(c, hipMalloc((void **)&c->polishList, (size_t)(FV_POLISH_CAP + 1) * sizeof(unsigned long long)));
-            HIPCHK(c, hipMemsetAsync(c->polishList, 0, sizeof(unsigned long long), c->stream));
-            hipLaunchKernelGGL(k_visc_massless_find, GRID3(R0), 0, c->stream, R0, (const float *)c->volEU, (const float *)c->volEV, (const float *)c->volEW, (const float *)c->volU,
-                               (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, c->polishList);
-            hipLaunchKernelGGL(k_visc_massless_polish, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
-                               (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, c->U, c->V, c->W,
-                               c->vFactorNow, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, c->prm.verbose ? c->d_flags + 13 : (int *)nullptr);
-        }
+            hipLaunchKernelGGL(k_visc_massless_polish<false>, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
+                               (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
+                               c->vFactorNow, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, c->prm.verbose ? c->d_flags + 13 : (int *)nullptr, (uint8_t *)nullptr, c->LB);   // (the list k_visc_massless_find made before the solve)
         if (c->prm.verbose && nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {
             int np = 0;
             HIPCHK(c, hipMemcpy(&np, c->d_flags + 13, sizeof(int), hipMemcpyDeviceToHost));   // (d_flags[13]: the run builder's second word, rewritten by every fv_build_runs)
