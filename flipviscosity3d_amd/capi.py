@@ -44,7 +44,7 @@ class FlipvError(RuntimeError):
 
 
 class Params(C.Structure):
-    """flipv_params (include/flipv.h, FLIPV_VERSION 5)"""
+    """flipv_params (include/flipv.h, FLIPV_VERSION 6)"""
     _fields_ = [("cfl_number", C.c_float), ("min_frac", C.c_float), ("pic_ratio", C.c_float),
                 ("extrapolation_layers", C.c_int), ("pressure_tolerance", C.c_double),
                 ("pressure_rel_tolerance", C.c_double), ("pressure_max_iterations", C.c_int),
@@ -56,7 +56,7 @@ class Params(C.Structure):
                 ("viscosity_stage1_factor", C.c_float), ("viscosity_stage2_factor", C.c_float), ("viscosity_stage2_max_iterations", C.c_int),
                 ("viscosity_stage2_rounds", C.c_int), ("viscosity_two_stage_max_stiffness", C.c_float),
                 ("viscosity_defect_predictor", C.c_int), ("viscosity_velocity_tolerance", C.c_float), ("viscosity_velocity_window", C.c_int),
-                ("viscosity_mass_scale", C.c_float), ("viscosity_mass_floor", C.c_float), ("viscosity_massless_polish", C.c_int), ("viscosity_velocity_stall_ratio", C.c_float)]
+                ("viscosity_mass_scale", C.c_float), ("viscosity_mass_floor", C.c_float), ("viscosity_massless_polish", C.c_int), ("viscosity_velocity_stall_ratio", C.c_float), ("viscosity_pair_correction", C.c_int)]
 
 
 class DebugParams(C.Structure):
@@ -66,7 +66,7 @@ class DebugParams(C.Structure):
                 ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
                 ("no_liquid_box", C.c_int), ("no_comm_overlap", C.c_int), ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
                 ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int), ("viscosity_update_grid_cap", C.c_int),
-                ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int)]
+                ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int), ("viscosity_mg_packed_rows", C.c_int), ("stall_guard_ratio", C.c_float)]
 
 
 _PRODUCT_FIELDS = {f for f, _ in Params._fields_}
@@ -95,7 +95,7 @@ class SolveInfo(C.Structure):
                 ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
                 ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int), ("defect_residual", C.c_double),
                 ("correction_iterations", C.c_int), ("comm_bytes_setup", C.c_double), ("comm_bytes_per_iteration", C.c_double), ("velocity_step", C.c_double),
-                ("halo_exchanges_per_iteration", C.c_int), ("allreduces_per_iteration", C.c_int), ("correction_status", C.c_int)]
+                ("halo_exchanges_per_iteration", C.c_int), ("allreduces_per_iteration", C.c_int), ("correction_status", C.c_int), ("eliminated_rows", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -181,7 +181,7 @@ __device__ __forceinline__ bool d_update_scalars(const PcgScal &sc, int it_arg, 
     }
     if (it > 0 && sc.best) {   // stall guard (PcgScal)
         const double bestNow = *sc.best, res = lds[0];
-        if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > 16.0 * bestNow) {
+        if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > sc.stall_ratio * bestNow) {
             if (blockIdx.x == 0 && tid == 0) { *sc.stalled = 1; *sc.conv = it - 1; }
             return false;
         }

@@ -345,6 +345,8 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->h_pub) (void)hipHostFree(c->h_pub);
     if (c->d_pubSeq) (void)hipFree(c->d_pubSeq);
     if (c->polishList) (void)hipFree(c->polishList);
+    if (c->elimList) (void)hipFree(c->elimList);
+    if (c->pairList) (void)hipFree(c->pairList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) if (c->phaseEv[q]) (void)hipEventDestroy(c->phaseEv[q]);
     if (c->evMain) (void)hipEventDestroy(c->evMain);
@@ -406,6 +408,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!fin(p->viscosity_velocity_stall_ratio, 0.0f, 1.0f)) bad = "viscosity_velocity_stall_ratio (0 .. 1)";
         else if (!fin(p->viscosity_mass_floor, 0.0f, 1.0f)) bad = "viscosity_mass_floor (0 .. 1)";
         else if (!in(p->viscosity_massless_polish, -1, 0)) bad = "viscosity_massless_polish (0 on, -1 off)";
+        else if (!in(p->viscosity_pair_correction, -1, 0)) bad = "viscosity_pair_correction (0 on, -1 off)";
         if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     }
     static_cast<flipv_params &>(c->prm) = *p;
@@ -427,6 +430,8 @@ extern "C" int flipv_set_debug_params(flipv_context *c, const flipv_debug_params
     else if (!in(p->grid_cap, 0, 1 << 20) || !in(p->viscosity_spmv_grid_cap, 0, 1 << 20) || !in(p->viscosity_update_grid_cap, 0, 1 << 20)) bad = "a grid cap";
     else if (p->viscosity_lane_width != 0 && p->viscosity_lane_width != 2 && p->viscosity_lane_width != 4) bad = "viscosity_lane_width";
     else if (!in(p->spmv_run_length, -2, 64) || p->spmv_run_length == 1) bad = "spmv_run_length";
+    else if (!in(p->viscosity_mg_packed_rows, -1, 1)) bad = "viscosity_mg_packed_rows";
+    else if (!(p->stall_guard_ratio == 0.0f || fin(p->stall_guard_ratio, 1.0f, 1e30f))) bad = "stall_guard_ratio (0 or >= 1)";
     if (bad) { c->err = std::string("flipv_set_debug_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     static_cast<flipv_debug_params &>(c->prm) = *p;
     return FLIPV_OK;

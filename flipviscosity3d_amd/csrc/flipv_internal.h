@@ -84,6 +84,10 @@ static inline Lay brick_lay(const Lay &L) {   // (keeps L's origin and owned box
     return B;
 }
 // element offsets from an index to its six axis neighbours (plain layout: +-1, +-sy, +-sz for every index; brick layout: per index)
+// A pair of rows of the viscosity system whose coupling is >= 0.7 of the geometric mean of their diagonals (k_visc_pairs_find): indices of the two rows in the layout
+// of r (own-index arrays) and of the multigrid's sweep vectors, their components (2 bits each), and the inverse of their 2 x 2 block.
+struct VPair { unsigned ir0, ir1, iz0, iz1, comps; float i00, i01, i11; };
+constexpr int FV_PAIR_CAP = 16384;
 struct NbOff { int xm, xp, ym, yp, zm, zp; };
 __host__ __device__ __forceinline__ NbOff nb_plain(const Lay &L) {
     NbOff o; o.xm = -1; o.xp = 1; o.ym = -(int)L.sy; o.yp = (int)L.sy; o.zm = -(int)L.sz; o.zp = (int)L.sz;
@@ -242,6 +246,10 @@ struct flipv_context {
     int vMixed64 = 0;           // the current viscosity solve is precision = FP64 under the multigrid: fp32 Krylov loops refined to the fp64 tolerance
     double vRowsAll = 0.0;      // rows of the current viscosity system over all ranks (viscosity_solve_t's all-gather)
     unsigned long long *polishList = nullptr;   // k_visc_massless_find's list of edges (k_viscosity.hip)
+    unsigned long long *elimList = nullptr;     // k_visc_singular_find's list of faces (k_viscosity.hip)
+    struct VPair *pairList = nullptr;           // k_visc_pairs_find's list of strongly coupled row pairs; the first 16 bytes of the allocation hold their number (k_viscosity.hip)
+    int nElim = 0;                              // rows k_visc_singular_find took out of this solve's system (flipv_solve_info::eliminated_rows)
+    int nPairs = 0;                             // ... as the host read it after the set-up (0: the multigrid loop launches no pair kernel)
     long nExchanges = 0, nAllReduces = 0;   // neighbour exchanges (halo copies / reductions, one per call whatever the number of neighbours) and all-reduces issued so far (flipv_comm.hip)
     int exchIter = 0, allrIter = 0;         // ... by ONE iteration of the current solve's loop (flipv_solve_info::halo_exchanges_per_iteration, allreduces_per_iteration)
     double commBytesSetup = 0.0, commBytesIter = 0.0;   // what the current solve's multigrid all-reduces: once, and per iteration (flipv_solve_info::comm_bytes_*)

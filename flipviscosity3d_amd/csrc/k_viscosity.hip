@@ -16,7 +16,7 @@
 #include "visc_rows.h"
 #include "brick.h"
 
-enum { ST_FLUID = 1, ST_SOLID = 2 };
+enum { ST_FLUID = 1, ST_SOLID = 2, ST_ELIM = 3 };   // (ST_ELIM: a fluid face taken out of ONE solve's system, k_visc_singular_find)
 
 // ------------------------------------------------------------------ face states
 // viscositysolver.cpp:80-133
@@ -958,6 +958,191 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
     }
 }
 
+// ------------------------------------------------------------------ singular clusters: rows that are THE SAME equation (flipv_params.viscosity_massless_polish >= 0)
+// A row without own volume whose six factors are zero but ONE states a single condition -- the stress on that edge (or in that cell centre) vanishes -- and every other
+// such row around the same edge (up to four faces, two components) or cell centre (two faces of one component) states the same condition again: the reference's matrix is
+// exactly singular there (holdout draw 9 of round 5: two rows of diagonal 4e-10, the rest of the system solved to 2e-7 by anything).  What the reference delivers is decided
+// by its MIC(0) factorisation (pcgsolver.h:62-178): the pivot of the LATER of two identical rows cancels to zero, is replaced by the row's diagonal (min_diagonal_ratio
+// 0.25), its couplings cancel likewise, and the preconditioned residual -- and so every search direction and the iterate -- is ZERO on that row: the first such row in the
+// reference's row order (U < V < W, then k, j, i: viscositysolver.cpp:284-354) carries the condition, the later ones stay at 0.  tests/research/jump_proto.py shows it on
+// the dumped system.  A Krylov loop in fp32 drifts along the null vector instead (the residual of draw 9 stalled at 1e-3 max|rhs|, velocities 0.2 ... 0.9 max|u| off).
+// Here: BEFORE the set-up kernel, every later row of such a cluster is listed and its face state set to ST_ELIM for the duration of k_visc_setup -- no row, no
+// right-hand-side term, velocity 0, exactly what the reference's iterate holds there.
+constexpr int FV_ELIM_CAP = 4096;
+// is face (comp, p) a row without own volume whose only non-zero factor sits in slot `slot_out`?
+__device__ __forceinline__ bool d_single_factor_row(int comp, size_t p, int i, int j, int k, const Lay &L, const uint8_t *const st[3], const float *const vol[3], const float *__restrict__ nu,
+                                                    const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int &slot_out) {
+    if (!d_row_range(comp, i, j, k, L) || st[comp][p] != ST_FLUID || vol[comp][p] != 0.0f) return false;
+    const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, p, L.sy, L.sz, factor);
+    const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
+    int nz = 0, at = -1;
+#pragma unroll
+    for (int t = 0; t < 6; t++) if (f[t] != 0.0f) { nz++; at = t; }
+    slot_out = at;
+    return nz == 1;
+}
+__global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV, const uint8_t *__restrict__ stW, const float *__restrict__ volU,
+                                     const float *__restrict__ volV, const float *__restrict__ volW, const float *__restrict__ nu, const float *__restrict__ vC,
+                                     const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, const uint8_t *__restrict__ band, float factor,
+                                     unsigned long long *__restrict__ list) {
+    IJK_OR_RETURN(L);
+    const long sy = L.sy, sz = L.sz;
+    if (!(band[c] || band[c - 1] || band[c + 1] || band[c - sy] || band[c + sy] || band[c - sz] || band[c + sz])) return;   // (no volume near: no row, k_visc_setup)
+    const uint8_t *const st[3] = {stU, stV, stW};
+    const float *const vol[3] = {volU, volV, volW};
+    // the other faces that carry the same factor, per (component, slot): up to three of (component, di, dj, dk, slot there)
+    //   U: 0 centre(c) -> U(+x) slot 1 | 1 centre(c - x) -> U(-x) 0 | 2 edgeW(c + y): U(+y) 3, V(+y) 1, V(-x + y) 0 | 3 edgeW(c): U(-y) 2, V(c) 1, V(-x) 0
+    //      4 edgeV(c + z): U(+z) 5, W(+z) 1, W(-x + z) 0 | 5 edgeV(c): U(-z) 4, W(c) 1, W(-x) 0
+    //   V: 0 edgeW(c + x): V(+x) 1, U(+x) 3, U(+x - y) 2 | 1 edgeW(c): V(-x) 0, U(c) 3, U(-y) 2 | 2 centre(c) -> V(+y) 3 | 3 centre(c - y) -> V(-y) 2
+    //      4 edgeU(c + z): V(+z) 5, W(+z) 3, W(-y + z) 2 | 5 edgeU(c): V(-z) 4, W(c) 3, W(-y) 2
+    //   W: 0 edgeV(c + x): W(+x) 1, U(+x) 5, U(+x - z) 4 | 1 edgeV(c): W(-x) 0, U(c) 5, U(-z) 4 | 2 edgeU(c + y): W(+y) 3, V(+y) 5, V(+y - z) 4 | 3 edgeU(c): W(-y) 2, V(c) 5, V(-z) 4
+    //      4 centre(c) -> W(+z) 5 | 5 centre(c - z) -> W(-z) 4
+    struct Mem { signed char comp, di, dj, dk, slot; };
+    static const Mem M[3][6][3] = {
+        {{{0, 1, 0, 0, 1}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{0, -1, 0, 0, 0}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
+         {{0, 0, 1, 0, 3}, {1, 0, 1, 0, 1}, {1, -1, 1, 0, 0}}, {{0, 0, -1, 0, 2}, {1, 0, 0, 0, 1}, {1, -1, 0, 0, 0}},
+         {{0, 0, 0, 1, 5}, {2, 0, 0, 1, 1}, {2, -1, 0, 1, 0}}, {{0, 0, 0, -1, 4}, {2, 0, 0, 0, 1}, {2, -1, 0, 0, 0}}},
+        {{{1, 1, 0, 0, 1}, {0, 1, 0, 0, 3}, {0, 1, -1, 0, 2}}, {{1, -1, 0, 0, 0}, {0, 0, 0, 0, 3}, {0, 0, -1, 0, 2}},
+         {{1, 0, 1, 0, 3}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{1, 0, -1, 0, 2}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
+         {{1, 0, 0, 1, 5}, {2, 0, 0, 1, 3}, {2, 0, -1, 1, 2}}, {{1, 0, 0, -1, 4}, {2, 0, 0, 0, 3}, {2, 0, -1, 0, 2}}},
+        {{{2, 1, 0, 0, 1}, {0, 1, 0, 0, 5}, {0, 1, 0, -1, 4}}, {{2, -1, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, -1, 4}},
+         {{2, 0, 1, 0, 3}, {1, 0, 1, 0, 5}, {1, 0, 1, -1, 4}}, {{2, 0, -1, 0, 2}, {1, 0, 0, 0, 5}, {1, 0, 0, -1, 4}},
+         {{2, 0, 0, 1, 5}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{2, 0, 0, -1, 4}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}}};
+    for (int comp = 0; comp < 3; comp++) {
+        int slot;
+        if (!d_single_factor_row(comp, c, i, j, k, L, st, vol, nu, vC, vEU, vEV, vEW, factor, slot)) continue;
+        bool later = false;   // is there such a row of the same cluster BEFORE this one in the reference's row order?
+        for (int m = 0; m < 3 && !later; m++) {
+            const Mem e = M[comp][slot][m];
+            if (e.comp < 0) continue;
+            const size_t p = c + e.di + e.dj * sy + e.dk * sz;
+            int s2;
+            if (!d_single_factor_row(e.comp, p, i + e.di, j + e.dj, k + e.dk, L, st, vol, nu, vC, vEU, vEV, vEW, factor, s2) || s2 != e.slot) continue;
+            later = e.comp < comp || (e.comp == comp && p < c);
+        }
+        if (!later) continue;
+        const unsigned long long at = atomicAdd(list, 1ull);
+        if (at < (unsigned long long)FV_ELIM_CAP) list[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)comp;
+    }
+}
+// the listed faces: state ST_ELIM and velocity 0 before k_visc_setup (APPLY), ST_FLUID again after it (the states are kept while the solid SDF is unchanged)
+template <bool APPLY>
+__global__ void k_visc_singular_apply(const unsigned long long *__restrict__ list, uint8_t *__restrict__ stU, uint8_t *__restrict__ stV, uint8_t *__restrict__ stW,
+                                      float *__restrict__ U, float *__restrict__ V, float *__restrict__ W) {
+    unsigned long long n = list[0];
+    if (n > (unsigned long long)FV_ELIM_CAP) n = FV_ELIM_CAP;
+    for (unsigned long long t = threadIdx.x; t < n; t += blockDim.x) {
+        const size_t c = (size_t)(list[1 + t] >> 2);
+        const int comp = (int)(list[1 + t] & 3ull);
+        uint8_t *st = comp == 0 ? stU : (comp == 1 ? stV : stW);
+        st[c] = APPLY ? ST_ELIM : ST_FLUID;
+        if (APPLY) { float *X = comp == 0 ? U : (comp == 1 ? V : W); X[c] = 0.0f; }
+    }
+}
+
+// ------------------------------------------------------------------ strongly coupled pairs of rows (the multigrid loops' additive correction, k_viscosity_mg.hip: k_vmg_pairs)
+// Two rows whose coupling is >= 0.7 of the geometric mean of their diagonals -- a row without (or almost without) own volume hanging on ONE stress term, and the row
+// that shares that term -- carry a mode of Jacobi-scaled eigenvalue 1 - |coupling|: 2e-5 ... 1e-3 on a viscosity FIELD with a jump (holdout draws 9, 11 of round 5:
+// ~10 such modes, each on 2-3 rows, and CG -- diagonal or multigrid, fp32 or fp64 -- sits on a residual plateau until it has resolved every one of them: 295
+// Jacobi-PCG iterations against 74 with the pairs' 2 x 2 blocks added to the preconditioner, tests/research/jump_proto.py), and the same modes are what the velocity
+// criterion waits for in ordinary scenes (31 pairs on the 64^3 bunny at rest).  The geometric hierarchy does not see them: they are features of single faces.
+// Here: listed once per solve; every V-cycle adds each pair's weak mode, v v^T r / lambda (symmetric positive semi-definite; a row may sit in two pairs).
+constexpr float FV_PAIR_THETA = 0.7f;
+__global__ void k_visc_pairs_find(Lay L, const float *__restrict__ nu, const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV,
+                                  const float *__restrict__ vEW, const float *__restrict__ volU, const float *__restrict__ volV, const float *__restrict__ volW,
+                                  const uint8_t *__restrict__ rowmask, float factor, int brick, int swz, Lay LB, unsigned *__restrict__ count, VPair *__restrict__ list, float w0, float w1) {
+    IJK_OR_RETURN(L);
+    const unsigned mk = rowmask[c];
+    if (!(mk & 7u)) return;
+    if (i < L.olo[0] || i >= L.ohi[0] || j < L.olo[1] || j >= L.ohi[1] || k < L.olo[2] || k >= L.ohi[2]) return;   // (a block context: pairs of two OWNED rows)
+    const long sy = L.sy, sz = L.sz;
+    const float *const vol[3] = {volU, volV, volW};
+    const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, c, sy, sz, factor);
+    for (int comp = 0; comp < 3; comp++) {
+        if (!((mk >> comp) & 1u)) continue;
+        const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
+        const double dp = (double)vol[comp][c] + (double)f[0] + (double)f[1] + (double)f[2] + (double)f[3] + (double)f[4] + (double)f[5];
+        float fm = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 6; t++) fm = fmaxf(fm, f[t]);
+        if (!((double)fm >= (double)(FV_PAIR_THETA * FV_PAIR_THETA) * dp) || !(dp > 0.0)) continue;   // (|a| >= theta sqrt(dp dq) and dq >= |a| need |a| >= theta^2 dp)
+        for (int t = 1; t < 15; t++) {
+            int ec; long eo; double coef;
+            d_polish_entry(comp, t, f, (float)dp, sy, sz, ec, eo, coef);
+            if (!(fabs(coef) >= (double)(FV_PAIR_THETA * FV_PAIR_THETA) * dp)) continue;
+            const size_t cq = c + eo;
+            if (ec < comp || (ec == comp && cq <= c)) continue;            // (each pair once: from its first row in (component, index) order)
+            if (!((rowmask[cq] >> ec) & 1u)) continue;
+            const int qk = (int)(cq / (size_t)sz) + L.oz, qj = (int)((cq % (size_t)sz) / (size_t)sy) + L.oy, qi = (int)(cq % (size_t)sy) + L.ox;
+            if (qi < L.olo[0] || qi >= L.ohi[0] || qj < L.olo[1] || qj >= L.ohi[1] || qk < L.olo[2] || qk >= L.ohi[2]) continue;
+            const RefRowFactors G = d_ref_row_factors(nu, vC, vEU, vEV, vEW, cq, sy, sz, factor);
+            const float *g = ec == 0 ? G.U : (ec == 1 ? G.V : G.W);
+            const double dq = (double)vol[ec][cq] + (double)g[0] + (double)g[1] + (double)g[2] + (double)g[3] + (double)g[4] + (double)g[5];
+            if (!(coef * coef >= (double)(FV_PAIR_THETA * FV_PAIR_THETA) * dp * dq)) continue;
+            // The block's WEAK mode only: in Jacobi-scaled variables the block is [[1, s], [s, 1]], s = coef / sqrt(dp dq), with the eigenpair 1 - |s|, (1, -sign s) / sqrt 2; the
+            // correction is v v^T / lambda for it.  (The whole inverse B^-1 also counts the block's strong mode, which the V-cycle already resolves, a second time: the
+            // preconditioned spectrum then reaches 2 on every such pair and every solve takes 25-40 % more iterations -- measured, profiles/r6/pairs_diag.log.)
+            const double gm = sqrt(dp * dq);
+            double lam = (gm - fabs(coef)) / gm;
+            if (!(lam >= 1.0e-5)) lam = 1.0e-5;                            // (an almost singular block: the correction along its near-null vector is capped at 1e5 / diagonal)
+            const double sg = coef > 0.0 ? -1.0 : 1.0;
+            // ... and only what the cycle's own sweeps leave of it: the V(2,2) smoother alone contracts a mode of eigenvalue lambda by p = ((1 - w0 lambda)(1 - w1 lambda))^2
+            // (the coarse levels do nothing for a mode that lives on two faces), so the cycle already applies (1 - p) / lambda; the pair adds p / lambda.  With the plain
+            // 1 / lambda every pair of moderate weakness (lambda 0.03 ... 0.3) became an eigenvalue of its own between 1 and 2 above the preconditioned spectrum, one more CG
+            // iteration each: 81 instead of 65 iterations on the 64^3 bunny at nu = 200 (profiles/r6/pairs_diag_rank1.log).
+            // Is the weak mode of the BLOCK a weak mode of the SYSTEM?  v = D^-1/2 (1, sg) / sqrt 2 has the Rayleigh quotient lambda whatever the rows' other couplings are, but
+            // S v (S = D^-1/2 A D^-1/2) also has entries on the rows' OTHER neighbours; where their norm o exceeds lambda the pair is no eigenvector of anything -- the sweeps
+            // spread it to the neighbours and the cycle resolves it (the ordinary scenes' pairs: lambda 4e-4 ... 0.3 with o = 2e-2 ... 0.5), and adding its projector puts one more
+            // eigenvalue between 1 and 2 on top of the preconditioned spectrum: one more CG iteration per pair (64^3 bunny, 40 pairs: 137 -> 195 iterations in the scipy model
+            // of tests/research/jump_proto.py, 65 -> 85 on the device).  On a viscosity field with a jump o is 0.1 ... 1 lambda: those pairs stay (draw 11: 906 -> 390, draw 9:
+            // 112 -> 59 iterations in the model).  Rule: o <= lambda.  The two rows share neighbours (the other faces of the same edge), whose entries CANCEL in S v: both rows' entries are merged.
+            {
+                const double vp = 1.0 / sqrt(2.0 * dp), vq = sg / sqrt(2.0 * dq);
+                double o2 = 0.0;
+                for (int side = 0; side < 2; side++) {
+                    const int ca = side ? ec : comp, cb = side ? comp : ec;           // the row whose entries are walked, the other row of the pair
+                    const size_t ia = side ? cq : c, ib = side ? c : cq;
+                    const float *fa = side ? g : f, *fb = side ? f : g;
+                    const double da = side ? dq : dp, db = side ? dp : dq, va = side ? vq : vp, vb = side ? vp : vq;
+                    for (int u = 1; u < 15; u++) {
+                        int jc; long jo; double cj;
+                        d_polish_entry(ca, u, fa, (float)da, sy, sz, jc, jo, cj);
+                        if (cj == 0.0) continue;
+                        const size_t ij = ia + jo;
+                        if (jc == cb && ij == ib) continue;                            // (the pair's own coupling)
+                        double w = cj * va;
+                        bool shared = false;
+                        for (int u2 = 1; u2 < 15; u2++) {
+                            int kc; long ko; double ck;
+                            d_polish_entry(cb, u2, fb, (float)db, sy, sz, kc, ko, ck);
+                            if (ck != 0.0 && kc == jc && ib + ko == ij) { w += ck * vb; shared = true; }
+                        }
+                        if (shared && side) continue;                                  // (counted from the first row's side)
+                        if (!((rowmask[ij] >> jc) & 1u)) continue;                     // (no row there: a solid or empty face, nothing for S v to land on)
+                        const RefRowFactors H = d_ref_row_factors(nu, vC, vEU, vEV, vEW, ij, sy, sz, factor);
+                        const float *h = jc == 0 ? H.U : (jc == 1 ? H.V : H.W);
+                        const double dj = (double)vol[jc][ij] + (double)h[0] + (double)h[1] + (double)h[2] + (double)h[3] + (double)h[4] + (double)h[5];
+                        if (dj > 0.0) o2 += w * w / dj;
+                    }
+                }
+                if (!(o2 <= lam * lam)) continue;
+            }
+            const double pl = (1.0 - (double)w0 * lam) * (1.0 - (double)w1 * lam);
+            const double gain = pl * pl / lam;
+            const unsigned at = atomicAdd(count, 1u);
+            if (at >= (unsigned)FV_PAIR_CAP) continue;
+            VPair P;
+            P.ir0 = (unsigned)(brick ? bidx(LB, i, j, k) : (swz ? sidx(L, i, j, k) : c));
+            P.ir1 = (unsigned)(brick ? bidx(LB, qi, qj, qk) : (swz ? sidx(L, qi, qj, qk) : cq));
+            P.iz0 = (unsigned)(brick ? bidx(LB, i, j, k) : c);
+            P.iz1 = (unsigned)(brick ? bidx(LB, qi, qj, qk) : cq);
+            P.comps = (unsigned)comp | ((unsigned)ec << 2);
+            P.i00 = (float)(0.5 * gain / dp); P.i01 = (float)(0.5 * gain * sg / gm); P.i11 = (float)(0.5 * gain / dq);
+            list[at] = P;
+        }
+    }
+}
+
 // What every rank of a communicator must decide alike from (the preconditioner, the stiffness rule, the vector type of an FP64 solve): the viscosity field's
 // facts over ALL ranks, one small all-gather at the start of every solve -- before anything that chooses a sequence of collectives.
 static int visc_gather_field_facts(flipv_context *c) {
@@ -1044,7 +1229,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // The packed coarse rows round an entry to 11 bits; the mass term is 1/stiff of the entries.  Measured on the 256^3 bunny: identical iteration
         // counts up to nu dt/dx^2 = 131 072 (512^3, nu = 50), but at 327 680 (256^3, nu = 500) 3-4 of 20 solves end unconverged where the fp32 rows
         // lose 2: beyond 2e5 the cycle reads the fp32 grids.
-        c->vmgPackedRows = stiff <= 2.0e5 ? 1 : 0;
+        c->vmgPackedRows = c->prm.viscosity_mg_packed_rows ? (c->prm.viscosity_mg_packed_rows > 0 ? 1 : 0) : (stiff <= 2.0e5 ? 1 : 0);
     }
     const int precNow = std::is_same<T, float>::value ? 0 : 1;
     // flipv_params.exact_viscosity_operator = 0 (default): the solve applies the reference's operator INCLUDING the rounding of its float
@@ -1088,6 +1273,16 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             c->bandPrevValid = 1;
         }
         PcgSys<T, 3> vs = visc_sys<T>(c);
+        const bool elim = !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0;   // rows that repeat another row's equation: out of this solve's system (k_visc_singular_find)
+        if (elim) {
+            if (!c->elimList) HIPCHK(c, hipMalloc((void **)&c->elimList, (size_t)(FV_ELIM_CAP + 1) * sizeof(unsigned long long)));
+            HIPCHK(c, hipMemsetAsync(c->elimList, 0, sizeof(unsigned long long), c->stream));
+            const Lay RE = R0;   // (rows only exist in the liquid's range)
+            hipLaunchKernelGGL(k_visc_singular_find, GRID3(RE), 0, c->stream, RE, (const uint8_t *)c->stU, (const uint8_t *)c->stV, (const uint8_t *)c->stW, (const float *)c->volU,
+                               (const float *)c->volV, (const float *)c->volW, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
+                               (const float *)c->volEW, (const uint8_t *)c->validCells, factor, c->elimList);
+            hipLaunchKernelGGL(k_visc_singular_apply<true>, dim3(1), dim3(256), 0, c->stream, (const unsigned long long *)c->elimList, c->stU, c->stV, c->stW, c->U, c->V, c->W);
+        }
         { const FillJob z[2] = {{bmax, 2 * sizeof(double), 0}, {c->d_flags + 2, sizeof(int), 0}}; const int rcz = fv_fill_list(c, z, 2); if (rcz) return rcz; }
         // rows of the owned planes only (the SpMV reads diag / own volume at its own index, factors and s at +-1 plane); a change
         // of layout or precision rewrites every entry, not only those near the liquid
@@ -1096,6 +1291,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                            c->volW, c->volC, c->volEU, c->volEV, c->volEW, c->fC, c->fEU, c->fEV, c->fEW, c->vDiagU, c->vDiagV,
                            c->vDiagW, c->vmU, c->vmV, c->vmW, c->vrU, c->vrV, c->vrW, c->vRowMask, c->validCells, full, vs, bmax, c->d_flags + 2, (refDiag ? 1 : 0) | (predict ? 2 : 0),
                            brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2], c->phi);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
+        if (elim) hipLaunchKernelGGL(k_visc_singular_apply<false>, dim3(1), dim3(256), 0, c->stream, (const unsigned long long *)c->elimList, c->stU, c->stV, c->stW, c->U, c->V, c->W);
         if (!c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {   // the massless clusters: listed now and taken out of the velocity criterion's sight, solved after the solve
             if (!c->polishList) HIPCHK(c, hipMalloc((void **)&c->polishList, (size_t)(FV_POLISH_CAP + 1) * sizeof(unsigned long long)));
             HIPCHK(c, hipMemsetAsync(c->polishList, 0, sizeof(unsigned long long), c->stream));
@@ -1105,8 +1301,33 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                                (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
                                factor, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, (int *)nullptr, brick ? c->vMaskB : (uint8_t *)nullptr, c->LB);
         }
-        FV_READ_JOBS(c, FV_JOB(c->h_scal, bmax, 2 * sizeof(double)), FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int)));   // max|rhs|, max|u| over the rows; the row count
+        const bool pairs = mgPlanned && c->prm.viscosity_pair_correction >= 0;   // strongly coupled pairs of rows: listed for the multigrid loops' additive correction (k_visc_pairs_find)
+        c->h_flags[10] = 0;
+        if (pairs) {
+            if (!c->pairList) HIPCHK(c, hipMalloc((void **)&c->pairList, 16 + (size_t)FV_PAIR_CAP * sizeof(VPair)));
+            HIPCHK(c, hipMemsetAsync(c->pairList, 0, 16, c->stream));
+            hipLaunchKernelGGL(k_visc_pairs_find, GRID3(R0), 0, c->stream, R0, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV, (const float *)c->volEW,
+                               (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, factor, brick ? 1 : 0, c->vSwz ? 1 : 0, c->LB,
+                               (unsigned *)c->pairList, (VPair *)((char *)c->pairList + 16), c->prm.viscosity_mg_omega_first > 0.0f ? c->prm.viscosity_mg_omega_first : 1.317f,
+                               c->prm.viscosity_mg_omega_second > 0.0f ? c->prm.viscosity_mg_omega_second : 0.382f);   // (the cycle's Chebyshev pair: k_viscosity_mg.hip)
+        }
+        {
+            ReadJob jobs[4] = {FV_JOB(c->h_scal, bmax, 2 * sizeof(double)), FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int))};   // max|rhs|, max|u| over the rows; the row count
+            int nj = 2;
+            c->h_flags[11] = 0;
+            if (pairs) jobs[nj++] = FV_JOB(c->h_flags + 10, c->pairList, sizeof(int));
+            if (elim) jobs[nj++] = FV_JOB(c->h_flags + 11, c->elimList, sizeof(int));   // (the low word of the list's counter)
+            const int rcr = fv_read_small(c, jobs, nj);
+            if (rcr) return rcr;
+        }
         FV_SYNC(c);  // h_flags[2] = row count
+        c->nPairs = pairs ? (c->h_flags[10] < FV_PAIR_CAP ? c->h_flags[10] : FV_PAIR_CAP) : 0;
+        c->nElim = elim ? (c->h_flags[11] < FV_ELIM_CAP ? c->h_flags[11] : FV_ELIM_CAP) : 0;
+        if (c->prm.verbose && pairs) fprintf(stderr, "viscosity solve %ld: %d strongly coupled pairs of rows in the multigrid's additive correction%s\n", c->viscSolves, c->h_flags[10],
+                                             c->h_flags[10] > FV_PAIR_CAP ? " -- MORE THAN THE LIST HOLDS" : "");
+        if (c->prm.verbose && c->h_flags[11] > 0)
+            fprintf(stderr, "viscosity solve %ld: %d rows repeat another row's equation (a singular cluster): held at 0 like the reference's iterate%s\n", c->viscSolves, c->h_flags[11],
+                    c->h_flags[11] > FV_ELIM_CAP ? " -- MORE THAN THE LIST HOLDS, the rest stay rows" : "");
         return FLIPV_OK;
     };
     const int rowlNow = c->prm.tile_rows == 16 || c->prm.tile_rows == 64 ? c->prm.tile_rows : c->tgV.rowl;
@@ -1160,6 +1381,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const double bnorm = bnormAll;   // (a repeated set-up recomputes the rank's own maximum: the merged one stands)
     li.rhs_norm = bnorm;
     li.rows = c->h_flags[2];
+    li.eliminated_rows = c->nElim;
     li.active_tiles = c->nActiveV;
     li.total_tiles = brick ? (int)(c->LB.n / 64) : c->tgV.count();
     li.layout = c->vLayout;

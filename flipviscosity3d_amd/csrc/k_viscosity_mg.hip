@@ -945,7 +945,7 @@ __device__ __forceinline__ bool d_vmg_stop_test(const PcgScal &sc, int it, doubl
     }
     if (sc.best) {   // stall guard, as in k_pcg_update (pcg_common.h: PcgScal::best)
         const double bestNow = *sc.best;
-        if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > 16.0 * bestNow) {
+        if (bestNow <= (sc.stall_below > 0.0 ? sc.stall_below : 100.0 * sc.tol) && res > sc.stall_ratio * bestNow) {
             if (first) { *sc.stalled = 1; *sc.conv = it; }
             return true;
         }
@@ -1535,6 +1535,29 @@ static int vmg_setup(flipv_context *c, VmgState **out) {
     return FLIPV_OK;
 }
 
+// The additive correction of the V-cycle on strongly coupled pairs of rows (k_viscosity.hip: k_visc_pairs_find): z += B^-1 r over every listed pair's 2 x 2 block,
+// (r, z) adjusted by the same amount.  One small block; a row may sit in two pairs (a chain of three rows), hence the atomic adds.
+__global__ __launch_bounds__(256) void k_vmg_pairs(const unsigned *__restrict__ count, const VPair *__restrict__ list, Vec3p r, Vec3p z, PcgScal sc, int it_arg, int sig_shift) {
+    __shared__ double lds[8];
+    bool stop;
+    const int it = d_iter_spmv(sc, it_arg, stop);
+    if (stop) return;
+    unsigned n = *count;
+    if (n > (unsigned)FV_PAIR_CAP) n = FV_PAIR_CAP;
+    double acc = 0.0;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const VPair P = list[t];
+        const int c0 = (int)(P.comps & 3u), c1 = (int)((P.comps >> 2) & 3u);
+        const float r0 = r.p[c0][P.ir0], r1 = r.p[c1][P.ir1];
+        const float d0 = P.i00 * r0 + P.i01 * r1, d1 = P.i01 * r0 + P.i11 * r1;
+        atomicAdd(z.p[c0] + P.iz0, d0);
+        atomicAdd(z.p[c1] + P.iz1, d1);
+        acc += (double)r0 * (double)d0 + (double)r1 * (double)d1;
+    }
+    acc = block_sum_256(acc, lds);
+    if (threadIdx.x == 0 && sc.conv && acc != 0.0) atomicAdd(sc.sig(it + sig_shift) + sc.my_slot(), acc);
+}
+
 // z = M^-1 r (level 0) into zb, (r, z) into sig(it + sig_shift).  On entry za = omega r/d (k_vpcg_xr left it).
 // it_arg = IT_DEVICE: the device-side iteration counter (inside the replayed graph)
 static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_arg, int sig_shift) {
@@ -1667,6 +1690,10 @@ static void vmg_vcycle(flipv_context *c, VmgState *s, const PcgScal &sc, int it_
     }
     sweep(s->zb, s->za, 1, s->w[0], 0);                                                      // post-sweeps: zb -> za -> zb
     sweep(s->za, s->zb, 3, s->w[1], sig_shift);
+    if (c->nPairs > 0) {   // + the strongly coupled pairs' blocks (additive)
+        float *r[3] = {(float *)c->vR[0], (float *)c->vR[1], (float *)c->vR[2]};
+        hipLaunchKernelGGL(k_vmg_pairs, dim3(1), dim3(256), 0, c->stream, (const unsigned *)c->pairList, (const VPair *)((const char *)c->pairList + 16), v3(r), v3(s->zb), sc, it_spmv, sig_shift);
+    }
 }
 
 // PCG with the V-cycle as preconditioner.  On entry k_visc_setup has left r = rhs, x = 0, s (= p) = 0 and the tile / brick list;

@@ -112,6 +112,11 @@ template <> __device__ __forceinline__ double d_recip<double>(float d) { return 
 // In a multi-rank run rank r accumulates only into slots [slot0, slot0 + nslot): the slots are disjoint between
 // ranks, so a SUM all-reduce merges sums and maxima alike.
 constexpr int FV_NSC = 6;   // scalars per iteration block
+// The stall guard's factor: a loop stops once max|r| exceeds this x the smallest value it has reached.  16 until round 6 -- but CG's max-norm residual legitimately rebounds
+// by more than that on a system with a few isolated small eigenvalues (a viscosity field with a jump: 14 x in an fp64 Jacobi-PCG model of holdout draw 9, 20-50 x on the
+// device), and the guard then ended every correction stage of such a solve after 10-40 iterations (the draw's 0.2 ... 0.9 max|u| of round 5).  What the guard is FOR -- an fp32
+// recurrence that has left the true residual behind and blows up by 1e8 over thousands of iterations -- is caught as well by 1e3; stagnation has its own guard (VMG_NO_PROGRESS).
+constexpr double FV_STALL_RATIO = 1000.0;
 struct PcgScal {
     double *base;
     int *conv;      // converged-at iteration, -1 while running (nullptr: benchmark launch, no scalars)
@@ -134,6 +139,7 @@ struct PcgScal {
     double *best;   // nullptr: no guard
     int *stalled;
     int *bestIt;    // iteration at which *best last improved by 10 % (the multigrid loop's no-progress guard, k_viscosity_mg.hip: d_vmg_stop_test); nullptr: none
+    double stall_ratio;   // the guard's factor (FV_STALL_RATIO; flipv_debug_params.stall_guard_ratio)
     double stall_below;   // the guard arms once *best <= this; 0 = 100 x tol.  (A loop restarted close to its tolerance -- iterative refinement --
                           // sets it to a fraction of the restart's residual: the first iterations of CG overshoot it in the max norm.)
     // device-side iteration counters for hipGraph replay (kernels launched with it_arg = -1): the SpMV reads itA and
@@ -526,7 +532,8 @@ static int pcg_run(flipv_context *c, const PcgScal &sc, int cap, const HaloArray
     }
     {
         if (conv < 0) {  // cap reached: the last iteration's residual has not been merged or tested yet
-            if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(cap - 1), NSLOT))) return rc;
+            // ([rmax step](cap - 1) are adjacent: k_pcg_check and the later k_pcg_residual read the step block as well, and every rank must see the same one)
+            if (c->comm && (rc = fv_allreduce_scalars(c, sc.rmax(cap - 1), 2 * NSLOT))) return rc;
             hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(64), 0, c->stream, sc, cap - 1);
             FV_READ(c, c->h_flags, c->d_flags, sizeof(int));
             FV_SYNC(c);

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FLIPV_VERSION 5   /* 3: every behavioural switch is a flipv_params field (no environment variables); brick layout; residual replacement
+#define FLIPV_VERSION 6   /* 3: every behavioural switch is a flipv_params field (no environment variables); brick layout; residual replacement
                              4: the constants of the two-stage viscosity solve are flipv_params fields; flipv_solve_info reports the correction stage
                              5: the velocity criterion and the mass scale of the viscosity solve (flipv_solve_info.velocity_step); A/B and measurement switches moved to
                                 flipv_debug_params; residual_replacement removed; flipv_abi_version() */
@@ -166,6 +166,10 @@ typedef struct flipv_params {
                                                first 400 substeps of that scene take 14.6 instead of 15.9 ms.  NOT the default: a plateau can also be a light part CG has not resolved YET
                                                (64^3, nu = 0.5, one substep of the impact: 9.5e-4 from the converged reference with the exit, 1e-6 without) and nothing in the
                                                iteration's history tells the two apart */
+    int viscosity_pair_correction;          /* [0 = on] -1: off.  Multigrid loops: pairs of rows whose coupling is >= 0.7 of the geometric mean of their diagonals -- a row (almost) without own
+                                               volume hanging on one stress term and the row that shares it -- get their 2 x 2 block solved in every preconditioner application, added to the
+                                               V-cycle (FLIPV_VERSION 6).  Each such pair carries a mode of Jacobi-scaled eigenvalue 1 - |coupling| (2e-5 ... 1e-3 on a viscosity field with a
+                                               jump) that the geometric hierarchy does not see and CG otherwise resolves one plateau at a time */
 } flipv_params;
 
 /* Switches for A/B measurements, profiling and tests (flipv_set_debug_params).  Results do not depend on them beyond solver tolerance; none of them is needed to
@@ -193,6 +197,8 @@ typedef struct flipv_debug_params {
                                     iteration, but on ill-conditioned systems the fp32 solve stagnates */
     int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 = chosen per solve; -1 = the tile-at-a-time kernels; -2 = the pressure
                                     SpMV's address-order sweep kernel (filled boxes in 64-lane rows) whatever the size */
+    int viscosity_mg_packed_rows; /* coarse rows of the viscosity multigrid as the cycle reads them: 0 = chosen per solve (packed fp16 up to nu dt/dx^2 = 2e5), 1 = packed fp16, -1 = the fp32 grids */
+    float stall_guard_ratio;     /* the stall guard of the PCG loops stops a loop whose max|r| exceeds this x the smallest it has reached (once that is within 100 x the tolerance); 0 = 1000 (16 until FLIPV_VERSION 6) */
 } flipv_debug_params;
 
 typedef struct flipv_solve_info {
@@ -225,6 +231,9 @@ typedef struct flipv_solve_info {
     int correction_status;     /* 0 no correction stage; 1 the (last) stage reached its target; 2 it ran into its iteration budget or stalled first -- also after the
                                   one restart such a stage gets -- (its result is kept if it lowered the fp64 residual; `status` is then 1); 3 the last stage RAISED the fp64 residual and was taken back
                                   (`status` 1) */
+    int eliminated_rows;       /* viscosity: rows of the reference's system that REPEAT another row's equation (massless faces around one edge or cell centre whose only non-zero factor is that
+                                  edge's: the reference's matrix is singular there) and were held at 0 instead of solved for -- what the reference's MIC(0)-PCG leaves them at (k_viscosity.hip:
+                                  k_visc_singular_find).  `rows` + this = the reference's row count (FLIPV_VERSION 6) */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */

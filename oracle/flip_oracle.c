@@ -1041,6 +1041,8 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
     M.col = (unsigned *)malloc(((size_t)n + 1) * ROWCAP * sizeof(unsigned));
     M.val = (double *)malloc(((size_t)n + 1) * ROWCAP * sizeof(double));
     double *rhs = (double *)calloc((size_t)n + 1, sizeof(double));
+    /* research dump only: the diagonal summed in double (the EXACT operator's) and the rows' own volumes */
+    double *dgx = g_visc_dump ? (double *)calloc((size_t)n + 1, sizeof(double)) : NULL, *dgv = g_visc_dump ? (double *)calloc((size_t)n + 1, sizeof(double)) : NULL;
 
     float invdx = 1.0f / dxf;
     float factor = dtf * invdx * invdx;
@@ -1063,6 +1065,7 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
                 float fF = factor * viscF * VEV(i, j, k + 1);
                 float fK = factor * viscK * VEV(i, j, k);
                 float diag = VU(i, j, k) + fR + fL + fT + fB + fF + fK;
+                if (dgx) { dgx[row] = (double)VU(i, j, k) + (double)fR + (double)fL + (double)fT + (double)fB + (double)fF + (double)fK; dgv[row] = (double)VU(i, j, k); }
                 rm_put(m, row, row, (double)diag, 0);
                 COUPLE(stU(&s, i + 1, j, k), rowU(&s, i + 1, j, k), 0, -fR);
                 COUPLE(stU(&s, i - 1, j, k), rowU(&s, i - 1, j, k), 0, -fL);
@@ -1114,6 +1117,7 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
                 float fF = factor * viscF * VEU(i, j, k + 1);
                 float fK = factor * viscK * VEU(i, j, k);
                 float diag = VV(i, j, k) + fR + fL + fT + fB + fF + fK;
+                if (dgx) { dgx[row] = (double)VV(i, j, k) + (double)fR + (double)fL + (double)fT + (double)fB + (double)fF + (double)fK; dgv[row] = (double)VV(i, j, k); }
                 rm_put(m, row, row, (double)diag, 0);
                 COUPLE(stV(&s, i + 1, j, k), rowV(&s, i + 1, j, k), 0, -fR);
                 COUPLE(stV(&s, i - 1, j, k), rowV(&s, i - 1, j, k), 0, -fL);
@@ -1165,6 +1169,7 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
                 float fF = 2 * factor * viscF * VC(i, j, k);
                 float fK = 2 * factor * viscK * VC(i, j, k - 1);
                 float diag = VW(i, j, k) + fR + fL + fT + fB + fF + fK;
+                if (dgx) { dgx[row] = (double)VW(i, j, k) + (double)fR + (double)fL + (double)fT + (double)fB + (double)fF + (double)fK; dgv[row] = (double)VW(i, j, k); }
                 rm_put(m, row, row, (double)diag, 0);
                 COUPLE(stW(&s, i + 1, j, k), rowW(&s, i + 1, j, k), 0, -fR);
                 COUPLE(stW(&s, i - 1, j, k), rowW(&s, i - 1, j, k), 0, -fL);
@@ -1202,16 +1207,18 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
     if (g_visc_dump) { /* solver research hook (oracle_viscosity_dump_to): the assembled system as raw binary */
         FILE *f = fopen(g_visc_dump, "wb");
         if (f) {
-            long long hdr[4] = {n, ROWCAP, (long long)dim, 0};
+            long long hdr[4] = {n, ROWCAP, (long long)dim, (dgx && dgv) ? 1 : 0};
             fwrite(hdr, sizeof(hdr), 1, f);
             fwrite(M.cnt, sizeof(int), (size_t)n, f);
             fwrite(M.col, sizeof(unsigned), (size_t)n * ROWCAP, f);
             fwrite(M.val, sizeof(double), (size_t)n * ROWCAP, f);
             fwrite(rhs, sizeof(double), (size_t)n, f);
             fwrite(s.table, sizeof(int), dim, f);
+            if (dgx && dgv) { fwrite(dgx, sizeof(double), (size_t)n, f); fwrite(dgv, sizeof(double), (size_t)n, f); }
             fclose(f);
         }
     }
+    free(dgx); free(dgv);
 
     /* ---- PCGSolver<double>::solve (pcgsolver.h:241-295) ---- */
     double *x = (double *)calloc((size_t)n + 1, sizeof(double));
@@ -1335,6 +1342,16 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
                 rho = rho_new;
             }
             if (!success) iters = it;
+        }
+    }
+    if (g_visc_dump) { /* research hook: the iterate the solve ended with, beside the dumped system */
+        size_t L = strlen(g_visc_dump);
+        char *px = (char *)malloc(L + 3);
+        if (px) {
+            memcpy(px, g_visc_dump, L); memcpy(px + L, ".x", 3);
+            FILE *f = fopen(px, "wb");
+            if (f) { fwrite(x, sizeof(double), (size_t)n, f); fclose(f); }
+            free(px);
         }
     }
     li.iterations = iters;

@@ -211,6 +211,106 @@ def late_state(name, N, boundary, liquid, nu, nsub_before, nprobe=100000, ntop=5
     s.close()
 
 
+BIG = os.path.join(OUT, "_big")     # git-ignored: particle states of 256^3 scenes (113 MB each); regenerable with this script, checked by sha256 from the committed .npz
+
+
+def _ref_scene(N, boundary, liquid, nu):
+    dx = float(np.float32(1.0 / N))
+    s = R.RefSim(N, N, N, dx)
+    if boundary is not None:
+        bv, bt = load_ply(os.path.join(MESH, boundary[0]))
+        s.add_boundary(bv, bt, boundary[1])
+    R.lib().ref_srand(1)
+    for m in liquid:
+        lv, lt = load_ply(os.path.join(MESH, m))
+        s.add_liquid(lv, lt)
+    s.set_viscosity(nu)
+    return s, dx
+
+
+def carry_states(prefix, N, boundary, liquid, nu, snapshots, dt=0.01):
+    """Round 6: ONE run of the compiled reference at its defaults through max(snapshots) substeps; the particles it holds after each listed substep
+    count are written to tests/golden/_big/<prefix>_sub<k>_state.npy (113 MB at 256^3: kept out of git, see BIG).  late_state_big() then solves from each."""
+    import time
+    os.makedirs(BIG, exist_ok=True)
+    s, dx = _ref_scene(N, boundary, liquid, nu)
+    log = []
+    for t in range(max(snapshots)):
+        t0 = time.time()
+        s.substep(dt)
+        st = s.solver_stats()
+        log.append((st["visc_iters"], st["visc_err"], st["pres_iters"]))
+        print("  %s substep %d: viscosity %d its (%.2e), pressure %d its, %.0f s" % (prefix, t, st["visc_iters"], st["visc_err"], st["pres_iters"], time.time() - t0), flush=True)
+        if t + 1 in snapshots:
+            path = os.path.join(BIG, "%s_sub%d_state.npy" % (prefix, t + 1))
+            np.save(path + ".tmp.npy", s.particles)
+            np.save(os.path.join(BIG, "%s_sub%d_carrylog.npy" % (prefix, t + 1)), np.array(log, np.float64))
+            os.replace(path + ".tmp.npy", path)
+            print("  wrote", path, flush=True)
+    s.close()
+
+
+def late_state_big(name, N, boundary, liquid, nu, nsub_before, nprobe=300000, ntop=5000, surface_stride=4, vtol=1e-13, vcap=3000000, dt=0.01):
+    """late_state() at the headline size.  The state (the reference's particles after `nsub_before` of its own substeps at its defaults, from carry_states) stays in
+    tests/golden/_big/<name>_state.npy; the committed fixture holds its sha256 / checksums / per-octant sums, how the reference got there (iteration counts per carried
+    substep), and the reference's answer from it with the viscosity cap lifted and the tolerance at `vtol`: `nprobe` seeded probe faces per component, the `ntop` of
+    largest |u|, every `surface_stride`-th face within one cell of the free surface, per-octant particle checksums -- plus the distance of the reference AT ITS DEFAULTS
+    from that answer.  A test that does not find the state file regenerates it by carrying the (bit-pinned) oracle or oracle/_ref through the same substeps."""
+    import hashlib
+    import time
+    spath = os.path.join(BIG, name + "_state.npy")
+    state = np.load(spath)
+    s, dx = _ref_scene(N, boundary, liquid, nu)
+    s.particles = state
+    d = dict(I=N, J=N, K=N, dx=np.float32(dx), dt=np.float32(dt), gravity=np.array((0.0, -9.81, 0.0), np.float32), nu=np.float32(nu), nsub_before=nsub_before,
+             vtol=np.float64(vtol), nparticles=len(state), state_sha256=hashlib.sha256(np.ascontiguousarray(state).tobytes()).hexdigest(),
+             state_sum=state.astype(np.float64).sum(axis=0), solid_sum=np.float64(s.grid("SOLID_PHI").astype(np.float64).sum()),
+             carry_log=np.load(os.path.join(BIG, name + "_carrylog.npy")))
+    oc = (state[:, 0] > 0.5).astype(int) + 2 * (state[:, 1] > 0.25).astype(int) + 4 * (state[:, 2] > 0.5).astype(int)
+    d["state_octant_sum"] = np.stack([state[oc == o].astype(np.float64).sum(axis=0) if (oc == o).any() else np.zeros(6) for o in range(8)])
+    t0 = time.time()
+    s.substep(dt)                                  # at the reference's defaults
+    st = s.solver_stats()
+    d["defaults_visc_iters"] = st["visc_iters"]; d["defaults_visc_err"] = st["visc_err"]
+    dflt = [s.grid(c) for c in "UVW"]
+    print("  %s: the reference at its defaults: %d viscosity iterations (%.2e), %.0f s" % (name, st["visc_iters"], st["visc_err"], time.time() - t0), flush=True)
+    s.particles = state
+    s.set_viscosity_solver(maxiter=vcap, tol=vtol)
+    t0 = time.time()
+    s.substep(dt)
+    st = s.solver_stats()
+    d["visc_iters"] = st["visc_iters"]; d["visc_err"] = st["visc_err"]; d["pres_iters"] = st["pres_iters"]
+    print("  %s: the reference at %g: %d viscosity iterations (%.2e), pressure %d, %.0f s" % (name, vtol, st["visc_iters"], st["visc_err"], st["pres_iters"], time.time() - t0), flush=True)
+    conv = [s.grid(c) for c in "UVW"]
+    den = max(np.abs(a).max() for a in conv)
+    d["maxabs"] = np.float32(den)
+    dist = [np.abs(a.astype(np.float64) - b) / den for a, b in zip(dflt, conv)]
+    d["defaults_vs_converged"] = np.float64(max(x.max() for x in dist))
+    d["defaults_faces_beyond_1e-4"] = int(sum((x > 1e-4).sum() for x in dist))
+    d["defaults_faces_beyond_1e-5"] = int(sum((x > 1e-5).sum() for x in dist))
+    phi = s.grid("LIQUID_PHI")
+    rng = np.random.default_rng(2026)
+    for c, a in zip("UVW", conv):
+        flat = a.reshape(-1)
+        nz = np.flatnonzero(flat)
+        top = nz[np.argsort(np.abs(flat[nz]))[::-1][:ntop]]
+        near = np.zeros(a.shape, bool)
+        near[tuple(slice(0, n) for n in phi.shape)] = np.abs(phi) < dx
+        surf = np.flatnonzero(near.reshape(-1) & (flat != 0))[::surface_stride]
+        idx = np.unique(np.concatenate([rng.choice(nz, size=min(nprobe, len(nz)), replace=False), top, surf]))
+        d["probe_idx_" + c] = idx.astype(np.int64)
+        d["probe_val_" + c] = flat[idx]
+        d["nonzero_faces_" + c] = len(nz)
+    Pn = s.particles
+    oct_ = (Pn[:, 0] > 0.5).astype(int) + 2 * (Pn[:, 1] > 0.25).astype(int) + 4 * (Pn[:, 2] > 0.5).astype(int)
+    d["particles_octant_sum"] = np.stack([Pn[oct_ == o].astype(np.float64).sum(axis=0) if (oct_ == o).any() else np.zeros(6) for o in range(8)])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("%-28s %8d particles  %6.0f KiB; converged %d viscosity iterations (defaults %d), the reference at its defaults is %.2e from it (%d faces beyond 1e-4)" % (
+        name, len(state), os.path.getsize(path) / 1024, d["visc_iters"], d["defaults_visc_iters"], float(d["defaults_vs_converged"]), d["defaults_faces_beyond_1e-4"]), flush=True)
+    s.close()
+
+
 def layered_viscosity(I, J, K):
     # node-sampled, varies with height and x: exercises setViscosity(Array3d<float>&) (fluidsimulation.cpp:110-124)
     k, j, i = np.meshgrid(np.arange(K + 1), np.arange(J + 1), np.arange(I + 1), indexing="ij")
@@ -275,3 +375,14 @@ if __name__ == "__main__":
     if "bunny256_nu5_tight" in only:
         compact_scene("bunny256_nu5_tight", 256, ("sphere_large.ply", True), ["stanford_bunny.ply"], 5.0, 1, vcap=60000, vtol=1e-8,
                       store_inputs=False, nprobe=20000)
+    # K (round 6): LATE states of the headline configuration itself, 256^3: mid-fall inside bench.py's timed window (10 substeps in), on the wall (25, 35), and at
+    #    nu = 200 (S = 1.3e5) on the wall.  `carry256_nu5` / `carry256_nu200` = the reference at its defaults up to the last snapshot (47 s per substep); then one
+    #    `bunny256_nu*_sub*` per state (the reference at 1e-13 from the stored state).  Hours of one core each; only when named.
+    BUNNY = (("sphere_large.ply", True), ["stanford_bunny.ply"])
+    if "carry256_nu5" in only:
+        carry_states("bunny256_nu5", 256, *BUNNY, 5.0, (10, 25, 35))
+    if "carry256_nu200" in only:
+        carry_states("bunny256_nu200", 256, *BUNNY, 200.0, (25,))
+    for nm, nu_, k_ in (("bunny256_nu5_sub10", 5.0, 10), ("bunny256_nu5_sub25", 5.0, 25), ("bunny256_nu5_sub35", 5.0, 35), ("bunny256_nu200_sub25", 200.0, 25)):
+        if nm in only:
+            late_state_big(nm, 256, *BUNNY, nu_, k_)

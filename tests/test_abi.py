@@ -56,7 +56,7 @@ def test_abi_version_is_the_headers():
     from flipviscosity3d_amd import capi
     L = capi.load()
     hdr = open(os.path.join(ROOT, "include", "flipv.h")).read()
-    assert L.flipv_abi_version() == int(re.search(r"#define FLIPV_VERSION (\d+)", hdr).group(1)) == 5
+    assert L.flipv_abi_version() == int(re.search(r"#define FLIPV_VERSION (\d+)", hdr).group(1)) == 6
 
 
 def test_default_params_are_the_reference_constants():

@@ -2,7 +2,7 @@
 converged answers (1e-13 / 1e-13) committed under tests/golden/holdout/ (the tool's `prepare` step wrote them; the draws themselves are regenerated from the seed).
 Scenes, sizes (non-cubic included), time steps, viscosities (5 % either side of the rule's thresholds among them) and viscosity FIELDS that none of the scans behind the
 rule's constants used.  The GPU runs with NO field of flipv_params set; bar: <= 1e-4 relative max-norm on EVERY face.
-The full sweep (47 draws): profiles/r5/holdout_sweep.log.  Its failures are fixtures too -- see the second test."""
+The full sweep (47 draws): profiles/r5/holdout_sweep.log; with round 6's library: profiles/r6/holdout_sweep_r5seed.log.  Its two failures of round 5 are the second test."""
 import os
 import sys
 
@@ -15,11 +15,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 HOLD = os.path.join(GOLDEN, "holdout")
 PASSING = [0, 6, 7, 8, 13, 15, 21, 23, 26, 29, 36, 39, 40]
-# draws the default solve does NOT bring within 1e-4 (profiles/r5/holdout_sweep.log), kept as fixtures with what is known about them
-KNOWN = {9: "honey 40^3, viscosity 1e-4 | 200 (contrast 2e6) after 40 substeps: the reference's operator is indefinite on the sliver rows at the jump (own volume + rounding "
-            "defect < 0); the fp32 correction stage stalls at 1e-3 max|rhs| and the solve SAYS so (status 1) -- the reference's own MIC(0) PCG gets through in 310 iterations",
-         11: "honey 40^3, viscosity 0 | 3 000 after 5 substeps: 600+ iterations, within 1e-4 ... 8e-4 on a few faces from run to run (the correction stages end short: status 1)"}
-
+# Round 5's misses: draw 9 (honey 40^3, viscosity 1e-4 | 200 after 40 substeps: 0.2 ... 0.9 max|u|, status 1) and draw 11 (honey 40^3, 0 | 3 000 after 5 substeps: 2e-5 ... 8e-2 from run
+# to run, status 1).  What they were (round 6, tests/research/jump_proto.py on the oracle's dumped systems): (i) two rows that are the SAME equation -- the reference's
+# matrix is exactly singular, its MIC(0)-PCG holds the later row at 0 --, now taken out of the system the same way (flipv_solve_info.eliminated_rows); (ii) ~10 (draw 9) / 64 (draw 11)
+# strongly coupled pairs of rows, each a mode of Jacobi-scaled eigenvalue 1e-5 ... 1e-3 the multigrid does not see: their weak modes are now part of the preconditioner
+# (flipv_params.viscosity_pair_correction); (iii) a stall guard that read CG's legitimate 20-50 x rebounds of max|r| on such a spectrum as a blow-up and ended every correction
+# stage after 10-40 iterations (16 x -> 1 000 x).  Five consecutive runs each, NO parameter set: <= 1e-4, status 0.
+FIXED_IN_ROUND_6 = [9, 11]
 
 def run_draw(i):
     import holdout_sweep as H
@@ -53,9 +55,12 @@ def test_holdout_draw_default_parameters(i):
     assert err <= 1e-4, err
 
 
-@pytest.mark.parametrize("i", sorted(KNOWN))
-def test_holdout_known_failures_say_so(i):
-    """the draws of the sweep that miss the bar: either they have come within it, or the solve reports that it did not converge (status 1) -- never a silent miss"""
-    err, nbad, st = run_draw(i)
-    print("known:", KNOWN[i])
-    assert err <= 1e-4 or st["viscosity"]["status"] == 1, (err, st["viscosity"])
+@pytest.mark.parametrize("i", FIXED_IN_ROUND_6)
+def test_holdout_viscosity_jump_draws_five_consecutive_runs(i):
+    errs = []
+    for rep in range(5):
+        err, nbad, st = run_draw(i)
+        assert st["viscosity"]["status"] == 0 and st["pressure"]["status"] in (0, 3), st
+        errs.append(err)
+    print("draw %d, five runs: %s" % (i, " ".join("%.2e" % e for e in errs)))
+    assert max(errs) <= 1e-4, errs

@@ -58,9 +58,9 @@ def test_slab_decomposition_matches_single_domain(name, nranks):
         want = [ref.grid(n) for n in "UVW"]
         assert rel_maxnorm3(got, want) <= 2e-5, (t, rel_maxnorm3(got, want))
         assert rel_maxnorm3(got, g.uvw(t, "final")) <= 1e-4
-        # liquid SDF is order-free: identical bits
+        # liquid SDF is order-free: the same values for the same particles -- which after a substep agree to the last bits of the velocities (1e-7 of a cell)
         phi = partition.gather_owned([c.grid("LIQUID_PHI") for c in ctxs], ranges, K)
-        assert np.array_equal(phi, ref.grid("LIQUID_PHI"))
+        assert np.array_equal(phi, ref.grid("LIQUID_PHI")) if t == 0 else np.abs(phi - ref.grid("LIQUID_PHI")).max() <= 1e-6 * g.dx
         # particles: same set (order differs after migration)
         allp = np.concatenate([c.particles for c in ctxs])
         assert_same_particle_set(allp, ref.particles, 1e-5)
@@ -171,7 +171,8 @@ def test_block_decomposition_matches_single_domain(name, dims):
         want = [ref.grid(n) for n in "UVW"]
         assert rel_maxnorm3(got, want) <= 2e-5, (t, rel_maxnorm3(got, want))
         assert rel_maxnorm3(got, g.uvw(t, "final")) <= 1e-4
-        assert np.array_equal(assemble(ctxs, "LIQUID_PHI"), ref.grid("LIQUID_PHI"))      # order-free: identical bits
+        phi_b, phi_r = assemble(ctxs, "LIQUID_PHI"), ref.grid("LIQUID_PHI")             # order-free: identical bits for identical particles (substep 0); afterwards the particles agree to the velocities' last bits
+        assert np.array_equal(phi_b, phi_r) if t == 0 else np.abs(phi_b - phi_r).max() <= 1e-6 * g.dx
         allp = np.concatenate([c.particles for c in ctxs])
         assert_same_particle_set(allp, ref.particles, 1e-5)
         own = partition.box_owner(allp, g.dx, boxes, dims)                               # ownership after migration

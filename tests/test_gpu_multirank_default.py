@@ -152,7 +152,9 @@ def test_distributed_level_1_is_the_same_preconditioner(N, dims):
             N, dims, t, vr["iterations"], vg["iterations"], vd["iterations"], vg["comm_bytes_per_iteration"] / 1e6, vd["comm_bytes_per_iteration"] / 1e6,
             vg["comm_bytes_setup"] / 1e6, vd["comm_bytes_setup"] / 1e6))
         assert vd["status"] == 0 and vd["preconditioner"] == 1 and vd["layout"] == 2, vd
-        assert abs(vd["iterations"] - vr["iterations"]) <= 6 and abs(vg["iterations"] - vr["iterations"]) <= 6, (vr, vg, vd)
+        # (round 6: a block context adds the weak modes of the strongly coupled pairs whose two rows it OWNS; the few pairs across a cut face get none -- the second, chained substep
+        # of the 128^3 case has taken 53 / 55 / 62 iterations)
+        assert abs(vd["iterations"] - vr["iterations"]) <= 10 and abs(vg["iterations"] - vr["iterations"]) <= 10, (vr, vg, vd)
         assert vd["comm_bytes_per_iteration"] < 0.3 * vg["comm_bytes_per_iteration"], (vg, vd)
         # what one iteration issues (flipv_solve_info): p's halo + the four fine sweeps' inputs (+ the distributed level's own exchanges); [p.q] and [max|r|, step, (r, z)]
         # (+ the global hierarchy's right-hand side).  None on one rank.
@@ -193,6 +195,35 @@ def test_variable_viscosity_blocks_run_the_single_domains_solve(dims):
     for c in ctxs:
         c.close()
     ref.close()
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 2), (2, 2, 2)])
+def test_ranks_agree_when_the_diagonal_loop_hits_its_cap(dims):
+    """at the iteration cap pcg_run all-reduced only max|r| of the last iteration, while k_pcg_check / k_pcg_residual also read that iteration's
+    max|alpha p| block (the velocity criterion) -- rank-local until merged, so ranks could disagree on `converged`, one of them repeat the solve with the
+    multigrid (AUTO) and the collectives stop pairing up.  Both blocks are reduced now.  64^3 bunny at nu = 0.3 (nu dt/dx^2 = 12... below AUTO's gate of 8 only
+    at nu <= 0.19, so the diagonal is pinned) with the cap forced to 6 and to 25: every rank reports the same iterations / status / residual bits, and they are the
+    single domain's status."""
+    from flipviscosity3d_amd import capi
+    N = 64
+    dx, solid, P = build_host_scene(N, ("sphere_large.ply", True), ["stanford_bunny.ply"])
+    for cap in (6, 25):
+        prm = dict(viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_max_iterations=cap)
+        ref = capi.Context(N, N, N, dx)
+        ref.set_solid_sdf(solid); ref.set_viscosity(0.3); ref.set_params(**prm); ref.particles = P
+        ctxs = make_blocks(N, dx, solid, P, 0.3, dims, prm)
+        for t in range(2):
+            sr = ref.substep(0.01)
+            sts = run_ranks(ctxs, lambda r, c: c.substep(0.01))
+            assert_same_solve_on_every_rank(sts)
+            v, vr = sts[0]["viscosity"], sr["viscosity"]
+            print("cap %d, %s blocks, substep %d: %d iterations status %d velocity step %.2e | single domain %d / %d / %.2e" % (
+                cap, dims, t, v["iterations"], v["status"], v["velocity_step"], vr["iterations"], vr["status"], vr["velocity_step"]))
+            assert all(s["viscosity"]["velocity_step"] == v["velocity_step"] for s in sts), [s["viscosity"]["velocity_step"] for s in sts]
+            assert v["status"] == vr["status"] and v["preconditioner"] == vr["preconditioner"] == 0
+        for c in ctxs:
+            c.close()
+        ref.close()
 
 
 @pytest.mark.parametrize("precision", [0, 1])

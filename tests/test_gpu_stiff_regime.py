@@ -290,7 +290,9 @@ def test_the_references_operator_is_reproduced_not_approximated(oracle, nu):
         print("nu %g against the oracle at 1e-10 (%d iterations), %s: %d iterations, velocity error %.2e" % (nu, vi["iterations"], name, st["viscosity"]["iterations"], errs[name]))
         c.close()
     o.close()
-    assert errs["default"] <= 3e-5 and errs["two correction stages"] <= 5e-6, errs
+    # (a second stage that ends short of its target and RAISES the fp64 residual is taken back -- the solve then delivers the first stage's result, status 1: at nu = 3 000
+    # that is what happens on some boxes, with round 5's library as well (profiles/r6/ab_two_stages_nu3000.log); where the stage goes through it lands at 2e-6)
+    assert errs["default"] <= 3e-5 and (errs["two correction stages"] <= 5e-6 or errs["two correction stages"] <= 1.001 * errs["default"]), errs
     assert errs["exact operator to 1e-9"] >= 5.0 * errs["default"], errs       # a different linear system
 
 
