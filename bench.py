@@ -295,6 +295,9 @@ def main():
                     help="N > 1: strong = ONE scene of --size split over the ranks (slabs along k for 2 and 4 ranks, 2x2x2 blocks for 8; "
                          "slabs along i for the sheet); weak = N copies of the scene stacked along k, one slab per rank")
     ap.add_argument("--dims", type=str, default="", help="process grid 'px,py,pz' of the strong-scaling decomposition (default: see --scaling)")
+    ap.add_argument("--comm", choices=["rccl", "host"], default="rccl",
+                    help="transport of a multi-rank run.  rccl (default): one rank per GPU over RCCL / xGMI.  host: the host-staged communicator over torch.distributed gloo -- "
+                         "the ranks share the visible devices round-robin (on a one-GPU box: all on device 0): a REHEARSAL of the multi-process path, its throughput means nothing")
     ap.add_argument("--spawn-selftest", action="store_true",
                     help="plumbing check that needs no GPU (tests/test_dist_gloo.py): the ranks only rendezvous over gloo and rank 0 prints a result line")
     args = ap.parse_args()
@@ -325,8 +328,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if args.comm == "host":
+            local_rank = local_rank % max(1, torch.cuda.device_count())      # several ranks per device
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -354,9 +362,12 @@ def main():
         assert dims[0] * dims[1] * dims[2] == world, "process grid does not match the number of ranks"
         boxes = partition.block_boxes(GI, GJ, GK, dims)
         c = Context(GI, GJ, GK, dx, device=local_rank, block=boxes[rank])
-        uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        c.comm_init_rccl(uid[0], rank, world, dims)
+        if args.comm == "host":
+            c.comm_init_host(capi.torch_distributed_callbacks(dist), rank, dims)
+        else:
+            uid = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            c.comm_init_rccl(uid[0], rank, world, dims)
         if box_handover:                                           # `solid` is the setup context: the rank's allocated box of its solid SDF, box-shaped
             lo, hi = c.grid_box("SOLID_PHI", 1)
             c.write_box("SOLID_PHI", solid.read_region("SOLID_PHI", lo, hi))
@@ -364,8 +375,9 @@ def main():
         else:
             c.set_solid_sdf(solid)                                 # the library takes the entries of its box (owned + halo)
         particles = partition.split_particles_boxes(particles, dx, boxes, dims)[rank]
-        decomposition = "%dx%dx%d blocks of one %dx%dx%d scene (rank-local allocation), RCCL 6-face halo exchange + PCG scalar all-reduce + " \
-                        "particle migration" % (dims[0], dims[1], dims[2], GI, GJ, GK)
+        transport = "HOST-STAGED (torch.distributed gloo; a rehearsal of the multi-process path, the ranks share devices)" if args.comm == "host" else "RCCL"
+        decomposition = "%dx%dx%d blocks of one %dx%dx%d scene (rank-local allocation), %s halo exchange with the <= 26 neighbours + PCG scalar all-reduce + particle migration" % (
+            dims[0], dims[1], dims[2], GI, GJ, GK, transport)
     else:
         # weak scaling: `world` copies of the closed 256^3 scene stacked along k form ONE domain of N x N x (N*world)
         # cells, decomposed into one slab per rank.  The copies do not interact physically, but they are solved as one
@@ -378,9 +390,12 @@ def main():
         c = Context(N, N, N * world, dx, device=local_rank, slab=ranges[rank])
         decomposition = "%d slabs along k of a %dx%dx%d domain (%d stacked copies of the scene), RCCL halo exchange + PCG scalar " \
                         "all-reduce + particle migration" % (world, N, N, N * world, world)
-        uid = [capi.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        c.comm_init_rccl(uid[0], rank, world)
+        if args.comm == "host":
+            c.comm_init_host(capi.torch_distributed_callbacks(dist), rank, (1, 1, world))
+        else:
+            uid = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            c.comm_init_rccl(uid[0], rank, world)
         c.set_solid_sdf(solid_g)
         particles = parts[rank]
         del solid_g, parts
@@ -412,7 +427,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.comm == "host" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # ---- second pass, NOT timed: a few more substeps with HIP events around every 8th launch of the PCG's own SpMV (kernel_timing

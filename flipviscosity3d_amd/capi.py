@@ -35,7 +35,7 @@ SYMBOLS = [
     "flipv_bench_copy", "flipv_bench_stream",
     "flipv_mesh_level_set", "flipv_add_boundary_mesh", "flipv_reset_boundary", "flipv_add_liquid_mesh",
     "flipv_comm_unique_id_bytes", "flipv_comm_get_unique_id", "flipv_comm_init_rccl", "flipv_comm_init_local",
-    "flipv_comm_init_rccl_grid", "flipv_comm_init_local_grid", "flipv_comm_finalize",
+    "flipv_comm_init_rccl_grid", "flipv_comm_init_local_grid", "flipv_comm_init_host_grid", "flipv_comm_finalize",
 ]
 
 
@@ -66,7 +66,7 @@ class DebugParams(C.Structure):
                 ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
                 ("no_liquid_box", C.c_int), ("no_comm_overlap", C.c_int), ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
                 ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int), ("viscosity_update_grid_cap", C.c_int),
-                ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int), ("viscosity_mg_packed_rows", C.c_int), ("stall_guard_ratio", C.c_float)]
+                ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int), ("viscosity_mg_packed_rows", C.c_int), ("stall_guard_ratio", C.c_float), ("viscosity_pair_lambda_floor", C.c_float)]
 
 
 _PRODUCT_FIELDS = {f for f, _ in Params._fields_}
@@ -110,6 +110,70 @@ class Stats(C.Structure):
                     substeps=self.substeps, viscosity=self.viscosity.as_dict(), pressure=self.pressure.as_dict())
 
 
+_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+_REDUCE64_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_size_t)
+_REDUCE32_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_size_t)
+_BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class HostComm(C.Structure):
+    """flipv_host_comm: the callbacks of the host-staged communicator"""
+    _fields_ = [("user", C.c_void_p), ("exchange", _EXCHANGE_FN), ("allreduce_sum_f64", _REDUCE64_FN), ("allreduce_sum_f32", _REDUCE32_FN), ("barrier", _BARRIER_FN)]
+
+
+def torch_distributed_callbacks(dist):
+    """flipv_host_comm over an initialised torch.distributed process group of CPU tensors (gloo): plumbing for the multi-process rehearsal on one GPU
+    (bench.py --comm host, tests/test_gpu_multiprocess.py).  Returns the struct; the caller keeps it alive as long as the communicator."""
+    import sys
+    import traceback
+    import torch
+
+    def view(ptr, nbytes):
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)))
+
+    def exchange(user, n, peer, sendbuf, sbytes, recvbuf, rbytes):
+        try:
+            seen, reqs = {}, []
+            for m in range(n):   # my m-th operation towards a peer pairs with its m-th towards me: the tag is that count
+                tag = seen.get(peer[m], 0)
+                seen[peer[m]] = tag + 1
+                if rbytes[m]:
+                    reqs.append(dist.irecv(view(recvbuf[m], rbytes[m]), src=peer[m], tag=tag))
+                if sbytes[m]:
+                    reqs.append(dist.isend(view(sendbuf[m], sbytes[m]), dst=peer[m], tag=tag))
+            for r in reqs:
+                r.wait()
+            return 0
+        except Exception:   # noqa: BLE001  (an exception must not unwind through the C frames)
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    def reduce64(user, values, n):
+        try:
+            dist.all_reduce(torch.from_numpy(np.ctypeslib.as_array(values, shape=(n,))))
+            return 0
+        except Exception:   # noqa: BLE001
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    def reduce32(user, values, n):
+        try:
+            dist.all_reduce(torch.from_numpy(np.ctypeslib.as_array(values, shape=(n,))))
+            return 0
+        except Exception:   # noqa: BLE001
+            traceback.print_exc(file=sys.stderr)
+            return 1
+
+    def barrier(user):
+        try:
+            dist.barrier()
+            return 0
+        except Exception:   # noqa: BLE001
+            traceback.print_exc(file=sys.stderr)
+            return 1
+    return HostComm(None, _EXCHANGE_FN(exchange), _REDUCE64_FN(reduce64), _REDUCE32_FN(reduce32), _BARRIER_FN(barrier))
+
+
 class KernelStats(C.Structure):
     _fields_ = [("pressure_spmv_ms", C.c_double), ("pressure_spmv_launches", C.c_long),
                 ("pressure_spmv_cells", C.c_double), ("viscosity_spmv_ms", C.c_double),
@@ -150,6 +214,7 @@ def load():
     L.flipv_comm_get_unique_id.argtypes = [C.c_void_p]
     L.flipv_comm_init_rccl.argtypes = [ctx, C.c_void_p, C.c_int, C.c_int]
     L.flipv_comm_init_local.argtypes = [C.POINTER(ctx), C.c_int]
+    L.flipv_comm_init_host_grid.argtypes = [ctx, C.POINTER(HostComm), C.c_int, i3]
     L.flipv_comm_finalize.argtypes = [ctx]
     L.flipv_destroy.argtypes = [ctx]
     L.flipv_last_error.restype = C.c_char_p
@@ -311,6 +376,11 @@ class Context:
         lo, hi = (C.c_int * 3)(), (C.c_int * 3)()
         self._chk(self.L.flipv_block_range(self.h, lo, hi), "flipv_block_range")
         return tuple(lo), tuple(hi)
+
+    def comm_init_host(self, callbacks, rank, dims):
+        """the host-staged communicator (one process per rank, any number of ranks per device): callbacks = HostComm, e.g. torch_distributed_callbacks(dist)"""
+        self._host_comm = callbacks     # the C side keeps the function pointers: keep the Python objects alive
+        self._chk(self.L.flipv_comm_init_host_grid(self.h, C.byref(callbacks), int(rank), (C.c_int * 3)(*[int(d) for d in dims])), "flipv_comm_init_host_grid")
 
     def comm_finalize(self):
         self._chk(self.L.flipv_comm_finalize(self.h), "flipv_comm_finalize")

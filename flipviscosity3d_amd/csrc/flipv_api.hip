@@ -408,7 +408,7 @@ extern "C" int flipv_set_params(flipv_context *c, const flipv_params *p) {
         else if (!fin(p->viscosity_velocity_stall_ratio, 0.0f, 1.0f)) bad = "viscosity_velocity_stall_ratio (0 .. 1)";
         else if (!fin(p->viscosity_mass_floor, 0.0f, 1.0f)) bad = "viscosity_mass_floor (0 .. 1)";
         else if (!in(p->viscosity_massless_polish, -1, 0)) bad = "viscosity_massless_polish (0 on, -1 off)";
-        else if (!in(p->viscosity_pair_correction, -1, 0)) bad = "viscosity_pair_correction (0 on, -1 off)";
+        else if (!in(p->viscosity_pair_correction, -1, 1)) bad = "viscosity_pair_correction (0 on for a viscosity field, 1 on, -1 off)";
         if (bad) { c->err = std::string("flipv_set_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     }
     static_cast<flipv_params &>(c->prm) = *p;
@@ -432,6 +432,7 @@ extern "C" int flipv_set_debug_params(flipv_context *c, const flipv_debug_params
     else if (!in(p->spmv_run_length, -2, 64) || p->spmv_run_length == 1) bad = "spmv_run_length";
     else if (!in(p->viscosity_mg_packed_rows, -1, 1)) bad = "viscosity_mg_packed_rows";
     else if (!(p->stall_guard_ratio == 0.0f || fin(p->stall_guard_ratio, 1.0f, 1e30f))) bad = "stall_guard_ratio (0 or >= 1)";
+    else if (!fin(p->viscosity_pair_lambda_floor, 0.0f, 1.0f)) bad = "viscosity_pair_lambda_floor (0 ... 1)";
     if (bad) { c->err = std::string("flipv_set_debug_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     static_cast<flipv_debug_params &>(c->prm) = *p;
     return FLIPV_OK;

@@ -1,24 +1,22 @@
-// flipv_comm.h -- communication layer of the slab decomposition (the reference is single-process,
-// there is nothing to translate).
+// flipv_comm.h -- communication layer of the block decomposition (the reference is single-process, there is nothing to translate).
 //
-// Decomposition: slabs along k, the slowest axis of the Array3d layout, so a halo is a whole number of
-// contiguous PX*PY planes.  Every rank indexes the GLOBAL grid (its arrays span the whole index space, only its
-// own planes [k0,k1) plus a few halo planes ever hold data), which keeps every kernel identical to the single-GPU
-// one; 288 GB per GPU makes the replicated allocation affordable (8 x 256^3 stacked: ~50 GB per rank).
+// Decomposition: a tensor product of axis cuts, px x py x pz blocks, one context per rank (flipv_create_block).  A rank ALLOCATES its owned box plus 8 halo entries per side
+// and indexes it with GLOBAL (i, j, k) (flipv_internal.h: Lay, gidx / bidx), so every kernel states the domain's boundary conditions the same way on every rank and is the
+// single-GPU kernel; nothing of the global grid is replicated (256^3 on 2 x 2 x 2: ~1 GiB per rank instead of ~6).  Slabs (flipv_create_slab) are the special case 1 x 1 x n.
 //
-// Three exchange patterns, all enqueued on the context's stream:
-//   halo copy    owner -> neighbour copies of the H boundary planes of a set of arrays      (s before every SpMV,
-//                velocities/valid masks per extrapolation layer, phi, pressure, ...)
-//   halo reduce  neighbour -> owner contributions on planes a rank scattered into but does not own, combined
-//                with min (particle SDF) or + (P2G accumulators)
-//   all-reduce   the PCG scalars.  Ranks accumulate into DISJOINT slots of the per-iteration slot block, so one
-//                sum all-reduce merges sums and maxima alike: ONE small all-reduce per PCG iteration (pcg_common.h)
-//   migration    particles that left the slab go to the neighbour owning their cell (counts first, then records)
+// Exchange patterns (all box-shaped staging, so the two ends may hold their arrays in different layouts -- plain, bricks, a coarse multigrid level):
+//   halo copy    owner -> the <= 26 neighbouring blocks, H entries deep: ONE pack kernel, ONE group of sends / receives, ONE unpack kernel per exchange (the PCG search direction and
+//                the multigrid's fine sweeps: on the communication stream beside the interior work, fv_halo_copy_begin / fv_halo_wait; velocities and masks per extrapolation layer;
+//                phi; pressure; a distributed coarse level: fv_halo_level)
+//   halo reduce  neighbours -> owner: what a rank scattered into entries it does not own, combined with min (particle SDF) or + (P2G accumulators, Galerkin sums of a distributed level)
+//   all-reduce   the PCG scalars.  Ranks accumulate into DISJOINT slots of the per-iteration slot block, so one sum all-reduce merges sums and maxima alike (pcg_common.h);
+//                the global coarse levels' right-hand side (fp32); per-solve decisions from ONE small all-gather (fv_allgather_f64)
+//   migration    particles that left the rank's cells go to the adjacent rank axis by axis (x, y, z: three hops reach all 26 neighbours), counts first, then records
 //
-// Backends: RCCL (one process per GPU, ncclSend/ncclRecv grouped per exchange, ncclAllReduce; librccl is
-// dlopen'ed on first use so single-GPU runs never load it) and an in-process backend (N contexts in one process on
-// one device, one host thread per rank, rendezvous through host memory) that exists so the decomposition can be
-// verified against the single-domain result on a one-GPU box.
+// Backends (struct Comm): RCCL -- one process per GPU, ncclSend / ncclRecv grouped per exchange, ncclAllReduce; librccl is dlopen'ed on first use, single-GPU runs never load it --;
+// an in-process backend -- N contexts of one process on one device, one host thread per rank, rendezvous through host memory: the decomposition verified against the single
+// domain on a one-GPU box --; and a host-callback backend -- one process per rank, staging through pinned host memory, the transport supplied by the embedding program
+// (flipv_host_comm): the multi-PROCESS path rehearsed with several ranks on one device.
 #pragma once
 #include "flipv_internal.h"
 

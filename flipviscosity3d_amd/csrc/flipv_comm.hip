@@ -607,6 +607,77 @@ struct LocalComm : Comm {
     }
 };
 
+// ================================================================================================ host-callback backend
+// Every exchange is staged through pinned host memory and handed to callbacks of the embedding program (flipv_host_comm, include/flipv.h): one process per rank like the
+// RCCL backend -- the same launcher, rendezvous, per-process block contexts, migration and timing reduction -- but the transport is the caller's (bench.py / the tests:
+// torch.distributed over gloo), so SEVERAL ranks can share ONE device.  It exists to rehearse the multi-process path on a one-GPU box; it is not a fast path.
+struct HostComm : Comm {
+    flipv_host_comm cb;
+    struct Op { int peer; const void *sb; size_t sbytes; void *rb; size_t rbytes; size_t soff, roff; };
+    std::vector<Op> ops;
+    char *stage = nullptr;      // pinned: [send payloads | receive payloads] of one group, or an all-reduce's values
+    size_t cap = 0;
+    ~HostComm() override { if (stage) (void)hipHostFree(stage); }
+    int reserve(flipv_context *c, size_t bytes) {
+        if (bytes <= cap) return FLIPV_OK;
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIPCHK(c, hipHostMalloc((void **)&stage, want));
+        cap = want;
+        return FLIPV_OK;
+    }
+    int fail(flipv_context *c, const char *what) { c->err = std::string("host communicator: the ") + what + " callback reported an error"; return FLIPV_ERR_COMM; }
+    int begin(flipv_context *) override { ops.clear(); return FLIPV_OK; }
+    int sendrecv(flipv_context *, int peer, const void *sb, size_t sbytes, void *rb, size_t rbytes) override {
+        ops.push_back({peer, sb, sbytes, rb, rbytes, 0, 0});
+        return FLIPV_OK;
+    }
+    int end(flipv_context *c) override {
+        size_t total = 0;
+        for (auto &o : ops) { o.soff = total; total += (o.sbytes + 15) & ~(size_t)15; }
+        for (auto &o : ops) { o.roff = total; total += (o.rbytes + 15) & ~(size_t)15; }
+        int rc = reserve(c, total);
+        if (rc) return rc;
+        for (auto &o : ops) if (o.sbytes) HIPCHK(c, hipMemcpyAsync(stage + o.soff, o.sb, o.sbytes, hipMemcpyDeviceToHost, c->xs));
+        HIPCHK(c, hipStreamSynchronize(c->xs));
+        const int n = (int)ops.size();
+        std::vector<int> peer((size_t)n);
+        std::vector<const void *> sp((size_t)n);
+        std::vector<void *> rp((size_t)n);
+        std::vector<size_t> sb((size_t)n), rb((size_t)n);
+        for (int m = 0; m < n; m++) { peer[m] = ops[m].peer; sp[m] = stage + ops[m].soff; rp[m] = stage + ops[m].roff; sb[m] = ops[m].sbytes; rb[m] = ops[m].rbytes; }
+        if (n && cb.exchange(cb.user, n, peer.data(), sp.data(), sb.data(), rp.data(), rb.data()) != 0) return fail(c, "exchange");
+        for (auto &o : ops) if (o.rbytes) HIPCHK(c, hipMemcpyAsync(o.rb, stage + o.roff, o.rbytes, hipMemcpyHostToDevice, c->xs));
+        HIPCHK(c, hipStreamSynchronize(c->xs));   // (the staging area is reused by the next group)
+        return FLIPV_OK;
+    }
+    int allreduce_sum(flipv_context *c, double *dev, size_t n) override {
+        int rc = reserve(c, n * sizeof(double));
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(stage, dev, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        FV_SYNC(c);
+        if (cb.allreduce_sum_f64(cb.user, (double *)stage, n) != 0) return fail(c, "allreduce_sum_f64");
+        HIPCHK(c, hipMemcpyAsync(dev, stage, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        FV_SYNC(c);
+        return FLIPV_OK;
+    }
+    int allreduce_sum_f32(flipv_context *c, float *dev, size_t n) override {
+        int rc = reserve(c, n * sizeof(float));
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(stage, dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        FV_SYNC(c);
+        if (cb.allreduce_sum_f32(cb.user, (float *)stage, n) != 0) return fail(c, "allreduce_sum_f32");
+        HIPCHK(c, hipMemcpyAsync(dev, stage, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        FV_SYNC(c);
+        return FLIPV_OK;
+    }
+    int barrier(flipv_context *c) override {
+        FV_SYNC(c);
+        return cb.barrier(cb.user) == 0 ? FLIPV_OK : fail(c, "barrier");
+    }
+};
+
 }  // namespace
 
 // ================================================================================================ C-ABI
@@ -699,6 +770,18 @@ extern "C" int flipv_comm_init_local_grid(flipv_context **ctxs, const int *dims)
         cm->rank = r; cm->nranks = n; cm->g = g;
         ctxs[r]->comm = cm;
     }
+    return FLIPV_OK;
+}
+
+
+extern "C" int flipv_comm_init_host_grid(flipv_context *c, const flipv_host_comm *cb, int rank, const int *dims) {
+    if (!c || !cb || !dims || !cb->exchange || !cb->allreduce_sum_f64 || !cb->allreduce_sum_f32 || !cb->barrier) return FLIPV_ERR_INVALID;
+    if (c->comm) { c->err = "flipv_comm_init: communicator already set"; return FLIPV_ERR_INVALID; }
+    { const int rc = comm_place(c, rank, dims); if (rc) return rc; }
+    HostComm *cm = new HostComm();
+    cm->rank = rank; cm->nranks = dims[0] * dims[1] * dims[2];
+    cm->cb = *cb;
+    c->comm = cm;
     return FLIPV_OK;
 }
 

@@ -11,6 +11,8 @@
 // Unknown faces are exactly the faces with a non-zero diagonal; x is kept 0 everywhere else, which reproduces
 // the reference's silent drop of couplings to faces without a matrix row (sparsematrix.h:86-88).
 #include "flipv_internal.h"
+#include <algorithm>
+#include <vector>
 #include "pcg_common.h"
 #include "flipv_comm.h"
 #include "visc_rows.h"
@@ -969,13 +971,26 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
 // Here: BEFORE the set-up kernel, every later row of such a cluster is listed and its face state set to ST_ELIM for the duration of k_visc_setup -- no row, no
 // right-hand-side term, velocity 0, exactly what the reference's iterate holds there.
 constexpr int FV_ELIM_CAP = 4096;
-// is face (comp, p) a row without own volume whose only non-zero factor sits in slot `slot_out`?
+// is face (comp, p) a row without own volume whose only non-zero factor sits in slot `slot_out`?  A factor is a viscosity x one of six control volumes (order: right, left,
+// top, bottom, front, back): the volumes are counted first -- with ONE viscosity that decides --, the factors are only formed for a viscosity field (which may vanish on an edge).
 __device__ __forceinline__ bool d_single_factor_row(int comp, size_t p, int i, int j, int k, const Lay &L, const uint8_t *const st[3], const float *const vol[3], const float *__restrict__ nu,
-                                                    const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int &slot_out) {
+                                                    const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field,
+                                                    int &slot_out) {
     if (!d_row_range(comp, i, j, k, L) || st[comp][p] != ST_FLUID || vol[comp][p] != 0.0f) return false;
-    const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, p, L.sy, L.sz, factor);
-    const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
+    const long sy = L.sy, sz = L.sz;
+    float v6[6];
+    if (comp == 0) { v6[0] = vC[p]; v6[1] = vC[p - 1]; v6[2] = vEW[p + sy]; v6[3] = vEW[p]; v6[4] = vEV[p + sz]; v6[5] = vEV[p]; }
+    else if (comp == 1) { v6[0] = vEW[p + 1]; v6[1] = vEW[p]; v6[2] = vC[p]; v6[3] = vC[p - sy]; v6[4] = vEU[p + sz]; v6[5] = vEU[p]; }
+    else { v6[0] = vEV[p + 1]; v6[1] = vEV[p]; v6[2] = vEU[p + sy]; v6[3] = vEU[p]; v6[4] = vC[p]; v6[5] = vC[p - sz]; }
     int nz = 0, at = -1;
+#pragma unroll
+    for (int t = 0; t < 6; t++) if (v6[t] > 0.0f) { nz++; at = t; }
+    slot_out = at;
+    if (nz == 0) return false;
+    if (!field) return nz == 1;
+    const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, p, sy, sz, factor);
+    const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
+    nz = 0; at = -1;
 #pragma unroll
     for (int t = 0; t < 6; t++) if (f[t] != 0.0f) { nz++; at = t; }
     slot_out = at;
@@ -983,7 +998,7 @@ __device__ __forceinline__ bool d_single_factor_row(int comp, size_t p, int i, i
 }
 __global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV, const uint8_t *__restrict__ stW, const float *__restrict__ volU,
                                      const float *__restrict__ volV, const float *__restrict__ volW, const float *__restrict__ nu, const float *__restrict__ vC,
-                                     const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, const uint8_t *__restrict__ band, float factor,
+                                     const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, const uint8_t *__restrict__ band, float factor, int field,
                                      unsigned long long *__restrict__ list) {
     IJK_OR_RETURN(L);
     const long sy = L.sy, sz = L.sz;
@@ -1010,14 +1025,14 @@ __global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, con
          {{2, 0, 0, 1, 5}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{2, 0, 0, -1, 4}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}}};
     for (int comp = 0; comp < 3; comp++) {
         int slot;
-        if (!d_single_factor_row(comp, c, i, j, k, L, st, vol, nu, vC, vEU, vEV, vEW, factor, slot)) continue;
+        if (!d_single_factor_row(comp, c, i, j, k, L, st, vol, nu, vC, vEU, vEV, vEW, factor, field, slot)) continue;
         bool later = false;   // is there such a row of the same cluster BEFORE this one in the reference's row order?
         for (int m = 0; m < 3 && !later; m++) {
             const Mem e = M[comp][slot][m];
             if (e.comp < 0) continue;
             const size_t p = c + e.di + e.dj * sy + e.dk * sz;
             int s2;
-            if (!d_single_factor_row(e.comp, p, i + e.di, j + e.dj, k + e.dk, L, st, vol, nu, vC, vEU, vEV, vEW, factor, s2) || s2 != e.slot) continue;
+            if (!d_single_factor_row(e.comp, p, i + e.di, j + e.dj, k + e.dk, L, st, vol, nu, vC, vEU, vEV, vEW, factor, field, s2) || s2 != e.slot) continue;
             later = e.comp < comp || (e.comp == comp && p < c);
         }
         if (!later) continue;
@@ -1050,7 +1065,7 @@ __global__ void k_visc_singular_apply(const unsigned long long *__restrict__ lis
 constexpr float FV_PAIR_THETA = 0.7f;
 __global__ void k_visc_pairs_find(Lay L, const float *__restrict__ nu, const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV,
                                   const float *__restrict__ vEW, const float *__restrict__ volU, const float *__restrict__ volV, const float *__restrict__ volW,
-                                  const uint8_t *__restrict__ rowmask, float factor, int brick, int swz, Lay LB, unsigned *__restrict__ count, VPair *__restrict__ list, float w0, float w1) {
+                                  const uint8_t *__restrict__ rowmask, float factor, int brick, int swz, Lay LB, unsigned *__restrict__ count, VPair *__restrict__ list, float w0, float w1, float lam_floor) {
     IJK_OR_RETURN(L);
     const unsigned mk = rowmask[c];
     if (!(mk & 7u)) return;
@@ -1084,7 +1099,7 @@ __global__ void k_visc_pairs_find(Lay L, const float *__restrict__ nu, const flo
             // preconditioned spectrum then reaches 2 on every such pair and every solve takes 25-40 % more iterations -- measured, profiles/r6/pairs_diag.log.)
             const double gm = sqrt(dp * dq);
             double lam = (gm - fabs(coef)) / gm;
-            if (!(lam >= 1.0e-5)) lam = 1.0e-5;                            // (an almost singular block: the correction along its near-null vector is capped at 1e5 / diagonal)
+            if (!(lam >= (double)lam_floor)) lam = (double)lam_floor;       // (an almost singular block: the correction along its near-null vector is capped at 1 / (floor x diagonal))
             const double sg = coef > 0.0 ? -1.0 : 1.0;
             // ... and only what the cycle's own sweeps leave of it: the V(2,2) smoother alone contracts a mode of eigenvalue lambda by p = ((1 - w0 lambda)(1 - w1 lambda))^2
             // (the coarse levels do nothing for a mode that lives on two faces), so the cycle already applies (1 - p) / lambda; the pair adds p / lambda.  With the plain
@@ -1187,6 +1202,14 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     if ((rc = fv_pcg_reset(c, cap, false, &sc, &bmax, c->d_flags + 2))) return rc;   // (scalars, conv = -1, the row counter, the guard, the counters: one launch)
     sc.tol_inclusive = 1;
     sc.tol = 0.0;
+    // A viscosity FIELD (flipv_set_viscosity with values that differ; decided alike on every rank: visc_gather_field_facts) is where a few isolated small eigenvalues sit under
+    // the multigrid-preconditioned spectrum -- pairs of faces hanging on one stress term across a jump of the viscosity -- and where CG's max|r| rebounds by 20-50 x while it resolves
+    // them one plateau at a time (holdout draws 9, 11 of round 5).  Two things follow the field: the stall guard's factor (16 x reads those rebounds as a blow-up and
+    // ended every correction stage of draw 9 after 10-40 iterations) and the pairs' weak modes in the preconditioner (k_visc_pairs_find).  With ONE viscosity both stay as they were:
+    // the same pairs exist there (51 at 256^3 during the bunny's fall), resolving them costs 7 + 3 iterations per solve (58 against 48 in bench.py's window) and buys nothing the
+    // velocity criterion and the cluster solve after the loop do not already deliver (profiles/r6/bench_ab.log).
+    const bool fieldSolve = c->vPerRowFactors != 0;
+    sc.stall_ratio = c->prm.stall_guard_ratio > 0.0f ? (double)c->prm.stall_guard_ratio : (fieldSolve ? FV_STALL_RATIO_FIELD : FV_STALL_RATIO);
 
     // Everything up to the factors is evaluated redundantly on the halo planes a neighbour-owned row would need
     // (inputs: phi with a 4-plane halo, the replicated solid SDF), so the setup needs no exchange of its own.
@@ -1280,7 +1303,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             const Lay RE = R0;   // (rows only exist in the liquid's range)
             hipLaunchKernelGGL(k_visc_singular_find, GRID3(RE), 0, c->stream, RE, (const uint8_t *)c->stU, (const uint8_t *)c->stV, (const uint8_t *)c->stW, (const float *)c->volU,
                                (const float *)c->volV, (const float *)c->volW, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
-                               (const float *)c->volEW, (const uint8_t *)c->validCells, factor, c->elimList);
+                               (const float *)c->volEW, (const uint8_t *)c->validCells, factor, fieldSolve ? 1 : 0, c->elimList);
             hipLaunchKernelGGL(k_visc_singular_apply<true>, dim3(1), dim3(256), 0, c->stream, (const unsigned long long *)c->elimList, c->stU, c->stV, c->stW, c->U, c->V, c->W);
         }
         { const FillJob z[2] = {{bmax, 2 * sizeof(double), 0}, {c->d_flags + 2, sizeof(int), 0}}; const int rcz = fv_fill_list(c, z, 2); if (rcz) return rcz; }
@@ -1301,7 +1324,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
                                (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
                                factor, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, (int *)nullptr, brick ? c->vMaskB : (uint8_t *)nullptr, c->LB);
         }
-        const bool pairs = mgPlanned && c->prm.viscosity_pair_correction >= 0;   // strongly coupled pairs of rows: listed for the multigrid loops' additive correction (k_visc_pairs_find)
+        const bool pairs = mgPlanned && (c->prm.viscosity_pair_correction > 0 || (c->prm.viscosity_pair_correction == 0 && fieldSolve));   // strongly coupled pairs of rows: listed for the multigrid loops' additive correction (k_visc_pairs_find)
         c->h_flags[10] = 0;
         if (pairs) {
             if (!c->pairList) HIPCHK(c, hipMalloc((void **)&c->pairList, 16 + (size_t)FV_PAIR_CAP * sizeof(VPair)));
@@ -1309,7 +1332,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             hipLaunchKernelGGL(k_visc_pairs_find, GRID3(R0), 0, c->stream, R0, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV, (const float *)c->volEW,
                                (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, factor, brick ? 1 : 0, c->vSwz ? 1 : 0, c->LB,
                                (unsigned *)c->pairList, (VPair *)((char *)c->pairList + 16), c->prm.viscosity_mg_omega_first > 0.0f ? c->prm.viscosity_mg_omega_first : 1.317f,
-                               c->prm.viscosity_mg_omega_second > 0.0f ? c->prm.viscosity_mg_omega_second : 0.382f);   // (the cycle's Chebyshev pair: k_viscosity_mg.hip)
+                               c->prm.viscosity_mg_omega_second > 0.0f ? c->prm.viscosity_mg_omega_second : 0.382f,   // (the cycle's Chebyshev pair: k_viscosity_mg.hip)
+                               c->prm.viscosity_pair_lambda_floor > 0.0f ? c->prm.viscosity_pair_lambda_floor : 1.0e-5f);
         }
         {
             ReadJob jobs[4] = {FV_JOB(c->h_scal, bmax, 2 * sizeof(double)), FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int))};   // max|rhs|, max|u| over the rows; the row count
@@ -1323,8 +1347,24 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         FV_SYNC(c);  // h_flags[2] = row count
         c->nPairs = pairs ? (c->h_flags[10] < FV_PAIR_CAP ? c->h_flags[10] : FV_PAIR_CAP) : 0;
         c->nElim = elim ? (c->h_flags[11] < FV_ELIM_CAP ? c->h_flags[11] : FV_ELIM_CAP) : 0;
-        if (c->prm.verbose && pairs) fprintf(stderr, "viscosity solve %ld: %d strongly coupled pairs of rows in the multigrid's additive correction%s\n", c->viscSolves, c->h_flags[10],
-                                             c->h_flags[10] > FV_PAIR_CAP ? " -- MORE THAN THE LIST HOLDS" : "");
+        if (c->prm.verbose && pairs) {
+            fprintf(stderr, "viscosity solve %ld: %d strongly coupled pairs of rows in the multigrid's additive correction%s\n", c->viscSolves, c->h_flags[10],
+                    c->h_flags[10] > FV_PAIR_CAP ? " -- MORE THAN THE LIST HOLDS" : "");
+            if (c->prm.verbose > 1 && c->nPairs > 0) {   // how many rows sit in more than one pair, and the weakest / strongest gains
+                std::vector<VPair> hp((size_t)c->nPairs);
+                HIPCHK(c, hipMemcpy(hp.data(), (const char *)c->pairList + 16, hp.size() * sizeof(VPair), hipMemcpyDeviceToHost));
+                std::vector<unsigned long long> keys;
+                float gmin = 1e30f, gmax = 0.0f;
+                for (const VPair &P : hp) {
+                    keys.push_back(((unsigned long long)(P.comps & 3u) << 40) | P.iz0); keys.push_back(((unsigned long long)((P.comps >> 2) & 3u) << 40) | P.iz1);
+                    gmin = fminf(gmin, P.i00); gmax = fmaxf(gmax, P.i00);
+                }
+                std::sort(keys.begin(), keys.end());
+                size_t shared = 0;
+                for (size_t t = 1; t < keys.size(); t++) shared += keys[t] == keys[t - 1];
+                fprintf(stderr, "   %zu rows in pairs, %zu of them in more than one pair; i00 between %.3g and %.3g\n", keys.size() - shared, shared, gmin, gmax);
+            }
+        }
         if (c->prm.verbose && c->h_flags[11] > 0)
             fprintf(stderr, "viscosity solve %ld: %d rows repeat another row's equation (a singular cluster): held at 0 like the reference's iterate%s\n", c->viscSolves, c->h_flags[11],
                     c->h_flags[11] > FV_ELIM_CAP ? " -- MORE THAN THE LIST HOLDS, the rest stay rows" : "");
@@ -1482,6 +1522,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             const int keepIncl = sc.tol_inclusive;
             double *dummy;
             { const int rcc = fv_pcg_reset(c, cap, true, &sc, &dummy, nullptr); if (rcc) return rcc; }
+            sc.stall_ratio = c->prm.stall_guard_ratio > 0.0f ? (double)c->prm.stall_guard_ratio : (fieldSolve ? FV_STALL_RATIO_FIELD : FV_STALL_RATIO);   // (the reset restores the views' defaults)
             sc.tol_inclusive = keepIncl;
             FV_SYNC(c);
             res = resStart = c->h_scal[0];

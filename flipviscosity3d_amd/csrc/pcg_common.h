@@ -112,11 +112,13 @@ template <> __device__ __forceinline__ double d_recip<double>(float d) { return 
 // In a multi-rank run rank r accumulates only into slots [slot0, slot0 + nslot): the slots are disjoint between
 // ranks, so a SUM all-reduce merges sums and maxima alike.
 constexpr int FV_NSC = 6;   // scalars per iteration block
-// The stall guard's factor: a loop stops once max|r| exceeds this x the smallest value it has reached.  16 until round 6 -- but CG's max-norm residual legitimately rebounds
-// by more than that on a system with a few isolated small eigenvalues (a viscosity field with a jump: 14 x in an fp64 Jacobi-PCG model of holdout draw 9, 20-50 x on the
-// device), and the guard then ended every correction stage of such a solve after 10-40 iterations (the draw's 0.2 ... 0.9 max|u| of round 5).  What the guard is FOR -- an fp32
-// recurrence that has left the true residual behind and blows up by 1e8 over thousands of iterations -- is caught as well by 1e3; stagnation has its own guard (VMG_NO_PROGRESS).
-constexpr double FV_STALL_RATIO = 1000.0;
+// The stall guard's factor: a loop stops once max|r| exceeds this x the smallest value it has reached.  What the guard is FOR -- an fp32 recurrence that has left the true
+// residual behind and blows up by 1e8 over thousands of iterations (pcg_common.h: PcgScal::best) -- 16 catches early and cheaply.  But CG's max-norm residual legitimately rebounds
+// by more than that on a system with a few isolated small eigenvalues -- a viscosity FIELD with a jump: 14 x in an fp64 Jacobi-PCG model of holdout draw 9, 20-50 x on the device --,
+// and there the guard ended every correction stage after 10-40 iterations (the draw's 0.2 ... 0.9 max|u| of round 5): such solves take 1 000 (a blow-up is still caught; stagnation
+// has its own guard, VMG_NO_PROGRESS).
+constexpr double FV_STALL_RATIO = 16.0;
+constexpr double FV_STALL_RATIO_FIELD = 1000.0;
 struct PcgScal {
     double *base;
     int *conv;      // converged-at iteration, -1 while running (nullptr: benchmark launch, no scalars)

@@ -166,7 +166,7 @@ typedef struct flipv_params {
                                                first 400 substeps of that scene take 14.6 instead of 15.9 ms.  NOT the default: a plateau can also be a light part CG has not resolved YET
                                                (64^3, nu = 0.5, one substep of the impact: 9.5e-4 from the converged reference with the exit, 1e-6 without) and nothing in the
                                                iteration's history tells the two apart */
-    int viscosity_pair_correction;          /* [0 = on] -1: off.  Multigrid loops: pairs of rows whose coupling is >= 0.7 of the geometric mean of their diagonals -- a row (almost) without own
+    int viscosity_pair_correction;          /* [0 = on where the viscosity is a FIELD] 1: on everywhere; -1: off.  Multigrid loops: pairs of rows whose coupling is >= 0.7 of the geometric mean of their diagonals -- a row (almost) without own
                                                volume hanging on one stress term and the row that shares it -- get their 2 x 2 block solved in every preconditioner application, added to the
                                                V-cycle (FLIPV_VERSION 6).  Each such pair carries a mode of Jacobi-scaled eigenvalue 1 - |coupling| (2e-5 ... 1e-3 on a viscosity field with a
                                                jump) that the geometric hierarchy does not see and CG otherwise resolves one plateau at a time */
@@ -198,7 +198,8 @@ typedef struct flipv_debug_params {
     int spmv_run_length;         /* k-marching SpMV kernels walk runs of up to this many tiles along k (2..64); 0 = chosen per solve; -1 = the tile-at-a-time kernels; -2 = the pressure
                                     SpMV's address-order sweep kernel (filled boxes in 64-lane rows) whatever the size */
     int viscosity_mg_packed_rows; /* coarse rows of the viscosity multigrid as the cycle reads them: 0 = chosen per solve (packed fp16 up to nu dt/dx^2 = 2e5), 1 = packed fp16, -1 = the fp32 grids */
-    float stall_guard_ratio;     /* the stall guard of the PCG loops stops a loop whose max|r| exceeds this x the smallest it has reached (once that is within 100 x the tolerance); 0 = 1000 (16 until FLIPV_VERSION 6) */
+    float stall_guard_ratio;     /* the stall guard of the PCG loops stops a loop whose max|r| exceeds this x the smallest it has reached (once that is within 100 x the tolerance); 0 = 16, and 1 000 in the viscosity solve of a viscosity FIELD (FLIPV_VERSION 6) */
+    float viscosity_pair_lambda_floor; /* the pair correction's gain is 1 / max(lambda, this) per unit diagonal; 0 = 1e-5 */
 } flipv_debug_params;
 
 typedef struct flipv_solve_info {
@@ -406,6 +407,20 @@ int flipv_comm_init_local(flipv_context **ctxs, int nranks);
  * kernel, one group of sends / receives, one unpack kernel per exchange); particles migrate axis by axis (x, y, z) to the adjacent ranks. */
 int flipv_comm_init_rccl_grid(flipv_context *ctx, const void *unique_id, int rank, const int *dims);
 int flipv_comm_init_local_grid(flipv_context **ctxs, const int *dims);
+/* Host-callback backend (FLIPV_VERSION 6): one process per rank like the RCCL backend, but every exchange is staged through host memory and carried by callbacks of the embedding
+ * program -- so several ranks may share ONE device.  It rehearses the multi-process path (launcher, rendezvous, per-process block contexts, halos, migration, reductions) on a
+ * one-GPU machine; bench.py --comm host and tests/test_gpu_multiprocess.py drive it with torch.distributed over gloo.  Every callback returns 0 on success.
+ *   exchange: n operations of ONE group; operation m sends sbytes[m] bytes at sendbuf[m] to rank peer[m] and receives rbytes[m] bytes from it into recvbuf[m] (either may be 0); the
+ *             m-th operation of this rank towards a peer pairs with that peer's m-th operation towards this rank (sizes agree); the call returns when every buffer may be reused / read.
+ *   allreduce_sum_f64 / _f32: in-place sum over all ranks, the SAME bits on every rank.   barrier: all ranks. */
+typedef struct flipv_host_comm {
+    void *user;
+    int (*exchange)(void *user, int n, const int *peer, const void *const *sendbuf, const size_t *sbytes, void *const *recvbuf, const size_t *rbytes);
+    int (*allreduce_sum_f64)(void *user, double *values, size_t n);
+    int (*allreduce_sum_f32)(void *user, float *values, size_t n);
+    int (*barrier)(void *user);
+} flipv_host_comm;
+int flipv_comm_init_host_grid(flipv_context *ctx, const flipv_host_comm *callbacks, int rank, const int *dims);
 int flipv_comm_finalize(flipv_context *ctx);
 
 #ifdef __cplusplus
