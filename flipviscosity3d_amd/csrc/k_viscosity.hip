@@ -898,7 +898,10 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
             if (!((rowmask[p] >> comp) & 1) || vol[comp][p] != 0.0f) continue;
             if (inner) {   // (a block context: rows whose stencil stays inside what the rank holds current values of)
                 const int pi = i + (ro[fam][q] == -1 ? -1 : 0), pj = j + (ro[fam][q] == -sy ? -1 : 0), pk = k + (ro[fam][q] == -sz ? -1 : 0);
-                if (pi - 1 < L.olo[0] || pi + 1 >= L.ohi[0] || pj - 1 < L.olo[1] || pj + 1 >= L.ohi[1] || pk - 1 < L.olo[2] || pk + 1 >= L.ohi[2]) continue;
+                // (only towards sides that HAVE a neighbouring rank: at a wall of the domain the owned box ends where the lattice ends -- ADVICE r5: the test used to drop
+                // the rows along physical walls too, so that block runs polished another set of rows than the single domain)
+                if ((pi - 1 < L.olo[0] && L.olo[0] > 0) || (pi + 1 >= L.ohi[0] && L.ohi[0] < L.I) || (pj - 1 < L.olo[1] && L.olo[1] > 0) || (pj + 1 >= L.ohi[1] && L.ohi[1] < L.J) ||
+                    (pk - 1 < L.olo[2] && L.olo[2] > 0) || (pk + 1 >= L.ohi[2] && L.ohi[2] < L.K)) continue;
             }
             const RefRowFactors F = d_ref_row_factors(nu, volC, volEU, volEV, volEW, p, sy, sz, factor);
             const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
