@@ -346,6 +346,8 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->d_pubSeq) (void)hipFree(c->d_pubSeq);
     if (c->polishList) (void)hipFree(c->polishList);
     if (c->elimList) (void)hipFree(c->elimList);
+    if (c->floatList) (void)hipFree(c->floatList);
+    if (c->groundMark) (void)hipFree(c->groundMark - c->L.guard);
     if (c->pairList) (void)hipFree(c->pairList);
     for (hipEvent_t e : c->evPool) (void)hipEventDestroy(e);
     for (int q = 0; q <= FLIPV_PHASE_COUNT; q++) if (c->phaseEv[q]) (void)hipEventDestroy(c->phaseEv[q]);

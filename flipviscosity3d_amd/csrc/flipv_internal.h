@@ -247,6 +247,8 @@ struct flipv_context {
     double vRowsAll = 0.0;      // rows of the current viscosity system over all ranks (viscosity_solve_t's all-gather)
     unsigned long long *polishList = nullptr;   // k_visc_massless_find's list of edges (k_viscosity.hip)
     unsigned long long *elimList = nullptr;     // k_visc_singular_find's list of faces (k_viscosity.hip)
+    unsigned long long *floatList = nullptr;    // ... its list of massless rows not grounded at once, and the marks of k_visc_floating (one byte per index of the allocated box)
+    uint8_t *groundMark = nullptr;
     struct VPair *pairList = nullptr;           // k_visc_pairs_find's list of strongly coupled row pairs; the first 16 bytes of the allocation hold their number (k_viscosity.hip)
     int nElim = 0;                              // rows k_visc_singular_find took out of this solve's system (flipv_solve_info::eliminated_rows)
     int nPairs = 0;                             // ... as the host read it after the set-up (0: the multigrid loop launches no pair kernel)

@@ -974,6 +974,58 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
 // Here: BEFORE the set-up kernel, every later row of such a cluster is listed and its face state set to ST_ELIM for the duration of k_visc_setup -- no row, no
 // right-hand-side term, velocity 0, exactly what the reference's iterate holds there.
 constexpr int FV_ELIM_CAP = 4096;
+constexpr int FV_FLOAT_CAP = 8192;   // candidates of floating sets (massless rows not grounded at once)
+struct FvMem { signed char comp, di, dj, dk, slot; };
+__device__ const FvMem FV_MEM[3][6][3] = {
+    {{{0, 1, 0, 0, 1}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{0, -1, 0, 0, 0}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
+     {{0, 0, 1, 0, 3}, {1, 0, 1, 0, 1}, {1, -1, 1, 0, 0}}, {{0, 0, -1, 0, 2}, {1, 0, 0, 0, 1}, {1, -1, 0, 0, 0}},
+     {{0, 0, 0, 1, 5}, {2, 0, 0, 1, 1}, {2, -1, 0, 1, 0}}, {{0, 0, 0, -1, 4}, {2, 0, 0, 0, 1}, {2, -1, 0, 0, 0}}},
+    {{{1, 1, 0, 0, 1}, {0, 1, 0, 0, 3}, {0, 1, -1, 0, 2}}, {{1, -1, 0, 0, 0}, {0, 0, 0, 0, 3}, {0, 0, -1, 0, 2}},
+     {{1, 0, 1, 0, 3}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{1, 0, -1, 0, 2}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
+     {{1, 0, 0, 1, 5}, {2, 0, 0, 1, 3}, {2, 0, -1, 1, 2}}, {{1, 0, 0, -1, 4}, {2, 0, 0, 0, 3}, {2, 0, -1, 0, 2}}},
+    {{{2, 1, 0, 0, 1}, {0, 1, 0, 0, 5}, {0, 1, 0, -1, 4}}, {{2, -1, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, -1, 4}},
+     {{2, 0, 1, 0, 3}, {1, 0, 1, 0, 5}, {1, 0, 1, -1, 4}}, {{2, 0, -1, 0, 2}, {1, 0, 0, 0, 5}, {1, 0, 0, -1, 4}},
+     {{2, 0, 0, 1, 5}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{2, 0, 0, -1, 4}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}}};
+// which of the six factors of face (comp, p) are non-zero, as a bit mask (order: right, left, top, bottom, front, back)
+__device__ __forceinline__ unsigned d_factor_mask(int comp, size_t p, const Lay &L, const float *__restrict__ nu, const float *__restrict__ vC, const float *__restrict__ vEU,
+                                                  const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field) {
+    const long sy = L.sy, sz = L.sz;
+    unsigned m = 0u;
+    if (!field) {
+        float v6[6];
+        if (comp == 0) { v6[0] = vC[p]; v6[1] = vC[p - 1]; v6[2] = vEW[p + sy]; v6[3] = vEW[p]; v6[4] = vEV[p + sz]; v6[5] = vEV[p]; }
+        else if (comp == 1) { v6[0] = vEW[p + 1]; v6[1] = vEW[p]; v6[2] = vC[p]; v6[3] = vC[p - sy]; v6[4] = vEU[p + sz]; v6[5] = vEU[p]; }
+        else { v6[0] = vEV[p + 1]; v6[1] = vEV[p]; v6[2] = vEU[p + sy]; v6[3] = vEU[p]; v6[4] = vC[p]; v6[5] = vC[p - sz]; }
+#pragma unroll
+        for (int t = 0; t < 6; t++) if (v6[t] > 0.0f) m |= 1u << t;
+        return m;
+    }
+    const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, p, sy, sz, factor);
+    const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
+#pragma unroll
+    for (int t = 0; t < 6; t++) if (f[t] != 0.0f) m |= 1u << t;
+    return m;
+}
+// FLOATING rows.  A row without own volume is tied to the rest of the system through the rows it shares a stress term with; a connected set of such rows none of which shares a
+// term with a row that HAS own volume, or with a solid face, is a system of its own -- singular in the exact operator (any constant solves it), zero right-hand side, and in the
+// reference's operator held at exactly 0 by the rounding defect of a diagonal (or, where that vanishes, by PCG's zero start): holdout draw 35 of round 6's sweep, three W faces in a
+// column above a speck of liquid smaller than a control volume.  The multigrid's prolongation leaks a value into such rows that nothing in the iteration can take out again (1e-1 of
+// max|u| on 159 faces there, status 0).  "Grounded at once": the row shares a term with a solid face or with a row that has own volume.
+__device__ __forceinline__ bool d_is_row_face(int comp, size_t p, int i, int j, int k, const Lay &L, const uint8_t *const st[3]) { return d_row_range(comp, i, j, k, L) && st[comp][p] == ST_FLUID; }
+__device__ __forceinline__ bool d_grounded_at_once(int comp, size_t p, int i, int j, int k, unsigned fm, const Lay &L, const uint8_t *const st[3], const float *const vol[3]) {
+    const long sy = L.sy, sz = L.sz;
+    for (int t = 0; t < 6; t++) {
+        if (!((fm >> t) & 1u)) continue;
+        for (int m = 0; m < 3; m++) {
+            const FvMem e = FV_MEM[comp][t][m];
+            if (e.comp < 0) continue;
+            const size_t q = p + e.di + e.dj * sy + e.dk * sz;
+            if (st[e.comp][q] == ST_SOLID) return true;
+            if (d_is_row_face(e.comp, q, i + e.di, j + e.dj, k + e.dk, L, st) && vol[e.comp][q] > 0.0f) return true;
+        }
+    }
+    return false;
+}
 // is face (comp, p) a row without own volume whose only non-zero factor sits in slot `slot_out`?  A factor is a viscosity x one of six control volumes (order: right, left,
 // top, bottom, front, back): the volumes are counted first -- with ONE viscosity that decides --, the factors are only formed for a viscosity field (which may vanish on an edge).
 __device__ __forceinline__ bool d_single_factor_row(int comp, size_t p, int i, int j, int k, const Lay &L, const uint8_t *const st[3], const float *const vol[3], const float *__restrict__ nu,
@@ -1002,7 +1054,7 @@ __device__ __forceinline__ bool d_single_factor_row(int comp, size_t p, int i, i
 __global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV, const uint8_t *__restrict__ stW, const float *__restrict__ volU,
                                      const float *__restrict__ volV, const float *__restrict__ volW, const float *__restrict__ nu, const float *__restrict__ vC,
                                      const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, const uint8_t *__restrict__ band, float factor, int field,
-                                     unsigned long long *__restrict__ list) {
+                                     unsigned long long *__restrict__ list, unsigned long long *__restrict__ flist) {
     IJK_OR_RETURN(L);
     const long sy = L.sy, sz = L.sz;
     if (!(band[c] || band[c - 1] || band[c + 1] || band[c - sy] || band[c + sy] || band[c - sz] || band[c + sz])) return;   // (no volume near: no row, k_visc_setup)
@@ -1015,23 +1067,19 @@ __global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, con
     //      4 edgeU(c + z): V(+z) 5, W(+z) 3, W(-y + z) 2 | 5 edgeU(c): V(-z) 4, W(c) 3, W(-y) 2
     //   W: 0 edgeV(c + x): W(+x) 1, U(+x) 5, U(+x - z) 4 | 1 edgeV(c): W(-x) 0, U(c) 5, U(-z) 4 | 2 edgeU(c + y): W(+y) 3, V(+y) 5, V(+y - z) 4 | 3 edgeU(c): W(-y) 2, V(c) 5, V(-z) 4
     //      4 centre(c) -> W(+z) 5 | 5 centre(c - z) -> W(-z) 4
-    struct Mem { signed char comp, di, dj, dk, slot; };
-    static const Mem M[3][6][3] = {
-        {{{0, 1, 0, 0, 1}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{0, -1, 0, 0, 0}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
-         {{0, 0, 1, 0, 3}, {1, 0, 1, 0, 1}, {1, -1, 1, 0, 0}}, {{0, 0, -1, 0, 2}, {1, 0, 0, 0, 1}, {1, -1, 0, 0, 0}},
-         {{0, 0, 0, 1, 5}, {2, 0, 0, 1, 1}, {2, -1, 0, 1, 0}}, {{0, 0, 0, -1, 4}, {2, 0, 0, 0, 1}, {2, -1, 0, 0, 0}}},
-        {{{1, 1, 0, 0, 1}, {0, 1, 0, 0, 3}, {0, 1, -1, 0, 2}}, {{1, -1, 0, 0, 0}, {0, 0, 0, 0, 3}, {0, 0, -1, 0, 2}},
-         {{1, 0, 1, 0, 3}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{1, 0, -1, 0, 2}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
-         {{1, 0, 0, 1, 5}, {2, 0, 0, 1, 3}, {2, 0, -1, 1, 2}}, {{1, 0, 0, -1, 4}, {2, 0, 0, 0, 3}, {2, 0, -1, 0, 2}}},
-        {{{2, 1, 0, 0, 1}, {0, 1, 0, 0, 5}, {0, 1, 0, -1, 4}}, {{2, -1, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, -1, 4}},
-         {{2, 0, 1, 0, 3}, {1, 0, 1, 0, 5}, {1, 0, 1, -1, 4}}, {{2, 0, -1, 0, 2}, {1, 0, 0, 0, 5}, {1, 0, 0, -1, 4}},
-         {{2, 0, 0, 1, 5}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{2, 0, 0, -1, 4}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}}};
     for (int comp = 0; comp < 3; comp++) {
+        if (d_is_row_face(comp, c, i, j, k, L, st) && vol[comp][c] == 0.0f) {   // a massless row that shares no term with mass or a wall: a candidate for a floating set (k_visc_floating)
+            const unsigned fm = d_factor_mask(comp, c, L, nu, vC, vEU, vEV, vEW, factor, field);
+            if (fm && !d_grounded_at_once(comp, c, i, j, k, fm, L, st, vol)) {
+                const unsigned long long at = atomicAdd(flist, 1ull);
+                if (at < (unsigned long long)FV_FLOAT_CAP) flist[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)comp;
+            }
+        }
         int slot;
         if (!d_single_factor_row(comp, c, i, j, k, L, st, vol, nu, vC, vEU, vEV, vEW, factor, field, slot)) continue;
         bool later = false;   // is there such a row of the same cluster BEFORE this one in the reference's row order?
         for (int m = 0; m < 3 && !later; m++) {
-            const Mem e = M[comp][slot][m];
+            const FvMem e = FV_MEM[comp][slot][m];
             if (e.comp < 0) continue;
             const size_t p = c + e.di + e.dj * sy + e.dk * sz;
             int s2;
@@ -1041,6 +1089,69 @@ __global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, con
         if (!later) continue;
         const unsigned long long at = atomicAdd(list, 1ull);
         if (at < (unsigned long long)FV_ELIM_CAP) list[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)comp;
+    }
+}
+// One workgroup over the candidates (massless rows that share no term with mass or a wall): a candidate becomes grounded once a row it shares a term with is -- a massless row
+// grounded at once (recomputed here), or a candidate grounded in an earlier round (marks: one byte per index, bits 0-2, cleared again at the end) --; rounds until nothing changes.
+// What stays ungrounded floats: appended to the elimination list (state ST_ELIM, velocity 0 for this solve).
+__global__ __launch_bounds__(1024) void k_visc_floating(Lay L, const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV, const uint8_t *__restrict__ stW, const float *__restrict__ volU,
+                                                        const float *__restrict__ volV, const float *__restrict__ volW, const float *__restrict__ nu, const float *__restrict__ vC,
+                                                        const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field,
+                                                        const unsigned long long *__restrict__ flist, uint8_t *__restrict__ mark, unsigned long long *__restrict__ elist) {
+    __shared__ int changed;
+    const uint8_t *const st[3] = {stU, stV, stW};
+    const float *const vol[3] = {volU, volV, volW};
+    const long sy = L.sy, sz = L.sz;
+    unsigned long long n = flist[0];
+    if (n > (unsigned long long)FV_FLOAT_CAP) n = FV_FLOAT_CAP;
+    if (n == 0) return;
+    for (int round = 0; round < 256; round++) {
+        if (threadIdx.x == 0) changed = 0;
+        __syncthreads();
+        for (unsigned long long t = threadIdx.x; t < n; t += blockDim.x) {
+            const size_t c = (size_t)(flist[1 + t] >> 2);
+            const int comp = (int)(flist[1 + t] & 3ull);
+            if ((mark[c] >> comp) & 1u) continue;
+            const int k = (int)(c / (size_t)sz) + L.oz, j = (int)((c % (size_t)sz) / (size_t)sy) + L.oy, i = (int)(c % (size_t)sy) + L.ox;
+            const unsigned fm = d_factor_mask(comp, c, L, nu, vC, vEU, vEV, vEW, factor, field);
+            // (a block context sees the rows of its box: a set that reaches a cut face may be grounded beyond it -- candidates within three entries of a cut count as grounded, on every
+            // rank that sees them alike)
+            bool g = (i - 3 < L.olo[0] && L.olo[0] > 0) || (i + 3 >= L.ohi[0] && L.ohi[0] < L.I) || (j - 3 < L.olo[1] && L.olo[1] > 0) || (j + 3 >= L.ohi[1] && L.ohi[1] < L.J) ||
+                     (k - 3 < L.olo[2] && L.olo[2] > 0) || (k + 3 >= L.ohi[2] && L.ohi[2] < L.K);
+            for (int s6 = 0; s6 < 6 && !g; s6++) {
+                if (!((fm >> s6) & 1u)) continue;
+                for (int m = 0; m < 3 && !g; m++) {
+                    const FvMem e = FV_MEM[comp][s6][m];
+                    if (e.comp < 0) continue;
+                    const size_t q = c + e.di + e.dj * sy + e.dk * sz;
+                    const int qi = i + e.di, qj = j + e.dj, qk = k + e.dk;
+                    if (!d_is_row_face(e.comp, q, qi, qj, qk, L, st)) continue;
+                    if ((mark[q] >> e.comp) & 1u) { g = true; break; }
+                    if (round == 0) {   // (a neighbour that was grounded at once is not on the list: its state is recomputed, in the first round only -- it cannot change)
+                        const unsigned fq = d_factor_mask(e.comp, q, L, nu, vC, vEU, vEV, vEW, factor, field);
+                        if (fq && d_grounded_at_once(e.comp, q, qi, qj, qk, fq, L, st, vol)) g = true;
+                    }
+                }
+            }
+            if (g) { atomicOr(reinterpret_cast<unsigned *>(mark + (c & ~(size_t)3)), (1u << comp) << (8u * (unsigned)(c & 3))); changed = 1; }
+        }
+        __syncthreads();
+        const int ch = changed;
+        __syncthreads();
+        if (!ch) break;
+    }
+    for (unsigned long long t = threadIdx.x; t < n; t += blockDim.x) {
+        const size_t c = (size_t)(flist[1 + t] >> 2);
+        const int comp = (int)(flist[1 + t] & 3ull);
+        if (!((mark[c] >> comp) & 1u)) {
+            const unsigned long long at = atomicAdd(elist, 1ull);
+            if (at < (unsigned long long)FV_ELIM_CAP) elist[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)comp;
+        }
+    }
+    __syncthreads();
+    for (unsigned long long t = threadIdx.x; t < n; t += blockDim.x) {   // the marks go back to zero: the array is only ever cleared where it was written
+        const size_t c = (size_t)(flist[1 + t] >> 2);
+        atomicAnd(reinterpret_cast<unsigned *>(mark + (c & ~(size_t)3)), ~(0xffu << (8u * (unsigned)(c & 3))));
     }
 }
 // the listed faces: state ST_ELIM and velocity 0 before k_visc_setup (APPLY), ST_FLUID again after it (the states are kept while the solid SDF is unchanged)
@@ -1302,11 +1413,21 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const bool elim = !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0;   // rows that repeat another row's equation: out of this solve's system (k_visc_singular_find)
         if (elim) {
             if (!c->elimList) HIPCHK(c, hipMalloc((void **)&c->elimList, (size_t)(FV_ELIM_CAP + 1) * sizeof(unsigned long long)));
+            if (!c->floatList) {
+                HIPCHK(c, hipMalloc((void **)&c->floatList, (size_t)(FV_FLOAT_CAP + 1) * sizeof(unsigned long long)));
+                HIPCHK(c, hipMalloc((void **)&c->groundMark, c->L.n + 2 * c->L.guard + 64));
+                HIPCHK(c, hipMemsetAsync(c->groundMark, 0, c->L.n + 2 * c->L.guard + 64, c->stream));
+                c->groundMark += c->L.guard;   // (indexed like every plain array; cleared by the kernel that marks)
+            }
             HIPCHK(c, hipMemsetAsync(c->elimList, 0, sizeof(unsigned long long), c->stream));
+            HIPCHK(c, hipMemsetAsync(c->floatList, 0, sizeof(unsigned long long), c->stream));
             const Lay RE = R0;   // (rows only exist in the liquid's range)
             hipLaunchKernelGGL(k_visc_singular_find, GRID3(RE), 0, c->stream, RE, (const uint8_t *)c->stU, (const uint8_t *)c->stV, (const uint8_t *)c->stW, (const float *)c->volU,
                                (const float *)c->volV, (const float *)c->volW, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
-                               (const float *)c->volEW, (const uint8_t *)c->validCells, factor, fieldSolve ? 1 : 0, c->elimList);
+                               (const float *)c->volEW, (const uint8_t *)c->validCells, factor, fieldSolve ? 1 : 0, c->elimList, c->floatList);
+            hipLaunchKernelGGL(k_visc_floating, dim3(1), dim3(1024), 0, c->stream, c->L, (const uint8_t *)c->stU, (const uint8_t *)c->stV, (const uint8_t *)c->stW, (const float *)c->volU,
+                               (const float *)c->volV, (const float *)c->volW, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
+                               (const float *)c->volEW, factor, fieldSolve ? 1 : 0, (const unsigned long long *)c->floatList, c->groundMark, c->elimList);
             hipLaunchKernelGGL(k_visc_singular_apply<true>, dim3(1), dim3(256), 0, c->stream, (const unsigned long long *)c->elimList, c->stU, c->stV, c->stW, c->U, c->V, c->W);
         }
         { const FillJob z[2] = {{bmax, 2 * sizeof(double), 0}, {c->d_flags + 2, sizeof(int), 0}}; const int rcz = fv_fill_list(c, z, 2); if (rcz) return rcz; }
