@@ -1349,16 +1349,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const int prc = fv_vmg_prepare(c);   // allocate the hierarchy now, whichever solve first uses it
         if (prc) return prc;
     }
-    // How accurately the coarsest (16^3) level is solved mattered while stage 1 of the solve ran to 1e-6 (bunny 256^3, 12 substeps from
-    // rest, iterations summed: 2303 / 2005 / 1720 / 1476 / 1366 / 1363 with 8 / 16 / 32 / 64 / 128 / 256 Jacobi sweeps, each ~1 us of a ~300 us
-    // iteration; with Chebyshev weights -- k_viscosity_mg.hip: VMG_CHEB_KAPPA -- 8 / 16 / 32 sweeps do what 32 / 64 / 256 did), and the rule was 32
-    // sweeps on stiff systems whose last solve needed more than 60 iterations, else 16.  With stage 1 stopping at 1e-4 (below) the last, slow decade of
-    // the loop is gone and 8 Chebyshev sweeps win or tie everywhere (25 substeps of the 256^3 bunny: 1 318 iterations / 407 ms with the old rule,
-    // 1 312 / 404 with 32, 1 377 / 409 with 16, 1 370 / 389-395 with 8, 1 403 / 410 with 4; honey 256^3: 450 -> 418 ms; 512^3 honey, the 512 x 256 x 256
-    // sheet, 150 substeps of the bunny: -0 ... -1 %; 128^3: -3 %) -- for THOSE solves.  A solve that runs ONE loop to 1e-6 (exact operator, block
-    // contexts, nu dt/dx^2 > 2e4) keeps the old rule: with 8 sweeps the bench's exact-operator run needs 88 instead of 74 iterations (721 -> 675
-    // MCells/s), the one-rank communicator run 120 instead of 94 (446 -> 405).  A power of two selects the Chebyshev weights, any other count plain
-    // damped Jacobi.
+    // sweeps on the LDS-resident coarsest level: 16, 32 on stiff systems whose last solve needed more than 60 iterations; 8 where stage 1 stops early (below).  A power of two selects the
+    // Chebyshev weights, any other count plain damped Jacobi.  (The scans: HISTORY.md, "Round 6: notes moved out of viscosity_solve_t", A.)
     {
         const double stiff = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
         c->vmgSweeps = c->prm.viscosity_mg_coarsest_sweeps > 0 ? (c->prm.viscosity_mg_coarsest_sweeps + 1) / 2 * 2
@@ -1372,19 +1364,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // flipv_params.exact_viscosity_operator = 0 (default): the solve applies the reference's operator INCLUDING the rounding of its float
     // diagonal (d_ref_volume) -- at 256^3 the reference's converged answer is 7e-6 from this operator's and 1.5e-4 from the exact one's.
     const int refDiag = c->prm.exact_viscosity_operator ? 0 : 1;
-    // DEFECT PREDICTOR (the two-stage solve below: the Krylov loop runs on the exact operator A, the solve is for the reference's A_ref = A + E, E diagonal):
-    // stage 1 solves A x = b - E u_old, u_old = the incoming velocity of the row -- one step of the fixed point x <- A^-1 (b - E x) started from u_old
-    // instead of from 0.  What stage 1 then leaves of the defect is E (x - u_old) instead of E x, so the correction stage starts closer: the same or fewer
-    // iterations for the same or better velocities on every fixture (tools/r4_predict_scan.py, profiles/r4/predictor_scan.log: 256^3 62/59 -> 60/59 iterations,
-    // 1.9e-5/2.5e-5 -> 1.5e-5/2.6e-5; nu dt/dx^2 = 1.2e5: 199/149 -> 162/149, 2.5e-5/3.9e-6 -> 1.6e-5/1.9e-5; config 4's scene 233/234 -> 233/219;
-    // bench lines: 512^3 bunny 1 160 -> 1 365 MCells/s, honey 512^3 1 325 -> 1 468, the 1024 x 512 x 512 sheet 603 -> 699 -- the stiffer and larger, the more it saves).
-    // The correction stage stays: SKIPPING it where the prediction looks good was measured too -- bench 957 -> 1 107 MCells/s, 256^3 still 2.1e-5/2.6e-5, but
-    // 1.1e-4/2.2e-4 at nu dt/dx^2 = 1.2e5, and neither max|b - A_ref x| nor what one multigrid cycle on that residual moves (3e-6 ... 1e-5 of max|u| in every
-    // case) tells the two apart: the defect's error sits in the near-rigid modes a residual does not show.  The right-hand side's copy (vB) stays b: the
-    // fp64 residual after stage 1 is b - A_ref x.  (Not with the opt-in residual replacement, which recomputes the LOOP's residual from vB.)
-    // Only where stage 1 stops early (the rule further down): a stage 1 run to the final tolerance itself -- viscosity_stage1_factor = 1, or nu dt/dx^2 beyond the
-    // gate -- stagnates on b - E u_old (E u_old is rough and largest on the sliver rows: the fp32 loop's accuracy floor; bench.py's mode_b_strict: 155 iterations,
-    // 5.7e-6 instead of 99 and 1e-6).
+    // DEFECT PREDICTOR: stage 1 solves A x = b - E u_old (u_old = the row's incoming velocity) -- one step of the fixed point x <- A^-1 (b - E x) started from u_old instead of 0 --, only
+    // where stage 1 stops early; the correction stage stays (skipping it was measured and misses the bar at nu dt/dx^2 = 1.2e5).  HISTORY.md, same section, B.
     const double stiffSolve = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
     const bool stage1Early = c->prm.viscosity_stage1_factor != 1.0f && stiffSolve <= (c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 1.0e6);
     const bool predict = refDiag && mgPlanned && std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && c->prm.viscosity_defect_predictor >= 0 &&
@@ -1560,22 +1541,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     double velStep = 0.0;
     int anyActive = c->nActiveV;
     int replacePeriod = 0;   // (periodic residual replacement inside a loop -- k_viscosity_brick.hip: fv_brick_replace -- was an opt-in study until version 4 of the ABI: it restarts CG with a stale direction again and again, HISTORY.md; the kernels remain as the refinement steps' building blocks)
-    // The reference's operator (exact_viscosity_operator = 0, the default) under the multigrid, fp32 vectors, brick layout: DEFECT CORRECTION.
-    // A_ref = A + E, E the rounding defect of the reference's float diagonal (d_ref_volume): |E| ~ 1e-3 of what a row does to a near-rigid
-    // motion, enough to make the near-rigid modes of small liquid clusters (own volumes of the size of the defect) nearly indefinite.  PCG
-    // applied to A_ref itself converges on some substeps and stagnates at 1e-5 max|b| on others (256^3 bunny, substeps 4, 5, 7: three
-    // refinements and the cap) -- the reference's own MIC(0) PCG needs 7 689-42 223 iterations for the same reason.  So the Krylov loop only
-    // ever sees the exact, positive definite A, and the solve for A_ref is the outer iteration
-    //     r = b - A_ref x   (fp64, x in the fp64 accumulator)  ;  solve A dx = r to 1e-3 |r| with the fp32 multigrid-PCG  ;  x += dx
-    // in TWO steps: (1) A x = b to the final tolerance in ONE uninterrupted run -- measured on the 256^3 bunny drop this converges on every
-    // substep (99-247 iterations), whereas any restart of the fp32 loop near its accuracy floor (~1e-6 max|b| at that size) forgets the
-    // handful of isolated slow modes CG had resolved and stagnates at 3e-6 (staged variants: cap and fallback on 4-7 of the first 15
-    // substeps); (2) ONE correction A dx = b - A_ref x, whose right-hand side is -E x ~ 1.5e-4 max|b|, to 2e-2 of it and at most 48
-    // iterations, accepted as it comes: what is left of the defect is second order (|A^-1 E|^2 ~ 1e-7) plus 2 % of the first.  The
-    // residual reported is max|b - A_ref x| recomputed in fp64 at the end.
-    // The same flush / recompute / restart step rescues any fp32 brick solve the stall guard of PcgScal stops (either operator, either
-    // preconditioner); the diagonal loop applies A_ref directly and is only restarted when it stalls (it converges superlinearly:
-    // a restart costs it ~2 000 iterations at 256^3).
+    // DEFECT CORRECTION (the default operator under the multigrid, fp32 bricks): the Krylov loop only ever sees the exact, positive definite A; the solve for A_ref = A + E is the outer
+    // iteration  r = b - A_ref x (fp64, x in the fp64 accumulator) ; solve A dx = r with the fp32 multigrid-PCG ; x += dx.  The same flush / recompute / restart step rescues any fp32
+    // solve the stall guard stops.  The rule: include/flipv.h ("THE DEFAULT VISCOSITY SOLVE"); why: DESIGN.md 4.2; the measurements: HISTORY.md, same section, C.
     const bool canRefine = std::is_same<T, float>::value && (brick || c->vwV == 4);   // bricks: k_viscosity_brick.hip; planes: fv_plane_refine above
     const bool staged = canRefine && (refDiag || c->vMixed64);   // (mixed fp64 mode: refinement towards whichever operator the solve is for)
     const bool useAcc = canRefine;
@@ -1593,12 +1561,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // this solve is a share of is capped at viscosity_mass_scale x max|u| (100: with viscosity_tolerance = 1e-6 the final target is never above 1e-4 of one full
         // control volume moving at max|u|; 30 and 10 cost 10 % / 30 % more iterations at 256^3 for the same 3e-6 ... 5e-6, profiles/r5/eta_scan_256.log).  flipv_solve_info.rhs_norm stays max|rhs|.
         const double massScale = c->prm.viscosity_mass_scale > 0.0f ? (double)c->prm.viscosity_mass_scale : (c->prm.viscosity_mass_scale < 0.0f ? 0.0 : 100.0);
-        // (... and never below 3e-2 max|rhs|: a liquid almost at rest next to solid faces that still hold old velocities has max|u| / max|rhs| ~ 1e-5, and a target of
-        // 1e-10 max|rhs| is beyond what fp32 correction stages reach -- 200 substeps of the resting 512 x 256 x 256 sheet: two solves ended short at 1.4e-9)
-        // ... and the floor grows with the stiffness: what an fp32 correction stage reaches scales with |A| ~ S.  256^3 honey (S = 32 768) settling on the floor, floor 0.03:
-        // the stage's target is 9e-8 max|rhs|, 26 ... 86 of 330 solves run out of its 200 iterations and their one restart (status 1, 250-440 iterations); floor 0.3: 2 of 330,
-        // 20 % less time, the late states within 4e-5 of the tightened solve either way (profiles/r5/mass_floor_scan.log).  At S = 3 277 (256^3 bunny, nu = 5) the floor stays
-        // 0.033: there 0.3 would loosen the bulk from < 1e-5 to 7e-5.
+        // (... and never below a floor that grows with the stiffness -- what an fp32 correction stage reaches scales with |A| ~ S --: max(0.03, min(0.3, 1e-5 S, 1e4 / S)) x max|rhs|;
+        // DESIGN.md 4.3, HISTORY.md same section, D)
         const double massFloor = c->prm.viscosity_mass_floor > 0.0f ? (double)c->prm.viscosity_mass_floor : fmax(3.0e-2, fmin(0.3, fmin(1.0e-5 * stiffSolve, 1.0e4 / fmax(stiffSolve, 1.0))));   // (1e-6 x floor x S, the bound on the bulk's relative error, stays <= 1e-2: holdout draw 7, S = 2.1e5, is 1.0e-4 at 0.3 and 3e-5 at 0.03)
         const double bnormEff = (massScale > 0.0 && umaxAll > 0.0 && !c->vMixed64) ? fmin(bnorm, fmax(massScale * umaxAll, massFloor * bnorm)) : bnorm;
         const double tolFinal = c->prm.viscosity_tolerance * bnormEff;
@@ -1683,12 +1647,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             sc.vel_window = c->prm.viscosity_velocity_window > 0 ? c->prm.viscosity_velocity_window : 4;
             sc.vel_stall = c->prm.viscosity_velocity_stall_ratio > 0.0f ? (double)c->prm.viscosity_velocity_stall_ratio : 0.0;   // (off by default: flipv.h)
         }
-        // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272).  Two extra criteria for the multigrid loop --
-        // max|r/d| and max|M^-1 r| against the velocity scale -- were tried against the one weakness measured (forced multigrid on the
-        // mildly stiff twobody20 fixture leaves 3-5 faces of tiny liquid clusters 30 % off at a converged max|r|: their near-rigid modes
-        // have residual ~ own volume x error) and dropped: sliver rows with diagonals of 1e-6 sit at fp32 noise in either norm, so once
-        // the liquid moves the final stage could never pass them (256^3 bunny, substeps 4, 5, 7: stall, cap, fallback).  AUTO keeps such
-        // systems on the diagonal instead (fv_visc_auto_pick).)
+        // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272); two further norms were tried and dropped: HISTORY.md, same section, E.)
         conv = -1;
         if (useMg) {
             if ((rc = fv_viscosity_pcg_mg(c, sc, capNow, mgspmv, replacePeriod, itersDone > 0 ? 1 : 0, &conv))) return rc;
@@ -1797,15 +1756,8 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         const bool restartForVelocity = !innerDiffers && velUnmet && !wasConverged && refinements < 8 && itersDone < cap;
         if (res <= tolFinal && !restartForVelocity) { success = true; if (innerDiffers) { defectRes = res; if (corrections >= 1) res = mainRes; } break; }
         if (innerDiffers && wasConverged) {
-            // The defect E x the exact-operator loop left behind: ONE bounded correction stage, accepted as it comes -- a first-order
-            // correction.  |A^-1 E| is ~1e-3 at 256^3 / nu = 5: what is left is 2 % of the first order plus the second, and the velocities
-            // land 4e-5 from the reference's converged ones (1.5e-4 without).  Where nu dt/dx^2 is extreme the reference's float diagonal is
-            // simply wrong -- 512^3 / nu = 50, nu dt/dx^2 = 131 072: max|E x| = 1.2 max|b|, further stages contract by 2-50x each and stop
-            // contracting around 1e-5 -- and chasing it costs more than the solve (measured: 6 stages, +70 % iterations, no convergence).
-            // The solve's status and residual are the exact-operator loop's; `defect_residual` reports max|b - A_ref x| at the end.
-            // A stage that ENDED SHORT (stalled, or out of its budget: an fp32 recurrence that has lost its conjugacy, typically within a factor of a few of its
-            // target -- honey 256^3 at nu = 50, 16 of 1 500 substeps: 1.2e-6 ... 3.4e-6 max|rhs| where 1e-6 was asked for) is restarted ONCE from the fp64
-            // residual just recomputed, like any stalled loop; its own outcome is what the solve reports.
+            // The defect E x the exact-operator loop left behind: ONE bounded correction stage (two by the field's contrast), accepted as it comes; a stage that ENDED SHORT is restarted once from
+            // the residual just recomputed; the solve's status and residual are the exact-operator loop's, `defect_residual` reports max|b - A_ref x| at the end.  (HISTORY.md, same section, F.)
             const bool again = !c->vMixed64 && corrStatus == 2 && corrections == rounds && !extraStage && !tookBack && itersDone < cap;
             if (again) extraStage = true;
             if ((corrections >= rounds && !again) || itersDone >= cap || tookBack) {

@@ -72,6 +72,10 @@ enum flipv_precision {
 
 /* THE DEFAULT VISCOSITY SOLVE, stated once (k_viscosity.hip: viscosity_solve_t implements this table; DESIGN.md 4 gives the measurements behind every number).
  *   S = nu_max dt/dx^2, the a-priori stiffness (all ranks).                     N = the norm every tolerance is a share of = min(max|rhs|, max(viscosity_mass_scale x max|u|, viscosity_mass_floor x max|rhs|))
+ *   before the solve         rows the reference's system determines only through its solver's start at 0 are taken OUT of the system and held at 0 (flipv_solve_info.eliminated_rows):
+ *                            (i) of two or more rows without own volume that are THE SAME equation (their only non-zero factor is one edge's / cell centre's) all but the first in the
+ *                            reference's row order -- its MIC(0) factorisation zeroes the later ones' pivots and couplings (pcgsolver.h:62-178) --; (ii) connected sets of such rows that
+ *                            share no stress term with a row that has own volume or with a solid face (zero right-hand side, singular in the exact operator)   [FLIPV_VERSION 6]
  *   preconditioner (AUTO)    S <= 8: diagonal PCG on the reference's operator A_ref (one loop to viscosity_tolerance x N).   S > 8: Galerkin multigrid V(2,2), unless
  *                            the previous solve shows the diagonal to converge for less; a diagonal solve AUTO picked that hits the cap is repeated with the multigrid
  *   under the multigrid      defect correction towards A_ref = A + E (E: the rounding of the reference's float diagonal; with a viscosity FIELD also its per-row edge factors):
@@ -86,6 +90,9 @@ enum flipv_precision {
  *                            viscosity_velocity_window (4) iterations together moved no velocity the substep uses by more than viscosity_velocity_tolerance (3e-5; 1e-5 where S > 5e4) x max|u|;
  *                            (held for at most 48 iterations past the residual test; optional early way out: viscosity_velocity_stall_ratio, off by default);
  *                            a loop the stall guard stops with the criterion unmet is restarted from the fp64 residual
+ *   a viscosity FIELD        (values that differ) also gets: the weak modes of strongly coupled PAIRS of rows in the preconditioner (viscosity_pair_correction: coupling >= 0.7 of the geometric
+ *                            mean of the diagonals, the pair's other couplings no larger than its weak eigenvalue; each adds what the V(2,2) smoother leaves of v v^T / lambda), and a stall
+ *                            guard of 1 000 x instead of 16 x (CG's max|r| rebounds 20-50 x while it resolves the isolated modes of a viscosity jump)   [FLIPV_VERSION 6]
  *   after the solve          clusters of <= 4 rows without own volume that share one dominant stress term are solved exactly in fp64 (viscosity_massless_polish)
  *   status                   0 = every stage reached its target; 1 = cap / stalled / a stage ended short or was taken back (the result is applied, like the reference's
  *                            accepted iterate); flipv_solve_info: residual (stage 1's), defect_residual = max|b - A_ref x| delivered, velocity_step, correction_* */
