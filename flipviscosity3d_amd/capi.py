@@ -66,7 +66,7 @@ class DebugParams(C.Structure):
                 ("viscosity_mg_omega_first", C.c_float), ("viscosity_mg_omega_second", C.c_float),
                 ("no_liquid_box", C.c_int), ("no_comm_overlap", C.c_int), ("no_graph_replay", C.c_int), ("unbinned_scatter", C.c_int), ("grid_cap", C.c_int),
                 ("viscosity_lane_width", C.c_int), ("viscosity_spmv_grid_cap", C.c_int), ("viscosity_update_grid_cap", C.c_int),
-                ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int), ("viscosity_mg_packed_rows", C.c_int), ("stall_guard_ratio", C.c_float), ("viscosity_pair_lambda_floor", C.c_float)]
+                ("beta_from_conjugacy", C.c_int), ("spmv_run_length", C.c_int), ("viscosity_mg_packed_rows", C.c_int), ("stall_guard_ratio", C.c_float), ("viscosity_pair_lambda_floor", C.c_float), ("velocity_patience", C.c_int)]
 
 
 _PRODUCT_FIELDS = {f for f, _ in Params._fields_}

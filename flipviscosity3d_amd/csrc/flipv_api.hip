@@ -435,6 +435,7 @@ extern "C" int flipv_set_debug_params(flipv_context *c, const flipv_debug_params
     else if (!in(p->viscosity_mg_packed_rows, -1, 1)) bad = "viscosity_mg_packed_rows";
     else if (!(p->stall_guard_ratio == 0.0f || fin(p->stall_guard_ratio, 1.0f, 1e30f))) bad = "stall_guard_ratio (0 or >= 1)";
     else if (!fin(p->viscosity_pair_lambda_floor, 0.0f, 1.0f)) bad = "viscosity_pair_lambda_floor (0 ... 1)";
+    else if (!in(p->velocity_patience, 0, 1 << 20)) bad = "velocity_patience";
     if (bad) { c->err = std::string("flipv_set_debug_params: out of range: ") + bad; return FLIPV_ERR_INVALID; }
     static_cast<flipv_debug_params &>(c->prm) = *p;
     return FLIPV_OK;

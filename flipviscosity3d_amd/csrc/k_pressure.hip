@@ -414,7 +414,7 @@ static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **ext
     sc->stall_ratio = c->prm.stall_guard_ratio > 0.0f ? (double)c->prm.stall_guard_ratio : FV_STALL_RATIO;   // (the viscosity solve of a viscosity FIELD takes FV_STALL_RATIO_FIELD: k_viscosity.hip)
     sc->stalled = c->d_flags + 11;
     sc->bestIt = c->d_flags + 14;
-    sc->vel_tol = 0.0; sc->vel_stall = 0.0; sc->vel_window = 0; sc->vel_patience = 48; sc->passIt = c->d_flags + 15;   // (the velocity criterion: set by the viscosity solve for its last loop)
+    sc->vel_tol = 0.0; sc->vel_stall = 0.0; sc->vel_window = 0; sc->vel_patience = c->prm.velocity_patience > 0 ? c->prm.velocity_patience : 48; sc->passIt = c->d_flags + 15;   // (the velocity criterion: set by the viscosity solve for its last loop)
     *extra = c->d_scal + FV_NSC * n;
 }
 

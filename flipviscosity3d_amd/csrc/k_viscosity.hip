@@ -976,6 +976,25 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
 constexpr int FV_ELIM_CAP = 4096;
 constexpr int FV_FLOAT_CAP = 8192;   // candidates of floating sets (massless rows not grounded at once)
 struct FvMem { signed char comp, di, dj, dk, slot; };
+// the other faces that carry the same factor, per (component, slot): up to three of (component, di, dj, dk, slot there); comp -1 = none
+//   U: 0 centre(c) -> U(+x) slot 1 | 1 centre(c - x) -> U(-x) 0 | 2 edgeW(c + y): U(+y) 3, V(+y) 1, V(-x + y) 0 | 3 edgeW(c): U(-y) 2, V(c) 1, V(-x) 0
+//      4 edgeV(c + z): U(+z) 5, W(+z) 1, W(-x + z) 0 | 5 edgeV(c): U(-z) 4, W(c) 1, W(-x) 0
+//   V: 0 edgeW(c + x): V(+x) 1, U(+x) 3, U(+x - y) 2 | 1 edgeW(c): V(-x) 0, U(c) 3, U(-y) 2 | 2 centre(c) -> V(+y) 3 | 3 centre(c - y) -> V(-y) 2
+//      4 edgeU(c + z): V(+z) 5, W(+z) 3, W(-y + z) 2 | 5 edgeU(c): V(-z) 4, W(c) 3, W(-y) 2
+//   W: 0 edgeV(c + x): W(+x) 1, U(+x) 5, U(+x - z) 4 | 1 edgeV(c): W(-x) 0, U(c) 5, U(-z) 4 | 2 edgeU(c + y): W(+y) 3, V(+y) 5, V(+y - z) 4 | 3 edgeU(c): W(-y) 2, V(c) 5, V(-z) 4
+//      4 centre(c) -> W(+z) 5 | 5 centre(c - z) -> W(-z) 4
+// (constexpr: every use below has compile-time indices -- fully unrolled loops over a template parameter --, so that nothing is indexed at run time: a kernel with dynamically
+// indexed per-thread arrays goes through scratch memory, and a grid-sized launch with scratch pays ~200 us at 256^3; the run-time copy FV_MEM is for the one-workgroup kernel)
+static constexpr FvMem FV_MEMC[3][6][3] = {
+    {{{0, 1, 0, 0, 1}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{0, -1, 0, 0, 0}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
+     {{0, 0, 1, 0, 3}, {1, 0, 1, 0, 1}, {1, -1, 1, 0, 0}}, {{0, 0, -1, 0, 2}, {1, 0, 0, 0, 1}, {1, -1, 0, 0, 0}},
+     {{0, 0, 0, 1, 5}, {2, 0, 0, 1, 1}, {2, -1, 0, 1, 0}}, {{0, 0, 0, -1, 4}, {2, 0, 0, 0, 1}, {2, -1, 0, 0, 0}}},
+    {{{1, 1, 0, 0, 1}, {0, 1, 0, 0, 3}, {0, 1, -1, 0, 2}}, {{1, -1, 0, 0, 0}, {0, 0, 0, 0, 3}, {0, 0, -1, 0, 2}},
+     {{1, 0, 1, 0, 3}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{1, 0, -1, 0, 2}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
+     {{1, 0, 0, 1, 5}, {2, 0, 0, 1, 3}, {2, 0, -1, 1, 2}}, {{1, 0, 0, -1, 4}, {2, 0, 0, 0, 3}, {2, 0, -1, 0, 2}}},
+    {{{2, 1, 0, 0, 1}, {0, 1, 0, 0, 5}, {0, 1, 0, -1, 4}}, {{2, -1, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, -1, 4}},
+     {{2, 0, 1, 0, 3}, {1, 0, 1, 0, 5}, {1, 0, 1, -1, 4}}, {{2, 0, -1, 0, 2}, {1, 0, 0, 0, 5}, {1, 0, 0, -1, 4}},
+     {{2, 0, 0, 1, 5}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{2, 0, 0, -1, 4}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}}};
 __device__ const FvMem FV_MEM[3][6][3] = {
     {{{0, 1, 0, 0, 1}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{0, -1, 0, 0, 0}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}},
      {{0, 0, 1, 0, 3}, {1, 0, 1, 0, 1}, {1, -1, 1, 0, 0}}, {{0, 0, -1, 0, 2}, {1, 0, 0, 0, 1}, {1, -1, 0, 0, 0}},
@@ -986,32 +1005,42 @@ __device__ const FvMem FV_MEM[3][6][3] = {
     {{{2, 1, 0, 0, 1}, {0, 1, 0, 0, 5}, {0, 1, 0, -1, 4}}, {{2, -1, 0, 0, 0}, {0, 0, 0, 0, 5}, {0, 0, 0, -1, 4}},
      {{2, 0, 1, 0, 3}, {1, 0, 1, 0, 5}, {1, 0, 1, -1, 4}}, {{2, 0, -1, 0, 2}, {1, 0, 0, 0, 5}, {1, 0, 0, -1, 4}},
      {{2, 0, 0, 1, 5}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}, {{2, 0, 0, -1, 4}, {-1, 0, 0, 0, 0}, {-1, 0, 0, 0, 0}}}};
-// which of the six factors of face (comp, p) are non-zero, as a bit mask (order: right, left, top, bottom, front, back)
+// the six control volumes behind the factors of face (COMP, p), order: right, left, top, bottom, front, back
+template <int COMP>
+__device__ __forceinline__ void d_vol6(size_t p, long sy, long sz, const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW,
+                                       float &a0, float &a1, float &a2, float &a3, float &a4, float &a5) {
+    if (COMP == 0) { a0 = vC[p]; a1 = vC[p - 1]; a2 = vEW[p + sy]; a3 = vEW[p]; a4 = vEV[p + sz]; a5 = vEV[p]; }
+    else if (COMP == 1) { a0 = vEW[p + 1]; a1 = vEW[p]; a2 = vC[p]; a3 = vC[p - sy]; a4 = vEU[p + sz]; a5 = vEU[p]; }
+    else { a0 = vEV[p + 1]; a1 = vEV[p]; a2 = vEU[p + sy]; a3 = vEU[p]; a4 = vC[p]; a5 = vC[p - sz]; }
+}
+// which of the six factors of face (COMP, p) are non-zero, as a bit mask.  A factor is a viscosity x one of the six volumes: with ONE viscosity the volumes decide, the factors
+// themselves are only formed for a viscosity field (which may vanish on an edge).
+template <int COMP>
+__device__ __forceinline__ unsigned d_factor_mask_t(size_t p, const Lay &L, const float *__restrict__ nu, const float *__restrict__ vC, const float *__restrict__ vEU,
+                                                    const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field) {
+    const long sy = L.sy, sz = L.sz;
+    float a0, a1, a2, a3, a4, a5;
+    if (!field) d_vol6<COMP>(p, sy, sz, vC, vEU, vEV, vEW, a0, a1, a2, a3, a4, a5);
+    else {
+        const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, p, sy, sz, factor);
+        if (COMP == 0) { a0 = F.U[0]; a1 = F.U[1]; a2 = F.U[2]; a3 = F.U[3]; a4 = F.U[4]; a5 = F.U[5]; }
+        else if (COMP == 1) { a0 = F.V[0]; a1 = F.V[1]; a2 = F.V[2]; a3 = F.V[3]; a4 = F.V[4]; a5 = F.V[5]; }
+        else { a0 = F.W[0]; a1 = F.W[1]; a2 = F.W[2]; a3 = F.W[3]; a4 = F.W[4]; a5 = F.W[5]; }
+    }
+    return (a0 != 0.0f ? 1u : 0u) | (a1 != 0.0f ? 2u : 0u) | (a2 != 0.0f ? 4u : 0u) | (a3 != 0.0f ? 8u : 0u) | (a4 != 0.0f ? 16u : 0u) | (a5 != 0.0f ? 32u : 0u);
+}
 __device__ __forceinline__ unsigned d_factor_mask(int comp, size_t p, const Lay &L, const float *__restrict__ nu, const float *__restrict__ vC, const float *__restrict__ vEU,
                                                   const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field) {
-    const long sy = L.sy, sz = L.sz;
-    unsigned m = 0u;
-    if (!field) {
-        float v6[6];
-        if (comp == 0) { v6[0] = vC[p]; v6[1] = vC[p - 1]; v6[2] = vEW[p + sy]; v6[3] = vEW[p]; v6[4] = vEV[p + sz]; v6[5] = vEV[p]; }
-        else if (comp == 1) { v6[0] = vEW[p + 1]; v6[1] = vEW[p]; v6[2] = vC[p]; v6[3] = vC[p - sy]; v6[4] = vEU[p + sz]; v6[5] = vEU[p]; }
-        else { v6[0] = vEV[p + 1]; v6[1] = vEV[p]; v6[2] = vEU[p + sy]; v6[3] = vEU[p]; v6[4] = vC[p]; v6[5] = vC[p - sz]; }
-#pragma unroll
-        for (int t = 0; t < 6; t++) if (v6[t] > 0.0f) m |= 1u << t;
-        return m;
-    }
-    const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, p, sy, sz, factor);
-    const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
-#pragma unroll
-    for (int t = 0; t < 6; t++) if (f[t] != 0.0f) m |= 1u << t;
-    return m;
+    return comp == 0 ? d_factor_mask_t<0>(p, L, nu, vC, vEU, vEV, vEW, factor, field) : (comp == 1 ? d_factor_mask_t<1>(p, L, nu, vC, vEU, vEV, vEW, factor, field)
+                                                                                                   : d_factor_mask_t<2>(p, L, nu, vC, vEU, vEV, vEW, factor, field));
 }
+__device__ __forceinline__ bool d_is_row_face_p(const uint8_t *__restrict__ stc, int comp, size_t p, int i, int j, int k, const Lay &L) { return d_row_range(comp, i, j, k, L) && stc[p] == ST_FLUID; }
+__device__ __forceinline__ bool d_is_row_face(int comp, size_t p, int i, int j, int k, const Lay &L, const uint8_t *const st[3]) { return d_row_range(comp, i, j, k, L) && st[comp][p] == ST_FLUID; }
 // FLOATING rows.  A row without own volume is tied to the rest of the system through the rows it shares a stress term with; a connected set of such rows none of which shares a
 // term with a row that HAS own volume, or with a solid face, is a system of its own -- singular in the exact operator (any constant solves it), zero right-hand side, and in the
 // reference's operator held at exactly 0 by the rounding defect of a diagonal (or, where that vanishes, by PCG's zero start): holdout draw 35 of round 6's sweep, three W faces in a
 // column above a speck of liquid smaller than a control volume.  The multigrid's prolongation leaks a value into such rows that nothing in the iteration can take out again (1e-1 of
 // max|u| on 159 faces there, status 0).  "Grounded at once": the row shares a term with a solid face or with a row that has own volume.
-__device__ __forceinline__ bool d_is_row_face(int comp, size_t p, int i, int j, int k, const Lay &L, const uint8_t *const st[3]) { return d_row_range(comp, i, j, k, L) && st[comp][p] == ST_FLUID; }
 __device__ __forceinline__ bool d_grounded_at_once(int comp, size_t p, int i, int j, int k, unsigned fm, const Lay &L, const uint8_t *const st[3], const float *const vol[3]) {
     const long sy = L.sy, sz = L.sz;
     for (int t = 0; t < 6; t++) {
@@ -1026,30 +1055,88 @@ __device__ __forceinline__ bool d_grounded_at_once(int comp, size_t p, int i, in
     }
     return false;
 }
-// is face (comp, p) a row without own volume whose only non-zero factor sits in slot `slot_out`?  A factor is a viscosity x one of six control volumes (order: right, left,
-// top, bottom, front, back): the volumes are counted first -- with ONE viscosity that decides --, the factors are only formed for a viscosity field (which may vanish on an edge).
-__device__ __forceinline__ bool d_single_factor_row(int comp, size_t p, int i, int j, int k, const Lay &L, const uint8_t *const st[3], const float *const vol[3], const float *__restrict__ nu,
-                                                    const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field,
-                                                    int &slot_out) {
-    if (!d_row_range(comp, i, j, k, L) || st[comp][p] != ST_FLUID || vol[comp][p] != 0.0f) return false;
+// the same with everything known at compile time (the grid-sized kernel)
+template <int COMP>
+__device__ __forceinline__ bool d_grounded_at_once_t(size_t p, int i, int j, int k, unsigned fm, const Lay &L, const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV,
+                                                     const uint8_t *__restrict__ stW, const float *__restrict__ volU, const float *__restrict__ volV, const float *__restrict__ volW) {
     const long sy = L.sy, sz = L.sz;
-    float v6[6];
-    if (comp == 0) { v6[0] = vC[p]; v6[1] = vC[p - 1]; v6[2] = vEW[p + sy]; v6[3] = vEW[p]; v6[4] = vEV[p + sz]; v6[5] = vEV[p]; }
-    else if (comp == 1) { v6[0] = vEW[p + 1]; v6[1] = vEW[p]; v6[2] = vC[p]; v6[3] = vC[p - sy]; v6[4] = vEU[p + sz]; v6[5] = vEU[p]; }
-    else { v6[0] = vEV[p + 1]; v6[1] = vEV[p]; v6[2] = vEU[p + sy]; v6[3] = vEU[p]; v6[4] = vC[p]; v6[5] = vC[p - sz]; }
-    int nz = 0, at = -1;
+    bool g = false;
 #pragma unroll
-    for (int t = 0; t < 6; t++) if (v6[t] > 0.0f) { nz++; at = t; }
-    slot_out = at;
-    if (nz == 0) return false;
-    if (!field) return nz == 1;
-    const RefRowFactors F = d_ref_row_factors(nu, vC, vEU, vEV, vEW, p, sy, sz, factor);
-    const float *f = comp == 0 ? F.U : (comp == 1 ? F.V : F.W);
-    nz = 0; at = -1;
+    for (int t = 0; t < 6; t++) {
 #pragma unroll
-    for (int t = 0; t < 6; t++) if (f[t] != 0.0f) { nz++; at = t; }
-    slot_out = at;
-    return nz == 1;
+        for (int m = 0; m < 3; m++) {
+            constexpr int ec = 0;
+            (void)ec;
+            const int mc = FV_MEMC[COMP][t][m].comp;
+            if (mc < 0) continue;
+            if (!((fm >> t) & 1u) || g) continue;
+            const uint8_t *stc = mc == 0 ? stU : (mc == 1 ? stV : stW);
+            const float *vc = mc == 0 ? volU : (mc == 1 ? volV : volW);
+            const size_t q = p + FV_MEMC[COMP][t][m].di + FV_MEMC[COMP][t][m].dj * sy + FV_MEMC[COMP][t][m].dk * sz;
+            const uint8_t sq = stc[q];
+            if (sq == ST_SOLID) g = true;
+            else if (sq == ST_FLUID && d_row_range(mc, i + FV_MEMC[COMP][t][m].di, j + FV_MEMC[COMP][t][m].dj, k + FV_MEMC[COMP][t][m].dk, L) && vc[q] > 0.0f) g = true;
+        }
+    }
+    return g;
+}
+// is face (MC, p) a row without own volume whose ONLY non-zero factor sits in slot SLOT?  (compile-time component and slot)
+template <int MC, int SLOT>
+__device__ __forceinline__ bool d_single_factor_at(size_t p, int i, int j, int k, const Lay &L, const uint8_t *__restrict__ stc, const float *__restrict__ volc, const float *__restrict__ nu,
+                                                   const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field) {
+    if (!d_row_range(MC, i, j, k, L) || stc[p] != ST_FLUID || volc[p] != 0.0f) return false;
+    return d_factor_mask_t<MC>(p, L, nu, vC, vEU, vEV, vEW, factor, field) == (1u << SLOT);
+}
+// one component of k_visc_singular_find
+template <int COMP>
+__device__ __forceinline__ void d_singular_find_comp(const Lay &L, size_t c, int i, int j, int k, const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV, const uint8_t *__restrict__ stW,
+                                                     const float *__restrict__ volU, const float *__restrict__ volV, const float *__restrict__ volW, const float *__restrict__ nu,
+                                                     const float *__restrict__ vC, const float *__restrict__ vEU, const float *__restrict__ vEV, const float *__restrict__ vEW, float factor, int field,
+                                                     unsigned long long *__restrict__ list, unsigned long long *__restrict__ flist) {
+    const uint8_t *stc = COMP == 0 ? stU : (COMP == 1 ? stV : stW);
+    const float *volc = COMP == 0 ? volU : (COMP == 1 ? volV : volW);
+    if (!d_row_range(COMP, i, j, k, L) || stc[c] != ST_FLUID || volc[c] != 0.0f) return;     // not a massless fluid face
+    const unsigned fm = d_factor_mask_t<COMP>(c, L, nu, vC, vEU, vEV, vEW, factor, field);
+    if (!fm) return;                                                                            // no volume around it: no row
+    const long sy = L.sy, sz = L.sz;
+    if (!d_grounded_at_once_t<COMP>(c, i, j, k, fm, L, stU, stV, stW, volU, volV, volW)) {      // a candidate for a floating set (k_visc_floating)
+        // (one atomic per wave: the second layer of a liquid's fringe is full of such rows -- thousands at 256^3 --, and that many atomics on one address took 250 us)
+        const unsigned long long act = __ballot(1);
+        const int lane = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z)) & 63;
+        const int leader = __ffsll((long long)act) - 1, rank = __popcll(act & ((1ull << lane) - 1ull));
+        unsigned long long base = 0ull;
+        if (lane == leader) base = atomicAdd(flist, (unsigned long long)__popcll(act));
+        base = __shfl(base, leader, 64);
+        const unsigned long long at = base + (unsigned long long)rank;
+        if (at < (unsigned long long)FV_FLOAT_CAP) flist[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)COMP;
+    }
+    if (fm & (fm - 1u)) return;                                                                 // more than one factor: not a row that can repeat another
+    bool later = false;   // is there such a row of the same cluster BEFORE this one in the reference's row order?
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+        if (fm != (1u << t)) continue;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            if (FV_MEMC[COMP][t][m].comp < 0) continue;
+            // (compile-time member: component, offset and slot fold to constants)
+#define FV_MEMBER_CHECK(MC_, SL_)                                                                                                                              \
+            if (FV_MEMC[COMP][t][m].comp == MC_ && FV_MEMC[COMP][t][m].slot == SL_ && !later) {                                                                 \
+                const size_t p = c + FV_MEMC[COMP][t][m].di + FV_MEMC[COMP][t][m].dj * sy + FV_MEMC[COMP][t][m].dk * sz;                                        \
+                if (d_single_factor_at<MC_, SL_>(p, i + FV_MEMC[COMP][t][m].di, j + FV_MEMC[COMP][t][m].dj, k + FV_MEMC[COMP][t][m].dk, L,                     \
+                                                 MC_ == 0 ? stU : (MC_ == 1 ? stV : stW), MC_ == 0 ? volU : (MC_ == 1 ? volV : volW), nu, vC, vEU, vEV, vEW, factor, field)) \
+                    later = MC_ < COMP || (MC_ == COMP && p < c);                                                                                               \
+            }
+            FV_MEMBER_CHECK(0, 0) FV_MEMBER_CHECK(0, 1) FV_MEMBER_CHECK(0, 2) FV_MEMBER_CHECK(0, 3) FV_MEMBER_CHECK(0, 4) FV_MEMBER_CHECK(0, 5)
+            FV_MEMBER_CHECK(1, 0) FV_MEMBER_CHECK(1, 1) FV_MEMBER_CHECK(1, 2) FV_MEMBER_CHECK(1, 3) FV_MEMBER_CHECK(1, 4) FV_MEMBER_CHECK(1, 5)
+            FV_MEMBER_CHECK(2, 0) FV_MEMBER_CHECK(2, 1) FV_MEMBER_CHECK(2, 2) FV_MEMBER_CHECK(2, 3) FV_MEMBER_CHECK(2, 4) FV_MEMBER_CHECK(2, 5)
+#undef FV_MEMBER_CHECK
+        }
+    }
+    if (!later) return;
+    const unsigned long long at = atomicAdd(list, 1ull);
+    if (at < (unsigned long long)FV_ELIM_CAP) list[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)COMP;
 }
 __global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, const uint8_t *__restrict__ stV, const uint8_t *__restrict__ stW, const float *__restrict__ volU,
                                      const float *__restrict__ volV, const float *__restrict__ volW, const float *__restrict__ nu, const float *__restrict__ vC,
@@ -1058,38 +1145,9 @@ __global__ void k_visc_singular_find(Lay L, const uint8_t *__restrict__ stU, con
     IJK_OR_RETURN(L);
     const long sy = L.sy, sz = L.sz;
     if (!(band[c] || band[c - 1] || band[c + 1] || band[c - sy] || band[c + sy] || band[c - sz] || band[c + sz])) return;   // (no volume near: no row, k_visc_setup)
-    const uint8_t *const st[3] = {stU, stV, stW};
-    const float *const vol[3] = {volU, volV, volW};
-    // the other faces that carry the same factor, per (component, slot): up to three of (component, di, dj, dk, slot there)
-    //   U: 0 centre(c) -> U(+x) slot 1 | 1 centre(c - x) -> U(-x) 0 | 2 edgeW(c + y): U(+y) 3, V(+y) 1, V(-x + y) 0 | 3 edgeW(c): U(-y) 2, V(c) 1, V(-x) 0
-    //      4 edgeV(c + z): U(+z) 5, W(+z) 1, W(-x + z) 0 | 5 edgeV(c): U(-z) 4, W(c) 1, W(-x) 0
-    //   V: 0 edgeW(c + x): V(+x) 1, U(+x) 3, U(+x - y) 2 | 1 edgeW(c): V(-x) 0, U(c) 3, U(-y) 2 | 2 centre(c) -> V(+y) 3 | 3 centre(c - y) -> V(-y) 2
-    //      4 edgeU(c + z): V(+z) 5, W(+z) 3, W(-y + z) 2 | 5 edgeU(c): V(-z) 4, W(c) 3, W(-y) 2
-    //   W: 0 edgeV(c + x): W(+x) 1, U(+x) 5, U(+x - z) 4 | 1 edgeV(c): W(-x) 0, U(c) 5, U(-z) 4 | 2 edgeU(c + y): W(+y) 3, V(+y) 5, V(+y - z) 4 | 3 edgeU(c): W(-y) 2, V(c) 5, V(-z) 4
-    //      4 centre(c) -> W(+z) 5 | 5 centre(c - z) -> W(-z) 4
-    for (int comp = 0; comp < 3; comp++) {
-        if (d_is_row_face(comp, c, i, j, k, L, st) && vol[comp][c] == 0.0f) {   // a massless row that shares no term with mass or a wall: a candidate for a floating set (k_visc_floating)
-            const unsigned fm = d_factor_mask(comp, c, L, nu, vC, vEU, vEV, vEW, factor, field);
-            if (fm && !d_grounded_at_once(comp, c, i, j, k, fm, L, st, vol)) {
-                const unsigned long long at = atomicAdd(flist, 1ull);
-                if (at < (unsigned long long)FV_FLOAT_CAP) flist[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)comp;
-            }
-        }
-        int slot;
-        if (!d_single_factor_row(comp, c, i, j, k, L, st, vol, nu, vC, vEU, vEV, vEW, factor, field, slot)) continue;
-        bool later = false;   // is there such a row of the same cluster BEFORE this one in the reference's row order?
-        for (int m = 0; m < 3 && !later; m++) {
-            const FvMem e = FV_MEM[comp][slot][m];
-            if (e.comp < 0) continue;
-            const size_t p = c + e.di + e.dj * sy + e.dk * sz;
-            int s2;
-            if (!d_single_factor_row(e.comp, p, i + e.di, j + e.dj, k + e.dk, L, st, vol, nu, vC, vEU, vEV, vEW, factor, field, s2) || s2 != e.slot) continue;
-            later = e.comp < comp || (e.comp == comp && p < c);
-        }
-        if (!later) continue;
-        const unsigned long long at = atomicAdd(list, 1ull);
-        if (at < (unsigned long long)FV_ELIM_CAP) list[1 + at] = ((unsigned long long)c << 2) | (unsigned long long)comp;
-    }
+    d_singular_find_comp<0>(L, c, i, j, k, stU, stV, stW, volU, volV, volW, nu, vC, vEU, vEV, vEW, factor, field, list, flist);
+    d_singular_find_comp<1>(L, c, i, j, k, stU, stV, stW, volU, volV, volW, nu, vC, vEU, vEV, vEW, factor, field, list, flist);
+    d_singular_find_comp<2>(L, c, i, j, k, stU, stV, stW, volU, volV, volW, nu, vC, vEU, vEV, vEW, factor, field, list, flist);
 }
 // One workgroup over the candidates (massless rows that share no term with mass or a wall): a candidate becomes grounded once a row it shares a term with is -- a massless row
 // grounded at once (recomputed here), or a candidate grounded in an earlier round (marks: one byte per index, bits 0-2, cleared again at the end) --; rounds until nothing changes.

@@ -207,6 +207,7 @@ typedef struct flipv_debug_params {
     int viscosity_mg_packed_rows; /* coarse rows of the viscosity multigrid as the cycle reads them: 0 = chosen per solve (packed fp16 up to nu dt/dx^2 = 2e5), 1 = packed fp16, -1 = the fp32 grids */
     float stall_guard_ratio;     /* the stall guard of the PCG loops stops a loop whose max|r| exceeds this x the smallest it has reached (once that is within 100 x the tolerance); 0 = 16, and 1 000 in the viscosity solve of a viscosity FIELD (FLIPV_VERSION 6) */
     float viscosity_pair_lambda_floor; /* the pair correction's gain is 1 / max(lambda, this) per unit diagonal; 0 = 1e-5 */
+    int velocity_patience;       /* iterations the velocity criterion holds a loop whose residual has passed before it lets it end (flipv_solve_info.velocity_step tells what was left); 0 = 48 */
 } flipv_debug_params;
 
 typedef struct flipv_solve_info {

@@ -36,8 +36,9 @@ def run(i, reps=1, **prm):
 
 if __name__ == "__main__":
     from flipviscosity3d_amd import capi
-    for i in [int(a) for a in sys.argv[1:]] or [0, 7, 9, 22, 25, 35, 42, 45]:
-        run(i, reps=2)
-        run(i, viscosity_massless_polish=-1)
-        run(i, viscosity_preconditioner=capi.PRECOND_DIAGONAL, viscosity_max_iterations=20000)
-        run(i, viscosity_stage1_factor=1.0)
+    for i in [int(a) for a in sys.argv[1:]] or [7, 22, 25]:
+        run(i)
+        for pat in (200, 1000):
+            run(i, velocity_patience=pat, viscosity_max_iterations=5000)
+        run(i, viscosity_preconditioner=capi.PRECOND_MULTIGRID, viscosity_pair_correction=1)
+        run(i, viscosity_preconditioner=capi.PRECOND_MULTIGRID, viscosity_pair_correction=1, stall_guard_ratio=1000.0)
