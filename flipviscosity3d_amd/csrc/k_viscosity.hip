@@ -1704,6 +1704,9 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             sc.vel_tol = (lastLoop && !c->vMixed64) ? eta * umaxAll : 0.0;
             sc.vel_window = c->prm.viscosity_velocity_window > 0 ? c->prm.viscosity_velocity_window : 4;
             sc.vel_stall = c->prm.viscosity_velocity_stall_ratio > 0.0f ? (double)c->prm.viscosity_velocity_stall_ratio : 0.0;   // (off by default: flipv.h)
+            // (how long the criterion may hold a loop whose residual has passed: 48 iterations, PcgScal::vel_patience.  A longer patience for the cheap diagonal loop was scanned on the
+            // three low-viscosity misses of round 6's second holdout sweep and on the 256^3 bunny at nu = 1e-3: 72 / 100 / 140 / 200 move the misses up and down without order -- 7.4e-4,
+            // 1.8e-4, 1.8e-4, 5.7e-4, 1.7e-5 on one draw -- and cost 6 / 16 / 22 / 30 % of that scene's substep: not a lever.  profiles/r6/patience_scan.log; flipv_debug_params.velocity_patience)
         }
         // (Stop test of every stage: the reference's own, max|r| <= tol (pcgsolver.h:259-272); two further norms were tried and dropped: HISTORY.md, same section, E.)
         conv = -1;

@@ -36,9 +36,7 @@ def run(i, reps=1, **prm):
 
 if __name__ == "__main__":
     from flipviscosity3d_amd import capi
-    for i in [int(a) for a in sys.argv[1:]] or [7, 22, 25]:
-        run(i)
-        for pat in (200, 1000):
-            run(i, velocity_patience=pat, viscosity_max_iterations=5000)
+    for i in [int(a) for a in sys.argv[1:]] or [7, 22, 25, 1, 3, 28, 36, 37, 39, 44]:
+        run(i, viscosity_preconditioner=capi.PRECOND_MULTIGRID, viscosity_pair_correction=1, stall_guard_ratio=1000.0, reps=3 if i in (7, 22, 25) else 1)
         run(i, viscosity_preconditioner=capi.PRECOND_MULTIGRID, viscosity_pair_correction=1)
-        run(i, viscosity_preconditioner=capi.PRECOND_MULTIGRID, viscosity_pair_correction=1, stall_guard_ratio=1000.0)
+        run(i, viscosity_preconditioner=capi.PRECOND_MULTIGRID)
