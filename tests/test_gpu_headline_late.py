@@ -73,7 +73,10 @@ def probe_error(g, uvw):
 
 
 def load(name):
+    # the fixture cut at 1e-13 where that run has finished, else the one at 1e-10 from the same state (make_golden.py: ..._tol10)
     path = os.path.join(GOLDEN, name + ".npz")
+    if not os.path.exists(path):
+        path = os.path.join(GOLDEN, name + "_tol10.npz")
     if not os.path.exists(path):
         pytest.skip("fixture %s not built (make_golden.py K: hours of one core)" % name)
     g = np.load(path)
@@ -107,9 +110,9 @@ def test_headline_late_state_default_parameters_against_the_reference(name):
     strict, st_s, _ = gpu(viscosity_stage1_factor=1.0)
     err_s, beyond_s, _ = probe_error(g, strict)
     v = st["viscosity"]
-    print("%s (%d probe faces; the reference at 1e-13: %d iterations, at its defaults %d iterations and %.2e from that on %d faces beyond 1e-4):\n"
+    print("%s (%d probe faces; the reference at %g: %d iterations, at its defaults %d iterations and %.2e from that on %d faces beyond 1e-4):\n"
           "   GPU default %.2e [%d probes beyond 1e-5] in %d viscosity iterations (status %d, velocity step %.1e, %d rows eliminated) | round 4's rule %.2e [%d] in %d | stage 1 to 1e-6 %.2e [%d] in %d" % (
-              name, n, int(g["visc_iters"]), int(g["defaults_visc_iters"]), float(g["defaults_vs_converged"]), int(g["defaults_faces_beyond_1e-4"]),
+              name, n, float(g["vtol"]), int(g["visc_iters"]), int(g["defaults_visc_iters"]), float(g["defaults_vs_converged"]), int(g["defaults_faces_beyond_1e-4"]),
               err, beyond, v["iterations"], v["status"], v["velocity_step"], v["eliminated_rows"], err_old, beyond_old, st_old["viscosity"]["iterations"], err_s, beyond_s, st_s["viscosity"]["iterations"]))
     assert v["status"] == 0 and st["pressure"]["status"] == 0, st
     assert err <= VEL_TOL, err
