@@ -180,6 +180,27 @@ def test_late_state_128_against_the_reference_golden():
     assert err <= VEL_TOL, err
 
 
+@pytest.mark.parametrize("dims", [(1, 1, 2), (2, 2, 2)])
+def test_splash_state_on_blocks(oracle, dims):
+    """the 64^3 splash state (nu = 5 after 18 substeps) -- the case the massless-cluster solve exists for -- on 1 x 1 x 2 and 2 x 2 x 2 blocks, whose cut planes
+    (k = 32; i, j, k = 32) pass through the splash.  Until round 6 a block context skipped every cluster within one entry of ANY face of its owned box, the domain's walls included
+    (ADVICE r5); now only towards sides that have a neighbouring rank.  NO parameter set: <= 1e-4 against the oracle at 1e-13, every rank the same solve."""
+    from test_gpu_multirank import assemble, run_ranks
+    from test_gpu_multirank_default import assert_same_solve_on_every_rank, make_blocks
+    N, nu = 64, 5.0
+    dx, solid, P = late_state(oracle, "bunny", N, nu, 18)
+    conv, _ = converged_and_default_reference(oracle, N, dx, solid, nu, P)["converged"]
+    ctxs = make_blocks(N, dx, solid, P, nu, dims)
+    sts = run_ranks(ctxs, lambda r, c: c.substep(0.01))
+    assert_same_solve_on_every_rank(sts)
+    err = rel_maxnorm3([assemble(ctxs, n) for n in "UVW"], conv)
+    v = sts[0]["viscosity"]
+    print("splash state on %s blocks: %.2e in %d viscosity iterations, status %d, %d rows eliminated on rank 0" % (dims, err, v["iterations"], v["status"], v["eliminated_rows"]))
+    assert v["status"] == 0 and err <= VEL_TOL, (err, v)
+    for c in ctxs:
+        c.close()
+
+
 def test_close_chains():
     for ch in _chains.values():
         ch["o"].close()
