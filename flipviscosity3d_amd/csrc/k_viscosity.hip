@@ -1352,26 +1352,31 @@ static int visc_gather_field_facts(flipv_context *c) {
     return FLIPV_OK;
 }
 
+// What one viscosity solve has decided before its set-up kernel runs (visc_plan), shared by the steps of viscosity_solve_t.
+struct ViscPlan {
+    int cap = 0;                       // iteration cap of the whole solve
+    PcgScal sc;                        // the loops' scalars (views into ctx->d_scal), stop flag, guards
+    double *bmax = nullptr;            // device: max|rhs|, max|u| over the rows
+    bool fieldSolve = false;           // the viscosity is a FIELD: pairs' weak modes in the preconditioner, the wider stall guard
+    Lay R0, R1;                        // the liquid's range with margins 0 / 1
+    int fullVol = 0;
+    float factor = 0.0f;               // dt / dx^2 (viscositysolver.cpp:379-380)
+    int forcedLayout = 0;
+    bool brickOk = false, swzOk = false, mgPossible = false, mgPlanned = false;
+    int precNow = 0, refDiag = 1;
+    double stiffSolve = 0.0;           // nu_max dt / dx^2
+    bool stage1Early = false, predict = false;
+    double bnormAll = 0.0, umaxAll = 0.0, rowsAll = 0.0, fillLocal = 0.0;   // visc_layout_and_lists: max|rhs|, max|u|, rows over all ranks; the rank's row fill
+};
+// PLAN: scalars, what follows the viscosity field, the geometry of the system (face states, band, control volumes), which preconditioner, which operator, whether stage 1 stops early.
 template <typename T>
-static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info) {
-    const Lay &L = c->L;
-    flipv_solve_info li;
-    memset(&li, 0, sizeof(li));
-    c->commBytesSetup = c->commBytesIter = 0.0;
-    c->exchIter = c->allrIter = 0;
-    // (vPerRowFactors: a VARIABLE viscosity field -- the fp64 residual of the two-stage solve then forms the reference's rows with their own factors,
-    // visc_rows.h: d_ref_row_factors; k_bresidual on bricks, k_plane_residual_ref on the plane layouts)
-    if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
-        li.status = 3;
-        if (info) *info = li;
-        return FLIPV_OK;
-    }
-    const int cap = c->prm.viscosity_max_iterations;
+static int visc_plan(flipv_context *c, float dt, ViscPlan &P) {
+    P.cap = c->prm.viscosity_max_iterations;
+    const int cap = P.cap;
     int rc = fv_scal_reserve(c, cap);
     if (rc) return rc;
-    PcgScal sc;
-    double *bmax;
-    if ((rc = fv_pcg_reset(c, cap, false, &sc, &bmax, c->d_flags + 2))) return rc;   // (scalars, conv = -1, the row counter, the guard, the counters: one launch)
+    PcgScal &sc = P.sc;
+    if ((rc = fv_pcg_reset(c, cap, false, &sc, &P.bmax, c->d_flags + 2))) return rc;   // (scalars, conv = -1, the row counter, the guard, the counters: one launch)
     sc.tol_inclusive = 1;
     sc.tol = 0.0;
     // A viscosity FIELD (flipv_set_viscosity with values that differ; decided alike on every rank: visc_gather_field_facts) is where a few isolated small eigenvalues sit under
@@ -1380,28 +1385,31 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     // ended every correction stage of draw 9 after 10-40 iterations) and the pairs' weak modes in the preconditioner (k_visc_pairs_find).  With ONE viscosity both stay as they were:
     // the same pairs exist there (51 at 256^3 during the bunny's fall), resolving them costs 7 + 3 iterations per solve (58 against 48 in bench.py's window) and buys nothing the
     // velocity criterion and the cluster solve after the loop do not already deliver (profiles/r6/bench_ab.log).
-    const bool fieldSolve = c->vPerRowFactors != 0;
+    P.fieldSolve = c->vPerRowFactors != 0;
+    const bool fieldSolve = P.fieldSolve;
     sc.stall_ratio = c->prm.stall_guard_ratio > 0.0f ? (double)c->prm.stall_guard_ratio : (fieldSolve ? FV_STALL_RATIO_FIELD : FV_STALL_RATIO);
 
     // Everything up to the factors is evaluated redundantly on the halo planes a neighbour-owned row would need
     // (inputs: phi with a 4-plane halo, the replicated solid SDF), so the setup needs no exchange of its own.
     // The GEOMETRY of the system -- face states, band mask, the seven control-volume lattices: functions of the liquid SDF and the solid SDF alone (visc_geometry).
-    const Lay R0 = fv_range_liquid(c, 0, 4), R1 = fv_range_liquid(c, 1, 4);
-    const int fullVol = c->bandPrevValid ? 0 : 1;  // volumes and factors are stored only where the band is or was in the previous solve
+    P.R0 = fv_range_liquid(c, 0, 4); P.R1 = fv_range_liquid(c, 1, 4);
+    P.fullVol = c->bandPrevValid ? 0 : 1;  // volumes and factors are stored only where the band is or was in the previous solve
     if ((rc = visc_geometry(c, c->stream))) return rc;
     const float invdx = 1.0f / c->dx;
-    const float factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
-    c->vFactorNow = factor;
+    P.factor = dt * invdx * invdx;  // viscositysolver.cpp:379-380
+    c->vFactorNow = P.factor;
     // ---- which layout the solver's arrays take (flipv_internal.h: VLAYOUT_*).  Bricks on sparse liquids of a single-domain context, the
     // plain planes (with the swizzled own-index arrays under the 16-lane tile geometry) otherwise.  How sparse the liquid is is only known
     // after the set-up kernel has counted the rows, so the set-up runs in the previous solve's layout and is repeated on the rare solve
     // where the choice changes.
-    const int forcedLayout = c->prm.viscosity_layout;   // 0 auto, 1 plain, 2 plain / swizzled, 3 brick
-    const bool brickOk = c->prm.viscosity_lane_width != 2 && forcedLayout != 1 && forcedLayout != 2;   // (block contexts too: the halo exchange addresses either layout, flipv_comm.h: HaloArray::lay)
-    const bool swzOk = forcedLayout != 1;   // (also under the multigrid: its own kernels address diag / x / r / q / own volumes through sidx, its sweep vectors stay plain)
+    P.forcedLayout = c->prm.viscosity_layout;
+    const int forcedLayout = P.forcedLayout;   // 0 auto, 1 plain, 2 plain / swizzled, 3 brick
+    P.brickOk = c->prm.viscosity_lane_width != 2 && forcedLayout != 1 && forcedLayout != 2;   // (block contexts too: the halo exchange addresses either layout, flipv_comm.h: HaloArray::lay)
+    P.swzOk = forcedLayout != 1;   // (also under the multigrid: its own kernels address diag / x / r / q / own volumes through sidx, its sweep vectors stay plain)
     // the preconditioner of this solve (the multigrid needs fp32 vectors over a whole, single-rank index space)
-    const bool mgPossible = std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && !c->vNoMultigridOnce;   // (block contexts too: a rank-local hierarchy, k_viscosity_mg.hip)
-    const bool mgPlanned = mgPossible && (c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || c->vForceMultigridOnce || c->vMixed64 ||
+    P.mgPossible = std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && !c->vNoMultigridOnce;   // (block contexts too: a rank-local hierarchy, k_viscosity_mg.hip)
+    const bool mgPossible = P.mgPossible;
+    P.mgPlanned = mgPossible && (c->prm.viscosity_preconditioner == FLIPV_PRECOND_MULTIGRID || c->vForceMultigridOnce || c->vMixed64 ||
                                           (c->prm.viscosity_preconditioner == FLIPV_PRECOND_AUTO && fv_visc_auto_pick(c, dt)));
     if (mgPossible && c->prm.viscosity_preconditioner != FLIPV_PRECOND_DIAGONAL && !c->vmgState) {
         const int prc = fv_vmg_prepare(c);   // allocate the hierarchy now, whichever solve first uses it
@@ -1418,17 +1426,32 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         // lose 2: beyond 2e5 the cycle reads the fp32 grids.
         c->vmgPackedRows = c->prm.viscosity_mg_packed_rows ? (c->prm.viscosity_mg_packed_rows > 0 ? 1 : 0) : (stiff <= 2.0e5 ? 1 : 0);
     }
-    const int precNow = std::is_same<T, float>::value ? 0 : 1;
+    P.precNow = std::is_same<T, float>::value ? 0 : 1;
     // flipv_params.exact_viscosity_operator = 0 (default): the solve applies the reference's operator INCLUDING the rounding of its float
     // diagonal (d_ref_volume) -- at 256^3 the reference's converged answer is 7e-6 from this operator's and 1.5e-4 from the exact one's.
-    const int refDiag = c->prm.exact_viscosity_operator ? 0 : 1;
+    P.refDiag = c->prm.exact_viscosity_operator ? 0 : 1;
     // DEFECT PREDICTOR: stage 1 solves A x = b - E u_old (u_old = the row's incoming velocity) -- one step of the fixed point x <- A^-1 (b - E x) started from u_old instead of 0 --, only
     // where stage 1 stops early; the correction stage stays (skipping it was measured and misses the bar at nu dt/dx^2 = 1.2e5).  HISTORY.md, same section, B.
-    const double stiffSolve = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
-    const bool stage1Early = c->prm.viscosity_stage1_factor != 1.0f && stiffSolve <= (c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 1.0e6);
-    const bool predict = refDiag && mgPlanned && std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && c->prm.viscosity_defect_predictor >= 0 &&
+    P.stiffSolve = (double)c->viscosity_max_any * (double)dt / ((double)c->dx * (double)c->dx);
+    const double stiffSolve = P.stiffSolve;
+    P.stage1Early = c->prm.viscosity_stage1_factor != 1.0f && stiffSolve <= (c->prm.viscosity_two_stage_max_stiffness > 0.0f ? (double)c->prm.viscosity_two_stage_max_stiffness : 1.0e6);
+    const int refDiag = P.refDiag;
+    const bool mgPlanned = P.mgPlanned, stage1Early = P.stage1Early;
+    P.predict = refDiag && mgPlanned && std::is_same<T, float>::value && c->prm.viscosity_lane_width != 2 && c->prm.viscosity_defect_predictor >= 0 &&
                          stage1Early;
-    auto run_setup = [&](int layout, bool first) -> int {
+    (void)fieldSolve; (void)forcedLayout;
+    return FLIPV_OK;
+}
+// SET-UP in one layout: factors, the rows taken out of the system (k_visc_singular_find / k_visc_floating), diagonal + right-hand side + row mask (k_visc_setup), the massless
+// clusters and -- for a viscosity field under the multigrid -- the strongly coupled pairs listed; max|rhs|, max|u| and the counts read back.  Repeated on the rare solve whose layout changes.
+template <typename T>
+static int visc_run_setup(flipv_context *c, const ViscPlan &P, int layout, bool first) {
+    const Lay &L = c->L;
+    const Lay &R0 = P.R0, &R1 = P.R1;
+    const int fullVol = P.fullVol, precNow = P.precNow, refDiag = P.refDiag;
+    const float factor = P.factor;
+    const bool fieldSolve = P.fieldSolve, mgPlanned = P.mgPlanned, predict = P.predict;
+    double *const bmax = P.bmax;
         const bool brick = layout == VLAYOUT_BRICK;
         if (c->viscStateValid && (c->vLayout == VLAYOUT_BRICK) != brick) {
             int zr = visc_zero_solver_arrays(c);
@@ -1531,8 +1554,18 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
         if (c->prm.verbose && c->h_flags[11] > 0)
             fprintf(stderr, "viscosity solve %ld: %d rows repeat another row's equation (a singular cluster): held at 0 like the reference's iterate%s\n", c->viscSolves, c->h_flags[11],
                     c->h_flags[11] > FV_ELIM_CAP ? " -- MORE THAN THE LIST HOLDS, the rest stay rows" : "");
-        return FLIPV_OK;
-    };
+    return FLIPV_OK;
+}
+// LAYOUT AND LISTS: the set-up in the previous solve's layout, the facts every rank must decide alike from (ONE all-gather), the layout this solve takes -- bricks on sparse
+// liquids, the plane layouts otherwise (set-up repeated where the choice changes) --, the brick list or the tile / run lists.
+template <typename T>
+static int visc_layout_and_lists(flipv_context *c, ViscPlan &P) {
+    const Lay &L = c->L;
+    const Lay &R0 = P.R0;
+    const bool brickOk = P.brickOk, swzOk = P.swzOk;
+    const int forcedLayout = P.forcedLayout;
+    int rc;
+    auto run_setup = [&](int layout, bool first) -> int { return visc_run_setup<T>(c, P, layout, first); };
     const int rowlNow = c->prm.tile_rows == 16 || c->prm.tile_rows == 64 ? c->prm.tile_rows : c->tgV.rowl;
     int layoutTry = c->vLayout;
     if (!c->viscStateValid) layoutTry = brickOk ? VLAYOUT_BRICK : VLAYOUT_PLAIN;   // first solve: the reference's scenes are sparse
@@ -1580,6 +1613,67 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
             if ((rc = run_setup(c->vSwz ? VLAYOUT_PLAIN : VLAYOUT_SWZ, false))) return rc;
         }
     }
+    P.bnormAll = bnormAll; P.umaxAll = umaxAll; P.rowsAll = rowsAll; P.fillLocal = fillLocal;
+    return FLIPV_OK;
+}
+
+// APPLY (_applySolutionToVelocityField, viscositysolver.cpp:692-727): x (+ the fp64 accumulator) into U, V, W -- 0 off the rows --, the massless clusters solved apart
+// (k_visc_massless_polish), the velocities' halo.
+template <typename T>
+static int visc_apply_solution(flipv_context *c, const Lay &R0, bool brick, bool useAcc, int refinements, bool nontrivial, const PcgSys<T, 3> &v) {
+    const Lay &L = c->L;
+    int rc;
+    const size_t off = plane_off(L, R0.kb), cnt = (size_t)(R0.ke - R0.kb) * L.sz;
+    float *uvw[3] = {c->U, c->V, c->W};
+    for (int m = 0; m < 3; m++) {
+        if (brick) fv_brick_writeback<T>(c, R0, m, useAcc, uvw[m]);   // x (+ the fp64 accumulator refinements / replacements flushed it into)
+        else if (useAcc && refinements > 0) hipLaunchKernelGGL(k_plane_writeback<T>, GRID3(R0), 0, c->stream, R0, c->vSwz, (const T *)v.x[m], (const double *)c->vXacc[m], uvw[m]);
+        else if (c->vSwz) hipLaunchKernelGGL(k_unswizzle_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);
+        else if (c->pgrid[0] > 1 || c->pgrid[1] > 1) hipLaunchKernelGGL(k_box_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);   // only what the rank owns: its i / j halo holds the neighbours' velocities
+        else hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[m] + off, uvw[m] + off, cnt);
+    }
+    if (c->prm.verbose) HIPCHK(c, hipMemsetAsync(c->d_flags + 13, 0, sizeof(int), c->stream));   // (the count the verbose line below prints; the word is fv_build_runs' otherwise)
+    if (nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0)   // (the clusters the iteration leaves where fp32 cannot see them: k_visc_massless_polish)
+        hipLaunchKernelGGL(k_visc_massless_polish<false>, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
+                           (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
+                           c->vFactorNow, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, c->prm.verbose ? c->d_flags + 13 : (int *)nullptr, (uint8_t *)nullptr, c->LB);   // (the list k_visc_massless_find made before the solve)
+    if (c->prm.verbose && nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {
+        int np = 0;
+        HIPCHK(c, hipMemcpy(&np, c->d_flags + 13, sizeof(int), hipMemcpyDeviceToHost));   // (d_flags[13]: the run builder's second word, rewritten by every fv_build_runs)
+        fprintf(stderr, "viscosity solve %ld: %d rows of massless clusters solved apart\n", c->viscSolves, np);
+    }
+    const HaloArray uv[3] = {{c->U, 4}, {c->V, 4}, {c->W, 4}};
+    if ((rc = fv_halo_copy(c, uv, 3, 1))) return rc;  // the pressure rhs at plane k1-1 reads W(k1)
+    return FLIPV_OK;
+}
+
+template <typename T>
+static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info) {
+    const Lay &L = c->L;
+    flipv_solve_info li;
+    memset(&li, 0, sizeof(li));
+    c->commBytesSetup = c->commBytesIter = 0.0;
+    c->exchIter = c->allrIter = 0;
+    // (vPerRowFactors: a VARIABLE viscosity field -- the fp64 residual of the two-stage solve then forms the reference's rows with their own factors,
+    // visc_rows.h: d_ref_row_factors; k_bresidual on bricks, k_plane_residual_ref on the plane layouts)
+    if (!c->viscosity_nonzero_any) {  // fluidsimulation.cpp:171-184
+        li.status = 3;
+        if (info) *info = li;
+        return FLIPV_OK;
+    }
+    ViscPlan P;
+    int rc = visc_plan<T>(c, dt, P);
+    if (rc) return rc;
+    const int cap = P.cap;
+    PcgScal &sc = P.sc;
+    double *const bmax = P.bmax;
+    const bool fieldSolve = P.fieldSolve, mgPossible = P.mgPossible, mgPlanned = P.mgPlanned;
+    const Lay R0 = P.R0;
+    const int refDiag = P.refDiag;
+    const double stiffSolve = P.stiffSolve;
+    if ((rc = visc_layout_and_lists<T>(c, P))) return rc;
+    const double bnormAll = P.bnormAll, umaxAll = P.umaxAll, rowsAll = P.rowsAll;
+    const bool brick = c->vLayout == VLAYOUT_BRICK;
     PcgSys<T, 3> v = visc_sys<T>(c);
     const double bnorm = bnormAll;   // (a repeated set-up recomputes the rank's own maximum: the merged one stands)
     li.rhs_norm = bnorm;
@@ -1879,29 +1973,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     const bool accepted = success || defectLimited || ((iters == cap || stalled) && res < c->prm.viscosity_accept_tolerance);
     const bool complete = success && corrStatus <= 1;   // (a correction stage that ran out of budget, stalled or was taken back: the result is applied, the status says "not converged")
     li.status = success ? (iters == 0 ? 3 : (complete ? 0 : 1)) : (accepted ? 1 : 2);
-    if (accepted) {  // _applySolutionToVelocityField (viscositysolver.cpp:692-727): x is 0 off the rows
-        const size_t off = plane_off(L, R0.kb), cnt = (size_t)(R0.ke - R0.kb) * L.sz;
-        float *uvw[3] = {c->U, c->V, c->W};
-        for (int m = 0; m < 3; m++) {
-            if (brick) fv_brick_writeback<T>(c, R0, m, useAcc, uvw[m]);   // x (+ the fp64 accumulator refinements / replacements flushed it into)
-            else if (useAcc && refinements > 0) hipLaunchKernelGGL(k_plane_writeback<T>, GRID3(R0), 0, c->stream, R0, c->vSwz, (const T *)v.x[m], (const double *)c->vXacc[m], uvw[m]);
-            else if (c->vSwz) hipLaunchKernelGGL(k_unswizzle_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);
-            else if (c->pgrid[0] > 1 || c->pgrid[1] > 1) hipLaunchKernelGGL(k_box_to_f32<T>, GRID3(R0), 0, c->stream, R0, (const T *)v.x[m], uvw[m]);   // only what the rank owns: its i / j halo holds the neighbours' velocities
-            else hipLaunchKernelGGL(k_vec_to_f32<T>, dim3(2048), dim3(256), 0, c->stream, (const T *)v.x[m] + off, uvw[m] + off, cnt);
-        }
-        if (c->prm.verbose) HIPCHK(c, hipMemsetAsync(c->d_flags + 13, 0, sizeof(int), c->stream));   // (the count the verbose line below prints; the word is fv_build_runs' otherwise)
-        if (nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0)   // (the clusters the iteration leaves where fp32 cannot see them: k_visc_massless_polish)
-            hipLaunchKernelGGL(k_visc_massless_polish<false>, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
-                               (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
-                               c->vFactorNow, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, c->prm.verbose ? c->d_flags + 13 : (int *)nullptr, (uint8_t *)nullptr, c->LB);   // (the list k_visc_massless_find made before the solve)
-        if (c->prm.verbose && nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {
-            int np = 0;
-            HIPCHK(c, hipMemcpy(&np, c->d_flags + 13, sizeof(int), hipMemcpyDeviceToHost));   // (d_flags[13]: the run builder's second word, rewritten by every fv_build_runs)
-            fprintf(stderr, "viscosity solve %ld: %d rows of massless clusters solved apart\n", c->viscSolves, np);
-        }
-        const HaloArray uv[3] = {{c->U, 4}, {c->V, 4}, {c->W, 4}};
-        if ((rc = fv_halo_copy(c, uv, 3, 1))) return rc;  // the pressure rhs at plane k1-1 reads W(k1)
-    }
+    if (accepted && (rc = visc_apply_solution<T>(c, R0, brick, useAcc, refinements, nontrivial, v))) return rc;
     // the accumulator is zero between solves (its halo reads rely on it)
     if (useAcc && nontrivial && !brick && refinements > 0) plane_flush<T>(c, R0, 4);
     if (useAcc && nontrivial && brick && c->nBricks > 0) hipLaunchKernelGGL(k_brick_zero_f64, dim3(cdiv(c->nBricks, 4) < 2048 ? cdiv(c->nBricks, 4) : 2048), dim3(64, 4, 1), 0, c->stream, (const int *)c->brickList, c->nBricks, c->vXacc[0], c->vXacc[1], c->vXacc[2]);
