@@ -241,3 +241,50 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert len(lines) == 1, lines
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["sum"] == 3.0
+
+
+def _callback_worker(rank, world, port, q):
+    """the flipv_host_comm callbacks of capi.torch_distributed_callbacks, called the way libflipv's HostComm calls them (through the C function pointers), without a GPU"""
+    import ctypes as C
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flipviscosity3d_amd import capi
+        cb = capi.torch_distributed_callbacks(dist)
+        peer = 1 - rank
+        # one group of three operations towards the same peer (their order pairs them): sizes 40 / 0 / 8 bytes one way, 24 / 16 / 0 the other
+        ssz = [40, 0, 8] if rank == 0 else [24, 16, 0]
+        rsz = [24, 16, 0] if rank == 0 else [40, 0, 8]
+        sbuf = [np.full(max(n, 1), 10 * rank + m, np.uint8) for m, n in enumerate(ssz)]
+        rbuf = [np.zeros(max(n, 1), np.uint8) for n in rsz]
+        n = 3
+        rc = cb.exchange(None, n, (C.c_int * n)(peer, peer, peer), (C.c_void_p * n)(*[b.ctypes.data for b in sbuf]), (C.c_size_t * n)(*ssz),
+                         (C.c_void_p * n)(*[b.ctypes.data for b in rbuf]), (C.c_size_t * n)(*rsz))
+        ok = rc == 0 and all((rbuf[m][:rsz[m]] == 10 * peer + m).all() for m in range(n))
+        d = np.arange(5, dtype=np.float64) + rank
+        f = (np.arange(7, dtype=np.float32) + 1) * (rank + 1)
+        rc2 = cb.allreduce_sum_f64(None, d.ctypes.data_as(C.POINTER(C.c_double)), 5)
+        rc3 = cb.allreduce_sum_f32(None, f.ctypes.data_as(C.POINTER(C.c_float)), 7)
+        rc4 = cb.barrier(None)
+        q.put((rank, ok, rc2 == 0 and np.array_equal(d, 2 * np.arange(5.0) + 1), rc3 == 0 and np.array_equal(f, 3 * (np.arange(7, dtype=np.float32) + 1)), rc4 == 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_communicator_callbacks_over_gloo():
+    """flipv_host_comm (include/flipv.h) as bench.py --comm host and tests/test_gpu_multiprocess.py supply it: a group of sends / receives whose m-th operation towards a peer pairs
+    with that peer's m-th towards this rank (empty sides included), the two all-reduces, the barrier -- two processes over gloo, no GPU"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_callback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ok64, ok32, okb in got:
+        assert ok and ok64 and ok32 and okb, (rank, ok, ok64, ok32, okb)

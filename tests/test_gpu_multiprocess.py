@@ -34,8 +34,8 @@ def torchrun(nproc, script_args):
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
 
 
-@pytest.mark.parametrize("dims", [(1, 1, 2), (2, 2, 1)])
-def test_two_and_four_processes_on_one_device_run_the_single_domains_solve(tmp_path, dims):
+@pytest.mark.parametrize("dims", [(1, 1, 2), (2, 2, 1), (2, 2, 2)])      # (2 x 2 x 2: BASELINE configs[3]'s decomposition, eight processes on the one device)
+def test_two_four_and_eight_processes_on_one_device_run_the_single_domains_solve(tmp_path, dims):
     from flipviscosity3d_amd.capi import Context
     N, nsub = 64, 3
     world = dims[0] * dims[1] * dims[2]
