@@ -387,6 +387,6 @@ if __name__ == "__main__":
         if nm in only:
             late_state_big(nm, 256, *BUNNY, nu_, k_)
     # (fall-backs at 1e-10, should the runs at 1e-13 not finish inside a round: the same states)
-    for nm, nu_, k_ in (("bunny256_nu5_sub10", 5.0, 10), ("bunny256_nu5_sub25", 5.0, 25)):
+    for nm, nu_, k_ in (("bunny256_nu5_sub10", 5.0, 10), ("bunny256_nu5_sub25", 5.0, 25), ("bunny256_nu200_sub25", 200.0, 25)):
         if nm + "_tol10" in only:
             late_state_big(nm + "_tol10", 256, *BUNNY, nu_, k_, vtol=1e-10, state_name=nm)
