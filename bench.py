@@ -652,12 +652,11 @@ def dense_roofline(N, precision, reps=50, **extra):
                      "frac": gbs / HBM_PEAK_GBS, "swept_indices_per_launch": swept}
     out["viscosity_spmv"]["variant"] = "the diagonal-preconditioned loop's launch: reads the residual for the fused (r/d, q) as well (64 B per unit move, 52 are counted)"
     # the variant the multigrid-preconditioned loop launches (what AUTO runs on a stiff system): q = A p and p.q only, exactly the 52 B per unit
-    c.set_params(precision=precision, pressure_max_iterations=4, viscosity_max_iterations=4, check_every=4, beta_from_conjugacy=1, **extra)
-    ms, swept = c.bench_spmv(1, reps)
+    ms, swept = c.bench_spmv(2, reps)
     gbs = VISC_SPMV_BYTES_PER_INDEX * (vi["rows"] / 3.0) / (ms * 1e-3) / 1e9
     out["viscosity_spmv_multigrid_loop"] = {"avg_launch_us": ms * 1e3, "units_per_launch": vi["rows"] / 3.0, "bytes_per_unit": VISC_SPMV_BYTES_PER_INDEX, "achieved": gbs,
                                             "frac": gbs / HBM_PEAK_GBS, "swept_indices_per_launch": swept,
-                                            "variant": "no residual read (the multigrid loop needs p.q only; also flipv_params.beta_from_conjugacy = 1)"}
+                                            "variant": "flipv_bench_spmv(which = 2): the kernel the multigrid-preconditioned loop launches -- no residual read, p.q alone (EPI_SPMV_A)"}
     c.close()
     return out
 

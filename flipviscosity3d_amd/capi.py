@@ -577,7 +577,7 @@ class Context:
 
     def bench_spmv(self, which, reps=50):
         ms, cells = C.c_double(), C.c_double()
-        self._chk(self.L.flipv_bench_spmv(self.h, 0 if which in (0, "pressure") else 1, reps, C.byref(ms),
+        self._chk(self.L.flipv_bench_spmv(self.h, {0: 0, "pressure": 0, 1: 1, "viscosity": 1, 2: 2, "viscosity_mg": 2}[which], reps, C.byref(ms),
                                           C.byref(cells)), "flipv_bench_spmv")
         return ms.value, cells.value
 

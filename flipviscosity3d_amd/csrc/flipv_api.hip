@@ -972,12 +972,13 @@ extern "C" int flipv_synchronize(flipv_context *c) {
 }
 
 int fv_bench_pressure_spmv(flipv_context *c, int reps, double *ms, double *cells);
-int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cells);
+int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cells, int mgLoop);
 extern "C" int flipv_bench_spmv(flipv_context *c, int which, int reps, double *ms_out, double *cells_out) {
     ENTER(c);
     NOT_SETUP_ONLY(c);
     if (!ms_out || !cells_out || reps < 1) return FLIPV_ERR_INVALID;
-    return which == 0 ? fv_bench_pressure_spmv(c, reps, ms_out, cells_out) : fv_bench_viscosity_spmv(c, reps, ms_out, cells_out);
+    if (which < 0 || which > 2) return FLIPV_ERR_INVALID;
+    return which == 0 ? fv_bench_pressure_spmv(c, reps, ms_out, cells_out) : fv_bench_viscosity_spmv(c, reps, ms_out, cells_out, which == 2);
 }
 
 extern "C" int flipv_bench_copy(flipv_context *c, size_t bytes, int reps, double *gbps_out) {

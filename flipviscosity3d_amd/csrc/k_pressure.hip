@@ -407,6 +407,7 @@ static void scal_views_host(flipv_context *c, int cap, PcgScal *sc, double **ext
     sc->bstride = (int)fv_scal_stride(cap);
     sc->cap = cap;
     sc->noB = c->prm.beta_from_conjugacy ? 1 : 0;
+    sc->onlyA = 0;
     sc->itA = c->d_flags + 4;
     sc->itB = c->d_flags + 5;
     sc->best = c->d_scal_small + 49;

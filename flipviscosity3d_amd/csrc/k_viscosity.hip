@@ -513,24 +513,34 @@ static void launch_visc_spmv(flipv_context *c, const PcgScal &sc, int it, int fi
     const float *const vo[3] = {c->vOperatorExact ? c->vmU : c->vrU, c->vOperatorExact ? c->vmV : c->vrV, c->vOperatorExact ? c->vmW : c->vrW};
 #define VSPMV(N_, P_, R_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, N_, P_, R_>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L, \
                            vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
+#define VSPMV_A(N_, P_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv<T, N_, P_, false, EPI_SPMV_A>), dim3(nb), dim3(64, 4, 1), 0, c->stream, c->tileListV + first, count, c->tgV, c->L, \
+                           vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
     const bool rdot = forceRdot >= 0 ? forceRdot != 0 : (sc.conv ? !sc.noB : c->prm.beta_from_conjugacy == 0);   // benchmark launches (no scalars): the variant the solve would run
+    const bool onlyA = !rdot && sc.onlyA;   // the multigrid-preconditioned loop (fv_viscosity_pcg_mg; fv_bench_viscosity_spmv mode 2)
     if (NV == 4 && c->nRunsV > 0 && first == 0 && count == c->nActiveV) {   // k-marching over the run list (the whole system)
         int nbm = pcg_grid(c, c->nRunsV);
-        if (nbm > cap) nbm = cap;
+        const int capm = c->prm.viscosity_spmv_grid_cap > 0 ? cap : 256 * FLIPV_MARCH_OCC;
+        if (nbm > capm) nbm = capm;
 #define VMARCH(P_, R_, S_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv_march<T, P_, R_, S_>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsV, c->nRunsV, \
                            (const unsigned *)(c->vPred ? c->rmaskV : nullptr), c->tgV, c->L, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
         // streaming accesses on filled systems whose 52 bytes per index exceed the memory-side cache (pcg_common.h: ldvs)
         const bool stream = !c->vPred && (double)c->nActiveV * (256 * 4) * 52.0 > 256.0 * 1024 * 1024;
-        if (c->vPred) { if (rdot) VMARCH(true, true, false); else VMARCH(true, false, false); }
+#define VMARCH_A(P_, S_) GEO_RUN(c->tgV.rowl, hipLaunchKernelGGL((k_visc_spmv_march<T, P_, false, S_, true>), dim3(nbm), dim3(64, 4, 1), 0, c->stream, (const Run *)c->runsV, c->nRunsV, \
+                           (const unsigned *)(c->vPred ? c->rmaskV : nullptr), c->tgV, c->L, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, vv, sc, it))
+        if (onlyA) { if (c->vPred) VMARCH_A(true, false); else if (stream) VMARCH_A(false, true); else VMARCH_A(false, false); }
+        else if (c->vPred) { if (rdot) VMARCH(true, true, false); else VMARCH(true, false, false); }
         else if (stream) { if (rdot) VMARCH(false, true, true); else VMARCH(false, false, true); }
         else { if (rdot) VMARCH(false, true, false); else VMARCH(false, false, false); }
 #undef VMARCH
+#undef VMARCH_A
         if (timed) fv_ev_end(c);
         return;
     }
-    if (NV == 4 && c->vPred) { if (rdot) VSPMV(4, true, true); else VSPMV(4, true, false); }
+    if (onlyA) { if (NV == 4 && c->vPred) VSPMV_A(4, true); else VSPMV_A(NV, NV == 2); }
+    else if (NV == 4 && c->vPred) { if (rdot) VSPMV(4, true, true); else VSPMV(4, true, false); }
     else { if (rdot) VSPMV(NV, NV == 2, true); else VSPMV(NV, NV == 2, false); }
 #undef VSPMV
+#undef VSPMV_A
     if (timed) fv_ev_end(c);
 }
 
@@ -2022,7 +2032,7 @@ int fv_viscosity_solve(flipv_context *c, float dt, flipv_solve_info *info) {
     return viscosity_solve_t<float>(c, dt, info);
 }
 
-int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cells) {
+int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cells, int mgLoop) {   // mgLoop: the launch of the multigrid-preconditioned loop whatever the last solve ran (q = A p and p.q alone: EPI_SPMV_A)
     if (!c->viscosityReady || c->nActiveV <= 0) { c->err = "flipv_bench_spmv: run flipv_viscosity_solve first"; return FLIPV_ERR_INVALID; }
     hipEvent_t a, b;
     HIPCHK(c, hipEventCreate(&a));
@@ -2033,7 +2043,8 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
     memset(&sc, 0, sizeof(sc));
     if (c->vLayout == VLAYOUT_BRICK) {   // the brick kernel, in the variant the last solve's loop launched: with the fused (r, q) dots in the diagonal loop
         // (unless flipv_params.beta_from_conjugacy), q = A p and p.q alone in the multigrid loop
-        const bool rdot = c->prm.beta_from_conjugacy == 0 && c->vLastPrec != 2;
+        const bool rdot = c->prm.beta_from_conjugacy == 0 && c->vLastPrec != 2 && !mgLoop;
+        sc.onlyA = (mgLoop || c->vLastPrec == 2) ? 1 : 0;
         for (int w = 0; w < 3; w++) { if (c->viscosityPrec) fv_brick_spmv<double>(c, sc, 0, rdot); else fv_brick_spmv<float>(c, sc, 0, rdot); }
         HIPCHK(c, hipEventRecord(a, c->stream));
         for (int r = 0; r < reps; r++) { if (c->viscosityPrec) fv_brick_spmv<double>(c, sc, 0, rdot); else fv_brick_spmv<float>(c, sc, 0, rdot); }
@@ -2048,14 +2059,16 @@ int fv_bench_viscosity_spmv(flipv_context *c, int reps, double *ms, double *cell
         *cells = (double)c->nBricks * 64;
         return FLIPV_OK;
     }
+    const int fr = mgLoop ? 0 : -1;
+    sc.onlyA = mgLoop ? 1 : 0;
     for (int w = 0; w < 3; w++) {
-        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 4>(c, sc, 0, 0, c->nActiveV); }
-        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 2>(c, sc, 0, 0, c->nActiveV); }
+        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0, 0, c->nActiveV, nullptr, fr); else launch_visc_spmv<float, 4>(c, sc, 0, 0, c->nActiveV, nullptr, fr); }
+        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0, 0, c->nActiveV, nullptr, fr); else launch_visc_spmv<float, 2>(c, sc, 0, 0, c->nActiveV, nullptr, fr); }
     }
     HIPCHK(c, hipEventRecord(a, c->stream));
     for (int r = 0; r < reps; r++) {
-        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 4>(c, sc, 0, 0, c->nActiveV); }
-        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0, 0, c->nActiveV); else launch_visc_spmv<float, 2>(c, sc, 0, 0, c->nActiveV); }
+        if (c->vwV == 4) { if (c->viscosityPrec) launch_visc_spmv<double, 4>(c, sc, 0, 0, c->nActiveV, nullptr, fr); else launch_visc_spmv<float, 4>(c, sc, 0, 0, c->nActiveV, nullptr, fr); }
+        else { if (c->viscosityPrec) launch_visc_spmv<double, 2>(c, sc, 0, 0, c->nActiveV, nullptr, fr); else launch_visc_spmv<float, 2>(c, sc, 0, 0, c->nActiveV, nullptr, fr); }
     }
     HIPCHK(c, hipEventRecord(b, c->stream));
     HIPCHK(c, hipEventSynchronize(b));

@@ -205,11 +205,11 @@ __global__ __launch_bounds__(256) void k_bvisc_spmv(const int *__restrict__ bric
         }
     }
     if (EPI == EPI_JACOBI || EPI == EPI_RESIDUAL) return;
-    if (EPI == EPI_JACOBI_DOT) {   // (r, z) into sig(it + sig_shift)
+    if (EPI == EPI_JACOBI_DOT || EPI == EPI_SPMV_A) {   // (r, z) into sig(it + sig_shift) | p.q into a(it)
         const double rz = block_sum_256(da, lds);
         if (threadIdx.x == 0 && threadIdx.y == 0 && sc.conv) {
             const int sl = sc.my_slot();
-            if (rz != 0.0) atomicAdd(sc.sig(it + sig_shift) + sl, rz);
+            if (rz != 0.0) atomicAdd((EPI == EPI_SPMV_A ? sc.a(it) : sc.sig(it + sig_shift)) + sl, rz);
         }
         return;
     }
@@ -543,6 +543,7 @@ void fv_brick_spmv(flipv_context *c, const PcgScal &sc, int it, bool rdot, int f
     const dim3 g(fv_brick_grid(c, count, c->prm.viscosity_spmv_grid_cap > 0 ? c->prm.viscosity_spmv_grid_cap : 1280)), b(64, 4, 1);
     const int *list = (const int *)c->brickList + first;
     if (rdot) hipLaunchKernelGGL((k_bvisc_spmv<T, true, EPI_SPMV>), g, b, 0, c->stream, list, count, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
+    else if (sc.onlyA) hipLaunchKernelGGL((k_bvisc_spmv<T, false, EPI_SPMV_A>), g, b, 0, c->stream, list, count, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
     else hipLaunchKernelGGL((k_bvisc_spmv<T, false, EPI_SPMV>), g, b, 0, c->stream, list, count, vo[0], vo[1], vo[2], c->fC, c->fEU, c->fEV, c->fEW, v, sc, it, 0.0f, 0);
     if (timed) fv_ev_end(c);
 }

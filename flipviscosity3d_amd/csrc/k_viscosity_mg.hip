@@ -1710,7 +1710,8 @@ int fv_viscosity_pcg_mg(flipv_context *c, const PcgScal &sc_in, int cap, void (*
     } else HIPCHK(c, hipMemsetAsync(s->fineVecs, 0, s->fineVecBytes, c->stream));
     if (rc) return rc;
     PcgScal sc = sc_in;
-    sc.noB = 1;   // this loop needs p.q only: the SpMV variant that does not read the residual
+    sc.noB = 1;   // this loop needs p.q only: the SpMV variant that does not read the residual ...
+    sc.onlyA = 1; // ... and forms neither the diagonal nor (q, q/d) (EPI_SPMV_A, visc_rows.h)
     const bool brick = vmg_brick(c);
     const int nb = brick ? fv_brick_grid(c, c->nBricks, 2048) : pcg_grid(c, c->nActiveV);
     const dim3 blk(64, 4, 1);

@@ -133,6 +133,7 @@ struct PcgScal {
     int bstride;
     int cap;        // iteration cap
     int noB;        // 1: the SpMV did not form b = (r/d).q; the update uses b = a (conjugacy of successive directions)
+    int onlyA;      // 1: the loop's update reads a = p.q alone (the multigrid-preconditioned loop): its SpMV launches the EPI_SPMV_A variant (visc_rows.h)
     // Stall guard.  An fp32 solve whose attainable residual sits right at the tolerance can miss it by a hair, stagnate and --
     // thousands of iterations later, the recurrence residual having drifted from the true one -- blow up (seen on a thin-sheet
     // scene with the cap lifted: relative residual 1.4e-6 against a tolerance of 1e-6 around iteration 1 100, 1e+2 at 3 000).
@@ -239,6 +240,9 @@ __device__ __forceinline__ void block_sum3_256(double &a, double &b, double &c, 
 // x, s (search direction), q = A s and the residual r are stored in T (fp32 by default, fp64 with
 // flipv_params.precision = 1).  -DFLIPV_R64=1 keeps r in fp64 even for T = float (measured: no gain in attainable
 // accuracy once the SpMV is evaluated in difference form, 9 % slower).
+#ifndef FLIPV_MARCH_OCC
+#define FLIPV_MARCH_OCC 2   // blocks per CU of the k-marching viscosity SpMV (k_viscosity_geo.inc)
+#endif
 #ifndef FLIPV_R64
 #define FLIPV_R64 0
 #endif

@@ -20,7 +20,9 @@ __device__ __forceinline__ float d_ref_volume(float vol, float fR, float fL, flo
 //   1  y = x + omega (r - A x)/d            one damped-Jacobi sweep
 //   2  y = r - A x                          the residual that is restricted to the first coarse level
 //   3  as 1, and ta = this lane's share of (r, y)
-constexpr int EPI_SPMV = 0, EPI_JACOBI = 1, EPI_RESIDUAL = 2, EPI_JACOBI_DOT = 3;
+//   4  y = A x and ta = (x, y) ALONE: the multigrid-preconditioned loop's SpMV (its update needs p.q only -- no diagonal, no reciprocal, no (q, q/d): 591 -> 474 instructions
+//      per step of the marching kernel, which is issue-bound on filled boxes)
+constexpr int EPI_SPMV = 0, EPI_JACOBI = 1, EPI_RESIDUAL = 2, EPI_JACOBI_DOT = 3, EPI_SPMV_A = 4;
 template <typename T, int NV, bool RDOT, int EPI = EPI_SPMV>
 __device__ __forceinline__ void d_visc_rows(
     const Vec<float, NV> &MU, const Vec<float, NV> &MV, const Vec<float, NV> &MW, const Vec<float, NV> &C0, const Vec<float, NV> &Cjm,
@@ -53,6 +55,8 @@ __device__ __forceinline__ void d_visc_rows(
                 if (EPI == EPI_SPMV) {
                     const T yi = y * d_recip<T>(dg);
                     ta += uc * y; if (RDOT) tb += (T)RU.v[e] * yi; tc += y * yi;
+                } else if (EPI == EPI_SPMV_A) {
+                    ta += uc * y;
                 } else if (EPI == EPI_RESIDUAL) {
                     y = (T)RU.v[e] - y;
                 } else {
@@ -74,6 +78,8 @@ __device__ __forceinline__ void d_visc_rows(
                 if (EPI == EPI_SPMV) {
                     const T yi = y * d_recip<T>(dg);
                     ta += vc * y; if (RDOT) tb += (T)RV.v[e] * yi; tc += y * yi;
+                } else if (EPI == EPI_SPMV_A) {
+                    ta += vc * y;
                 } else if (EPI == EPI_RESIDUAL) {
                     y = (T)RV.v[e] - y;
                 } else {
@@ -95,6 +101,8 @@ __device__ __forceinline__ void d_visc_rows(
                 if (EPI == EPI_SPMV) {
                     const T yi = y * d_recip<T>(dg);
                     ta += wc * y; if (RDOT) tb += (T)RW.v[e] * yi; tc += y * yi;
+                } else if (EPI == EPI_SPMV_A) {
+                    ta += wc * y;
                 } else if (EPI == EPI_RESIDUAL) {
                     y = (T)RW.v[e] - y;
                 } else {

@@ -388,7 +388,8 @@ int flipv_kernel_stats_reset(flipv_context *ctx);
 int flipv_kernel_stats_get(flipv_context *ctx, flipv_kernel_stats *out);
 int flipv_synchronize(flipv_context *ctx);
 /* `reps` back-to-back launches of one SpMV kernel on the current system (after a solve), HIP-event timed.
- * which: 0 pressure, 1 viscosity.  ms_out = average per launch, cells_out = cells swept per launch. */
+ * which: 0 pressure, 1 viscosity (the variant the last solve's loop launched), 2 viscosity as the multigrid-preconditioned loop launches it (q = A p and p.q alone).
+ * ms_out = average per launch, cells_out = cells swept per launch. */
 int flipv_bench_spmv(flipv_context *ctx, int which, int reps, double *ms_out, double *cells_out);
 /* device-to-device copy bandwidth (attainable HBM peak): bytes moved (read+write) per second */
 int flipv_bench_copy(flipv_context *ctx, size_t bytes, int reps, double *gbps_out);

@@ -301,7 +301,8 @@ def test_per_row_factor_residual_equals_the_stored_factor_residual_where_the_fie
     """The fp64 residual that forms the reference's rows one by one (a variable viscosity field: k_bresidual with RefRowInputs on bricks, k_plane_residual_ref on
     the plane layouts) against the one that reads the stored edge factors: the viscosity field is uniform except for ONE node buried in the solid wall -- enough to
     switch the per-row path on, nowhere near a row -- so every factor is what the stored one is and the two runs must deliver the same velocities (the residual kernels
-    differ, the arithmetic does not: <= 2e-6; both layouts)."""
+    differ, the arithmetic does not; since round 6 a viscosity FIELD also switches the pairs' weak modes and the wider stall guard on, so the two runs take
+    different preconditioners to the same tolerance: <= 5e-6; both layouts)."""
     from flipviscosity3d_amd.capi import Context
     if scene.startswith("sparse"):
         N, nu0 = 64, 200.0
@@ -329,7 +330,7 @@ def test_per_row_factor_residual_equals_the_stored_factor_residual_where_the_fie
     den = max(float(np.abs(x).max()) for x in a)
     err = max(float(np.abs(x.astype(np.float64) - y).max()) for x, y in zip(a, b)) / den
     print("%s: stored factors %d iterations, per-row factors %d, velocity difference %.2e" % (scene, ia, ib, err))
-    assert abs(ia - ib) <= 3 and err <= 2e-6, (ia, ib, err)
+    assert abs(ia - ib) <= 3 and err <= 5e-6, (ia, ib, err)
 
 
 def test_viscosity_field_that_is_zero_on_part_of_the_liquid(oracle):
