@@ -500,7 +500,8 @@ def main():
         # the instantiation the PCG loop itself launches (the multigrid's fine-level sweeps are other instantiations of the same kernel)
         kvariant = None
         if last["viscosity"]["layout"] == 2:
-            kvariant = "k_bvisc_spmv<%s, %s, 0>" % ("float" if args.precision == 0 else "double", "false" if last["viscosity"]["preconditioner"] == 1 else "true")
+            # (the multigrid-preconditioned loop launches EPI_SPMV_A = 4: q = A p and p.q alone; the diagonal loop EPI_SPMV = 0 with the fused (r/d, q) and (q, q/d))
+            kvariant = "k_bvisc_spmv<%s, %s>" % ("float" if args.precision == 0 else "double", "false, 4" if last["viscosity"]["preconditioner"] == 1 else "true, 0")
         roof = {"kernel": kname, "bound": "hbm",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_us": avg_ms * 1e3, "launches": v_n, "units_per_launch": units, "bytes_per_unit": VISC_SPMV_BYTES_PER_INDEX,
