@@ -390,3 +390,5 @@ if __name__ == "__main__":
     for nm, nu_, k_ in (("bunny256_nu5_sub10", 5.0, 10), ("bunny256_nu5_sub25", 5.0, 25), ("bunny256_nu200_sub25", 200.0, 25)):
         if nm + "_tol10" in only:
             late_state_big(nm + "_tol10", 256, *BUNNY, nu_, k_, vtol=1e-10, state_name=nm)
+        if nm + "_tol8" in only:    # (where the run at 1e-10 has not ended after three hours of one core either)
+            late_state_big(nm + "_tol8", 256, *BUNNY, nu_, k_, vtol=1e-8, state_name=nm)

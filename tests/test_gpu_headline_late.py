@@ -73,10 +73,11 @@ def probe_error(g, uvw):
 
 
 def load(name):
-    # the fixture cut at 1e-13 where that run has finished, else the one at 1e-10 from the same state (make_golden.py: ..._tol10)
+    # the fixture cut at 1e-13 where that run has finished, else the one at 1e-10 / 1e-8 from the same state (make_golden.py: ..._tol10, ..._tol8; the tolerance is printed)
     path = os.path.join(GOLDEN, name + ".npz")
-    if not os.path.exists(path):
-        path = os.path.join(GOLDEN, name + "_tol10.npz")
+    for suffix in ("_tol10", "_tol8"):
+        if not os.path.exists(path):
+            path = os.path.join(GOLDEN, name + suffix + ".npz")
     if not os.path.exists(path):
         pytest.skip("fixture %s not built (make_golden.py K: hours of one core)" % name)
     g = np.load(path)

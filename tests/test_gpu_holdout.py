@@ -14,7 +14,7 @@ from helpers import GOLDEN, ROOT
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 pytestmark = pytest.mark.gpu
 HOLD = os.path.join(GOLDEN, "holdout")
-PASSING = [0, 6, 7, 8, 13, 15, 21, 23, 26, 29, 36, 39, 40]
+PASSING = [0, 6, 7, 8, 13, 15, 20, 21, 23, 26, 29, 30, 36, 39, 40]   # (20, 30: round 5's massless-cluster draws, fixtures committed in round 6 for the block test below)
 # Round 5's misses: draw 9 (honey 40^3, viscosity 1e-4 | 200 after 40 substeps: 0.2 ... 0.9 max|u|, status 1) and draw 11 (honey 40^3, 0 | 3 000 after 5 substeps: 2e-5 ... 8e-2 from run
 # to run, status 1).  What they were (round 6, tests/research/jump_proto.py on the oracle's dumped systems): (i) two rows that are the SAME equation -- the reference's
 # matrix is exactly singular, its MIC(0)-PCG holds the later row at 0 --, now taken out of the system the same way (flipv_solve_info.eliminated_rows); (ii) 23 (draw 9) / 64 (draw 11)
@@ -68,3 +68,38 @@ def test_holdout_viscosity_jump_draws_five_consecutive_runs(i):
         errs.append(err)
     print("draw %d, five runs: %s" % (i, " ".join("%.2e" % e for e in errs)))
     assert sorted(errs)[2] <= 1e-4 and max(errs) <= (3e-4 if i == 9 else 1e-4), errs
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 2), (2, 2, 2)])
+@pytest.mark.parametrize("i", [20, 30])
+def test_massless_cluster_draws_on_blocks(i, dims):
+    """the two draws the massless-cluster solve was written for (two bodies at 96^3, nu = 1.1 / 0.8, 5 / 40 substeps in: ONE face of a cluster the substep uses was
+    2.2e-4 / 3.8e-4 off in round 5's first sweep) on 1 x 1 x 2 and 2 x 2 x 2 blocks -- the cut planes at 48 pass through both bodies.  NO parameter set: <= 1e-4 on every face, every
+    rank the same solve."""
+    import holdout_sweep as H
+    from flipviscosity3d_amd import capi, partition
+    from test_gpu_multirank import assemble, run_ranks
+    from test_gpu_multirank_default import assert_same_solve_on_every_rank
+    d = [x for x in H.draws() if x["id"] == i][0]
+    z = np.load(os.path.join(HOLD, "draw_%02d.npz" % i))
+    I, J, K, dx, solid, P, g = H.build_scene(d["scene"], d["N"])
+    nu = H.viscosity_of(d["visc"], I, J, K, dx)
+    boxes = partition.block_boxes(I, J, K, dims)
+    ctxs = [capi.Context(I, J, K, dx, device=0, block=b) for b in boxes]
+    capi.comm_init_local(ctxs, dims)
+    for c, p in zip(ctxs, partition.split_particles_boxes(z["state"], dx, boxes, dims)):
+        c.set_solid_sdf(solid); c.set_viscosity(nu); c.set_gravity(*g)
+        c.particles = p
+    sts = run_ranks(ctxs, lambda r, c: c.substep(float(np.float32(d["dt"]))))
+    assert_same_solve_on_every_rank(sts)
+    den, err = float(z["den"]), 0.0
+    for n in "UVW":
+        a = assemble(ctxs, n).reshape(-1).astype(np.float64)
+        r = np.zeros_like(a)
+        r[z["idx_" + n]] = z["val_" + n]
+        err = max(err, float((np.abs(a - r) / den).max()))
+    v = sts[0]["viscosity"]
+    print("draw %d on %s blocks: %.2e in %d viscosity iterations, status %d" % (i, dims, err, v["iterations"], v["status"]))
+    for c in ctxs:
+        c.close()
+    assert v["status"] in (0, 3) and err <= 1e-4, (err, v)
