@@ -10,7 +10,7 @@ if [ "$mode" = build ]; then
     name=$1; flags=$2; shift 2
     mkdir -p $cs/build/variants/$name
     for f in $cs/*.hip; do
-      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -Wno-unused-function $flags -c $f -o $cs/build/variants/$name/$(basename $f .hip).o &
+      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -munsafe-fp-atomics -fno-slp-vectorize -Wno-unused-function $flags -c $f -o $cs/build/variants/$name/$(basename $f .hip).o &
     done
     wait
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $cs/build/variants/$name.so $cs/build/variants/$name/*.o -ldl -lpthread
