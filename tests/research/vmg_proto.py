@@ -143,8 +143,10 @@ def transfer(comp, ijk, dims, mode="lin"):
 
 class MG:
     def __init__(self, A, comp, ijk, dims, nu1=2, nu2=2, omega=0.6, min_dim=4, smoother="jacobi", cheb_deg=2, f32=False, mode="lin", coarse_sweeps=8,
-                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0, gamma_at=-1, omega_coarse=0.0, nu_deep=0, deep_from=2, skip=-1):
+                 cheb_lo=0.25, alpha=1.0, gamma=1, lam_its=20, nu_fine=0, l1=0.0, nu_coarse=0, additive=0, gamma_at=-1, omega_coarse=0.0, nu_deep=0, deep_from=2, skip=-1, papp="",
+                 papp_from=0):
         self.skip = skip
+        self.papp = papp   # "tri": the CYCLE interpolates trilinearly while the coarse operators stay the Galerkin products of `mode` (round 6: is the cheap half of the trilinear hierarchy worth anything?)
         self.lev = []
         self.nu1, self.nu2, self.omega, self.smoother, self.cheb_deg, self.coarse_sweeps, self.cheb_lo = nu1, nu2, omega, smoother, cheb_deg, coarse_sweeps, cheb_lo
         self.alpha, self.gamma, self.nu_fine, self.nu_coarse = alpha, gamma, nu_fine, nu_coarse
@@ -163,8 +165,28 @@ class MG:
             self.lev.append(dict(A=A, d=d, lam=lam))
             if max(dims) <= min_dim or A.shape[0] < 30:
                 break
+            comp_f, ijk_f, dims_f = comp, ijk, dims
             P, comp, ijk, dims = transfer(comp, ijk, dims, mode)
             self.lev[-1]["P"] = P
+            self.lev[-1]["Pa"] = P
+            if papp and len(self.lev) - 1 >= papp_from:
+                # the application transfer: `papp`'s weights, restricted to the coarse dofs the Galerkin hierarchy has, rows rescaled to their original sums
+                Pt, ct, it_, _ = transfer(comp_f, ijk_f, dims_f, papp)
+                stride = np.int64(4 * (max(dims) + 2))
+                key = lambda c_, q: ((c_.astype(np.int64) * stride + q[:, 2]) * stride + q[:, 1]) * stride + q[:, 0]
+                kg, kt = key(comp, ijk.astype(np.int64)), key(ct, it_.astype(np.int64))
+                order = np.argsort(kg); pos = np.searchsorted(kg[order], kt)
+                ok = (pos < len(kg)) & (kg[order][np.minimum(pos, len(kg) - 1)] == kt)
+                col = np.where(ok, order[np.minimum(pos, len(kg) - 1)], -1)
+                Pt = Pt.tocoo()
+                keep = col[Pt.col] >= 0
+                Pa = sp.csr_matrix((Pt.data[keep], (Pt.row[keep], col[Pt.col[keep]])), shape=P.shape)
+                rs_full = np.asarray(Pt.tocsr().sum(axis=1)).ravel(); rs = np.asarray(Pa.sum(axis=1)).ravel()
+                scale = np.where(rs > 0, rs_full / np.where(rs > 0, rs, 1.0), 0.0)
+                Pa = sp.diags(scale) @ Pa
+                self.lev[-1]["Pa"] = Pa.tocsr()
+                print("  level %d: application transfer %s: %.1f entries per fine row (Galerkin transfer %.1f), %d of %d of its coarse dofs exist" % (
+                    len(self.lev) - 1, papp, Pa.nnz / Pa.shape[0], P.nnz / P.shape[0], int(ok.sum()), len(kt)), flush=True)
             A = (P.T @ A @ P).tocsr()
             if f32:
                 A = A.astype(np.float32).astype(np.float64)
@@ -236,12 +258,12 @@ class MG:
             nu1 = nu2 = self.nu_deep
         x = self.smooth(l, None, b, nu1)
         r = b - L["A"] @ x
-        bc = L["P"].T @ r
+        bc = L["Pa"].T @ r
         xc = self.cycle(l + 1, bc)
         for _ in range((self.gamma if self.gamma_at in (-1, l) else 1) - 1):   # W-cycle: second visit, as a correction on the coarse level
             Ac = self.lev[l + 1]["A"]
             xc = xc + self.cycle(l + 1, bc - Ac @ xc)
-        x = x + self.alpha * (L["P"] @ xc)
+        x = x + self.alpha * (L["Pa"] @ xc)
         return self.smooth(l, x, b, nu2)
 
     def __call__(self, r):

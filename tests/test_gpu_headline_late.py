@@ -1,7 +1,7 @@
 """GPU (-m gpu): the HEADLINE configuration -- BASELINE configs[2], the 256^3 bunny drop -- in the states bench.py's timed window and a long run actually spend their time in,
 against the COMPILED REFERENCE (round 5 compared these states with the GPU's own tightened solve).
 
-tests/golden/bunny256_nu5_sub10 / _sub25 and bunny256_nu200_sub25 (tests/golden/make_golden.py K): the reference carried the scene at ITS defaults (dt = 0.01, viscosity
+tests/golden/bunny256_nu5_sub10 / _sub25 (and bunny256_nu200_sub25: the last test) (tests/golden/make_golden.py K): the reference carried the scene at ITS defaults (dt = 0.01, viscosity
 cap 700 -- at 256^3 every carried solve ends at the cap) through 10 substeps (mid-fall, inside the window bench.py times: substeps 5 ... 24) and 25 (the liquid on the container
 wall), and at nu = 200 (nu dt/dx^2 = 131 072) through 25; the particles it then holds are the state.  From the state ONE substep of the reference with its viscosity cap lifted and the
 tolerance at 1e-13: ~305 000 probe faces per component (300 000 seeded among the faces that carry a velocity, the 5 000 of largest |u|, every 4th face within one cell of the free
@@ -24,7 +24,7 @@ from test_oracle_compact_golden import build_host_scene
 pytestmark = pytest.mark.gpu
 BIG = os.path.join(GOLDEN, "_big")
 VEL_TOL = 1e-4
-NAMES = ["bunny256_nu5_sub10", "bunny256_nu5_sub25", "bunny256_nu200_sub25"]   # (a state at 35 substeps was carried too; three 113 MB states are what a gpurun snapshot of 512 MiB holds)
+NAMES = ["bunny256_nu5_sub10", "bunny256_nu5_sub25"]   # (a state at 35 substeps was carried too; three 113 MB states are what a gpurun snapshot of 512 MiB holds)
 
 
 def headline_state(g, name, P0, solid):
@@ -137,3 +137,25 @@ def test_headline_late_state_default_blocks_against_the_reference(name):
     assert v["status"] == 0 and err <= VEL_TOL, (err, v)
     for c in ctxs:
         c.close()
+
+
+def test_headline_size_at_nu_200_is_not_pinned_and_the_solve_says_so():
+    """nu = 200 at 256^3 (nu dt/dx^2 = 131 072), 25 substeps in: the compiled reference needs 15 148 iterations for 1e-8 from its own state (at its defaults it stops at the cap of
+    700, 0.82 max|u| from that), and 1e-8 is NOT converged in the velocities there: GPU runs at 6e-8 ... 2e-8 relative residual (stage 1 to 1e-6 under a lifted cap; 19 355 fp64
+    diagonal-PCG iterations) are 0.19 / 0.52 from the fixture and as far from each other (profiles/r6/nu200_256_late_probe.log); the reference's run at 1e-10 had not ended after
+    four hours of one core.  So this state pins nothing to 1e-4.  What IS asserted: the default solve does not claim what it has not got -- flipv_solve_info.status != 0 (a stage
+    short of its target inside the reference's cap) whenever it is beyond the bar against the best fixture there is -- and it is no further from that fixture than the reference at
+    its own defaults."""
+    from flipviscosity3d_amd.capi import Context
+    g, N, dx, solid, S = load("bunny256_nu200_sub25")
+    c = Context(N, N, N, dx)
+    c.set_solid_sdf(solid); c.set_viscosity(float(g["nu"]))
+    c.particles = S
+    st = c.substep(float(g["dt"]))
+    err, beyond, n = probe_error(g, [c.grid(k) for k in "UVW"])
+    c.close()
+    v = st["viscosity"]
+    print("bunny256_nu200_sub25 (the reference at %g: %d iterations; at its defaults %.2e from that): GPU default %.2e in %d viscosity iterations, status %d (correction stage %d), velocity step %.1e" % (
+        float(g["vtol"]), int(g["visc_iters"]), float(g["defaults_vs_converged"]), err, v["iterations"], v["status"], v["correction_status"], v["velocity_step"]))
+    assert err <= VEL_TOL or v["status"] != 0, (err, v)
+    assert err <= float(g["defaults_vs_converged"]), (err, float(g["defaults_vs_converged"]))
