@@ -95,7 +95,7 @@ class SolveInfo(C.Structure):
                 ("status", C.c_int), ("rows", C.c_int), ("active_tiles", C.c_int), ("total_tiles", C.c_int),
                 ("preconditioner", C.c_int), ("layout", C.c_int), ("refinements", C.c_int), ("defect_residual", C.c_double),
                 ("correction_iterations", C.c_int), ("comm_bytes_setup", C.c_double), ("comm_bytes_per_iteration", C.c_double), ("velocity_step", C.c_double),
-                ("halo_exchanges_per_iteration", C.c_int), ("allreduces_per_iteration", C.c_int), ("correction_status", C.c_int), ("eliminated_rows", C.c_int)]
+                ("halo_exchanges_per_iteration", C.c_int), ("allreduces_per_iteration", C.c_int), ("correction_status", C.c_int), ("eliminated_rows", C.c_int), ("massless_cluster_edges", C.c_int)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

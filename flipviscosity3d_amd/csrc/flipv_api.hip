@@ -345,6 +345,8 @@ extern "C" int flipv_destroy(flipv_context *c) {
     if (c->h_pub) (void)hipHostFree(c->h_pub);
     if (c->d_pubSeq) (void)hipFree(c->d_pubSeq);
     if (c->polishList) (void)hipFree(c->polishList);
+    if (c->polishRow) (void)hipFree(c->polishRow);
+    if (c->polishVal) (void)hipFree(c->polishVal);
     if (c->elimList) (void)hipFree(c->elimList);
     if (c->floatList) (void)hipFree(c->floatList);
     if (c->groundMark) (void)hipFree(c->groundMark - c->L.guard);

@@ -246,6 +246,9 @@ struct flipv_context {
     int vMixed64 = 0;           // the current viscosity solve is precision = FP64 under the multigrid: fp32 Krylov loops refined to the fp64 tolerance
     double vRowsAll = 0.0;      // rows of the current viscosity system over all ranks (viscosity_solve_t's all-gather)
     unsigned long long *polishList = nullptr;   // k_visc_massless_find's list of edges (k_viscosity.hip)
+    unsigned long long *polishRow = nullptr;    // k_visc_massless_polish<false>: (component << 62 | index) and value of up to four rows per listed edge, stored by k_visc_massless_write
+    float *polishVal = nullptr;
+    int nPolishEdges = 0;                       // edges listed before this solve (may exceed FV_POLISH_CAP: flipv_solve_info::massless_cluster_edges)
     unsigned long long *elimList = nullptr;     // k_visc_singular_find's list of faces (k_viscosity.hip)
     unsigned long long *floatList = nullptr;    // ... its list of massless rows not grounded at once, and the marks of k_visc_floating (one byte per index of the allocated box)
     uint8_t *groundMark = nullptr;

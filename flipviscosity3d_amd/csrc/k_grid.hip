@@ -427,7 +427,8 @@ struct PubDev { const int *src[6]; int words[6], at[6], n; };
 __global__ __launch_bounds__(64) void k_publish(PubDev j, int *__restrict__ host, int *__restrict__ seq) {
     for (int q = 0; q < j.n; q++)
         for (int w = (int)threadIdx.x; w < j.words[q]; w += 64) __hip_atomic_store(host + j.at[q] + w, j.src[q][w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();   // (every lane's stores have landed before lane 0 announces them)
+    __threadfence_system();   // (every lane's stores have landed before lane 0 announces them ...
+    __syncthreads();          //  ... and every lane has passed its fence: the block is one wave today, the barrier is what says so -- ADVICE r5)
     if (threadIdx.x == 0) {
         const int s = (int)((unsigned)*seq + 1u);
         *seq = s;
@@ -454,8 +455,12 @@ int fv_read_small(flipv_context *c, const ReadJob *jobs, int n) {
         c->pubUsed += jobs[q].words;
     }
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, j, c->d_pubMap, c->d_pubSeq);
+    if (hipGetLastError() != hipSuccess) {   // nothing was enqueued: the jobs are dropped and the sequence number stays where the device's is
+        c->pubPendingN -= n; c->pubUsed -= need;
+        c->err = "fv_read_small: the publish kernel did not launch";
+        return FLIPV_ERR_HIP;
+    }
     c->pubSeq = (int)((unsigned)c->pubSeq + 1u);
-    HIPCHK(c, hipGetLastError());
     return FLIPV_OK;
 }
 int fv_read_capture(flipv_context *c, const void *dev, int words) {
@@ -483,7 +488,13 @@ int fv_read_wait_seq(flipv_context *c, int want) {
 }
 int fv_read_wait(flipv_context *c) {
     const int rc = fv_read_wait_seq(c, c->pubSeq);
-    if (rc) return rc;
+    if (rc) {
+        // the pending jobs' host pointers are mostly the callers' stack locals: never copy into them after an error return; and take the sequence number the
+        // device actually reached, so that a later wait does not spin on a publication that was never made
+        c->pubPendingN = 0; c->pubUsed = 0;
+        if (hipStreamSynchronize(c->stream) == hipSuccess) c->pubSeq = __atomic_load_n(c->h_pub, __ATOMIC_ACQUIRE);
+        return rc;
+    }
     for (int q = 0; q < c->pubPendingN; q++)
         if (c->pubPending[q].host) memcpy(c->pubPending[q].host, c->h_pub + c->pubPending[q].at, (size_t)c->pubPending[q].words * 4);
     c->pubPendingN = 0;

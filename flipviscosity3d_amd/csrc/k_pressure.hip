@@ -162,10 +162,14 @@ __global__ __launch_bounds__(256) void k_pressure_spmv_sweep(TileGrid tg, Lay L,
     if (cnt > 0 && l < per * nk) {
         const int kz = l / per, rr = l - kz * per, ty2 = r0s + rr / ntx, tx = rr % ntx;
         const int i0 = tg.ox + tx * TW + lane * 4, j0 = tg.oy + ty2 * RPB + ((int)threadIdx.y * RG + rg) * 2, k = k0 + kz;
-        if (i0 < L.ox + L.PX && j0 + 1 < L.oy + L.PY) {   // inside the allocated box (whole rows of a wave at a time)
-        const bool lfirst = lane == 0 && i0 > 0, llast = lane == RL - 1 && i0 + 4 < L.I;
-        const size_t c0 = gidx(L, i0, j0, k), c1 = c0 + sy;
-        const bool own0 = i0 < L.I && j0 < L.J, own1 = i0 < L.I && j0 + 1 < L.J;   // rows / lanes that hold cells; the others load nothing (every coefficient towards them is zero)
+        // Lanes beyond the allocated box stay ACTIVE with `inbox` false -- they load and store nothing, their vectors are zero -- so that the lane shifts below never read a
+        // lane the branch has masked out (a lane inside the box never needs more than zeros from them: every coefficient towards an index without a cell is zero,
+        // the invariant of k_pressure_setup that this kernel and the march rely on -- diag, pi, pj, pk and s are exactly 0 wherever there is no cell).
+        const bool inbox = i0 < L.ox + L.PX && j0 + 1 < L.oy + L.PY;
+        {
+        const bool lfirst = inbox && lane == 0 && i0 > 0, llast = inbox && lane == RL - 1 && i0 + 4 < L.I;
+        const size_t c0 = inbox ? gidx(L, i0, j0, k) : 0, c1 = c0 + sy;
+        const bool own0 = inbox && i0 < L.I && j0 < L.J, own1 = inbox && i0 < L.I && j0 + 1 < L.J;   // rows / lanes that hold cells; the others load nothing (every coefficient towards them is zero)
         Vec<float, 4> dg0{}, dg1{}, ci0{}, ci1{}, cj0{}, cj1{}, cjm{}, ck0{}, ck1{}, ckm0{}, ckm1{};
         Vec<T, 4> s0{}, s1{}, sjm{}, sjp{}, skm0{}, skm1{}, skp0{}, skp1{};
         Vec<RT<T>, 4> r0{}, r1{};

@@ -882,7 +882,10 @@ template <bool MARK>
 __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float *__restrict__ nu, const float *__restrict__ volC, const float *__restrict__ volEU, const float *__restrict__ volEV,
                                        const float *__restrict__ volEW, const float *__restrict__ volU, const float *__restrict__ volV, const float *__restrict__ volW,
                                        uint8_t *__restrict__ rowmask, float *__restrict__ U, float *__restrict__ V, float *__restrict__ W, float factor, int inner,
-                                       const unsigned long long *__restrict__ list, int *__restrict__ count, uint8_t *__restrict__ maskB, Lay LB) {
+                                       const unsigned long long *__restrict__ list, int *__restrict__ count, uint8_t *__restrict__ maskB, Lay LB,
+                                       unsigned long long *__restrict__ outRow, float *__restrict__ outVal) {
+    // (solve pass: the clusters' values go to outRow / outVal -- four slots per listed edge, row = ~0 where unused -- and k_visc_massless_write stores them afterwards: every
+    // cluster is solved against the SAME velocities, whichever threads run first.  ADVICE r5: written in place, a cluster read neighbours another thread was replacing.)
     const long sy = L.sy, sz = L.sz;
     const float *const vol[3] = {volU, volV, volW};
     float *const X[3] = {U, V, W};
@@ -902,6 +905,7 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
         size_t mp[4];
         float mF[4][6], md[4];
         int n = 0;
+        if (!MARK) for (int r = 0; r < 4; r++) outRow[4 * item + r] = ~0ull;
         for (int q = 0; q < 4; q++) {
             const int comp = rc_[fam][q];
             const size_t p = c + ro[fam][q];
@@ -968,8 +972,19 @@ __global__ __launch_bounds__(64) void k_visc_massless_polish(Lay L, const float 
             for (int m = r + 1; m < n; m++) t -= A[r][m] * x[m];
             x[r] = t / A[r][r];
         }
-        for (int r = 0; r < n; r++) X[mc[r]][mp[r]] = (float)x[r];
+        for (int r = 0; r < n; r++) { outRow[4 * item + r] = ((unsigned long long)mc[r] << 62) | (unsigned long long)mp[r]; outVal[4 * item + r] = (float)x[r]; }
         if (count) atomicAdd(count, n);
+    }
+}
+// ... and the stores (a row that sits in two clusters takes the value of whichever is stored last: both were solved against the same snapshot)
+__global__ __launch_bounds__(256) void k_visc_massless_write(const unsigned long long *__restrict__ list, const unsigned long long *__restrict__ outRow, const float *__restrict__ outVal,
+                                                             float *__restrict__ U, float *__restrict__ V, float *__restrict__ W) {
+    unsigned long long n = list[0];
+    if (n > (unsigned long long)FV_POLISH_CAP) n = FV_POLISH_CAP;
+    float *const X[3] = {U, V, W};
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < 4 * n; t += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long r = outRow[t];
+        if (r != ~0ull) X[(int)(r >> 62)][(size_t)(r & ((1ull << 62) - 1))] = outVal[t];
     }
 }
 
@@ -1512,13 +1527,18 @@ static int visc_run_setup(flipv_context *c, const ViscPlan &P, int layout, bool 
                            brick ? 1 : 0, c->LB, c->vMaskB, c->vB[0], c->vB[1], c->vB[2], c->phi);   // (the right-hand side's copy in the layout of s: the fp64 residual of either layout reads it)
         if (elim) hipLaunchKernelGGL(k_visc_singular_apply<false>, dim3(1), dim3(256), 0, c->stream, (const unsigned long long *)c->elimList, c->stU, c->stV, c->stW, c->U, c->V, c->W);
         if (!c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {   // the massless clusters: listed now and taken out of the velocity criterion's sight, solved after the solve
-            if (!c->polishList) HIPCHK(c, hipMalloc((void **)&c->polishList, (size_t)(FV_POLISH_CAP + 1) * sizeof(unsigned long long)));
+            if (!c->polishList) {   // the list of edges, and the solve pass's rows and values (four per edge)
+                HIPCHK(c, hipMalloc((void **)&c->polishList, (size_t)(FV_POLISH_CAP + 1) * sizeof(unsigned long long)));
+                HIPCHK(c, hipMalloc((void **)&c->polishRow, (size_t)FV_POLISH_CAP * 4 * sizeof(unsigned long long)));
+                HIPCHK(c, hipMalloc((void **)&c->polishVal, (size_t)FV_POLISH_CAP * 4 * sizeof(float)));
+            }
             HIPCHK(c, hipMemsetAsync(c->polishList, 0, sizeof(unsigned long long), c->stream));
             hipLaunchKernelGGL(k_visc_massless_find, GRID3(RS), 0, c->stream, RS, (const float *)c->volEU, (const float *)c->volEV, (const float *)c->volEW, (const float *)c->volU,
                                (const float *)c->volV, (const float *)c->volW, (const uint8_t *)c->vRowMask, c->polishList);
             hipLaunchKernelGGL(k_visc_massless_polish<true>, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
                                (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
-                               factor, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, (int *)nullptr, brick ? c->vMaskB : (uint8_t *)nullptr, c->LB);
+                               factor, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, (int *)nullptr, brick ? c->vMaskB : (uint8_t *)nullptr, c->LB,
+                               (unsigned long long *)nullptr, (float *)nullptr);
         }
         const bool pairs = mgPlanned && (c->prm.viscosity_pair_correction > 0 || (c->prm.viscosity_pair_correction == 0 && fieldSolve));   // strongly coupled pairs of rows: listed for the multigrid loops' additive correction (k_visc_pairs_find)
         c->h_flags[10] = 0;
@@ -1532,9 +1552,11 @@ static int visc_run_setup(flipv_context *c, const ViscPlan &P, int layout, bool 
                                c->prm.viscosity_pair_lambda_floor > 0.0f ? c->prm.viscosity_pair_lambda_floor : 1.0e-5f);
         }
         {
-            ReadJob jobs[4] = {FV_JOB(c->h_scal, bmax, 2 * sizeof(double)), FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int))};   // max|rhs|, max|u| over the rows; the row count
+            ReadJob jobs[5] = {FV_JOB(c->h_scal, bmax, 2 * sizeof(double)), FV_JOB(c->h_flags + 2, c->d_flags + 2, sizeof(int))};   // max|rhs|, max|u| over the rows; the row count
             int nj = 2;
             c->h_flags[11] = 0;
+            c->nPolishEdges = 0;
+            if (!c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) jobs[nj++] = FV_JOB(&c->nPolishEdges, c->polishList, sizeof(int));   // (the low word of the list's counter)
             if (pairs) jobs[nj++] = FV_JOB(c->h_flags + 10, c->pairList, sizeof(int));
             if (elim) jobs[nj++] = FV_JOB(c->h_flags + 11, c->elimList, sizeof(int));   // (the low word of the list's counter)
             const int rcr = fv_read_small(c, jobs, nj);
@@ -1561,6 +1583,9 @@ static int visc_run_setup(flipv_context *c, const ViscPlan &P, int layout, bool 
                 fprintf(stderr, "   %zu rows in pairs, %zu of them in more than one pair; i00 between %.3g and %.3g\n", keys.size() - shared, shared, gmin, gmax);
             }
         }
+        if (c->prm.verbose && c->nPolishEdges > FV_POLISH_CAP)
+            fprintf(stderr, "viscosity solve %ld: %d edges with massless clusters around them -- MORE THAN THE LIST HOLDS (%d): the rest are neither solved apart nor taken out of the velocity criterion's sight\n",
+                    c->viscSolves, c->nPolishEdges, FV_POLISH_CAP);
         if (c->prm.verbose && c->h_flags[11] > 0)
             fprintf(stderr, "viscosity solve %ld: %d rows repeat another row's equation (a singular cluster): held at 0 like the reference's iterate%s\n", c->viscSolves, c->h_flags[11],
                     c->h_flags[11] > FV_ELIM_CAP ? " -- MORE THAN THE LIST HOLDS, the rest stay rows" : "");
@@ -1646,7 +1671,10 @@ static int visc_apply_solution(flipv_context *c, const Lay &R0, bool brick, bool
     if (nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0)   // (the clusters the iteration leaves where fp32 cannot see them: k_visc_massless_polish)
         hipLaunchKernelGGL(k_visc_massless_polish<false>, dim3(64), dim3(64), 0, c->stream, c->L, (const float *)c->visc, (const float *)c->volC, (const float *)c->volEU, (const float *)c->volEV,
                            (const float *)c->volEW, (const float *)c->volU, (const float *)c->volV, (const float *)c->volW, c->vRowMask, c->U, c->V, c->W,
-                           c->vFactorNow, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, c->prm.verbose ? c->d_flags + 13 : (int *)nullptr, (uint8_t *)nullptr, c->LB);   // (the list k_visc_massless_find made before the solve)
+                           c->vFactorNow, c->comm ? 1 : 0, (const unsigned long long *)c->polishList, c->prm.verbose ? c->d_flags + 13 : (int *)nullptr, (uint8_t *)nullptr, c->LB,   // (the list k_visc_massless_find made before the solve)
+                           c->polishRow, c->polishVal);
+    if (nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0)
+        hipLaunchKernelGGL(k_visc_massless_write, dim3(64), dim3(256), 0, c->stream, (const unsigned long long *)c->polishList, (const unsigned long long *)c->polishRow, (const float *)c->polishVal, c->U, c->V, c->W);
     if (c->prm.verbose && nontrivial && !c->prm.exact_viscosity_operator && c->prm.viscosity_massless_polish >= 0) {
         int np = 0;
         HIPCHK(c, hipMemcpy(&np, c->d_flags + 13, sizeof(int), hipMemcpyDeviceToHost));   // (d_flags[13]: the run builder's second word, rewritten by every fv_build_runs)
@@ -1689,6 +1717,7 @@ static int viscosity_solve_t(flipv_context *c, float dt, flipv_solve_info *info)
     li.rhs_norm = bnorm;
     li.rows = c->h_flags[2];
     li.eliminated_rows = c->nElim;
+    li.massless_cluster_edges = c->nPolishEdges;
     li.active_tiles = c->nActiveV;
     li.total_tiles = brick ? (int)(c->LB.n / 64) : c->tgV.count();
     li.layout = c->vLayout;

@@ -243,6 +243,8 @@ typedef struct flipv_solve_info {
     int eliminated_rows;       /* viscosity: rows of the reference's system that REPEAT another row's equation (massless faces around one edge or cell centre whose only non-zero factor is that
                                   edge's: the reference's matrix is singular there) and were held at 0 instead of solved for -- what the reference's MIC(0)-PCG leaves them at (k_viscosity.hip:
                                   k_visc_singular_find).  `rows` + this = the reference's row count (FLIPV_VERSION 6) */
+    int massless_cluster_edges; /* viscosity: control-volume edges with a massless cluster around them that were listed before the solve (viscosity_massless_polish); the list holds
+                                  65 536: beyond that the rest are neither solved apart nor taken out of the velocity criterion's sight (FLIPV_VERSION 6) */
 } flipv_solve_info;
 
 /* Per-substep report (replaces the reference's stdout banners, fluidsimulation.cpp:143-163). */
