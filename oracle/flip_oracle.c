@@ -1315,6 +1315,8 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
             memcpy(sv, z, (size_t)n * sizeof(double));
             int it;
             success = 0;
+            const char *te_ = getenv("ORACLE_TRACE_EVERY");   /* research: the residual history of a long converged solve (test infrastructure; the library reads no environment) */
+            const int trace_every = te_ ? atoi(te_) : 0;
             for (it = 0; it < maxiter; it++) {
                 OMP_FOR
                 for (int i = 0; i < n; i++) { /* multiply (sparsematrix.h:166-176) */
@@ -1332,6 +1334,7 @@ void oracle_viscosity_solve(int I, int J, int K, float dxf, float dtf, float *U,
                 OMP_FOR_MAX(mv)
                 for (int c = 0; c < n; c++) if (fabs(r[c]) > mv) mv = fabs(r[c]);
                 res = mv;
+                if (trace_every > 0 && (it + 1) % trace_every == 0) { fprintf(stderr, "  oracle viscosity PCG: iteration %d, max|r| %.3e (target %.3e)\n", it + 1, res, tolabs); fflush(stderr); }
                 if (res <= tolabs) { iters = it + 1; success = 1; break; }
                 APPLY_PRECON(r, z);
                 double rho_new = vdot(z, r, n);

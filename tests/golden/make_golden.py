@@ -250,6 +250,28 @@ def carry_states(prefix, N, boundary, liquid, nu, snapshots, dt=0.01):
     s.close()
 
 
+def carry_on(prefix, N, boundary, liquid, nu, k_from, snapshots, dt=0.01):
+    """carry_states() continued: the compiled reference takes the particles it held after `k_from` of its substeps (tests/golden/_big/<prefix>_sub<k_from>_state.npy; the
+    particles are all a FluidSimulation carries from one substep to the next) and runs on to max(snapshots) at its defaults."""
+    import time
+    s, dx = _ref_scene(N, boundary, liquid, nu)
+    s.particles = np.load(os.path.join(BIG, "%s_sub%d_state.npy" % (prefix, k_from)))
+    log = [tuple(r) for r in np.load(os.path.join(BIG, "%s_sub%d_carrylog.npy" % (prefix, k_from)))]
+    for t in range(k_from, max(snapshots)):
+        t0 = time.time()
+        s.substep(dt)
+        st = s.solver_stats()
+        log.append((st["visc_iters"], st["visc_err"], st["pres_iters"]))
+        print("  %s substep %d: viscosity %d its (%.2e), pressure %d its, %.0f s" % (prefix, t, st["visc_iters"], st["visc_err"], st["pres_iters"], time.time() - t0), flush=True)
+        if t + 1 in snapshots:
+            path = os.path.join(BIG, "%s_sub%d_state.npy" % (prefix, t + 1))
+            np.save(path + ".tmp.npy", s.particles)
+            np.save(os.path.join(BIG, "%s_sub%d_carrylog.npy" % (prefix, t + 1)), np.array(log, np.float64))
+            os.replace(path + ".tmp.npy", path)
+            print("  wrote", path, flush=True)
+    s.close()
+
+
 def late_state_big(name, N, boundary, liquid, nu, nsub_before, nprobe=300000, ntop=5000, surface_stride=4, vtol=1e-13, vcap=3000000, dt=0.01, state_name=None):
     """late_state() at the headline size.  The state (the reference's particles after `nsub_before` of its own substeps at its defaults, from carry_states) stays in
     tests/golden/_big/<name>_state.npy; the committed fixture holds its sha256 / checksums / per-octant sums, how the reference got there (iteration counts per carried
@@ -383,6 +405,9 @@ if __name__ == "__main__":
         carry_states("bunny256_nu5", 256, *BUNNY, 5.0, (10, 25, 35))
     if "carry256_nu200" in only:
         carry_states("bunny256_nu200", 256, *BUNNY, 200.0, (25,))
+    if "carry256_nu5_sub20" in only:   # (from the state at 10: substeps 10 ... 19 of the same run)
+        carry_on("bunny256_nu5", 256, *BUNNY, 5.0, 10, (20,))
+        late_state_big("bunny256_nu5_sub20_tol10", 256, *BUNNY, 5.0, 20, vtol=1e-10, state_name="bunny256_nu5_sub20")
     for nm, nu_, k_ in (("bunny256_nu5_sub10", 5.0, 10), ("bunny256_nu5_sub25", 5.0, 25), ("bunny256_nu5_sub35", 5.0, 35), ("bunny256_nu200_sub25", 200.0, 25)):
         if nm in only:
             late_state_big(nm, 256, *BUNNY, nu_, k_)

@@ -2,8 +2,8 @@
 against the COMPILED REFERENCE (round 5 compared these states with the GPU's own tightened solve).
 
 tests/golden/bunny256_nu5_sub10 / _sub25 (and bunny256_nu200_sub25: the last test) (tests/golden/make_golden.py K): the reference carried the scene at ITS defaults (dt = 0.01, viscosity
-cap 700 -- at 256^3 every carried solve ends at the cap) through 10 substeps (mid-fall, inside the window bench.py times: substeps 5 ... 24) and 25 (the liquid on the container
-wall), and at nu = 200 (nu dt/dx^2 = 131 072) through 25; the particles it then holds are the state.  From the state ONE substep of the reference with its viscosity cap lifted and the
+cap 700 -- at 256^3 every carried solve ends at the cap) through 10 substeps (mid-fall, inside the window bench.py times: substeps 5 ... 24), 20 (just landed, inside the window
+too) and 25 (the liquid on the container wall), and at nu = 200 (nu dt/dx^2 = 131 072) through 25; the particles it then holds are the state.  From the state ONE substep of the reference with its viscosity cap lifted and the
 tolerance at 1e-13: ~305 000 probe faces per component (300 000 seeded among the faces that carry a velocity, the 5 000 of largest |u|, every 4th face within one cell of the free
 surface) and per-octant particle checksums.
 
@@ -24,7 +24,7 @@ from test_oracle_compact_golden import build_host_scene
 pytestmark = pytest.mark.gpu
 BIG = os.path.join(GOLDEN, "_big")
 VEL_TOL = 1e-4
-NAMES = ["bunny256_nu5_sub10", "bunny256_nu5_sub25"]   # (a state at 35 substeps was carried too; three 113 MB states are what a gpurun snapshot of 512 MiB holds)
+NAMES = ["bunny256_nu5_sub10", "bunny256_nu5_sub20", "bunny256_nu5_sub25"]   # (a state at 35 substeps was carried too; three 113 MB states are what a gpurun snapshot of 512 MiB holds)
 
 
 def headline_state(g, name, P0, solid):
@@ -123,7 +123,7 @@ def test_headline_late_state_default_parameters_against_the_reference(name):
     assert d[:, :3].max() <= 1e-6 and d[:, 3:].max() <= 1e-5, d      # (a particle that changes octant between the two runs would show as ~1/n per particle: none does)
 
 
-@pytest.mark.parametrize("name", ["bunny256_nu5_sub10", "bunny256_nu5_sub25"])
+@pytest.mark.parametrize("name", ["bunny256_nu5_sub10", "bunny256_nu5_sub20", "bunny256_nu5_sub25"])
 def test_headline_late_state_default_blocks_against_the_reference(name):
     from test_gpu_multirank import assemble, run_ranks
     from test_gpu_multirank_default import assert_same_solve_on_every_rank, make_blocks

@@ -183,15 +183,16 @@ def test_oracle_late_state_golden_128(oracle):
     s.close()
 
 
-def test_oracle_headline_late_state_256(oracle):
+@pytest.mark.parametrize("state", ["bunny256_nu5_sub20", "bunny256_nu5_sub25"])
+def test_oracle_headline_late_state_256(oracle, state):
     """bunny256_nu5_sub25(_tol10) (make_golden.py K, round 6): the compiled reference carried BASELINE configs[2] itself -- the 256^3 bunny drop, nu = 5 -- through 25 of its own
     substeps (every carried viscosity solve ends at or near its cap of 700), and its particles are the fixture's state (tests/golden/_big/, 113 MB, not in git: sha256 in the fixture).
     The reference's converged answer from there (1e-10: 12 212 iterations) is hours of one core and is not re-run here; what IS re-run is the substep at the reference's DEFAULTS from that
     state: the oracle must take the same number of viscosity iterations (558) and end at the same residual (to the six digits the reference prints) -- the pin of oracle against reference ON this state (the GPU is held
     against the converged answer in tests/test_gpu_headline_late.py).  ~3 minutes of one core; skipped where the state file has not been generated."""
     import hashlib
-    name = "bunny256_nu5_sub25" if os.path.exists(os.path.join(GOLDEN, "bunny256_nu5_sub25.npz")) else "bunny256_nu5_sub25_tol10"
-    spath = os.path.join(GOLDEN, "_big", "bunny256_nu5_sub25_state.npy")
+    name = state if os.path.exists(os.path.join(GOLDEN, state + ".npz")) else state + "_tol10"      # (sub20: 20 substeps in, inside bench.py's timed window: 584 iterations at the defaults, 11 073 to 1e-10)
+    spath = os.path.join(GOLDEN, "_big", state + "_state.npy")
     if not (os.path.exists(os.path.join(GOLDEN, name + ".npz")) and os.path.exists(spath)):
         pytest.skip("fixture or its state not present (make_golden.py carry256_nu5)")
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
