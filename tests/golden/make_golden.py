@@ -272,6 +272,84 @@ def carry_on(prefix, N, boundary, liquid, nu, k_from, snapshots, dt=0.01):
     s.close()
 
 
+def system_golden(name, state_name, N, boundary, liquid, nu, vtol=1e-8, dt=0.01, nprobe=300000, ntop=5000, nmassless=100000):
+    """Round 6, the mid-fall state of the headline scene, where the reference's OWN solver does not converge (profiles/r6/sub10_reference_residual_history.log): the viscosity
+    system the reference assembles from that state -- by the bit-pinned oracle: float-rounded diagonal, rhs and all (oracle_viscosity_dump_to) -- solved by an INDEPENDENT
+    method, fp64 diagonal-PCG in scipy, to max|b - A x| <= vtol max|b| (true residual recomputed).  Probes: `nprobe` seeded rows per component, the `ntop` of largest |x|,
+    up to `nmassless` rows without own volume.  What it pins is the viscosity SOLVE (post-viscosity face velocities), not the end of the substep."""
+    import hashlib
+    import sys
+    import time
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    from oracle import oraclebind as O
+    state = np.load(os.path.join(BIG, state_name + "_state.npy"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_compact_golden import build_host_scene
+    dx, solid, P0 = build_host_scene(N, boundary, liquid)
+    scratch = os.path.join(ROOT, "scratch", "jump")
+    os.makedirs(scratch, exist_ok=True)
+    dump = os.path.join(scratch, name + ".vdump")
+    if not os.path.exists(dump):
+        o = O.OracleSim(N, N, N, dx); o.set_solid(solid); o.set_viscosity(nu)
+        o.set_solver_limits(vmaxiter=1, vtol=1e-6, pmaxiter=0)      # (the system is written at assembly; the oracle's own solve is not wanted)
+        o.particles = state
+        O.lib().oracle_viscosity_dump_to(dump.encode()); o.substep(dt); O.lib().oracle_viscosity_dump_to(None)
+        o.close()
+    with open(dump, "rb") as f:
+        n, cap, dim, ext = np.fromfile(f, np.int64, 4)
+        cnt = np.fromfile(f, np.int32, n)
+        col = np.fromfile(f, np.uint32, n * cap).reshape(n, cap)
+        val = np.fromfile(f, np.float64, n * cap).reshape(n, cap)
+        b = np.fromfile(f, np.float64, n)
+        table = np.fromfile(f, np.int32, dim)
+        dgx = np.fromfile(f, np.float64, n); vol = np.fromfile(f, np.float64, n)
+    m = np.arange(cap)[None, :] < cnt[:, None]
+    A = sp.csr_matrix((val[m], (np.repeat(np.arange(n), cnt), col[m].astype(np.int64))), shape=(n, n))
+    del col, val, m
+    sol = os.path.join(scratch, name + "_solution.npz")
+    if os.path.exists(sol):
+        x = np.load(sol)["x"]; its = int(np.load(sol)["iterations"])
+    else:
+        d = A.diagonal(); live = d > 0
+        di = np.where(live, 1.0 / np.where(live, d, 1.0), 0.0)
+        x = np.zeros(n); r = b.copy(); z = di * r; p = z.copy(); rz = r @ z; bmax = np.abs(b).max(); t0 = time.time()
+        for its in range(1, 400001):
+            q = A @ p; al = rz / (p @ q); x += al * p; r -= al * q
+            if its % 50 == 0 and np.abs(r).max() <= vtol * bmax:
+                break
+            if its % 1000 == 0:
+                print("  %s: iteration %d, max|r| / max|b| %.3e, %.0f s" % (name, its, np.abs(r).max() / bmax, time.time() - t0), flush=True)
+            z = di * r; rz2 = r @ z; p = z + (rz2 / rz) * p; rz = rz2
+        np.savez(sol, x=x, iterations=its)
+    true_res = float(np.abs(b - A @ x).max() / np.abs(b).max())
+    moved = 0   # (the rows that repeat one equation -- the reference's matrix is singular there -- are left as CG from zero leaves them: an even split; the test does not judge rows without own volume)
+    print("  %s: %d rows, %d iterations, true residual %.3e max|b|, max|x| %.5f" % (name, n, its, true_res, np.abs(x).max()), flush=True)
+    I = J = K = N
+    sizes = ((I + 1) * J * K, I * (J + 1) * K, I * J * (K + 1))
+    offs = (0, sizes[0], sizes[0] + sizes[1])
+    d = dict(I=N, J=N, K=N, dx=np.float32(dx), dt=np.float32(dt), nu=np.float32(nu), vtol=np.float64(vtol), iterations=its, true_residual=true_res, rows=int(n),
+             maxabs=np.float64(np.abs(x).max()), repeated_rows=moved, nparticles=len(state), state_sha256=hashlib.sha256(np.ascontiguousarray(state).tobytes()).hexdigest(),
+             state_sum=state.astype(np.float64).sum(axis=0), rhs_max=np.float64(np.abs(b).max()))
+    rng = np.random.default_rng(2026)
+    for c, (o_, sz) in enumerate(zip(offs, sizes)):
+        t = table[o_:o_ + sz]
+        faces = np.flatnonzero(t >= 0)
+        rows = t[faces]
+        pick = rng.choice(len(faces), size=min(nprobe, len(faces)), replace=False)
+        top = np.argsort(np.abs(x[rows]))[::-1][:ntop]
+        ml = np.flatnonzero(vol[rows] == 0.0)
+        if len(ml) > nmassless:
+            ml = rng.choice(ml, size=nmassless, replace=False)
+        sel = np.unique(np.concatenate([pick, top, ml]))
+        d["idx_" + "UVW"[c]] = faces[sel].astype(np.uint32)
+        d["val_" + "UVW"[c]] = x[rows[sel]]
+        d["massless_" + "UVW"[c]] = vol[rows[sel]] == 0.0
+    out = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(out, **d)
+    print("%-28s %8d rows  %7d KiB; %d iterations of fp64 diagonal-PCG, true residual %.2e" % (name, n, os.path.getsize(out) // 1024, its, true_res))
+
+
 def late_state_big(name, N, boundary, liquid, nu, nsub_before, nprobe=300000, ntop=5000, surface_stride=4, vtol=1e-13, vcap=3000000, dt=0.01, state_name=None):
     """late_state() at the headline size.  The state (the reference's particles after `nsub_before` of its own substeps at its defaults, from carry_states) stays in
     tests/golden/_big/<name>_state.npy; the committed fixture holds its sha256 / checksums / per-octant sums, how the reference got there (iteration counts per carried
@@ -405,6 +483,8 @@ if __name__ == "__main__":
         carry_states("bunny256_nu5", 256, *BUNNY, 5.0, (10, 25, 35))
     if "carry256_nu200" in only:
         carry_states("bunny256_nu200", 256, *BUNNY, 200.0, (25,))
+    if "bunny256_nu5_sub10_system" in only:
+        system_golden("bunny256_nu5_sub10_system", "bunny256_nu5_sub10", 256, *BUNNY, 5.0)
     if "carry256_nu5_sub20" in only:   # (from the state at 10: substeps 10 ... 19 of the same run)
         carry_on("bunny256_nu5", 256, *BUNNY, 5.0, 10, (20,))
         late_state_big("bunny256_nu5_sub20_tol10", 256, *BUNNY, 5.0, 20, vtol=1e-10, state_name="bunny256_nu5_sub20")
